@@ -1,0 +1,169 @@
+/*
+ * tilemotion.h -- C ABI of libtilemotion.so: the MI355X (gfx950) implementation of the TileMotion
+ * encoder's per-frame tile pipeline (gligli/tiler: tilingencoder.pas / utils.pas / extern.pas).
+ *
+ * Plain pointers and sizes only; every function returns 0 on success or a negative TM_E_* code, never
+ * throws or aborts across the boundary.  tm_last_error() gives the message of the calling thread's last
+ * failure.  There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * TM_E_NODEVICE.
+ *
+ * Three layers, each replacing a reference seam (file:line in the reference tree):
+ *   1. Coarse seam  tm_encoder_*  == TTilingEncoder's public surface (tilingencoder.pas:486-568):
+ *      Create/Destroy, settings properties (3745-3770, clamps 2919-3047), frame callback contract of
+ *      TFFMPEGFrameCallback (extern.pas:149), Run(step) with TEncoderStep values (tilingencoder.pas:18),
+ *      read-only Tiles/Frames/Palettes views (509-512).
+ *   2. Stage seam   tm_stage_*    == the per-step workers behind Run, on DEVICE pointers, so a host that
+ *      owns several processes/GPUs (bench.py, tiler_amd.distributed) can put RCCL collectives between them.
+ *   3. Fine seam    ann_kdtree_* / yakmo_* / bico_*  == the DLL imports of extern.pas:178-223, same
+ *      per-call semantics, plus *_batch twins (per-call GPU use is latency bound; kept for compatibility).
+ */
+#ifndef TILEMOTION_H
+#define TILEMOTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_API __attribute__((visibility("default")))
+
+enum {
+  TM_OK = 0,
+  TM_E_INVAL = -1,     /* bad argument / bad state (the reference would Assert) */
+  TM_E_NODEVICE = -2,  /* no HIP device, or kernels for gfx950 cannot run here */
+  TM_E_HIP = -3,       /* a HIP runtime call failed */
+  TM_E_NOMEM = -4,
+  TM_E_IO = -5,
+  TM_E_UNSUPPORTED = -6 /* reference feature outside the hot path */
+};
+
+/* TEncoderStep, tilingencoder.pas:18 */
+enum { TM_STEP_ALL = -1, TM_STEP_LOAD = 0, TM_STEP_PREDICT_MOTION = 1, TM_STEP_REDUCE = 2, TM_STEP_PREPARE_PALETTES = 3,
+       TM_STEP_DITHER = 4, TM_STEP_RECONSTRUCT = 5, TM_STEP_REINDEX = 6, TM_STEP_SAVE = 7 };
+
+/* TPsyVisMode, tilingencoder.pas:21 */
+enum { TM_PVS_DCT = 0, TM_PVS_WEIGHTED_DCT = 1, TM_PVS_WAVELETS = 2, TM_PVS_SPE_DCT = 3, TM_PVS_WEIGHTED_SPE_DCT = 4 };
+
+#define TM_NULL_COLOR ((int32_t)0xffff00ff) /* cDitheringNullColor, utils.pas:45 */
+
+/* TTile header, packed, 20 bytes (tilingencoder.pas:116-121).  Flags bits: 0 Active, 1 HasRGBPixels,
+ * 2 HasPalPixels, 3 HMirror_Initial, 4 VMirror_Initial (FPC set, 4 bytes). */
+#pragma pack(push, 1)
+typedef struct { uint32_t UseCount; int32_t TmpIndex; int32_t MergeIndex; int32_t PalIdx_Initial; uint32_t Flags; } tm_tile_hdr;
+/* TTileMapItem, packed, 18 bytes (tilingencoder.pas:178-184).  Flags bits: 0 HMirror, 1 VMirror, 2 Predicted. */
+typedef struct { int32_t TileIdx; int32_t PalIdx; int8_t PredictedX; int8_t PredictedY; float PSNR; uint32_t Flags; } tm_tilemap_item;
+#pragma pack(pop)
+
+TM_API const char *tm_last_error(void);
+TM_API int tm_device_count(void);           /* usable gfx950 devices, 0 if none */
+TM_API const char *tm_version(void);
+
+/* ======================================================================================= coarse seam */
+typedef struct tm_encoder tm_encoder;
+typedef void (*tm_progress_cb)(void *user, int step, int position, int max, int hourglass); /* OnProgress, :304 */
+
+TM_API tm_encoder *tm_create(void);                 /* TTilingEncoder.Create, :5484; NULL on failure */
+TM_API void tm_destroy(tm_encoder *);               /* Destroy, :5516 */
+TM_API int tm_set_device(tm_encoder *, int device); /* which HIP device this encoder (process) drives */
+/* Settings: keys are the INI names of SaveSettings (:3745-3770); setters clamp like :2919-3047. */
+TM_API int tm_load_default_settings(tm_encoder *);  /* LoadDefaultSettings, :3817-3845 */
+TM_API int tm_load_settings_ini(tm_encoder *, const char *path); /* LoadSettings, :3777 */
+TM_API int tm_set_int(tm_encoder *, const char *key, int64_t v);
+TM_API int tm_set_float(tm_encoder *, const char *key, double v);
+TM_API int tm_set_bool(tm_encoder *, const char *key, int v);
+TM_API int tm_set_str(tm_encoder *, const char *key, const char *v);
+TM_API int tm_get_int(tm_encoder *, const char *key, int64_t *v);
+TM_API int tm_get_float(tm_encoder *, const char *key, double *v);
+TM_API int tm_set_progress_cb(tm_encoder *, tm_progress_cb cb, void *user);
+/* Video: what FFMPEG_Open + ReframeUI + InitFrames establish (:1772-1776, :2631, :2661). */
+TM_API int tm_set_video(tm_encoder *, int width, int height, double fps, int frame_count);
+/* One decoded frame, AV_PIX_FMT_RGB32 (uint32 0xAARRGGBB), as TFFMPEGFrameCallback hands it (extern.pas:149);
+ * read during the call only.  stride_px = pixels per row. */
+TM_API int tm_push_frame_rgb32(tm_encoder *, int index, const uint32_t *pixels, int stride_px);
+/* Same, but the frames already sit in device memory as [frame_count][height][width] uint32 (bench path). */
+TM_API int tm_set_frames_device(tm_encoder *, const void *dev_frames);
+TM_API int tm_run(tm_encoder *, int step);          /* Run(AStep), :5529-5554; blocking */
+/* read-back views (copy-out) */
+TM_API int tm_get_counts(tm_encoder *, int64_t *tiles, int *frames, int *palettes, int *tm_w, int *tm_h, int *keyframes);
+TM_API int tm_get_tile(tm_encoder *, int64_t i, tm_tile_hdr *hdr, uint8_t pal_px[64], uint32_t rgb_px[64]);
+TM_API int tm_get_tiles(tm_encoder *, int64_t first, int64_t count, tm_tile_hdr *hdrs, uint8_t *pal_px, uint32_t *rgb_px);
+TM_API int tm_get_tilemap(tm_encoder *, int frame, tm_tilemap_item *items /* tm_w*tm_h */);
+TM_API int tm_get_palette(tm_encoder *, int i, int32_t *rgb /* PaletteSize */);
+TM_API int tm_get_keyframes(tm_encoder *, int32_t *start_frames /* keyframes */);
+TM_API int tm_get_frame_correlations(tm_encoder *, float *correl /* frames */);
+TM_API int tm_get_stage_ms(tm_encoder *, double ms[8]); /* wall ms of the last run of each step (ProgressRedraw, :3925) */
+TM_API int tm_save_gtm(tm_encoder *, const char *path);  /* Save, :2040 */
+
+/* ======================================================================================= stage seam
+ * All pointers are DEVICE pointers unless named host_*.  `stream` is a hipStream_t (NULL = default stream).
+ * Tiles are [n][64] uint32 0x00BBGGRR in the reference's canonical (mirrored) orientation. */
+
+/* A1+A2+A3: TFrame.LoadFromImage (:1293) + PrepareInterFrameData (:1329) + mirror canonicalisation (:1393-1411).
+ * frames: [nframes][img_h][img_w] RGB32.  Outputs: tiles [nframes*tm_w*tm_h][64], flags u8 (bit0 H, bit1 V),
+ * lab_means f32 [ntiles][3]. */
+TM_API int tm_stage_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h,
+                         void *tiles, void *flags, void *lab_means, void *stream);
+
+/* A4+A5: ConvertToCpnPixels (:3049) + ComputeCpnPixelsPsyVisFeatures (:3103) -> int16 [n][192].
+ * mirror_flags may be NULL (no un-mirroring). */
+TM_API int tm_stage_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab,
+                                 void *out_i16, void *stream);
+/* FromPal=True variant (PrepareReconstruct.DoPsyV, :4570-4583): pal_px u8 [n][64], pal_idx i32 [n],
+ * palettes i32 [npal][pal_size]. */
+TM_API int tm_stage_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size,
+                                 int mode, void *out_i16, void *stream);
+/* A6 as used by DoPalettization (:4126,:4160): double DCT with UseLAB, Round()ed to int32 [n][192]. */
+TM_API int tm_stage_features_cluster(const void *tiles, int64_t n, int mode, void *out_i32, void *stream);
+
+/* A13+A14 (KNN branch): exact nearest neighbour of every query in the database, both int16 [.][192];
+ * what ann_kdtree_short_search(eps=0) answers (:1547).  Ties: lowest database index.
+ * out_idx i32 [nq], out_err u32 [nq].  Blocking (needs one 1.5 KB read-back for the digit plan). */
+TM_API int tm_stage_knn(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt,
+                        void *out_idx, void *out_err, void *stream);
+/* Same with a prepared database (ann_kdtree_create analogue): pack once, search many query batches. */
+typedef struct tm_knn_index tm_knn_index;
+TM_API tm_knn_index *tm_knn_index_create(const void *db_i16, int64_t nt, void *stream);
+TM_API void tm_knn_index_destroy(tm_knn_index *);
+TM_API int tm_knn_index_search(tm_knn_index *, const void *queries_i16, int64_t nq, void *out_idx, void *out_err, void *stream);
+/* measured device time (ms, HIP events on `stream`) of the distance kernel in the last search, and its MFMA K */
+TM_API int tm_knn_index_last_stats(tm_knn_index *, double *kernel_ms, int *k_bytes, int64_t *pairs);
+
+/* A12: Dither (:1873) = PreparePlan (:2268) + DitherTile (:2688) for every tile.  tiles/flags as above,
+ * pal_idx i32 [n], palettes i32 [npal][pal_size] -> pal_px u8 [n][64] (canonical orientation). */
+TM_API int tm_stage_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes,
+                           int npal, int pal_size, int use_thomas_knoll, int y2_mixed_colors, void *out_pal_px, void *stream);
+
+/* A8/A16: MakeTilesUnique (:4720) + ReindexTiles (:4626) on n rows of `row_bytes` (256: RGB dwords compared as
+ * unsigned dwords; 64: palette indices compared as bytes).  use_in u32[n] or NULL (=1).
+ * Outputs: remap i32 [n] (final index of each row's representative, -1 if its use count is 0),
+ * order i32 [n] (first *n_unique entries: original index of the representative at each final position),
+ * use_out u32 [n].  Blocking. */
+TM_API int tm_stage_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in,
+                          void *remap, void *order, void *use_out, int64_t *host_n_unique, void *stream);
+
+/* A9/A10: the build's deterministic k-means (farthest-first init, exact integer sums); pts i32 [n][d],
+ * weights u32 [n] or NULL.  assign i32 [n], centroids f64 [k][d] (device).  Returns live centroid count in *host_k. */
+TM_API int tm_stage_kmeans(const void *pts_i32, const void *weights, int64_t n, int d, int k, int max_iter,
+                           void *assign, void *centroids, int *host_k, int *host_iters, void *stream);
+/* QuantizeUsingYakmo + DoQuantization (:4434-4564) for every palette at once: pixels of tiles grouped by pal_idx. */
+TM_API int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter,
+                                      void *out_palettes, void *stream);
+/* DoPalettization (:4105-4245): cluster features -> PalIdx_Initial ranked by tile count. */
+TM_API int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx,
+                              void *stream);
+
+/* ======================================================================================= fine seam
+ * extern.pas:182-185 (ANN_short.dll), :198-203 (yakmo.dll), :218-223 (BICO.dll).  Host pointers. */
+typedef struct tm_ann tm_ann;
+TM_API tm_ann *ann_kdtree_short_create(int16_t **rows, int n, int dd, int bs, int split);
+TM_API void ann_kdtree_short_destroy(tm_ann *);
+TM_API int ann_kdtree_short_search(tm_ann *, const int16_t *q, uint32_t eps, uint32_t *err);
+TM_API void ann_kdtree_short_search_multi(tm_ann *, int32_t *idxs, uint32_t *errs, int cnt, const int16_t *q, uint32_t eps);
+TM_API int ann_kdtree_short_search_batch(tm_ann *, const int16_t *queries, int nq, int32_t *idxs, uint32_t *errs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,931 @@
+/*
+ * tm_oracle.c -- CPU restatement of the TileMotion per-frame tile pipeline.  TEST INFRASTRUCTURE ONLY
+ * (see tm_oracle.h).  Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ * Citations are file:line in the gligli/tiler reference tree.
+ */
+#define _GNU_SOURCE
+#include "tm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ tables (utils.pas:47-109) */
+
+const uint8_t tmo_dithering_map[64] = { /* cDitheringMap, utils.pas:47-56 */
+    0, 48, 12, 60, 3, 51, 15, 63, 32, 16, 44, 28, 35, 19, 47, 31, 8,  56, 4,  52, 11, 59, 7,  55, 40, 24, 36, 20, 43, 27, 39, 23,
+    2, 50, 14, 62, 1, 49, 13, 61, 34, 18, 46, 30, 33, 17, 45, 29, 10, 58, 6,  54, 9,  57, 5,  53, 42, 26, 38, 22, 41, 25, 37, 21};
+
+const uint8_t tmo_dct_snake[64] = { /* cDCTSnake, utils.pas:59-68 */
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+const double tmo_dct_weights[3][8][8] = { /* cDCTWeights, utils.pas:72-97 */
+    {{1.6193873005, 2.2901594831, 2.08509755623, 1.48366094411, 1.00227514334, 0.678296995242, 0.466224900598, 0.3265091542},
+     {2.2901594831, 1.94321815382, 2.04793073064, 1.68731108984, 1.2305666963, 0.868920337363, 0.61280991668, 0.436405793551},
+     {2.08509755623, 2.04793073064, 1.34329019223, 1.09205635862, 0.875748795257, 0.670882927016, 0.501731932449, 0.372504254596},
+     {1.48366094411, 1.68731108984, 1.09205635862, 0.772819797575, 0.605636379554, 0.48309405692, 0.380429446972, 0.295774038565},
+     {1.00227514334, 1.2305666963, 0.875748795257, 0.605636379554, 0.448996256676, 0.352889268808, 0.283006984131, 0.226951348204},
+     {0.678296995242, 0.868920337363, 0.670882927016, 0.48309405692, 0.352889268808, 0.27032073436, 0.215017739696, 0.17408067321},
+     {0.466224900598, 0.61280991668, 0.501731932449, 0.380429446972, 0.283006984131, 0.215017739696, 0.168869545842, 0.136153931001},
+     {0.3265091542, 0.436405793551, 0.372504254596, 0.295774038565, 0.226951348204, 0.17408067321, 0.136153931001, 0.109083846276}},
+    {{1.91113096927, 2.46074210438, 1.18284184739, 1.14982565193, 1.05017074788, 0.898018824055, 0.74725392039, 0.615105596242},
+     {2.46074210438, 1.58529308355, 1.21363250036, 1.38190029285, 1.33100189972, 1.17428548929, 0.996404342439, 0.830890433625},
+     {1.18284184739, 1.21363250036, 0.978712413627, 1.02624506078, 1.03145147362, 0.960060382087, 0.849823426169, 0.731221236837},
+     {1.14982565193, 1.38190029285, 1.02624506078, 0.861317501629, 0.801821139099, 0.751437590932, 0.685398513368, 0.608694761374},
+     {1.05017074788, 1.33100189972, 1.03145147362, 0.801821139099, 0.676555426187, 0.605503172737, 0.55002013668, 0.495804539034},
+     {0.898018824055, 1.17428548929, 0.960060382087, 0.751437590932, 0.605503172737, 0.514674450957, 0.454353482512, 0.407050308965},
+     {0.74725392039, 0.996404342439, 0.849823426169, 0.685398513368, 0.55002013668, 0.454353482512, 0.389234902883, 0.342353999733},
+     {0.615105596242, 0.830890433625, 0.731221236837, 0.608694761374, 0.495804539034, 0.407050308965, 0.342353999733, 0.295530605237}},
+    {{2.03871978502, 2.62502345193, 1.26180942886, 1.11019789803, 1.01397751469, 0.867069376285, 0.721500455585, 0.593906509971},
+     {2.62502345193, 1.69112867013, 1.17180569821, 1.3342742857, 1.28513006198, 1.13381474809, 0.962064122248, 0.802254508198},
+     {1.26180942886, 1.17180569821, 0.944981930573, 0.990876405848, 0.995903384143, 0.926972725286, 0.820534991409, 0.706020324706},
+     {1.11019789803, 1.3342742857, 0.990876405848, 0.831632933426, 0.77418706195, 0.725539939514, 0.661776842059, 0.587716619023},
+     {1.01397751469, 1.28513006198, 0.995903384143, 0.77418706195, 0.653238524286, 0.584635025748, 0.531064164893, 0.478717061273},
+     {0.867069376285, 1.13381474809, 0.926972725286, 0.725539939514, 0.584635025748, 0.496936637883, 0.438694579826, 0.393021669543},
+     {0.721500455585, 0.962064122248, 0.820534991409, 0.661776842059, 0.531064164893, 0.438694579826, 0.375820256136, 0.330555063063},
+     {0.593906509971, 0.802254508198, 0.706020324706, 0.587716619023, 0.478717061273, 0.393021669543, 0.330555063063, 0.285345396658}}};
+
+static float g_lut_f32[2][4096];
+static double g_lut_f64[2][4096];
+static double g_inv_lut_f64[4096];
+static float g_srgb_lut[256];
+static int g_luts_ready = 0;
+
+static float uv_ratio(int v, int u) { /* cDCTUVRatio, utils.pas:100-109 (TFloat = Single) */
+  if (v == 0 && u == 0) return 0.5f;
+  if (v == 0 || u == 0) return (float)sqrt(0.5);
+  return 1.0f;
+}
+
+static void init_luts(void) { /* InitLuts, tilingencoder.pas:1703-1726 */
+  if (g_luts_ready) return;
+  int i = 0;
+  for (int v = 0; v < 8; v++)
+    for (int u = 0; u < 8; u++)
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+          double r = (double)uv_ratio(v, u);
+          double a = cos((x + 0.5) * u * M_PI / 8) * cos((y + 0.5) * v * M_PI / 8) * r;
+          double b = cos((x + 0.5) * u * M_PI / 16) * cos((y + 0.5) * v * M_PI / 16) * r;
+          g_lut_f64[0][i] = a;
+          g_lut_f64[1][i] = b;
+          g_lut_f32[0][i] = (float)a;
+          g_lut_f32[1][i] = (float)b;
+          i++;
+        }
+  i = 0;
+  for (int v = 0; v < 8; v++)
+    for (int u = 0; u < 8; u++)
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+          g_inv_lut_f64[i] =
+              cos((u + 0.5) * x * M_PI / 8) * cos((v + 0.5) * y * M_PI / 8) * (double)uv_ratio(y, x) * 2 / 8 * 2 / 8;
+          i++;
+        }
+  for (int c = 0; c < 256; c++) { /* utils.pas:378-384 */
+    float r = (float)(c / 255.0);
+    if ((double)r > 0.04045)
+      r = (float)pow(((double)r + 0.055) / 1.055, 2.4);
+    else
+      r = (float)((double)r / 12.92);
+    g_srgb_lut[c] = r;
+  }
+  g_luts_ready = 1;
+}
+
+const float *tmo_dct_lut_f32(int special) { init_luts(); return g_lut_f32[special ? 1 : 0]; }
+const double *tmo_dct_lut_f64(int special) { init_luts(); return g_lut_f64[special ? 1 : 0]; }
+const double *tmo_inv_dct_lut_f64(void) { init_luts(); return g_inv_lut_f64; }
+const float *tmo_srgb_lut_f32(void) { init_luts(); return g_srgb_lut; }
+
+/* Pascal Round(): half-to-even to Int64 (default FP rounding mode) */
+static inline int64_t pas_round(double x) { return (int64_t)llrint(x); }
+static inline int clampi(int64_t v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
+
+/* ------------------------------------------------------------------ colour */
+
+uint32_t tmo_swap_rb(uint32_t c) { /* utils.pas:238-241 */
+  return ((c & 0xff) << 16) | ((c >> 16) & 0xff) | (c & 0xff00);
+}
+
+void tmo_rgb_to_yuv(int r, int g, int b, float *y, float *u, float *v) { /* utils.pas:478-490 */
+  float yy = (float)(r * (299.0 / 1000.0) + g * (587.0 / 1000.0) + b * (114.0 / 1000.0));
+  float uu = (float)(((double)b - (double)yy) * 0.492);
+  float vv = (float)(((double)r - (double)yy) * 0.877);
+  *y = yy; *u = uu; *v = vv;
+}
+
+int32_t tmo_yuv_to_rgb(float y, float u, float v) { /* utils.pas:492-509 */
+  float r = (float)((double)y + (double)v * 1.13983);
+  float g = (float)((double)y - (double)u * 0.39465 - (double)v * 0.58060);
+  float b = (float)((double)y + (double)u * 2.03211);
+  int rr = clampi(pas_round(r), 0, 255), gg = clampi(pas_round(g), 0, 255), bb = clampi(pas_round(b), 0, 255);
+  return (bb << 16) | (gg << 8) | rr;
+}
+
+/* Deterministic cube root for x in (0, 4): integer-seeded Newton in IEEE double, +,-,*,/ only, so the
+ * HIP kernels reproduce it bit for bit.  Build rule standing in for power(x, 1/3) at utils.pas:403-405. */
+double tmo_cbrt_det(double x) {
+  union { double d; uint64_t u; } c;
+  c.d = x;
+  c.u = c.u / 3 + 0x2A9F7893782DA1CEull; /* classic exponent/3 seed, ~5% */
+  double y = c.d;
+  for (int i = 0; i < 6; i++) {
+    double y2 = y * y;
+    y = y - (y2 * y - x) / (3.0 * y2);
+  }
+  return y;
+}
+
+static void lab_core(int ir, int ig, int ib, int det, float *ol, float *oa, float *ob) { /* utils.pas:374-410 */
+  init_luts();
+  float r = g_srgb_lut[ir], g = g_srgb_lut[ig], b = g_srgb_lut[ib];
+  float x = (float)(((double)r * 0.49000 + (double)g * 0.31000 + (double)b * 0.20000) / 0.17697);
+  float y = (float)(((double)r * 0.17697 + (double)g * 0.81240 + (double)b * 0.01063) / 0.17697);
+  float z = (float)(((double)r * 0.00000 + (double)g * 0.01000 + (double)b * 0.99000) / 0.17697);
+  x = (float)((double)x * (1 / (96.6797 / 100)));
+  y = (float)((double)y * (1 / (100.000 / 100)));
+  z = (float)((double)z * (1 / (82.5188 / 100)));
+#define LABF(t)                                                                  \
+  if ((double)(t) > 0.008856)                                                    \
+    (t) = (float)(det ? tmo_cbrt_det((double)(t)) : pow((double)(t), 1.0 / 3));  \
+  else                                                                           \
+    (t) = (float)((7.787 * (double)(t)) + 16.0 / 116)
+  LABF(x);
+  LABF(y);
+  LABF(z);
+#undef LABF
+  *ol = (float)((116 * (double)y) - 16);
+  *oa = (float)(500 * (double)(float)(x - y));
+  *ob = (float)(200 * (double)(float)(y - z));
+}
+
+void tmo_rgb_to_lab(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 0, ol, oa, ob); }
+void tmo_rgb_to_lab_det(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 1, ol, oa, ob); }
+
+int32_t tmo_lab_to_rgb(float ll, float aa, float bb) { /* utils.pas:422-466 */
+  float y = (float)(((double)ll + 16) / 116);
+  float x = (float)((double)aa / 500 + (double)y);
+  float z = (float)((double)y - (double)bb / 200);
+#define INVF(t)                                                        \
+  {                                                                    \
+    double t3 = (double)(t) * (double)(t) * (double)(t);               \
+    if (t3 > 0.008856)                                                 \
+      (t) = (float)t3;                                                 \
+    else                                                               \
+      (t) = (float)(((double)(t) - 16.0 / 116) / 7.787);               \
+  }
+  INVF(y);
+  INVF(x);
+  INVF(z);
+#undef INVF
+  x = (float)(96.6797 / 100 * (double)x);
+  y = (float)(100.000 / 100 * (double)y);
+  z = (float)(82.5188 / 100 * (double)z);
+  float r = (float)((double)x * 0.41847 + (double)y * (-0.15866) + (double)z * (-0.082835));
+  float g = (float)((double)x * (-0.091169) + (double)y * 0.25243 + (double)z * 0.015708);
+  float b = (float)((double)x * 0.00092090 + (double)y * (-0.0025498) + (double)z * 0.17860);
+#define GAM(t)                                                              \
+  if ((double)(t) > 0.0031308)                                              \
+    (t) = (float)(1.055 * pow((double)(t), 1 / 2.4) - 0.055);               \
+  else                                                                      \
+    (t) = (float)(12.92 * (double)(t))
+  GAM(r);
+  GAM(g);
+  GAM(b);
+#undef GAM
+  int rr = clampi(pas_round((double)r * 255.0), 0, 255);
+  int gg = clampi(pas_round((double)g * 255.0), 0, 255);
+  int bq = clampi(pas_round((double)b * 255.0), 0, 255);
+  return (bq << 16) | (gg << 8) | rr;
+}
+
+/* Windows MulDiv: (a*b)/c rounded half away from zero */
+static int muldiv(int a, int b, int c) {
+  int64_t p = (int64_t)a * b;
+  int64_t q = (p >= 0 ? p : -p), cc = c >= 0 ? c : -c;
+  int64_t res = (q + cc / 2) / cc;
+  return (int)(((p < 0) != (c < 0)) ? -res : res);
+}
+
+void tmo_rgb_to_hsv(uint32_t col, uint8_t *h, uint8_t *s, uint8_t *v) { /* utils.pas:278-325 */
+  int rr = col & 0xff, gg = (col >> 8) & 0xff, bb = (col >> 16) & 0xff;
+  int mx = rr, mn = rr;
+  if (mx < gg) mx = gg;
+  if (mx < bb) mx = bb;
+  if (mn > gg) mn = gg;
+  if (mn > bb) mn = bb;
+  int hh = 0, ss = 0, ll = mx;
+  if (ll != mn) {
+    int delta = ll - mn;
+    ss = muldiv(delta, 255, ll);
+    if (rr == ll)
+      hh = muldiv(42, gg - bb, delta);
+    else if (gg == ll)
+      hh = muldiv(42, bb - rr, delta) + 84;
+    else if (bb == ll)
+      hh = muldiv(42, rr - gg, delta) + 168;
+    hh = hh % 252; /* Pascal mod: sign follows dividend, like C */
+  }
+  *h = (uint8_t)(hh & 0xff);
+  *s = (uint8_t)(ss & 0xff);
+  *v = (uint8_t)(ll & 0xff);
+}
+
+/* ------------------------------------------------------------------ A1-A3 load side */
+
+void tmo_load_from_image(const uint32_t *img, int img_w, int img_h, int tm_w, int tm_h, uint32_t *tiles) {
+  /* TFrame.LoadFromImage, tilingencoder.pas:1293-1320.  Tiles not covered by the image stay zero. */
+  int sw = tm_w * 8, sh = tm_h * 8;
+  memset(tiles, 0, (size_t)tm_w * tm_h * 64 * sizeof(uint32_t));
+  for (int j = 0; j < img_h; j++)
+    for (int i = 0; i < img_w; i++) {
+      uint32_t col = img[(size_t)j * img_w + i];
+      if (j < sh && i < sw) {
+        int ti = tm_w * (j >> 3) + (i >> 3);
+        tiles[(size_t)ti * 64 + (j & 7) * 8 + (i & 7)] = tmo_swap_rb(col);
+      }
+    }
+}
+
+void tmo_inter_frame_data(const uint32_t *tiles, int ntiles, float *out3) { /* tilingencoder.pas:1329-1367 */
+  for (int t = 0; t < ntiles; t++) {
+    float sl = 0, sa = 0, sb = 0;
+    for (int p = 0; p < 64; p++) {
+      uint32_t c = tiles[(size_t)t * 64 + p];
+      float l, a, b;
+      tmo_rgb_to_lab_det(c & 0xff, (c >> 8) & 0xff, (c >> 16) & 0xff, &l, &a, &b);
+      sl += l;
+      sa += a;
+      sb += b;
+    }
+    const float inv = 1.0f / 64;
+    out3[t * 3 + 0] = sl * inv;
+    out3[t * 3 + 1] = sa * inv;
+    out3[t * 3 + 2] = sb * inv;
+  }
+}
+
+float tmo_pearson(const float *x, const float *y, int n) { /* tilingencoder.pas:2201-2228; Math.mean sums in double */
+  double sx = 0, sy = 0;
+  for (int i = 0; i < n; i++) { sx += x[i]; sy += y[i]; }
+  float mx = (float)(sx / n), my = (float)(sy / n);
+  float num = 0, denx = 0, deny = 0;
+  for (int i = 0; i < n; i++) {
+    float dx = x[i] - mx, dy = y[i] - my;
+    num += dx * dy;
+    denx += dx * dx;
+    deny += dy * dy;
+  }
+  denx = sqrtf(denx);
+  deny = sqrtf(deny);
+  float den = denx * deny;
+  return den != 0.0f ? num / den : 1.0f;
+}
+
+static int zone_sum(const uint32_t *t, int x, int y) { /* GetTileZoneSum, tilingencoder.pas:4842-4863 */
+  int s = 0;
+  for (int j = y; j < y + 4; j++)
+    for (int i = x; i < x + 4; i++) {
+      uint32_t c = t[j * 8 + i];
+      s += (int)(c & 0xff) * 299 + (int)((c >> 8) & 0xff) * 587 + (int)((c >> 16) & 0xff) * 114;
+    }
+  return s;
+}
+
+void tmo_mirror_heuristics(const uint32_t *tile, int *hm, int *vm) { /* tilingencoder.pas:4865-4878 */
+  int q00 = zone_sum(tile, 0, 0), q01 = zone_sum(tile, 4, 0), q10 = zone_sum(tile, 0, 4), q11 = zone_sum(tile, 4, 4);
+  *hm = (q00 + q10) < (q01 + q11);
+  *vm = (q00 + q01) < (q10 + q11);
+}
+
+#define MIRROR_IMPL(NAME, T, H)                                    \
+  void NAME(T *t) {                                                \
+    for (int j = 0; j < (H ? 8 : 4); j++)                          \
+      for (int i = 0; i < (H ? 4 : 8); i++) {                      \
+        int a = j * 8 + i, b = H ? j * 8 + (7 - i) : (7 - j) * 8 + i; \
+        T v = t[a];                                                \
+        t[a] = t[b];                                               \
+        t[b] = v;                                                  \
+      }                                                            \
+  }
+MIRROR_IMPL(tmo_hmirror_u32, uint32_t, 1) /* HMirrorTile, tilingencoder.pas:3285-3311 */
+MIRROR_IMPL(tmo_vmirror_u32, uint32_t, 0) /* VMirrorTile, tilingencoder.pas:3257-3283 */
+MIRROR_IMPL(tmo_hmirror_u8, uint8_t, 1)
+MIRROR_IMPL(tmo_vmirror_u8, uint8_t, 0)
+
+void tmo_canonicalise_tiles(uint32_t *tiles, int ntiles, uint8_t *flags) { /* tilingencoder.pas:1393-1411 */
+  for (int t = 0; t < ntiles; t++) {
+    int h, v;
+    uint32_t *p = tiles + (size_t)t * 64;
+    tmo_mirror_heuristics(p, &h, &v);
+    if (h) tmo_hmirror_u32(p);
+    if (v) tmo_vmirror_u32(p);
+    flags[t] = (uint8_t)(h | (v << 1));
+  }
+}
+
+int tmo_find_keyframes(const float *correl, int nframes, double fps, double max_s, double min_s, double lo, uint8_t *is_kf) {
+  /* FindKeyFrames automatic mode, tilingencoder.pas:3373-3411 */
+  int64_t last = INT32_MIN;
+  int n = 0;
+  for (int f = 0; f < nframes; f++) {
+    int kf = 0;
+    if (f == 0) kf = 1;
+    if (!kf && (double)correl[f] < lo) kf = 1;
+    if (!kf && (double)(f - last) >= max_s * fps) kf = 1;
+    if ((double)(f - last) < min_s * fps) kf = 0;
+    is_kf[f] = (uint8_t)kf;
+    if (kf) { last = f; n++; }
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ A4-A6 features */
+
+static void to_cpn(uint32_t col, int use_lab, float *cpn, int pos) { /* ToCpn, tilingencoder.pas:3051-3070 */
+  int r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
+  float yy, uu, vv;
+  if (use_lab)
+    tmo_rgb_to_lab_det(r, g, b, &yy, &uu, &vv);
+  else
+    tmo_rgb_to_yuv(r, g, b, &yy, &uu, &vv);
+  cpn[pos] = yy;
+  cpn[64 + pos] = uu;
+  cpn[128 + pos] = vv;
+}
+
+void tmo_cpn_from_rgb(const uint32_t *rgb, int use_lab, int hm, int vm, float cpn[192]) { /* tilingencoder.pas:3090-3099 */
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) {
+      int xx = hm ? 7 - x : x, yy = vm ? 7 - y : y;
+      to_cpn(rgb[yy * 8 + xx], use_lab, cpn, y * 8 + x);
+    }
+}
+
+void tmo_cpn_from_pal(const uint8_t *pp, const int32_t *pal, int use_lab, int hm, int vm, float cpn[192]) { /* 3077-3086 */
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) {
+      int xx = hm ? 7 - x : x, yy = vm ? 7 - y : y;
+      to_cpn((uint32_t)pal[pp[yy * 8 + xx]], use_lab, cpn, y * 8 + x);
+    }
+}
+
+static double dct_inner_asm(const float *c, const float *l) { /* DCTInner_asm, utils.pas:874-1035 */
+  double acc0 = 0, acc1 = 0;
+  for (int k = 0; k < 64; k += 16) {
+    float p[16];
+    for (int j = 0; j < 16; j++) p[j] = c[k + j] * l[k + j];   /* mulps */
+    float s[4], t[4];
+    for (int j = 0; j < 4; j++) { s[j] = p[j] + p[j + 4]; t[j] = p[j + 8] + p[j + 12]; } /* addps */
+    double a0 = (double)s[0] + (double)t[0], a1 = (double)s[1] + (double)t[1];           /* addpd xmm2,xmm4 */
+    double b0 = (double)s[2] + (double)t[2], b1 = (double)s[3] + (double)t[3];           /* addpd xmm6,xmm8 */
+    a0 = a0 + b0;                                                                       /* addpd xmm2,xmm6 */
+    a1 = a1 + b1;
+    acc0 = acc0 + a0;                                                                   /* addpd xmm0,xmm2 */
+    acc1 = acc1 + a1;
+  }
+  return acc0 + acc1; /* haddpd */
+}
+
+static int mode_special(int mode) { return mode == TMO_PVS_SPE_DCT || mode == TMO_PVS_WEIGHTED_SPE_DCT; }
+static int mode_weighted(int mode) { return mode == TMO_PVS_WEIGHTED_DCT || mode == TMO_PVS_WEIGHTED_SPE_DCT; }
+
+void tmo_features_i16(const float cpn[192], int mode, int16_t out[192]) { /* tilingencoder.pas:3103-3131 */
+  const float *lut = tmo_dct_lut_f32(mode_special(mode));
+  for (int c = 0; c < 3; c++)
+    for (int v = 0; v < 8; v++)
+      for (int u = 0; u < 8; u++) {
+        double z = dct_inner_asm(cpn + c * 64, lut + (v * 8 + u) * 64);
+        if (mode_weighted(mode)) z *= tmo_dct_weights[c][v][u];
+        out[c * 64 + tmo_dct_snake[v * 8 + u]] = (int16_t)pas_round(z);
+      }
+}
+
+static double dct_inner_f64(const double *c, const double *l) { /* DCTInner<PDouble>, utils.pas:782-872 */
+  double r = 0;
+  for (int k = 0; k < 64; k++) r += c[k] * l[k];
+  return r;
+}
+
+void tmo_features_f64(const float cpn[192], int mode, double out[192]) { /* tilingencoder.pas:3133-3182 (DCT modes) */
+  const double *lut = tmo_dct_lut_f64(mode_special(mode));
+  double cd[192], loc[192];
+  for (int i = 0; i < 192; i++) cd[i] = cpn[i];
+  for (int c = 0; c < 3; c++)
+    for (int v = 0; v < 8; v++)
+      for (int u = 0; u < 8; u++) {
+        double z = dct_inner_f64(cd + c * 64, lut + (v * 8 + u) * 64);
+        if (mode_weighted(mode)) z *= tmo_dct_weights[c][v][u];
+        loc[c * 64 + v * 8 + u] = z;
+      }
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 64; i++) out[tmo_dct_snake[i] + c * 64] = loc[i + c * 64];
+}
+
+void tmo_inv_features_f64(const double dct[192], int mode, int use_lab, uint32_t rgb_out[64]) { /* 3184-3255 */
+  const double *ilut = tmo_inv_dct_lut_f64();
+  double loc[192], cpn[192];
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 64; i++) {
+      double d = dct[tmo_dct_snake[i] + c * 64];
+      loc[c * 64 + i] = mode_weighted(mode) ? d / tmo_dct_weights[c][i >> 3][i & 7] : d;
+    }
+  for (int c = 0; c < 3; c++)
+    for (int p = 0; p < 64; p++) cpn[c * 64 + p] = dct_inner_f64(loc + c * 64, ilut + p * 64);
+  for (int p = 0; p < 64; p++) {
+    float yy = (float)cpn[p], uu = (float)cpn[64 + p], vv = (float)cpn[128 + p];
+    rgb_out[p] = (uint32_t)(use_lab ? tmo_lab_to_rgb(yy, uu, vv) : tmo_yuv_to_rgb(yy, uu, vv));
+  }
+}
+
+void tmo_tiles_features_i16(const uint32_t *tiles, int n, const uint8_t *mf, int mode, int use_lab, int16_t *out) {
+  for (int t = 0; t < n; t++) {
+    float cpn[192];
+    int f = mf ? mf[t] : 0;
+    tmo_cpn_from_rgb(tiles + (size_t)t * 64, use_lab, f & 1, (f >> 1) & 1, cpn);
+    tmo_features_i16(cpn, mode, out + (size_t)t * 192);
+  }
+}
+
+void tmo_paltiles_features_i16(const uint8_t *pp, const int32_t *pal_idx, int n, const int32_t *palettes, int pal_size,
+                               int mode, int16_t *out) { /* PrepareReconstruct.DoPsyV, tilingencoder.pas:4570-4583 */
+  for (int t = 0; t < n; t++) {
+    float cpn[192];
+    tmo_cpn_from_pal(pp + (size_t)t * 64, palettes + (size_t)pal_idx[t] * pal_size, 0, 0, 0, cpn);
+    tmo_features_i16(cpn, mode, out + (size_t)t * 192);
+  }
+}
+
+void tmo_tiles_features_cluster_i32(const uint32_t *tiles, int n, int mode, int32_t *out) {
+  /* DoPalettization feature (tilingencoder.pas:4126,4160): A6 with UseLAB, then the build's Round() to int32 */
+  for (int t = 0; t < n; t++) {
+    float cpn[192];
+    double f[192];
+    tmo_cpn_from_rgb(tiles + (size_t)t * 64, 1, 0, 0, cpn);
+    tmo_features_f64(cpn, mode, f);
+    for (int i = 0; i < 192; i++) out[(size_t)t * 192 + i] = (int32_t)pas_round(f[i]);
+  }
+}
+
+/* ------------------------------------------------------------------ A15 distances */
+
+uint32_t tmo_ssd_i16(const int16_t *a, const int16_t *b) { /* CompareEuclideanDCTPtr, utils.pas:541-557 */
+  uint32_t r = 0;
+  for (int i = 0; i < 192; i++) {
+    int32_t d = (int32_t)a[i] - (int32_t)b[i];
+    r += (uint32_t)(d * d);
+  }
+  return r;
+}
+
+static inline int16_t sat16(int32_t v) { return (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
+
+uint32_t tmo_ssd_i16_sse_quirk(const int16_t *a, const int16_t *b) {
+  /* CompareEuclideanDCTPtr_asm as written (utils.pas:559-725): per 96-element half, 12 blocks of 8 int16 in
+   * xmm1..xmm12.  Block 5 is loaded into xmm6 then overwritten by block 6 (591-592); xmm6 gets psubsw of b block 5
+   * AND b block 6 (604-605); xmm7 is never loaded yet is squared (618) and summed (628).  After half 1, xmm7 holds
+   * pmaddwd(xmm7_in) + block-7 squares, which half 2 re-squares as int16 pairs (678).  Entry xmm7 taken as 0
+   * (Win64 ABI leaves it undefined). */
+  uint32_t total = 0;
+  uint32_t x7[4] = {0, 0, 0, 0};
+  for (int half = 0; half < 2; half++) {
+    const int16_t *pa = a + half * 96, *pb = b + half * 96;
+    for (int k = 0; k < 4; k++) { /* pmaddwd xmm7,xmm7 */
+      int32_t lo = (int16_t)(x7[k] & 0xffff), hi = (int16_t)(x7[k] >> 16);
+      x7[k] = (uint32_t)(lo * lo) + (uint32_t)(hi * hi);
+    }
+    for (int blk = 0; blk < 12; blk++) {
+      if (blk == 5) continue; /* dropped */
+      for (int j = 0; j < 8; j++) {
+        int16_t d;
+        if (blk == 6) {
+          d = sat16((int32_t)pa[48 + j] - pb[40 + j]); /* psubsw xmm6,[rdx+$50] */
+          d = sat16((int32_t)d - pb[48 + j]);          /* psubsw xmm6,[rdx+$60] */
+        } else {
+          d = sat16((int32_t)pa[blk * 8 + j] - pb[blk * 8 + j]);
+        }
+        uint32_t sq = (uint32_t)((int32_t)d * (int32_t)d);
+        if (blk == 7) x7[j >> 1] += sq; /* paddd xmm7,xmm8 */
+        else total += sq;
+      }
+    }
+    for (int k = 0; k < 4; k++) total += x7[k]; /* paddd xmm5,xmm7 ... phaddd */
+  }
+  return total;
+}
+
+float tmo_euclidean_to_psnr(uint32_t e) { /* utils.pas:1074-1078 */
+  float r = (float)((double)e * (1.0 / 192));
+  float m = r > 0.5f ? r : 0.5f;
+  return (float)(10 * log10(255 * 255 / (double)m));
+}
+
+/* ------------------------------------------------------------------ A13/A14 KNN */
+
+void tmo_knn1(const int16_t *q, int64_t nq, const int16_t *db, int64_t nt, int32_t *idx, uint32_t *err) {
+  /* exact nearest neighbour = what ann_kdtree_search(eps=0) returns (tilingencoder.pas:1547); build's tie rule: lowest index */
+  for (int64_t i = 0; i < nq; i++) {
+    uint32_t best = UINT32_MAX;
+    int32_t bi = -1;
+    for (int64_t t = 0; t < nt; t++) {
+      uint32_t d = tmo_ssd_i16(q + i * 192, db + t * 192);
+      if (d < best || bi < 0) { best = d; bi = (int32_t)t; }
+    }
+    idx[i] = bi;
+    err[i] = best;
+  }
+}
+
+void tmo_knnk(const int16_t *q, int64_t nq, const int16_t *db, int64_t nt, int k, int32_t *idx, uint32_t *err) {
+  /* ann_kdtree_search_multi(k=64, eps=0) (tilingencoder.pas:1563); build's order: (err asc, idx asc); short lists pad -1 */
+  for (int64_t i = 0; i < nq; i++) {
+    int32_t *oi = idx + i * k;
+    uint32_t *oe = err + i * k;
+    int cnt = 0;
+    for (int64_t t = 0; t < nt; t++) {
+      uint32_t d = tmo_ssd_i16(q + i * 192, db + t * 192);
+      if (cnt == k && d >= oe[k - 1]) continue;
+      int p = cnt < k ? cnt : k - 1;
+      while (p > 0 && oe[p - 1] > d) { oe[p] = oe[p - 1]; oi[p] = oi[p - 1]; p--; }
+      oe[p] = d;
+      oi[p] = (int32_t)t;
+      if (cnt < k) cnt++;
+    }
+    for (int p = cnt; p < k; p++) { oi[p] = -1; oe[p] = UINT32_MAX; }
+  }
+}
+
+/* ------------------------------------------------------------------ QuickSort (extern.pas:370-418) */
+
+void tmo_quicksort(void *data, int64_t first, int64_t last, int isz, tmo_cmp_fn cmp, void *user) {
+  if (last <= first) return;
+  uint8_t *pd = (uint8_t *)data;
+  uint8_t tmp[4096];
+  int64_t i, j, p;
+  do {
+    i = first;
+    j = last;
+    p = (first + last) >> 1;
+    do {
+      while (cmp(pd + i * isz, pd + p * isz, user) < 0) i++;
+      while (cmp(pd + j * isz, pd + p * isz, user) > 0) j--;
+      if (i <= j) {
+        memcpy(tmp, pd + j * isz, (size_t)isz);
+        memcpy(pd + j * isz, pd + i * isz, (size_t)isz);
+        memcpy(pd + i * isz, tmp, (size_t)isz);
+        if (p == i)
+          p = j;
+        else if (p == j)
+          p = i;
+        i++;
+        j--;
+      }
+    } while (i <= j);
+    if (first < j) tmo_quicksort(data, first, j, isz, cmp, user);
+    first = i;
+  } while (i < last);
+}
+
+/* ------------------------------------------------------------------ A12 dithering */
+
+void tmo_prepare_plan(tmo_plan *plan, const int32_t *pal, int pal_size, int y2_mixed) { /* tilingencoder.pas:2268-2301 */
+  memset(plan, 0, sizeof(*plan));
+  plan->y2_mixed_colors = y2_mixed;
+  int cnt = 0;
+  for (int i = 0; i < pal_size; i++) {
+    if (pal[i] == TMO_NULL_COLOR) continue;
+    int r = pal[i] & 0xff, g = (pal[i] >> 8) & 0xff, b = (pal[i] >> 16) & 0xff;
+    plan->luma[cnt] = r * 299 + g * 587 + b * 114;
+    plan->y2[cnt][0] = r;
+    plan->y2[cnt][1] = g;
+    plan->y2[cnt][2] = b;
+    plan->y2[cnt][3] = plan->luma[cnt] / 1000;
+    plan->remap[cnt] = (uint8_t)i;
+    cnt++;
+  }
+  plan->count = cnt;
+}
+
+int64_t tmo_color_compare(int64_t r1, int64_t g1, int64_t b1, int64_t r2, int64_t g2, int64_t b2) { /* 2323-2337 */
+  int64_t luma1 = r1 * 299 + g1 * 587 + b1 * 114;
+  int64_t luma2 = r2 * 299 + g2 * 587 + b2 * 114;
+  int64_t ld = (luma1 - luma2) / 1000; /* div: toward zero */
+  int64_t dr = r1 - r2, dg = g1 - g2, db = b1 - b2;
+  return dr * dr * 13 + dg * dg * 13 + db * db * 13 + ((ld * ld) << 5);
+}
+
+static int cmp_luma(const void *a, const void *b, void *user) { /* PlanCompareLuma, tilingencoder.pas:2310-2321 */
+  const int32_t *l = (const int32_t *)user;
+  int32_t x = l[*(const uint8_t *)a], y = l[*(const uint8_t *)b];
+  return (x > y) - (x < y);
+}
+
+void tmo_mixing_plan_tk(const tmo_plan *plan, uint32_t col, uint8_t list[64]) { /* tilingencoder.pas:2565-2612 */
+  int64_t s[3] = {col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff}, e[3] = {0, 0, 0}, t[3];
+  for (int c = 0; c < 64; c++) {
+    for (int k = 0; k < 3; k++) t[k] = s[k] + (e[k] * 9) / 100;
+    int64_t least = INT64_MAX;
+    int chosen = c % plan->count;
+    for (int i = 0; i < plan->count; i++) {
+      int64_t pen = tmo_color_compare(t[0], t[1], t[2], plan->y2[i][0], plan->y2[i][1], plan->y2[i][2]);
+      if (pen < least) { least = pen; chosen = i; }
+    }
+    list[c] = (uint8_t)chosen;
+    for (int k = 0; k < 3; k++) e[k] += s[k] - plan->y2[chosen][k];
+  }
+  tmo_quicksort(list, 0, 63, 1, cmp_luma, (void *)plan->luma);
+}
+
+int tmo_mixing_plan_yliluoma(const tmo_plan *plan, uint32_t col, uint8_t list[256]) {
+  /* DeviseBestMixingPlanYliluoma, live SSE4.1 path (ASM_DBMP), tilingencoder.pas:2339-2563:
+   * averages via the reciprocal table FVecInv[4t..4t+3] = 65536 div t (1698-1699), 32-bit lanes incl. luma,
+   * penalty = 13(dR^2+dG^2+dB^2)+32 dL^2 as a 32-bit sum compared unsigned, first strict minimum wins. */
+  int32_t tgt[4] = {(int32_t)(col & 0xff), (int32_t)((col >> 8) & 0xff), (int32_t)((col >> 16) & 0xff), 0};
+  tgt[3] = (int32_t)((uint32_t)(tgt[0] * 299 + tgt[1] * 587 + tgt[2] * 114) / 1000u);
+  const uint32_t w[4] = {13, 13, 13, 32};
+  int plan_count = 0;
+  int32_t so_far[4] = {0, 0, 0, 0};
+  while (plan_count < plan->y2_mixed_colors) {
+    int max_test = plan_count == 0 ? 1 : plan_count;
+    uint64_t best = ((uint64_t)1 << 63) - 1;
+    int chosen = 0, chosen_amount = 1;
+    for (int idx = 0; idx < plan->count; idx++) {
+      uint32_t sum[4], add[4];
+      for (int k = 0; k < 4; k++) { sum[k] = (uint32_t)so_far[k]; add[k] = (uint32_t)plan->y2[idx][k]; }
+      for (int t = plan_count + 1; t <= plan_count + max_test; t++) {
+        uint32_t inv = 65536u / (uint32_t)t, pen = 0;
+        for (int k = 0; k < 4; k++) {
+          sum[k] += add[k];
+          add[k] += 1;
+          uint32_t avg = (sum[k] * inv) >> 16;
+          uint32_t d = avg - (uint32_t)tgt[k];
+          pen += d * d * w[k];
+        }
+        if ((uint64_t)pen < best) { best = pen; chosen = idx; chosen_amount = t - plan_count; }
+      }
+    }
+    if (chosen_amount > 256 - plan_count) chosen_amount = 256 - plan_count;
+    memset(list + plan_count, chosen, (size_t)chosen_amount);
+    plan_count += chosen_amount;
+    for (int k = 0; k < 4; k++) so_far[k] += plan->y2[chosen][k] * chosen_amount;
+  }
+  tmo_quicksort(list, 0, plan_count - 1, 1, cmp_luma, (void *)plan->luma);
+  return plan_count;
+}
+
+void tmo_dither_tile(const uint32_t *rgb_canon, int hm, int vm, const tmo_plan *plan, int use_tk, uint8_t pal_out[64]) {
+  /* DitherTile, tilingencoder.pas:2688-2724 */
+  uint32_t nat[64];
+  memcpy(nat, rgb_canon, sizeof(nat));
+  if (hm) tmo_hmirror_u32(nat);
+  if (vm) tmo_vmirror_u32(nat);
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) {
+      int map_value = tmo_dithering_map[((y & 7) << 3) | (x & 7)];
+      if (use_tk) {
+        uint8_t l[64];
+        tmo_mixing_plan_tk(plan, nat[y * 8 + x], l);
+        pal_out[y * 8 + x] = plan->remap[l[map_value]];
+      } else {
+        uint8_t l[256];
+        int count = tmo_mixing_plan_yliluoma(plan, nat[y * 8 + x], l);
+        map_value = (map_value * count) >> 6;
+        pal_out[y * 8 + x] = plan->remap[l[map_value]];
+      }
+    }
+  if (hm) tmo_hmirror_u8(pal_out);
+  if (vm) tmo_vmirror_u8(pal_out);
+}
+
+void tmo_dither_tiles(const uint32_t *tiles, const uint8_t *flags, const int32_t *pal_idx, int64_t n, const int32_t *palettes,
+                      int pal_size, int use_tk, int y2_mixed, uint8_t *pal_out) { /* Dither, tilingencoder.pas:1873-1907 */
+  int maxp = 0;
+  for (int64_t t = 0; t < n; t++)
+    if (pal_idx[t] > maxp) maxp = pal_idx[t];
+  tmo_plan *plans = (tmo_plan *)malloc(sizeof(tmo_plan) * (size_t)(maxp + 1));
+  for (int p = 0; p <= maxp; p++) tmo_prepare_plan(&plans[p], palettes + (size_t)p * pal_size, pal_size, y2_mixed);
+  for (int64_t t = 0; t < n; t++) {
+    int f = flags ? flags[t] : 0;
+    tmo_dither_tile(tiles + t * 64, f & 1, (f >> 1) & 1, &plans[pal_idx[t]], use_tk, pal_out + t * 64);
+  }
+  free(plans);
+}
+
+/* ------------------------------------------------------------------ A8/A16 exact dedup + reindex */
+
+typedef struct { const void *keys; int width; int is_u8; const uint32_t *use; } sort_ctx;
+static sort_ctx g_sc; /* qsort has no user pointer; the oracle is single-threaded */
+
+static int cmp_content(int64_t a, int64_t b) { /* CompareDWord / CompareByte, tilingencoder.pas:940-948 */
+  if (g_sc.is_u8) {
+    int r = memcmp((const uint8_t *)g_sc.keys + a * g_sc.width, (const uint8_t *)g_sc.keys + b * g_sc.width, (size_t)g_sc.width);
+    return (r > 0) - (r < 0);
+  }
+  const uint32_t *pa = (const uint32_t *)g_sc.keys + a * g_sc.width, *pb = (const uint32_t *)g_sc.keys + b * g_sc.width;
+  for (int i = 0; i < g_sc.width; i++)
+    if (pa[i] != pb[i]) return pa[i] < pb[i] ? -1 : 1;
+  return 0;
+}
+static int cmp_rows(const void *x, const void *y) {
+  int64_t a = *(const int64_t *)x, b = *(const int64_t *)y;
+  int r = cmp_content(a, b);
+  return r ? r : (a > b) - (a < b);
+}
+static int cmp_use_desc(const void *x, const void *y) { /* CompareTileUseCountRev, tilingencoder.pas:584-599 */
+  int64_t a = *(const int64_t *)x, b = *(const int64_t *)y;
+  if (g_sc.use[a] != g_sc.use[b]) return g_sc.use[a] > g_sc.use[b] ? -1 : 1;
+  return cmp_content(a, b);
+}
+
+static int64_t dedup_common(const void *keys, int64_t n, int width, int is_u8, const uint32_t *use_in, int64_t *rep,
+                            int64_t *order, uint32_t *use_out, int64_t *remap) {
+  /* MakeTilesUnique (tilingencoder.pas:4720-4781) + MergeTiles (4783-4813) + ReindexTiles (4626-4700) */
+  if (n <= 0) return 0;
+  int64_t *srt = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  uint32_t *use = (uint32_t *)calloc((size_t)n, sizeof(uint32_t));
+  for (int64_t i = 0; i < n; i++) srt[i] = i;
+  g_sc.keys = keys; g_sc.width = width; g_sc.is_u8 = is_u8; g_sc.use = use;
+  qsort(srt, (size_t)n, sizeof(int64_t), cmp_rows);
+  int64_t nu = 0, first = 0;
+  for (int64_t i = 0; i <= n; i++) {
+    if (i == n || (i > 0 && cmp_content(srt[i - 1], srt[i]) != 0)) {
+      if (i > first || i == n) {
+        int64_t r = srt[first]; /* lowest original index of the run: build's representative rule */
+        uint32_t u = 0;
+        for (int64_t j = first; j < i; j++) { rep[srt[j]] = r; u += use_in ? use_in[srt[j]] : 1u; }
+        use[r] = u;
+        order[nu++] = r;
+      }
+      first = i;
+    }
+  }
+  /* drop zero-use (ReindexTiles packs Active and UseCount>0 only), then sort by use desc, content asc */
+  int64_t m = 0;
+  for (int64_t i = 0; i < nu; i++)
+    if (use[order[i]] > 0) order[m++] = order[i];
+  qsort(order, (size_t)m, sizeof(int64_t), cmp_use_desc);
+  int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  for (int64_t i = 0; i < n; i++) pos[i] = -1;
+  for (int64_t i = 0; i < m; i++) { pos[order[i]] = i; if (use_out) use_out[i] = use[order[i]]; }
+  if (remap)
+    for (int64_t i = 0; i < n; i++) remap[i] = pos[rep[i]];
+  free(pos); free(use); free(srt);
+  return m;
+}
+
+int64_t tmo_dedup_u32(const uint32_t *keys, int64_t n, int kd, const uint32_t *use_in, int64_t *rep, int64_t *order,
+                      uint32_t *use_out, int64_t *remap) {
+  return dedup_common(keys, n, kd, 0, use_in, rep, order, use_out, remap);
+}
+int64_t tmo_dedup_u8(const uint8_t *keys, int64_t n, int kb, const uint32_t *use_in, int64_t *rep, int64_t *order,
+                     uint32_t *use_out, int64_t *remap) {
+  return dedup_common(keys, n, kb, 1, use_in, rep, order, use_out, remap);
+}
+
+int tmo_equal_quality_tile_count(double tc) { /* utils.pas:1038-1041; TFloat argument */
+  float f = (float)tc;
+  return (int)pas_round(sqrt((double)f) * log2(1 + (double)f));
+}
+
+/* ------------------------------------------------------------------ A9/A10 k-means of the build */
+
+static inline int64_t sqdist_i(const int32_t *a, const int32_t *b, int d) {
+  int64_t s = 0;
+  for (int i = 0; i < d; i++) { int64_t t = (int64_t)a[i] - b[i]; s += t * t; }
+  return s;
+}
+
+int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int max_iter, int32_t *assign,
+                   double *cent, int *iters_out) {
+  if (iters_out) *iters_out = 0;
+  if (n <= 0 || k <= 0) return 0;
+  /* farthest-first ("maximin") init from point 0, ties -> lowest index (cf. InitFarthestFirst, kmodes.pas:694) */
+  int64_t *mind = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  for (int64_t i = 0; i < n; i++) mind[i] = INT64_MAX;
+  int kk = 0;
+  int64_t cur = 0;
+  while (kk < k) {
+    for (int j = 0; j < d; j++) cent[(size_t)kk * d + j] = (double)pts[cur * d + j];
+    kk++;
+    int64_t best = 0, bi = -1;
+    for (int64_t i = 0; i < n; i++) {
+      int64_t dd = sqdist_i(pts + i * d, pts + cur * d, d);
+      if (dd < mind[i]) mind[i] = dd;
+      if (mind[i] > best) { best = mind[i]; bi = i; }
+    }
+    if (bi < 0) break; /* no distinct point left */
+    cur = bi;
+  }
+  free(mind);
+  /* Lloyd: double distances summed in dimension order, ties -> lowest centroid; exact integer weighted sums */
+  int64_t *sum = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk * d);
+  int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk);
+  for (int64_t i = 0; i < n; i++) assign[i] = -1;
+  int it = 0;
+  for (; it < max_iter; it++) {
+    int64_t changed = 0;
+    memset(sum, 0, sizeof(int64_t) * (size_t)kk * d);
+    memset(cnt, 0, sizeof(int64_t) * (size_t)kk);
+    for (int64_t i = 0; i < n; i++) {
+      double bd = 0;
+      int bc = -1;
+      for (int c = 0; c < kk; c++) {
+        double s = 0;
+        for (int j = 0; j < d; j++) {
+          double t = (double)pts[i * d + j] - cent[(size_t)c * d + j];
+          s = s + t * t;
+        }
+        if (bc < 0 || s < bd) { bd = s; bc = c; }
+      }
+      if (assign[i] != bc) { assign[i] = bc; changed++; }
+      int64_t wi = w ? w[i] : 1;
+      cnt[bc] += wi;
+      for (int j = 0; j < d; j++) sum[(size_t)bc * d + j] += wi * pts[i * d + j];
+    }
+    if (!changed) break;
+    for (int c = 0; c < kk; c++)
+      if (cnt[c] > 0)
+        for (int j = 0; j < d; j++) cent[(size_t)c * d + j] = (double)sum[(size_t)c * d + j] / (double)cnt[c];
+  }
+  if (iters_out) *iters_out = it;
+  free(sum); free(cnt);
+  return kk;
+}
+
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return (x > y) - (x < y); }
+
+typedef struct { uint8_t v, s, h, r, g, b; int idx; } cm_item;
+static int cmp_cm(const void *a, const void *b) { /* CompareCountIndexVSH, utils.pas:741-748; then r,g,b,idx (build rule) */
+  const cm_item *x = (const cm_item *)a, *y = (const cm_item *)b;
+  if (x->v != y->v) return x->v < y->v ? -1 : 1;
+  if (x->s != y->s) return x->s < y->s ? -1 : 1;
+  if (x->h != y->h) return x->h < y->h ? -1 : 1;
+  if (x->r != y->r) return x->r < y->r ? -1 : 1;
+  if (x->g != y->g) return x->g < y->g ? -1 : 1;
+  if (x->b != y->b) return x->b < y->b ? -1 : 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+void tmo_quantize_palette(const uint32_t *pixels, int64_t npx, int pal_size, int max_iter, int32_t *pal_out) {
+  /* QuantizeUsingYakmo + DoQuantization, tilingencoder.pas:4434-4564, on the (G,R,B)-sorted colour histogram */
+  for (int i = 0; i < pal_size; i++) pal_out[i] = TMO_NULL_COLOR;
+  if (npx <= 0) return;
+  uint32_t *key = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)npx);
+  for (int64_t i = 0; i < npx; i++) { /* CompareDSPixel: G, R, B (tilingencoder.pas:1046-1056) */
+    uint32_t c = pixels[i];
+    key[i] = (((c >> 8) & 0xff) << 16) | ((c & 0xff) << 8) | ((c >> 16) & 0xff);
+  }
+  qsort(key, (size_t)npx, sizeof(uint32_t), cmp_u32);
+  int64_t nu = 0;
+  for (int64_t i = 0; i < npx; i++)
+    if (i == 0 || key[i] != key[i - 1]) nu++;
+  int32_t *pts = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)nu);
+  uint32_t *w = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nu);
+  int64_t u = -1;
+  for (int64_t i = 0; i < npx; i++) {
+    if (i == 0 || key[i] != key[i - 1]) {
+      u++;
+      pts[u * 3 + 0] = (int32_t)((key[i] >> 8) & 0xff);  /* R */
+      pts[u * 3 + 1] = (int32_t)((key[i] >> 16) & 0xff); /* G */
+      pts[u * 3 + 2] = (int32_t)(key[i] & 0xff);         /* B */
+      w[u] = 0;
+    }
+    w[u]++;
+  }
+  int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)nu);
+  double cent[64 * 3];
+  int kk = tmo_kmeans_i32(pts, w, nu, 3, pal_size, max_iter, assign, cent, NULL);
+  cm_item items[64];
+  for (int i = 0; i < kk; i++) {
+    items[i].r = (uint8_t)clampi(pas_round(cent[i * 3 + 0]), 0, 255); /* Posterize(v,255) = v, utils.pas:526-534 */
+    items[i].g = (uint8_t)clampi(pas_round(cent[i * 3 + 1]), 0, 255);
+    items[i].b = (uint8_t)clampi(pas_round(cent[i * 3 + 2]), 0, 255);
+    items[i].idx = i;
+    tmo_rgb_to_hsv((uint32_t)items[i].r | ((uint32_t)items[i].g << 8) | ((uint32_t)items[i].b << 16), &items[i].h, &items[i].s,
+                   &items[i].v);
+  }
+  qsort(items, (size_t)kk, sizeof(cm_item), cmp_cm);
+  for (int i = 0; i < kk; i++) pal_out[i] = (int32_t)((uint32_t)items[i].r | ((uint32_t)items[i].g << 8) | ((uint32_t)items[i].b << 16));
+  free(assign); free(w); free(pts); free(key);
+}
+
+void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, int pal_count, int max_iter, int32_t *pal_idx_out) {
+  /* DoPalettization, tilingencoder.pas:4105-4245, with BICO+ANN+yakmo replaced by the build's k-means on all tiles */
+  double *cent = (double *)malloc(sizeof(double) * (size_t)pal_count * 192);
+  int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  tmo_kmeans_i32(feat, use, n, 192, pal_count, max_iter, assign, cent, NULL);
+  int64_t *cnt = (int64_t *)calloc((size_t)pal_count, sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) cnt[assign[i]]++; /* Inc(FPalettes[..].UseCount) per tile, 4229-4230 */
+  int *ord = (int *)malloc(sizeof(int) * (size_t)pal_count), *lut = (int *)malloc(sizeof(int) * (size_t)pal_count);
+  for (int i = 0; i < pal_count; i++) ord[i] = i;
+  for (int i = 1; i < pal_count; i++) { /* use count desc (ComparePaletteUseCount, utils.pas:750-753), then initial index */
+    int v = ord[i], j = i;
+    while (j > 0 && cnt[ord[j - 1]] < cnt[v]) { ord[j] = ord[j - 1]; j--; }
+    ord[j] = v;
+  }
+  for (int i = 0; i < pal_count; i++) lut[ord[i]] = i;
+  for (int64_t i = 0; i < n; i++) pal_idx_out[i] = lut[assign[i]];
+  free(lut); free(ord); free(cnt); free(assign); free(cent);
+}

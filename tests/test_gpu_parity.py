@@ -1,0 +1,150 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bit-exact everywhere (integer/byte/index outputs, and floats because the build only uses IEEE +,-,*,/ in a fixed order)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint32:
+        a = a.view(np.int32)
+    return torch.from_numpy(a).cuda()
+
+
+def _host_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    from tiler_amd import synth
+    return synth.video(3, 100, 60)  # not a multiple of 8: exercises the crop/zero-fill edge (tile map 13x8)
+
+
+@pytest.fixture(scope="module")
+def tiles_flags(frames, oracle):
+    tm_w, tm_h = 13, 8
+    all_tiles, all_flags = [], []
+    for f in range(frames.shape[0]):
+        t = oracle.load_from_image(frames[f], tm_w, tm_h)
+        c, fl = oracle.canonicalise(t)
+        all_tiles.append(c)
+        all_flags.append(fl)
+    return np.concatenate(all_tiles), np.concatenate(all_flags)
+
+
+def test_load_stage(frames, oracle):
+    from tiler_amd import stages
+    tm_w, tm_h = 13, 8
+    tiles, flags, lab = stages.load(_dev(frames), tm_w, tm_h)
+    torch.cuda.synchronize()
+    exp_tiles, exp_flags, exp_lab = [], [], []
+    for f in range(frames.shape[0]):
+        t = oracle.load_from_image(frames[f], tm_w, tm_h)
+        exp_lab.append(oracle.inter_frame_data(t))
+        c, fl = oracle.canonicalise(t)
+        exp_tiles.append(c)
+        exp_flags.append(fl)
+    assert np.array_equal(_host_u32(tiles), np.concatenate(exp_tiles))
+    assert np.array_equal(flags.cpu().numpy(), np.concatenate(exp_flags))
+    got = lab.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.concatenate(exp_lab).view(np.uint32)), "Lab tile means must match bit for bit"
+
+
+@pytest.mark.parametrize("mode,use_lab,mirrors", [(1, False, False), (1, False, True), (0, False, False), (3, False, True),
+                                                  (4, True, False), (4, False, True)])
+def test_features_rgb(tiles_flags, oracle, mode, use_lab, mirrors):
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    exp = oracle.features_rgb(tiles, flags if mirrors else None, mode, use_lab)
+    got = stages.features_rgb(_dev(tiles), _dev(flags) if mirrors else None, mode, use_lab).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
+def test_features_rgb_extremes(oracle):
+    from tiler_amd import stages
+    rng = np.random.default_rng(7)
+    t = rng.integers(0, 1 << 24, size=(257, 64), dtype=np.uint32)  # odd count: ragged last workgroup
+    t[0] = 0
+    t[1] = 0xFFFFFF
+    t[2, ::2] = 0xFFFFFF
+    t[2, 1::2] = 0
+    exp = oracle.features_rgb(t, None, 1, False)
+    got = stages.features_rgb(_dev(t), None, 1, False).cpu().numpy()
+    assert np.array_equal(got, exp)
+    assert stages.features_rgb(_dev(t[:0]), None, 1, False).shape == (0, 192)
+
+
+def test_features_pal_and_cluster(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, _ = tiles_flags
+    rng = np.random.default_rng(3)
+    n = tiles.shape[0]
+    palettes = rng.integers(0, 1 << 24, size=(5, 16), dtype=np.int32)
+    pal_idx = rng.integers(0, 5, size=n, dtype=np.int32)
+    pal_px = rng.integers(0, 16, size=(n, 64), dtype=np.uint8)
+    exp = oracle.features_pal(pal_px, pal_idx, palettes, 1)
+    got = stages.features_pal(_dev(pal_px), _dev(pal_idx), _dev(palettes), 1).cpu().numpy()
+    assert np.array_equal(got, exp)
+    expc = oracle.features_cluster(tiles, 4)
+    gotc = stages.features_cluster(_dev(tiles), 4).cpu().numpy()
+    assert np.array_equal(gotc, expc)
+
+
+def _rand_features(rng, n, spread):
+    """int16[192] rows shaped like real features: a few wide (DC-like) columns, the rest narrow"""
+    f = rng.integers(-spread, spread + 1, size=(n, 192)).astype(np.int32)
+    f[:, [0, 64, 128]] = rng.integers(-13000, 13001, size=(n, 3))
+    f[:, 1:6] = rng.integers(-3000, 3001, size=(n, 5))
+    return f.astype(np.int16)
+
+
+@pytest.mark.parametrize("nq,nt,spread", [(70, 100, 90), (1, 1, 90), (33, 31, 20000), (300, 1000, 600), (64, 2049, 100)])
+def test_knn_exact(oracle, nq, nt, spread):
+    from tiler_amd import stages
+    rng = np.random.default_rng(nq * 1000 + nt)
+    db = _rand_features(rng, nt, spread)
+    q = _rand_features(rng, nq, spread)
+    if nt > 10:  # plant exact duplicates so the lowest-index tie rule is exercised
+        db[7] = db[3]
+        q[0] = db[3]
+        db[nt - 1] = db[nt - 2]
+        q[nq - 1] = db[nt - 1]
+    eidx, eerr = oracle.knn1(q, db)
+    idx, err = stages.knn(_dev(q), _dev(db))
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+
+
+def test_knn_real_features(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    feats = oracle.features_rgb(tiles, None, 1, False)
+    db, q = feats[:150], feats
+    eidx, eerr = oracle.knn1(q, db)
+    idx, err = stages.knn(_dev(q), _dev(db))
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+
+
+def test_dither_thomas_knoll(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    tiles, flags = tiles[:120], flags[:120]
+    rng = np.random.default_rng(11)
+    palettes = rng.integers(0, 1 << 24, size=(4, 16), dtype=np.int32)
+    palettes[1, 5:] = -0xFF0001  # cDitheringNullColor $FFFF00FF as int32: short palette
+    palettes[2, 3] = palettes[2, 9]  # duplicate colour
+    # two DIFFERENT colours with equal luma (299*15 - 587*9 + 114*7 = 0): the unstable-sort tie case of extern.pas:370
+    r, g, b = 100, 120, 60
+    palettes[3, 0] = (b << 16) | (g << 8) | r
+    palettes[3, 1] = ((b + 7) << 16) | ((g - 9) << 8) | (r + 15)
+    palettes[3, 2] = ((b + 14) << 16) | ((g - 18) << 8) | (r + 30)
+    pal_idx = rng.integers(0, 4, size=tiles.shape[0], dtype=np.int32)
+    exp = oracle.dither(tiles, flags, pal_idx, palettes, True)
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
+    assert np.array_equal(got, exp)

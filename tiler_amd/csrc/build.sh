@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds libtilemotion.so for gfx950 in-tree (tiler_amd/lib/).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/.obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall -Wno-unused-function ${TM_EXTRA_FLAGS:-}"
+pids=()
+objs=()
+for src in "$HERE"/*.hip; do
+  obj="$HERE/.obj/$(basename "${src%.hip}").o"
+  objs+=("$obj")
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" "$HERE/../../include" -name '*.h' -newer "$obj" 2>/dev/null | head -1)" ]; then
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtilemotion.so" "${objs[@]}"
+echo "built $OUT/libtilemotion.so"

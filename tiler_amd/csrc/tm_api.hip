@@ -1,0 +1,70 @@
+// tm_api.hip -- extern "C" surface of libtilemotion.so: stage seam + KNN index + misc (include/tilemotion.h).
+#include "tm_common.h"
+#include "tm_internal.h"
+
+using namespace tmx;
+
+extern "C" {
+
+const char *tm_last_error(void) { return tmx::get_error(); }
+
+int tm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *tm_version(void) { return "tilemotion-mi355x 0.1 (gfx950)"; }
+
+int tm_stage_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
+                  void *lab_means, void *stream) {
+  return launch_load(frames, nframes, img_w, img_h, tm_w, tm_h, tiles, flags, lab_means, (hipStream_t)stream);
+}
+
+int tm_stage_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out_i16,
+                          void *stream) {
+  return launch_features_rgb(tiles, n, mirror_flags, mode, use_lab, out_i16, (hipStream_t)stream);
+}
+
+int tm_stage_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode,
+                          void *out_i16, void *stream) {
+  return launch_features_pal(pal_px, pal_idx, n, palettes, pal_size, mode, out_i16, (hipStream_t)stream);
+}
+
+int tm_stage_features_cluster(const void *tiles, int64_t n, int mode, void *out_i32, void *stream) {
+  return launch_features_cluster(tiles, n, mode, out_i32, (hipStream_t)stream);
+}
+
+tm_knn_index *tm_knn_index_create(const void *db_i16, int64_t nt, void *stream) {
+  tm_knn_index_impl *ix = nullptr;
+  if (knn_index_create(db_i16, nt, (hipStream_t)stream, &ix) != TM_OK) return nullptr;
+  return reinterpret_cast<tm_knn_index *>(ix);
+}
+
+void tm_knn_index_destroy(tm_knn_index *ix) { knn_index_destroy(reinterpret_cast<tm_knn_index_impl *>(ix)); }
+
+int tm_knn_index_search(tm_knn_index *ix, const void *queries_i16, int64_t nq, void *out_idx, void *out_err, void *stream) {
+  return knn_index_search(reinterpret_cast<tm_knn_index_impl *>(ix), queries_i16, nq, out_idx, out_err, (hipStream_t)stream);
+}
+
+int tm_knn_index_last_stats(tm_knn_index *ix, double *kernel_ms, int *k_bytes, int64_t *pairs) {
+  TM_CHECK(ix != nullptr, TM_E_INVAL, "null index");
+  knn_index_stats(reinterpret_cast<tm_knn_index_impl *>(ix), kernel_ms, k_bytes, pairs);
+  return TM_OK;
+}
+
+int tm_stage_knn(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt, void *out_idx, void *out_err, void *stream) {
+  tm_knn_index_impl *ix = nullptr;
+  TM_TRY(knn_index_create(db_i16, nt, (hipStream_t)stream, &ix));
+  int rc = knn_index_search(ix, queries_i16, nq, out_idx, out_err, (hipStream_t)stream);
+  knn_index_destroy(ix);
+  return rc;
+}
+
+int tm_stage_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal,
+                    int pal_size, int use_thomas_knoll, int y2_mixed_colors, void *out_pal_px, void *stream) {
+  return launch_dither(tiles, flags, pal_idx, n, palettes, npal, pal_size, use_thomas_knoll, y2_mixed_colors, out_pal_px,
+                       (hipStream_t)stream);
+}
+
+}  // extern "C"

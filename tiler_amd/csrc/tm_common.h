@@ -1,0 +1,98 @@
+// tm_common.h -- shared host-side helpers of libtilemotion (error plumbing, device buffers, tables).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tilemotion.h"
+
+namespace tmx {
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define TM_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      tmx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);        \
+      return (e_ == hipErrorOutOfMemory) ? TM_E_NOMEM : TM_E_HIP;                                      \
+    }                                                                                                  \
+  } while (0)
+
+#define TM_CHECK(cond, code, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      tmx::set_error(__VA_ARGS__);        \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+#define TM_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != TM_OK) return rc_; \
+  } while (0)
+
+// Fails loudly when no gfx950 device can run the kernels (there is no CPU path).
+int require_device();
+
+// RAII device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(size_t n) {
+    if (n <= bytes && p) return TM_OK;
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+      return TM_E_NOMEM;
+    }
+    bytes = n;
+    return TM_OK;
+  }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Constant tables of the reference (utils.pas:47-109) + LUTs of InitLuts (tilingencoder.pas:1683-1727),
+// uploaded once per device.
+struct DeviceTables {
+  float *dct_lut_f32[2] = {nullptr, nullptr};   // FDCTLut[special][4096]
+  double *dct_lut_f64[2] = {nullptr, nullptr};  // FDCTLutDouble
+  double *weights = nullptr;                    // cDCTWeights [3][8][8]
+  float *srgb_lut = nullptr;                    // inverse sRGB of c/255, as Single
+  uint8_t *snake = nullptr;                     // cDCTSnake
+  uint8_t *dither_map = nullptr;                // cDitheringMap
+};
+int get_tables(const DeviceTables **out);
+
+extern const uint8_t kDitheringMap[64];
+extern const uint8_t kDCTSnake[64];
+extern const double kDCTWeights[3][8][8];
+
+inline bool mode_special(int mode) { return mode == TM_PVS_SPE_DCT || mode == TM_PVS_WEIGHTED_SPE_DCT; }
+inline bool mode_weighted(int mode) { return mode == TM_PVS_WEIGHTED_DCT || mode == TM_PVS_WEIGHTED_SPE_DCT; }
+
+}  // namespace tmx

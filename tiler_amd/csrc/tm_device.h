@@ -1,0 +1,61 @@
+// tm_device.h -- device-side colour math shared by the kernels.  Every operation is one IEEE op via the
+// *_rn intrinsics so hipcc can never fuse or reassociate it; see DESIGN.md "Arithmetic".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tmx {
+
+__device__ __forceinline__ uint32_t swap_rb(uint32_t c) {  // SwapRB, utils.pas:238-241 (alpha dropped)
+  return ((c & 0xff) << 16) | ((c >> 16) & 0xff) | (c & 0xff00);
+}
+
+// RGBToYUV, utils.pas:478-490.  Right-hand sides evaluate in double (constants are doubles), one narrowing
+// to Single per assignment.
+__device__ __forceinline__ void rgb_to_yuv(int r, int g, int b, float &y, float &u, float &v) {
+  const double yd = __dadd_rn(__dadd_rn(__dmul_rn((double)r, 299.0 / 1000.0), __dmul_rn((double)g, 587.0 / 1000.0)),
+                              __dmul_rn((double)b, 114.0 / 1000.0));
+  const float yy = (float)yd;
+  u = (float)__dmul_rn(__dsub_rn((double)b, (double)yy), 0.492);
+  v = (float)__dmul_rn(__dsub_rn((double)r, (double)yy), 0.877);
+  y = yy;
+}
+
+// +,-,*,/-only cube root (integer exponent/3 seed + 6 Newton steps): the build's stand-in for power(x, 1/3)
+// at utils.pas:403-405, bit-identical on host and device.
+__device__ __forceinline__ double cbrt_det(double x) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  u = u / 3ull + 0x2A9F7893782DA1CEull;
+  double y = __longlong_as_double((long long)u);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double y2 = __dmul_rn(y, y);
+    y = __dsub_rn(y, __ddiv_rn(__dsub_rn(__dmul_rn(y2, y), x), __dmul_rn(3.0, y2)));
+  }
+  return y;
+}
+
+__device__ __forceinline__ float lab_f(float t) {
+  if ((double)t > 0.008856) return (float)cbrt_det((double)t);
+  return (float)__dadd_rn(__dmul_rn(7.787, (double)t), 16.0 / 116);
+}
+
+// RGBToLAB, utils.pas:374-410, with the gamma expansion taken from the host-built 256-entry Single table.
+__device__ __forceinline__ void rgb_to_lab_det(int ir, int ig, int ib, const float *__restrict__ srgb_lut, float &ol, float &oa,
+                                               float &ob) {
+  const double r = (double)srgb_lut[ir], g = (double)srgb_lut[ig], b = (double)srgb_lut[ib];
+  float x = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.49000), __dmul_rn(g, 0.31000)), __dmul_rn(b, 0.20000)), 0.17697);
+  float y = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.17697), __dmul_rn(g, 0.81240)), __dmul_rn(b, 0.01063)), 0.17697);
+  float z = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.00000), __dmul_rn(g, 0.01000)), __dmul_rn(b, 0.99000)), 0.17697);
+  x = (float)__dmul_rn((double)x, 1 / (96.6797 / 100));
+  y = (float)__dmul_rn((double)y, 1 / (100.000 / 100));
+  z = (float)__dmul_rn((double)z, 1 / (82.5188 / 100));
+  x = lab_f(x);
+  y = lab_f(y);
+  z = lab_f(z);
+  ol = (float)__dsub_rn(__dmul_rn(116.0, (double)y), 16.0);
+  oa = (float)__dmul_rn(500.0, (double)__fsub_rn(x, y));
+  ob = (float)__dmul_rn(200.0, (double)__fsub_rn(y, z));
+}
+
+}  // namespace tmx

@@ -1,0 +1,136 @@
+// tm_dither.hip -- positional (ordered) dithering of global tiles, A12.
+//
+// Restates Dither (tilingencoder.pas:1873-1907) = PreparePlan (2268-2301) + DitherTile (2688-2724) +
+// DeviseBestMixingPlanThomasKnoll (2565-2612) + ColorCompare (2323-2337) + the byte QuickSort of extern.pas:370-418.
+// One wave (= one workgroup) per tile, one lane per pixel; every lane runs its own 64-step error-feedback plan and
+// then sorts its own 64 picks by luma with a literal emulation of the reference's unstable quicksort (explicit
+// stack, pivot value held constant because the reference tracks the pivot element through swaps), so equal-luma
+// picks land exactly where the reference puts them.  Integer only.  All values fit int32: |e| <= 64*255,
+// |t| <= 255 + 16320*9/100, penalty < 2^29 (the reference uses Int64).
+#include <algorithm>
+#include <climits>
+
+#include "tm_common.h"
+#include "tm_internal.h"
+
+namespace tmx {
+
+__device__ __forceinline__ int div_trunc_1000(int v) { return v / 1000; }  // Pascal div: toward zero, like C
+
+__global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
+                                                  const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
+                                                  int npal, int pal_size, const uint8_t *__restrict__ dither_map,
+                                                  uint8_t *__restrict__ out) {
+  __shared__ int4 s_plan[64];          // r, g, b, luma of live entries (Y2Palette / LumaPal)
+  __shared__ uint8_t s_rank[64];       // #entries with strictly smaller luma: order-isomorphic to LumaPal incl. ties
+  __shared__ uint8_t s_remap[64];      // Plan.Remap
+  __shared__ uint16_t s_list[64][64];  // [position][lane] = rank<<8 | plan index
+  __shared__ uint16_t s_stack[64][64]; // [depth][lane] = i<<8 | last
+  const int lane = threadIdx.x;
+  const int map_value = dither_map[lane];  // cDitheringMap[((y and 7) shl 3) or (x and 7)], natural orientation
+  int cached_pal = -1, cnt = 0;
+  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const int pi = pal_idx[t];
+    if (pi != cached_pal) {  // PreparePlan: drop cDitheringNullColor entries, keep order
+      __syncthreads();
+      int col = TM_NULL_COLOR;
+      if (lane < pal_size && pi >= 0 && pi < npal) col = palettes[(int64_t)pi * pal_size + lane];
+      const bool live = col != TM_NULL_COLOR;
+      const unsigned long long m = __ballot(live);
+      cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      const int r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
+      const int luma = r * 299 + g * 587 + b * 114;
+      if (live) {
+        s_plan[pos] = make_int4(r, g, b, luma);
+        s_remap[pos] = (uint8_t)lane;
+      }
+      __syncthreads();
+      if (lane < cnt) {
+        const int my = s_plan[lane].w;
+        int rk = 0;
+        for (int i = 0; i < cnt; i++) rk += (s_plan[i].w < my) ? 1 : 0;
+        s_rank[lane] = (uint8_t)rk;
+      }
+      __syncthreads();
+      cached_pal = pi;
+    }
+    if (cnt == 0) {  // a palette with no colours cannot own tiles in the reference (would divide by zero at 2589)
+      out[t * 64 + lane] = 0;
+      continue;
+    }
+    const int f = flags ? flags[t] : 0;
+    const int y = lane >> 3, x = lane & 7;
+    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // un-mirror (2696-2697)
+    const uint32_t c = tiles[t * 64 + src];
+    const int s0 = c & 0xff, s1 = (c >> 8) & 0xff, s2 = (c >> 16) & 0xff;
+    int e0 = 0, e1 = 0, e2 = 0;
+    for (int k = 0; k < 64; k++) {
+      const int t0 = s0 + (e0 * 9) / 100, t1 = s1 + (e1 * 9) / 100, t2 = s2 + (e2 * 9) / 100;
+      const int lt = t0 * 299 + t1 * 587 + t2 * 114;
+      int least = INT_MAX, chosen = 0;
+      for (int i = 0; i < cnt; i++) {
+        const int4 p = s_plan[i];
+        const int dr = t0 - p.x, dg = t1 - p.y, db = t2 - p.z;
+        const int ld = div_trunc_1000(lt - p.w);
+        const int pen = (dr * dr + dg * dg + db * db) * 13 + ((ld * ld) << 5);
+        if (pen < least) { least = pen; chosen = i; }
+      }
+      s_list[k][lane] = (uint16_t)((s_rank[chosen] << 8) | chosen);
+      const int4 p = s_plan[chosen];
+      e0 += s0 - p.x; e1 += s1 - p.y; e2 += s2 - p.z;
+    }
+    // QuickSort(List[0], 0, 63, 1, PlanCompareLuma) -- extern.pas:370-418, iterative form
+    {
+      int first = 0, last = 63, sp = 0;
+      while (true) {
+        int i = first, j = last;
+        const int pv = s_list[(first + last) >> 1][lane] >> 8;
+        do {
+          while ((s_list[i][lane] >> 8) < pv) i++;
+          while ((s_list[j][lane] >> 8) > pv) j--;
+          if (i <= j) {
+            const uint16_t a = s_list[i][lane], b = s_list[j][lane];
+            s_list[i][lane] = b;
+            s_list[j][lane] = a;
+            i++;
+            j--;
+          }
+        } while (i <= j);
+        if (first < j) {  // recurse left, remember (i, last) for the loop tail
+          s_stack[sp++][lane] = (uint16_t)((i << 8) | last);
+          last = j;
+          continue;
+        }
+        // first := i; until i >= last
+        bool done = false;
+        while (i >= last) {
+          if (sp == 0) { done = true; break; }
+          const uint16_t fr = s_stack[--sp][lane];
+          i = fr >> 8;
+          last = fr & 0xff;
+        }
+        if (done) break;
+        first = i;
+      }
+    }
+    const int pick = s_list[map_value][lane] & 0xff;
+    out[t * 64 + src] = s_remap[pick];  // re-mirror (2721-2722): natural (y,x) lives at canonical position src
+  }
+}
+
+int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,
+                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
+  TM_CHECK(use_tk, TM_E_UNSUPPORTED, "Yliluoma dithering is not built yet (DitheringUseThomasKnoll=0); see DESIGN.md");
+  if (n <= 0) return TM_OK;
+  int grid = (int)std::min<int64_t>(n, 256 * 40);
+  hipLaunchKernelGGL(k_dither_tk, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
+                     (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, tab->dither_map, (uint8_t *)out_pal_px);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+}  // namespace tmx

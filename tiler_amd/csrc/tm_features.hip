@@ -1,0 +1,264 @@
+// tm_features.hip -- load-side (A1-A3) and feature-extraction (A4-A6) kernels for gfx950.
+//
+// Bit-exactness rules (DESIGN.md "Arithmetic"): every floating-point step is a single IEEE +,-,*,/ issued through
+// the __f*_rn / __d*_rn intrinsics (never contracted into FMA), in the order the reference's code performs it
+// (DCTInner_asm, utils.pas:874-1035; RGBToYUV 478-490; RGBToLAB 374-410).  Transcendentals are replaced by host
+// built tables (sRGB gamma, cosines) or a +,-,*,/-only Newton cube root, so CPU and GPU agree to the bit.
+#include "tm_common.h"
+#include "tm_device.h"
+#include "tm_internal.h"
+
+namespace tmx {
+
+// ---------------------------------------------------------------------------------------------------------------
+// A1+A2+A3: one wave per tile, one lane per pixel.
+// LoadFromImage (tilingencoder.pas:1293-1320) -> PrepareInterFrameData (1329-1367) -> mirror heuristics
+// (4865-4878) + H/V flip (1393-1411).
+__global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__ frames, int nframes, int img_w, int img_h,
+                                                    int tm_w, int tm_h, const float *__restrict__ srgb_lut,
+                                                    uint32_t *__restrict__ tiles, uint8_t *__restrict__ flags,
+                                                    float *__restrict__ lab_means) {
+  __shared__ float s_lab[4][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tiles_per_frame = (int64_t)tm_w * tm_h;
+  const int64_t total = tiles_per_frame * nframes;
+  const int64_t nblk_iter = (total + 3) / 4;
+  for (int64_t it = blockIdx.x; it < nblk_iter; it += gridDim.x) {
+    const int64_t t = it * 4 + wave;
+    const bool valid = t < total;
+    uint32_t px = 0;
+    if (valid) {
+      const int64_t f = t / tiles_per_frame;
+      const int ti = (int)(t - f * tiles_per_frame);
+      const int sy = ti / tm_w, sx = ti - sy * tm_w;
+      const int j = sy * 8 + (lane >> 3), i = sx * 8 + (lane & 7);
+      if (j < img_h && i < img_w) px = swap_rb(frames[(f * img_h + j) * (int64_t)img_w + i]);
+      float l, a, b;
+      rgb_to_lab_det(px & 0xff, (px >> 8) & 0xff, (px >> 16) & 0xff, srgb_lut, l, a, b);
+      s_lab[wave][0][lane] = l;
+      s_lab[wave][1][lane] = a;
+      s_lab[wave][2][lane] = b;
+    }
+    __syncthreads();
+    if (valid) {
+      // Result[di+c] += lab, 64 Singles in raster order, then *= 1/64 (1349-1362): sequential on lanes 0..2
+      if (lane < 3) {
+        float s = 0.0f;
+        for (int p = 0; p < 64; p++) s = __fadd_rn(s, s_lab[wave][lane][p]);
+        lab_means[t * 3 + lane] = __fmul_rn(s, 1.0f / 64);
+      }
+      // quadrant luma sums (GetTileZoneSum, 4842-4863): integer, order free -> wave reduction
+      const int luma = (int)(px & 0xff) * 299 + (int)((px >> 8) & 0xff) * 587 + (int)((px >> 16) & 0xff) * 114;
+      const bool right = (lane & 4) != 0, bottom = (lane & 32) != 0;
+      int left_s = right ? 0 : luma, right_s = right ? luma : 0, top_s = bottom ? 0 : luma, bot_s = bottom ? luma : 0;
+      for (int o = 32; o > 0; o >>= 1) {
+        left_s += __shfl_xor(left_s, o);
+        right_s += __shfl_xor(right_s, o);
+        top_s += __shfl_xor(top_s, o);
+        bot_s += __shfl_xor(bot_s, o);
+      }
+      const bool hm = left_s < right_s;  // q00+q10 < q01+q11
+      const bool vm = top_s < bot_s;     // q00+q01 < q10+q11
+      const int y = lane >> 3, x = lane & 7;
+      const int src = ((vm ? 7 - y : y) << 3) | (hm ? 7 - x : x);
+      const uint32_t canon = __shfl(px, src);
+      tiles[t * 64 + lane] = canon;
+      if (lane == 0) flags[t] = (uint8_t)((hm ? 1 : 0) | (vm ? 2 : 0));
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A4+A5: int16[192] features.  One wave per tile; lane = DCT position (v,u) and holds its 64-entry LUT row in
+// registers; the 3x64 component planes live in LDS and are read as wave-wide broadcasts.
+template <bool FROM_PAL>
+__global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ pal_px,
+                                                      const int32_t *__restrict__ pal_idx, const int32_t *__restrict__ palettes,
+                                                      int pal_size, const uint8_t *__restrict__ mirror_flags, int64_t n,
+                                                      int weighted, int use_lab, const float *__restrict__ lut,
+                                                      const double *__restrict__ weights, const uint8_t *__restrict__ snake,
+                                                      const float *__restrict__ srgb_lut, int16_t *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_cpn[2][4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float l[64];
+#pragma unroll
+  for (int k = 0; k < 64; k += 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(lut + lane * 64 + k);
+    l[k] = v.x; l[k + 1] = v.y; l[k + 2] = v.z; l[k + 3] = v.w;
+  }
+  double w[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) w[c] = weights[c * 64 + lane];
+  const int zz = snake[lane];
+  const int64_t niter = (n + 3) / 4;
+  int buf = 0;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x, buf ^= 1) {
+    const int64_t t = it * 4 + wave;
+    const bool valid = t < n;
+    if (valid) {
+      const int f = mirror_flags ? mirror_flags[t] : 0;
+      const int y = lane >> 3, x = lane & 7;
+      const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // ConvertToCpnPixels 3080-3085 / 3093-3098
+      uint32_t col;
+      if (FROM_PAL)
+        col = (uint32_t)palettes[(int64_t)pal_idx[t] * pal_size + pal_px[t * 64 + src]];
+      else
+        col = tiles[t * 64 + src];
+      float yy, uu, vv;
+      if (use_lab)
+        rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
+      else
+        rgb_to_yuv(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, yy, uu, vv);
+      s_cpn[buf][wave][lane] = yy;
+      s_cpn[buf][wave][64 + lane] = uu;
+      s_cpn[buf][wave][128 + lane] = vv;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float *cp = &s_cpn[buf][wave][c * 64];
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; k += 16) {  // DCTInner_asm, one 16-element step (utils.pas:892-921)
+          float p[16];
+#pragma unroll
+          for (int q = 0; q < 16; q += 4) {
+            const float4 cv = *reinterpret_cast<const float4 *>(cp + k + q);
+            p[q] = __fmul_rn(cv.x, l[k + q]);
+            p[q + 1] = __fmul_rn(cv.y, l[k + q + 1]);
+            p[q + 2] = __fmul_rn(cv.z, l[k + q + 2]);
+            p[q + 3] = __fmul_rn(cv.w, l[k + q + 3]);
+          }
+          const float s0 = __fadd_rn(p[0], p[4]), s1 = __fadd_rn(p[1], p[5]), s2 = __fadd_rn(p[2], p[6]), s3 = __fadd_rn(p[3], p[7]);
+          const float t0 = __fadd_rn(p[8], p[12]), t1 = __fadd_rn(p[9], p[13]), t2 = __fadd_rn(p[10], p[14]), t3 = __fadd_rn(p[11], p[15]);
+          const double a0 = __dadd_rn(__dadd_rn((double)s0, (double)t0), __dadd_rn((double)s2, (double)t2));
+          const double a1 = __dadd_rn(__dadd_rn((double)s1, (double)t1), __dadd_rn((double)s3, (double)t3));
+          acc0 = __dadd_rn(acc0, a0);
+          acc1 = __dadd_rn(acc1, a1);
+        }
+        double z = __dadd_rn(acc0, acc1);
+        if (weighted) z = __dmul_rn(z, w[c]);
+        out[t * 192 + c * 64 + zz] = (int16_t)__double2ll_rn(z);  // Round(): half to even (3126)
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A6 as DoPalettization uses it (tilingencoder.pas:4126, 4160): UseLAB planes, double LUT, sequential double sum
+// (DCTInner<PDouble>, utils.pas:782-872), weight, then the build's Round() to int32 (DESIGN.md "k-means").
+__global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__restrict__ tiles, int64_t n, int weighted,
+                                                              const double *__restrict__ lut, const double *__restrict__ weights,
+                                                              const uint8_t *__restrict__ snake, const float *__restrict__ srgb_lut,
+                                                              int32_t *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_cpn[2][4][192];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double l[64];
+#pragma unroll
+  for (int k = 0; k < 64; k += 2) {
+    const double2 v = *reinterpret_cast<const double2 *>(lut + lane * 64 + k);
+    l[k] = v.x; l[k + 1] = v.y;
+  }
+  double w[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) w[c] = weights[c * 64 + lane];
+  const int zz = snake[lane];
+  const int64_t niter = (n + 3) / 4;
+  int buf = 0;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x, buf ^= 1) {
+    const int64_t t = it * 4 + wave;
+    const bool valid = t < n;
+    if (valid) {
+      const uint32_t col = tiles[t * 64 + lane];
+      float yy, uu, vv;
+      rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
+      s_cpn[buf][wave][lane] = yy;
+      s_cpn[buf][wave][64 + lane] = uu;
+      s_cpn[buf][wave][128 + lane] = vv;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float *cp = &s_cpn[buf][wave][c * 64];
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+          const float4 cv = *reinterpret_cast<const float4 *>(cp + k);
+          r = __dadd_rn(r, __dmul_rn((double)cv.x, l[k]));
+          r = __dadd_rn(r, __dmul_rn((double)cv.y, l[k + 1]));
+          r = __dadd_rn(r, __dmul_rn((double)cv.z, l[k + 2]));
+          r = __dadd_rn(r, __dmul_rn((double)cv.w, l[k + 3]));
+        }
+        if (weighted) r = __dmul_rn(r, w[c]);
+        out[t * 192 + c * 64 + zz] = (int32_t)__double2ll_rn(r);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int grid_for(int64_t work_items, int per_block) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  const int64_t cap = 256 * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
+                void *lab_means, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(nframes >= 0 && img_w > 0 && img_h > 0 && tm_w > 0 && tm_h > 0, TM_E_INVAL, "tm_stage_load: bad dimensions");
+  const int64_t total = (int64_t)nframes * tm_w * tm_h;
+  if (total == 0) return TM_OK;
+  hipLaunchKernelGGL(k_load_tiles, dim3(grid_for(total, 4)), dim3(256), 0, stream, (const uint32_t *)frames, nframes, img_w,
+                     img_h, tm_w, tm_h, tab->srgb_lut, (uint32_t *)tiles, (uint8_t *)flags, (float *)lab_means);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out,
+                        hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(mode != TM_PVS_WAVELETS, TM_E_UNSUPPORTED, "wavelet features on int16 vectors are unimplemented in the reference too (tilingencoder.pas:3111)");
+  TM_CHECK(mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_i16<false>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
+                     nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode,
+                        void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
+  TM_CHECK(pal_size >= 1 && pal_size <= 256, TM_E_INVAL, "bad palette size %d", pal_size);
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_i16<true>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
+                     (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_cluster_i32, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, n,
+                     mode_weighted(mode) ? 1 : 0, tab->dct_lut_f64[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut,
+                     (int32_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+}  // namespace tmx

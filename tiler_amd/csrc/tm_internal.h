@@ -1,0 +1,37 @@
+// tm_internal.h -- launcher prototypes shared between the kernel files, the stage ABI and the encoder.
+#pragma once
+#include "tm_common.h"
+
+namespace tmx {
+
+// tm_features.hip
+int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
+                void *lab_means, hipStream_t stream);
+int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out, hipStream_t stream);
+int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
+                        hipStream_t stream);
+int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
+
+// tm_knn.hip
+struct tm_knn_index_impl;
+int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_index_impl **out);
+void knn_index_destroy(tm_knn_index_impl *ix);
+int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream);
+void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs);
+
+// tm_dither.hip
+int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,
+                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream);
+
+// tm_dedup.hip
+int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+              int64_t *host_n_unique, hipStream_t stream);
+
+// tm_kmeans.hip
+int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,
+               int *host_iters, hipStream_t stream);
+int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
+                          hipStream_t stream);
+int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
+
+}  // namespace tmx

@@ -1,0 +1,124 @@
+// tm_tables.hip -- constant tables of the reference + LUT construction, error state, device check.
+#include <cmath>
+#include <mutex>
+
+#include "tm_common.h"
+
+namespace tmx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (%s); libtilemotion has no CPU path", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    return TM_E_NODEVICE;
+  }
+  return TM_OK;
+}
+
+// cDitheringMap, utils.pas:47-56
+const uint8_t kDitheringMap[64] = {0,  48, 12, 60, 3,  51, 15, 63, 32, 16, 44, 28, 35, 19, 47, 31, 8,  56, 4,  52, 11, 59,
+                                   7,  55, 40, 24, 36, 20, 43, 27, 39, 23, 2,  50, 14, 62, 1,  49, 13, 61, 34, 18, 46, 30,
+                                   33, 17, 45, 29, 10, 58, 6,  54, 9,  57, 5,  53, 42, 26, 38, 22, 41, 25, 37, 21};
+
+// cDCTSnake, utils.pas:59-68 (raster v*8+u -> zig-zag rank)
+const uint8_t kDCTSnake[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                               41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                               46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+// cDCTWeights, utils.pas:72-97 (Daala PSNR-HVS CSF, Y/U/V)
+const double kDCTWeights[3][8][8] = {
+    {{1.6193873005, 2.2901594831, 2.08509755623, 1.48366094411, 1.00227514334, 0.678296995242, 0.466224900598, 0.3265091542},
+     {2.2901594831, 1.94321815382, 2.04793073064, 1.68731108984, 1.2305666963, 0.868920337363, 0.61280991668, 0.436405793551},
+     {2.08509755623, 2.04793073064, 1.34329019223, 1.09205635862, 0.875748795257, 0.670882927016, 0.501731932449, 0.372504254596},
+     {1.48366094411, 1.68731108984, 1.09205635862, 0.772819797575, 0.605636379554, 0.48309405692, 0.380429446972, 0.295774038565},
+     {1.00227514334, 1.2305666963, 0.875748795257, 0.605636379554, 0.448996256676, 0.352889268808, 0.283006984131, 0.226951348204},
+     {0.678296995242, 0.868920337363, 0.670882927016, 0.48309405692, 0.352889268808, 0.27032073436, 0.215017739696, 0.17408067321},
+     {0.466224900598, 0.61280991668, 0.501731932449, 0.380429446972, 0.283006984131, 0.215017739696, 0.168869545842, 0.136153931001},
+     {0.3265091542, 0.436405793551, 0.372504254596, 0.295774038565, 0.226951348204, 0.17408067321, 0.136153931001, 0.109083846276}},
+    {{1.91113096927, 2.46074210438, 1.18284184739, 1.14982565193, 1.05017074788, 0.898018824055, 0.74725392039, 0.615105596242},
+     {2.46074210438, 1.58529308355, 1.21363250036, 1.38190029285, 1.33100189972, 1.17428548929, 0.996404342439, 0.830890433625},
+     {1.18284184739, 1.21363250036, 0.978712413627, 1.02624506078, 1.03145147362, 0.960060382087, 0.849823426169, 0.731221236837},
+     {1.14982565193, 1.38190029285, 1.02624506078, 0.861317501629, 0.801821139099, 0.751437590932, 0.685398513368, 0.608694761374},
+     {1.05017074788, 1.33100189972, 1.03145147362, 0.801821139099, 0.676555426187, 0.605503172737, 0.55002013668, 0.495804539034},
+     {0.898018824055, 1.17428548929, 0.960060382087, 0.751437590932, 0.605503172737, 0.514674450957, 0.454353482512, 0.407050308965},
+     {0.74725392039, 0.996404342439, 0.849823426169, 0.685398513368, 0.55002013668, 0.454353482512, 0.389234902883, 0.342353999733},
+     {0.615105596242, 0.830890433625, 0.731221236837, 0.608694761374, 0.495804539034, 0.407050308965, 0.342353999733, 0.295530605237}},
+    {{2.03871978502, 2.62502345193, 1.26180942886, 1.11019789803, 1.01397751469, 0.867069376285, 0.721500455585, 0.593906509971},
+     {2.62502345193, 1.69112867013, 1.17180569821, 1.3342742857, 1.28513006198, 1.13381474809, 0.962064122248, 0.802254508198},
+     {1.26180942886, 1.17180569821, 0.944981930573, 0.990876405848, 0.995903384143, 0.926972725286, 0.820534991409, 0.706020324706},
+     {1.11019789803, 1.3342742857, 0.990876405848, 0.831632933426, 0.77418706195, 0.725539939514, 0.661776842059, 0.587716619023},
+     {1.01397751469, 1.28513006198, 0.995903384143, 0.77418706195, 0.653238524286, 0.584635025748, 0.531064164893, 0.478717061273},
+     {0.867069376285, 1.13381474809, 0.926972725286, 0.725539939514, 0.584635025748, 0.496936637883, 0.438694579826, 0.393021669543},
+     {0.721500455585, 0.962064122248, 0.820534991409, 0.661776842059, 0.531064164893, 0.438694579826, 0.375820256136, 0.330555063063},
+     {0.593906509971, 0.802254508198, 0.706020324706, 0.587716619023, 0.478717061273, 0.393021669543, 0.330555063063, 0.285345396658}}};
+
+// cDCTUVRatio, utils.pas:100-109 (array of TFloat: the sqrt(0.5) entries are Singles)
+static float uv_ratio(int v, int u) {
+  if (v == 0 && u == 0) return 0.5f;
+  if (v == 0 || u == 0) return static_cast<float>(std::sqrt(0.5));
+  return 1.0f;
+}
+
+static std::mutex g_tab_mu;
+static DeviceTables g_tab[16];
+static bool g_tab_ready[16] = {false};
+
+template <class T> static int upload(T **dst, const T *src, size_t n) {
+  TM_HIP(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
+  TM_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return TM_OK;
+}
+
+int get_tables(const DeviceTables **out) {
+  TM_TRY(require_device());
+  int dev = 0;
+  TM_HIP(hipGetDevice(&dev));
+  TM_CHECK(dev >= 0 && dev < 16, TM_E_INVAL, "device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  if (!g_tab_ready[dev]) {
+    DeviceTables &t = g_tab[dev];
+    // InitLuts, tilingencoder.pas:1703-1714: index ((v*8+u)*8+y)*8+x, evaluated in double, stored also as Single
+    std::vector<double> l64(4096);
+    std::vector<float> l32(4096);
+    for (int special = 0; special < 2; special++) {
+      const double div = special ? 16.0 : 8.0;
+      int i = 0;
+      for (int v = 0; v < 8; v++)
+        for (int u = 0; u < 8; u++)
+          for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++, i++) {
+              double val = std::cos((x + 0.5) * u * M_PI / div) * std::cos((y + 0.5) * v * M_PI / div) * (double)uv_ratio(v, u);
+              l64[i] = val;
+              l32[i] = static_cast<float>(val);
+            }
+      TM_TRY(upload(&t.dct_lut_f64[special], l64.data(), 4096));
+      TM_TRY(upload(&t.dct_lut_f32[special], l32.data(), 4096));
+    }
+    TM_TRY(upload(&t.weights, &kDCTWeights[0][0][0], 192));
+    float srgb[256];  // utils.pas:378-384: r := ir/255.0 (Single); gamma expansion; stored back into a Single
+    for (int c = 0; c < 256; c++) {
+      float r = static_cast<float>(c / 255.0);
+      srgb[c] = ((double)r > 0.04045) ? static_cast<float>(std::pow(((double)r + 0.055) / 1.055, 2.4))
+                                      : static_cast<float>((double)r / 12.92);
+    }
+    TM_TRY(upload(&t.srgb_lut, srgb, 256));
+    TM_TRY(upload(&t.snake, kDCTSnake, 64));
+    TM_TRY(upload(&t.dither_map, kDitheringMap, 64));
+    g_tab_ready[dev] = true;
+  }
+  *out = &g_tab[dev];
+  return TM_OK;
+}
+
+}  // namespace tmx

@@ -1,0 +1,106 @@
+"""Stage-level host wrappers over the C ABI for torch device tensors (tm_stage_*, include/tilemotion.h).
+
+Each function names the reference routine it stands for; tensors must live on the current CUDA(HIP) device.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def load(frames, tm_w, tm_h):
+    """TFrame.LoadFromImage + PrepareInterFrameData + mirror canonicalisation (tilingencoder.pas:1293-1411).
+    frames: uint32-as-int32 [F][H][W] RGB32 -> (tiles int32 [F*tm_w*tm_h][64], flags uint8, lab_means float32 [.,3])"""
+    assert frames.is_cuda and frames.dtype == torch.int32 and frames.is_contiguous()
+    f, h, w = frames.shape
+    n = f * tm_w * tm_h
+    tiles = torch.empty((n, 64), dtype=torch.int32, device=frames.device)
+    flags = torch.empty((n,), dtype=torch.uint8, device=frames.device)
+    lab = torch.empty((n, 3), dtype=torch.float32, device=frames.device)
+    check(lib().tm_stage_load(_p(frames), f, w, h, tm_w, tm_h, _p(tiles), _p(flags), _p(lab), _stream()))
+    return tiles, flags, lab
+
+
+def features_rgb(tiles, mirror_flags=None, mode=1, use_lab=False):
+    """ConvertToCpnPixels + ComputeCpnPixelsPsyVisFeatures (tilingencoder.pas:3049-3131) -> int16 [n][192]"""
+    assert tiles.is_cuda and tiles.dtype == torch.int32 and tiles.is_contiguous()
+    n = tiles.shape[0]
+    out = torch.empty((n, 192), dtype=torch.int16, device=tiles.device)
+    check(lib().tm_stage_features_rgb(_p(tiles), n, _p(mirror_flags), mode, int(use_lab), _p(out), _stream()))
+    return out
+
+
+def features_pal(pal_px, pal_idx, palettes, mode=1):
+    """PrepareReconstruct.DoPsyV (tilingencoder.pas:4570-4583) -> int16 [n][192]"""
+    n = pal_px.shape[0]
+    out = torch.empty((n, 192), dtype=torch.int16, device=pal_px.device)
+    check(lib().tm_stage_features_pal(_p(pal_px), _p(pal_idx), n, _p(palettes), palettes.shape[1], mode, _p(out), _stream()))
+    return out
+
+
+def features_cluster(tiles, mode=4):
+    """ComputeTilePsyVisFeatures as DoPalettization calls it (tilingencoder.pas:4126), Round()ed -> int32 [n][192]"""
+    n = tiles.shape[0]
+    out = torch.empty((n, 192), dtype=torch.int32, device=tiles.device)
+    check(lib().tm_stage_features_cluster(_p(tiles), n, mode, _p(out), _stream()))
+    return out
+
+
+def knn(queries, db):
+    """ann_kdtree_short_search(eps=0) for every query (tilingencoder.pas:1547) -> (idx int32, err int32-as-uint32)"""
+    nq, nt = queries.shape[0], db.shape[0]
+    idx = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    err = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    check(lib().tm_stage_knn(_p(queries), nq, _p(db), nt, _p(idx), _p(err), _stream()))
+    return idx, err
+
+
+class KnnIndex:
+    """ann_kdtree_short_create analogue: the database is packed once and searched by many query batches."""
+
+    def __init__(self, db):
+        self.db = db  # borrowed for the index lifetime, like the reference's DS.Dataset (tilingencoder.pas:4600)
+        self.h = lib().tm_knn_index_create(_p(db), db.shape[0], _stream())
+        if not self.h:
+            check(-3)
+
+    def search(self, queries):
+        nq = queries.shape[0]
+        idx = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+        err = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+        check(lib().tm_knn_index_search(ctypes.c_void_p(self.h), _p(queries), nq, _p(idx), _p(err), _stream()))
+        return idx, err
+
+    def last_stats(self):
+        ms, kb, pairs = ctypes.c_double(), ctypes.c_int(), ctypes.c_int64()
+        check(lib().tm_knn_index_last_stats(ctypes.c_void_p(self.h), ctypes.byref(ms), ctypes.byref(kb), ctypes.byref(pairs)))
+        return ms.value, kb.value, pairs.value
+
+    def close(self):
+        if self.h:
+            lib().tm_knn_index_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dither(tiles, flags, pal_idx, palettes, use_thomas_knoll=True, y2_mixed=4):
+    """Dither = PreparePlan + DitherTile per tile (tilingencoder.pas:1873-1907) -> uint8 [n][64]"""
+    n = tiles.shape[0]
+    out = torch.empty((n, 64), dtype=torch.uint8, device=tiles.device)
+    check(lib().tm_stage_dither(_p(tiles), _p(flags), _p(pal_idx), n, _p(palettes), palettes.shape[0], palettes.shape[1],
+                                int(use_thomas_knoll), y2_mixed, _p(out), _stream()))
+    return out
