@@ -137,7 +137,7 @@ def test_dither_thomas_knoll(tiles_flags, oracle):
     tiles, flags = tiles[:120], flags[:120]
     rng = np.random.default_rng(11)
     palettes = rng.integers(0, 1 << 24, size=(4, 16), dtype=np.int32)
-    palettes[1, 5:] = -0xFF0001  # cDitheringNullColor $FFFF00FF as int32: short palette
+    palettes[1, 5:] = -65281  # cDitheringNullColor $FFFF00FF as int32: short palette
     palettes[2, 3] = palettes[2, 9]  # duplicate colour
     # two DIFFERENT colours with equal luma (299*15 - 587*9 + 114*7 = 0): the unstable-sort tie case of extern.pas:370
     r, g, b = 100, 120, 60
@@ -148,3 +148,63 @@ def test_dither_thomas_knoll(tiles_flags, oracle):
     exp = oracle.dither(tiles, flags, pal_idx, palettes, True)
     got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("kind", ["rgb", "pal"])
+def test_dedup_reindex(tiles_flags, oracle, kind):
+    from tiler_amd import stages
+    tiles, _ = tiles_flags
+    rng = np.random.default_rng(5)
+    if kind == "rgb":
+        rows = np.concatenate([tiles, tiles[::3], tiles[5:40]])  # planted duplicates
+        rows[-1, 63] ^= 0x80000000  # differs only in the last dword's top bit: unsigned compare matters
+        use = None
+    else:
+        rows = rng.integers(0, 4, size=(700, 64), dtype=np.uint8)
+        rows[:, :60] = 1  # long common prefix
+        rows[100:200] = rows[0:100]
+        rows[5, 0] = 200  # > 127: CompareByte is unsigned
+        use = rng.integers(0, 4, size=700).astype(np.uint32)  # zero-use rows must drop out (ReindexTiles packs UseCount>0)
+    nu, rep, order, use_out, remap = oracle.dedup(rows, use)
+    g_nu, g_remap, g_order, g_use = stages.dedup(_dev(rows), _dev(use) if use is not None else None)
+    assert g_nu == nu
+    assert np.array_equal(g_order.cpu().numpy().astype(np.int64), order)
+    assert np.array_equal(g_use.cpu().numpy().view(np.uint32), use_out)
+    assert np.array_equal(g_remap.cpu().numpy().astype(np.int64), remap)
+
+
+@pytest.mark.parametrize("n,d,k", [(500, 3, 16), (40, 3, 64), (300, 192, 8), (1, 3, 4), (2000, 192, 40)])
+def test_kmeans(oracle, n, d, k):
+    from tiler_amd import stages
+    rng = np.random.default_rng(n + d + k)
+    if d == 3:
+        pts = rng.integers(0, 256, size=(n, 3)).astype(np.int32)
+        if n > 10:
+            pts[n // 2:] = pts[: n - n // 2] // 8 * 8  # repeated colours -> fewer distinct points than k in the small case
+    else:
+        centres = rng.integers(-3000, 3000, size=(5, d))
+        pts = (centres[rng.integers(0, 5, size=n)] + rng.integers(-200, 200, size=(n, d))).astype(np.int32)
+    w = rng.integers(1, 50, size=n).astype(np.uint32)
+    kk, assign, cent, iters = oracle.kmeans(pts, w, k)
+    g_kk, g_assign, g_cent, g_iters = stages.kmeans(_dev(pts), _dev(w), k)
+    assert g_kk == kk and g_iters == iters
+    assert np.array_equal(g_assign.cpu().numpy(), assign)
+    assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64)), "centroids must match bit for bit"
+
+
+def test_quantize_and_palettize(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, _ = tiles_flags
+    tiles = tiles[:200]
+    rng = np.random.default_rng(9)
+    npal, pal_size = 5, 16
+    pal_idx = rng.integers(0, npal - 1, size=tiles.shape[0], dtype=np.int32)  # palette 4 owns no tile: all null colours
+    exp = np.stack([oracle.quantize_palette(tiles[pal_idx == p].ravel(), pal_size) for p in range(npal)])
+    got = stages.quantize_palettes(_dev(tiles), _dev(pal_idx), npal, pal_size).cpu().numpy()
+    assert np.array_equal(got, exp)
+    assert (got[4] == -65281).all()  # cDitheringNullColor
+    feat = oracle.features_cluster(tiles, 4)
+    use = rng.integers(1, 9, size=tiles.shape[0]).astype(np.uint32)
+    exp_idx = oracle.palettize(feat, use, 6)
+    got_idx = stages.palettize(_dev(feat), _dev(use), 6).cpu().numpy()
+    assert np.array_equal(got_idx, exp_idx)

@@ -67,4 +67,23 @@ int tm_stage_dither(const void *tiles, const void *flags, const void *pal_idx, i
                        (hipStream_t)stream);
 }
 
+int tm_stage_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+                   int64_t *host_n_unique, void *stream) {
+  return run_dedup(rows, n, row_bytes, use_in, remap, order, use_out, host_n_unique, (hipStream_t)stream);
+}
+
+int tm_stage_kmeans(const void *pts_i32, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids,
+                    int *host_k, int *host_iters, void *stream) {
+  return run_kmeans(pts_i32, weights, n, d, k, max_iter, assign, centroids, host_k, host_iters, (hipStream_t)stream);
+}
+
+int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter,
+                               void *out_palettes, void *stream) {
+  return run_quantize_palettes(tiles, pal_idx, n, npal, pal_size, max_iter, out_palettes, (hipStream_t)stream);
+}
+
+int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, void *stream) {
+  return run_palettize(feat_i32, use, n, npal, max_iter, out_pal_idx, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,163 @@
+// tm_dedup.hip -- exact tile deduplication + reindexing, A8/A16.
+//
+// MakeTilesUnique (tilingencoder.pas:4720-4781) sorts tile pointers by pixel content and merges equal runs
+// (MergeTiles 4783-4813: sum UseCount into the run's first tile); ReindexTiles (4626-4700) then packs the tiles that
+// are Active with UseCount > 0 and sorts them by UseCount descending, content ascending (CompareTileUseCountRev,
+// 584-599).  Content order is CompareDWord on the 64 RGB dwords (unsigned) or CompareByte on the 64 palette
+// indices (940-948).
+//
+// GPU form: one stable merge sort of row indices with a comparator that reads the rows (rocPRIM sort primitive;
+// the comparator, run detection, merge bookkeeping and ranking kernels are ours), run heads by neighbour compare,
+// integer atomics for the merged use counts (order free), then a stable radix sort on ~UseCount.  Representative
+// of a run = its lowest original index (the reference's choice among byte-identical tiles is implementation
+// defined).
+#include <cstring>
+
+#include <rocprim/device/device_merge_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+
+#include "tm_common.h"
+#include "tm_internal.h"
+
+namespace tmx {
+
+struct RowLess {
+  const uint32_t *rows;
+  int dwords;
+  int bytewise;  // CompareByte order: compare dwords big-endian
+  __device__ int cmp(uint32_t a, uint32_t b) const {
+    const uint4 *pa = reinterpret_cast<const uint4 *>(rows + (int64_t)a * dwords);
+    const uint4 *pb = reinterpret_cast<const uint4 *>(rows + (int64_t)b * dwords);
+    for (int i = 0; i < dwords / 4; i++) {
+      const uint4 x = pa[i], y = pb[i];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (xs[k] != ys[k]) {
+          const uint32_t u = bytewise ? __builtin_bswap32(xs[k]) : xs[k];
+          const uint32_t v = bytewise ? __builtin_bswap32(ys[k]) : ys[k];
+          return u < v ? -1 : 1;
+        }
+      }
+    }
+    return 0;
+  }
+  __device__ bool operator()(const uint32_t &a, const uint32_t &b) const { return cmp(a, b) < 0; }
+};
+
+__global__ void k_iota(uint32_t *p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
+}
+
+// head[i] = 1 when sorted[i] starts a run of equal rows; headpos[i] = i at heads else 0 (for a max-scan)
+__global__ void k_mark_heads(const uint32_t *__restrict__ sorted, int64_t n, RowLess less, uint32_t *__restrict__ head,
+                             uint32_t *__restrict__ headpos) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool h = (i == 0) || less.cmp(sorted[i - 1], sorted[i]) != 0;
+    head[i] = h ? 1u : 0u;
+    headpos[i] = h ? (uint32_t)i : 0u;
+  }
+}
+
+// rep[row] = first row of its run; use_rep[rep] += use_in[row]; uniq[rank of run] = rep (content order)
+__global__ void k_merge_runs(const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ headpos_scanned,
+                             const uint32_t *__restrict__ head_excl, const uint32_t *__restrict__ head, int64_t n,
+                             const uint32_t *__restrict__ use_in, uint32_t *__restrict__ rep, uint32_t *__restrict__ use_rep,
+                             uint32_t *__restrict__ uniq) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t row = sorted[i], r = sorted[headpos_scanned[i]];
+    rep[row] = r;
+    atomicAdd(&use_rep[r], use_in ? use_in[row] : 1u);
+    if (head[i]) uniq[head_excl[i]] = r;
+  }
+}
+
+__global__ void k_rank_keys(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep,
+                            uint32_t *__restrict__ key, unsigned long long *__restrict__ live_count) {
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t u = use_rep[uniq[i]];
+    key[i] = ~u;  // ascending ~use == descending use; zero-use rows (~0) sink to the end
+    local += u > 0 ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(live_count, local);
+}
+
+__global__ void k_scatter_pos(const uint32_t *__restrict__ order, int64_t nlive, const uint32_t *__restrict__ use_rep,
+                              int32_t *__restrict__ pos, uint32_t *__restrict__ use_out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nlive; i += (int64_t)gridDim.x * blockDim.x) {
+    pos[order[i]] = (int32_t)i;
+    use_out[i] = use_rep[order[i]];
+  }
+}
+
+__global__ void k_remap(const uint32_t *__restrict__ rep, const int32_t *__restrict__ pos, int64_t n, int32_t *__restrict__ remap) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) remap[i] = pos[rep[i]];
+}
+
+static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
+
+int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+              int64_t *host_n_unique, hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(row_bytes == 256 || row_bytes == 64, TM_E_INVAL, "dedup: row_bytes must be 256 (RGB) or 64 (palette indices)");
+  TM_CHECK(n >= 0 && n < (int64_t)1 << 31, TM_E_INVAL, "dedup: row count out of range");
+  if (host_n_unique) *host_n_unique = 0;
+  if (n == 0) return TM_OK;
+  RowLess less{(const uint32_t *)rows, row_bytes / 4, row_bytes == 64 ? 1 : 0};
+  DevBuf idx, sorted, head, headpos, hps, head_excl, rep, use_rep, uniq, key, key2, ord2, pos, tmp, cnt;
+  TM_TRY(idx.alloc(n * 4)); TM_TRY(sorted.alloc(n * 4)); TM_TRY(head.alloc(n * 4)); TM_TRY(headpos.alloc(n * 4));
+  TM_TRY(head_excl.alloc(n * 4)); TM_TRY(hps.alloc(n * 4)); TM_TRY(rep.alloc(n * 4)); TM_TRY(use_rep.alloc(n * 4)); TM_TRY(uniq.alloc(n * 4));
+  TM_TRY(key.alloc(n * 4)); TM_TRY(key2.alloc(n * 4)); TM_TRY(ord2.alloc(n * 4)); TM_TRY(pos.alloc(n * 4)); TM_TRY(cnt.alloc(16));
+  hipLaunchKernelGGL(k_iota, dim3(gridn(n)), dim3(256), 0, stream, idx.as<uint32_t>(), n);
+  size_t tb = 0;
+  TM_HIP(rocprim::merge_sort(nullptr, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+  TM_TRY(tmp.alloc(tb));
+  TM_HIP(rocprim::merge_sort(tmp.p, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+  hipLaunchKernelGGL(k_mark_heads, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), n, less, head.as<uint32_t>(),
+                     headpos.as<uint32_t>());
+  size_t tb2 = 0;
+  TM_HIP(rocprim::inclusive_scan(nullptr, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
+  size_t tb3 = 0;
+  TM_HIP(rocprim::exclusive_scan(nullptr, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+  TM_TRY(tmp.alloc(std::max(tb2, tb3)));
+  TM_HIP(rocprim::inclusive_scan(tmp.p, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
+  TM_HIP(rocprim::exclusive_scan(tmp.p, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+  TM_HIP(hipMemsetAsync(use_rep.p, 0, n * 4, stream));
+  hipLaunchKernelGGL(k_merge_runs, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), hps.as<uint32_t>(),
+                     head_excl.as<uint32_t>(), head.as<uint32_t>(), n, (const uint32_t *)use_in, rep.as<uint32_t>(),
+                     use_rep.as<uint32_t>(), uniq.as<uint32_t>());
+  // number of runs = head_excl[n-1] + head[n-1]
+  uint32_t last_excl = 0, last_head = 0;
+  TM_HIP(hipMemcpyAsync(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(&last_head, head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  const int64_t nu = (int64_t)last_excl + last_head;
+  TM_HIP(hipMemsetAsync(cnt.p, 0, 16, stream));
+  hipLaunchKernelGGL(k_rank_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(),
+                     key.as<uint32_t>(), cnt.as<unsigned long long>());
+  size_t tb4 = 0;
+  TM_HIP(rocprim::radix_sort_pairs(nullptr, tb4, key.as<uint32_t>(), key2.as<uint32_t>(), uniq.as<uint32_t>(), ord2.as<uint32_t>(),
+                                   (size_t)nu, 0, 32, stream));
+  TM_TRY(tmp.alloc(tb4));
+  TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb4, key.as<uint32_t>(), key2.as<uint32_t>(), uniq.as<uint32_t>(), ord2.as<uint32_t>(),
+                                   (size_t)nu, 0, 32, stream));
+  unsigned long long live = 0;
+  TM_HIP(hipMemcpyAsync(&live, cnt.p, 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  TM_HIP(hipMemsetAsync(pos.p, 0xff, n * 4, stream));
+  hipLaunchKernelGGL(k_scatter_pos, dim3(gridn((int64_t)live)), dim3(256), 0, stream, ord2.as<uint32_t>(), (int64_t)live,
+                     use_rep.as<uint32_t>(), pos.as<int32_t>(), (uint32_t *)use_out);
+  hipLaunchKernelGGL(k_remap, dim3(gridn(n)), dim3(256), 0, stream, rep.as<uint32_t>(), pos.as<int32_t>(), n, (int32_t *)remap);
+  TM_HIP(hipMemcpyAsync(order, ord2.p, (size_t)live * 4, hipMemcpyDeviceToDevice, stream));
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(stream));  // the scratch DevBufs die with this frame
+  if (host_n_unique) *host_n_unique = (int64_t)live;
+  return TM_OK;
+}
+
+}  // namespace tmx

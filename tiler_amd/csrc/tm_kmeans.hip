@@ -1,0 +1,519 @@
+// tm_kmeans.hip -- the build's deterministic k-means, A9/A10 (replaces BICO.dll + ANN.dll + yakmo.dll; the DLLs'
+// RNG/tie behaviour is not recoverable, SURVEY.md section 8c, so the algorithm below IS the specification and the
+// oracle (oracle/tm_oracle.c: tmo_kmeans_i32) states the same thing for the CPU):
+//   * points are int32 vectors with uint32 weights, grouped in contiguous segments (one independent problem each);
+//   * init = farthest-first from the segment's first point, exact int64 distances, ties -> lowest index
+//     (cf. TKModes.InitFarthestFirst, kmodes.pas:694); stops early when no distinct point is left;
+//   * Lloyd: distance = sum over dimensions in order of (p - c)^2 in IEEE double (no FMA), ties -> lowest centroid;
+//     centroid = exact integer weighted sum / weight (one IEEE division); empty clusters keep their centroid;
+//     stop when no assignment changes or after max_iter (cYakmoMaxIterations = 300, utils.pas:17).
+// Integer sums are order independent, so the parallel reduction is bit-reproducible.
+//
+// Callers: tm_stage_kmeans (one segment), run_palettize (DoPalettization, tilingencoder.pas:4105-4245, D = 192) and
+// run_quantize_palettes (QuantizeUsingYakmo + DoQuantization, 4434-4564, D = 3, one segment per palette, run on the
+// (G,R,B)-sorted colour histogram of each palette's pixels).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <vector>
+
+#include "tm_common.h"
+#include "tm_internal.h"
+
+namespace tmx {
+
+typedef unsigned long long u64;
+
+struct Seg {      // per segment state, device resident
+  int64_t begin;  // first point
+  int64_t count;  // number of points
+  int kk;         // live centroids so far
+  int init_done;
+  int64_t cur;    // point index chosen as the newest centroid
+  int changed;
+  int pad;
+};
+
+// ---- farthest-first ------------------------------------------------------------------------------------------
+// best key: larger mindist wins, then lower index.  mindist can reach 2^38 (D=192), indices 2^31: two words.
+struct BestKey { long long dist; long long negidx; };
+__device__ __forceinline__ bool better(const BestKey &a, const BestKey &b) {
+  return a.dist > b.dist || (a.dist == b.dist && a.negidx > b.negidx);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_ff_update(const int32_t *__restrict__ pts, Seg *__restrict__ segs, int k,
+                                                   long long *__restrict__ mind, BestKey *__restrict__ partial) {
+  __shared__ BestKey s_best[4];
+  const int seg = blockIdx.y;
+  const Seg sg = segs[seg];
+  BestKey mine{0, LLONG_MIN};
+  if (!sg.init_done && sg.kk <= k) {
+    int32_t c[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) c[j] = pts[sg.cur * D + j];  // wave-uniform: scalar loads
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+      const int32_t *p = pts + (sg.begin + i) * D;
+      long long d = 0;
+#pragma unroll
+      for (int j = 0; j < D; j++) { const long long t = (long long)p[j] - c[j]; d += t * t; }
+      long long m = mind[sg.begin + i];
+      if (d < m) { m = d; mind[sg.begin + i] = m; }
+      const BestKey cand{m, -(long long)i};
+      if (better(cand, mine)) mine = cand;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    BestKey other{__shfl_xor(mine.dist, o), __shfl_xor(mine.negidx, o)};
+    if (better(other, mine)) mine = other;
+  }
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      if (better(s_best[w], mine)) mine = s_best[w];
+    partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+  }
+}
+
+// D=192 variant: the centre row does not fit registers as scalars cheaply; read it through LDS.
+__global__ __launch_bounds__(256) void k_ff_update_wide(const int32_t *__restrict__ pts, int d, Seg *__restrict__ segs, int k,
+                                                        long long *__restrict__ mind, BestKey *__restrict__ partial) {
+  __shared__ BestKey s_best[4];
+  __shared__ int32_t s_c[256];
+  const int seg = blockIdx.y;
+  const Seg sg = segs[seg];
+  BestKey mine{0, LLONG_MIN};
+  const bool active = !sg.init_done && sg.kk <= k;
+  if (active)
+    for (int j = threadIdx.x; j < d; j += 256) s_c[j] = pts[sg.cur * d + j];
+  __syncthreads();
+  if (active) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+      const int4 *p = reinterpret_cast<const int4 *>(pts + (sg.begin + i) * d);
+      long long dd = 0;
+      for (int j = 0; j < d / 4; j++) {
+        const int4 v = p[j];
+        const long long t0 = (long long)v.x - s_c[4 * j], t1 = (long long)v.y - s_c[4 * j + 1];
+        const long long t2 = (long long)v.z - s_c[4 * j + 2], t3 = (long long)v.w - s_c[4 * j + 3];
+        dd += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+      }
+      long long m = mind[sg.begin + i];
+      if (dd < m) { m = dd; mind[sg.begin + i] = m; }
+      const BestKey cand{m, -(long long)i};
+      if (better(cand, mine)) mine = cand;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    BestKey other{__shfl_xor(mine.dist, o), __shfl_xor(mine.negidx, o)};
+    if (better(other, mine)) mine = other;
+  }
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      if (better(s_best[w], mine)) mine = s_best[w];
+    partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+  }
+}
+
+// one thread per segment: fold block partials, append the next centre (or finish)
+__global__ void k_ff_pick(Seg *__restrict__ segs, int nseg, int k, const BestKey *__restrict__ partial, int nblk,
+                          const int32_t *__restrict__ pts, int d, double *__restrict__ cent) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  Seg sg = segs[seg];
+  if (sg.init_done) return;
+  BestKey best{0, LLONG_MIN};
+  for (int b = 0; b < nblk; b++) {
+    const BestKey c = partial[(int64_t)seg * nblk + b];
+    if (better(c, best)) best = c;
+  }
+  if (sg.kk >= k || best.dist <= 0) {  // enough centres, or no distinct point left
+    sg.init_done = 1;
+  } else {
+    sg.cur = sg.begin + (-best.negidx);
+    for (int j = 0; j < d; j++) cent[((int64_t)seg * k + sg.kk) * d + j] = (double)pts[sg.cur * d + j];
+    sg.kk++;
+  }
+  segs[seg] = sg;
+}
+
+__global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_t *__restrict__ pts, int d, double *__restrict__ cent) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  Seg sg = segs[seg];
+  sg.kk = 0;
+  sg.init_done = 0;
+  sg.changed = 0;
+  if (sg.count <= 0 || k <= 0) {
+    sg.init_done = 1;
+  } else {
+    sg.cur = sg.begin;
+    for (int j = 0; j < d; j++) cent[((int64_t)seg * k) * d + j] = (double)pts[sg.cur * d + j];
+    sg.kk = 1;
+  }
+  segs[seg] = sg;
+}
+
+// ---- Lloyd ---------------------------------------------------------------------------------------------------
+constexpr int KCH = 32;  // centroids scored per pass (register accumulators)
+
+template <int D>
+__global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, Seg *__restrict__ segs, int k,
+                                                const double *__restrict__ cent, int32_t *__restrict__ assign) {
+  extern __shared__ double s_cent[];  // [KCH][D]
+  const int seg = blockIdx.y;
+  const Seg sg = segs[seg];
+  const int kk = sg.kk;
+  int changed = 0;
+  const int64_t iters = (sg.count + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  for (int64_t it = 0; it < iters; it++) {
+    const int64_t i = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const bool valid = i < sg.count;
+    double bd = 0.0;
+    int bc = -1;
+    for (int c0 = 0; c0 < kk; c0 += KCH) {
+      const int nc = min(KCH, kk - c0);
+      __syncthreads();
+      for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
+      __syncthreads();
+      if (valid) {
+        double s[KCH];
+#pragma unroll
+        for (int c = 0; c < KCH; c++) s[c] = 0.0;
+        const int32_t *p = pts + (sg.begin + i) * D;
+        for (int j = 0; j < D; j++) {
+          const double pj = (double)p[j];
+#pragma unroll
+          for (int c = 0; c < KCH; c++) {
+            if (c < nc) {
+              const double t = __dsub_rn(pj, s_cent[c * D + j]);
+              s[c] = __dadd_rn(s[c], __dmul_rn(t, t));
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < KCH; c++)
+          if (c < nc && (bc < 0 || s[c] < bd)) { bd = s[c]; bc = c0 + c; }
+      }
+    }
+    if (valid) {
+      if (assign[sg.begin + i] != bc) { assign[sg.begin + i] = bc; changed++; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
+  if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&segs[seg].changed, changed);
+}
+
+// exact integer weighted sums: LDS partials per workgroup for up to KCH_ACC clusters x D, flushed with global atomics
+template <int D>
+__global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w,
+                                                    const Seg *__restrict__ segs, int k, const int32_t *__restrict__ assign,
+                                                    u64 *__restrict__ sums, u64 *__restrict__ cnts) {
+  extern __shared__ u64 s_acc[];  // [kk][D+1] when it fits, else straight to global
+  const int seg = blockIdx.y;
+  const Seg sg = segs[seg];
+  const int kk = sg.kk;
+  const bool use_lds = (size_t)kk * (D + 1) * 8 <= 64 * 1024;
+  if (use_lds) {
+    for (int e = threadIdx.x; e < kk * (D + 1); e += 256) s_acc[e] = 0;
+    __syncthreads();
+  }
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+    const int c = assign[sg.begin + i];
+    const long long wi = w ? (long long)w[sg.begin + i] : 1;
+    const int32_t *p = pts + (sg.begin + i) * D;
+    if (use_lds) {
+      atomicAdd(&s_acc[c * (D + 1) + D], (u64)wi);
+      for (int j = 0; j < D; j++) atomicAdd(&s_acc[c * (D + 1) + j], (u64)(wi * p[j]));
+    } else {
+      atomicAdd(&cnts[(int64_t)seg * k + c], (u64)wi);
+      for (int j = 0; j < D; j++) atomicAdd(&sums[((int64_t)seg * k + c) * D + j], (u64)(wi * p[j]));
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < kk * (D + 1); e += 256) {
+      const u64 v = s_acc[e];
+      if (v == 0) continue;
+      const int c = e / (D + 1), j = e - c * (D + 1);
+      if (j == D) atomicAdd(&cnts[(int64_t)seg * k + c], v);
+      else atomicAdd(&sums[((int64_t)seg * k + c) * D + j], v);
+    }
+  }
+}
+
+// centroid = sum / weight where weight > 0; resets sums; latches per-segment convergence into *any_changed
+__global__ void k_update(Seg *__restrict__ segs, int nseg, int k, int d, u64 *__restrict__ sums, u64 *__restrict__ cnts,
+                         double *__restrict__ cent, int *__restrict__ any_changed) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)nseg * k * d;
+  if (e < total) {
+    const int64_t sc = e / d;
+    const int seg = (int)(sc / k);
+    const u64 cn = cnts[sc];
+    if (segs[seg].changed && cn > 0) cent[e] = __ddiv_rn((double)(long long)sums[e], (double)(long long)cn);
+    sums[e] = 0;
+  }
+}
+__global__ void k_update_finish(Seg *__restrict__ segs, int nseg, int k, u64 *__restrict__ cnts, int *__restrict__ any_changed) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg < nseg) {
+    if (segs[seg].changed) atomicOr(any_changed, 1);
+    segs[seg].changed = 0;
+    for (int c = 0; c < k; c++) cnts[(int64_t)seg * k + c] = 0;
+  }
+}
+
+// ---- driver ----------------------------------------------------------------------------------------------------
+// Batched k-means over nseg contiguous segments.  seg_begin/seg_count are host arrays.  Outputs assign (global point
+// order), cent [nseg][k][d], host_kk[nseg] live centroid counts.
+static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const std::vector<int64_t> &seg_begin,
+                          const std::vector<int64_t> &seg_count, int k, int max_iter, int32_t *assign, double *cent,
+                          std::vector<int> *host_kk, int *host_iters, hipStream_t stream) {
+  TM_CHECK(d == 3 || d == 192, TM_E_INVAL, "kmeans: only d = 3 (pixels) or 192 (tile features) are built");
+  TM_CHECK(k >= 1 && k <= 65536, TM_E_INVAL, "kmeans: k out of range");
+  const int nseg = (int)seg_begin.size();
+  if (host_iters) *host_iters = 0;
+  if (nseg == 0) return TM_OK;
+  int64_t n = 0, maxcount = 0;
+  for (int s = 0; s < nseg; s++) { n = std::max(n, seg_begin[s] + seg_count[s]); maxcount = std::max(maxcount, seg_count[s]); }
+  std::vector<Seg> hs(nseg);
+  for (int s = 0; s < nseg; s++) { memset(&hs[s], 0, sizeof(Seg)); hs[s].begin = seg_begin[s]; hs[s].count = seg_count[s]; }
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((maxcount + 255) / 256, nseg >= 8 ? 64 : 512));
+  DevBuf dsegs, mind, partial, sums, cnts, flag;
+  TM_TRY(dsegs.alloc(sizeof(Seg) * nseg));
+  TM_TRY(mind.alloc(std::max<int64_t>(n, 1) * 8));
+  TM_TRY(partial.alloc(sizeof(BestKey) * (size_t)nseg * nblk));
+  TM_TRY(sums.alloc((size_t)nseg * k * d * 8));
+  TM_TRY(cnts.alloc((size_t)nseg * k * 8));
+  TM_TRY(flag.alloc(4));
+  TM_HIP(hipMemcpyAsync(dsegs.p, hs.data(), sizeof(Seg) * nseg, hipMemcpyHostToDevice, stream));
+  TM_HIP(hipMemsetAsync(mind.p, 0x7f, std::max<int64_t>(n, 1) * 8, stream));  // 0x7f7f... ~ 9.2e18 > any distance
+  TM_HIP(hipMemsetAsync(sums.p, 0, (size_t)nseg * k * d * 8, stream));
+  TM_HIP(hipMemsetAsync(cnts.p, 0, (size_t)nseg * k * 8, stream));
+  TM_HIP(hipMemsetAsync(assign, 0xff, std::max<int64_t>(n, 1) * 4, stream));
+  TM_HIP(hipMemsetAsync(cent, 0, (size_t)nseg * k * d * 8, stream));
+  Seg *ds = dsegs.as<Seg>();
+  const int sg_grid = (nseg + 63) / 64;
+  hipLaunchKernelGGL(k_ff_first, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, pts, d, cent);
+  for (int c = 1; c < k; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
+    if (d == 3)
+      hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk, nseg), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
+    else
+      hipLaunchKernelGGL(k_ff_update_wide, dim3(nblk, nseg), dim3(256), 0, stream, pts, d, ds, k, mind.as<long long>(), partial.as<BestKey>());
+    hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
+  }
+  TM_HIP(hipGetLastError());
+  const size_t lds_assign = (size_t)KCH * d * 8;
+  const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
+  int it = 0;
+  for (; it < max_iter; it++) {
+    if (d == 3) {
+      hipLaunchKernelGGL(k_assign<3>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
+      hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+    } else {
+      hipLaunchKernelGGL(k_assign<192>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
+      hipLaunchKernelGGL(k_accumulate<192>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+    }
+    TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    const int64_t total = (int64_t)nseg * k * d;
+    hipLaunchKernelGGL(k_update, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, flag.as<int>());
+    hipLaunchKernelGGL(k_update_finish, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, cnts.as<u64>(), flag.as<int>());
+    int any = 0;
+    TM_HIP(hipMemcpyAsync(&any, flag.p, 4, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    if (!any) break;
+  }
+  TM_HIP(hipGetLastError());
+  if (host_iters) *host_iters = it;
+  TM_HIP(hipMemcpyAsync(hs.data(), dsegs.p, sizeof(Seg) * nseg, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  if (host_kk) {
+    host_kk->resize(nseg);
+    for (int s = 0; s < nseg; s++) (*host_kk)[s] = hs[s].kk;
+  }
+  return TM_OK;
+}
+
+int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,
+               int *host_iters, hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(n >= 0, TM_E_INVAL, "kmeans: negative point count");
+  if (host_k) *host_k = 0;
+  if (host_iters) *host_iters = 0;
+  if (n == 0) return TM_OK;
+  std::vector<int64_t> b{0}, c{n};
+  std::vector<int> kk;
+  TM_TRY(kmeans_batched((const int32_t *)pts, (const uint32_t *)weights, d, b, c, k, max_iter, (int32_t *)assign, (double *)centroids,
+                        &kk, host_iters, stream));
+  if (host_k) *host_k = kk[0];
+  return TM_OK;
+}
+
+// ---- DoPalettization -------------------------------------------------------------------------------------------
+__global__ void k_count_assign(const int32_t *__restrict__ assign, int64_t n, u64 *__restrict__ cnt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&cnt[assign[i]], 1ull);
+}
+__global__ void k_apply_lut(const int32_t *__restrict__ assign, int64_t n, const int32_t *__restrict__ lut, int32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = lut[assign[i]];
+}
+
+int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536 (tilingencoder.pas:2959)", npal);
+  if (n <= 0) return TM_OK;
+  DevBuf assign, cent, cnt, lut;
+  TM_TRY(assign.alloc(n * 4));
+  TM_TRY(cent.alloc((size_t)npal * 192 * 8));
+  TM_TRY(cnt.alloc((size_t)npal * 8));
+  TM_TRY(lut.alloc((size_t)npal * 4));
+  int kk = 0, iters = 0;
+  TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
+  // palettes ranked by number of tiles, descending (tilingencoder.pas:4229-4234); ties keep the initial order
+  TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)npal * 8, stream));
+  hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, assign.as<int32_t>(), n,
+                     cnt.as<u64>());
+  std::vector<u64> hc(npal);
+  TM_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)npal * 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  std::vector<int> ord(npal), hl(npal);
+  for (int i = 0; i < npal; i++) ord[i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hc[a] > hc[b]; });
+  for (int i = 0; i < npal; i++) hl[ord[i]] = i;
+  TM_HIP(hipMemcpyAsync(lut.p, hl.data(), (size_t)npal * 4, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_apply_lut, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, assign.as<int32_t>(), n,
+                     lut.as<int32_t>(), (int32_t *)out_pal_idx);
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(stream));
+  return TM_OK;
+}
+
+// ---- QuantizeUsingYakmo + DoQuantization -----------------------------------------------------------------------
+// pixel key = palette << 24 | G << 16 | R << 8 | B  (CompareDSPixel: G, then R, then B; tilingencoder.pas:1046-1056)
+__global__ void k_pixel_keys(const uint32_t *__restrict__ tiles, const int32_t *__restrict__ pal_idx, int64_t n, u64 *__restrict__ keys) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * 64; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = tiles[i];
+    const u64 p = (u64)(uint32_t)pal_idx[i >> 6];
+    keys[i] = (p << 24) | ((u64)((c >> 8) & 0xff) << 16) | ((u64)(c & 0xff) << 8) | (u64)((c >> 16) & 0xff);
+  }
+}
+__global__ void k_unpack_colours(const u64 *__restrict__ ukeys, int64_t nu, int32_t *__restrict__ pts) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+    const u64 kx = ukeys[i];
+    pts[i * 3 + 0] = (int32_t)((kx >> 8) & 0xff);   // R
+    pts[i * 3 + 1] = (int32_t)((kx >> 16) & 0xff);  // G
+    pts[i * 3 + 2] = (int32_t)(kx & 0xff);          // B
+  }
+}
+
+static int muldiv_win(int a, int b, int c) {  // Windows MulDiv: round half away from zero
+  long long p = (long long)a * b, q = p >= 0 ? p : -p, cc = c >= 0 ? c : -c;
+  long long r = (q + cc / 2) / cc;
+  return (int)(((p < 0) != (c < 0)) ? -r : r);
+}
+static void rgb_to_hsv_bytes(int rr, int gg, int bb, int &h, int &s, int &v) {  // RGBToHSV, utils.pas:278-325
+  int mx = std::max(rr, std::max(gg, bb)), mn = std::min(rr, std::min(gg, bb));
+  int hh = 0, ss = 0, ll = mx;
+  if (ll != mn) {
+    const int delta = ll - mn;
+    ss = muldiv_win(delta, 255, ll);
+    if (rr == ll) hh = muldiv_win(42, gg - bb, delta);
+    else if (gg == ll) hh = muldiv_win(42, bb - rr, delta) + 84;
+    else if (bb == ll) hh = muldiv_win(42, rr - gg, delta) + 168;
+    hh = hh % 252;
+  }
+  h = hh & 0xff; s = ss & 0xff; v = ll & 0xff;
+}
+
+int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
+                          hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536", npal);
+  TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
+  std::vector<int32_t> hpal((size_t)npal * pal_size, TM_NULL_COLOR);  // unused slots: cDitheringNullColor (4557-4558)
+  if (n > 0) {
+    const int64_t npx = n * 64;
+    DevBuf keys, keys2, ukeys, ucnt, nruns, tmp, pts, assign, cent;
+    TM_TRY(keys.alloc(npx * 8)); TM_TRY(keys2.alloc(npx * 8)); TM_TRY(ukeys.alloc(npx * 8)); TM_TRY(ucnt.alloc(npx * 4));
+    TM_TRY(nruns.alloc(8));
+    hipLaunchKernelGGL(k_pixel_keys, dim3((int)std::min<int64_t>((npx + 255) / 256, 4096)), dim3(256), 0, stream, (const uint32_t *)tiles,
+                       (const int32_t *)pal_idx, n, keys.as<u64>());
+    size_t tb = 0;
+    TM_HIP(rocprim::radix_sort_keys(nullptr, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, 41, stream));
+    TM_TRY(tmp.alloc(tb));
+    TM_HIP(rocprim::radix_sort_keys(tmp.p, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, 41, stream));
+    size_t tb2 = 0;
+    TM_HIP(rocprim::run_length_encode(nullptr, tb2, keys2.as<u64>(), (unsigned int)npx, ukeys.as<u64>(), ucnt.as<uint32_t>(),
+                                      nruns.as<unsigned int>(), stream));
+    TM_TRY(tmp.alloc(tb2));
+    TM_HIP(rocprim::run_length_encode(tmp.p, tb2, keys2.as<u64>(), (unsigned int)npx, ukeys.as<u64>(), ucnt.as<uint32_t>(),
+                                      nruns.as<unsigned int>(), stream));
+    unsigned int nu = 0;
+    TM_HIP(hipMemcpyAsync(&nu, nruns.p, 4, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    // segment boundaries per palette: binary search on the host copy of the unique keys' palette field
+    std::vector<u64> hk(nu);
+    TM_HIP(hipMemcpyAsync(hk.data(), ukeys.p, (size_t)nu * 8, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    std::vector<int64_t> sb(npal, 0), sc(npal, 0);
+    {
+      int64_t i = 0;
+      for (int p = 0; p < npal; p++) {
+        sb[p] = i;
+        while (i < (int64_t)nu && (int)(hk[i] >> 24) == p) i++;
+        sc[p] = i - sb[p];
+      }
+      TM_CHECK(i == (int64_t)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
+    }
+    TM_TRY(pts.alloc((size_t)std::max<unsigned>(nu, 1) * 12));
+    TM_TRY(assign.alloc((size_t)std::max<unsigned>(nu, 1) * 4));
+    TM_TRY(cent.alloc((size_t)npal * pal_size * 3 * 8));
+    hipLaunchKernelGGL(k_unpack_colours, dim3((int)std::min<int64_t>(((int64_t)nu + 255) / 256, 4096)), dim3(256), 0, stream,
+                       ukeys.as<u64>(), (int64_t)nu, pts.as<int32_t>());
+    std::vector<int> kk;
+    int iters = 0;
+    TM_TRY(kmeans_batched(pts.as<int32_t>(), ucnt.as<uint32_t>(), 3, sb, sc, pal_size, max_iter, assign.as<int32_t>(), cent.as<double>(),
+                          &kk, &iters, stream));
+    std::vector<double> hc((size_t)npal * pal_size * 3);
+    TM_HIP(hipMemcpyAsync(hc.data(), cent.p, hc.size() * 8, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    // host tail (P x PaletteSize colours): Round, clamp, Posterize(.,255) = identity, sort by (Val, Sat, Hue)
+    // -- tilingencoder.pas:4513-4558, utils.pas:526-534, 741-748
+    struct Item { int v, s, h, r, g, b, idx; };
+    for (int p = 0; p < npal; p++) {
+      std::vector<Item> items;
+      for (int i = 0; i < kk[p]; i++) {
+        const double *c = &hc[((size_t)p * pal_size + i) * 3];
+        Item it;
+        it.r = (int)std::min<long long>(255, std::max<long long>(0, llrint(c[0])));
+        it.g = (int)std::min<long long>(255, std::max<long long>(0, llrint(c[1])));
+        it.b = (int)std::min<long long>(255, std::max<long long>(0, llrint(c[2])));
+        it.idx = i;
+        rgb_to_hsv_bytes(it.r, it.g, it.b, it.h, it.s, it.v);
+        items.push_back(it);
+      }
+      std::sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+        if (a.v != b.v) return a.v < b.v;
+        if (a.s != b.s) return a.s < b.s;
+        if (a.h != b.h) return a.h < b.h;
+        if (a.r != b.r) return a.r < b.r;
+        if (a.g != b.g) return a.g < b.g;
+        if (a.b != b.b) return a.b < b.b;
+        return a.idx < b.idx;
+      });
+      for (size_t i = 0; i < items.size(); i++) hpal[(size_t)p * pal_size + i] = (items[i].b << 16) | (items[i].g << 8) | items[i].r;
+    }
+  }
+  TM_HIP(hipMemcpyAsync(out_palettes, hpal.data(), hpal.size() * 4, hipMemcpyHostToDevice, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  return TM_OK;
+}
+
+}  // namespace tmx

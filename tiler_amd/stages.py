@@ -104,3 +104,40 @@ def dither(tiles, flags, pal_idx, palettes, use_thomas_knoll=True, y2_mixed=4):
     check(lib().tm_stage_dither(_p(tiles), _p(flags), _p(pal_idx), n, _p(palettes), palettes.shape[0], palettes.shape[1],
                                 int(use_thomas_knoll), y2_mixed, _p(out), _stream()))
     return out
+
+
+def dedup(rows, use_in=None):
+    """MakeTilesUnique + ReindexTiles (tilingencoder.pas:4720-4781, 4626-4700).  rows: int32 [n][64] (RGB tiles) or
+    uint8 [n][64] (palette-index tiles).  -> (n_unique, remap int32 [n], order int32 [n_unique], use uint32-as-int32 [n_unique])"""
+    n = rows.shape[0]
+    row_bytes = rows.shape[1] * rows.element_size()
+    remap = torch.empty((n,), dtype=torch.int32, device=rows.device)
+    order = torch.empty((n,), dtype=torch.int32, device=rows.device)
+    use = torch.empty((n,), dtype=torch.int32, device=rows.device)
+    nu = ctypes.c_int64()
+    check(lib().tm_stage_dedup(_p(rows), n, row_bytes, _p(use_in), _p(remap), _p(order), _p(use), ctypes.byref(nu), _stream()))
+    return nu.value, remap, order[: nu.value], use[: nu.value]
+
+
+def kmeans(pts, weights, k, max_iter=300):
+    """the build's deterministic k-means: pts int32 [n][d] -> (live_k, assign int32 [n], centroids float64 [k][d], iters)"""
+    n, d = pts.shape
+    assign = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    cent = torch.zeros((k, d), dtype=torch.float64, device=pts.device)
+    hk, hi = ctypes.c_int(), ctypes.c_int()
+    check(lib().tm_stage_kmeans(_p(pts), _p(weights), n, d, k, max_iter, _p(assign), _p(cent), ctypes.byref(hk), ctypes.byref(hi), _stream()))
+    return hk.value, assign, cent, hi.value
+
+
+def quantize_palettes(tiles, pal_idx, npal, pal_size, max_iter=300):
+    """QuantizeUsingYakmo + DoQuantization for every palette (tilingencoder.pas:4434-4564) -> int32 [npal][pal_size]"""
+    out = torch.empty((npal, pal_size), dtype=torch.int32, device=tiles.device)
+    check(lib().tm_stage_quantize_palettes(_p(tiles), _p(pal_idx), tiles.shape[0], npal, pal_size, max_iter, _p(out), _stream()))
+    return out
+
+
+def palettize(feat, use, npal, max_iter=300):
+    """DoPalettization (tilingencoder.pas:4105-4245): cluster features -> PalIdx_Initial int32 [n], palettes ranked by tile count"""
+    out = torch.empty((feat.shape[0],), dtype=torch.int32, device=feat.device)
+    check(lib().tm_stage_palettize(_p(feat), _p(use), feat.shape[0], npal, max_iter, _p(out), _stream()))
+    return out
