@@ -1,0 +1,72 @@
+"""End-to-end: TTilingEncoder.Run(esAll) through the coarse C ABI against the oracle pipeline (BASELINE config 1:
+64x64, 10 frames, 8x8 tiles, 1 palette; plus a multi-palette, non-multiple-of-8 case)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _run_encoder(frames, **settings):
+    from tiler_amd.encoder import TilingEncoder
+    enc = TilingEncoder()
+    enc.LoadDefaultSettings()
+    for k, v in settings.items():
+        setattr(enc, k, v)
+    nf, h, w = frames.shape
+    enc.SetVideo(w, h, 24.0, nf)
+    for f in range(nf):
+        enc.PushFrame(f, frames[f])
+    enc.Run()
+    return enc
+
+
+@pytest.mark.parametrize("shape,pc", [((10, 64, 64), 1), ((6, 52, 100), 3)])
+def test_run_all_matches_oracle(oracle, shape, pc):
+    from tiler_amd import synth
+    from tests import oracle_pipeline
+    frames = synth.video(*shape[:1], shape[2], shape[1], cut=4)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=pc, min_s=0.1)
+    enc = _run_encoder(frames, PaletteCount=pc, ShotTransMinSecondsPerKF=0.1)
+    c = enc.counts()
+    assert np.array_equal(enc.FrameCorrelations().view(np.uint32), exp["correl"].view(np.uint32))
+    assert np.array_equal(enc.KeyFrames(), exp["keyframes"])
+    assert c["tiles"] == exp["final_T"]
+    hdr, pal, rgb = enc.Tiles()
+    assert np.array_equal(pal, exp["final_pal_px"])
+    assert np.array_equal(hdr["UseCount"], exp["final_use"])
+    assert np.array_equal(hdr["PalIdx_Initial"], exp["final_pal_idx"])
+    assert np.array_equal(rgb, exp["final_rgb"])
+    assert np.array_equal(enc.Palettes(), exp["palettes"])
+    per = exp["per"]
+    for f in range(shape[0]):
+        tm = enc.TileMap(f)
+        sl = slice(f * per, (f + 1) * per)
+        assert np.array_equal(tm["TileIdx"], exp["final_tm_tile"][sl])
+        assert np.array_equal(tm["PalIdx"], exp["tm_pal"][sl])
+        assert np.array_equal(tm["Flags"] & 3, exp["flags"][sl])
+        psnr = np.array([oracle.L.tmo_euclidean_to_psnr(int(e)) for e in exp["knn_err"][sl]], np.float32)
+        assert np.allclose(tm["PSNR"], psnr, rtol=1e-6)  # PSNR goes through log10: tolerance 1e-6 relative
+    enc.close()
+
+
+def test_step_order_and_errors():
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep
+    from tiler_amd import TileMotionError
+    enc = TilingEncoder()
+    with pytest.raises(TileMotionError):
+        enc.Run(TEncoderStep.esLoad)  # no video yet
+    enc.SetVideo(16, 16, 24.0, 1)
+    enc.PushFrame(0, np.zeros((16, 16), np.uint32))
+    with pytest.raises(TileMotionError):
+        enc.Run(TEncoderStep.esDither)  # Reduce/PreparePalettes not run
+    enc.PaletteSize = 1000
+    assert enc.PaletteSize == 64  # clamp of SetPaletteSize, tilingencoder.pas:2965
+    enc.PaletteCount = 0
+    assert enc.PaletteCount == 1
+    enc.PaletteCount = 1
+    enc.Run()  # a single black frame: 4 identical tiles -> 1 global tile
+    assert enc.counts()["tiles"] == 1
+    with pytest.raises(TileMotionError):
+        enc.Run(TEncoderStep.esSave)
+    enc.close()

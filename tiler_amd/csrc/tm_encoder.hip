@@ -1,0 +1,622 @@
+// tm_encoder.hip -- coarse seam: the TTilingEncoder object behind tm_create/tm_run (include/tilemotion.h).
+//
+// Mirrors TTilingEncoder (tilingencoder.pas:308-568): settings with the reference's clamps (2919-3047) and INI keys
+// (3745-3770), Run(step) walking esLoad..esSave (5529-5554), read-only Tiles/Frames/Palettes views.  Everything a
+// step computes stays resident in HBM between steps; only small control data (correlations, digit plans, palette
+// colours, counts) crosses to the host.  What is not built yet (motion prediction, EPU re-rank, OptimizePalettes,
+// .gtm writer) is listed in DESIGN.md "Scope" and fails or no-ops loudly below.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "tm_common.h"
+#include "tm_internal.h"
+
+namespace tmx {
+
+// ---- small device helpers ------------------------------------------------------------------------------------
+__global__ void k_gather_rows16(const uint4 *__restrict__ src, const int32_t *__restrict__ idx, int64_t n, int vec_per_row,
+                                uint4 *__restrict__ dst) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * vec_per_row; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / vec_per_row;
+    const int v = (int)(e - r * vec_per_row);
+    dst[e] = src[(int64_t)idx[r] * vec_per_row + v];
+  }
+}
+template <class T> __global__ void k_gather(const T *__restrict__ src, const int32_t *__restrict__ idx, int64_t n, T *__restrict__ dst) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void k_clip_index(int32_t *__restrict__ idx, int64_t n, int32_t limit) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (idx[i] >= limit) idx[i] = -1;
+}
+__global__ void k_histogram(const int32_t *__restrict__ idx, int64_t n, uint32_t *__restrict__ hist) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (idx[i] >= 0) atomicAdd(&hist[idx[i]], 1u);
+}
+__global__ void k_lookup(const int32_t *__restrict__ idx, int64_t n, const int32_t *__restrict__ table, int32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = idx[i] >= 0 ? table[idx[i]] : -1;
+}
+static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
+
+static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, utils.pas:1038-1041 (TFloat argument)
+  const float f = (float)tc;
+  return (int)llrint(std::sqrt((double)f) * std::log2(1 + (double)f));
+}
+
+static float pearson(const float *x, const float *y, int n) {  // PearsonCorrelation, tilingencoder.pas:2201-2228
+  double sx = 0, sy = 0;                                       // Math.mean accumulates in float(=double on Win64)
+  for (int i = 0; i < n; i++) { sx += x[i]; sy += y[i]; }
+  const float mx = (float)(sx / n), my = (float)(sy / n);
+  float num = 0, denx = 0, deny = 0;
+  for (int i = 0; i < n; i++) {
+    const float dx = x[i] - mx, dy = y[i] - my;
+    num += dx * dy;
+    denx += dx * dx;
+    deny += dy * dy;
+  }
+  denx = std::sqrt(denx);
+  deny = std::sqrt(deny);
+  const float den = denx * deny;
+  return den != 0.0f ? num / den : 1.0f;
+}
+
+static float euclidean_to_psnr(uint32_t e) {  // EuclideanToPSNR, utils.pas:1074-1078
+  const float r = (float)((double)e * (1.0 / 192));
+  const float m = r > 0.5f ? r : 0.5f;
+  return (float)(10 * std::log10(255 * 255 / (double)m));
+}
+
+struct Settings {
+  std::string InputFileName, OutputFileName;
+  int StartFrame = 0, FrameCount = 0;
+  double Scaling = 1.0;
+  int MotionPredictRadius = 32;
+  bool GlobalTilingUseTargetPSNR = false;
+  double GlobalTilingTargetPSNR = 20.0, GlobalTilingQualityBasedTileCount = 7.0;
+  int GlobalTilingTileCount = 0;
+  int PaletteSize = 16, PaletteCount = 1024;
+  int DitheringMode = TM_PVS_WEIGHTED_SPE_DCT;
+  bool DitheringUseThomasKnoll = true;
+  int DitheringYliluoma2MixedColors = 4;
+  bool FrameTilingExtendedPaletteUsage = true;
+  int MaxThreadCount = 1;
+  double ShotTransMaxSecondsPerKF = 15.0, ShotTransMinSecondsPerKF = 1.0, ShotTransCorrelLoThres = 0.8;
+};
+
+}  // namespace tmx
+
+using namespace tmx;
+
+struct tm_encoder {
+  Settings s;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  tm_progress_cb cb = nullptr;
+  void *cb_user = nullptr;
+  // video (ReframeUI, tilingencoder.pas:2631-2638)
+  int width = 0, height = 0, tm_w = 0, tm_h = 0, nframes = 0;
+  double fps = 24.0;
+  bool auto_tile_count = true;
+  // device state
+  DevBuf frames_owned;
+  const void *frames = nullptr;  // [nframes][height][width] RGB32
+  DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
+  DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
+  DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, KNN error
+  int64_t q = 0, t = 0;
+  bool has_pal_px = false, reconstructed = false;
+  // host state
+  std::vector<float> correl;
+  std::vector<int32_t> kf_start;
+  std::vector<int32_t> palettes_host;
+  std::vector<uint8_t> h_fflags;
+  double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int steps_done = 0;  // bit per step
+
+  int64_t tm_size() const { return (int64_t)tm_w * tm_h; }
+};
+
+static void progress(tm_encoder *e, int step, int pos, int max) {
+  if (e->cb) e->cb(e->cb_user, step, pos, max, 0);
+}
+
+// ---- settings ------------------------------------------------------------------------------------------------
+static int clampi(int64_t v, int lo, int hi) { return (int)std::min<int64_t>(hi, std::max<int64_t>(lo, v)); }
+
+static void recompute_auto_tile_count(tm_encoder *e) {  // SetGlobalTilingQualityBasedTileCount, tilingencoder.pas:2937-2948
+  const int64_t raw = (int64_t)e->nframes * e->tm_size();
+  const int eqtc = equal_quality_tile_count((double)raw);
+  e->s.GlobalTilingTileCount = (int)std::min<int64_t>(llrint(e->s.GlobalTilingQualityBasedTileCount * eqtc), raw);
+}
+
+static int set_number(tm_encoder *e, const std::string &k, double v, bool is_int_like) {
+  Settings &s = e->s;
+  (void)is_int_like;
+  if (k == "StartFrame") s.StartFrame = std::max(0, (int)v);
+  else if (k == "FrameCount") s.FrameCount = std::max(0, (int)v);
+  else if (k == "Scaling") s.Scaling = std::max(0.01, v);
+  else if (k == "MotionPredictRadius") s.MotionPredictRadius = clampi((int64_t)v, 1, 128);
+  else if (k == "GlobalTilingUseTargetPSNR") s.GlobalTilingUseTargetPSNR = v != 0;
+  else if (k == "GlobalTilingTargetPSNR") s.GlobalTilingTargetPSNR = std::min(10 * std::log(255 * 255 / 0.5) / std::log(10.0), std::max(0.0, v));
+  else if (k == "GlobalTilingQualityBasedTileCount") { s.GlobalTilingQualityBasedTileCount = v; e->auto_tile_count = true; if (e->nframes) recompute_auto_tile_count(e); }
+  else if (k == "GlobalTilingTileCount") {  // SetGlobalTilingTileCount, 2974-2986: has priority over the quality-based value
+    const int64_t raw = (int64_t)e->nframes * e->tm_size();
+    s.GlobalTilingTileCount = raw ? clampi((int64_t)v, 0, (int)std::min<int64_t>(raw, INT32_MAX)) : std::max(0, (int)v);
+    e->auto_tile_count = s.GlobalTilingTileCount <= 0;
+  }
+  else if (k == "PaletteSize") s.PaletteSize = clampi((int64_t)v, 2, 64);
+  else if (k == "PaletteCount") s.PaletteCount = clampi((int64_t)v, 1, 65536);
+  else if (k == "DitheringMode") s.DitheringMode = clampi((int64_t)v, 0, 4);
+  else if (k == "DitheringUseThomasKnoll") s.DitheringUseThomasKnoll = v != 0;
+  else if (k == "DitheringYliluoma2MixedColors") s.DitheringYliluoma2MixedColors = clampi((int64_t)v, 1, 16);
+  else if (k == "FrameTilingExtendedPaletteUsage") s.FrameTilingExtendedPaletteUsage = v != 0;
+  else if (k == "MaxThreadCount") s.MaxThreadCount = std::max(1, (int)v);
+  else if (k == "ShotTransMaxSecondsPerKF") s.ShotTransMaxSecondsPerKF = std::max(0.0, v);
+  else if (k == "ShotTransMinSecondsPerKF") s.ShotTransMinSecondsPerKF = std::max(0.0, v);
+  else if (k == "ShotTransCorrelLoThres") s.ShotTransCorrelLoThres = std::min(1.0, std::max(-1.0, v));
+  else { set_error("unknown setting '%s'", k.c_str()); return TM_E_INVAL; }
+  return TM_OK;
+}
+
+static int get_number(tm_encoder *e, const std::string &k, double *v) {
+  const Settings &s = e->s;
+  if (k == "StartFrame") *v = s.StartFrame;
+  else if (k == "FrameCount") *v = s.FrameCount;
+  else if (k == "Scaling") *v = s.Scaling;
+  else if (k == "MotionPredictRadius") *v = s.MotionPredictRadius;
+  else if (k == "GlobalTilingUseTargetPSNR") *v = s.GlobalTilingUseTargetPSNR;
+  else if (k == "GlobalTilingTargetPSNR") *v = s.GlobalTilingTargetPSNR;
+  else if (k == "GlobalTilingQualityBasedTileCount") *v = s.GlobalTilingQualityBasedTileCount;
+  else if (k == "GlobalTilingTileCount") *v = s.GlobalTilingTileCount;
+  else if (k == "PaletteSize") *v = s.PaletteSize;
+  else if (k == "PaletteCount") *v = s.PaletteCount;
+  else if (k == "DitheringMode") *v = s.DitheringMode;
+  else if (k == "DitheringUseThomasKnoll") *v = s.DitheringUseThomasKnoll;
+  else if (k == "DitheringYliluoma2MixedColors") *v = s.DitheringYliluoma2MixedColors;
+  else if (k == "FrameTilingExtendedPaletteUsage") *v = s.FrameTilingExtendedPaletteUsage;
+  else if (k == "MaxThreadCount") *v = s.MaxThreadCount;
+  else if (k == "ShotTransMaxSecondsPerKF") *v = s.ShotTransMaxSecondsPerKF;
+  else if (k == "ShotTransMinSecondsPerKF") *v = s.ShotTransMinSecondsPerKF;
+  else if (k == "ShotTransCorrelLoThres") *v = s.ShotTransCorrelLoThres;
+  else { set_error("unknown setting '%s'", k.c_str()); return TM_E_INVAL; }
+  return TM_OK;
+}
+
+// ---- steps ---------------------------------------------------------------------------------------------------
+static int need(tm_encoder *e, int step_bit, const char *what) {
+  TM_CHECK(e->steps_done & (1 << step_bit), TM_E_INVAL, "step order: %s has not been run", what);
+  return TM_OK;
+}
+
+static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
+  TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
+  TM_CHECK(e->frames != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device first");
+  e->q = (int64_t)e->nframes * e->tm_size();
+  TM_TRY(e->ftiles.alloc((size_t)e->q * 256));
+  TM_TRY(e->fflags.alloc((size_t)e->q));
+  TM_TRY(e->flab.alloc((size_t)e->q * 12));
+  TM_TRY(launch_load(e->frames, e->nframes, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.p, e->fflags.p, e->flab.p, e->stream));
+  progress(e, TM_STEP_LOAD, 1, 3);
+  // inter-frame correlation on the host: a 43 200-term sequential Single sum per frame (order matters)
+  std::vector<float> lab((size_t)e->q * 3);
+  e->h_fflags.resize((size_t)e->q);
+  TM_HIP(hipMemcpyAsync(lab.data(), e->flab.p, lab.size() * 4, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipMemcpyAsync(e->h_fflags.data(), e->fflags.p, (size_t)e->q, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
+  const int per = (int)e->tm_size() * 3;
+  e->correl.assign(e->nframes, 0.0f);
+  for (int f = 1; f < e->nframes; f++) e->correl[f] = pearson(&lab[(size_t)(f - 1) * per], &lab[(size_t)f * per], per);
+  progress(e, TM_STEP_LOAD, 2, 3);
+  // FindKeyFrames, automatic mode (3373-3411)
+  e->kf_start.clear();
+  int64_t last = INT32_MIN;
+  for (int f = 0; f < e->nframes; f++) {
+    bool kf = f == 0;
+    if (!kf && (double)e->correl[f] < e->s.ShotTransCorrelLoThres) kf = true;
+    if (!kf && (double)(f - last) >= e->s.ShotTransMaxSecondsPerKF * e->fps) kf = true;
+    if ((double)(f - last) < e->s.ShotTransMinSecondsPerKF * e->fps) kf = false;
+    if (kf) { e->kf_start.push_back(f); last = f; }
+  }
+  if (e->auto_tile_count || e->s.GlobalTilingTileCount <= 0) recompute_auto_tile_count(e);
+  // tile map starts empty (InitFrames, 2661-2686)
+  TM_TRY(e->tm_tile.alloc((size_t)e->q * 4));
+  TM_TRY(e->tm_pal.alloc((size_t)e->q * 4));
+  TM_TRY(e->tm_err.alloc((size_t)e->q * 4));
+  TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
+  TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
+  TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
+  e->t = 0;
+  e->has_pal_px = e->reconstructed = false;
+  progress(e, TM_STEP_LOAD, 3, 3);
+  return TM_OK;
+}
+
+static int step_reduce(tm_encoder *e) {
+  // Reduce, tilingencoder.pas:1909-1926 = SolveTileCount (4043) + ReindexTiles(True).  With motion prediction not
+  // built no tile-map item is predicted, so TransferTiles (4048) moves every frame tile; MakeTilesUnique(True)+
+  // ReindexTiles(True) are exact; the tile budget is then met by keeping the first GlobalTilingTileCount tiles of
+  // that order (most used first) -- the build's stand-in for the PSNR threshold search, see DESIGN.md "Scope".
+  TM_TRY(need(e, TM_STEP_LOAD, "Load"));
+  DevBuf remap, order, use;
+  TM_TRY(remap.alloc((size_t)e->q * 4));
+  TM_TRY(order.alloc((size_t)e->q * 4));
+  TM_TRY(use.alloc((size_t)e->q * 4));
+  int64_t nu = 0;
+  TM_TRY(run_dedup(e->ftiles.p, e->q, 256, nullptr, remap.p, order.p, use.p, &nu, e->stream));
+  progress(e, TM_STEP_REDUCE, 1, 2);
+  int64_t target = e->s.GlobalTilingTileCount > 0 ? e->s.GlobalTilingTileCount : nu;
+  e->t = std::min<int64_t>(nu, target);
+  TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
+  TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
+  TM_TRY(e->guse.alloc((size_t)e->t * 4));
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(e->t * 16)), dim3(256), 0, e->stream, e->ftiles.as<uint4>(), order.as<int32_t>(), e->t, 16,
+                     e->gtiles.as<uint4>());
+  hipLaunchKernelGGL(k_gather<uint8_t>, dim3(gridn(e->t)), dim3(256), 0, e->stream, e->fflags.as<uint8_t>(), order.as<int32_t>(), e->t,
+                     e->gflags.as<uint8_t>());
+  TM_HIP(hipMemcpyAsync(e->guse.p, use.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
+  TM_HIP(hipMemcpyAsync(e->tm_tile.p, remap.p, (size_t)e->q * 4, hipMemcpyDeviceToDevice, e->stream));
+  hipLaunchKernelGGL(k_clip_index, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, (int32_t)e->t);
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->has_pal_px = e->reconstructed = false;
+  progress(e, TM_STEP_REDUCE, 2, 2);
+  return TM_OK;
+}
+
+static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingencoder.pas:1843-1871
+  TM_TRY(need(e, TM_STEP_REDUCE, "Reduce"));
+  TM_CHECK(e->t > 0, TM_E_INVAL, "no global tiles");
+  DevBuf feat;
+  TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
+  TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
+  TM_TRY(e->gpal_idx.alloc((size_t)e->t * 4));
+  TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
+  progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
+  TM_TRY(e->palettes_dev.alloc((size_t)e->s.PaletteCount * e->s.PaletteSize * 4));
+  TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream));
+  e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
+  TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
+  progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
+  // OptimizePalettes (4309-4432): slot permutation by Powell; host-side, not built yet (DESIGN.md "Scope")
+  progress(e, TM_STEP_PREPARE_PALETTES, 3, 3);
+  return TM_OK;
+}
+
+static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
+  TM_TRY(need(e, TM_STEP_PREPARE_PALETTES, "PreparePalettes"));
+  TM_TRY(e->gpal_px.alloc((size_t)e->t * 64));
+  TM_TRY(launch_dither(e->gtiles.p, e->gflags.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteCount, e->s.PaletteSize,
+                       e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors, e->gpal_px.p, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->has_pal_px = true;
+  progress(e, TM_STEP_DITHER, 2, 2);
+  return TM_OK;
+}
+
+static int step_reconstruct(tm_encoder *e) {
+  // Reconstruct, tilingencoder.pas:1928-1962: PrepareReconstruct (4566) builds the int16 database of all global
+  // tiles; TFrame.Reconstruct.DoXY (1464-1659) matches every frame tile.  KNN branch only (motion branch not built):
+  // the nearest-neighbour part does not depend on the previous reconstructed frame, so all frames go in one batch.
+  TM_TRY(need(e, TM_STEP_DITHER, "Dither"));
+  DevBuf db, qf;
+  TM_TRY(db.alloc((size_t)e->t * 384));
+  TM_TRY(launch_features_pal(e->gpal_px.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteSize, TM_PVS_WEIGHTED_DCT, db.p, e->stream));
+  tm_knn_index_impl *ix = nullptr;
+  TM_TRY(knn_index_create(db.p, e->t, e->stream, &ix));
+  progress(e, TM_STEP_RECONSTRUCT, 1, 2);
+  // query features in frame chunks (bounded scratch for long / 4K clips: streaming through HBM)
+  const int64_t per = e->tm_size();
+  int chunk_frames = (int)std::max<int64_t>(1, std::min<int64_t>(e->nframes, ((int64_t)8 << 30) / (per * 384)));
+  int rc = qf.alloc((size_t)chunk_frames * per * 384);
+  for (int f0 = 0; rc == TM_OK && f0 < e->nframes; f0 += chunk_frames) {
+    const int nf = std::min(chunk_frames, e->nframes - f0);
+    const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
+    rc = launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream);
+    if (rc == TM_OK) rc = knn_index_search(ix, qf.p, n, e->tm_tile.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
+  }
+  knn_index_destroy(ix);
+  TM_TRY(rc);
+  hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
+                     e->tm_pal.as<int32_t>());  // TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial (1551)
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->reconstructed = true;
+  progress(e, TM_STEP_RECONSTRUCT, 2, 2);
+  return TM_OK;
+}
+
+static int step_reindex(tm_encoder *e) {  // Reindex, tilingencoder.pas:1993-2038
+  TM_TRY(need(e, TM_STEP_RECONSTRUCT, "Reconstruct"));
+  DevBuf hist, remap, order, use;
+  TM_TRY(hist.alloc((size_t)e->t * 4));
+  TM_TRY(remap.alloc((size_t)e->t * 4));
+  TM_TRY(order.alloc((size_t)e->t * 4));
+  TM_TRY(use.alloc((size_t)e->t * 4));
+  // UseCount recount from the tile maps (2018-2031); MakeTilesUnique(False) merges by palette-index content and
+  // sums the counts of merged tiles -- same totals as counting after the merge remap
+  TM_HIP(hipMemsetAsync(hist.p, 0, (size_t)e->t * 4, e->stream));
+  hipLaunchKernelGGL(k_histogram, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, hist.as<uint32_t>());
+  int64_t nu = 0;
+  TM_TRY(run_dedup(e->gpal_px.p, e->t, 64, hist.p, remap.p, order.p, use.p, &nu, e->stream));
+  progress(e, TM_STEP_REINDEX, 2, 3);
+  DevBuf ntiles, nflags, npal_idx, npal_px, ntm;
+  TM_TRY(ntiles.alloc((size_t)nu * 256)); TM_TRY(nflags.alloc((size_t)std::max<int64_t>(nu, 1))); TM_TRY(npal_idx.alloc((size_t)nu * 4));
+  TM_TRY(npal_px.alloc((size_t)nu * 64)); TM_TRY(ntm.alloc((size_t)e->q * 4));
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(nu * 16)), dim3(256), 0, e->stream, e->gtiles.as<uint4>(), order.as<int32_t>(), nu, 16, ntiles.as<uint4>());
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(nu * 4)), dim3(256), 0, e->stream, e->gpal_px.as<uint4>(), order.as<int32_t>(), nu, 4, npal_px.as<uint4>());
+  hipLaunchKernelGGL(k_gather<uint8_t>, dim3(gridn(nu)), dim3(256), 0, e->stream, e->gflags.as<uint8_t>(), order.as<int32_t>(), nu, nflags.as<uint8_t>());
+  hipLaunchKernelGGL(k_gather<int32_t>, dim3(gridn(nu)), dim3(256), 0, e->stream, e->gpal_idx.as<int32_t>(), order.as<int32_t>(), nu, npal_idx.as<int32_t>());
+  hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, remap.as<int32_t>(), ntm.as<int32_t>());
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->gtiles = std::move(ntiles); e->gflags = std::move(nflags); e->gpal_idx = std::move(npal_idx); e->gpal_px = std::move(npal_px);
+  e->tm_tile = std::move(ntm);
+  e->guse = std::move(use);
+  e->t = nu;
+  progress(e, TM_STEP_REINDEX, 3, 3);
+  return TM_OK;
+}
+
+static int run_step(tm_encoder *e, int step) {
+  TM_HIP(hipSetDevice(e->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = TM_OK;
+  switch (step) {
+    case TM_STEP_LOAD: rc = step_load(e); break;
+    case TM_STEP_PREDICT_MOTION: break;  // PredictMotion (1964): not built; every tile stays unpredicted (DESIGN.md "Scope")
+    case TM_STEP_REDUCE: rc = step_reduce(e); break;
+    case TM_STEP_PREPARE_PALETTES: rc = step_prepare_palettes(e); break;
+    case TM_STEP_DITHER: rc = step_dither(e); break;
+    case TM_STEP_RECONSTRUCT: rc = step_reconstruct(e); break;
+    case TM_STEP_REINDEX: rc = step_reindex(e); break;
+    case TM_STEP_SAVE:
+      set_error("Save (.gtm writer + LZMA) is not built yet; see DESIGN.md \"Scope\"");
+      rc = TM_E_UNSUPPORTED;
+      break;
+    default: set_error("bad step %d", step); rc = TM_E_INVAL;
+  }
+  if (rc == TM_OK) {
+    e->stage_ms[step] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    e->steps_done |= 1 << step;
+    for (int later = step + 1; later < 8; later++) e->steps_done &= ~(1 << later);  // later state is stale now
+  }
+  return rc;
+}
+
+extern "C" {
+
+tm_encoder *tm_create(void) {
+  if (require_device() != TM_OK) return nullptr;
+  tm_encoder *e = new tm_encoder();
+  if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+  return e;
+}
+
+void tm_destroy(tm_encoder *e) { delete e; }
+
+int tm_set_device(tm_encoder *e, int device) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_HIP(hipSetDevice(device));
+  e->device = device;
+  return TM_OK;
+}
+
+int tm_load_default_settings(tm_encoder *e) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  e->s = Settings();
+  e->auto_tile_count = true;
+  return TM_OK;
+}
+
+int tm_load_settings_ini(tm_encoder *e, const char *path) {  // LoadSettings, tilingencoder.pas:3777-3815
+  TM_CHECK(e && path, TM_E_INVAL, "null argument");
+  std::ifstream in(path);
+  TM_CHECK(in.good(), TM_E_IO, "cannot open %s", path);
+  tm_load_default_settings(e);
+  std::map<std::string, std::string> kv;
+  std::string line;
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+    if (line.empty() || line[0] == '[' || line[0] == ';') continue;  // key names are unique across sections
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;
+    kv[line.substr(0, eq)] = line.substr(eq + 1);
+  }
+  // GlobalTilingTileCount after GlobalTilingQualityBasedTileCount: it has priority (3796)
+  static const char *order[] = {"StartFrame", "FrameCount", "Scaling", "MotionPredictRadius", "GlobalTilingUseTargetPSNR",
+                                "GlobalTilingTargetPSNR", "GlobalTilingQualityBasedTileCount", "GlobalTilingTileCount", "PaletteSize",
+                                "PaletteCount", "DitheringMode", "DitheringUseThomasKnoll", "DitheringYliluoma2MixedColors",
+                                "FrameTilingExtendedPaletteUsage", "MaxThreadCount", "ShotTransMaxSecondsPerKF",
+                                "ShotTransMinSecondsPerKF", "ShotTransCorrelLoThres"};
+  for (const char *k : order) {
+    auto it = kv.find(k);
+    if (it == kv.end()) continue;
+    std::string v = it->second;
+    std::replace(v.begin(), v.end(), ',', '.');
+    TM_TRY(set_number(e, k, atof(v.c_str()), false));
+  }
+  if (kv.count("InputFileName")) e->s.InputFileName = kv["InputFileName"];
+  if (kv.count("OutputFileName")) e->s.OutputFileName = kv["OutputFileName"];
+  return TM_OK;
+}
+
+int tm_set_int(tm_encoder *e, const char *key, int64_t v) { TM_CHECK(e && key, TM_E_INVAL, "null argument"); return set_number(e, key, (double)v, true); }
+int tm_set_float(tm_encoder *e, const char *key, double v) { TM_CHECK(e && key, TM_E_INVAL, "null argument"); return set_number(e, key, v, false); }
+int tm_set_bool(tm_encoder *e, const char *key, int v) { TM_CHECK(e && key, TM_E_INVAL, "null argument"); return set_number(e, key, v ? 1 : 0, true); }
+int tm_set_str(tm_encoder *e, const char *key, const char *v) {
+  TM_CHECK(e && key && v, TM_E_INVAL, "null argument");
+  if (!strcmp(key, "InputFileName")) e->s.InputFileName = v;
+  else if (!strcmp(key, "OutputFileName")) e->s.OutputFileName = v;
+  else { set_error("unknown string setting '%s'", key); return TM_E_INVAL; }
+  return TM_OK;
+}
+int tm_get_int(tm_encoder *e, const char *key, int64_t *v) {
+  TM_CHECK(e && key && v, TM_E_INVAL, "null argument");
+  double d;
+  TM_TRY(get_number(e, key, &d));
+  *v = (int64_t)llrint(d);
+  return TM_OK;
+}
+int tm_get_float(tm_encoder *e, const char *key, double *v) { TM_CHECK(e && key && v, TM_E_INVAL, "null argument"); return get_number(e, key, v); }
+
+int tm_set_progress_cb(tm_encoder *e, tm_progress_cb cb, void *user) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  e->cb = cb;
+  e->cb_user = user;
+  return TM_OK;
+}
+
+int tm_set_video(tm_encoder *e, int width, int height, double fps, int frame_count) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(width > 0 && height > 0 && frame_count > 0 && fps >= 0, TM_E_INVAL, "bad video geometry %dx%d x%d", width, height, frame_count);
+  TM_HIP(hipSetDevice(e->device));
+  e->width = width; e->height = height; e->fps = fps; e->nframes = frame_count;
+  e->tm_w = (width - 1) / 8 + 1;   // ReframeUI((DstWidth - 1) div cTileWidth + 1, ...), tilingencoder.pas:1776
+  e->tm_h = (height - 1) / 8 + 1;
+  e->frames = nullptr;
+  e->frames_owned.release();
+  e->steps_done = 0;
+  if (e->auto_tile_count) recompute_auto_tile_count(e);
+  return TM_OK;
+}
+
+int tm_push_frame_rgb32(tm_encoder *e, int index, const uint32_t *pixels, int stride_px) {
+  TM_CHECK(e && pixels, TM_E_INVAL, "null argument");
+  TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
+  TM_CHECK(index >= 0 && index < e->nframes && stride_px >= e->width, TM_E_INVAL, "bad frame index/stride");
+  TM_HIP(hipSetDevice(e->device));
+  const size_t fbytes = (size_t)e->width * e->height * 4;
+  if (!e->frames_owned.p || e->frames != e->frames_owned.p) {
+    TM_TRY(e->frames_owned.alloc(fbytes * e->nframes));
+    TM_HIP(hipMemsetAsync(e->frames_owned.p, 0, fbytes * e->nframes, e->stream));
+    e->frames = e->frames_owned.p;
+  }
+  TM_HIP(hipMemcpy2DAsync(e->frames_owned.as<uint8_t>() + fbytes * index, (size_t)e->width * 4, pixels, (size_t)stride_px * 4,
+                          (size_t)e->width * 4, e->height, hipMemcpyHostToDevice, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));  // caller's buffer is only valid during the call (extern.pas:883-892)
+  return TM_OK;
+}
+
+int tm_set_frames_device(tm_encoder *e, const void *dev_frames) {
+  TM_CHECK(e && dev_frames, TM_E_INVAL, "null argument");
+  TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
+  e->frames_owned.release();
+  e->frames = dev_frames;
+  return TM_OK;
+}
+
+int tm_run(tm_encoder *e, int step) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (step == TM_STEP_ALL) {  // Run(esAll): every step in order (5535-5553); Save only once an output name is set
+    for (int s = TM_STEP_LOAD; s <= TM_STEP_REINDEX; s++) TM_TRY(run_step(e, s));
+    if (!e->s.OutputFileName.empty()) TM_TRY(run_step(e, TM_STEP_SAVE));
+    return TM_OK;
+  }
+  return run_step(e, step);
+}
+
+int tm_get_counts(tm_encoder *e, int64_t *tiles, int *frames, int *palettes, int *tm_w, int *tm_h, int *keyframes) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (tiles) *tiles = e->t;
+  if (frames) *frames = e->nframes;
+  if (palettes) *palettes = e->palettes_host.empty() ? 0 : e->s.PaletteCount;
+  if (tm_w) *tm_w = e->tm_w;
+  if (tm_h) *tm_h = e->tm_h;
+  if (keyframes) *keyframes = (int)e->kf_start.size();
+  return TM_OK;
+}
+
+int tm_get_tiles(tm_encoder *e, int64_t first, int64_t count, tm_tile_hdr *hdrs, uint8_t *pal_px, uint32_t *rgb_px) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(first >= 0 && count >= 0 && first + count <= e->t, TM_E_INVAL, "tile range [%lld,+%lld) outside 0..%lld", (long long)first,
+           (long long)count, (long long)e->t);
+  if (count == 0) return TM_OK;
+  TM_HIP(hipSetDevice(e->device));
+  if (rgb_px) TM_HIP(hipMemcpy(rgb_px, e->gtiles.as<uint8_t>() + first * 256, (size_t)count * 256, hipMemcpyDeviceToHost));
+  if (pal_px) {
+    if (e->has_pal_px) TM_HIP(hipMemcpy(pal_px, e->gpal_px.as<uint8_t>() + first * 64, (size_t)count * 64, hipMemcpyDeviceToHost));
+    else memset(pal_px, 0, (size_t)count * 64);
+  }
+  if (hdrs) {
+    std::vector<uint32_t> use(count);
+    std::vector<int32_t> pi(count, -1);
+    std::vector<uint8_t> fl(count);
+    TM_HIP(hipMemcpy(use.data(), e->guse.as<uint8_t>() + first * 4, (size_t)count * 4, hipMemcpyDeviceToHost));
+    TM_HIP(hipMemcpy(fl.data(), e->gflags.as<uint8_t>() + first, (size_t)count, hipMemcpyDeviceToHost));
+    if (e->gpal_idx.p && (e->steps_done & (1 << TM_STEP_PREPARE_PALETTES)))
+      TM_HIP(hipMemcpy(pi.data(), e->gpal_idx.as<uint8_t>() + first * 4, (size_t)count * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < count; i++) {
+      hdrs[i].UseCount = use[i];
+      hdrs[i].TmpIndex = (int32_t)(first + i);
+      hdrs[i].MergeIndex = -1;
+      hdrs[i].PalIdx_Initial = pi[i];
+      hdrs[i].Flags = 1u | 2u | 4u | ((fl[i] & 1) ? 8u : 0u) | ((fl[i] & 2) ? 16u : 0u);  // Active, HasRGB, HasPal, H/V mirror
+    }
+  }
+  return TM_OK;
+}
+
+int tm_get_tile(tm_encoder *e, int64_t i, tm_tile_hdr *hdr, uint8_t pal_px[64], uint32_t rgb_px[64]) {
+  return tm_get_tiles(e, i, 1, hdr, pal_px, rgb_px);
+}
+
+int tm_get_tilemap(tm_encoder *e, int frame, tm_tilemap_item *items) {
+  TM_CHECK(e && items, TM_E_INVAL, "null argument");
+  TM_CHECK(frame >= 0 && frame < e->nframes && (e->steps_done & 1), TM_E_INVAL, "bad frame %d", frame);
+  TM_HIP(hipSetDevice(e->device));
+  const int64_t per = e->tm_size(), off = (int64_t)frame * per;
+  std::vector<int32_t> ti(per), pi(per);
+  std::vector<uint32_t> er(per);
+  TM_HIP(hipMemcpy(ti.data(), e->tm_tile.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
+  TM_HIP(hipMemcpy(pi.data(), e->tm_pal.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
+  TM_HIP(hipMemcpy(er.data(), e->tm_err.as<uint32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < per; i++) {
+    items[i].TileIdx = ti[i];
+    items[i].PalIdx = pi[i];
+    items[i].PredictedX = 0;
+    items[i].PredictedY = 0;
+    items[i].PSNR = e->reconstructed ? euclidean_to_psnr(er[i]) : 0.0f;  // TMI^.PSNR := EuclideanToPSNR(knnErr), 1619
+    const uint8_t f = e->h_fflags[(size_t)(off + i)];
+    items[i].Flags = (f & 1 ? 1u : 0u) | (f & 2 ? 2u : 0u);
+  }
+  return TM_OK;
+}
+
+int tm_get_palette(tm_encoder *e, int i, int32_t *rgb) {
+  TM_CHECK(e && rgb, TM_E_INVAL, "null argument");
+  TM_CHECK(!e->palettes_host.empty() && i >= 0 && i < e->s.PaletteCount, TM_E_INVAL, "bad palette %d", i);
+  memcpy(rgb, &e->palettes_host[(size_t)i * e->s.PaletteSize], (size_t)e->s.PaletteSize * 4);
+  return TM_OK;
+}
+
+int tm_get_keyframes(tm_encoder *e, int32_t *start_frames) {
+  TM_CHECK(e && start_frames, TM_E_INVAL, "null argument");
+  memcpy(start_frames, e->kf_start.data(), e->kf_start.size() * 4);
+  return TM_OK;
+}
+
+int tm_get_frame_correlations(tm_encoder *e, float *correl) {
+  TM_CHECK(e && correl, TM_E_INVAL, "null argument");
+  memcpy(correl, e->correl.data(), e->correl.size() * 4);
+  return TM_OK;
+}
+
+int tm_get_stage_ms(tm_encoder *e, double ms[8]) {
+  TM_CHECK(e && ms, TM_E_INVAL, "null argument");
+  memcpy(ms, e->stage_ms, sizeof(e->stage_ms));
+  return TM_OK;
+}
+
+int tm_save_gtm(tm_encoder *e, const char *path) {
+  TM_CHECK(e && path, TM_E_INVAL, "null argument");
+  set_error("Save (.gtm writer + LZMA) is not built yet; see DESIGN.md \"Scope\"");
+  return TM_E_UNSUPPORTED;
+}
+
+}  // extern "C"

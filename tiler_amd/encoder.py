@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's TTilingEncoder (tilingencoder.pas:308-568) over the coarse C ABI.
+
+Same names and argument meaning as the Pascal class: LoadDefaultSettings / LoadSettings, the settings properties
+(INI key names, tilingencoder.pas:3745-3770), Run(step) with TEncoderStep values, Tiles / TileMap / Palettes views.
+Errors that the reference raises as exceptions/assertions surface as TileMotionError.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from ._lib import lib, check, TileMotionError, c_void_p, c_int, c_int64, c_double, c_char_p
+
+
+class TEncoderStep(enum.IntEnum):  # tilingencoder.pas:18
+    esAll = -1
+    esLoad = 0
+    esPredictMotion = 1
+    esReduce = 2
+    esPreparePalettes = 3
+    esDither = 4
+    esReconstruct = 5
+    esReindex = 6
+    esSave = 7
+
+
+class TPsyVisMode(enum.IntEnum):  # tilingencoder.pas:21
+    pvsDCT = 0
+    pvsWeightedDCT = 1
+    pvsWavelets = 2
+    pvsSpeDCT = 3
+    pvsWeightedSpeDCT = 4
+
+
+TILE_HDR = np.dtype([("UseCount", "<u4"), ("TmpIndex", "<i4"), ("MergeIndex", "<i4"), ("PalIdx_Initial", "<i4"), ("Flags", "<u4")])
+TILEMAP_ITEM = np.dtype([("TileIdx", "<i4"), ("PalIdx", "<i4"), ("PredictedX", "i1"), ("PredictedY", "i1"), ("PSNR", "<f4"),
+                         ("Flags", "<u4")])  # packed, 18 bytes (tilingencoder.pas:178-184)
+assert TILE_HDR.itemsize == 20 and TILEMAP_ITEM.itemsize == 18
+
+_ENC_SIGS = {
+    "tm_create": (c_void_p, []),
+    "tm_destroy": (None, [c_void_p]),
+    "tm_set_device": (c_int, [c_void_p, c_int]),
+    "tm_load_default_settings": (c_int, [c_void_p]),
+    "tm_load_settings_ini": (c_int, [c_void_p, c_char_p]),
+    "tm_set_int": (c_int, [c_void_p, c_char_p, c_int64]),
+    "tm_set_float": (c_int, [c_void_p, c_char_p, c_double]),
+    "tm_set_bool": (c_int, [c_void_p, c_char_p, c_int]),
+    "tm_set_str": (c_int, [c_void_p, c_char_p, c_char_p]),
+    "tm_get_int": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_int64)]),
+    "tm_get_float": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_double)]),
+    "tm_set_progress_cb": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "tm_set_video": (c_int, [c_void_p, c_int, c_int, c_double, c_int]),
+    "tm_push_frame_rgb32": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "tm_set_frames_device": (c_int, [c_void_p, c_void_p]),
+    "tm_run": (c_int, [c_void_p, c_int]),
+    "tm_get_counts": (c_int, [c_void_p, ctypes.POINTER(c_int64)] + [ctypes.POINTER(c_int)] * 5),
+    "tm_get_tile": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "tm_get_tiles": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "tm_get_tilemap": (c_int, [c_void_p, c_int, c_void_p]),
+    "tm_get_palette": (c_int, [c_void_p, c_int, c_void_p]),
+    "tm_get_keyframes": (c_int, [c_void_p, c_void_p]),
+    "tm_get_frame_correlations": (c_int, [c_void_p, c_void_p]),
+    "tm_get_stage_ms": (c_int, [c_void_p, c_void_p]),
+    "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
+}
+
+_INT_KEYS = ["StartFrame", "FrameCount", "MotionPredictRadius", "GlobalTilingTileCount", "PaletteSize", "PaletteCount", "DitheringMode",
+             "DitheringYliluoma2MixedColors", "MaxThreadCount"]
+_BOOL_KEYS = ["GlobalTilingUseTargetPSNR", "DitheringUseThomasKnoll", "FrameTilingExtendedPaletteUsage"]
+_FLOAT_KEYS = ["Scaling", "GlobalTilingTargetPSNR", "GlobalTilingQualityBasedTileCount", "ShotTransMaxSecondsPerKF",
+               "ShotTransMinSecondsPerKF", "ShotTransCorrelLoThres"]
+
+
+def _bind():
+    L = lib()
+    if not getattr(L, "_enc_bound", False):
+        for name, (res, args) in _ENC_SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        L._enc_bound = True
+    return L
+
+
+class TilingEncoder:
+    """TTilingEncoder: Create -> settings -> SetVideo/PushFrame (the FFMPEG callback's contract) -> Run(step)."""
+
+    def __init__(self):
+        self._L = _bind()
+        self._h = self._L.tm_create()
+        if not self._h:
+            check(-2)
+        self._frames_ref = None
+
+    def close(self):
+        if self._h:
+            self._L.tm_destroy(c_void_p(self._h))
+            self._h = None
+
+    __del__ = close
+
+    # -- settings (properties named like the Pascal ones)
+    def __getattr__(self, name):
+        if name in _INT_KEYS or name in _BOOL_KEYS:
+            v = c_int64()
+            check(self._L.tm_get_int(c_void_p(self._h), name.encode(), ctypes.byref(v)))
+            return bool(v.value) if name in _BOOL_KEYS else v.value
+        if name in _FLOAT_KEYS:
+            v = c_double()
+            check(self._L.tm_get_float(c_void_p(self._h), name.encode(), ctypes.byref(v)))
+            return v.value
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in _INT_KEYS:
+            check(self._L.tm_set_int(c_void_p(self._h), name.encode(), int(value)))
+        elif name in _BOOL_KEYS:
+            check(self._L.tm_set_bool(c_void_p(self._h), name.encode(), int(bool(value))))
+        elif name in _FLOAT_KEYS:
+            check(self._L.tm_set_float(c_void_p(self._h), name.encode(), float(value)))
+        elif name in ("InputFileName", "OutputFileName"):
+            check(self._L.tm_set_str(c_void_p(self._h), name.encode(), str(value).encode()))
+        else:
+            object.__setattr__(self, name, value)
+
+    def LoadDefaultSettings(self):
+        check(self._L.tm_load_default_settings(c_void_p(self._h)))
+
+    def LoadSettings(self, path):
+        check(self._L.tm_load_settings_ini(c_void_p(self._h), str(path).encode()))
+
+    # -- video
+    def SetVideo(self, width, height, fps, frame_count):
+        check(self._L.tm_set_video(c_void_p(self._h), width, height, float(fps), frame_count))
+
+    def PushFrame(self, index, pixels):
+        """pixels: numpy uint32 [height][width] RGB32 (AV_PIX_FMT_RGB32), host memory, read during the call only"""
+        a = np.ascontiguousarray(pixels, dtype=np.uint32)
+        check(self._L.tm_push_frame_rgb32(c_void_p(self._h), index, a.ctypes.data_as(c_void_p), a.shape[1]))
+
+    def SetFramesDevice(self, frames):
+        """frames: torch int32 CUDA tensor [F][H][W] holding RGB32; borrowed until the encoder is closed"""
+        self._frames_ref = frames
+        check(self._L.tm_set_frames_device(c_void_p(self._h), c_void_p(frames.data_ptr())))
+
+    def Run(self, step=TEncoderStep.esAll):
+        check(self._L.tm_run(c_void_p(self._h), int(step)))
+
+    # -- read-back
+    def counts(self):
+        t = c_int64()
+        v = [c_int() for _ in range(5)]
+        check(self._L.tm_get_counts(c_void_p(self._h), ctypes.byref(t), *[ctypes.byref(x) for x in v]))
+        return dict(tiles=t.value, frames=v[0].value, palettes=v[1].value, tm_w=v[2].value, tm_h=v[3].value, keyframes=v[4].value)
+
+    def Tiles(self, first=0, count=None):
+        n = self.counts()["tiles"]
+        count = n - first if count is None else count
+        hdr = np.zeros(count, TILE_HDR)
+        pal = np.zeros((count, 64), np.uint8)
+        rgb = np.zeros((count, 64), np.uint32)
+        check(self._L.tm_get_tiles(c_void_p(self._h), first, count, hdr.ctypes.data_as(c_void_p), pal.ctypes.data_as(c_void_p),
+                                   rgb.ctypes.data_as(c_void_p)))
+        return hdr, pal, rgb
+
+    def TileMap(self, frame):
+        c = self.counts()
+        items = np.zeros(c["tm_w"] * c["tm_h"], TILEMAP_ITEM)
+        check(self._L.tm_get_tilemap(c_void_p(self._h), frame, items.ctypes.data_as(c_void_p)))
+        return items
+
+    def Palettes(self):
+        c = self.counts()
+        out = np.zeros((c["palettes"], self.PaletteSize), np.int32)
+        for i in range(c["palettes"]):
+            check(self._L.tm_get_palette(c_void_p(self._h), i, out[i].ctypes.data_as(c_void_p)))
+        return out
+
+    def KeyFrames(self):
+        n = self.counts()["keyframes"]
+        out = np.zeros(n, np.int32)
+        check(self._L.tm_get_keyframes(c_void_p(self._h), out.ctypes.data_as(c_void_p)))
+        return out
+
+    def FrameCorrelations(self):
+        out = np.zeros(self.counts()["frames"], np.float32)
+        check(self._L.tm_get_frame_correlations(c_void_p(self._h), out.ctypes.data_as(c_void_p)))
+        return out
+
+    def StageMs(self):
+        out = np.zeros(8, np.float64)
+        check(self._L.tm_get_stage_ms(c_void_p(self._h), out.ctypes.data_as(c_void_p)))
+        return out
