@@ -95,6 +95,15 @@ TM_API int tm_get_keyframes(tm_encoder *, int32_t *start_frames /* keyframes */)
 TM_API int tm_get_frame_correlations(tm_encoder *, float *correl /* frames */);
 TM_API int tm_get_stage_ms(tm_encoder *, double ms[8]); /* wall ms of the last run of each step (ProgressRedraw, :3925) */
 TM_API int tm_save_gtm(tm_encoder *, const char *path);  /* Save, :2040 */
+/* Multi-GPU (one process per GPU): this process matches only frames [first, first+count) in Reconstruct (frames are
+ * independent in the KNN branch, DoXY :1464); the host then merges the per-frame results of all processes with an
+ * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex. */
+enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL = 2 };
+TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
+TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* int32 elements */);
+TM_API int tm_sync_tilemap(tm_encoder *);
+/* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
+TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes);
 
 /* ======================================================================================= stage seam
  * All pointers are DEVICE pointers unless named host_*.  `stream` is a hipStream_t (NULL = default stream).

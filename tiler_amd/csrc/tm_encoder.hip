@@ -116,6 +116,10 @@ struct tm_encoder {
   std::vector<int32_t> palettes_host;
   std::vector<uint8_t> h_fflags;
   double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int shard_first = 0, shard_count = -1;  // query frames this process matches in Reconstruct (multi-GPU: one shard per rank)
+  double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
+  int64_t knn_pairs = 0;
+  int knn_launches = 0, knn_kbytes = 0;
   int steps_done = 0;  // bit per step
 
   int64_t tm_size() const { return (int64_t)tm_w * tm_h; }
@@ -312,13 +316,25 @@ static int step_reconstruct(tm_encoder *e) {
   progress(e, TM_STEP_RECONSTRUCT, 1, 2);
   // query features in frame chunks (bounded scratch for long / 4K clips: streaming through HBM)
   const int64_t per = e->tm_size();
-  int chunk_frames = (int)std::max<int64_t>(1, std::min<int64_t>(e->nframes, ((int64_t)8 << 30) / (per * 384)));
+  const int sf = std::max(0, std::min(e->shard_first, e->nframes));
+  const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
+  if (sf > 0 || sn < e->nframes) {  // frames of other shards: TileIdx -1 / err $FFFFFFFF so an all-reduce(MAX) merges shards
+    TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
+  }
+  e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0;
+  int chunk_frames = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(sn, 1), ((int64_t)8 << 30) / (per * 384)));
   int rc = qf.alloc((size_t)chunk_frames * per * 384);
-  for (int f0 = 0; rc == TM_OK && f0 < e->nframes; f0 += chunk_frames) {
-    const int nf = std::min(chunk_frames, e->nframes - f0);
+  for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
+    const int nf = std::min(chunk_frames, sf + sn - f0);
     const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
     rc = launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream);
     if (rc == TM_OK) rc = knn_index_search(ix, qf.p, n, e->tm_tile.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
+    if (rc == TM_OK) {
+      double ms = 0; int kb = 0; int64_t pairs = 0;
+      knn_index_stats(ix, &ms, &kb, &pairs);
+      e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
+    }
   }
   knn_index_destroy(ix);
   TM_TRY(rc);
@@ -610,6 +626,45 @@ int tm_get_frame_correlations(tm_encoder *e, float *correl) {
 int tm_get_stage_ms(tm_encoder *e, double ms[8]) {
   TM_CHECK(e && ms, TM_E_INVAL, "null argument");
   memcpy(ms, e->stage_ms, sizeof(e->stage_ms));
+  return TM_OK;
+}
+
+int tm_set_query_shard(tm_encoder *e, int first_frame, int frame_count) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(first_frame >= 0, TM_E_INVAL, "bad shard");
+  e->shard_first = first_frame;
+  e->shard_count = frame_count;
+  return TM_OK;
+}
+
+int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
+  TM_CHECK(e && ptr && count, TM_E_INVAL, "null argument");
+  switch (which) {
+    case TM_ARRAY_TILEMAP_TILE: *ptr = e->tm_tile.p; *count = e->q; break;
+    case TM_ARRAY_TILEMAP_ERR: *ptr = e->tm_err.p; *count = e->q; break;
+    case TM_ARRAY_TILEMAP_PAL: *ptr = e->tm_pal.p; *count = e->q; break;
+    default: set_error("bad array id %d", which); return TM_E_INVAL;
+  }
+  return TM_OK;
+}
+
+int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial for every item
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_TRY(need(e, TM_STEP_RECONSTRUCT, "Reconstruct"));
+  TM_HIP(hipSetDevice(e->device));
+  hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
+                     e->tm_pal.as<int32_t>());
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(e->stream));
+  return TM_OK;
+}
+
+int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (kernel_ms) *kernel_ms = e->knn_ms;
+  if (pairs) *pairs = e->knn_pairs;
+  if (launches) *launches = e->knn_launches;
+  if (k_bytes) *k_bytes = e->knn_kbytes;
   return TM_OK;
 }
 

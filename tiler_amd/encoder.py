@@ -63,6 +63,10 @@ _ENC_SIGS = {
     "tm_get_frame_correlations": (c_int, [c_void_p, c_void_p]),
     "tm_get_stage_ms": (c_int, [c_void_p, c_void_p]),
     "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
+    "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
+    "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
+    "tm_sync_tilemap": (c_int, [c_void_p]),
+    "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
 }
 
 _INT_KEYS = ["StartFrame", "FrameCount", "MotionPredictRadius", "GlobalTilingTileCount", "PaletteSize", "PaletteCount", "DitheringMode",
@@ -191,3 +195,26 @@ class TilingEncoder:
         out = np.zeros(8, np.float64)
         check(self._L.tm_get_stage_ms(c_void_p(self._h), out.ctypes.data_as(c_void_p)))
         return out
+
+    # -- multi-GPU plumbing (one process per GPU; collectives stay in the host, see tiler_amd/distributed.py)
+    def SetQueryShard(self, first_frame, frame_count):
+        check(self._L.tm_set_query_shard(c_void_p(self._h), first_frame, frame_count))
+
+    def DeviceArray(self, which):
+        """int32 torch view of an encoder-owned device array (0 TileIdx, 1 KNN error, 2 PalIdx), no copy"""
+        import torch
+        ptr, cnt = c_void_p(), c_int64()
+        check(self._L.tm_get_device_array(c_void_p(self._h), which, ctypes.byref(ptr), ctypes.byref(cnt)))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (cnt.value,), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
+
+        return torch.as_tensor(_View(), device="cuda")
+
+    def SyncTileMap(self):
+        check(self._L.tm_sync_tilemap(c_void_p(self._h)))
+
+    def KnnStats(self):
+        ms, pairs, launches, kb = c_double(), c_int64(), c_int(), c_int()
+        check(self._L.tm_get_knn_stats(c_void_p(self._h), ctypes.byref(ms), ctypes.byref(pairs), ctypes.byref(launches), ctypes.byref(kb)))
+        return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value)
