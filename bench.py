@@ -171,16 +171,18 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
                                f"Thomas-Knoll dither, KNN k=1 (EPU off), motion prediction not built",
-                   "frames": F, "tiles_per_frame": c["tm_w"] * c["tm_h"], "query_tiles": q_total, "global_tiles_T": int(c["tiles"]),
+                   "frames": F, "tiles_per_frame": c["tm_w"] * c["tm_h"], "query_tiles": q_total, "global_tiles_T": int(enc.GlobalTilingTileCount),
+                   "distinct_database_rows": int(ks["db_rows"]), "final_tiles_after_reindex": int(c["tiles"]),
                    "parallelism": f"frames sharded over {world} GPU(s) for Reconstruct; other steps replicated"},
         "tiles_matched_per_sec": q_total / (float(stage_ms[5]) / args.steps * 1e-3) if stage_ms[5] > 0 else None,
         "stage_ms": {n: round(float(v) / args.steps, 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], stage_ms)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_DENSE_PEAK_TOPS,
                      "traffic": None, "kernel": "k_knn_mfma", "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
-                     "note": "int8 ops; algorithmic = 384 ops per (query,tile) pair; the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
+                     "pairs_per_launch": knn_pairs / max(knn_launches, 1),
+                     "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair; the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, int(c["tiles"]) if c["tiles"] > 0 else 320705)
+        out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, int(enc.GlobalTilingTileCount))
         out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

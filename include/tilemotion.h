@@ -103,7 +103,8 @@ TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* 
 TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* int32 elements */);
 TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
-TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes);
+/* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */
+TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows);
 
 /* ======================================================================================= stage seam
  * All pointers are DEVICE pointers unless named host_*.  `stream` is a hipStream_t (NULL = default stream).

@@ -75,13 +75,13 @@ __global__ void k_merge_runs(const uint32_t *__restrict__ sorted, const uint32_t
   }
 }
 
-__global__ void k_rank_keys(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep,
+__global__ void k_rank_keys(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, int by_index,
                             uint32_t *__restrict__ key, unsigned long long *__restrict__ live_count) {
   unsigned long long local = 0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t u = use_rep[uniq[i]];
-    key[i] = ~u;  // ascending ~use == descending use; zero-use rows (~0) sink to the end
-    local += u > 0 ? 1 : 0;
+    key[i] = by_index ? uniq[i] : ~u;  // ascending ~use == descending use; zero-use rows (~0) sink to the end
+    local += (u > 0 || by_index) ? 1 : 0;
   }
   for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(live_count, local);
@@ -101,14 +101,18 @@ __global__ void k_remap(const uint32_t *__restrict__ rep, const int32_t *__restr
 
 static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
 
-int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
-              int64_t *host_n_unique, hipStream_t stream) {
+// by_index = 0: the reference's ReindexTiles order (use desc, content asc), zero-use rows dropped.
+// by_index = 1: representatives in ascending original index (used to search only distinct database rows; any
+//               row_bytes multiple of 16, content compared as dwords).
+int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+                 int64_t *host_n_unique, int by_index, hipStream_t stream) {
   TM_TRY(require_device());
-  TM_CHECK(row_bytes == 256 || row_bytes == 64, TM_E_INVAL, "dedup: row_bytes must be 256 (RGB) or 64 (palette indices)");
+  TM_CHECK(by_index ? (row_bytes > 0 && row_bytes % 16 == 0) : (row_bytes == 256 || row_bytes == 64), TM_E_INVAL,
+           "dedup: row_bytes must be 256 (RGB) or 64 (palette indices)");
   TM_CHECK(n >= 0 && n < (int64_t)1 << 31, TM_E_INVAL, "dedup: row count out of range");
   if (host_n_unique) *host_n_unique = 0;
   if (n == 0) return TM_OK;
-  RowLess less{(const uint32_t *)rows, row_bytes / 4, row_bytes == 64 ? 1 : 0};
+  RowLess less{(const uint32_t *)rows, row_bytes / 4, (!by_index && row_bytes == 64) ? 1 : 0};
   DevBuf idx, sorted, head, headpos, hps, head_excl, rep, use_rep, uniq, key, key2, ord2, pos, tmp, cnt;
   TM_TRY(idx.alloc(n * 4)); TM_TRY(sorted.alloc(n * 4)); TM_TRY(head.alloc(n * 4)); TM_TRY(headpos.alloc(n * 4));
   TM_TRY(head_excl.alloc(n * 4)); TM_TRY(hps.alloc(n * 4)); TM_TRY(rep.alloc(n * 4)); TM_TRY(use_rep.alloc(n * 4)); TM_TRY(uniq.alloc(n * 4));
@@ -138,7 +142,7 @@ int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, vo
   TM_HIP(hipStreamSynchronize(stream));
   const int64_t nu = (int64_t)last_excl + last_head;
   TM_HIP(hipMemsetAsync(cnt.p, 0, 16, stream));
-  hipLaunchKernelGGL(k_rank_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(),
+  hipLaunchKernelGGL(k_rank_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), by_index,
                      key.as<uint32_t>(), cnt.as<unsigned long long>());
   size_t tb4 = 0;
   TM_HIP(rocprim::radix_sort_pairs(nullptr, tb4, key.as<uint32_t>(), key2.as<uint32_t>(), uniq.as<uint32_t>(), ord2.as<uint32_t>(),
@@ -158,6 +162,11 @@ int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, vo
   TM_HIP(hipStreamSynchronize(stream));  // the scratch DevBufs die with this frame
   if (host_n_unique) *host_n_unique = (int64_t)live;
   return TM_OK;
+}
+
+int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+              int64_t *host_n_unique, hipStream_t stream) {
+  return run_dedup_ex(rows, n, row_bytes, use_in, remap, order, use_out, host_n_unique, 0, stream);
 }
 
 }  // namespace tmx

@@ -41,6 +41,10 @@ __global__ void k_lookup(const int32_t *__restrict__ idx, int64_t n, const int32
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = idx[i] >= 0 ? table[idx[i]] : -1;
 }
+__global__ void k_lookup_inplace(int32_t *__restrict__ idx, int64_t n, const int32_t *__restrict__ table) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (idx[i] >= 0) idx[i] = table[idx[i]];
+}
 static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
 
 static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, utils.pas:1038-1041 (TFloat argument)
@@ -120,6 +124,7 @@ struct tm_encoder {
   double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
+  int64_t knn_db_rows = 0;  // distinct database rows actually searched
   int steps_done = 0;  // bit per step
 
   int64_t tm_size() const { return (int64_t)tm_w * tm_h; }
@@ -311,8 +316,20 @@ static int step_reconstruct(tm_encoder *e) {
   DevBuf db, qf;
   TM_TRY(db.alloc((size_t)e->t * 384));
   TM_TRY(launch_features_pal(e->gpal_px.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteSize, TM_PVS_WEIGHTED_DCT, db.p, e->stream));
+  // Many dithered tiles are byte-identical (Reindex merges them later, MakeTilesUnique(False) at 2014).  Under the
+  // lowest-index tie rule the nearest neighbour among ALL rows is the nearest among the DISTINCT rows taken in order of
+  // their first occurrence, so only those are searched; indices are mapped back afterwards.
+  DevBuf u_remap, u_order, u_use, udb;
+  TM_TRY(u_remap.alloc((size_t)e->t * 4)); TM_TRY(u_order.alloc((size_t)e->t * 4)); TM_TRY(u_use.alloc((size_t)e->t * 4));
+  int64_t nu = 0;
+  TM_TRY(run_dedup_ex(db.p, e->t, 384, nullptr, u_remap.p, u_order.p, u_use.p, &nu, 1, e->stream));
+  TM_TRY(udb.alloc((size_t)nu * 384));
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(nu * 24)), dim3(256), 0, e->stream, db.as<uint4>(), u_order.as<int32_t>(), nu, 24,
+                     udb.as<uint4>());
+  TM_HIP(hipGetLastError());
+  e->knn_db_rows = nu;
   tm_knn_index_impl *ix = nullptr;
-  TM_TRY(knn_index_create(db.p, e->t, e->stream, &ix));
+  TM_TRY(knn_index_create(udb.p, nu, e->stream, &ix));
   progress(e, TM_STEP_RECONSTRUCT, 1, 2);
   // query features in frame chunks (bounded scratch for long / 4K clips: streaming through HBM)
   const int64_t per = e->tm_size();
@@ -338,6 +355,7 @@ static int step_reconstruct(tm_encoder *e) {
   }
   knn_index_destroy(ix);
   TM_TRY(rc);
+  hipLaunchKernelGGL(k_lookup_inplace, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, u_order.as<int32_t>());
   hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
                      e->tm_pal.as<int32_t>());  // TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial (1551)
   TM_HIP(hipGetLastError());
@@ -659,7 +677,8 @@ int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx :
   return TM_OK;
 }
 
-int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes) {
+int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows) {
+  if (e && db_rows) *db_rows = e->knn_db_rows;
   TM_CHECK(e, TM_E_INVAL, "null encoder");
   if (kernel_ms) *kernel_ms = e->knn_ms;
   if (pairs) *pairs = e->knn_pairs;

@@ -26,6 +26,8 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
 // tm_dedup.hip
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
               int64_t *host_n_unique, hipStream_t stream);
+int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
+                 int64_t *host_n_unique, int by_index, hipStream_t stream);
 
 // tm_kmeans.hip
 int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,

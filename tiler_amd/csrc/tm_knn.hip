@@ -5,11 +5,12 @@
 // CompareEuclideanDCTPtr (utils.pas:541-557).  Brute force, bit-exact, ties -> lowest database index.
 //
 // Scheme (DESIGN.md "KNN"):
-//   SSD(q,t) = |q-c|^2 + |t-c|^2 - 2 (q-c).(t-c) for any per-column centre c.  Columns whose value range over
-//   Q u T is <= 254 fit one int8 digit after centring; the others ("big", data dependent, mostly DC/low
-//   frequencies) get a balanced base-256 split v = 256 h + l.  With big columns permuted first:
-//      X = 65536 * (T_H . Q_H) + 256 * (T_L[:H] . Q_H + T_H . Q_L[:H]) + T_L . Q_L
-//   = three int32 MFMA accumulators fed by v_mfma_i32_32x32x32_i8, K = 192 + 3H bytes instead of 4*192.
+//   SSD(q,t) = |q-c|^2 + |t-c|^2 - 2 (q-c).(t-c) for any per-column centre c.  On each SIDE (database, queries) a
+//   column whose centred values stay within +-127 fits one int8 digit; the others ("big": data dependent, DC/low
+//   frequencies for source tiles, many more for dithered tiles) get a balanced base-256 split v = 256 h + l.  Columns
+//   are permuted so each side's big columns are a prefix (the smaller set nested in the larger), HT / HQ chunks of 32:
+//      X = 65536 * (T_H . Q_H)[:min] + 256 * (T_L[:HQ] . Q_H + T_H . Q_L[:HT]) + T_L . Q_L
+//   = three int32 MFMA accumulators fed by v_mfma_i32_32x32x32_i8, K = 192 + 32 (HT + HQ + min(HT,HQ)) <= 768 bytes.
 //   The query digits are stored NEGATED, so one lane computes, with nq2 = 2 * (|q-c|^2 >> 1),
 //      d'' = |t-c|^2 + 2 * (acc2<<16 + acc1<<8 + acc0) + nq2  ==  SSD - (|q-c|^2 & 1)   (exact mod 2^32, SSD < 2^31)
 //   with three v_lshl_add_u32 + one add per element, and keeps a running (min d'', first tile) per lane.  Database rows ride
@@ -22,17 +23,15 @@
 
 #include "tm_common.h"
 #include "tm_internal.h"
+#include "tm_knn_kernel.h"
 
 namespace tmx {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
 struct KnnPlan {
-  int hch = 6;            // H / 32, in {0,1,2,3,4,6}
+  int ht = 6, hq = 6;     // 32-column chunks that carry a high digit on the database / query side (0..6)
   int16_t centre[192];    // per source column
-  int16_t perm[192];      // packed position -> source column (big columns first)
-  int nbig = 192;
+  int16_t perm[192];      // packed position -> source column (columns with high digits first, nested sets)
+  int nbig_t = 192, nbig_q = 192;
 };
 
 __host__ __device__ inline int knn_tile_bytes(int hch) { return (6 + hch) * 1024 + 128; }
@@ -122,130 +121,6 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The distance GEMM.  NW waves per workgroup, each holding NQ query sub-tiles (32 queries) as MFMA B fragments in
-// registers for the whole database sweep; database tiles (32 rows) stream global -> registers -> LDS (double
-// buffered) and are read back as A fragments with lane-linear ds_read_b128.
-template <int HCH, int NQ, int NW>
-__global__ __launch_bounds__(NW * 64) void k_knn_mfma(const uint8_t *__restrict__ tpack, int64_t tile_begin, int64_t tile_end,
-                                                      const uint8_t *__restrict__ qpack, int64_t n_qtiles,
-                                                      int *__restrict__ best_key, int *__restrict__ best_tile, int accumulate) {
-  constexpr int KCH = 6 + HCH;
-  constexpr int TILE_BYTES = KCH * 1024 + 128;
-  constexpr int TILE_VEC = TILE_BYTES / 16;
-  constexpr int NT = NW * 64;
-  constexpr int NST = (TILE_VEC + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2][TILE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-  constexpr int QT_PER_WG = NW * NQ;
-  const int64_t n_wg_tiles = (n_qtiles + QT_PER_WG - 1) / QT_PER_WG;
-
-  for (int64_t wgt = blockIdx.x; wgt < n_wg_tiles; wgt += gridDim.x) {
-    v4i bq[NQ][KCH];
-    int nq2[NQ], best[NQ], bestt[NQ];
-    int64_t qtile[NQ];
-#pragma unroll
-    for (int s = 0; s < NQ; s++) {
-      qtile[s] = wgt * QT_PER_WG + wave * NQ + s;
-      const int64_t qt = qtile[s] < n_qtiles ? qtile[s] : n_qtiles - 1;
-      const uint8_t *qb = qpack + qt * (int64_t)TILE_BYTES;
-#pragma unroll
-      for (int kc = 0; kc < KCH; kc++) bq[s][kc] = *reinterpret_cast<const v4i *>(qb + (kc * 64 + lane) * 16);
-      nq2[s] = reinterpret_cast<const int *>(qb + KCH * 1024)[lane & 31] << 1;  // 2*(|q-c|^2 >> 1)
-      best[s] = INT_MAX;
-      bestt[s] = INT_MAX;
-    }
-
-    v4i st[NST];
-    {  // prologue: first database tile -> LDS buffer 0
-      const uint8_t *src = tpack + tile_begin * (int64_t)TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < NST; i++)
-        if (tid + i * NT < TILE_VEC) st[i] = *reinterpret_cast<const v4i *>(src + (tid + i * NT) * 16);
-#pragma unroll
-      for (int i = 0; i < NST; i++)
-        if (tid + i * NT < TILE_VEC) *reinterpret_cast<v4i *>(&lds[0][(tid + i * NT) * 16]) = st[i];
-    }
-    __syncthreads();
-
-    for (int64_t t = tile_begin; t < tile_end; t++) {
-      const int cur = (int)((t - tile_begin) & 1);
-      const bool more = t + 1 < tile_end;
-      if (more) {
-        const uint8_t *src = tpack + (t + 1) * (int64_t)TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NST; i++)
-          if (tid + i * NT < TILE_VEC) st[i] = *reinterpret_cast<const v4i *>(src + (tid + i * NT) * 16);
-      }
-      const uint8_t *L = lds[cur];
-      // accumulator row of register r: (r&3) + 8*(r>>2) + 4*half  -> norms as four 16-byte reads
-      int nt[16];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const v4i x = *reinterpret_cast<const v4i *>(L + KCH * 1024 + (g * 8 + half * 4) * 4);
-        nt[g * 4] = x[0]; nt[g * 4 + 1] = x[1]; nt[g * 4 + 2] = x[2]; nt[g * 4 + 3] = x[3];
-      }
-      // 2-deep software pipeline over the query sub-tiles: the MFMAs of sub-tile s run beside the VALU epilogue of
-      // sub-tile s-1; the sched_barrier keeps hipcc from interleaving more sub-tiles (register budget).
-      v16i acc0[2], acc1[2], acc2[2];
-#pragma unroll
-      for (int s = 0; s <= NQ; s++) {
-        if (s < NQ) {
-          const int b = s & 1;
-#pragma unroll
-          for (int r = 0; r < 16; r++) { acc0[b][r] = 0; acc1[b][r] = 0; acc2[b][r] = 0; }
-#pragma unroll
-          for (int kc = 0; kc < 6; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);  // T_L chunk
-            acc0[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc0[b], 0, 0, 0);                     // T_L . Q_L
-            if (kc < HCH) acc1[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc1[b], 0, 0, 0);  // T_L . Q_H
-          }
-#pragma unroll
-          for (int kc = 0; kc < HCH; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
-            acc1[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc1[b], 0, 0, 0);      // T_H . Q_L
-            acc2[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc2[b], 0, 0, 0);  // T_H . Q_H
-          }
-        }
-        if (s > 0) {
-          const int b = (s - 1) & 1;
-          int m = INT_MAX;
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            int x = acc0[b][r];
-            if (HCH > 0) x = (int)(((unsigned)(((unsigned)acc2[b][r] << 8) + (unsigned)acc1[b][r]) << 8) + (unsigned)acc0[b][r]);
-            const int d = (int)(((unsigned)x << 1) + (unsigned)nt[r] + (unsigned)nq2[s - 1]);
-            m = min(m, d);
-          }
-          if (m < best[s - 1]) { best[s - 1] = m; bestt[s - 1] = (int)t; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < NST; i++)
-          if (tid + i * NT < TILE_VEC) *reinterpret_cast<v4i *>(&lds[cur ^ 1][(tid + i * NT) * 16]) = st[i];
-      }
-      __syncthreads();
-    }
-
-#pragma unroll
-    for (int s = 0; s < NQ; s++) {
-      const int ob = __shfl_xor(best[s], 32), ot = __shfl_xor(bestt[s], 32);
-      if (ob < best[s] || (ob == best[s] && ot < bestt[s])) { best[s] = ob; bestt[s] = ot; }
-      if (lane < 32 && qtile[s] < n_qtiles) {
-        const int64_t q = qtile[s] * 32 + lane;
-        if (accumulate) {
-          const int pk = best_key[q], pt = best_tile[q];
-          if (pk < best[s] || (pk == best[s] && pt < bestt[s])) { best[s] = pk; bestt[s] = pt; }
-        }
-        best_key[q] = best[s];
-        best_tile[q] = bestt[s];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Rescan the winning 32-row tile of each query with the plain SSD (CompareEuclideanDCTPtr, utils.pas:541-557).
 // One wave per query, lanes 0..31 = rows of the tile; min by (ssd, row).
 __global__ __launch_bounds__(256) void k_knn_refine(const int16_t *__restrict__ queries, int64_t nq, const int16_t *__restrict__ db,
@@ -310,37 +185,55 @@ static void merge_stats(ColStats &a, const ColStats &b) {
   for (int i = 0; i < 192; i++) { a.mn[i] = std::min(a.mn[i], b.mn[i]); a.mx[i] = std::max(a.mx[i], b.mx[i]); }
 }
 
-static const int kHchVariants[] = {0, 1, 2, 3, 4, 6};
-
-static int make_plan(const ColStats &st, KnnPlan *plan) {
-  int big[192], nbig = 0, small_[192], nsmall = 0;
+// Per-side digit plan.  For every column pick the centre (midpoint of the union, of the database or of the query range)
+// that needs the fewest int8 products, then nest the smaller big-set into the larger one so both are prefixes.
+static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
+  bool tb[192], qb[192];
   for (int c = 0; c < 192; c++) {
-    int lo = st.mn[c], hi = st.mx[c];
-    if (lo > hi) { lo = 0; hi = 0; }  // no rows
-    const int range = hi - lo;
-    plan->centre[c] = (int16_t)(lo + range / 2);
-    if (range > 254) big[nbig++] = c; else small_[nsmall++] = c;
+    int tlo = ts.mn[c], thi = ts.mx[c], qlo = qs.mn[c], qhi = qs.mx[c];
+    if (tlo > thi) { tlo = qlo; thi = qhi; }
+    if (qlo > qhi) { qlo = tlo; qhi = thi; }
+    if (tlo > thi) { tlo = thi = qlo = qhi = 0; }
+    const int ulo = std::min(tlo, qlo), uhi = std::max(thi, qhi);
+    const int cand[3] = {ulo + (uhi - ulo) / 2, tlo + (thi - tlo) / 2, qlo + (qhi - qlo) / 2};
+    int best_cost = 99, best_c = cand[0];
+    bool bt = true, bq = true;
+    for (int k = 0; k < 3; k++) {
+      const int cc = cand[k];
+      const bool t2 = (thi - cc > 127) || (cc - tlo > 127), q2 = (qhi - cc > 127) || (cc - qlo > 127);
+      const int cost = 1 + (t2 ? 1 : 0) + (q2 ? 1 : 0) + (t2 && q2 ? 1 : 0);
+      if (cost < best_cost) { best_cost = cost; best_c = cc; bt = t2; bq = q2; }
+    }
+    plan->centre[c] = (int16_t)best_c;
+    tb[c] = bt;
+    qb[c] = bq;
   }
-  int hch = -1;
-  for (int v : kHchVariants)
-    if (nbig <= v * 32) { hch = v; break; }
-  TM_CHECK(hch >= 0, TM_E_INVAL, "knn plan: %d big columns", nbig);
+  int nt = 0, nq = 0, nu = 0;
+  for (int c = 0; c < 192; c++) { nt += tb[c]; nq += qb[c]; nu += (tb[c] || qb[c]); }
+  auto chunks = [](int n) { return (n + 31) / 32; };
+  // option A: queries' set inside the database's (database digits widened to the union); option B the other way round
+  const int costA = chunks(nu) + 2 * chunks(nq), costB = chunks(nu) + 2 * chunks(nt);
+  const bool a = costA <= costB;
+  const bool *inner = a ? qb : tb;
   int p = 0;
-  for (int i = 0; i < nbig; i++) plan->perm[p++] = (int16_t)big[i];
-  for (int i = 0; i < nsmall; i++) plan->perm[p++] = (int16_t)small_[i];
-  plan->hch = hch;
-  plan->nbig = nbig;
+  for (int c = 0; c < 192; c++) if (inner[c]) plan->perm[p++] = (int16_t)c;
+  for (int c = 0; c < 192; c++) if (!inner[c] && (tb[c] || qb[c])) plan->perm[p++] = (int16_t)c;
+  for (int c = 0; c < 192; c++) if (!tb[c] && !qb[c]) plan->perm[p++] = (int16_t)c;
+  plan->ht = a ? chunks(nu) : chunks(nt);
+  plan->hq = a ? chunks(nq) : chunks(nu);
+  plan->nbig_t = nt;
+  plan->nbig_q = nq;
   return TM_OK;
 }
 
-// does `plan` represent every value of `st` exactly?
-static bool plan_covers(const KnnPlan &plan, const ColStats &st) {
+// does `plan` represent every value of one side's statistics exactly?  (both signs are checked: queries are negated)
+static bool plan_covers(const KnnPlan &plan, const ColStats &st, int hch) {
   for (int p = 0; p < 192; p++) {
     const int c = plan.perm[p];
     if (st.mn[c] > st.mx[c]) continue;
     const int lo = st.mn[c] - plan.centre[c], hi = st.mx[c] - plan.centre[c];
-    if (p >= plan.hch * 32) {
-      if (lo < -127 || hi > 127) return false;  // both signs are packed (database v-c, queries c-v)
+    if (p >= hch * 32) {
+      if (lo < -127 || hi > 127) return false;
     } else {
       if (lo < -32000 || hi > 32000) return false;
     }
@@ -375,43 +268,26 @@ static int upload_plan(tm_knn_index_impl *ix, hipStream_t stream) {
   return TM_OK;
 }
 
-static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int negate, DevBuf &out, hipStream_t stream) {
+static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int negate, int hch, DevBuf &out, hipStream_t stream) {
   const int64_t ntiles = (n + 31) / 32;
-  TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(ix->plan.hch)));
+  TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch)));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   int grid = (int)std::min<int64_t>(ntiles, 4096);
-  hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, ix->plan.hch, negate,
+  hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate,
                      ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, out.as<uint8_t>(), ix->err_flag.as<int>());
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
 
-// Workgroup shapes: variant 0 = 8 waves x 2 query sub-tiles (2 waves/SIMD, <=256 VGPRs), variant 1 = 4 waves x 4
-// (1 wave/SIMD, 512 VGPRs), variant 2 = 4 waves x 3.  TM_KNN_VARIANT overrides the default for A/B runs.
-static int knn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("TM_KNN_VARIANT");
-    v = e ? atoi(e) : 0;
-    if (v < 0 || v > 2) v = 0;
-  }
-  return v;
-}
-
-template <int HCH, int NQ, int NW>
-static void launch_mfma_v(const uint8_t *tpack, int64_t tb, int64_t te, const uint8_t *qpack, int64_t nqt, int *bk, int *bt, int acc,
-                          int ncu, hipStream_t stream) {
-  const int64_t wg_tiles = (nqt + NQ * NW - 1) / (NQ * NW);
-  const int grid = (int)std::min<int64_t>(wg_tiles, ncu);
-  hipLaunchKernelGGL((k_knn_mfma<HCH, NQ, NW>), dim3(grid), dim3(NW * 64), 0, stream, tpack, tb, te, qpack, nqt, bk, bt, acc);
-}
-
-template <int HCH> static void launch_mfma(const uint8_t *tpack, int64_t tb, int64_t te, const uint8_t *qpack, int64_t nqt, int *bk,
-                                           int *bt, int acc, int ncu, hipStream_t stream) {
-  switch (knn_variant()) {
-    case 0: launch_mfma_v<HCH, 2, 8>(tpack, tb, te, qpack, nqt, bk, bt, acc, ncu, stream); break;
-    case 2: launch_mfma_v<HCH, 3, 4>(tpack, tb, te, qpack, nqt, bk, bt, acc, ncu, stream); break;
-    default: launch_mfma_v<HCH, 4, 4>(tpack, tb, te, qpack, nqt, bk, bt, acc, ncu, stream); break;
+static void launch_mfma(int ht, int hq, const KnnLaunch &a) {
+  switch (ht) {
+    case 0: knn_launch_ht<0>(hq, a); break;
+    case 1: knn_launch_ht<1>(hq, a); break;
+    case 2: knn_launch_ht<2>(hq, a); break;
+    case 3: knn_launch_ht<3>(hq, a); break;
+    case 4: knn_launch_ht<4>(hq, a); break;
+    case 5: knn_launch_ht<5>(hq, a); break;
+    default: knn_launch_ht<6>(hq, a); break;
   }
 }
 
@@ -446,15 +322,19 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
-  if (!ix->packed || !plan_covers(ix->plan, qs)) {
-    ColStats u = ix->tstats;
-    merge_stats(u, qs);
-    TM_TRY(make_plan(u, &ix->plan));
+  if (!ix->packed || !plan_covers(ix->plan, qs, ix->plan.hq)) {
+    TM_TRY(make_plan(ix->tstats, qs, &ix->plan));
+    TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
+             "knn: feature range exceeds the exact two-digit int8 split");
+    if (getenv("TM_KNN_DEBUG"))
+      fprintf(stderr, "[tm_knn] nq=%lld nt=%lld big columns: database %d, queries %d -> HT=%d HQ=%d K=%d bytes\n", (long long)nq,
+              (long long)ix->nt, ix->plan.nbig_t, ix->plan.nbig_q, ix->plan.ht, ix->plan.hq,
+              192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq)));
     TM_TRY(upload_plan(ix, stream));
-    TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->tpack, stream));
+    TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->plan.ht, ix->tpack, stream));
     ix->packed = true;
   }
-  TM_TRY(run_pack(ix, queries, nq, 1, ix->qpack, stream));
+  TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qpack, stream));
   const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
@@ -462,16 +342,9 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_HIP(hipGetDevice(&dev));
   TM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
   TM_HIP(hipEventRecord(ix->ev0, stream));
-  const uint8_t *tp = ix->tpack.as<uint8_t>(), *qp = ix->qpack.as<uint8_t>();
-  int *bk = ix->best_key.as<int>(), *bt = ix->best_tile.as<int>();
-  switch (ix->plan.hch) {
-    case 0: launch_mfma<0>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-    case 1: launch_mfma<1>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-    case 2: launch_mfma<2>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-    case 3: launch_mfma<3>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-    case 4: launch_mfma<4>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-    default: launch_mfma<6>(tp, 0, ntt, qp, nqt, bk, bt, 0, ncu, stream); break;
-  }
+  int *bt = ix->best_tile.as<int>();
+  launch_mfma(ix->plan.ht, ix->plan.hq,
+              KnnLaunch{ix->tpack.as<uint8_t>(), 0, ntt, ix->qpack.as<uint8_t>(), nqt, ix->best_key.as<int>(), bt, 0, ncu, stream});
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
@@ -487,7 +360,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   float ms = 0;
   TM_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
   ix->last_ms = ms;
-  ix->last_kbytes = 192 + 3 * 32 * ix->plan.hch;
+  ix->last_kbytes = 192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
   ix->last_pairs = nq * ix->nt;
   return TM_OK;
 }

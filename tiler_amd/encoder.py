@@ -66,7 +66,8 @@ _ENC_SIGS = {
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
-    "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                         ctypes.POINTER(c_int64)]),
 }
 
 _INT_KEYS = ["StartFrame", "FrameCount", "MotionPredictRadius", "GlobalTilingTileCount", "PaletteSize", "PaletteCount", "DitheringMode",
@@ -215,6 +216,7 @@ class TilingEncoder:
         check(self._L.tm_sync_tilemap(c_void_p(self._h)))
 
     def KnnStats(self):
-        ms, pairs, launches, kb = c_double(), c_int64(), c_int(), c_int()
-        check(self._L.tm_get_knn_stats(c_void_p(self._h), ctypes.byref(ms), ctypes.byref(pairs), ctypes.byref(launches), ctypes.byref(kb)))
-        return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value)
+        ms, pairs, launches, kb, rows = c_double(), c_int64(), c_int(), c_int(), c_int64()
+        check(self._L.tm_get_knn_stats(c_void_p(self._h), ctypes.byref(ms), ctypes.byref(pairs), ctypes.byref(launches), ctypes.byref(kb),
+                                       ctypes.byref(rows)))
+        return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value, db_rows=rows.value)
