@@ -17,6 +17,10 @@
 //   the MFMA A operand (accumulator rows), queries the B operand (accumulator columns = lanes), so the argmin of a
 //   query never leaves its lane until the final 2-lane merge.  A second tiny kernel rescans the winning 32-row
 //   tile with the plain int16 SSD to produce (index, error) under the lowest-index rule.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
@@ -34,7 +38,7 @@ struct KnnPlan {
   int nbig_t = 192, nbig_q = 192;
 };
 
-__host__ __device__ inline int knn_tile_bytes(int hch) { return (6 + hch) * 1024 + 128; }
+__host__ __device__ inline int knn_tile_bytes(int hch, int with_box) { return (6 + hch) * 1024 + 128 + (with_box ? 64 : 0); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // per-column min/max over n rows.  192 threads: thread = (row slot 0..7, 16-byte vector 0..23).
@@ -64,17 +68,21 @@ __global__ __launch_bounds__(192) void k_col_minmax(const int16_t *__restrict__ 
   if (a != INT_MAX) { atomicMin(&mn[c], a); atomicMax(&mx[c], b); }
 }
 
+struct CurveSpec { int col[KNN_ND]; int lo[3]; int range[3]; };
+
 // ---------------------------------------------------------------------------------------------------------------
 // Pack n rows into MFMA fragment order: per 32-row tile [kc][64 lanes][16 B] (lane = half*32 + row) followed by
 // 32 u32 norms.  negate=1 (query side): digits of (c - v) and norm >> 1; negate=0 (database): digits of (v - c).
 // Rows >= n replicate row n-1 (ties resolve to the lower, real index).  err_flag is set if a digit overflows int8.
 __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ feat, int64_t n, int64_t ntiles, int hch, int negate,
                                                   const int16_t *__restrict__ centre, const int16_t *__restrict__ perm,
-                                                  uint8_t *__restrict__ out, int *__restrict__ err_flag) {
+                                                  const uint32_t *__restrict__ rowperm, int with_box, CurveSpec cs,
+                                                  int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
+                                                  int *__restrict__ err_flag) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ int s_v[32][193];
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
-  const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch);
+  const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch, with_box);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
     // centred, permuted values of the 32 rows
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       const int r = i / 192, p = i - r * 192;
       int64_t row = tile * 32 + r;
       if (row >= n) row = n - 1;
+      if (rowperm) row = rowperm[row];  // rows are packed in DC-sorted order
       const int v = (int)feat[row * 192 + s_p[p]] - (int)s_c[p];
       s_v[r][p] = negate ? -v : v;
     }
@@ -117,34 +126,86 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       reinterpret_cast<uint32_t *>(obase + kch * 1024)[threadIdx.x] = negate ? (s >> 1) : s;
     }
     if (bad) atomicOr(err_flag, 1);
+    if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + KNN_ND) {  // bounding box of the tile over the box columns (raw values)
+      const int d = threadIdx.x - 64;
+      int a = INT_MAX, b = INT_MIN;
+      for (int r = 0; r < 32; r++) {
+        int64_t row = tile * 32 + r;
+        if (row >= n) break;
+        if (rowperm) row = rowperm[row];
+        const int v = feat[row * 192 + cs.col[d]];
+        a = min(a, v);
+        b = max(b, v);
+      }
+      int *tb = reinterpret_cast<int *>(obase + kch * 1024 + 128);
+      tb[d] = a;
+      tb[KNN_ND + d] = b;
+      box_lo[(int64_t)d * ntiles + tile] = a;
+      box_hi[(int64_t)d * ntiles + tile] = b;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ff;
+  v = (v | (v << 16)) & 0x030000ff;
+  v = (v | (v << 8)) & 0x0300f00f;
+  v = (v | (v << 4)) & 0x030c30c3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+
+// Morton key of the three widest columns (10 bits each over the union range), value = row index
+__global__ void k_curve_keys(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, uint32_t *__restrict__ key,
+                             uint32_t *__restrict__ idx) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t k = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      long long v = (long long)feat[i * 192 + cs.col[d]] - cs.lo[d];
+      v = v < 0 ? 0 : (v > cs.range[d] ? cs.range[d] : v);
+      k |= spread10((uint32_t)(v * 1023 / max(cs.range[d], 1))) << d;
+    }
+    key[i] = k;
+    idx[i] = (uint32_t)i;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Rescan the winning 32-row tile of each query with the plain SSD (CompareEuclideanDCTPtr, utils.pas:541-557).
-// One wave per query, lanes 0..31 = rows of the tile; min by (ssd, row).
-__global__ __launch_bounds__(256) void k_knn_refine(const int16_t *__restrict__ queries, int64_t nq, const int16_t *__restrict__ db,
-                                                    int64_t nt, const int *__restrict__ best_tile, int *__restrict__ out_idx,
-                                                    uint32_t *__restrict__ out_err) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nq; q += (int64_t)gridDim.x * 4) {
-    const int64_t row = (int64_t)best_tile[q] * 32 + (lane & 31);
-    unsigned long long key = ~0ull;
-    if (lane < 32 && row < nt) {
-      const v4i *qp = reinterpret_cast<const v4i *>(queries + q * 192);
-      const v4i *tp = reinterpret_cast<const v4i *>(db + row * 192);
-      uint32_t ssd = 0;
+// Rescan the winning 32-row tile of each query with the plain SSD (CompareEuclideanDCTPtr, utils.pas:541-557) and
+// apply the lowest-ORIGINAL-index rule inside it.  One wave per (sorted) query, lanes 0..31 = rows of the tile.
+// Queries whose minimum was reached by a second tile (tie flag) are queued for k_knn_ties.
+__device__ __forceinline__ uint32_t ssd_rows(const int16_t *__restrict__ a, const int16_t *__restrict__ b) {
+  const v4i *qp = reinterpret_cast<const v4i *>(a);
+  const v4i *tp = reinterpret_cast<const v4i *>(b);
+  uint32_t ssd = 0;
 #pragma unroll 4
-      for (int v = 0; v < 24; v++) {
-        const v4i a = qp[v], b = tp[v];
+  for (int v = 0; v < 24; v++) {
+    const v4i x = qp[v], y = tp[v];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int d0 = (int)(int16_t)(a[i] & 0xffff) - (int)(int16_t)(b[i] & 0xffff);
-          const int d1 = (a[i] >> 16) - (b[i] >> 16);
-          ssd += (uint32_t)(d0 * d0) + (uint32_t)(d1 * d1);
-        }
-      }
-      key = ((unsigned long long)ssd << 32) | (unsigned long long)(uint32_t)row;
+    for (int i = 0; i < 4; i++) {
+      const int d0 = (int)(int16_t)(x[i] & 0xffff) - (int)(int16_t)(y[i] & 0xffff);
+      const int d1 = (x[i] >> 16) - (y[i] >> 16);
+      ssd += (uint32_t)(d0 * d0) + (uint32_t)(d1 * d1);
+    }
+  }
+  return ssd;
+}
+
+__global__ __launch_bounds__(256) void k_knn_refine(const int16_t *__restrict__ queries, int64_t nq, const uint32_t *__restrict__ qperm,
+                                                    const int16_t *__restrict__ db, int64_t nt, const uint32_t *__restrict__ tperm,
+                                                    const int *__restrict__ best_tile, int *__restrict__ out_idx,
+                                                    uint32_t *__restrict__ out_err, uint32_t *__restrict__ tie_list,
+                                                    unsigned int *__restrict__ tie_count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < nq; p += (int64_t)gridDim.x * 4) {
+    const int bt = best_tile[p];
+    const int64_t q = qperm[p];
+    const int64_t srow = (int64_t)(bt & 0x3fffffff) * 32 + (lane & 31);
+    unsigned long long key = ~0ull;
+    if (lane < 32 && srow < nt) {
+      const uint32_t orow = tperm[srow];
+      key = ((unsigned long long)ssd_rows(queries + q * 192, db + (int64_t)orow * 192) << 32) | (unsigned long long)orow;
     }
     for (int o = 16; o > 0; o >>= 1) {
       const unsigned long long other = __shfl_xor(key, o);
@@ -153,7 +214,50 @@ __global__ __launch_bounds__(256) void k_knn_refine(const int16_t *__restrict__ 
     if (lane == 0) {
       out_idx[q] = (int)(uint32_t)(key & 0xffffffffull);
       out_err[q] = (uint32_t)(key >> 32);
+      if (bt & (1 << 30)) tie_list[atomicAdd(tie_count, 1u)] = (uint32_t)p;
     }
+  }
+}
+
+// Tie settlement: another tile reached the same minimum.  Every row with SSD == best lives in a tile whose box is
+// within sqrt(best) of the query, so a box test over all tiles finds the candidates; keep the lowest original index.
+// One workgroup per tie, thread = tile.
+__global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
+                                                  const int16_t *__restrict__ db, int64_t nt, int64_t n_ttiles,
+                                                  const uint32_t *__restrict__ tperm, KnnBoxes bx,
+                                                  const uint32_t *__restrict__ tie_list, const unsigned int *__restrict__ tie_count,
+                                                  int *__restrict__ out_idx, const uint32_t *__restrict__ out_err) {
+  __shared__ unsigned int s_min;
+  for (unsigned int k = blockIdx.x; k < *tie_count; k += gridDim.x) {
+    const uint32_t p = tie_list[k];
+    const int64_t q = qperm[p];
+    const int16_t *qrow = queries + q * 192;
+    const uint32_t best = out_err[q];
+    int qv[KNN_ND];
+#pragma unroll
+    for (int d = 0; d < KNN_ND; d++) qv[d] = qrow[bx.col[d]];
+    if (threadIdx.x == 0) s_min = 0xffffffffu;
+    __syncthreads();
+    unsigned int mine = 0xffffffffu;
+    for (int64_t t = threadIdx.x; t < n_ttiles; t += 256) {
+      long long lb = 0;
+#pragma unroll
+      for (int d = 0; d < KNN_ND; d++) {
+        const long long g = max(0, max(bx.lo[(int64_t)d * n_ttiles + t] - qv[d], qv[d] - bx.hi[(int64_t)d * n_ttiles + t]));
+        lb += g * g;
+      }
+      if (lb > (long long)best) continue;
+      for (int r = 0; r < 32; r++) {
+        const int64_t sr = t * 32 + r;
+        if (sr >= nt) break;
+        const uint32_t orow = tperm[sr];
+        if (orow < mine && ssd_rows(qrow, db + (int64_t)orow * 192) == best) mine = orow;
+      }
+    }
+    if (mine != 0xffffffffu) atomicMin(&s_min, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_min != 0xffffffffu) out_idx[q] = (int)s_min;
+    __syncthreads();
   }
 }
 
@@ -248,6 +352,11 @@ struct tm_knn_index_impl {
   KnnPlan plan;
   bool packed = false;
   DevBuf tpack, qpack, plan_dev, scratch, best_key, best_tile, err_flag;
+  DevBuf tperm, tkey, box_lo, box_hi;               // database sorted along the curve, per-tile boxes
+  DevBuf qperm, qkey, skey, skey2, sidx, sort_tmp;  // queries sorted along the curve
+  CurveSpec curve;
+  DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
+  int64_t last_visited = 0, last_ties = 0;
   double last_ms = 0;
   int last_kbytes = 0;
   int64_t last_pairs = 0;
@@ -268,13 +377,32 @@ static int upload_plan(tm_knn_index_impl *ix, hipStream_t stream) {
   return TM_OK;
 }
 
-static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int negate, int hch, DevBuf &out, hipStream_t stream) {
+// rows sorted along the Morton curve: perm (row order) and the sorted keys
+static int sort_by_curve(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &perm, DevBuf &keys_sorted, hipStream_t stream) {
+  TM_TRY(ix->skey.alloc((size_t)n * 4)); TM_TRY(ix->sidx.alloc((size_t)n * 4));
+  TM_TRY(perm.alloc((size_t)n * 4)); TM_TRY(keys_sorted.alloc((size_t)n * 4));
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_curve_keys, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve, ix->skey.as<uint32_t>(),
+                     ix->sidx.as<uint32_t>());
+  size_t tb = 0;
+  TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, ix->skey.as<uint32_t>(), keys_sorted.as<uint32_t>(), ix->sidx.as<uint32_t>(),
+                                   perm.as<uint32_t>(), (size_t)n, 0, 30, stream));
+  TM_TRY(ix->sort_tmp.alloc(tb));
+  TM_HIP(rocprim::radix_sort_pairs(ix->sort_tmp.p, tb, ix->skey.as<uint32_t>(), keys_sorted.as<uint32_t>(), ix->sidx.as<uint32_t>(),
+                                   perm.as<uint32_t>(), (size_t)n, 0, 30, stream));
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int negate, int hch, const DevBuf &perm, int with_box,
+                    DevBuf &out, hipStream_t stream) {
   const int64_t ntiles = (n + 31) / 32;
-  TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch)));
+  TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch, with_box)));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   int grid = (int)std::min<int64_t>(ntiles, 4096);
   hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate,
-                     ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, out.as<uint8_t>(), ix->err_flag.as<int>());
+                     ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, perm.as<uint32_t>(), with_box, ix->curve,
+                     ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>());
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -322,6 +450,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
+  const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
   if (!ix->packed || !plan_covers(ix->plan, qs, ix->plan.hq)) {
     TM_TRY(make_plan(ix->tstats, qs, &ix->plan));
     TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
@@ -331,37 +460,77 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
               (long long)ix->nt, ix->plan.nbig_t, ix->plan.nbig_q, ix->plan.ht, ix->plan.hq,
               192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq)));
     TM_TRY(upload_plan(ix, stream));
-    TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->plan.ht, ix->tpack, stream));
+    {  // curve + box columns: the KNN_ND widest columns of the union; the first three drive the Morton order
+      int order[192];
+      for (int c = 0; c < 192; c++) order[c] = c;
+      auto urange = [&](int c) {
+        const int lo = std::min(ix->tstats.mn[c], qs.mn[c]), hi = std::max(ix->tstats.mx[c], qs.mx[c]);
+        return hi >= lo ? hi - lo : 0;
+      };
+      std::stable_sort(order, order + 192, [&](int a, int b) { return urange(a) > urange(b); });
+      for (int d = 0; d < KNN_ND; d++) ix->curve.col[d] = order[d];
+      for (int d = 0; d < 3; d++) {
+        const int c = order[d];
+        ix->curve.lo[d] = std::min(ix->tstats.mn[c], qs.mn[c]);
+        ix->curve.range[d] = std::max(1, urange(c));
+      }
+    }
+    TM_TRY(sort_by_curve(ix, ix->db, ix->nt, ix->tperm, ix->skey2, stream));
+    TM_TRY(ix->tkey.alloc((size_t)ntt * 4));
+    TM_HIP(hipMemcpy2DAsync(ix->tkey.p, 4, ix->skey2.p, 128, 4, (size_t)ntt, hipMemcpyDeviceToDevice, stream));  // key of each tile's first row
+    TM_TRY(ix->box_lo.alloc((size_t)ntt * KNN_ND * 4));
+    TM_TRY(ix->box_hi.alloc((size_t)ntt * KNN_ND * 4));
+    TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->plan.ht, ix->tperm, 1, ix->tpack, stream));
     ix->packed = true;
   }
-  TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qpack, stream));
-  const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
+  TM_TRY(sort_by_curve(ix, queries, nq, ix->qperm, ix->qkey, stream));
+  TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qperm, 0, ix->qpack, stream));
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
-  int dev = 0, ncu = 256;
-  TM_HIP(hipGetDevice(&dev));
-  TM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
+  TM_TRY(ix->counters.alloc(32));
+  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 32, stream));
+  static const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;
   TM_HIP(hipEventRecord(ix->ev0, stream));
   int *bt = ix->best_tile.as<int>();
+  KnnBoxes bx;
+  bx.lo = ix->box_lo.as<int>();
+  bx.hi = ix->box_hi.as<int>();
+  bx.tkey = ix->tkey.as<uint32_t>();
+  for (int d = 0; d < KNN_ND; d++) bx.col[d] = ix->curve.col[d];
   launch_mfma(ix->plan.ht, ix->plan.hq,
-              KnnLaunch{ix->tpack.as<uint8_t>(), 0, ntt, ix->qpack.as<uint8_t>(), nqt, ix->best_key.as<int>(), bt, 0, ncu, stream});
+              KnnLaunch{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
+                        ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt,
+                        reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16), stream});
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
     int grid = (int)std::min<int64_t>((nq + 3) / 4, 8192);
-    hipLaunchKernelGGL(k_knn_refine, dim3(grid), dim3(256), 0, stream, (const int16_t *)queries, nq, ix->db, ix->nt, bt,
-                       (int *)out_idx, (uint32_t *)out_err);
+    hipLaunchKernelGGL(k_knn_refine, dim3(grid), dim3(256), 0, stream, (const int16_t *)queries, nq, ix->qperm.as<uint32_t>(), ix->db, ix->nt,
+                       ix->tperm.as<uint32_t>(), bt, (int *)out_idx, (uint32_t *)out_err, ix->tie_list.as<uint32_t>(),
+                       ix->counters.as<unsigned int>());
+    hipLaunchKernelGGL(k_knn_ties, dim3(1024), dim3(256), 0, stream, (const int16_t *)queries, ix->qperm.as<uint32_t>(), ix->db, ix->nt, ntt,
+                       ix->tperm.as<uint32_t>(), bx, ix->tie_list.as<uint32_t>(), ix->counters.as<unsigned int>(), (int *)out_idx,
+                       (const uint32_t *)out_err);
     TM_HIP(hipGetLastError());
   }
   int flag = 0;
+  unsigned long long cnt[4] = {0, 0, 0, 0};
   TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 32, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   float ms = 0;
   TM_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
   ix->last_ms = ms;
   ix->last_kbytes = 192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
-  ix->last_pairs = nq * ix->nt;
+  ix->last_visited = (int64_t)cnt[2];
+  ix->last_ties = (int64_t)(cnt[0] & 0xffffffffull);
+  ix->last_pairs = ix->last_visited * 1024;  // (database tile, query sub-tile) blocks of 32 x 32 pairs actually evaluated
+  if (getenv("TM_KNN_DEBUG"))
+    fprintf(stderr, "[tm_knn] kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (workgroups staged %.3f%% of tiles), %lld tie settlements\n", ms,
+            100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt,
+            100.0 * (double)cnt[3] / ((double)((nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW)) * (double)ntt), (long long)ix->last_ties);
   return TM_OK;
 }
 
