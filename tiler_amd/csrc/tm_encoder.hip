@@ -211,15 +211,15 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   TM_TRY(e->flab.alloc((size_t)e->q * 12));
   TM_TRY(launch_load(e->frames, e->nframes, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.p, e->fflags.p, e->flab.p, e->stream));
   progress(e, TM_STEP_LOAD, 1, 3);
-  // inter-frame correlation on the host: a 43 200-term sequential Single sum per frame (order matters)
-  std::vector<float> lab((size_t)e->q * 3);
-  e->h_fflags.resize((size_t)e->q);
-  TM_HIP(hipMemcpyAsync(lab.data(), e->flab.p, lab.size() * 4, hipMemcpyDeviceToHost, e->stream));
-  TM_HIP(hipMemcpyAsync(e->h_fflags.data(), e->fflags.p, (size_t)e->q, hipMemcpyDeviceToHost, e->stream));
-  TM_HIP(hipStreamSynchronize(e->stream));
+  // inter-frame correlation: one GPU thread per frame runs the reference's sequential Single sums (order matters)
   const int per = (int)e->tm_size() * 3;
+  DevBuf dcorrel;
+  TM_TRY(dcorrel.alloc((size_t)e->nframes * 4));
+  TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
   e->correl.assign(e->nframes, 0.0f);
-  for (int f = 1; f < e->nframes; f++) e->correl[f] = pearson(&lab[(size_t)(f - 1) * per], &lab[(size_t)f * per], per);
+  e->h_fflags.clear();  // fetched lazily by tm_get_tilemap
+  TM_HIP(hipMemcpyAsync(e->correl.data(), dcorrel.p, (size_t)e->nframes * 4, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_LOAD, 2, 3);
   // FindKeyFrames, automatic mode (3373-3411)
   e->kf_start.clear();
@@ -604,6 +604,10 @@ int tm_get_tilemap(tm_encoder *e, int frame, tm_tilemap_item *items) {
   TM_CHECK(e && items, TM_E_INVAL, "null argument");
   TM_CHECK(frame >= 0 && frame < e->nframes && (e->steps_done & 1), TM_E_INVAL, "bad frame %d", frame);
   TM_HIP(hipSetDevice(e->device));
+  if (e->h_fflags.size() != (size_t)e->q) {
+    e->h_fflags.resize((size_t)e->q);
+    TM_HIP(hipMemcpy(e->h_fflags.data(), e->fflags.p, (size_t)e->q, hipMemcpyDeviceToHost));
+  }
   const int64_t per = e->tm_size(), off = (int64_t)frame * per;
   std::vector<int32_t> ti(per), pi(per);
   std::vector<uint32_t> er(per);

@@ -200,6 +200,38 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// PearsonCorrelation (tilingencoder.pas:2201-2228) of consecutive frames' Lab tile means: one thread per frame, the
+// reference's exact sequence (Math.mean sums in double; everything else sequential Single), so the result is bit
+// identical to a CPU restatement and 300 frames run side by side instead of one after the other on the host.
+__global__ void k_pearson_frames(const float *__restrict__ lab, int nframes, int per, float *__restrict__ correl) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  if (f == 0) { correl[0] = 0.0f; return; }
+  const float *x = lab + (int64_t)(f - 1) * per, *y = lab + (int64_t)f * per;
+  double sx = 0.0, sy = 0.0;
+  for (int i = 0; i < per; i++) { sx = __dadd_rn(sx, (double)x[i]); sy = __dadd_rn(sy, (double)y[i]); }
+  const float mx = (float)__ddiv_rn(sx, (double)per), my = (float)__ddiv_rn(sy, (double)per);
+  float num = 0.0f, denx = 0.0f, deny = 0.0f;
+  for (int i = 0; i < per; i++) {
+    const float dx = __fsub_rn(x[i], mx), dy = __fsub_rn(y[i], my);
+    num = __fadd_rn(num, __fmul_rn(dx, dy));
+    denx = __fadd_rn(denx, __fmul_rn(dx, dx));
+    deny = __fadd_rn(deny, __fmul_rn(dy, dy));
+  }
+  denx = __fsqrt_rn(denx);
+  deny = __fsqrt_rn(deny);
+  const float den = __fmul_rn(denx, deny);
+  correl[f] = den != 0.0f ? __fdiv_rn(num, den) : 1.0f;
+}
+
+int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream) {
+  TM_TRY(require_device());
+  if (nframes <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_pearson_frames, dim3((nframes + 63) / 64), dim3(64), 0, stream, (const float *)lab, nframes, per, (float *)correl);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
 static int grid_for(int64_t work_items, int per_block) {
   int64_t g = (work_items + per_block - 1) / per_block;
   const int64_t cap = 256 * 8;

@@ -7,6 +7,7 @@ namespace tmx {
 // tm_features.hip
 int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
                 void *lab_means, hipStream_t stream);
+int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream);
 int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out, hipStream_t stream);
 int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
                         hipStream_t stream);

@@ -161,19 +161,23 @@ __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_
 }
 
 // ---- Lloyd ---------------------------------------------------------------------------------------------------
-constexpr int KCH = 32;  // centroids scored per pass (register accumulators)
+constexpr int KCH = 16;  // centroids scored per pass (register accumulators)
+constexpr int DCH = 32;  // dimensions staged per pass (D = 192): 256 points x 32 dims, padded rows
 
 template <int D>
 __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, Seg *__restrict__ segs, int k,
                                                 const double *__restrict__ cent, int32_t *__restrict__ assign) {
-  extern __shared__ double s_cent[];  // [KCH][D]
+  extern __shared__ double s_dyn[];  // [KCH][D] centroids, then (D > 3) [256][DCH+1] int32 points
+  double *s_cent = s_dyn;
+  int32_t *s_pts = reinterpret_cast<int32_t *>(s_dyn + KCH * D);
   const int seg = blockIdx.y;
   const Seg sg = segs[seg];
   const int kk = sg.kk;
   int changed = 0;
   const int64_t iters = (sg.count + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < iters; it++) {
-    const int64_t i = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const int64_t base = (it * gridDim.x + blockIdx.x) * 256;
+    const int64_t i = base + threadIdx.x;
     const bool valid = i < sg.count;
     double bd = 0.0;
     int bc = -1;
@@ -181,22 +185,46 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
       const int nc = min(KCH, kk - c0);
       __syncthreads();
       for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
-      __syncthreads();
-      if (valid) {
-        double s[KCH];
+      double s[KCH];
 #pragma unroll
-        for (int c = 0; c < KCH; c++) s[c] = 0.0;
-        const int32_t *p = pts + (sg.begin + i) * D;
-        for (int j = 0; j < D; j++) {
-          const double pj = (double)p[j];
+      for (int c = 0; c < KCH; c++) s[c] = 0.0;
+      if (D == 3) {
+        __syncthreads();
+        if (valid) {
+          const int32_t *p = pts + (sg.begin + i) * D;
 #pragma unroll
-          for (int c = 0; c < KCH; c++) {
-            if (c < nc) {
-              const double t = __dsub_rn(pj, s_cent[c * D + j]);
-              s[c] = __dadd_rn(s[c], __dmul_rn(t, t));
+          for (int j = 0; j < D; j++) {
+            const double pj = (double)p[j];
+#pragma unroll
+            for (int c = 0; c < KCH; c++)
+              if (c < nc) { const double t = __dsub_rn(pj, s_cent[c * D + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+          }
+        }
+      } else {
+        for (int j0 = 0; j0 < D; j0 += DCH) {
+          __syncthreads();  // previous chunk fully consumed (and centroids written, first time round)
+          // coalesced: 8 threads x 16 B cover one row's 32 dims; 32 rows per pass
+          for (int r = threadIdx.x >> 3; r < 256; r += 32) {
+            const int64_t pi = base + r;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (pi < sg.count) v = *reinterpret_cast<const int4 *>(pts + (sg.begin + pi) * D + j0 + (threadIdx.x & 7) * 4);
+            int32_t *dst = s_pts + r * (DCH + 1) + (threadIdx.x & 7) * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+          }
+          __syncthreads();
+          if (valid) {
+            const int32_t *pr = s_pts + threadIdx.x * (DCH + 1);
+#pragma unroll 8
+            for (int j = 0; j < DCH; j++) {
+              const double pj = (double)pr[j];
+#pragma unroll
+              for (int c = 0; c < KCH; c++)
+                if (c < nc) { const double t = __dsub_rn(pj, s_cent[c * D + j0 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
             }
           }
         }
+      }
+      if (valid) {
 #pragma unroll
         for (int c = 0; c < KCH; c++)
           if (c < nc && (bc < 0 || s[c] < bd)) { bd = s[c]; bc = c0 + c; }
@@ -270,6 +298,11 @@ __global__ void k_update_finish(Seg *__restrict__ segs, int nseg, int k, u64 *__
   }
 }
 
+// first iteration (if any) in which no assignment changed, latched on the device so the host can poll rarely
+__global__ void k_latch_quiet(const int *__restrict__ any_changed, int it, int *__restrict__ quiet_iter) {
+  if (*any_changed == 0 && *quiet_iter < 0) *quiet_iter = it;
+}
+
 // ---- driver ----------------------------------------------------------------------------------------------------
 // Batched k-means over nseg contiguous segments.  seg_begin/seg_count are host arrays.  Outputs assign (global point
 // order), cent [nseg][k][d], host_kk[nseg] live centroid counts.
@@ -310,25 +343,34 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
-  const size_t lds_assign = (size_t)KCH * d * 8;
+  const size_t lds_assign = (size_t)KCH * d * 8 + (d > 3 ? (size_t)256 * (DCH + 1) * 4 : 0);
   const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
-  int it = 0;
-  for (; it < max_iter; it++) {
-    if (d == 3) {
-      hipLaunchKernelGGL(k_assign<3>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
-      hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
-    } else {
-      hipLaunchKernelGGL(k_assign<192>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
-      hipLaunchKernelGGL(k_accumulate<192>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+  DevBuf quiet;
+  TM_TRY(quiet.alloc(4));
+  TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
+  int it = 0, issued = 0;
+  const int poll_every = 8;  // iterations after convergence are idempotent, so polling late costs time only
+  while (issued < max_iter) {
+    const int batch = std::min(poll_every, max_iter - issued);
+    for (int b = 0; b < batch; b++, issued++) {
+      if (d == 3) {
+        hipLaunchKernelGGL(k_assign<3>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
+        hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+      } else {
+        hipLaunchKernelGGL(k_assign<192>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
+        hipLaunchKernelGGL(k_accumulate<192>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+      }
+      TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+      const int64_t total = (int64_t)nseg * k * d;
+      hipLaunchKernelGGL(k_update, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, flag.as<int>());
+      hipLaunchKernelGGL(k_update_finish, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, cnts.as<u64>(), flag.as<int>());
+      hipLaunchKernelGGL(k_latch_quiet, dim3(1), dim3(1), 0, stream, flag.as<int>(), issued, quiet.as<int>());
     }
-    TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
-    const int64_t total = (int64_t)nseg * k * d;
-    hipLaunchKernelGGL(k_update, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, flag.as<int>());
-    hipLaunchKernelGGL(k_update_finish, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, cnts.as<u64>(), flag.as<int>());
-    int any = 0;
-    TM_HIP(hipMemcpyAsync(&any, flag.p, 4, hipMemcpyDeviceToHost, stream));
+    int q = -1;
+    TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
     TM_HIP(hipStreamSynchronize(stream));
-    if (!any) break;
+    if (q >= 0) { it = q; break; }
+    it = issued;
   }
   TM_HIP(hipGetLastError());
   if (host_iters) *host_iters = it;
