@@ -98,12 +98,14 @@ def test_features_pal_and_cluster(tiles_flags, oracle):
 def _rand_features(rng, n, spread):
     """int16[192] rows shaped like real features: a few wide (DC-like) columns, the rest narrow"""
     f = rng.integers(-spread, spread + 1, size=(n, 192)).astype(np.int32)
-    f[:, [0, 64, 128]] = rng.integers(-13000, 13001, size=(n, 3))
+    f[:, 0] = rng.integers(0, 13216, size=n)  # Y DC is non-negative (SURVEY.md A.3 bounds keep every SSD < 2^31)
+    f[:, 64] = rng.integers(-6500, 6501, size=n)
+    f[:, 128] = rng.integers(-9000, 9001, size=n)
     f[:, 1:6] = rng.integers(-3000, 3001, size=(n, 5))
     return f.astype(np.int16)
 
 
-@pytest.mark.parametrize("nq,nt,spread", [(70, 100, 90), (1, 1, 90), (33, 31, 20000), (300, 1000, 600), (64, 2049, 100)])
+@pytest.mark.parametrize("nq,nt,spread", [(70, 100, 90), (1, 1, 90), (33, 31, 1200), (300, 1000, 600), (64, 2049, 100), (700, 5000, 300)])
 def test_knn_exact(oracle, nq, nt, spread):
     from tiler_amd import stages
     rng = np.random.default_rng(nq * 1000 + nt)
@@ -118,6 +120,15 @@ def test_knn_exact(oracle, nq, nt, spread):
     idx, err = stages.knn(_dev(q), _dev(db))
     assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
     assert np.array_equal(idx.cpu().numpy(), eidx)
+
+
+def test_knn_refuses_out_of_domain_data():
+    """arbitrary int16 rows can reach SSD >= 2^31, where mod-2^32 arithmetic stops being exact: refuse loudly"""
+    from tiler_amd import stages, TileMotionError
+    rng = np.random.default_rng(0)
+    f = rng.integers(-20000, 20001, size=(64, 192)).astype(np.int16)
+    with pytest.raises(TileMotionError):
+        stages.knn(_dev(f), _dev(f))
 
 
 def test_knn_real_features(tiles_flags, oracle):

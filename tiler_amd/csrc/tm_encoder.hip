@@ -52,23 +52,6 @@ static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, util
   return (int)llrint(std::sqrt((double)f) * std::log2(1 + (double)f));
 }
 
-static float pearson(const float *x, const float *y, int n) {  // PearsonCorrelation, tilingencoder.pas:2201-2228
-  double sx = 0, sy = 0;                                       // Math.mean accumulates in float(=double on Win64)
-  for (int i = 0; i < n; i++) { sx += x[i]; sy += y[i]; }
-  const float mx = (float)(sx / n), my = (float)(sy / n);
-  float num = 0, denx = 0, deny = 0;
-  for (int i = 0; i < n; i++) {
-    const float dx = x[i] - mx, dy = y[i] - my;
-    num += dx * dy;
-    denx += dx * dx;
-    deny += dy * dy;
-  }
-  denx = std::sqrt(denx);
-  deny = std::sqrt(deny);
-  const float den = denx * deny;
-  return den != 0.0f ? num / den : 1.0f;
-}
-
 static float euclidean_to_psnr(uint32_t e) {  // EuclideanToPSNR, utils.pas:1074-1078
   const float r = (float)((double)e * (1.0 / 192));
   const float m = r > 0.5f ? r : 0.5f;
@@ -214,12 +197,18 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   // inter-frame correlation: one GPU thread per frame runs the reference's sequential Single sums (order matters)
   const int per = (int)e->tm_size() * 3;
   DevBuf dcorrel;
-  TM_TRY(dcorrel.alloc((size_t)e->nframes * 4));
+  TM_TRY(dcorrel.alloc((size_t)e->nframes * 12));
   TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
-  e->correl.assign(e->nframes, 0.0f);
+  std::vector<float> sums((size_t)e->nframes * 3);
   e->h_fflags.clear();  // fetched lazily by tm_get_tilemap
-  TM_HIP(hipMemcpyAsync(e->correl.data(), dcorrel.p, (size_t)e->nframes * 4, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipMemcpyAsync(sums.data(), dcorrel.p, sums.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
+  e->correl.assign(e->nframes, 0.0f);
+  for (int f = 1; f < e->nframes; f++) {  // tail of PearsonCorrelation (2221-2227) in host IEEE arithmetic
+    const float denx = std::sqrt(sums[f * 3 + 1]), deny = std::sqrt(sums[f * 3 + 2]);
+    const float den = denx * deny;
+    e->correl[f] = den != 0.0f ? sums[f * 3] / den : 1.0f;
+  }
   progress(e, TM_STEP_LOAD, 2, 3);
   // FindKeyFrames, automatic mode (3373-3411)
   e->kf_start.clear();

@@ -201,33 +201,52 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
 
 // ---------------------------------------------------------------------------------------------------------------
 // PearsonCorrelation (tilingencoder.pas:2201-2228) of consecutive frames' Lab tile means: one thread per frame, the
-// reference's exact sequence (Math.mean sums in double; everything else sequential Single), so the result is bit
-// identical to a CPU restatement and 300 frames run side by side instead of one after the other on the host.
-__global__ void k_pearson_frames(const float *__restrict__ lab, int nframes, int per, float *__restrict__ correl) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nframes) return;
-  if (f == 0) { correl[0] = 0.0f; return; }
+// reference's exact sequence (Math.mean sums in double; everything else sequential Single), so the sums are bit
+// identical to a CPU restatement and 300 frames run side by side.  Output: num, sum dx^2, sum dy^2 per frame.
+__global__ __launch_bounds__(64) void k_pearson_frames(const float *__restrict__ lab, int nframes, int per, float *__restrict__ correl) {
+  // one wave per frame: all lanes stream x,y chunks into LDS (coalesced), lanes 0..2 run the sequential chains
+  __shared__ float s_x[1024], s_y[1024];
+  __shared__ double s_sum[2];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f == 0) { if (lane < 3) correl[lane] = 0.0f; return; }
   const float *x = lab + (int64_t)(f - 1) * per, *y = lab + (int64_t)f * per;
-  double sx = 0.0, sy = 0.0;
-  for (int i = 0; i < per; i++) { sx = __dadd_rn(sx, (double)x[i]); sy = __dadd_rn(sy, (double)y[i]); }
-  const float mx = (float)__ddiv_rn(sx, (double)per), my = (float)__ddiv_rn(sy, (double)per);
-  float num = 0.0f, denx = 0.0f, deny = 0.0f;
-  for (int i = 0; i < per; i++) {
-    const float dx = __fsub_rn(x[i], mx), dy = __fsub_rn(y[i], my);
-    num = __fadd_rn(num, __fmul_rn(dx, dy));
-    denx = __fadd_rn(denx, __fmul_rn(dx, dx));
-    deny = __fadd_rn(deny, __fmul_rn(dy, dy));
+  double acc = 0.0;
+  for (int c0 = 0; c0 < per; c0 += 1024) {
+    const int n = min(1024, per - c0);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { s_x[i] = x[c0 + i]; s_y[i] = y[c0 + i]; }
+    __syncthreads();
+    if (lane < 2) {
+      const float *src = lane == 0 ? s_x : s_y;
+      for (int i = 0; i < n; i++) acc = __dadd_rn(acc, (double)src[i]);
+    }
   }
-  denx = __fsqrt_rn(denx);
-  deny = __fsqrt_rn(deny);
-  const float den = __fmul_rn(denx, deny);
-  correl[f] = den != 0.0f ? __fdiv_rn(num, den) : 1.0f;
+  if (lane < 2) s_sum[lane] = acc;
+  __syncthreads();
+  const float mx = (float)__ddiv_rn(s_sum[0], (double)per), my = (float)__ddiv_rn(s_sum[1], (double)per);
+  float chain = 0.0f;  // lane 0: num, lane 1: denx, lane 2: deny
+  for (int c0 = 0; c0 < per; c0 += 1024) {
+    const int n = min(1024, per - c0);
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) { s_x[i] = x[c0 + i]; s_y[i] = y[c0 + i]; }
+    __syncthreads();
+    if (lane < 3) {
+      for (int i = 0; i < n; i++) {
+        const float dx = __fsub_rn(s_x[i], mx), dy = __fsub_rn(s_y[i], my);
+        const float a = lane == 1 ? dx : (lane == 2 ? dy : dx), b = lane == 1 ? dx : dy;
+        chain = __fadd_rn(chain, __fmul_rn(a, b));
+      }
+    }
+  }
+  // the three raw sums go back to the host, which finishes with IEEE sqrt/divide (device __fsqrt_rn is a bare
+  // v_sqrt_f32: 1 ulp, not correctly rounded)
+  if (lane < 3) correl[f * 3 + lane] = chain;
 }
 
 int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream) {
   TM_TRY(require_device());
   if (nframes <= 0) return TM_OK;
-  hipLaunchKernelGGL(k_pearson_frames, dim3((nframes + 63) / 64), dim3(64), 0, stream, (const float *)lab, nframes, per, (float *)correl);
+  hipLaunchKernelGGL(k_pearson_frames, dim3(nframes), dim3(64), 0, stream, (const float *)lab, nframes, per, (float *)correl);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

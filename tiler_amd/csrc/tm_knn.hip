@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
     if (threadIdx.x < 32) {
       uint32_t s = 0;
       for (int p = 0; p < 192; p++) { const int v = s_v[threadIdx.x][p]; s += (uint32_t)(v * v); }
-      reinterpret_cast<uint32_t *>(obase + kch * 1024)[threadIdx.x] = negate ? (s >> 1) : s;
+      reinterpret_cast<uint32_t *>(obase + kch * 1024)[threadIdx.x] = s;  // |v-c|^2 (the kernel drops the query side's parity bit)
     }
     if (bad) atomicOr(err_flag, 1);
     if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + KNN_ND) {  // bounding box of the tile over the box columns (raw values)
@@ -192,30 +192,20 @@ __device__ __forceinline__ uint32_t ssd_rows(const int16_t *__restrict__ a, cons
   return ssd;
 }
 
-__global__ __launch_bounds__(256) void k_knn_refine(const int16_t *__restrict__ queries, int64_t nq, const uint32_t *__restrict__ qperm,
-                                                    const int16_t *__restrict__ db, int64_t nt, const uint32_t *__restrict__ tperm,
-                                                    const int *__restrict__ best_tile, int *__restrict__ out_idx,
-                                                    uint32_t *__restrict__ out_err, uint32_t *__restrict__ tie_list,
-                                                    unsigned int *__restrict__ tie_count) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < nq; p += (int64_t)gridDim.x * 4) {
-    const int bt = best_tile[p];
+__global__ __launch_bounds__(256) void k_knn_refine(int64_t nq, const uint32_t *__restrict__ qperm, int64_t nt,
+                                                    const uint32_t *__restrict__ tperm, const uint8_t *__restrict__ qpack, int q_bytes,
+                                                    const int *__restrict__ best_key, const int *__restrict__ best_row,
+                                                    int *__restrict__ out_idx, uint32_t *__restrict__ out_err,
+                                                    uint32_t *__restrict__ tie_list, unsigned int *__restrict__ tie_count) {
+  // The kernel already knows the sorted row of the (first) minimum and d'' = SSD - (|q-c|^2 & 1): undo both mappings.
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nq; p += (int64_t)gridDim.x * blockDim.x) {
+    const int br = best_row[p];
+    const int64_t srow = min((int64_t)(br & 0x3fffffff), nt - 1);  // padded rows replicate row nt-1
+    const uint32_t nqv = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31];
     const int64_t q = qperm[p];
-    const int64_t srow = (int64_t)(bt & 0x3fffffff) * 32 + (lane & 31);
-    unsigned long long key = ~0ull;
-    if (lane < 32 && srow < nt) {
-      const uint32_t orow = tperm[srow];
-      key = ((unsigned long long)ssd_rows(queries + q * 192, db + (int64_t)orow * 192) << 32) | (unsigned long long)orow;
-    }
-    for (int o = 16; o > 0; o >>= 1) {
-      const unsigned long long other = __shfl_xor(key, o);
-      key = other < key ? other : key;
-    }
-    if (lane == 0) {
-      out_idx[q] = (int)(uint32_t)(key & 0xffffffffull);
-      out_err[q] = (uint32_t)(key >> 32);
-      if (bt & (1 << 30)) tie_list[atomicAdd(tie_count, 1u)] = (uint32_t)p;
-    }
+    out_idx[q] = (int)tperm[srow];
+    out_err[q] = (uint32_t)best_key[p] + (nqv & 1u);
+    if ((br & (1 << 30)) || (int64_t)(br & 0x3fffffff) >= nt) tie_list[atomicAdd(tie_count, 1u)] = (uint32_t)p;
   }
 }
 
@@ -451,6 +441,16 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
   const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
+  {  // exactness domain: all arithmetic is mod 2^32 and compared as signed, which needs every SSD < 2^31.  Tile features
+     // satisfy it by construction (<= 1.35e9); arbitrary int16 data may not.
+    long long bound = 0;
+    for (int c = 0; c < 192; c++) {
+      const long long lo = std::min(ix->tstats.mn[c], qs.mn[c]), hi = std::max(ix->tstats.mx[c], qs.mx[c]);
+      if (hi > lo) bound += (hi - lo) * (hi - lo);
+    }
+    TM_CHECK(bound < (1ll << 31) - 2, TM_E_UNSUPPORTED,
+             "knn: column ranges allow an SSD of %lld >= 2^31, outside the exact domain of the int8/int32 kernel", bound);
+  }
   if (!ix->packed || !plan_covers(ix->plan, qs, ix->plan.hq)) {
     TM_TRY(make_plan(ix->tstats, qs, &ix->plan));
     TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
@@ -505,10 +505,10 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
-    int grid = (int)std::min<int64_t>((nq + 3) / 4, 8192);
-    hipLaunchKernelGGL(k_knn_refine, dim3(grid), dim3(256), 0, stream, (const int16_t *)queries, nq, ix->qperm.as<uint32_t>(), ix->db, ix->nt,
-                       ix->tperm.as<uint32_t>(), bt, (int *)out_idx, (uint32_t *)out_err, ix->tie_list.as<uint32_t>(),
-                       ix->counters.as<unsigned int>());
+    int grid = (int)std::min<int64_t>((nq + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_knn_refine, dim3(grid), dim3(256), 0, stream, nq, ix->qperm.as<uint32_t>(), ix->nt, ix->tperm.as<uint32_t>(),
+                       ix->qpack.as<uint8_t>(), knn_tile_bytes(ix->plan.hq, 0), ix->best_key.as<int>(), bt, (int *)out_idx,
+                       (uint32_t *)out_err, ix->tie_list.as<uint32_t>(), ix->counters.as<unsigned int>());
     hipLaunchKernelGGL(k_knn_ties, dim3(1024), dim3(256), 0, stream, (const int16_t *)queries, ix->qperm.as<uint32_t>(), ix->db, ix->nt, ntt,
                        ix->tperm.as<uint32_t>(), bx, ix->tie_list.as<uint32_t>(), ix->counters.as<unsigned int>(), (int *)out_idx,
                        (const uint32_t *)out_err);

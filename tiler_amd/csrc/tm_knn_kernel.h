@@ -31,13 +31,48 @@ constexpr int KNN_NW = 4;  // waves per workgroup (256 queries; two workgroups s
 // stage settles the lowest-index rule.
 constexpr int KNN_ND = 6;        // bounding-box columns
 constexpr int KNN_K0 = 8;        // tiles visited first, around the workgroup's position on the curve
-constexpr int KNN_CHUNK = 4096;  // tiles tested per compaction round
+constexpr int KNN_CHUNK = 1024;  // tiles tested per compaction round (bests are re-read for each round)
 
 struct KnnBoxes {
   const int *lo, *hi;   // [KNN_ND][n_ttiles] bounding boxes of the database tiles
   const uint32_t *tkey; // [n_ttiles] curve key of each tile's first row (ascending)
   int col[KNN_ND];      // source feature column of each box dimension
 };
+
+// Compacts into s_list the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
+// workgroup can still use: squared box-to-box distance over the KNN_ND box columns <= that sub-tile's largest running
+// best + 1 (d'' = SSD - parity, so SSD <= d'' + 1).  Kept out of line so its registers do not count against the MFMA loop.
+__device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
+                                                        int chunk_base, int r0a, int r0b, int prune, const int *s_box_lo,
+                                                        const int *s_box_hi, const int *s_smax, uint16_t *s_list, int *s_cnt) {
+  constexpr int NS = KNN_NW * KNN_NQ, ND = KNN_ND, NT = KNN_NW * 64;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid == 0) *s_cnt = 0;
+  __syncthreads();
+  for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT) {
+    const int t = chunk_base + k;
+    if (t >= r0a && t < r0b) continue;  // done in round 0
+    bool keep = !prune;
+    if (prune) {
+      int tlo[ND], thi[ND];
+#pragma unroll
+      for (int d = 0; d < ND; d++) { tlo[d] = box_lo[(int64_t)d * n_ttiles + t]; thi[d] = box_hi[(int64_t)d * n_ttiles + t]; }
+      for (int q = 0; q < NS && !keep; q++) {
+        long long lb = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+          const long long g = max(0, max(tlo[d] - s_box_hi[q * ND + d], s_box_lo[q * ND + d] - thi[d]));
+          lb += g * g;
+        }
+        keep = lb <= (long long)s_smax[q] + 1;
+      }
+    }
+    if (keep) s_list[atomicAdd(s_cnt, 1)] = (uint16_t)k;
+  }
+  __syncthreads();
+  return *s_cnt;
+}
 
 template <int HT, int HQ>
 __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__restrict__ tpack, int64_t n_ttiles, KnnBoxes bx,
@@ -53,9 +88,8 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   constexpr int NT = NW * 64;
   constexpr int NST = (TILE_VEC + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][T_BYTES];
-  __shared__ int s_wmax[2][NW];
+  __shared__ int s_smax[2][NW][NQ];  // largest running best of each query sub-tile, double buffered
   __shared__ int s_box[2][NW][NQ][ND];  // [lo|hi][wave][sub-tile][dim] query boxes
-  __shared__ int s_lb[KNN_CHUNK];      // box bound of each listed tile (fixed; only the threshold moves)
   __shared__ int s_ctl[4];
   __shared__ uint16_t s_list[KNN_CHUNK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -63,7 +97,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   const int64_t wgt = blockIdx.x;
 
   v4i bq[NQ][KQ];
-  int nq2[NQ], best[NQ], bestt[NQ], tie[NQ];
+  int nq2[NQ], best[NQ], bestt[NQ], tie[NQ];  // bestt = tile << 5 | row of the first minimum
   int64_t qtile[NQ];
 #pragma unroll
   for (int s = 0; s < NQ; s++) {
@@ -72,13 +106,12 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     const uint8_t *qb = qpack + qt * (int64_t)Q_BYTES;
 #pragma unroll
     for (int kc = 0; kc < KQ; kc++) bq[s][kc] = *reinterpret_cast<const v4i *>(qb + (kc * 64 + lane) * 16);
-    nq2[s] = reinterpret_cast<const int *>(qb + KQ * 1024)[lane & 31] << 1;  // 2*(|q-c|^2 >> 1)
+    nq2[s] = reinterpret_cast<const int *>(qb + KQ * 1024)[lane & 31] & ~1;  // 2*(|q-c|^2 >> 1); the parity bit returns in the refine stage
     best[s] = INT_MAX;
     bestt[s] = INT_MAX;
     tie[s] = 0;
   }
   // bounding boxes: per query sub-tile (lanes 0..31 / 32..63 hold sub-tile 0 / 1) and for the whole workgroup
-  int glo[ND], ghi[ND];
   {
     static_assert(NQ == 2, "lane <-> query mapping below assumes two sub-tiles per wave");
     const int64_t p = min(wgt * QT_PER_WG * 32 + (int64_t)wave * NQ * 32 + lane, nq - 1);
@@ -99,33 +132,14 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     start = (int)min((int64_t)start, max((int64_t)0, n_ttiles - KNN_K0));
     s_ctl[0] = start;
   }
-  if (tid < NW) { s_wmax[0][tid] = INT_MAX; s_wmax[1][tid] = INT_MAX; }
+  if (tid < NW * NQ) { (&s_smax[0][0][0])[tid] = INT_MAX; (&s_smax[1][0][0])[tid] = INT_MAX; }
   __syncthreads();
-#pragma unroll
-  for (int d = 0; d < ND; d++) {
-    glo[d] = INT_MAX; ghi[d] = INT_MIN;
-#pragma unroll
-    for (int w = 0; w < NW; w++)
-#pragma unroll
-      for (int q = 0; q < NQ; q++) { glo[d] = min(glo[d], s_box[0][w][q][d]); ghi[d] = max(ghi[d], s_box[1][w][q][d]); }
-  }
   const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
-  auto box_lb = [&](int t, const int *qlo, const int *qhi) -> long long {  // squared box-to-box distance
-    long long lb = 0;
-#pragma unroll
-    for (int d = 0; d < ND; d++) {
-      const long long g = max(0, max(bx.lo[(int64_t)d * n_ttiles + t] - qhi[d], qlo[d] - bx.hi[(int64_t)d * n_ttiles + t]));
-      lb += g * g;
-    }
-    return lb;
-  };
-
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
   int phase = 0, r0next = r0a, chunk_base = 0, list_n = 0, list_i = 0;
-  auto next_tile = [&](int wgmax) -> int {  // called by every thread at the same point (contains barriers)
-    const long long lim = (long long)wgmax + 1;  // d'' = SSD - parity, so SSD <= d'' + 1
+  auto next_tile = [&](int sbuf) -> int {  // called by every thread at the same point (contains barriers)
     while (true) {
       if (phase == 0) {
         if (r0next < r0b) return r0next++;
@@ -133,33 +147,17 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
         chunk_base = -KNN_CHUNK;
         list_n = list_i = 0;
       }
-      while (list_i < list_n) {
-        const int k = list_i++;
-        if (!prune || (long long)s_lb[k] <= lim) return chunk_base + s_list[k];  // re-test against the bests as they are now
-      }
+      if (list_i < list_n) return chunk_base + s_list[list_i++];
       chunk_base += KNN_CHUNK;
       if (chunk_base >= n_ttiles) return -1;
-      __syncthreads();
-      if (tid == 0) s_ctl[1] = 0;
-      __syncthreads();
-      for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT) {
-        const int t = chunk_base + k;
-        if (t >= r0a && t < r0b) continue;  // done in round 0
-        const long long lb = prune ? box_lb(t, glo, ghi) : 0;
-        if (lb <= lim) {
-          const int slot = atomicAdd(&s_ctl[1], 1);
-          s_list[slot] = (uint16_t)k;
-          s_lb[slot] = (int)min(lb, (long long)INT_MAX);
-        }
-      }
-      __syncthreads();
-      list_n = s_ctl[1];
+      list_n = knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0], &s_box[1][0][0][0],
+                              &s_smax[sbuf][0][0], s_list, &s_ctl[1]);
       list_i = 0;
     }
   };
 
   v4i st[NST];
-  int cur_tile = next_tile(INT_MAX);
+  int cur_tile = next_tile(0);
   if (cur_tile >= 0) {  // prologue: first database tile -> LDS buffer 0
     const uint8_t *src = tpack + cur_tile * (int64_t)T_BYTES;
 #pragma unroll
@@ -174,11 +172,8 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   int cur = 0;
   while (cur_tile >= 0) {
     nstaged++;
-    // the bests published one iteration ago (stale = larger = prunes less: still exact)
-    int wgmax = s_wmax[cur][0];
-#pragma unroll
-    for (int w = 1; w < NW; w++) wgmax = max(wgmax, s_wmax[cur][w]);
-    const int nxt_tile = next_tile(wgmax);
+    // list rounds read the bests published one iteration ago (stale = larger = prunes less: still exact)
+    const int nxt_tile = next_tile(cur);
     if (nxt_tile >= 0) {
       const uint8_t *src = tpack + nxt_tile * (int64_t)T_BYTES;
 #pragma unroll
@@ -252,15 +247,32 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
             m = min(m, d);
           }
           if (m == best[s - 1]) tie[s - 1] = 1;  // another tile reaches the same value
-          if (m < best[s - 1]) { best[s - 1] = m; bestt[s - 1] = cur_tile; tie[s - 1] = 0; }
+          if (__builtin_amdgcn_ballot_w64(m < best[s - 1])) {  // some lane improves (rare once the bests have settled)
+            int row = 0, cnt = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; r--) {
+              unsigned x = (unsigned)acc0[b][r];
+              if (HT + HQ > 0) {
+                unsigned hi = (unsigned)acc1[b][r];
+                if (HM > 0) hi += (unsigned)acc2[b][r] << 8;
+                x += hi << 8;
+              }
+              const int d = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s - 1]);
+              if (d == m) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
+            }
+            if (m < best[s - 1]) { best[s - 1] = m; bestt[s - 1] = (cur_tile << 5) | row; tie[s - 1] = cnt > 1; }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    int wmax = max(best[0], best[NQ - 1]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) s_wmax[cur ^ 1][wave] = wmax;
+    for (int s = 0; s < NQ; s++) {
+      int smax = best[s];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+      if (lane == 0) s_smax[cur ^ 1][wave][s] = smax;
+    }
     if (nxt_tile >= 0) {
 #pragma unroll
       for (int i = 0; i < NST; i++)
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   for (int s = 0; s < NQ; s++) {
     const int ob = __shfl_xor(best[s], 32), ot = __shfl_xor(bestt[s], 32), oti = __shfl_xor(tie[s], 32);
     if (ob == best[s]) {
-      tie[s] |= oti | (ot != bestt[s] ? 1 : 0);
+      tie[s] = 1;  // two rows (of one tile or two) reach the minimum: settled by original index later
       if (ot < bestt[s]) bestt[s] = ot;
     } else if (ob < best[s]) {
       best[s] = ob; bestt[s] = ot; tie[s] = oti;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     if (lane < 32 && qtile[s] < n_qtiles) {
       const int64_t q = qtile[s] * 32 + lane;
       best_key[q] = best[s];
-      best_tile[q] = bestt[s] | (tie[s] ? (1 << 30) : 0);  // bit 30: tie flag
+      best_tile[q] = (bestt[s] & 0x3fffffff) | (tie[s] ? (1 << 30) : 0);  // sorted row of the first minimum; bit 30: tie flag
     }
   }
   if (visited && lane == 0) atomicAdd(visited, (unsigned long long)nvisit);
