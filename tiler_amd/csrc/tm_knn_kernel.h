@@ -39,12 +39,25 @@ struct KnnBoxes {
   int col[KNN_ND];      // source feature column of each box dimension
 };
 
-// Compacts into s_list the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
-// workgroup can still use: squared box-to-box distance over the KNN_ND box columns <= that sub-tile's largest running
-// best + 1 (d'' = SSD - parity, so SSD <= d'' + 1).  Kept out of line so its registers do not count against the MFMA loop.
+// Conservative int32 form of the box bound: sum over the box columns of (gap >> 1)^2 <= (best + 1) >> 2 is implied by
+// sum gap^2 <= best + 1, so failing it proves the tile cannot matter (gaps < 2^15, six terms: no overflow).
+__device__ __forceinline__ bool knn_box_may_matter(const int *tlo, const int *thi, const int *qlo, const int *qhi, int smax) {
+  int lb = 0;
+#pragma unroll
+  for (int d = 0; d < KNN_ND; d++) {
+    const int g = max(0, max(tlo[d] - qhi[d], qlo[d] - thi[d])) >> 1;
+    lb += g * g;
+  }
+  return lb <= (int)(((unsigned)smax + 1u) >> 2);
+}
+
+// Compacts into s_list / s_mask the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
+// workgroup can still use (bit = wave * NQ + sub-tile), judged with that sub-tile's largest running best (d'' = SSD -
+// parity, so SSD <= d'' + 1).  Kept out of line so its registers do not count against the MFMA loop.
 __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
                                                         int chunk_base, int r0a, int r0b, int prune, const int *s_box_lo,
-                                                        const int *s_box_hi, const int *s_smax, uint16_t *s_list, int *s_cnt) {
+                                                        const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask,
+                                                        int *s_cnt) {
   constexpr int NS = KNN_NW * KNN_NQ, ND = KNN_ND, NT = KNN_NW * 64;
   const int tid = threadIdx.x;
   __syncthreads();
@@ -53,22 +66,19 @@ __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ 
   for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT) {
     const int t = chunk_base + k;
     if (t >= r0a && t < r0b) continue;  // done in round 0
-    bool keep = !prune;
+    unsigned mask = prune ? 0u : 0xffu;
     if (prune) {
       int tlo[ND], thi[ND];
 #pragma unroll
       for (int d = 0; d < ND; d++) { tlo[d] = box_lo[(int64_t)d * n_ttiles + t]; thi[d] = box_hi[(int64_t)d * n_ttiles + t]; }
-      for (int q = 0; q < NS && !keep; q++) {
-        long long lb = 0;
-#pragma unroll
-        for (int d = 0; d < ND; d++) {
-          const long long g = max(0, max(tlo[d] - s_box_hi[q * ND + d], s_box_lo[q * ND + d] - thi[d]));
-          lb += g * g;
-        }
-        keep = lb <= (long long)s_smax[q] + 1;
-      }
+      for (int q = 0; q < NS; q++)
+        if (knn_box_may_matter(tlo, thi, s_box_lo + q * ND, s_box_hi + q * ND, s_smax[q])) mask |= 1u << q;
     }
-    if (keep) s_list[atomicAdd(s_cnt, 1)] = (uint16_t)k;
+    if (mask) {
+      const int slot = atomicAdd(s_cnt, 1);
+      s_list[slot] = (uint16_t)k;
+      s_mask[slot] = (uint8_t)mask;
+    }
   }
   __syncthreads();
   return *s_cnt;
@@ -86,12 +96,15 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;  // database tiles carry their box (2*ND ints) too
   constexpr int TILE_VEC = T_BYTES / 16;
   constexpr int NT = NW * 64;
-  constexpr int NST = (TILE_VEC + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2][T_BYTES];
-  __shared__ int s_smax[2][NW][NQ];  // largest running best of each query sub-tile, double buffered
+  constexpr int NST = (TILE_VEC + NT - 1) / NT;       // LDS-DMA pieces (64 lanes x 16 B) each wave issues per tile
+  constexpr int BUF_BYTES = NST * NW * 1024;          // >= T_BYTES: the tail is padding that clamped lanes land in
+  constexpr int NBUF = 3;                             // ring: tile i is read while tiles i+1 and i+2 are in flight
+  __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF][BUF_BYTES];
+  __shared__ int s_smax[NW][NQ];     // largest running best of each query sub-tile
   __shared__ int s_box[2][NW][NQ][ND];  // [lo|hi][wave][sub-tile][dim] query boxes
   __shared__ int s_ctl[4];
   __shared__ uint16_t s_list[KNN_CHUNK];
+  __shared__ uint8_t s_mask[KNN_CHUNK];  // which sub-tiles wanted the listed tile (bit = wave * NQ + sub-tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int QT_PER_WG = NW * NQ;
   const int64_t wgt = blockIdx.x;
@@ -132,73 +145,76 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     start = (int)min((int64_t)start, max((int64_t)0, n_ttiles - KNN_K0));
     s_ctl[0] = start;
   }
-  if (tid < NW * NQ) { (&s_smax[0][0][0])[tid] = INT_MAX; (&s_smax[1][0][0])[tid] = INT_MAX; }
+  if (tid < NW * NQ) (&s_smax[0][0])[tid] = INT_MAX;
   __syncthreads();
   const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
   int phase = 0, r0next = r0a, chunk_base = 0, list_n = 0, list_i = 0;
-  auto next_tile = [&](int sbuf) -> int {  // called by every thread at the same point (contains barriers)
+  auto next_tile = [&]() -> int {  // called by every thread at the same point (contains barriers)
     while (true) {
       if (phase == 0) {
-        if (r0next < r0b) return r0next++;
+        if (r0next < r0b) return (r0next++) | (0xff << 23);
         phase = 1;
         chunk_base = -KNN_CHUNK;
         list_n = list_i = 0;
       }
-      if (list_i < list_n) return chunk_base + s_list[list_i++];
+      if (list_i < list_n) { const int k = list_i++; return (chunk_base + s_list[k]) | ((int)s_mask[k] << 23); }
       chunk_base += KNN_CHUNK;
       if (chunk_base >= n_ttiles) return -1;
       list_n = knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0], &s_box[1][0][0][0],
-                              &s_smax[sbuf][0][0], s_list, &s_ctl[1]);
+                              &s_smax[0][0], s_list, s_mask, &s_ctl[1]);
       list_i = 0;
     }
   };
 
-  v4i st[NST];
-  int cur_tile = next_tile(0);
-  if (cur_tile >= 0) {  // prologue: first database tile -> LDS buffer 0
-    const uint8_t *src = tpack + cur_tile * (int64_t)T_BYTES;
+  // async staging: every wave copies NST pieces of a tile straight into LDS (global_load_lds, no registers); lanes
+  // past the end of the tile re-read its last vector into the buffer padding so all waves issue the same count
+  auto issue = [&](int tile, int buf) {
+    const uint8_t *src = tpack + (tile & 0x7fffff) * (int64_t)T_BYTES;
 #pragma unroll
-    for (int i = 0; i < NST; i++)
-      if (tid + i * NT < TILE_VEC) st[i] = *reinterpret_cast<const v4i *>(src + (tid + i * NT) * 16);
-#pragma unroll
-    for (int i = 0; i < NST; i++)
-      if (tid + i * NT < TILE_VEC) *reinterpret_cast<v4i *>(&lds[0][(tid + i * NT) * 16]) = st[i];
+    for (int i = 0; i < NST; i++) {
+      const int piece = wave + i * NW;
+      const int v = min(piece * 64 + lane, TILE_VEC - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + v * 16),
+                                       (__attribute__((address_space(3))) void *)(&lds[buf][piece * 1024]), 16, 0, 0);
+    }
+  };
+  int cur_tile = next_tile(), nxt_tile = -1;
+  if (cur_tile >= 0) {
+    issue(cur_tile, 0);
+    nxt_tile = next_tile();
+    if (nxt_tile >= 0) issue(nxt_tile, 1);
   }
-  __syncthreads();
 
   int cur = 0;
+  int smax_reg[NQ];
+#pragma unroll
+  for (int s = 0; s < NQ; s++) smax_reg[s] = INT_MAX;
+  bool improved = false;
   while (cur_tile >= 0) {
     nstaged++;
-    // list rounds read the bests published one iteration ago (stale = larger = prunes less: still exact)
-    const int nxt_tile = next_tile(cur);
-    if (nxt_tile >= 0) {
-      const uint8_t *src = tpack + nxt_tile * (int64_t)T_BYTES;
-#pragma unroll
-      for (int i = 0; i < NST; i++)
-        if (tid + i * NT < TILE_VEC) st[i] = *reinterpret_cast<const v4i *>(src + (tid + i * NT) * 16);
-    }
+    // tile `cur_tile` landed?  Only this wave's own pieces are counted; the barrier publishes everyone's.  It also
+    // fences the previous iteration's LDS reads (buffer reuse) and s_smax writes.
+    if (nxt_tile >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nn_tile = nxt_tile >= 0 ? next_tile() : -1;  // two ahead, chosen with the bests as they are now
+    if (nn_tile >= 0) issue(nn_tile, cur >= 1 ? cur - 1 : NBUF - 1);  // buffer (cur + 2) % 3: read last in the previous iteration
     const uint8_t *L = lds[cur];
-    // sub-tile level skip: can this tile still matter for any of the 32 queries of sub-tile s?  (tile box rides in LDS)
+    // sub-tile level skip: the list round already judged every (tile, sub-tile) pair with the bests of that time;
+    // pairs it kept are re-judged against the current best with the tile's box (it rides in LDS behind the norms)
     bool do_sub[NQ];
     bool do_tile = false;
 #pragma unroll
     for (int s = 0; s < NQ; s++) {
-      int smax = best[s];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
-      long long lb = 0;
-      if (prune) {
+      do_sub[s] = ((cur_tile >> (23 + wave * NQ + s)) & 1) != 0;
+      if (do_sub[s] && prune) {
         const int *tb = reinterpret_cast<const int *>(L + KT * 1024 + 128);
-#pragma unroll
-        for (int d = 0; d < ND; d++) {
-          const long long g = max(0, max(tb[d] - s_box[1][wave][s][d], s_box[0][wave][s][d] - tb[ND + d]));
-          lb += g * g;
-        }
+        do_sub[s] = knn_box_may_matter(tb, tb + ND, &s_box[0][wave][s][0], &s_box[1][wave][s][0], smax_reg[s]);
       }
-      do_sub[s] = lb <= (long long)smax + 1;
       do_tile |= do_sub[s];
     }
     if (do_tile) {
@@ -209,78 +225,67 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
         const v4i x = *reinterpret_cast<const v4i *>(L + KT * 1024 + (g * 8 + half * 4) * 4);
         nt[g * 4] = x[0]; nt[g * 4 + 1] = x[1]; nt[g * 4 + 2] = x[2]; nt[g * 4 + 3] = x[3];
       }
-      // 2-deep software pipeline over the query sub-tiles: the MFMAs of sub-tile s run beside the VALU epilogue of
-      // sub-tile s-1 (and beside the other wave of this SIMD).
-      v16i acc0[2], acc1[2], acc2[2];
+      // one query sub-tile at a time (a single accumulator set keeps the kernel out of scratch; the other wave of the
+      // SIMD overlaps its MFMAs with this wave's VALU epilogue)
 #pragma unroll
-      for (int s = 0; s <= NQ; s++) {
-        if (s < NQ && do_sub[s]) {
-          nvisit++;
-          const int b = s & 1;
+      for (int s = 0; s < NQ; s++) {
+        if (!do_sub[s]) continue;
+        nvisit++;
+        v16i acc0, acc1, acc2;
 #pragma unroll
-          for (int r = 0; r < 16; r++) { acc0[b][r] = 0; acc1[b][r] = 0; acc2[b][r] = 0; }
+        for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; acc2[r] = 0; }
 #pragma unroll
-          for (int kc = 0; kc < 6; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);  // T_L chunk
-            acc0[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc0[b], 0, 0, 0);                    // T_L . Q_L
-            if (kc < HQ) acc1[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc1[b], 0, 0, 0);  // T_L . Q_H
-          }
-#pragma unroll
-          for (int kc = 0; kc < HT; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
-            acc1[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc1[b], 0, 0, 0);                    // T_H . Q_L
-            if (kc < HM) acc2[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc2[b], 0, 0, 0);  // T_H . Q_H
-          }
+        for (int kc = 0; kc < 6; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);  // T_L chunk
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc0, 0, 0, 0);                    // T_L . Q_L
+          if (kc < HQ) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc1, 0, 0, 0);  // T_L . Q_H
         }
-        if (s > 0 && do_sub[s > 0 ? s - 1 : 0]) {
-          const int b = (s - 1) & 1;
-          int m = INT_MAX;
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            unsigned x = (unsigned)acc0[b][r];
-            if (HT + HQ > 0) {
-              unsigned hi = (unsigned)acc1[b][r];
-              if (HM > 0) hi += (unsigned)acc2[b][r] << 8;
-              x += hi << 8;
-            }
-            const int d = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s - 1]);
-            m = min(m, d);
-          }
-          if (m == best[s - 1]) tie[s - 1] = 1;  // another tile reaches the same value
-          if (__builtin_amdgcn_ballot_w64(m < best[s - 1])) {  // some lane improves (rare once the bests have settled)
-            int row = 0, cnt = 0;
-#pragma unroll
-            for (int r = 15; r >= 0; r--) {
-              unsigned x = (unsigned)acc0[b][r];
-              if (HT + HQ > 0) {
-                unsigned hi = (unsigned)acc1[b][r];
-                if (HM > 0) hi += (unsigned)acc2[b][r] << 8;
-                x += hi << 8;
-              }
-              const int d = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s - 1]);
-              if (d == m) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
-            }
-            if (m < best[s - 1]) { best[s - 1] = m; bestt[s - 1] = (cur_tile << 5) | row; tie[s - 1] = cnt > 1; }
-          }
+        for (int kc = 0; kc < HT; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc1, 0, 0, 0);                    // T_H . Q_L
+          if (kc < HM) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc2, 0, 0, 0);  // T_H . Q_H
         }
-        __builtin_amdgcn_sched_barrier(0);
+        int d[16];
+        int m = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          unsigned x = (unsigned)acc0[r];
+          if (HT + HQ > 0) {
+            unsigned hi = (unsigned)acc1[r];
+            if (HM > 0) hi += (unsigned)acc2[r] << 8;
+            x += hi << 8;
+          }
+          d[r] = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s]);
+          m = min(m, d[r]);
+        }
+        if (m == best[s]) tie[s] = 1;  // another tile reaches the same value
+        if (m < best[s]) {             // this lane improves: which row, and is it alone?
+          int row = 0, cnt = 0;
+#pragma unroll
+          for (int r = 15; r >= 0; r--)
+            if (d[r] == m) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
+          best[s] = m;
+          bestt[s] = ((cur_tile & 0x7fffff) << 5) | row;
+          improved = true;
+          tie[s] = cnt > 1;
+        }
       }
     }
+    if (__builtin_amdgcn_ballot_w64(improved)) {  // some lane has a new best: refresh the sub-tile maxima
+      improved = false;
 #pragma unroll
-    for (int s = 0; s < NQ; s++) {
-      int smax = best[s];
+      for (int s = 0; s < NQ; s++) {
+        int smax = best[s];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
-      if (lane == 0) s_smax[cur ^ 1][wave][s] = smax;
+        for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+        smax_reg[s] = smax;
+        if (lane == 0) s_smax[wave][s] = smax;
+      }
     }
-    if (nxt_tile >= 0) {
-#pragma unroll
-      for (int i = 0; i < NST; i++)
-        if (tid + i * NT < TILE_VEC) *reinterpret_cast<v4i *>(&lds[cur ^ 1][(tid + i * NT) * 16]) = st[i];
-    }
-    __syncthreads();
-    cur ^= 1;
+    cur = cur == NBUF - 1 ? 0 : cur + 1;
     cur_tile = nxt_tile;
+    nxt_tile = nn_tile;
   }
 
 #pragma unroll
