@@ -164,16 +164,26 @@ __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_
 constexpr int KCH = 16;  // centroids scored per pass (register accumulators)
 constexpr int DCH = 32;  // dimensions staged per pass (D = 192): 256 points x 32 dims, padded rows
 
-template <int D>
-__global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, Seg *__restrict__ segs, int k,
-                                                const double *__restrict__ cent, int32_t *__restrict__ assign) {
-  extern __shared__ double s_dyn[];  // [KCH][D] centroids, then (D > 3) [256][DCH+1] int32 points
+// Assignment step.  D = 192: points and centroids are staged chunk by chunk through LDS (coalesced 16-byte loads,
+// padded rows, broadcast centroid reads).  D = 3 (FUSE_ACC): points are read directly and the exact integer sums of the
+// new assignment are accumulated in LDS in the same pass.
+template <int D, bool FUSE_ACC>
+__global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
+                                                int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
+                                                u64 *__restrict__ sums, u64 *__restrict__ cnts) {
+  extern __shared__ double s_dyn[];
+  // D > 3:  [KCH][DCH] centroid chunk (double) | [256][DCH+1] points (int32)
+  // D == 3: [KCH][3] centroid chunk (double)   | [kk][4] u64 partial sums (FUSE_ACC)
   double *s_cent = s_dyn;
-  int32_t *s_pts = reinterpret_cast<int32_t *>(s_dyn + KCH * D);
+  int32_t *s_pts = reinterpret_cast<int32_t *>(s_dyn + KCH * (D > 3 ? DCH : D));
+  u64 *s_acc = reinterpret_cast<u64 *>(s_dyn + KCH * D);
   const int seg = blockIdx.y;
   const Seg sg = segs[seg];
   const int kk = sg.kk;
   int changed = 0;
+  if (FUSE_ACC) {
+    for (int e = threadIdx.x; e < kk * (D + 1); e += 256) s_acc[e] = 0;
+  }
   const int64_t iters = (sg.count + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < iters; it++) {
     const int64_t base = (it * gridDim.x + blockIdx.x) * 256;
@@ -181,28 +191,39 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
     const bool valid = i < sg.count;
     double bd = 0.0;
     int bc = -1;
+    int32_t p3[3] = {0, 0, 0};
+    if (D == 3 && valid) { p3[0] = pts[(sg.begin + i) * 3]; p3[1] = pts[(sg.begin + i) * 3 + 1]; p3[2] = pts[(sg.begin + i) * 3 + 2]; }
     for (int c0 = 0; c0 < kk; c0 += KCH) {
       const int nc = min(KCH, kk - c0);
-      __syncthreads();
-      for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
       double s[KCH];
 #pragma unroll
       for (int c = 0; c < KCH; c++) s[c] = 0.0;
       if (D == 3) {
         __syncthreads();
+        for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
+        __syncthreads();
         if (valid) {
-          const int32_t *p = pts + (sg.begin + i) * D;
+          if (nc == KCH) {
 #pragma unroll
-          for (int j = 0; j < D; j++) {
-            const double pj = (double)p[j];
+            for (int j = 0; j < 3; j++) {
+              const double pj = (double)p3[j];
 #pragma unroll
-            for (int c = 0; c < KCH; c++)
-              if (c < nc) { const double t = __dsub_rn(pj, s_cent[c * D + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+              for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+            }
+          } else {
+            for (int j = 0; j < 3; j++) {
+              const double pj = (double)p3[j];
+              for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+            }
           }
         }
       } else {
         for (int j0 = 0; j0 < D; j0 += DCH) {
-          __syncthreads();  // previous chunk fully consumed (and centroids written, first time round)
+          __syncthreads();  // previous chunk fully consumed
+          for (int e = threadIdx.x; e < nc * DCH; e += 256) {
+            const int c = e / DCH, j = e - c * DCH;
+            s_cent[e] = cent[((int64_t)seg * k + c0 + c) * D + j0 + j];
+          }
           // coalesced: 8 threads x 16 B cover one row's 32 dims; 32 rows per pass
           for (int r = threadIdx.x >> 3; r < 256; r += 32) {
             const int64_t pi = base + r;
@@ -214,28 +235,55 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
           __syncthreads();
           if (valid) {
             const int32_t *pr = s_pts + threadIdx.x * (DCH + 1);
-#pragma unroll 8
-            for (int j = 0; j < DCH; j++) {
-              const double pj = (double)pr[j];
+            if (nc == KCH) {  // full chunk: branch-free, KCH independent accumulation chains
+#pragma unroll 4
+              for (int j = 0; j < DCH; j++) {
+                const double pj = (double)pr[j];
 #pragma unroll
-              for (int c = 0; c < KCH; c++)
-                if (c < nc) { const double t = __dsub_rn(pj, s_cent[c * D + j0 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+                for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+              }
+            } else {
+              for (int j = 0; j < DCH; j++) {
+                const double pj = (double)pr[j];
+                for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+              }
             }
           }
         }
       }
       if (valid) {
+        if (nc == KCH) {
 #pragma unroll
-        for (int c = 0; c < KCH; c++)
-          if (c < nc && (bc < 0 || s[c] < bd)) { bd = s[c]; bc = c0 + c; }
+          for (int c = 0; c < KCH; c++)
+            if (bc < 0 || s[c] < bd) { bd = s[c]; bc = c0 + c; }
+        } else {
+          for (int c = 0; c < nc; c++)
+            if (bc < 0 || s[c] < bd) { bd = s[c]; bc = c0 + c; }
+        }
       }
     }
     if (valid) {
       if (assign[sg.begin + i] != bc) { assign[sg.begin + i] = bc; changed++; }
+      if (FUSE_ACC) {
+        const long long wi = w ? (long long)w[sg.begin + i] : 1;
+        atomicAdd(&s_acc[bc * (D + 1) + D], (u64)wi);
+#pragma unroll
+        for (int j = 0; j < 3; j++) atomicAdd(&s_acc[bc * (D + 1) + j], (u64)(wi * p3[j]));
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
   if ((threadIdx.x & 63) == 0 && changed) atomicAdd(&segs[seg].changed, changed);
+  if (FUSE_ACC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < kk * (D + 1); e += 256) {
+      const u64 v = s_acc[e];
+      if (v == 0) continue;
+      const int c = e / (D + 1), j = e - c * (D + 1);
+      if (j == D) atomicAdd(&cnts[(int64_t)seg * k + c], v);
+      else atomicAdd(&sums[((int64_t)seg * k + c) * D + j], v);
+    }
+  }
 }
 
 // exact integer weighted sums: LDS partials per workgroup for up to KCH_ACC clusters x D, flushed with global atomics
@@ -276,31 +324,30 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
   }
 }
 
-// centroid = sum / weight where weight > 0; resets sums; latches per-segment convergence into *any_changed
-__global__ void k_update(Seg *__restrict__ segs, int nseg, int k, int d, u64 *__restrict__ sums, u64 *__restrict__ cnts,
-                         double *__restrict__ cent, int *__restrict__ any_changed) {
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+// One block: centroid = sum / weight where weight > 0 (segments that changed), reset sums/counts/changed, and latch the
+// first iteration in which nothing changed anywhere (so the host can poll rarely).
+__global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int nseg, int k, int d, u64 *__restrict__ sums,
+                                                     u64 *__restrict__ cnts, double *__restrict__ cent, int it,
+                                                     int *__restrict__ quiet_iter) {
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
   const int64_t total = (int64_t)nseg * k * d;
-  if (e < total) {
+  for (int64_t e = threadIdx.x; e < total; e += 1024) {
     const int64_t sc = e / d;
     const int seg = (int)(sc / k);
     const u64 cn = cnts[sc];
     if (segs[seg].changed && cn > 0) cent[e] = __ddiv_rn((double)(long long)sums[e], (double)(long long)cn);
     sums[e] = 0;
   }
-}
-__global__ void k_update_finish(Seg *__restrict__ segs, int nseg, int k, u64 *__restrict__ cnts, int *__restrict__ any_changed) {
-  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (seg < nseg) {
-    if (segs[seg].changed) atomicOr(any_changed, 1);
+  __syncthreads();
+  for (int seg = threadIdx.x; seg < nseg; seg += 1024) {
+    if (segs[seg].changed) s_any = 1;
     segs[seg].changed = 0;
-    for (int c = 0; c < k; c++) cnts[(int64_t)seg * k + c] = 0;
   }
-}
-
-// first iteration (if any) in which no assignment changed, latched on the device so the host can poll rarely
-__global__ void k_latch_quiet(const int *__restrict__ any_changed, int it, int *__restrict__ quiet_iter) {
-  if (*any_changed == 0 && *quiet_iter < 0) *quiet_iter = it;
+  for (int64_t sc = threadIdx.x; sc < (int64_t)nseg * k; sc += 1024) cnts[sc] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_any == 0 && *quiet_iter < 0) *quiet_iter = it;
 }
 
 // ---- driver ----------------------------------------------------------------------------------------------------
@@ -343,8 +390,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
-  const size_t lds_assign = (size_t)KCH * d * 8 + (d > 3 ? (size_t)256 * (DCH + 1) * 4 : 0);
+  const size_t lds_assign = d > 3 ? (size_t)KCH * DCH * 8 + (size_t)256 * (DCH + 1) * 4 : (size_t)KCH * 3 * 8 + (size_t)k * 4 * 8;
   const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
+  const bool fuse3 = d == 3 && (size_t)k * 4 * 8 <= 32 * 1024;
   DevBuf quiet;
   TM_TRY(quiet.alloc(4));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
@@ -354,17 +402,17 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     const int batch = std::min(poll_every, max_iter - issued);
     for (int b = 0; b < batch; b++, issued++) {
       if (d == 3) {
-        hipLaunchKernelGGL(k_assign<3>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
-        hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+        if (fuse3) {
+          hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
+        } else {
+          hipLaunchKernelGGL((k_assign<3, false>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+        }
       } else {
-        hipLaunchKernelGGL(k_assign<192>, dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, ds, k, cent, assign);
+        hipLaunchKernelGGL((k_assign<192, false>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
         hipLaunchKernelGGL(k_accumulate<192>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
       }
-      TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
-      const int64_t total = (int64_t)nseg * k * d;
-      hipLaunchKernelGGL(k_update, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, flag.as<int>());
-      hipLaunchKernelGGL(k_update_finish, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, cnts.as<u64>(), flag.as<int>());
-      hipLaunchKernelGGL(k_latch_quiet, dim3(1), dim3(1), 0, stream, flag.as<int>(), issued, quiet.as<int>());
+      hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
     int q = -1;
     TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
