@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
   const Seg sg = segs[seg];
   const int kk = sg.kk;
   int changed = 0;
+  constexpr int NCOPY = 16;  // private copies of the LDS sums (lane & 15): same-cluster lanes no longer serialise on one word
   if (FUSE_ACC) {
-    for (int e = threadIdx.x; e < kk * (D + 1); e += 256) s_acc[e] = 0;
+    for (int e = threadIdx.x; e < NCOPY * kk * (D + 1); e += 256) s_acc[e] = 0;
   }
   const int64_t iters = (sg.count + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
   for (int64_t it = 0; it < iters; it++) {
@@ -266,9 +267,10 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
       if (assign[sg.begin + i] != bc) { assign[sg.begin + i] = bc; changed++; }
       if (FUSE_ACC) {
         const long long wi = w ? (long long)w[sg.begin + i] : 1;
-        atomicAdd(&s_acc[bc * (D + 1) + D], (u64)wi);
+        u64 *acc = s_acc + ((threadIdx.x & (NCOPY - 1)) * kk + bc) * (D + 1);
+        atomicAdd(&acc[D], (u64)wi);
 #pragma unroll
-        for (int j = 0; j < 3; j++) atomicAdd(&s_acc[bc * (D + 1) + j], (u64)(wi * p3[j]));
+        for (int j = 0; j < 3; j++) atomicAdd(&acc[j], (u64)(wi * p3[j]));
       }
     }
   }
@@ -277,7 +279,9 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
   if (FUSE_ACC) {
     __syncthreads();
     for (int e = threadIdx.x; e < kk * (D + 1); e += 256) {
-      const u64 v = s_acc[e];
+      u64 v = 0;
+#pragma unroll
+      for (int cp = 0; cp < NCOPY; cp++) v += s_acc[cp * kk * (D + 1) + e];
       if (v == 0) continue;
       const int c = e / (D + 1), j = e - c * (D + 1);
       if (j == D) atomicAdd(&cnts[(int64_t)seg * k + c], v);
@@ -390,9 +394,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
-  const size_t lds_assign = d > 3 ? (size_t)KCH * DCH * 8 + (size_t)256 * (DCH + 1) * 4 : (size_t)KCH * 3 * 8 + (size_t)k * 4 * 8;
+  const size_t lds_assign = d > 3 ? (size_t)KCH * DCH * 8 + (size_t)256 * (DCH + 1) * 4 : (size_t)KCH * 3 * 8 + (size_t)16 * k * 4 * 8;
   const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
-  const bool fuse3 = d == 3 && (size_t)k * 4 * 8 <= 32 * 1024;
+  const bool fuse3 = d == 3 && (size_t)16 * k * 4 * 8 <= 48 * 1024;
   DevBuf quiet;
   TM_TRY(quiet.alloc(4));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));

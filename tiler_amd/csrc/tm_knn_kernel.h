@@ -12,7 +12,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int KNN_NQ = 2;  // query sub-tiles (32 queries each) per wave
-constexpr int KNN_NW = 4;  // waves per workgroup (256 queries; two workgroups share a CU)
+constexpr int KNN_NW = 2;  // waves per workgroup (128 queries; four workgroups share a CU)
 
 // Database tiles (32 rows): [6 low chunks | HT high chunks] x [64 lanes] x 16 B, then 32 u32 norms |t-c|^2.
 // Query tiles (32 queries): [6 low chunks | HQ high chunks] of the NEGATED centred values, then 32 u32 (|q-c|^2 >> 1).
