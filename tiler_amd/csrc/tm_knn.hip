@@ -490,7 +490,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
   TM_TRY(ix->counters.alloc(32));
   TM_HIP(hipMemsetAsync(ix->counters.p, 0, 32, stream));
-  static const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;
+  const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
   TM_HIP(hipEventRecord(ix->ev0, stream));
   int *bt = ix->best_tile.as<int>();
   KnnBoxes bx;
