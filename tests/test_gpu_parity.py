@@ -219,3 +219,18 @@ def test_quantize_and_palettize(tiles_flags, oracle):
     exp_idx = oracle.palettize(feat, use, 6)
     got_idx = stages.palettize(_dev(feat), _dev(use), 6).cpu().numpy()
     assert np.array_equal(got_idx, exp_idx)
+
+
+@pytest.mark.parametrize("mixed", [1, 4, 16])
+def test_dither_yliluoma(tiles_flags, oracle, mixed):
+    """DitheringUseThomasKnoll=0: the live SSE4.1 restatement (tilingencoder.pas:2417-2504) incl. its 32-bit wrap"""
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    tiles, flags = tiles[:96], flags[:96]
+    rng = np.random.default_rng(13 + mixed)
+    palettes = rng.integers(0, 1 << 24, size=(3, 16), dtype=np.int32)
+    palettes[1, 7:] = -65281
+    pal_idx = rng.integers(0, 3, size=tiles.shape[0], dtype=np.int32)
+    exp = oracle.dither(tiles, flags, pal_idx, palettes, False, mixed)
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), False, mixed).cpu().numpy()
+    assert np.array_equal(got, exp)

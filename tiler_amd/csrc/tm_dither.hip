@@ -17,6 +17,43 @@ namespace tmx {
 
 __device__ __forceinline__ int div_trunc_1000(int v) { return v / 1000; }  // Pascal div: toward zero, like C
 
+// QuickSort(List[0], 0, last, 1, PlanCompareLuma) of extern.pas:370-418 on one lane's list, iterative form: explicit
+// stack for the "recurse left, loop right" shape; the pivot VALUE is constant during a partition pass because the
+// reference tracks the pivot element through swaps.  Entries are rank << 8 | plan index; only the rank is compared.
+__device__ __forceinline__ void lane_quicksort(uint16_t (*s_list)[64], uint16_t (*s_stack)[64], int lane, int last_in) {
+  if (last_in <= 0) return;
+  int first = 0, last = last_in, sp = 0;
+  while (true) {
+    int i = first, j = last;
+    const int pv = s_list[(first + last) >> 1][lane] >> 8;
+    do {
+      while ((s_list[i][lane] >> 8) < pv) i++;
+      while ((s_list[j][lane] >> 8) > pv) j--;
+      if (i <= j) {
+        const uint16_t a = s_list[i][lane], b = s_list[j][lane];
+        s_list[i][lane] = b;
+        s_list[j][lane] = a;
+        i++;
+        j--;
+      }
+    } while (i <= j);
+    if (first < j) {  // recurse left, remember (i, last) for the loop tail
+      s_stack[sp++][lane] = (uint16_t)((i << 8) | last);
+      last = j;
+      continue;
+    }
+    bool done = false;  // first := i; until i >= last
+    while (i >= last) {
+      if (sp == 0) { done = true; break; }
+      const uint16_t fr = s_stack[--sp][lane];
+      i = fr >> 8;
+      last = fr & 0xff;
+    }
+    if (done) break;
+    first = i;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
                                                   const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
                                                   int npal, int pal_size, const uint8_t *__restrict__ dither_map,
@@ -80,42 +117,92 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
       const int4 p = s_plan[chosen];
       e0 += s0 - p.x; e1 += s1 - p.y; e2 += s2 - p.z;
     }
-    // QuickSort(List[0], 0, 63, 1, PlanCompareLuma) -- extern.pas:370-418, iterative form
-    {
-      int first = 0, last = 63, sp = 0;
-      while (true) {
-        int i = first, j = last;
-        const int pv = s_list[(first + last) >> 1][lane] >> 8;
-        do {
-          while ((s_list[i][lane] >> 8) < pv) i++;
-          while ((s_list[j][lane] >> 8) > pv) j--;
-          if (i <= j) {
-            const uint16_t a = s_list[i][lane], b = s_list[j][lane];
-            s_list[i][lane] = b;
-            s_list[j][lane] = a;
-            i++;
-            j--;
-          }
-        } while (i <= j);
-        if (first < j) {  // recurse left, remember (i, last) for the loop tail
-          s_stack[sp++][lane] = (uint16_t)((i << 8) | last);
-          last = j;
-          continue;
-        }
-        // first := i; until i >= last
-        bool done = false;
-        while (i >= last) {
-          if (sp == 0) { done = true; break; }
-          const uint16_t fr = s_stack[--sp][lane];
-          i = fr >> 8;
-          last = fr & 0xff;
-        }
-        if (done) break;
-        first = i;
-      }
-    }
+    lane_quicksort(s_list, s_stack, lane, 63);
     const int pick = s_list[map_value][lane] & 0xff;
     out[t * 64 + src] = s_remap[pick];  // re-mirror (2721-2722): natural (y,x) lives at canonical position src
+  }
+}
+
+// DeviseBestMixingPlanYliluoma, the live SSE4.1 path (ASM_DBMP, tilingencoder.pas:2339-2563): greedy mix of up to
+// Y2MixedColors palette entries; candidate averages use the reciprocal table FVecInv[4t..4t+3] = 65536 div t
+// (1698-1699) on four 32-bit lanes (r, g, b, luma div 1000), penalty = 13 (dR^2+dG^2+dB^2) + 32 dL^2 as a 32-bit
+// wrapping sum compared unsigned, first strict minimum wins; the list is sorted by luma and read at
+// (map * count) >> 6 (2716).
+__global__ __launch_bounds__(64) void k_dither_yliluoma(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
+                                                        const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
+                                                        int npal, int pal_size, int y2_mixed, const uint8_t *__restrict__ dither_map,
+                                                        uint8_t *__restrict__ out) {
+  __shared__ int4 s_plan[64];  // r, g, b, luma div 1000 (Y2Palette)
+  __shared__ int s_luma[64];   // LumaPal
+  __shared__ uint8_t s_rank[64], s_remap[64];
+  __shared__ uint16_t s_list[64][64], s_stack[64][64];
+  const int lane = threadIdx.x;
+  int cached_pal = -1, cnt = 0;
+  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const int pi = pal_idx[t];
+    if (pi != cached_pal) {
+      __syncthreads();
+      int col = TM_NULL_COLOR;
+      if (lane < pal_size && pi >= 0 && pi < npal) col = palettes[(int64_t)pi * pal_size + lane];
+      const bool live = col != TM_NULL_COLOR;
+      const unsigned long long m = __ballot(live);
+      cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      const int r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
+      const int luma = r * 299 + g * 587 + b * 114;
+      if (live) { s_plan[pos] = make_int4(r, g, b, luma / 1000); s_luma[pos] = luma; s_remap[pos] = (uint8_t)lane; }
+      __syncthreads();
+      if (lane < cnt) {
+        const int my = s_luma[lane];
+        int rk = 0;
+        for (int i = 0; i < cnt; i++) rk += (s_luma[i] < my) ? 1 : 0;
+        s_rank[lane] = (uint8_t)rk;
+      }
+      __syncthreads();
+      cached_pal = pi;
+    }
+    if (cnt == 0) { out[t * 64 + lane] = 0; continue; }
+    const int f = flags ? flags[t] : 0;
+    const int y = lane >> 3, x = lane & 7;
+    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);
+    const uint32_t c = tiles[t * 64 + src];
+    uint32_t tgt[4] = {c & 0xff, (c >> 8) & 0xff, (c >> 16) & 0xff, 0};
+    tgt[3] = (tgt[0] * 299u + tgt[1] * 587u + tgt[2] * 114u) / 1000u;
+    const uint32_t wgt[4] = {13, 13, 13, 32};
+    int plan_count = 0;
+    uint32_t so_far[4] = {0, 0, 0, 0};
+    while (plan_count < y2_mixed) {
+      const int max_test = plan_count == 0 ? 1 : plan_count;
+      unsigned long long best = (1ull << 63) - 1ull;
+      int chosen = 0, chosen_amount = 1;
+      for (int idx = 0; idx < cnt; idx++) {
+        const int4 p = s_plan[idx];
+        uint32_t sum[4] = {so_far[0], so_far[1], so_far[2], so_far[3]};
+        uint32_t add[4] = {(uint32_t)p.x, (uint32_t)p.y, (uint32_t)p.z, (uint32_t)p.w};
+        for (int tt = plan_count + 1; tt <= plan_count + max_test; tt++) {
+          const uint32_t inv = 65536u / (uint32_t)tt;
+          uint32_t pen = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            sum[k] += add[k];
+            add[k] += 1;
+            const uint32_t d = ((sum[k] * inv) >> 16) - tgt[k];
+            pen += d * d * wgt[k];
+          }
+          if ((unsigned long long)pen < best) { best = pen; chosen = idx; chosen_amount = tt - plan_count; }
+        }
+      }
+      if (chosen_amount > 64 - plan_count) chosen_amount = 64 - plan_count;  // list room (<= 30 entries for Y2MixedColors <= 16)
+      const uint16_t e = (uint16_t)((s_rank[chosen] << 8) | chosen);
+      for (int k = 0; k < chosen_amount; k++) s_list[plan_count + k][lane] = e;
+      plan_count += chosen_amount;
+      const int4 p = s_plan[chosen];
+      so_far[0] += (uint32_t)p.x * chosen_amount; so_far[1] += (uint32_t)p.y * chosen_amount;
+      so_far[2] += (uint32_t)p.z * chosen_amount; so_far[3] += (uint32_t)p.w * chosen_amount;
+    }
+    lane_quicksort(s_list, s_stack, lane, plan_count - 1);
+    const int map_value = (dither_map[lane] * plan_count) >> 6;
+    out[t * 64 + src] = s_remap[s_list[map_value][lane] & 0xff];
   }
 }
 
@@ -124,11 +211,16 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
   const DeviceTables *tab;
   TM_TRY(get_tables(&tab));
   TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
-  TM_CHECK(use_tk, TM_E_UNSUPPORTED, "Yliluoma dithering is not built yet (DitheringUseThomasKnoll=0); see DESIGN.md");
+  TM_CHECK(use_tk || (y2_mixed >= 1 && y2_mixed <= 16), TM_E_INVAL, "DitheringYliluoma2MixedColors %d outside 1..16 (tilingencoder.pas:2922)", y2_mixed);
   if (n <= 0) return TM_OK;
   int grid = (int)std::min<int64_t>(n, 256 * 40);
-  hipLaunchKernelGGL(k_dither_tk, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
-                     (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, tab->dither_map, (uint8_t *)out_pal_px);
+  if (use_tk)
+    hipLaunchKernelGGL(k_dither_tk, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
+                       (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, tab->dither_map, (uint8_t *)out_pal_px);
+  else
+    hipLaunchKernelGGL(k_dither_yliluoma, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
+                       (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, y2_mixed, tab->dither_map,
+                       (uint8_t *)out_pal_px);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
