@@ -164,6 +164,9 @@ TM_API int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, in
 TM_API int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx,
                               void *stream);
 
+/* A11: OptimizePalettes (:4309-4432), host arithmetic on HOST memory (P x PaletteSize colours); in place. */
+TM_API int tm_optimize_palettes_host(int32_t *palettes, int pal_count, int pal_size, int *sweeps);
+
 /* ======================================================================================= fine seam
  * extern.pas:182-185 (ANN_short.dll), :198-203 (yakmo.dll), :218-223 (BICO.dll).  Host pointers. */
 typedef struct tm_ann tm_ann;

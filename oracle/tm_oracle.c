@@ -929,3 +929,226 @@ void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, in
   for (int64_t i = 0; i < n; i++) pal_idx_out[i] = lut[assign[i]];
   free(lut); free(ord); free(cnt); free(assign); free(cent);
 }
+
+/* ------------------------------------------------------------------ A11 OptimizePalettes + Powell (powell.pas) */
+
+typedef double (*fn1_t)(double t, void *ctx);
+
+static void sw(double *a, double *b) { double t = *a; *a = *b; *b = t; }
+static double sgn(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
+
+static void bracket(fn1_t f, void *ctx, double xa, double xb, double out[3]) { /* Bracket, powell.pas:56-147 */
+  const double Gold = (1 + sqrt(5.0)) / 2, Small = 1e-21, GrowLimit = 110;
+  double fa = f(xa, ctx), fb = f(xb, ctx), fc, xc, w, fw, tmp1, tmp2, val, denom, wlim;
+  int iter = 0;
+  if (fa < fb) { sw(&xa, &xb); sw(&fa, &fb); }
+  xc = xb + Gold * (xb - xa);
+  fc = f(xc, ctx);
+  while (fc < fb) {
+    tmp1 = (xb - xa) * (fb - fc);
+    tmp2 = (xb - xc) * (fb - fa);
+    val = tmp2 - tmp1;
+    denom = fabs(val) < Small ? 2 * Small : 2 * val;
+    w = xb - ((xb - xc) * tmp2 - (xb - xa) * tmp1) / denom;
+    wlim = xb + GrowLimit * (xc - xb);
+    if (iter > 1000) break; /* the reference raises; unreachable for bounded objectives */
+    iter++;
+    fw = 0;
+    if ((w - xc) * (xb - w) > 0) {
+      fw = f(w, ctx);
+      if (fw < fc) { xa = xb; xb = w; fa = fb; fb = fw; break; }
+      else if (fw > fb) { xc = w; fc = fw; break; }
+      w = xc + Gold * (xc - xb);
+      fw = f(w, ctx);
+    } else if ((w - wlim) * (wlim - xc) >= 0) {
+      w = wlim;
+      fw = f(w, ctx);
+    } else if ((w - wlim) * (xc - w) > 0) {
+      fw = f(w, ctx);
+      if (fw < fc) { xb = xc; xc = w; w = xc + Gold * (xc - xb); fb = fc; fc = fw; fw = f(w, ctx); }
+    } else {
+      w = xc + Gold * (xc - xb);
+      fw = f(w, ctx);
+    }
+    xa = xb; xb = xc; xc = w;
+    fa = fb; fb = fc; fc = fw;
+  }
+  if (xa > xc) { sw(&xa, &xc); sw(&fa, &fc); }
+  out[0] = xa; out[1] = xb; out[2] = xc;
+}
+
+static void brent(fn1_t f, void *ctx, double xtol, int maxiter, double *xmin, double *fmin) { /* Brent + BrentHelper, 149-266 */
+  const double CG = (3 - sqrt(5.0)) / 2;
+  double br[3];
+  bracket(f, ctx, 0, 1, br);
+  double a = br[0], x = br[1], b = br[2], fx = f(x, ctx);
+  if (a > b) sw(&a, &b);
+  double w = x, v = x, fw = fx, fv = fx, deltax = 0, rat = 0, xmid, tmp1, tmp2, p, dx_temp, u, fu;
+  int iter = 0;
+  while (iter < maxiter) {
+    xmid = 0.5 * (a + b);
+    if (fabs(x - xmid) <= 2 * xtol - 0.5 * (b - a)) break;
+    if (fabs(deltax) <= xtol) {
+      deltax = x >= xmid ? a - x : b - x;
+      rat = CG * deltax;
+    } else {
+      tmp1 = (x - w) * (fx - fv);
+      tmp2 = (x - v) * (fx - fw);
+      p = (x - v) * tmp2 - (x - w) * tmp1;
+      tmp2 = 2 * (tmp2 - tmp1);
+      if (tmp2 > 0) p = -p;
+      tmp2 = fabs(tmp2);
+      dx_temp = deltax;
+      deltax = rat;
+      if (p > tmp2 * (a - x) && p < tmp2 * (b - x) && fabs(p) < fabs(0.5 * tmp2 * dx_temp)) {
+        rat = p / tmp2;
+        u = x + rat;
+        if (u - a < xtol || b - u < xtol) rat = sgn(xmid - x) * xtol;
+      } else {
+        deltax = x >= xmid ? a - x : b - x;
+        rat = CG * deltax;
+      }
+    }
+    u = fabs(rat) > xtol ? x + rat : x + sgn(rat) * xtol;
+    fu = f(u, ctx);
+    if (fu > fx) {
+      if (u < x) a = u; else b = u;
+      if (fu <= fw || w == x) { v = w; w = u; fv = fw; fw = fu; }
+      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+    } else {
+      if (u >= x) a = x; else b = x;
+      v = w; w = x; x = u;
+      fv = fw; fw = fx; fx = fu;
+    }
+    iter++;
+  }
+  *xmin = x;
+  *fmin = fx;
+}
+
+typedef double (*fnn_t)(const double *x, void *data);
+typedef struct { fnn_t f; void *data; const double *p, *xi; int n; double *tmp; } ray_ctx;
+static double along_ray(double t, void *c) { /* AlongRay1, powell.pas:273-282 */
+  ray_ctx *r = (ray_ctx *)c;
+  for (int i = 0; i < r->n; i++) r->tmp[i] = r->p[i] + t * r->xi[i];
+  return r->f(r->tmp, r->data);
+}
+
+static double linesearch(fnn_t f, void *data, double *p, double *xi, int n, double xtol, double *scratch) { /* 285-314 */
+  ray_ctx rc = {f, data, p, xi, n, scratch};
+  double sos = 0;
+  for (int i = 0; i < n; i++) sos += xi[i] * xi[i];
+  double sqsos = sqrt(sos), atol = 1.0;
+  if (sqsos != 0) atol = 5 * xtol / sqsos;
+  if (atol > 0.1) atol = 0.1;
+  double alpha, fret;
+  brent(along_ray, &rc, atol, 100, &alpha, &fret);
+  for (int i = 0; i < n; i++) { xi[i] = xi[i] * alpha; p[i] = p[i] + xi[i]; }
+  return fret;
+}
+
+static double powell_minimize(fnn_t f, void *data, double *x, int n, double scale, double xtol, double ftol, int maxiter) {
+  /* PowellMinimize, powell.pas:316-384.  FPC dynamic arrays are references: "direc[bigind] := direc[n-1];
+   * direc[n-1] := direc1" aliases the rows, and direc1 keeps being overwritten -- modelled with row pointers. */
+  double *store = (double *)calloc((size_t)(n + 1) * n + 3 * (size_t)n, sizeof(double));
+  double **direc = (double **)malloc(sizeof(double *) * (size_t)n);
+  for (int i = 0; i < n; i++) { direc[i] = store + (size_t)i * n; direc[i][i] = scale; }
+  double *direc1 = store + (size_t)n * n, *tmp = direc1 + n, *x1 = tmp + n, *scratch = x1 + n;
+  double fval = f(x, data);
+  memcpy(x1, x, sizeof(double) * (size_t)n);
+  int iter = 0;
+  for (;;) {
+    double fx = fval, delta = 0;
+    int bigind = 0;
+    for (int i = 0; i < n; i++) {
+      double fx2 = fval;
+      fval = linesearch(f, data, x, direc[i], n, xtol, scratch);
+      if (fx2 - fval > delta) { delta = fx2 - fval; bigind = i; }
+    }
+    iter++;
+    if (fx - fval <= ftol || iter >= maxiter) break;
+    for (int i = 0; i < n; i++) { direc1[i] = x[i] - x1[i]; tmp[i] = x[i] + direc1[i]; x1[i] = x[i]; }
+    double fx2 = f(tmp, data);
+    if (fx > fx2) {
+      double t = 2 * (fx + fx2 - 2 * fval), temp = fx - fval - delta;
+      t = t * temp * temp;
+      temp = fx - fx2;
+      t = t - delta * temp * temp;
+      if (t < 0) {
+        fval = linesearch(f, data, x, direc1, n, xtol, scratch);
+        direc[bigind] = direc[n - 1];
+        direc[n - 1] = direc1;
+      }
+    }
+  }
+  free(direc);
+  free(store);
+  return fval;
+}
+
+typedef struct { int pal_size, cur; const int32_t *pals; int32_t *newpal; uint64_t mean[3]; uint64_t acc[3][64]; } op_ctx;
+typedef struct { int count, index; } perm_item;
+static int cmp_perm(const void *a, const void *b) { /* ComparePerms, tilingencoder.pas:4258-4263 */
+  const perm_item *x = (const perm_item *)a, *y = (const perm_item *)b;
+  if (x->count != y->count) return x->count < y->count ? -1 : 1;
+  return (x->index > y->index) - (x->index < y->index);
+}
+
+static double powell_op(const double *x, void *data) { /* PowellOP, tilingencoder.pas:4265-4307 */
+  op_ctx *c = (op_ctx *)data;
+  perm_item perm[64];
+  perm[0].index = 0; perm[0].count = 0;
+  for (int i = 1; i < c->pal_size; i++) { perm[i].index = i; perm[i].count = (int)pas_round(x[i - 1] * 1000); }
+  qsort(perm, (size_t)c->pal_size, sizeof(perm_item), cmp_perm);
+  uint64_t sd[3] = {0, 0, 0};
+  for (int i = 0; i < c->pal_size; i++) {
+    const uint32_t col = (uint32_t)c->pals[(size_t)c->cur * c->pal_size + perm[i].index];
+    c->newpal[(size_t)c->cur * c->pal_size + i] = (int32_t)col;
+    const uint64_t ch[3] = {col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff};
+    for (int k = 0; k < 3; k++) { const uint64_t d = c->acc[k][i] + ch[k] - c->mean[k]; sd[k] += d * d; } /* UInt64 wrap = signed square */
+  }
+  const double r = (299 * sqrt((double)sd[0] / c->pal_size) + 587 * sqrt((double)sd[1] / c->pal_size) +
+                    114 * sqrt((double)sd[2] / c->pal_size)) / 1000;
+  return -r;
+}
+
+int tmo_optimize_palettes(int32_t *pals, int pal_count, int pal_size) { /* OptimizePalettes, tilingencoder.pas:4309-4432 */
+  int32_t *newpal = (int32_t *)malloc(sizeof(int32_t) * (size_t)pal_count * pal_size);
+  double *f = (double *)malloc(sizeof(double) * (size_t)pal_count);
+  uint64_t mean[3] = {0, 0, 0};
+  for (int p = 0; p < pal_count; p++)
+    for (int i = 0; i < pal_size; i++) {
+      const uint32_t col = (uint32_t)pals[(size_t)p * pal_size + i];
+      mean[0] += col & 0xff; mean[1] += (col >> 8) & 0xff; mean[2] += (col >> 16) & 0xff;
+    }
+  for (int k = 0; k < 3; k++) mean[k] /= (uint64_t)pal_size;
+  int iteration = 0;
+  double fsum = 0, prev = 0;
+  do {
+    prev = fsum > prev ? fsum : prev;
+    iteration++;
+    for (int a = 0; a < pal_count; a++) { /* DoPal; reads the palettes as they stood before this sweep */
+      op_ctx c;
+      memset(&c, 0, sizeof(c));
+      c.pal_size = pal_size; c.cur = a; c.pals = pals; c.newpal = newpal;
+      memcpy(c.mean, mean, sizeof(mean));
+      for (int p = 0; p < pal_count; p++)
+        if (p != a)
+          for (int i = 0; i < pal_size; i++) {
+            const uint32_t col = (uint32_t)pals[(size_t)p * pal_size + i];
+            c.acc[0][i] += col & 0xff; c.acc[1][i] += (col >> 8) & 0xff; c.acc[2][i] += (col >> 16) & 0xff;
+          }
+      double x[64];
+      for (int i = 1; i < pal_size; i++) x[i - 1] = i;
+      powell_minimize(powell_op, &c, x, pal_size - 1, 1.0, 1.0, 1.0, 2147483647);
+      f[a] = -powell_op(x, &c);
+    }
+    fsum = 0;
+    for (int p = 0; p < pal_count; p++) fsum += f[p];
+    memcpy(pals, newpal, sizeof(int32_t) * (size_t)pal_count * pal_size);
+    fsum /= pal_count;
+  } while (!(fsum <= prev));
+  free(f);
+  free(newpal);
+  return iteration;
+}

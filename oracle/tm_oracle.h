@@ -132,6 +132,9 @@ void tmo_quantize_palette(const uint32_t *pixels, int64_t npx, int pal_size, int
 /* tile->palette assignment + ranking by use count (tilingencoder.pas:4221-4244) */
 void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, int pal_count, int max_iter, int32_t *pal_idx_out);
 
+/* ---- A11 OptimizePalettes (tilingencoder.pas:4309-4432) with Powell/Brent (powell.pas); in place, returns sweeps ---- */
+int tmo_optimize_palettes(int32_t *palettes, int pal_count, int pal_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ def run(oracle, frames, fps=24.0, palette_size=16, palette_count=1, dithering_mo
     feat = oracle.features_cluster(gtiles, dithering_mode)
     pal_idx = oracle.palettize(feat, guse, palette_count)
     palettes = np.stack([oracle.quantize_palette(gtiles[pal_idx == p].ravel(), palette_size) for p in range(palette_count)])
+    import ctypes
+    palettes = np.ascontiguousarray(palettes, np.int32)
+    oracle.L.tmo_optimize_palettes(palettes.ctypes.data_as(ctypes.c_void_p), palette_count, palette_size)  # OptimizePalettes
     out.update(pal_idx=pal_idx, palettes=palettes)
     if timings is not None:
         timings["palettes"] = time.time() - t0

@@ -62,3 +62,18 @@ def test_product_never_touches_the_oracle():
                 assert "libtm_oracle" not in txt and "oracle_binding" not in txt and "tm_oracle.h" not in txt, fn
     out = subprocess.check_output(["ldd", LIB], text=True)
     assert "oracle" not in out
+
+
+def test_optimize_palettes_host_matches_oracle(built, oracle):
+    """A11 runs on the host in both builds: the product's C++ Powell/OptimizePalettes against the oracle's C restatement"""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    for pc, ps in ((1, 16), (6, 16), (3, 5), (9, 64)):
+        pals = rng.integers(0, 1 << 24, size=(pc, ps)).astype(np.int32)
+        pals[0, ps - 1] = -65281  # a null slot takes part as magenta (FromRGB of $FFFF00FF)
+        a, b = pals.copy(), pals.copy()
+        sw = ctypes.c_int()
+        assert built.tm_optimize_palettes_host(a.ctypes.data_as(ctypes.c_void_p), pc, ps, ctypes.byref(sw)) == 0
+        sweeps = oracle.L.tmo_optimize_palettes(b.ctypes.data_as(ctypes.c_void_p), pc, ps)
+        assert np.array_equal(a, b) and sw.value == sweeps
+        assert all(sorted(x) == sorted(y) for x, y in zip(a.tolist(), pals.tolist()))  # a permutation of each palette

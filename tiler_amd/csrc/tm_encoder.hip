@@ -281,7 +281,10 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
-  // OptimizePalettes (4309-4432): slot permutation by Powell; host-side, not built yet (DESIGN.md "Scope")
+  // OptimizePalettes (4309-4432): slot permutation by Powell on the host (P x PaletteSize colours)
+  TM_TRY(optimize_palettes_host(e->palettes_host, e->s.PaletteCount, e->s.PaletteSize, nullptr));
+  TM_HIP(hipMemcpyAsync(e->palettes_dev.p, e->palettes_host.data(), e->palettes_host.size() * 4, hipMemcpyHostToDevice, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 3, 3);
   return TM_OK;
 }

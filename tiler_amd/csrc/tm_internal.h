@@ -37,4 +37,7 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
                           hipStream_t stream);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
 
+// tm_optpal.hip (host only)
+int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_size, int *sweeps_out);
+
 }  // namespace tmx
