@@ -176,6 +176,25 @@ TM_API int ann_kdtree_short_search(tm_ann *, const int16_t *q, uint32_t eps, uin
 TM_API void ann_kdtree_short_search_multi(tm_ann *, int32_t *idxs, uint32_t *errs, int cnt, const int16_t *q, uint32_t eps);
 TM_API int ann_kdtree_short_search_batch(tm_ann *, const int16_t *queries, int nq, int32_t *idxs, uint32_t *errs);
 
+/* yakmo.dll (extern.pas:198-203).  The clustering is the build's deterministic k-means: yakmo's
+ * k-means++ RNG is not recoverable.  Inputs are rounded to int32; 3- or 192-column data only. */
+typedef struct tm_yakmo tm_yakmo;
+TM_API tm_yakmo *yakmo_create(uint32_t k, uint32_t restart_count, int max_iter, int init_type, int init_seed, int do_normalize, int is_verbose);
+TM_API void yakmo_destroy(tm_yakmo *);
+TM_API void yakmo_set_num_threads(int num_threads);
+TM_API void yakmo_load_train_data(tm_yakmo *, uint32_t row_count, uint32_t col_count, double **dataset);
+TM_API void yakmo_train_on_data(tm_yakmo *, int32_t *point_to_cluster);
+TM_API void yakmo_get_centroids(tm_yakmo *, double **centroids);
+
+/* BICO.dll (extern.pas:218-223): the "coreset" is the build's weighted k-means with `coresetsize` centres. */
+typedef struct tm_bico tm_bico;
+TM_API tm_bico *bico_create(int64_t dimension, int64_t npoints, int64_t k, int64_t nrandproj, int64_t coresetsize, int random_seed);
+TM_API void bico_destroy(tm_bico *);
+TM_API void bico_set_num_threads(int num_threads);
+TM_API void bico_set_rebuild_properties(tm_bico *, uint32_t interval, double initial, double grow);
+TM_API void bico_insert_line(tm_bico *, const double *line, double weight);
+TM_API int64_t bico_get_results(tm_bico *, double *centroids, double *weights);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,64 @@ def test_dither_yliluoma(tiles_flags, oracle, mixed):
     exp = oracle.dither(tiles, flags, pal_idx, palettes, False, mixed)
     got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), False, mixed).cpu().numpy()
     assert np.array_equal(got, exp)
+
+
+def test_fine_seam_twins(oracle):
+    """ann_kdtree_short_* / yakmo_* / bico_* called with host pointers exactly as extern.pas:182-223 declares them"""
+    import ctypes
+    from tiler_amd import lib
+    L = lib()
+    rng = np.random.default_rng(21)
+    # ANN: rows as an array of row pointers (PPSmallint)
+    db = _rand_features(rng, 300, 200)
+    q = _rand_features(rng, 5, 200)
+    rows = (ctypes.c_void_p * 300)(*[db[i].ctypes.data for i in range(300)])
+    L.ann_kdtree_short_create.restype = ctypes.c_void_p
+    tree = L.ann_kdtree_short_create(rows, 300, 192, 32, 0)
+    assert tree
+    eidx, eerr = oracle.knn1(q, db)
+    err = ctypes.c_uint32()
+    L.ann_kdtree_short_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    for i in range(5):
+        assert L.ann_kdtree_short_search(tree, q[i].ctypes.data, 0, ctypes.byref(err)) == eidx[i] and err.value == eerr[i]
+    kidx, kerr = oracle.knnk(q[:1], db, 64)
+    gi, ge = np.zeros(64, np.int32), np.zeros(64, np.uint32)
+    L.ann_kdtree_short_search_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32]
+    L.ann_kdtree_short_search_multi(tree, gi.ctypes.data, ge.ctypes.data, 64, q[0].ctypes.data, 0)
+    assert np.array_equal(gi, kidx[0]) and np.array_equal(ge, kerr[0])
+    L.ann_kdtree_short_destroy.argtypes = [ctypes.c_void_p]
+    L.ann_kdtree_short_destroy(tree)
+    # yakmo: rows of doubles (PPDouble), integer valued like QuantizeUsingYakmo's pixel dataset
+    px = rng.integers(0, 256, size=(400, 3)).astype(np.float64)
+    prow = (ctypes.c_void_p * 400)(*[px[i].ctypes.data for i in range(400)])
+    L.yakmo_create.restype = ctypes.c_void_p
+    y = L.yakmo_create(8, 1, 300, 1, 0, 0, 0)
+    L.yakmo_load_train_data.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    L.yakmo_load_train_data(y, 400, 3, prow)
+    assign = np.zeros(400, np.int32)
+    L.yakmo_train_on_data.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.yakmo_train_on_data(y, assign.ctypes.data)
+    cent = np.zeros((8, 3), np.float64)
+    crow = (ctypes.c_void_p * 8)(*[cent[i].ctypes.data for i in range(8)])
+    L.yakmo_get_centroids.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.yakmo_get_centroids(y, crow)
+    kk, eassign, ecent, _ = oracle.kmeans(px.astype(np.int32), None, 8)
+    assert kk == 8 and np.array_equal(assign, eassign) and np.array_equal(cent, ecent)
+    L.yakmo_destroy.argtypes = [ctypes.c_void_p]
+    L.yakmo_destroy(y)
+    # bico: weighted lines in, centres + weights out
+    L.bico_create.restype = ctypes.c_void_p
+    L.bico_create.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_int]
+    b = L.bico_create(3, 400, 2, 32, 16, 0x42381337)
+    L.bico_insert_line.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+    w = rng.integers(1, 9, size=400)
+    for i in range(400):
+        L.bico_insert_line(b, px[i].ctypes.data, float(w[i]))
+    bc, bw = np.zeros((16, 3)), np.zeros(16)
+    L.bico_get_results.restype = ctypes.c_int64
+    L.bico_get_results.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    n = L.bico_get_results(b, bc.ctypes.data, bw.ctypes.data)
+    kk, eassign, ecent, _ = oracle.kmeans(px.astype(np.int32), w.astype(np.uint32), 16)
+    assert n == kk and np.array_equal(bc[:kk], ecent[:kk]) and bw.sum() == w.sum()
+    L.bico_destroy.argtypes = [ctypes.c_void_p]
+    L.bico_destroy(b)

@@ -110,3 +110,106 @@ void ann_kdtree_short_search_multi(tm_ann *a, int32_t *idxs, uint32_t *errs, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// yakmo.dll / BICO.dll twins (extern.pas:198-203, 218-223).  Same call shapes, host pointers; the clustering itself
+// is the build's deterministic k-means (tm_kmeans.hip) -- yakmo's k-means++ RNG and BICO's
+// random projections are not recoverable, so results are the build's, not the DLLs'.  Inputs are rounded to int32
+// (exact for the reference's pixel datasets, tilingencoder.pas:4477-4480); only 3- and 192-column data are built.
+struct tm_yakmo {
+  int k = 0, max_iter = 300, rows = 0, cols = 0, live = 0;
+  std::vector<int32_t> pts;
+  std::vector<double> cent;
+};
+
+struct tm_bico {
+  int dim = 0;
+  int64_t k = 0, coreset = 0;
+  std::vector<int32_t> pts;
+  std::vector<uint32_t> w;
+};
+
+static int kmeans_host(const std::vector<int32_t> &pts, const uint32_t *w, int n, int d, int k, int max_iter, int32_t *assign,
+                       std::vector<double> &cent, int *live) {
+  TM_TRY(require_device());
+  TM_CHECK(d == 3 || d == 192, TM_E_UNSUPPORTED, "k-means twins: only 3 (pixels) or 192 (tile features) columns are built, got %d", d);
+  DevBuf dp, dw, da, dc;
+  TM_TRY(dp.alloc(pts.size() * 4)); TM_TRY(da.alloc((size_t)n * 4)); TM_TRY(dc.alloc((size_t)k * d * 8));
+  TM_HIP(hipMemcpy(dp.p, pts.data(), pts.size() * 4, hipMemcpyHostToDevice));
+  if (w) { TM_TRY(dw.alloc((size_t)n * 4)); TM_HIP(hipMemcpy(dw.p, w, (size_t)n * 4, hipMemcpyHostToDevice)); }
+  int iters = 0;
+  TM_TRY(run_kmeans(dp.p, w ? dw.p : nullptr, n, d, k, max_iter, da.p, dc.p, live, &iters, nullptr));
+  cent.resize((size_t)k * d);
+  TM_HIP(hipMemcpy(cent.data(), dc.p, cent.size() * 8, hipMemcpyDeviceToHost));
+  if (assign) TM_HIP(hipMemcpy(assign, da.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return TM_OK;
+}
+
+extern "C" {
+
+tm_yakmo *yakmo_create(uint32_t k, uint32_t restart_count, int max_iter, int init_type, int init_seed, int do_normalize, int is_verbose) {
+  (void)restart_count; (void)init_type; (void)init_seed; (void)do_normalize; (void)is_verbose;
+  if (k == 0 || k > 65536) { set_error("yakmo_create: k out of range"); return nullptr; }
+  tm_yakmo *y = new tm_yakmo();
+  y->k = (int)k;
+  y->max_iter = max_iter > 0 ? max_iter : 300;
+  return y;
+}
+void yakmo_destroy(tm_yakmo *y) { delete y; }
+void yakmo_set_num_threads(int) {}
+
+void yakmo_load_train_data(tm_yakmo *y, uint32_t row_count, uint32_t col_count, double **dataset) {  // copies, like the DLL (4203, 4495)
+  if (!y || !dataset) return;
+  y->rows = (int)row_count;
+  y->cols = (int)col_count;
+  y->pts.resize((size_t)row_count * col_count);
+  for (uint32_t r = 0; r < row_count; r++)
+    for (uint32_t c = 0; c < col_count; c++) y->pts[(size_t)r * col_count + c] = (int32_t)llrint(dataset[r][c]);
+}
+
+void yakmo_train_on_data(tm_yakmo *y, int32_t *point_to_cluster) {
+  if (!y || y->rows <= 0) return;
+  if (kmeans_host(y->pts, nullptr, y->rows, y->cols, std::min(y->k, y->rows), y->max_iter, point_to_cluster, y->cent, &y->live) != TM_OK)
+    y->live = 0;
+}
+
+void yakmo_get_centroids(tm_yakmo *y, double **centroids) {
+  if (!y || !centroids) return;
+  for (int c = 0; c < y->live; c++) memcpy(centroids[c], &y->cent[(size_t)c * y->cols], sizeof(double) * (size_t)y->cols);
+}
+
+tm_bico *bico_create(int64_t dimension, int64_t npoints, int64_t k, int64_t nrandproj, int64_t coresetsize, int random_seed) {
+  (void)nrandproj; (void)random_seed;
+  if (dimension <= 0 || coresetsize <= 0) { set_error("bico_create: bad arguments"); return nullptr; }
+  tm_bico *b = new tm_bico();
+  b->dim = (int)dimension;
+  b->k = k;
+  b->coreset = coresetsize;
+  b->pts.reserve((size_t)std::max<int64_t>(npoints, 0) * (size_t)dimension);
+  return b;
+}
+void bico_destroy(tm_bico *b) { delete b; }
+void bico_set_num_threads(int) {}
+void bico_set_rebuild_properties(tm_bico *, uint32_t, double, double) {}
+
+void bico_insert_line(tm_bico *b, const double *line, double weight) {
+  if (!b || !line) return;
+  for (int c = 0; c < b->dim; c++) b->pts.push_back((int32_t)llrint(line[c]));
+  b->w.push_back((uint32_t)std::max<long long>(1, llrint(weight)));
+}
+
+int64_t bico_get_results(tm_bico *b, double *centroids, double *weights) {
+  // the coreset of the inserted points = the build's k-means with coresetsize centres; weight = summed point weights
+  if (!b || !centroids || !weights || b->w.empty()) return 0;
+  const int n = (int)b->w.size(), k = (int)std::min<int64_t>(b->coreset, n);
+  std::vector<int32_t> assign(n);
+  std::vector<double> cent;
+  int live = 0;
+  if (kmeans_host(b->pts, b->w.data(), n, b->dim, k, 300, assign.data(), cent, &live) != TM_OK) return 0;
+  for (int c = 0; c < live; c++) weights[c] = 0;
+  for (int i = 0; i < n; i++) weights[assign[i]] += b->w[i];
+  memcpy(centroids, cent.data(), sizeof(double) * (size_t)live * b->dim);
+  return live;
+}
+
+}  // extern "C"
