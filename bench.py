@@ -19,6 +19,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 I8_DENSE_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: bf16 dense ~2.5 PF, i8 MFMA = 2x bf16 per clock
+# HBM-side bytes per launch of the dominant kernel on the default workload, from the separate rocprofv3 --pmc passes of
+# profiles/r01_pmc_knn.md: 2 x FETCH_SIZE (gfx950 counts half of a 16-B/lane stream) + WRITE_SIZE, in bytes
+PMC_TRAFFIC_BYTES = 2 * 92325954 * 1024 + 36914 * 1024
 
 
 def cpu_baseline(width, height, nframes, palette_count, t_global, seconds_budget=20.0):
@@ -178,7 +181,7 @@ def main():
         "stage_ms": {n: round(float(v) / args.steps, 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], stage_ms)},
         "nominal_pairs": float(q_total) * float(enc.GlobalTilingTileCount),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_DENSE_PEAK_TOPS,
-                     "traffic": None, "kernel": "k_knn_mfma", "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
+                     "traffic": PMC_TRAFFIC_BYTES if (W, H, F, args.palettes) == (1280, 720, 300, 16) else None, "kernel": "k_knn_mfma", "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
                      "pairs_per_launch": knn_pairs / max(knn_launches, 1),
                      "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair; the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }

@@ -107,8 +107,9 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   __shared__ uint8_t s_mask[KNN_CHUNK];  // which sub-tiles wanted the listed tile (bit = wave * NQ + sub-tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   constexpr int QT_PER_WG = NW * NQ;
+  // Workgroup -> query tile: identity.  XCD-contiguous ranges were measured (profiles/README.md): whole ranges per XCD
+  // lose 25 % to load imbalance (window sizes vary along the curve), runs of 32 per XCD tie with identity.
   const int64_t wgt = blockIdx.x;
-
   v4i bq[NQ][KQ];
   int nq2[NQ], best[NQ], bestt[NQ], tie[NQ];  // bestt = tile << 5 | row of the first minimum
   int64_t qtile[NQ];
