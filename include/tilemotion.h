@@ -94,7 +94,15 @@ TM_API int tm_get_palette(tm_encoder *, int i, int32_t *rgb /* PaletteSize */);
 TM_API int tm_get_keyframes(tm_encoder *, int32_t *start_frames /* keyframes */);
 TM_API int tm_get_frame_correlations(tm_encoder *, float *correl /* frames */);
 TM_API int tm_get_stage_ms(tm_encoder *, double ms[8]); /* wall ms of the last run of each step (ProgressRedraw, :3925) */
-TM_API int tm_save_gtm(tm_encoder *, const char *path);  /* Save, :2040 */
+TM_API int tm_save_gtm(tm_encoder *, const char *path);  /* Save, :2040 -> SaveStream, :5177 */
+/* The same writer on HOST arrays (no device needed): tiles in their final (Reindex) order with use counts, palettes
+ * [pal_count][pal_size], tile maps [nframes][tm_h*tm_w].  What SaveStream reads from FTiles/FPalettes/FFrames. */
+TM_API int tm_write_gtm_host(const char *path, int tm_w, int tm_h, int nframes, double fps, const int32_t *kf_start, int nkf,
+                             const uint8_t *pal_px, const uint32_t *use, int64_t ntiles, const int32_t *palettes, int pal_count,
+                             int pal_size, const tm_tilemap_item *tilemap, const char *settings_text);
+/* LZCompress, extern.pas:420-439 (LZMA-alone: lc 8, lp 0, pb 2, 4 MiB dictionary, unknown size, end marker), host
+ * buffers.  *out_n = compressed size; TM_E_INVAL (with *out_n set) when cap is too small. */
+TM_API int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n);
 /* Multi-GPU (one process per GPU): this process matches only frames [first, first+count) in Reconstruct (frames are
  * independent in the KNN branch, DoXY :1464); the host then merges the per-frame results of all processes with an
  * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex. */

@@ -1152,3 +1152,141 @@ int tmo_optimize_palettes(int32_t *pals, int pal_count, int pal_size) { /* Optim
   free(newpal);
   return iteration;
 }
+
+/* =====================================================================================================================
+ * (f)#2 checker: LZMA-alone decoder, restating decoders/htmljs/lzma.js (decodeHeader :395-450, decodeBody :477-576,
+ * RangeDecoder :128-190, LenDecoder :252-264, Decoder2 :270-300).  Used by tests/ to read back what the product's
+ * .gtm writer emits (the reference compresses with LZCompress, extern.pas:420-439: lc 8, lp 0, pb 2, end marker).
+ * ===================================================================================================================== */
+typedef struct { const uint8_t *p, *end; uint32_t range, code; int overrun; } lz_rc;
+static inline uint8_t lz_next(lz_rc *rc) { if (rc->p < rc->end) return *rc->p++; rc->overrun = 1; return 0; }
+static inline int lz_bit(lz_rc *rc, uint16_t *prob) {
+  const uint32_t bound = (rc->range >> 11) * *prob;
+  int b;
+  if (rc->code < bound) { rc->range = bound; *prob = (uint16_t)(*prob + ((2048 - *prob) >> 5)); b = 0; }
+  else { rc->range -= bound; rc->code -= bound; *prob = (uint16_t)(*prob - (*prob >> 5)); b = 1; }
+  if (rc->range < (1u << 24)) { rc->range <<= 8; rc->code = (rc->code << 8) | lz_next(rc); }
+  return b;
+}
+static inline uint32_t lz_direct(lz_rc *rc, int nbits) {
+  uint32_t r = 0;
+  for (int i = 0; i < nbits; i++) {
+    rc->range >>= 1;
+    const uint32_t t = (rc->code - rc->range) >> 31;  /* 1 if code < range */
+    rc->code -= rc->range & (t - 1);
+    r = (r << 1) | (1 - t);
+    if (rc->range < (1u << 24)) { rc->range <<= 8; rc->code = (rc->code << 8) | lz_next(rc); }
+  }
+  return r;
+}
+static inline uint32_t lz_tree(lz_rc *rc, uint16_t *probs, int nbits) {
+  uint32_t m = 1;
+  for (int i = 0; i < nbits; i++) m = (m << 1) | (uint32_t)lz_bit(rc, &probs[m]);
+  return m - (1u << nbits);
+}
+static inline uint32_t lz_rtree(lz_rc *rc, uint16_t *probs, int nbits) {
+  uint32_t m = 1, sym = 0;
+  for (int i = 0; i < nbits; i++) { const int b = lz_bit(rc, &probs[m]); m = (m << 1) | (uint32_t)b; sym |= (uint32_t)b << i; }
+  return sym;
+}
+typedef struct { uint16_t choice[2], low[16][8], mid[16][8], high[256]; } lz_len;
+static uint32_t lz_len_decode(lz_rc *rc, lz_len *l, uint32_t pos_state) {
+  if (!lz_bit(rc, &l->choice[0])) return lz_tree(rc, l->low[pos_state], 3);
+  if (!lz_bit(rc, &l->choice[1])) return 8 + lz_tree(rc, l->mid[pos_state], 3);
+  return 16 + lz_tree(rc, l->high, 8);
+}
+
+int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *consumed, int *props_out) {
+  if (n < 13 + 5) return -1;
+  int props = src[0];
+  if (props_out) { props_out[0] = props; props_out[1] = (int)(src[1] | (src[2] << 8) | (src[3] << 16) | ((uint32_t)src[4] << 24)); }
+  const int lc = props % 9; props /= 9;
+  const int lp = props % 5, pb = props / 5;
+  uint64_t usize = 0;
+  for (int i = 0; i < 8; i++) usize |= (uint64_t)src[5 + i] << (8 * i);
+  if (props_out) props_out[2] = usize == UINT64_MAX ? -1 : (int)usize;
+  const size_t nlit = (size_t)0x300 << (lc + lp);
+  uint16_t *lit = (uint16_t *)malloc(nlit * sizeof(uint16_t));
+  static _Thread_local uint16_t is_match[12 << 4], is_rep0_long[12 << 4], is_rep[12], is_g0[12], is_g1[12], is_g2[12], pos_slot[4][64],
+      pos_dec[128], pos_align[16];
+  static _Thread_local lz_len len_dec, rep_len_dec;
+#define LZ_INIT(a) do { uint16_t *q_ = (uint16_t *)(a); for (size_t i_ = 0; i_ < sizeof(a) / 2; i_++) q_[i_] = 1024; } while (0)
+  LZ_INIT(is_match); LZ_INIT(is_rep0_long); LZ_INIT(is_rep); LZ_INIT(is_g0); LZ_INIT(is_g1); LZ_INIT(is_g2); LZ_INIT(pos_slot);
+  LZ_INIT(pos_dec); LZ_INIT(pos_align);
+  { uint16_t *q = (uint16_t *)&len_dec; for (size_t i = 0; i < sizeof(len_dec) / 2; i++) q[i] = 1024; }
+  { uint16_t *q = (uint16_t *)&rep_len_dec; for (size_t i = 0; i < sizeof(rep_len_dec) / 2; i++) q[i] = 1024; }
+  for (size_t i = 0; i < nlit; i++) lit[i] = 1024;
+  lz_rc rc = { src + 13, src + n, 0xFFFFFFFFu, 0, 0 };
+  for (int i = 0; i < 5; i++) rc.code = (rc.code << 8) | lz_next(&rc);
+  uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
+  uint64_t pos = 0;
+  uint8_t prev = 0;
+  int64_t result = -1;
+  for (;;) {
+    if (usize != UINT64_MAX && pos >= usize) { result = (int64_t)pos; break; }
+    if (rc.overrun) break;
+    const uint32_t pos_state = (uint32_t)pos & ((1u << pb) - 1);
+    if (!lz_bit(&rc, &is_match[(state << 4) + pos_state])) {
+      uint16_t *probs = lit + (size_t)0x300 * ((((uint32_t)pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
+      uint32_t sym = 1;
+      if (state >= 7) {
+        uint32_t mb = dst[pos - rep0 - 1];
+        do {
+          const uint32_t mbit = (mb >> 7) & 1;
+          mb <<= 1;
+          const int b = lz_bit(&rc, &probs[((1 + mbit) << 8) + sym]);
+          sym = (sym << 1) | (uint32_t)b;
+          if (mbit != (uint32_t)b) { while (sym < 0x100) sym = (sym << 1) | (uint32_t)lz_bit(&rc, &probs[sym]); break; }
+        } while (sym < 0x100);
+      } else {
+        do sym = (sym << 1) | (uint32_t)lz_bit(&rc, &probs[sym]); while (sym < 0x100);
+      }
+      if (pos >= cap) break;
+      prev = (uint8_t)sym;
+      dst[pos++] = prev;
+      state = state < 4 ? 0 : state - (state < 10 ? 3 : 6);
+      continue;
+    }
+    uint32_t len;
+    if (lz_bit(&rc, &is_rep[state])) {
+      len = 0;
+      if (!lz_bit(&rc, &is_g0[state])) {
+        if (!lz_bit(&rc, &is_rep0_long[(state << 4) + pos_state])) { state = state < 7 ? 9 : 11; len = 1; }
+      } else {
+        uint32_t dist;
+        if (!lz_bit(&rc, &is_g1[state])) dist = rep1;
+        else {
+          if (!lz_bit(&rc, &is_g2[state])) dist = rep2;
+          else { dist = rep3; rep3 = rep2; }
+          rep2 = rep1;
+        }
+        rep1 = rep0;
+        rep0 = dist;
+      }
+      if (len == 0) { len = 2 + lz_len_decode(&rc, &rep_len_dec, pos_state); state = state < 7 ? 8 : 11; }
+    } else {
+      rep3 = rep2; rep2 = rep1; rep1 = rep0;
+      len = 2 + lz_len_decode(&rc, &len_dec, pos_state);
+      state = state < 7 ? 7 : 10;
+      const uint32_t slot = lz_tree(&rc, pos_slot[len <= 5 ? len - 2 : 3], 6);
+      if (slot >= 4) {
+        const int nd = (int)(slot >> 1) - 1;
+        rep0 = (2u | (slot & 1)) << nd;
+        if (slot < 14) rep0 += lz_rtree(&rc, pos_dec + rep0 - slot - 1, nd);
+        else {
+          rep0 += lz_direct(&rc, nd - 4) << 4;
+          rep0 += lz_rtree(&rc, pos_align, 4);
+          if (rep0 == 0xFFFFFFFFu) { result = (int64_t)pos; break; }  /* end marker */
+        }
+      } else rep0 = slot;
+    }
+    if ((uint64_t)rep0 >= pos || pos + len > cap) break;  /* lzma.js:561: corrupt */
+    for (uint32_t i = 0; i < len; i++, pos++) dst[pos] = dst[pos - rep0 - 1];
+    prev = dst[pos - 1];
+  }
+#undef LZ_INIT
+  free(lit);
+  if (rc.overrun) result = -1;
+  if (consumed) *consumed = (size_t)(rc.p - src);
+  return result;
+}

@@ -135,6 +135,10 @@ void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, in
 /* ---- A11 OptimizePalettes (tilingencoder.pas:4309-4432) with Powell/Brent (powell.pas); in place, returns sweeps ---- */
 int tmo_optimize_palettes(int32_t *palettes, int pal_count, int pal_size);
 
+/* ---- (f)#2 checker: LZMA-alone decoder (decoders/htmljs/lzma.js:395-576).  Returns the decoded size or -1;
+ * props_out (may be NULL) = {props byte, dictionary size, header size field or -1}. ---- */
+int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *consumed, int *props_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,36 @@ def test_step_order_and_errors():
     with pytest.raises(TileMotionError):
         enc.Run(TEncoderStep.esSave)
     enc.close()
+
+
+def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path):
+    """Run(esAll) with an OutputFileName ends in Save (tilingencoder.pas:5551): the file is byte-identical to the one the
+    host writer makes from the ORACLE pipeline's tables, and the player semantics show the encoder's frames"""
+    import ctypes
+    import os
+    from tiler_amd import synth
+    from tests import gtm_reader, oracle_pipeline, test_gtm
+    frames = synth.video(10, 64, 48, cut=5)
+    path = str(tmp_path / "enc.gtm")
+    enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, OutputFileName=path)
+    data = open(path, "rb").read()
+    hdr, pl = gtm_reader.play(oracle, data)
+    assert "PaletteCount=2" in pl.settings and "[Dither]" in pl.settings
+    exp = oracle_pipeline.run(oracle, frames, palette_count=2, min_s=0.1)
+    per = exp["per"]
+    tm = np.zeros((10, per), test_gtm.TMI)
+    tm["TileIdx"] = exp["final_tm_tile"].reshape(10, per)
+    tm["PalIdx"] = exp["tm_pal"].reshape(10, per)
+    tm["Flags"] = exp["flags"].reshape(10, per) & 3
+    L = ctypes.CDLL(test_gtm.LIB)
+    L.tm_write_gtm_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p]
+    L.tm_last_error.restype = ctypes.c_char_p
+    want = test_gtm.write(L, str(tmp_path / "host.gtm"), 8, 6, 24.0, exp["keyframes"], exp["final_pal_px"], exp["final_use"],
+                          exp["palettes"], tm, pl.settings)
+    assert data == want
+    assert np.array_equal(np.stack(pl.frames), gtm_reader.render_expected(exp["final_pal_px"], exp["palettes"], tm, 8, 6))
+    enc.Save(str(tmp_path / "again.gtm"))  # Save on its own, explicit path
+    assert open(str(tmp_path / "again.gtm"), "rb").read() == data
+    enc.close()

@@ -1,0 +1,207 @@
+"""(f)#2: the .gtm writer (SaveStream restatement + LZMA encoder) -- host-only code of the product, so these run
+without a GPU.  Files are read back with tests/gtm_reader.py (player semantics of decoders/htmljs/gtm.player.js, LZMA
+decoder restating lzma.js in the oracle) and, when node and the reference tree are present, with the reference's own
+lzma.js."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import gtm_reader, oracle_pipeline
+from tiler_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tiler_amd", "lib", "libtilemotion.so")
+TMI = np.dtype([("TileIdx", "<i4"), ("PalIdx", "<i4"), ("PredictedX", "i1"), ("PredictedY", "i1"), ("PSNR", "<f4"), ("Flags", "<u4")])
+REF_JS = "/root/reference/decoders/htmljs"
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tiler_amd", "csrc", "build.sh")])
+    lib = ctypes.CDLL(LIB)
+    lib.tm_lz_compress_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.tm_write_gtm_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p]
+    lib.tm_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def compress(L, data):
+    src = np.frombuffer(data, np.uint8) if len(data) else np.zeros(0, np.uint8)
+    cap = len(data) + len(data) // 4 + 64
+    dst = np.zeros(cap, np.uint8)
+    n = ctypes.c_size_t()
+    rc = L.tm_lz_compress_host(src.ctypes.data if src.size else None, src.size, dst.ctypes.data, cap, ctypes.byref(n))
+    assert rc == 0, L.tm_last_error()
+    return dst[:n.value].tobytes()
+
+
+def write(L, path, tm_w, tm_h, fps, kf, pal_px, use, palettes, tilemaps, settings="[Load]\n"):
+    kf = np.ascontiguousarray(kf, np.int32)
+    pal_px = np.ascontiguousarray(pal_px, np.uint8)
+    use = np.ascontiguousarray(use, np.uint32)
+    palettes = np.ascontiguousarray(palettes, np.int32)
+    tilemaps = np.ascontiguousarray(tilemaps)
+    assert tilemaps.dtype == TMI and TMI.itemsize == 18
+    rc = L.tm_write_gtm_host(os.fsencode(path), tm_w, tm_h, tilemaps.shape[0], fps, kf.ctypes.data, kf.size, pal_px.ctypes.data,
+                             use.ctypes.data, use.size, palettes.ctypes.data, palettes.shape[0], palettes.shape[1], tilemaps.ctypes.data,
+                             settings.encode())
+    assert rc == 0, L.tm_last_error()
+    return open(path, "rb").read()
+
+
+CASES = {
+    "empty": b"",
+    "one": b"\x00",
+    "zeros": bytes(100000),
+    "text": b"the quick brown fox jumps over the lazy dog. " * 500,
+    "random": np.random.default_rng(1).integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+    "ramp16": np.arange(60000, dtype="<u2").tobytes(),
+    "long_distance": (lambda r: r + bytes(3 << 20) + r)(np.random.default_rng(2).integers(0, 256, 5000, dtype=np.uint8).tobytes()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_lz_compress_round_trip(L, oracle, name):
+    data = CASES[name]
+    blob = compress(L, data)
+    assert blob[:13] == bytes([0x62, 0, 0, 0x40, 0]) + b"\xff" * 8  # extern.pas:427-436
+    back, consumed, props = gtm_reader.lzma_decode(oracle, blob, len(data) + 16)
+    assert back == data
+    assert consumed == len(blob)  # the player decodes keyframe streams back to back: no slack bytes allowed
+    if name in ("zeros", "text", "long_distance"):
+        assert len(blob) < len(data) // 8
+
+
+def test_lz_compress_capacity_error(L):
+    data = CASES["random"]
+    src = np.frombuffer(data, np.uint8)
+    dst = np.zeros(16, np.uint8)
+    n = ctypes.c_size_t()
+    assert L.tm_lz_compress_host(src.ctypes.data, src.size, dst.ctypes.data, 16, ctypes.byref(n)) == -1
+    assert n.value > len(data)
+
+
+def _pipeline_tables(oracle, nf=10, w=64, h=48, pal_count=2):
+    frames = synth.video(nf, w, h, cut=5)
+    out = oracle_pipeline.run(oracle, frames, fps=24.0, palette_count=pal_count, min_s=0.1)
+    per = out["per"]
+    tm = np.zeros((nf, per), TMI)
+    tm["TileIdx"] = out["final_tm_tile"].reshape(nf, per)
+    tm["PalIdx"] = out["final_pal_idx"][out["final_tm_tile"]].reshape(nf, per)
+    tm["Flags"] = out["flags"].reshape(nf, per) & 3
+    return out, tm, (w // 8, h // 8)
+
+
+def test_gtm_from_oracle_pipeline(L, oracle, tmp_path):
+    out, tm, (tm_w, tm_h) = _pipeline_tables(oracle)
+    nf = tm.shape[0]
+    kf = out["keyframes"]
+    assert kf.size >= 2
+    settings = "[Load]\nInputFileName=synthetic\n"
+    data = write(L, str(tmp_path / "a.gtm"), tm_w, tm_h, 24.0, kf, out["final_pal_px"], out["final_use"], out["palettes"], tm, settings)
+    hdr, pl = gtm_reader.play(oracle, data)
+    assert (hdr["version"], hdr["width"], hdr["height"], hdr["kf_count"], hdr["frame_count"]) == (4, tm_w * 8, tm_h * 8, kf.size, nf)
+    assert [k["frame"] for k in hdr["kf"]] == list(kf)
+    assert [k["ms"] for k in hdr["kf"]] == [int(np.rint(1000.0 * f / 24.0)) for f in kf]
+    assert pl.settings == settings and (pl.w, pl.h) == (tm_w, tm_h)
+    assert pl.frame_ns == int(np.rint(1e9 / 24.0)) and pl.tile_count == out["final_T"] and pl.pal_size == 16
+    ends = np.zeros(nf, int)
+    ends[np.r_[kf[1:] - 1, nf - 1]] = 1
+    assert pl.kf_ends == list(ends)
+    # header rates (5458-5472)
+    comp = np.array([k["comp"] for k in hdr["kf"]], float)
+    cnt = np.diff(np.r_[kf, nf])
+    assert hdr["avg_bps"] == int(np.rint(comp.sum() * 24.0 / nf))
+    assert hdr["kf_max_bps"] == max(int(np.rint(c * 24.0 / n)) for c, n in list(zip(comp, cnt))[1:])
+    # TileSet holds exactly the tiles before the first UseCount = 1 one (5296-5315); the others travel as IntraTile
+    use = out["final_use"]
+    reused = int(np.argmax(use == 1)) if (use == 1).any() else 0
+    assert 0 < reused < out["final_T"]
+    assert np.array_equal(pl.tiles[:reused].reshape(-1, 64), out["final_pal_px"][:reused])
+    kinds = [it[0] for fr in pl.items for it in fr]
+    assert kinds.count("intra") == int((use[tm["TileIdx"]] <= 1).sum()) and "ss" in kinds
+    # and the player shows what the encoder's tables say
+    want = gtm_reader.render_expected(out["final_pal_px"], out["palettes"], tm, tm_w, tm_h)
+    assert np.array_equal(np.stack(pl.frames), want)
+
+
+def test_gtm_every_command(L, oracle, tmp_path):
+    """crafted tile maps reach every tile-map command and the SkipBlock rules (CMinBlkSkipCount 4, at most 4096)"""
+    rng = np.random.default_rng(7)
+    tm_w, tm_h, nf = 100, 60, 3  # 6000 positions: room for a > 4096 run
+    nt, npal, ps = 70000, 1100, 4
+    pal_px = rng.integers(0, ps, (nt, 64), dtype=np.uint8)
+    use = np.full(nt, 2, np.uint32)
+    use[69990:] = 1  # sorted by use: the tail is single-use
+    palettes = rng.integers(0, 1 << 24, (npal, ps)).astype(np.int32)
+    palettes[3, 1] = -65281  # cDitheringNullColor -> 0xffffff (5284-5285)
+    tm = np.zeros((nf, tm_w * tm_h), TMI)
+    tm["TileIdx"] = rng.integers(0, 60000, (nf, tm_w * tm_h))
+    tm["PalIdx"] = rng.integers(0, 1024, (nf, tm_w * tm_h))
+    tm["Flags"] = rng.integers(0, 4, (nf, tm_w * tm_h))
+    f1 = tm[1]
+    f1["TileIdx"][0], f1["PalIdx"][0] = 66000, 5          # long tile, short palette
+    f1["TileIdx"][1], f1["PalIdx"][1] = 66001, 1050       # long tile, long palette
+    f1["TileIdx"][2], f1["PalIdx"][2] = 12, 1099          # short tile, long palette -> still the long/long form
+    f1["TileIdx"][3], f1["PalIdx"][3] = 69995, 3          # single use -> intra
+    f1["TileIdx"][4], f1["PalIdx"][4] = -1, -1            # Max(0, .) clamps (5233-5234)
+    def pred(row, a, b, x=0, y=0):
+        row["Flags"][a:b] = 4
+        row["PredictedX"][a:b] = x
+        row["PredictedY"][a:b] = y
+    pred(f1, 1010, 1013)            # 3 smoothed: below CMinBlkSkipCount -> three short predicted items
+    pred(f1, 1020, 1024)            # 4 -> one SkipBlock
+    pred(f1, 1100, 1100 + 4500)     # 4500 -> SkipBlock(4096) + SkipBlock(404)
+    pred(f1, 5800, 5801, 31, -32)   # short offsets at the range ends
+    pred(f1, 5802, 5803, 32, 0)     # just outside -> long offsets
+    pred(f1, 5804, 5805, -5, -33)
+    f2 = tm[2]
+    pred(f2, 0, 6000)               # whole frame smoothed: 4096 + 1904
+    data = write(L, str(tmp_path / "b.gtm"), tm_w, tm_h, 30.0, [0], pal_px, use, palettes, tm)
+    hdr, pl = gtm_reader.play(oracle, data)
+    assert hdr["kf_count"] == 1 and hdr["kf_max_bps"] == int(np.rint(hdr["kf"][0]["comp"] * 30.0 / nf))
+    assert np.array_equal(pl.tiles[:69990].reshape(-1, 64), pal_px[:69990])
+    it = pl.items[1]
+    assert it[0] == ("ls", 66000, 5, int(f1["Flags"][0]) & 3)
+    assert it[1] == ("ll", 66001, 1050, int(f1["Flags"][1]) & 3)
+    assert it[2] == ("ll", 12, 1099, int(f1["Flags"][2]) & 3)
+    assert it[3] == ("intra", pal_px[69995].tobytes(), 3, int(f1["Flags"][3]) & 3)
+    assert it[4] == ("ss", 0, 0, int(f1["Flags"][4]) & 3)
+    assert it[1010:1013] == [("ps", 0, 0)] * 3
+    assert it[1020] == ("skip", 4)
+    assert [x for x in it if x[0] == "skip"] == [("skip", 4), ("skip", 4096), ("skip", 404)]
+    assert ("ps", 31, -32) in it and ("pl", 32, 0) in it and ("pl", -5, -33) in it
+    assert pl.items[2] == [("skip", 4096), ("skip", 1904)]
+    assert pl.palettes[3][1] == 0xFFFFFFFF
+    # frame 0 has no predicted items: the player shows the tables; frame 2 repeats frame 1
+    want0 = gtm_reader.render_expected(pal_px, palettes, tm[:1], tm_w, tm_h)
+    assert np.array_equal(pl.frames[0], want0[0])
+    assert np.array_equal(pl.frames[2], pl.frames[1])
+
+
+def test_gtm_rejects_bad_input(L, tmp_path):
+    tm = np.zeros((1, 4), TMI)
+    rc = L.tm_write_gtm_host(os.fsencode(str(tmp_path / "c.gtm")), 2, 2, 1, 0.0, None, 0, None, None, 0, None, 0, 0, tm.ctypes.data, None)
+    assert rc == -1
+
+
+@pytest.mark.skipif(shutil.which("node") is None or not os.path.isdir(REF_JS), reason="node or the reference tree is not here")
+def test_reference_lzma_js_reads_our_streams(L, oracle, tmp_path):
+    """the reference's own decoder (lzma.js + lzma.shim.js, driven like wlzma.wrk.js:46-60) unpacks every keyframe stream
+    of a file we wrote to the same bytes our reader gets"""
+    out, tm, (tm_w, tm_h) = _pipeline_tables(oracle)
+    path = str(tmp_path / "n.gtm")
+    data = write(L, path, tm_w, tm_h, 24.0, out["keyframes"], out["final_pal_px"], out["final_use"], out["palettes"], tm)
+    hdr, raws = gtm_reader.unpack(oracle, data)
+    res = subprocess.run(["node", os.path.join(ROOT, "tests", "node_unpack_gtm.js"), REF_JS, path, path + ".raw"], capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    assert open(path + ".raw", "rb").read() == b"".join(raws)
+    assert res.stdout.split() == [str(len(r)) for r in raws]

@@ -389,6 +389,46 @@ static int step_reindex(tm_encoder *e) {  // Reindex, tilingencoder.pas:1993-203
   return TM_OK;
 }
 
+static std::string settings_text(const Settings &s) {  // GetSettings -> SaveSettings, tilingencoder.pas:2255, 3738-3775 (TMemIniFile layout)
+  char buf[2048];
+  auto flt = [](double v) { char b[64]; snprintf(b, sizeof(b), "%.15g", v); return std::string(b); };
+  snprintf(buf, sizeof(buf),
+           "[Load]\nInputFileName=%s\nOutputFileName=%s\nStartFrame=%d\nFrameCount=%d\nScaling=%s\nShotTransMaxSecondsPerKF=%s\n"
+           "ShotTransMinSecondsPerKF=%s\nShotTransCorrelLoThres=%s\n\n[MotionPredict]\nMotionPredictRadius=%d\n\n"
+           "[GlobalTiling]\nGlobalTilingUseTargetPSNR=%d\nGlobalTilingTargetPSNR=%s\nGlobalTilingQualityBasedTileCount=%s\n"
+           "GlobalTilingTileCount=%d\n\n[Dither]\nPaletteSize=%d\nPaletteCount=%d\nDitheringMode=%d\nDitheringUseThomasKnoll=%d\n"
+           "DitheringYliluoma2MixedColors=%d\n\n[FrameTiling]\nFrameTilingExtendedPaletteUsage=%d\n\n[Misc]\nMaxThreadCount=%d\n",
+           s.InputFileName.c_str(), s.OutputFileName.c_str(), s.StartFrame, s.FrameCount, flt(s.Scaling).c_str(),
+           flt(s.ShotTransMaxSecondsPerKF).c_str(), flt(s.ShotTransMinSecondsPerKF).c_str(), flt(s.ShotTransCorrelLoThres).c_str(),
+           s.MotionPredictRadius, (int)s.GlobalTilingUseTargetPSNR, flt(s.GlobalTilingTargetPSNR).c_str(),
+           flt(s.GlobalTilingQualityBasedTileCount).c_str(), s.GlobalTilingTileCount, s.PaletteSize, s.PaletteCount, s.DitheringMode,
+           (int)s.DitheringUseThomasKnoll, s.DitheringYliluoma2MixedColors, (int)s.FrameTilingExtendedPaletteUsage, s.MaxThreadCount);
+  return buf;
+}
+
+static int save_to(tm_encoder *e, const char *path) {  // Save, tilingencoder.pas:2040-2058 -> SaveStream, 5177
+  TM_TRY(need(e, TM_STEP_REINDEX, "Reindex"));
+  TM_CHECK(path && *path, TM_E_INVAL, "Save: no output file name");
+  TM_HIP(hipSetDevice(e->device));
+  GtmInput in;
+  in.tm_w = e->tm_w; in.tm_h = e->tm_h; in.nframes = e->nframes; in.fps = e->fps;
+  in.kf_start = e->kf_start;
+  std::vector<uint8_t> pal_px((size_t)e->t * 64);
+  in.use.resize((size_t)e->t);
+  if (e->t) {
+    TM_HIP(hipMemcpy(pal_px.data(), e->gpal_px.p, pal_px.size(), hipMemcpyDeviceToHost));
+    TM_HIP(hipMemcpy(in.use.data(), e->guse.p, (size_t)e->t * 4, hipMemcpyDeviceToHost));
+  }
+  in.pal_px = pal_px.data();
+  in.palettes = e->palettes_host.data();
+  in.pal_count = e->s.PaletteCount; in.pal_size = e->s.PaletteSize;
+  std::vector<tm_tilemap_item> tmi((size_t)e->q);
+  for (int f = 0; f < e->nframes; f++) TM_TRY(tm_get_tilemap(e, f, tmi.data() + (size_t)f * e->tm_size()));
+  in.tilemap = tmi.data();
+  in.settings = settings_text(e->s);
+  return write_gtm(path, in);
+}
+
 static int run_step(tm_encoder *e, int step) {
   TM_HIP(hipSetDevice(e->device));
   const auto t0 = std::chrono::steady_clock::now();
@@ -401,10 +441,7 @@ static int run_step(tm_encoder *e, int step) {
     case TM_STEP_DITHER: rc = step_dither(e); break;
     case TM_STEP_RECONSTRUCT: rc = step_reconstruct(e); break;
     case TM_STEP_REINDEX: rc = step_reindex(e); break;
-    case TM_STEP_SAVE:
-      set_error("Save (.gtm writer + LZMA) is not built yet; see DESIGN.md \"Scope\"");
-      rc = TM_E_UNSUPPORTED;
-      break;
+    case TM_STEP_SAVE: rc = save_to(e, e->s.OutputFileName.c_str()); break;
     default: set_error("bad step %d", step); rc = TM_E_INVAL;
   }
   if (rc == TM_OK) {
@@ -685,8 +722,7 @@ int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *laun
 
 int tm_save_gtm(tm_encoder *e, const char *path) {
   TM_CHECK(e && path, TM_E_INVAL, "null argument");
-  set_error("Save (.gtm writer + LZMA) is not built yet; see DESIGN.md \"Scope\"");
-  return TM_E_UNSUPPORTED;
+  return save_to(e, path);
 }
 
 }  // extern "C"

@@ -1,5 +1,8 @@
 // tm_internal.h -- launcher prototypes shared between the kernel files, the stage ABI and the encoder.
 #pragma once
+#include <string>
+#include <vector>
+
 #include "tm_common.h"
 
 namespace tmx {
@@ -39,5 +42,21 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
 
 // tm_optpal.hip (host only)
 int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_size, int *sweeps_out);
+
+
+// tm_gtm.hip (host only): SaveStream restatement, tilingencoder.pas:5177-5482
+struct GtmInput {
+  int tm_w = 0, tm_h = 0, nframes = 0;
+  double fps = 0;
+  std::vector<int32_t> kf_start;
+  const uint8_t *pal_px = nullptr;   // [ntiles][64], final (Reindex) order
+  std::vector<uint32_t> use;         // [ntiles]
+  const int32_t *palettes = nullptr; // [pal_count][pal_size]
+  int pal_count = 0, pal_size = 0;
+  const tm_tilemap_item *tilemap = nullptr;  // [nframes][tm_h*tm_w]
+  std::string settings;
+};
+int write_gtm(const char *path, const GtmInput &in);
+void lz_compress(const std::vector<uint8_t> &raw, std::vector<uint8_t> &dst);
 
 }  // namespace tmx

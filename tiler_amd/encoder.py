@@ -5,6 +5,7 @@ Same names and argument meaning as the Pascal class: LoadDefaultSettings / LoadS
 Errors that the reference raises as exceptions/assertions surface as TileMotionError.
 """
 import ctypes
+import os
 import enum
 
 import numpy as np
@@ -211,6 +212,13 @@ class TilingEncoder:
             __cuda_array_interface__ = {"shape": (cnt.value,), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
 
         return torch.as_tensor(_View(), device="cuda")
+
+    def Save(self, path=None):
+        """Save (tilingencoder.pas:2040) -> SaveStream (:5177): writes the .gtm; path defaults to OutputFileName"""
+        if path is None:
+            self.Run(TEncoderStep.esSave)
+        else:
+            check(self._L.tm_save_gtm(c_void_p(self._h), os.fsencode(path)))
 
     def SyncTileMap(self):
         check(self._L.tm_sync_tilemap(c_void_p(self._h)))
