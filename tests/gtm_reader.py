@@ -54,7 +54,10 @@ def unpack(oracle, data):
 class Player:
     """gtm.player.js state machine; frames come out as [H][W] uint32 0xAABBGGRR like the canvas' RGBA bytes."""
 
-    def __init__(self):
+    def __init__(self, max_frames=None, render=True):
+        self.max_frames = max_frames
+        self.render = render  # False: walk the commands only (dimensions may then be preset by the caller)
+        self.done = False
         self.w = self.h = 0
         self.tile_count = 0
         self.pal_size = 0
@@ -72,6 +75,9 @@ class Player:
         self.kf_ends = []
 
     def _draw(self, idx, attrs):
+        if not self.render:
+            self.pos += 1
+            return
         pal = self.palettes[attrs >> 2]
         t = self.tiles[idx]
         if attrs & 1:
@@ -83,6 +89,9 @@ class Player:
         self.pos += 1
 
     def _draw_pred(self, ox, oy):
+        if not self.render:
+            self.pos += 1
+            return
         x, y = (self.pos % self.w) * 8, (self.pos // self.w) * 8
         self.buf[self.dbl][y:y + 8, x:x + 8] = self.buf[1 - self.dbl][y + oy:y + oy + 8, x + ox:x + ox + 8]
         self.pos += 1
@@ -110,11 +119,14 @@ class Player:
             elif cmd == CMD_FRAME_END:
                 assert self.pos == self.w * self.h, "incomplete tile map"
                 self.pos = 0
-                self.frames.append(self.buf[self.dbl].copy())
+                self.frames.append(self.buf[self.dbl].copy() if self.render else None)
                 self.items.append(self._cur_items)
                 self._cur_items = []
                 self.kf_ends.append(arg & 1)
                 self.dbl = 1 - self.dbl
+                if self.max_frames is not None and len(self.frames) >= self.max_frames:
+                    self.done = True
+                    return
             elif cmd == CMD_SKIP:
                 self._cur_items.append(("skip", arg + 1))
                 for _ in range(arg + 1):
@@ -147,12 +159,14 @@ class Player:
                 self._draw_pred(ox, oy)
             elif cmd == CMD_INTRA:
                 pal = u16(); p += 2
-                self.tiles[self.cur_intra] = np.frombuffer(raw, np.uint8, 64, p).reshape(8, 8); p += 64
+                if self.render:
+                    self.tiles[self.cur_intra] = np.frombuffer(raw, np.uint8, 64, p).reshape(8, 8)
+                p += 64
                 self._cur_items.append(("intra", bytes(raw[p - 64:p]), pal, arg & 3))
                 self._draw(self.cur_intra, arg | (pal << 2))
                 self.cur_intra += 1
-                if self.cur_intra >= self.tiles.shape[0]:
-                    self.cur_intra = self.tiles.shape[0] - self.w * self.h * 2
+                if self.cur_intra >= self.tile_count + self.w * self.h * 2:
+                    self.cur_intra = self.tile_count
             elif cmd == CMD_EXTENDED:
                 n = u32(); p += 4
                 text = raw[p:p + n]; p += n

@@ -205,3 +205,59 @@ def test_reference_lzma_js_reads_our_streams(L, oracle, tmp_path):
     assert res.returncode == 0, res.stderr
     assert open(path + ".raw", "rb").read() == b"".join(raws)
     assert res.stdout.split() == [str(len(r)) for r in raws]
+
+
+# ---- the reader itself is pinned by the reference's demo files (docs/demo/*.gtm) ---------------
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _pins():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "gtm_demo_pins.json")))
+
+
+def test_reader_decodes_committed_reference_stream(oracle):
+    """football_cif.gtm's second keyframe stream (verbatim reference data): the oracle's LZMA decoder returns the raw size
+    its GTMk header states, consumes the stream exactly, and the command walk finds the pinned items"""
+    import collections
+    import hashlib
+    pins = _pins()["football_cif"]
+    blob = open(os.path.join(GOLDEN, "football_cif_kf1.lzma"), "rb").read()
+    assert len(blob) == pins["kf"][1]["comp"]
+    raw, consumed, props = gtm_reader.lzma_decode(oracle, blob, pins["kf"][1]["raw"] + 16)
+    assert props == (0x62, 1 << 22, -1) and consumed == len(blob) and len(raw) == pins["kf"][1]["raw"]
+    assert hashlib.sha256(raw).hexdigest() == pins["raw_sha256"][1]
+    w = gtm_reader.Player(render=False)
+    w.w, w.h, w.tile_count = pins["tm_w"], pins["tm_h"], pins["tile_count"]
+    w.feed(raw)
+    assert len(w.frames) == pins["kf1_walk"]["frames"] == pins["kf"][2]["frame"] - pins["kf"][1]["frame"]
+    assert dict(collections.Counter(it[0] for fr in w.items for it in fr)) == pins["kf1_walk"]["item_histogram"]
+    assert w.kf_ends == [0] * (len(w.frames) - 1) + [1]
+
+
+def test_lz_compress_recompresses_reference_stream(L, oracle):
+    """our encoder on real command bytes: round trip, and within 1.5x of the reference's own optimal-parse size"""
+    pins = _pins()["football_cif"]
+    blob = open(os.path.join(GOLDEN, "football_cif_kf1.lzma"), "rb").read()
+    raw, _, _ = gtm_reader.lzma_decode(oracle, blob, pins["kf"][1]["raw"] + 16)
+    ours = compress(L, raw)
+    back, consumed, _ = gtm_reader.lzma_decode(oracle, ours, len(raw) + 16)
+    assert back == raw and consumed == len(ours)
+    assert len(ours) < 1.5 * len(blob), (len(ours), len(blob))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/docs/demo"), reason="the reference tree is not here")
+def test_reader_pins_match_reference_demo_files(oracle):
+    """re-derives tests/golden/gtm_demo_pins.json from the reference's demo files (header fields, raw-stream hashes --
+    cross-checked with the reference's lzma.js when node is here --, command histogram, rendered-frame hashes)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_gtm_fixtures", os.path.join(GOLDEN, "make_gtm_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = _pins()
+    for name in ("city_cif", "football_cif"):
+        got, _, _ = mod.pins_for(oracle, name)
+        got = __import__("json").loads(__import__("json").dumps(got))
+        if "lzma_js_agrees" not in got:
+            want[name].pop("lzma_js_agrees", None)
+        assert got == want[name]
