@@ -106,9 +106,11 @@ TM_API int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, size_
 /* Multi-GPU (one process per GPU): this process matches only frames [first, first+count) in Reconstruct (frames are
  * independent in the KNN branch, DoXY :1464); the host then merges the per-frame results of all processes with an
  * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex. */
-enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL = 2 };
+enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL = 2,
+       /* with motion prediction: uint8 IsPredicted, int8 PredictedX, int8 PredictedY (1 byte per item; other shards hold 0: merge with SUM) */
+       TM_ARRAY_TILEMAP_PRED = 3, TM_ARRAY_TILEMAP_PX = 4, TM_ARRAY_TILEMAP_PY = 5 };
 TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
-TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* int32 elements */);
+TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* elements: int32 for 0-2, bytes for 3-5 */);
 TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */
@@ -134,6 +136,17 @@ TM_API int tm_stage_features_pal(const void *pal_px, const void *pal_idx, int64_
                                  int mode, void *out_i16, void *stream);
 /* A6 as used by DoPalettization (:4126,:4160): double DCT with UseLAB, Round()ed to int32 [n][192]. */
 TM_API int tm_stage_features_cluster(const void *tiles, int64_t n, int mode, void *out_i32, void *stream);
+
+/* Motion prediction (PredictMotion :1154-1282 and the redo in Reconstruct :1496-1532).
+ * DoDCTs: pvsWeightedDCT features of every 8x8 window of a frame buffer [height][width] u32 0x00BBGGRR
+ * -> int16 [(height-7)*(width-7)][192], row-major over window positions. */
+TM_API int tm_stage_window_dcts(const void *frame_buffer, int width, int height, void *out_i16, void *stream);
+/* DoXY search: cur = features of the frame's tiles in ORIGINAL orientation [tm_h*tm_w][192]; window_dcts of the
+ * previous frame buffer (tm_w*8 x tm_h*8); radius = MotionPredictRadius (1..128, decremented inside like :1271).
+ * Error = CompareEuclideanDCTPtr_asm as written (utils.pas:559-725, entry xmm7 = 0) + manhattan distance; first strict
+ * minimum in raster order.  out_err u32, out_px / out_py int8 (PredictedX / PredictedY). */
+TM_API int tm_stage_motion_search(const void *cur_i16, int tm_w, int tm_h, const void *window_dcts, int radius, void *out_err,
+                                  void *out_px, void *out_py, void *stream);
 
 /* A13+A14 (KNN branch): exact nearest neighbour of every query in the database, both int16 [.][192];
  * what ann_kdtree_short_search(eps=0) answers (:1547).  Ties: lowest database index.

@@ -1290,3 +1290,72 @@ int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, 
   if (consumed) *consumed = (size_t)(rc.p - src);
   return result;
 }
+
+/* =====================================================================================================================
+ * (f)#1 motion prediction: PredictMotion (tilingencoder.pas:1154-1282), the redo inside Reconstruct (1496-1532), the
+ * tile-count search of Reduce (4014-4046, utils.pas:1044-1072).
+ * ===================================================================================================================== */
+
+void tmo_window_dcts(const uint32_t *fb, int w, int h, int16_t *out) {
+  /* DoDCTs (1157-1182 / 1437-1462): for every top-left (x, y) of an 8x8 window inside the w x h frame buffer, the
+   * pvsWeightedDCT features of that window (ConvertToCpnPixels YUV, no mirrors); row-major, (w-7) per row */
+  const int ww = w - 7;
+  for (int y = 0; y + 8 <= h; y++)
+    for (int x = 0; x + 8 <= w; x++) {
+      uint32_t tile[64];
+      float cpn[192];
+      for (int j = 0; j < 8; j++) memcpy(tile + j * 8, fb + (size_t)(y + j) * w + x, 32); /* CopyRGBPixels, 879-887 */
+      tmo_cpn_from_rgb(tile, 0, 0, 0, cpn);
+      tmo_features_i16(cpn, TMO_PVS_WEIGHTED_DCT, out + ((size_t)y * ww + x) * 192);
+    }
+}
+
+void tmo_motion_search(const int16_t *cur, int tm_w, int tm_h, const int16_t *win, int radius, uint32_t *best_err, int8_t *px,
+                       int8_t *py) {
+  /* DoXY (1209-1253) == the redo (1496-1532): cur = features of the frame's tiles in their ORIGINAL orientation, win =
+   * tmo_window_dcts of the back buffer (screen = tm_w*8 x tm_h*8), radius = the MotionPredictRadius setting (the
+   * reference decrements it first, 1271/1666).  err = CompareEuclideanDCTPtr_asm(cur, prev) + manhattan distance to
+   * the tile's own position; first strict minimum in raster order wins.  The QuickTest early-out (1230, 1513) cannot
+   * change the outcome: its value is one of the non-negative terms of err. */
+  const int sw = tm_w * 8, sh = tm_h * 8, ww = sw - 7, r = radius - 1;
+  for (int sy = 0; sy < tm_h; sy++)
+    for (int sx = 0; sx < tm_w; sx++) {
+      const int dx = sx * 8, dy = sy * 8, i = sy * tm_w + sx;
+      const int oymn = dy - r - 1 > 0 ? dy - r - 1 : 0, oymx = dy + r < sh - 8 ? dy + r : sh - 8;
+      const int oxmn = dx - r - 1 > 0 ? dx - r - 1 : 0, oxmx = dx + r < sw - 8 ? dx + r : sw - 8;
+      uint32_t best = UINT32_MAX;
+      int bx = 0, by = 0;
+      for (int oy = oymn; oy <= oymx; oy++)
+        for (int ox = oxmn; ox <= oxmx; ox++) {
+          uint32_t err = tmo_ssd_i16_sse_quirk(cur + (size_t)i * 192, win + ((size_t)oy * ww + ox) * 192);
+          err += (uint32_t)(abs(ox - dx) + abs(oy - dy));
+          if (err < best) { best = err; bx = ox; by = oy; }
+        }
+      best_err[i] = best;
+      px[i] = (int8_t)(bx - dx);
+      py[i] = (int8_t)(by - dy);
+    }
+}
+
+/* GoldenRatioSearch(STCGREval) of SolveTileCount (4043-4046; utils.pas:1044-1072) on the sorted per-group minima of
+ * the effective PSNR (keyframe-start frames: PSNR / 10, 4028-4029): f(x) = number of groups (distinct tile contents)
+ * with at least one member that is NOT predicted at threshold x, i.e. with min effective PSNR <= x.
+ * Returns the LAST x the search evaluated (the encoder's state is whatever that probe left, 4036-4040);
+ * *probes = evaluations made (0: the interval was already closed, no state). */
+double tmo_solve_tile_count(const double *sorted_min_psnr, int64_t ngroups, double target, int *probes) {
+  const double phi = (1.0 + sqrt(5.0)) / 2.0, inv_phi = 1.0 / phi; /* cPhi, cInvPhi utils.pas:42-43 */
+  double mn = 0.0, mx = 10.0 * log(255.0 * 255.0 / 0.5) / log(10.0), last = 0.0; /* cPsnrMaxValue, utils.pas:111 */
+  int n = 0;
+  for (;;) {
+    if (fabs(mn - mx) <= 1e-6) break; /* SameValue(MinX, MaxX, cPsyVEpsilon) */
+    const double x = mn < mx ? mn + (mx - mn) * (1.0 - inv_phi) : mn + (mx - mn) * inv_phi;
+    int64_t lo = 0, hi = ngroups; /* count of minima <= x */
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_min_psnr[mid] <= x) lo = mid + 1; else hi = mid; }
+    const double y = (double)lo;
+    last = x; n++;
+    if (fabs(y - target) <= 0.5) break;       /* CompareValue(y, ObjectiveY, 0.5) = Equals */
+    if (y < target) mn = x; else mx = x;
+  }
+  if (probes) *probes = n;
+  return last;
+}

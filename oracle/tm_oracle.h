@@ -135,6 +135,12 @@ void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, in
 /* ---- A11 OptimizePalettes (tilingencoder.pas:4309-4432) with Powell/Brent (powell.pas); in place, returns sweeps ---- */
 int tmo_optimize_palettes(int32_t *palettes, int pal_count, int pal_size);
 
+/* ---- (f)#1 motion prediction (tilingencoder.pas:1154-1282, 1496-1532) and the Reduce threshold search (4014-4046) ---- */
+void tmo_window_dcts(const uint32_t *fb, int w, int h, int16_t *out /* [(h-7)*(w-7)][192] */);
+void tmo_motion_search(const int16_t *cur /* [tm_h*tm_w][192] */, int tm_w, int tm_h, const int16_t *win, int radius,
+                       uint32_t *best_err, int8_t *px, int8_t *py);
+double tmo_solve_tile_count(const double *sorted_min_psnr, int64_t ngroups, double target, int *probes);
+
 /* ---- (f)#2 checker: LZMA-alone decoder (decoders/htmljs/lzma.js:395-576).  Returns the decoded size or -1;
  * props_out (may be NULL) = {props byte, dictionary size, header size field or -1}. ---- */
 int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *consumed, int *props_out);

@@ -176,6 +176,33 @@ class Oracle:
             nu = self.L.tmo_dedup_u32(_p(rows), n, rows.shape[1], _p(u), _p(rep), _p(order), _p(use_out), _p(remap))
         return int(nu), rep, order[:nu].copy(), use_out[:nu].copy(), remap
 
+    # ---- motion prediction
+    def window_dcts(self, fb):
+        fb = np.ascontiguousarray(fb, np.uint32)
+        h, w = fb.shape
+        out = np.zeros(((h - 7) * (w - 7), 192), np.int16)
+        self.L.tmo_window_dcts(_p(fb), w, h, _p(out))
+        return out
+
+    def motion_search(self, cur, tm_w, tm_h, win, radius):
+        cur = np.ascontiguousarray(cur, np.int16)
+        win = np.ascontiguousarray(win, np.int16)
+        n = tm_w * tm_h
+        err, px, py = np.zeros(n, np.uint32), np.zeros(n, np.int8), np.zeros(n, np.int8)
+        self.L.tmo_motion_search(_p(cur), tm_w, tm_h, _p(win), radius, _p(err), _p(px), _p(py))
+        return err, px, py
+
+    def solve_tile_count(self, sorted_min_psnr, target):
+        a = np.ascontiguousarray(sorted_min_psnr, np.float64)
+        probes = ctypes.c_int()
+        self.L.tmo_solve_tile_count.restype = ctypes.c_double
+        self.L.tmo_solve_tile_count.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p]
+        x = self.L.tmo_solve_tile_count(_p(a), a.size, float(target), ctypes.byref(probes))
+        return x, probes.value
+
+    def psnr(self, err):
+        return np.array([self.L.tmo_euclidean_to_psnr(int(e)) for e in np.asarray(err).ravel()], np.float32).reshape(np.shape(err))
+
     # ---- k-means family
     def kmeans(self, pts, weights, k, max_iter=300):
         pts = np.ascontiguousarray(pts, np.int32)

@@ -21,13 +21,18 @@ def _run_encoder(frames, **settings):
     return enc
 
 
-@pytest.mark.parametrize("shape,pc", [((10, 64, 64), 1), ((6, 52, 100), 3)])
-def test_run_all_matches_oracle(oracle, shape, pc):
+@pytest.mark.parametrize("shape,pc,radius,tc", [((10, 64, 64), 1, 0, 0), ((6, 52, 100), 3, 0, 0), ((10, 64, 64), 1, 32, 0),
+                                                  ((10, 64, 64), 2, 32, 150), ((7, 52, 100), 3, 5, 300), ((1, 32, 32), 1, 32, 0)])
+def test_run_all_matches_oracle(oracle, shape, pc, radius, tc):
+    """radius 0 = motion prediction off (the build's switch); radius > 0 = the reference's default path: PredictMotion,
+    the PSNR threshold search of Reduce (tc = a GlobalTilingTileCount small enough to make the search bite), the motion
+    redo and KNN-vs-motion decision of Reconstruct"""
     from tiler_amd import synth
     from tests import oracle_pipeline
     frames = synth.video(*shape[:1], shape[2], shape[1], cut=4)
-    exp = oracle_pipeline.run(oracle, frames, palette_count=pc, min_s=0.1)
-    enc = _run_encoder(frames, PaletteCount=pc, ShotTransMinSecondsPerKF=0.1)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=pc, min_s=0.1, motion_radius=radius, tile_count=tc)
+    kw = dict(GlobalTilingTileCount=tc) if tc else {}
+    enc = _run_encoder(frames, PaletteCount=pc, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, **kw)
     c = enc.counts()
     assert np.array_equal(enc.FrameCorrelations().view(np.uint32), exp["correl"].view(np.uint32))
     assert np.array_equal(enc.KeyFrames(), exp["keyframes"])
@@ -45,7 +50,9 @@ def test_run_all_matches_oracle(oracle, shape, pc):
         assert np.array_equal(tm["TileIdx"], exp["final_tm_tile"][sl])
         assert np.array_equal(tm["PalIdx"], exp["tm_pal"][sl])
         assert np.array_equal(tm["Flags"] & 3, exp["flags"][sl])
-        psnr = np.array([oracle.L.tmo_euclidean_to_psnr(int(e)) for e in exp["knn_err"][sl]], np.float32)
+        assert np.array_equal((tm["Flags"] >> 2) & 1, exp["is_predicted"][sl])
+        assert np.array_equal(tm["PredictedX"], exp["pred_x"][sl]) and np.array_equal(tm["PredictedY"], exp["pred_y"][sl])
+        psnr = np.array([oracle.L.tmo_euclidean_to_psnr(int(e)) for e in exp["tm_err"][sl]], np.float32)
         assert np.allclose(tm["PSNR"], psnr, rtol=1e-6)  # PSNR goes through log10: tolerance 1e-6 relative
     enc.close()
 
@@ -72,7 +79,8 @@ def test_step_order_and_errors():
     enc.close()
 
 
-def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path):
+@pytest.mark.parametrize("radius", [0, 32])
+def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path, radius):
     """Run(esAll) with an OutputFileName ends in Save (tilingencoder.pas:5551): the file is byte-identical to the one the
     host writer makes from the ORACLE pipeline's tables, and the player semantics show the encoder's frames"""
     import ctypes
@@ -81,16 +89,19 @@ def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path):
     from tests import gtm_reader, oracle_pipeline, test_gtm
     frames = synth.video(10, 64, 48, cut=5)
     path = str(tmp_path / "enc.gtm")
-    enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, OutputFileName=path)
+    enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, OutputFileName=path, MotionPredictRadius=radius,
+                       GlobalTilingTileCount=120)
     data = open(path, "rb").read()
     hdr, pl = gtm_reader.play(oracle, data)
     assert "PaletteCount=2" in pl.settings and "[Dither]" in pl.settings
-    exp = oracle_pipeline.run(oracle, frames, palette_count=2, min_s=0.1)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=2, min_s=0.1, motion_radius=radius, tile_count=120)
     per = exp["per"]
     tm = np.zeros((10, per), test_gtm.TMI)
     tm["TileIdx"] = exp["final_tm_tile"].reshape(10, per)
     tm["PalIdx"] = exp["tm_pal"].reshape(10, per)
-    tm["Flags"] = exp["flags"].reshape(10, per) & 3
+    tm["Flags"] = (exp["flags"].reshape(10, per) & 3) | (exp["is_predicted"].reshape(10, per).astype(np.uint32) << 2)
+    tm["PredictedX"] = exp["pred_x"].reshape(10, per)
+    tm["PredictedY"] = exp["pred_y"].reshape(10, per)
     L = ctypes.CDLL(test_gtm.LIB)
     L.tm_write_gtm_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
@@ -99,7 +110,11 @@ def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path):
     want = test_gtm.write(L, str(tmp_path / "host.gtm"), 8, 6, 24.0, exp["keyframes"], exp["final_pal_px"], exp["final_use"],
                           exp["palettes"], tm, pl.settings)
     assert data == want
-    assert np.array_equal(np.stack(pl.frames), gtm_reader.render_expected(exp["final_pal_px"], exp["palettes"], tm, 8, 6))
+    if radius == 0:
+        assert np.array_equal(np.stack(pl.frames), gtm_reader.render_expected(exp["final_pal_px"], exp["palettes"], tm, 8, 6))
+    else:  # the player's last frame is the encoder's last reconstructed frame buffer (what the next frame was searched in)
+        assert exp["is_predicted"].any() and "ps" in {it[0] for fr in pl.items for it in fr}
+        assert np.array_equal(pl.frames[-1] & 0xFFFFFF, exp["recon_last"] & 0xFFFFFF)
     enc.Save(str(tmp_path / "again.gtm"))  # Save on its own, explicit path
     assert open(str(tmp_path / "again.gtm"), "rb").read() == data
     enc.close()

@@ -295,3 +295,64 @@ def test_fine_seam_twins(oracle):
     assert n == kk and np.array_equal(bc[:kk], ecent[:kk]) and bw.sum() == w.sum()
     L.bico_destroy.argtypes = [ctypes.c_void_p]
     L.bico_destroy(b)
+
+
+# ---- (f)#1 motion prediction -----------------------------------------------------------------------------------------
+def _screen(tiles, flags, tm_w, tm_h):
+    """un-mirror canonical tiles and lay them out as the frame buffer PredictMotion draws (tilingencoder.pas:1255-1260)"""
+    t = tiles.reshape(-1, 8, 8).copy()
+    for i, f in enumerate(flags):
+        if f & 1:
+            t[i] = t[i][:, ::-1]
+        if f & 2:
+            t[i] = t[i][::-1, :]
+    return np.ascontiguousarray(t.reshape(tm_h, tm_w, 8, 8).transpose(0, 2, 1, 3).reshape(tm_h * 8, tm_w * 8))
+
+
+def test_window_dcts(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    fb = _screen(tiles[:104], flags[:104], 13, 8)
+    got = stages.window_dcts(_dev(fb))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle.window_dcts(fb))
+
+
+@pytest.mark.parametrize("radius", [1, 2, 9, 32, 128])
+def test_motion_search(tiles_flags, oracle, radius):
+    """frame 1's tiles searched in frame 0's buffer: error (the asm's SSD quirks + manhattan penalty), offsets, first-minimum rule"""
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    tm_w, tm_h = 13, 8
+    fb = _screen(tiles[:104], flags[:104], tm_w, tm_h)
+    win = oracle.window_dcts(fb)
+    cur = oracle.features_rgb(tiles[104:208], flags[104:208], 1, False)
+    e_err, e_px, e_py = oracle.motion_search(cur, tm_w, tm_h, win, radius)
+    err, px, py = stages.motion_search(_dev(cur), tm_w, tm_h, _dev(win), radius)
+    torch.cuda.synchronize()
+    assert np.array_equal(_host_u32(err), e_err)
+    assert np.array_equal(px.cpu().numpy(), e_px) and np.array_equal(py.cpu().numpy(), e_py)
+
+
+def test_motion_search_quirks_and_ties(oracle):
+    """crafted vectors: saturating differences, the dropped block 5, the double subtraction in block 6, the re-squared
+    block-7 pair sums, and many equal candidates (a constant buffer: the manhattan penalty then decides)"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(11)
+    tm_w, tm_h = 5, 4
+    nwin = (tm_w * 8 - 7) * (tm_h * 8 - 7)
+    win = rng.integers(-30000, 30000, (nwin, 192)).astype(np.int16)  # big values: psubsw saturates, sums wrap mod 2^32
+    cur = rng.integers(-30000, 30000, (tm_w * tm_h, 192)).astype(np.int16)
+    win[::7] = win[3]            # repeated vectors: equal errors up to the penalty
+    cur[0] = win[3]              # an exact hit exists for tile 0 ... except the quirks make it non-zero
+    for radius in (3, 16):
+        e = oracle.motion_search(cur, tm_w, tm_h, win, radius)
+        g = stages.motion_search(_dev(cur), tm_w, tm_h, _dev(win), radius)
+        torch.cuda.synchronize()
+        assert np.array_equal(_host_u32(g[0]), e[0]) and np.array_equal(g[1].cpu().numpy(), e[1]) and np.array_equal(g[2].cpu().numpy(), e[2])
+    const = np.tile(rng.integers(-200, 200, (1, 192)).astype(np.int16), (nwin, 1))
+    e = oracle.motion_search(cur, tm_w, tm_h, const, 32)
+    g = stages.motion_search(_dev(cur), tm_w, tm_h, _dev(const), 32)
+    torch.cuda.synchronize()
+    assert np.array_equal(_host_u32(g[0]), e[0]) and np.array_equal(g[1].cpu().numpy(), e[1]) and np.array_equal(g[2].cpu().numpy(), e[2])
+    assert np.all(e[1] == 0) and np.all(e[2] == 0)  # all candidates equal: the tile's own position wins

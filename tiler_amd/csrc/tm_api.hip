@@ -35,6 +35,17 @@ int tm_stage_features_cluster(const void *tiles, int64_t n, int mode, void *out_
   return launch_features_cluster(tiles, n, mode, out_i32, (hipStream_t)stream);
 }
 
+int tm_stage_window_dcts(const void *frame_buffer, int width, int height, void *out_i16, void *stream) {
+  TM_TRY(require_device());
+  return launch_window_dcts(frame_buffer, width, height, out_i16, (hipStream_t)stream);
+}
+
+int tm_stage_motion_search(const void *cur_i16, int tm_w, int tm_h, const void *window_dcts, int radius, void *out_err, void *out_px,
+                           void *out_py, void *stream) {
+  TM_TRY(require_device());
+  return launch_motion_search(cur_i16, tm_w, tm_h, window_dcts, radius, out_err, out_px, out_py, (hipStream_t)stream);
+}
+
 tm_knn_index *tm_knn_index_create(const void *db_i16, int64_t nt, void *stream) {
   tm_knn_index_impl *ix = nullptr;
   if (knn_index_create(db_i16, nt, (hipStream_t)stream, &ix) != TM_OK) return nullptr;

@@ -164,6 +164,36 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   return TM_OK;
 }
 
+namespace {
+__global__ void k_scatter_kept(const int32_t *__restrict__ keep, const uint32_t *__restrict__ pos, int64_t n, int32_t *__restrict__ out_idx) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (keep[i]) out_idx[pos[i]] = (int32_t)i;
+}
+}  // namespace
+
+// indices of the flagged items in ascending order (TransferTiles' gather, tilingencoder.pas:4048-4103, made deterministic);
+// pos[i] = rank of item i among the kept ones (valid where keep[i] != 0)
+int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t *host_count, hipStream_t stream) {
+  TM_CHECK(n >= 0 && n < (int64_t)1 << 31, TM_E_INVAL, "compact: count out of range");
+  *host_count = 0;
+  if (n == 0) return TM_OK;
+  size_t tb = 0;
+  DevBuf tmp;
+  TM_HIP(rocprim::exclusive_scan(nullptr, tb, (const uint32_t *)keep, (uint32_t *)pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+  TM_TRY(tmp.alloc(tb));
+  TM_HIP(rocprim::exclusive_scan(tmp.p, tb, (const uint32_t *)keep, (uint32_t *)pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+  hipLaunchKernelGGL(k_scatter_kept, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, (const int32_t *)keep,
+                     (const uint32_t *)pos, n, (int32_t *)out_idx);
+  TM_HIP(hipGetLastError());
+  uint32_t last_pos = 0;
+  int32_t last_keep = 0;
+  TM_HIP(hipMemcpyAsync(&last_pos, (const uint32_t *)pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(&last_keep, (const int32_t *)keep + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  *host_count = (int64_t)last_pos + (last_keep ? 1 : 0);
+  return TM_OK;
+}
+
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
               int64_t *host_n_unique, hipStream_t stream) {
   return run_dedup_ex(rows, n, row_bytes, use_in, remap, order, use_out, host_n_unique, 0, stream);

@@ -33,6 +33,11 @@ __global__ void k_clip_index(int32_t *__restrict__ idx, int64_t n, int32_t limit
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     if (idx[i] >= limit) idx[i] = -1;
 }
+__global__ void k_tilemap_from_subset(const int32_t *__restrict__ keep, const int32_t *__restrict__ pos, const int32_t *__restrict__ sub_remap,
+                                      int64_t n, int32_t *__restrict__ tm_tile) {  // TransferTiles: TMI^.TileIdx := tIdx / -1 (4079-4083), then the remaps
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    tm_tile[i] = keep[i] ? sub_remap[pos[i]] : -1;
+}
 __global__ void k_histogram(const int32_t *__restrict__ idx, int64_t n, uint32_t *__restrict__ hist) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     if (idx[i] >= 0) atomicAdd(&hist[idx[i]], 1u);
@@ -52,11 +57,6 @@ static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, util
   return (int)llrint(std::sqrt((double)f) * std::log2(1 + (double)f));
 }
 
-static float euclidean_to_psnr(uint32_t e) {  // EuclideanToPSNR, utils.pas:1074-1078
-  const float r = (float)((double)e * (1.0 / 192));
-  const float m = r > 0.5f ? r : 0.5f;
-  return (float)(10 * std::log10(255 * 255 / (double)m));
-}
 
 struct Settings {
   std::string InputFileName, OutputFileName;
@@ -94,7 +94,11 @@ struct tm_encoder {
   const void *frames = nullptr;  // [nframes][height][width] RGB32
   DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
   DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
-  DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, KNN error
+  DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, error behind PSNR (KNN or motion)
+  DevBuf pm_err, tm_px, tm_py, tm_pred;  // motion prediction: PredictMotion's best error, PredictedX/Y (int8), IsPredicted (uint8)
+  bool has_pm = false;                   // PredictMotion ran with a radius > 0: Reduce and Reconstruct take their motion branches
+  double reduce_threshold = 0;           // last PSNR threshold SolveTileCount evaluated
+  int reduce_probes = 0;
   int64_t q = 0, t = 0;
   bool has_pal_px = false, reconstructed = false;
   // host state
@@ -132,7 +136,7 @@ static int set_number(tm_encoder *e, const std::string &k, double v, bool is_int
   if (k == "StartFrame") s.StartFrame = std::max(0, (int)v);
   else if (k == "FrameCount") s.FrameCount = std::max(0, (int)v);
   else if (k == "Scaling") s.Scaling = std::max(0.01, v);
-  else if (k == "MotionPredictRadius") s.MotionPredictRadius = clampi((int64_t)v, 1, 128);
+  else if (k == "MotionPredictRadius") s.MotionPredictRadius = clampi((int64_t)v, 0, 128);  // 3046 clamps to 1..128; 0 = motion prediction off (build extension: the reference code paths for <= 0 exist, 1972, 1496)
   else if (k == "GlobalTilingUseTargetPSNR") s.GlobalTilingUseTargetPSNR = v != 0;
   else if (k == "GlobalTilingTargetPSNR") s.GlobalTilingTargetPSNR = std::min(10 * std::log(255 * 255 / 0.5) / std::log(10.0), std::max(0.0, v));
   else if (k == "GlobalTilingQualityBasedTileCount") { s.GlobalTilingQualityBasedTileCount = v; e->auto_tile_count = true; if (e->nframes) recompute_auto_tile_count(e); }
@@ -229,8 +233,93 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
   TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
   e->t = 0;
-  e->has_pal_px = e->reconstructed = false;
+  e->has_pal_px = e->reconstructed = e->has_pm = false;
   progress(e, TM_STEP_LOAD, 3, 3);
+  return TM_OK;
+}
+
+static int step_predict_motion(tm_encoder *e) {
+  // PredictMotion, tilingencoder.pas:1964-1991: frame 0 is searched in frame 1, frame f >= 1 in the SOURCE pixels of
+  // frame f-1 (the front buffer is drawn from the un-mirrored frame tiles, 1255-1260), so frames are independent.
+  TM_TRY(need(e, TM_STEP_LOAD, "Load"));
+  e->has_pm = false;
+  if (e->s.MotionPredictRadius <= 0) return TM_OK;  // 1972
+  const int64_t per = e->tm_size();
+  const int sw = e->tm_w * 8, sh = e->tm_h * 8;
+  const int64_t nwin = (int64_t)(sw - 7) * (sh - 7);
+  TM_TRY(e->pm_err.alloc((size_t)e->q * 4));
+  TM_TRY(e->tm_px.alloc((size_t)e->q));
+  TM_TRY(e->tm_py.alloc((size_t)e->q));
+  TM_TRY(e->tm_pred.alloc((size_t)e->q));
+  TM_HIP(hipMemsetAsync(e->tm_pred.p, 0, (size_t)e->q, e->stream));
+  DevBuf screen, win, cur;
+  TM_TRY(screen.alloc((size_t)sw * sh * 4));
+  TM_TRY(win.alloc((size_t)nwin * 384));
+  TM_TRY(cur.alloc((size_t)per * 384));
+  for (int f = 0; f < e->nframes; f++) {
+    const int src = f >= 1 ? f - 1 : (e->nframes > 1 ? 1 : -1);
+    if (src >= 0) TM_TRY(launch_tiles_to_screen(e->ftiles.as<uint8_t>() + (int64_t)src * per * 256, e->fflags.as<uint8_t>() + (int64_t)src * per, e->tm_w, e->tm_h, screen.p, e->stream));
+    else TM_HIP(hipMemsetAsync(screen.p, 0, (size_t)sw * sh * 4, e->stream));  // a single frame is searched in a black buffer
+    TM_TRY(launch_window_dcts(screen.p, sw, sh, win.p, e->stream));
+    const int64_t off = (int64_t)f * per;
+    TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, per, e->fflags.as<uint8_t>() + off, TM_PVS_WEIGHTED_DCT, 0, cur.p, e->stream));
+    TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, e->pm_err.as<uint32_t>() + off,
+                                e->tm_px.as<int8_t>() + off, e->tm_py.as<int8_t>() + off, e->stream));
+    if ((f & 15) == 15) progress(e, TM_STEP_PREDICT_MOTION, f, e->nframes);
+  }
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->has_pm = true;
+  e->reconstructed = false;
+  progress(e, TM_STEP_PREDICT_MOTION, e->nframes, e->nframes);
+  return TM_OK;
+}
+
+static int step_reduce_motion(tm_encoder *e) {
+  // Reduce with motion prediction (1909-1926): SolveTileCount searches the PSNR threshold above which a tile-map item
+  // stays predicted (4014-4046); the items below it are transferred (4048-4103), made unique and ordered (4038, 1923).
+  // The search runs on per-group maxima of the prediction error (a group = one distinct tile content): PSNR is a
+  // non-increasing function of the error, so "some member has PSNR <= x" is "the group's largest error exceeds the
+  // largest error still predicted at x".  The state kept is the last probe's, as in the reference.
+  const int64_t per = e->tm_size();
+  DevBuf remap, order, use, kfmask, keep, sel, pos;
+  TM_TRY(remap.alloc((size_t)e->q * 4)); TM_TRY(order.alloc((size_t)e->q * 4)); TM_TRY(use.alloc((size_t)e->q * 4));
+  int64_t ngroups = 0;
+  TM_TRY(run_dedup(e->ftiles.p, e->q, 256, nullptr, remap.p, order.p, use.p, &ngroups, e->stream));
+  std::vector<uint8_t> hk((size_t)e->nframes, 0);
+  for (int32_t k : e->kf_start) hk[(size_t)k] = 1;
+  TM_TRY(kfmask.alloc(hk.size()));
+  TM_HIP(hipMemcpyAsync(kfmask.p, hk.data(), hk.size(), hipMemcpyHostToDevice, e->stream));
+  TM_TRY(keep.alloc((size_t)e->q * 4)); TM_TRY(sel.alloc((size_t)e->q * 4)); TM_TRY(pos.alloc((size_t)e->q * 4));
+  const double target = e->s.GlobalTilingTileCount > 0 ? (double)e->s.GlobalTilingTileCount : (double)ngroups;
+  TM_TRY(solve_tile_count(remap.p, ngroups, e->pm_err.p, kfmask.p, (int)per, e->q, target, e->tm_pred.p, keep.p, &e->reduce_threshold,
+                          &e->reduce_probes, e->stream));
+  progress(e, TM_STEP_REDUCE, 1, 2);
+  int64_t nkeep = 0;
+  TM_TRY(compact_kept(keep.p, e->q, sel.p, pos.p, &nkeep, e->stream));
+  TM_CHECK(nkeep > 0, TM_E_INVAL, "Reduce: every tile is predicted, no global tile left");
+  DevBuf sub, sremap, sorder, suse;
+  TM_TRY(sub.alloc((size_t)nkeep * 256)); TM_TRY(sremap.alloc((size_t)nkeep * 4)); TM_TRY(sorder.alloc((size_t)nkeep * 4)); TM_TRY(suse.alloc((size_t)nkeep * 4));
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(nkeep * 16)), dim3(256), 0, e->stream, e->ftiles.as<uint4>(), sel.as<int32_t>(), nkeep, 16, sub.as<uint4>());
+  int64_t nu = 0;
+  TM_TRY(run_dedup(sub.p, nkeep, 256, nullptr, sremap.p, sorder.p, suse.p, &nu, e->stream));
+  e->t = nu;
+  TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
+  TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
+  TM_TRY(e->guse.alloc((size_t)e->t * 4));
+  DevBuf gsrc;  // global tile -> frame tile index
+  TM_TRY(gsrc.alloc((size_t)e->t * 4));
+  hipLaunchKernelGGL(k_gather<int32_t>, dim3(gridn(e->t)), dim3(256), 0, e->stream, sel.as<int32_t>(), sorder.as<int32_t>(), e->t, gsrc.as<int32_t>());
+  hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(e->t * 16)), dim3(256), 0, e->stream, e->ftiles.as<uint4>(), gsrc.as<int32_t>(), e->t, 16,
+                     e->gtiles.as<uint4>());
+  hipLaunchKernelGGL(k_gather<uint8_t>, dim3(gridn(e->t)), dim3(256), 0, e->stream, e->fflags.as<uint8_t>(), gsrc.as<int32_t>(), e->t,
+                     e->gflags.as<uint8_t>());
+  TM_HIP(hipMemcpyAsync(e->guse.p, suse.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
+  hipLaunchKernelGGL(k_tilemap_from_subset, dim3(gridn(e->q)), dim3(256), 0, e->stream, keep.as<int32_t>(), pos.as<int32_t>(), sremap.as<int32_t>(),
+                     e->q, e->tm_tile.as<int32_t>());
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(e->stream));
+  e->has_pal_px = e->reconstructed = false;
+  progress(e, TM_STEP_REDUCE, 2, 2);
   return TM_OK;
 }
 
@@ -240,6 +329,7 @@ static int step_reduce(tm_encoder *e) {
   // ReindexTiles(True) are exact; the tile budget is then met by keeping the first GlobalTilingTileCount tiles of
   // that order (most used first) -- the build's stand-in for the PSNR threshold search, see DESIGN.md "Scope".
   TM_TRY(need(e, TM_STEP_LOAD, "Load"));
+  if (e->has_pm) return step_reduce_motion(e);
   DevBuf remap, order, use;
   TM_TRY(remap.alloc((size_t)e->q * 4));
   TM_TRY(order.alloc((size_t)e->q * 4));
@@ -351,6 +441,43 @@ static int step_reconstruct(tm_encoder *e) {
   hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
                      e->tm_pal.as<int32_t>());  // TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial (1551)
   TM_HIP(hipGetLastError());
+  if (e->has_pm) {
+    // motion branch (1496-1532, 1612-1654): frames in order, each searched in the previous RECONSTRUCTED frame; a key
+    // frame's first frame has no motion candidate, so key-frame groups are independent chains.
+    const int sw = e->tm_w * 8, sh = e->tm_h * 8;
+    const int64_t nwin = (int64_t)(sw - 7) * (sh - 7);
+    DevBuf fb[2], win, cur, mp;
+    TM_TRY(fb[0].alloc((size_t)sw * sh * 4)); TM_TRY(fb[1].alloc((size_t)sw * sh * 4));
+    TM_TRY(win.alloc((size_t)nwin * 384)); TM_TRY(cur.alloc((size_t)per * 384)); TM_TRY(mp.alloc((size_t)per * 4));
+    TM_HIP(hipMemsetAsync(fb[0].p, 0, (size_t)sw * sh * 4, e->stream));
+    TM_HIP(hipMemsetAsync(fb[1].p, 0, (size_t)sw * sh * 4, e->stream));
+    std::vector<uint8_t> is_kf((size_t)e->nframes, 0);
+    for (int32_t k : e->kf_start) is_kf[(size_t)k] = 1;
+    TM_CHECK(sn == 0 || is_kf[(size_t)sf], TM_E_INVAL, "Reconstruct with motion prediction: a shard must start on a key frame (frame %d does not)", sf);
+    if (sf > 0 || sn < e->nframes) {  // other shards' frames: zeros, so the host merges shards with all-reduce(SUM) on these arrays
+      const int64_t a = (int64_t)sf * per, b = (int64_t)(sf + sn) * per;
+      TM_HIP(hipMemsetAsync(e->tm_px.p, 0, (size_t)a, e->stream)); TM_HIP(hipMemsetAsync(e->tm_py.p, 0, (size_t)a, e->stream));
+      TM_HIP(hipMemsetAsync(e->tm_px.as<uint8_t>() + b, 0, (size_t)(e->q - b), e->stream));
+      TM_HIP(hipMemsetAsync(e->tm_py.as<uint8_t>() + b, 0, (size_t)(e->q - b), e->stream));
+      TM_HIP(hipMemsetAsync(e->tm_pred.p, 0, (size_t)e->q, e->stream));
+    }
+    int cb = 0;
+    for (int f = sf; f < sf + sn; f++) {
+      const int64_t off = (int64_t)f * per;
+      const bool search = !is_kf[(size_t)f];  // (Index <> PKeyFrame.StartFrame) and (ARadius >= 0), 1496
+      if (search) {
+        TM_TRY(launch_window_dcts(fb[cb].p, sw, sh, win.p, e->stream));
+        TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, per, e->fflags.as<uint8_t>() + off, TM_PVS_WEIGHTED_DCT, 0, cur.p, e->stream));
+        TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, mp.p, e->tm_px.as<int8_t>() + off,
+                                    e->tm_py.as<int8_t>() + off, e->stream));
+      }
+      TM_TRY(launch_recon_decide(e->tm_w, (int)per, search ? mp.p : nullptr, e->fflags.as<uint8_t>() + off, e->gpal_idx.p, e->gpal_px.p,
+                                 e->palettes_dev.p, e->s.PaletteSize, fb[cb].p, fb[cb ^ 1].p, e->tm_tile.as<int32_t>() + off,
+                                 e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->tm_px.as<int8_t>() + off,
+                                 e->tm_py.as<int8_t>() + off, e->tm_pred.as<uint8_t>() + off, e->stream));
+      cb ^= 1;
+    }
+  }
   TM_HIP(hipStreamSynchronize(e->stream));
   e->reconstructed = true;
   progress(e, TM_STEP_RECONSTRUCT, 2, 2);
@@ -435,7 +562,7 @@ static int run_step(tm_encoder *e, int step) {
   int rc = TM_OK;
   switch (step) {
     case TM_STEP_LOAD: rc = step_load(e); break;
-    case TM_STEP_PREDICT_MOTION: break;  // PredictMotion (1964): not built; every tile stays unpredicted (DESIGN.md "Scope")
+    case TM_STEP_PREDICT_MOTION: rc = step_predict_motion(e); break;
     case TM_STEP_REDUCE: rc = step_reduce(e); break;
     case TM_STEP_PREPARE_PALETTES: rc = step_prepare_palettes(e); break;
     case TM_STEP_DITHER: rc = step_dither(e); break;
@@ -643,14 +770,23 @@ int tm_get_tilemap(tm_encoder *e, int frame, tm_tilemap_item *items) {
   TM_HIP(hipMemcpy(ti.data(), e->tm_tile.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
   TM_HIP(hipMemcpy(pi.data(), e->tm_pal.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
   TM_HIP(hipMemcpy(er.data(), e->tm_err.as<uint32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
+  std::vector<int8_t> px(per, 0), py(per, 0);
+  std::vector<uint8_t> pr(per, 0);
+  if (e->has_pm) {
+    TM_HIP(hipMemcpy(px.data(), e->tm_px.as<int8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
+    TM_HIP(hipMemcpy(py.data(), e->tm_py.as<int8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
+    TM_HIP(hipMemcpy(pr.data(), e->tm_pred.as<uint8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
+    if (!e->reconstructed) TM_HIP(hipMemcpy(er.data(), e->pm_err.as<uint32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));  // 1250
+  }
   for (int64_t i = 0; i < per; i++) {
     items[i].TileIdx = ti[i];
     items[i].PalIdx = pi[i];
-    items[i].PredictedX = 0;
-    items[i].PredictedY = 0;
-    items[i].PSNR = e->reconstructed ? euclidean_to_psnr(er[i]) : 0.0f;  // TMI^.PSNR := EuclideanToPSNR(knnErr), 1619
+    items[i].PredictedX = px[i];
+    items[i].PredictedY = py[i];
+    // TMI^.PSNR := EuclideanToPSNR(knnErr | mpErr), 1619 / 1644; after PredictMotion alone: of its best error, 1250
+    items[i].PSNR = (e->reconstructed || e->has_pm) ? euclidean_to_psnr(er[i]) : 0.0f;
     const uint8_t f = e->h_fflags[(size_t)(off + i)];
-    items[i].Flags = (f & 1 ? 1u : 0u) | (f & 2 ? 2u : 0u);
+    items[i].Flags = (f & 1 ? 1u : 0u) | (f & 2 ? 2u : 0u) | (pr[i] ? 4u : 0u);
   }
   return TM_OK;
 }
@@ -694,6 +830,9 @@ int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
     case TM_ARRAY_TILEMAP_TILE: *ptr = e->tm_tile.p; *count = e->q; break;
     case TM_ARRAY_TILEMAP_ERR: *ptr = e->tm_err.p; *count = e->q; break;
     case TM_ARRAY_TILEMAP_PAL: *ptr = e->tm_pal.p; *count = e->q; break;
+    case TM_ARRAY_TILEMAP_PRED: *ptr = e->has_pm ? e->tm_pred.p : nullptr; *count = e->has_pm ? e->q : 0; break;
+    case TM_ARRAY_TILEMAP_PX: *ptr = e->has_pm ? e->tm_px.p : nullptr; *count = e->has_pm ? e->q : 0; break;
+    case TM_ARRAY_TILEMAP_PY: *ptr = e->has_pm ? e->tm_py.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     default: set_error("bad array id %d", which); return TM_E_INVAL;
   }
   return TM_OK;

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // A4+A5: int16[192] features.  One wave per tile; lane = DCT position (v,u) and holds its 64-entry LUT row in
 // registers; the 3x64 component planes live in LDS and are read as wave-wide broadcasts.
-template <bool FROM_PAL>
+// SRC: 0 = RGB tiles, 1 = palette-index tiles through their palette, 2 = every 8x8 window of a frame buffer
+// (PredictMotion.DoDCTs / Reconstruct.DoDCTs, tilingencoder.pas:1157-1182, 1437-1462: `tiles` is the buffer, pal_size its
+// width in pixels, tile t = window at (t mod (width-7), t div (width-7))).
+template <int SRC>
 __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ pal_px,
                                                       const int32_t *__restrict__ pal_idx, const int32_t *__restrict__ palettes,
                                                       int pal_size, const uint8_t *__restrict__ mirror_flags, int64_t n,
@@ -101,10 +104,15 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
       const int y = lane >> 3, x = lane & 7;
       const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // ConvertToCpnPixels 3080-3085 / 3093-3098
       uint32_t col;
-      if (FROM_PAL)
+      if (SRC == 1) {
         col = (uint32_t)palettes[(int64_t)pal_idx[t] * pal_size + pal_px[t * 64 + src]];
-      else
+      } else if (SRC == 2) {
+        const int ww = pal_size - 7;
+        const int64_t wy = t / ww, wx = t - wy * ww;
+        col = tiles[(wy + y) * pal_size + wx + x];  // CopyRGBPixels(ABackBuffer, x, AIndex), 879-887
+      } else {
         col = tiles[t * 64 + src];
+      }
       float yy, uu, vv;
       if (use_lab)
         rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
@@ -279,7 +287,7 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
   TM_CHECK(mode != TM_PVS_WAVELETS, TM_E_UNSUPPORTED, "wavelet features on int16 vectors are unimplemented in the reference too (tilingencoder.pas:3111)");
   TM_CHECK(mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   if (n <= 0) return TM_OK;
-  hipLaunchKernelGGL(k_features_i16<false>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
+  hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
   TM_HIP(hipGetLastError());
@@ -293,9 +301,21 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
   TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   TM_CHECK(pal_size >= 1 && pal_size <= 256, TM_E_INVAL, "bad palette size %d", pal_size);
   if (n <= 0) return TM_OK;
-  hipLaunchKernelGGL(k_features_i16<true>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
+  hipLaunchKernelGGL(k_features_i16<1>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
                      (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(w >= 8 && h >= 8, TM_E_INVAL, "frame buffer %dx%d smaller than a tile", w, h);
+  const int64_t n = (int64_t)(w - 7) * (h - 7);
+  hipLaunchKernelGGL(k_features_i16<2>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)fb, nullptr, nullptr, nullptr, w,
+                     nullptr, n, 1, 0, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights, tab->snake, tab->srgb_lut,
+                     (int16_t *)out);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

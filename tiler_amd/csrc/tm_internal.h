@@ -15,6 +15,7 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
 int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
+int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream);
 
 // tm_knn.hip
 struct tm_knn_index_impl;
@@ -32,6 +33,19 @@ int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, vo
               int64_t *host_n_unique, hipStream_t stream);
 int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
                  int64_t *host_n_unique, int by_index, hipStream_t stream);
+
+int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t *host_count, hipStream_t stream);
+
+// tm_motion.hip: motion prediction (tilingencoder.pas:1154-1282, 1496-1654) and Reduce's tile-count search (4014-4046)
+int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, int radius, void *best_err, void *px, void *py,
+                         hipStream_t stream);
+int launch_tiles_to_screen(const void *tiles, const void *flags, int tm_w, int tm_h, void *screen, hipStream_t stream);
+int launch_recon_decide(int tm_w, int per, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
+                        const void *palettes, int pal_size, const void *back, void *front, void *tm_tile, void *tm_pal, void *tm_err,
+                        const void *px, const void *py, void *pred, hipStream_t stream);
+int solve_tile_count(const void *group, int64_t ngroups, const void *pm_err, const void *frame_is_kf, int per, int64_t q, double target,
+                     void *pred, void *keep, double *x_out, int *probes_out, hipStream_t stream);
+float euclidean_to_psnr(uint32_t e);
 
 // tm_kmeans.hip
 int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,

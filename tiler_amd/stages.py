@@ -55,6 +55,24 @@ def features_cluster(tiles, mode=4):
     return out
 
 
+def window_dcts(frame_buffer):
+    """PredictMotion.DoDCTs / Reconstruct.DoDCTs (tilingencoder.pas:1157-1182): int32 [H][W] 0x00BBGGRR -> int16 [(H-7)*(W-7)][192]"""
+    h, w = frame_buffer.shape
+    out = torch.empty(((h - 7) * (w - 7), 192), dtype=torch.int16, device=frame_buffer.device)
+    check(lib().tm_stage_window_dcts(_p(frame_buffer), w, h, _p(out), _stream()))
+    return out
+
+
+def motion_search(cur, tm_w, tm_h, win, radius):
+    """PredictMotion.DoXY search (tilingencoder.pas:1209-1253) -> (err int32-as-uint32, px int8, py int8), one per tile"""
+    n = tm_w * tm_h
+    err = torch.empty((n,), dtype=torch.int32, device=cur.device)
+    px = torch.empty((n,), dtype=torch.int8, device=cur.device)
+    py = torch.empty((n,), dtype=torch.int8, device=cur.device)
+    check(lib().tm_stage_motion_search(_p(cur), tm_w, tm_h, _p(win), radius, _p(err), _p(px), _p(py), _stream()))
+    return err, px, py
+
+
 def knn(queries, db):
     """ann_kdtree_short_search(eps=0) for every query (tilingencoder.pas:1547) -> (idx int32, err int32-as-uint32)"""
     nq, nt = queries.shape[0], db.shape[0]
