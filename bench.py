@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--palettes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--motion-radius", type=int, default=0,
+                    help="MotionPredictRadius for the timed steps; 0 (default) = the headline definition of SURVEY.md 8(d): motion prediction excluded")
+    ap.add_argument("--no-motion-extra", action="store_true", help="skip the untimed extra pass with MotionPredictRadius=32")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +127,7 @@ def main():
     enc.PaletteCount = args.palettes
     enc.PaletteSize = 16
     enc.FrameTilingExtendedPaletteUsage = False  # headline KNN number: EPU off
+    enc.MotionPredictRadius = args.motion_radius
     enc.SetVideo(W, H, 24.0, F)
     enc.SetFramesDevice(frames)
 
@@ -173,7 +177,7 @@ def main():
         "dtype": "i8",
         "data": "synthetic",
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
-                               f"Thomas-Knoll dither, KNN k=1 (EPU off), motion prediction not built",
+                               f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else ""),
                    "frames": F, "tiles_per_frame": c["tm_w"] * c["tm_h"], "query_tiles": q_total, "global_tiles_T": int(enc.GlobalTilingTileCount),
                    "distinct_database_rows": int(ks["db_rows"]), "final_tiles_after_reindex": int(c["tiles"]),
                    "parallelism": f"frames sharded over {world} GPU(s) for Reconstruct; other steps replicated"},
@@ -200,6 +204,23 @@ def main():
                                  "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
                                  "launch_ms": kd["kernel_ms"] / max(kd["launches"], 1), "pairs_per_launch": kd["pairs"] / max(kd["launches"], 1),
                                  "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated"}
+    if world == 1 and args.motion_radius == 0 and not args.no_motion_extra:
+        # second number, outside the timed region: the reference's default path with motion prediction (radius 32)
+        enc.MotionPredictRadius = 32
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        enc.Run()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        sm = enc.StageMs()
+        pred = 0
+        for f in range(0, F, max(1, F // 10)):
+            pred += int(((enc.TileMap(f)["Flags"] >> 2) & 1).sum())
+        out["with_motion_prediction"] = {"value": F / dt1, "unit": "frames/s", "ms": dt1 * 1e3, "radius": 32,
+                                         "stage_ms": {n: round(float(v), 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], sm)},
+                                         "global_tiles": int(enc.counts()["tiles"]),
+                                         "predicted_fraction_sampled": pred / float(len(range(0, F, max(1, F // 10))) * c["tm_w"] * c["tm_h"])}
+        enc.MotionPredictRadius = 0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, int(enc.GlobalTilingTileCount))
         out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
