@@ -105,12 +105,15 @@ TM_API int tm_write_gtm_host(const char *path, int tm_w, int tm_h, int nframes, 
 TM_API int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n);
 /* Multi-GPU (one process per GPU): this process matches only frames [first, first+count) in Reconstruct (frames are
  * independent in the KNN branch, DoXY :1464); the host then merges the per-frame results of all processes with an
- * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex. */
+ * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex.
+ * PredictMotion honours the same range (its frames are independent, :1982-1985); with motion prediction on, the range
+ * given for Reconstruct must start on a key frame (frames chain inside a key frame, :1496). */
 enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL = 2,
        /* with motion prediction: uint8 IsPredicted, int8 PredictedX, int8 PredictedY (1 byte per item; other shards hold 0: merge with SUM) */
-       TM_ARRAY_TILEMAP_PRED = 3, TM_ARRAY_TILEMAP_PX = 4, TM_ARRAY_TILEMAP_PY = 5 };
+       TM_ARRAY_TILEMAP_PRED = 3, TM_ARRAY_TILEMAP_PX = 4, TM_ARRAY_TILEMAP_PY = 5,
+       TM_ARRAY_PM_ERR = 6 /* uint32 best error of PredictMotion per item; other shards hold 0 */ };
 TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
-TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* elements: int32 for 0-2, bytes for 3-5 */);
+TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* elements: int32 for 0-2 and 6, bytes for 3-5 */);
 TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */

@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: synthetic generator, shard maths, oracle k-means/dither invariants, encoder mirror."""
+import ctypes
+
 import numpy as np
 
 
@@ -72,3 +74,66 @@ def test_encoder_mirror_names():
                                               "esReconstruct", "esReindex", "esSave"]
     assert TEncoderStep.esAll == -1 and TEncoderStep.esSave == 7 and TPsyVisMode.pvsWeightedSpeDCT == 4
     assert TILEMAP_ITEM.itemsize == 18 and TILE_HDR.itemsize == 20
+
+
+# ---- (f)#1 motion prediction: the oracle's restatements checked against independent statements ----------------------
+def test_window_dcts_are_features_of_the_windows(oracle):
+    rng = np.random.default_rng(3)
+    fb = rng.integers(0, 1 << 24, (19, 26), dtype=np.uint32)
+    win = oracle.window_dcts(fb)
+    assert win.shape == (12 * 19, 192)
+    for (y, x) in [(0, 0), (11, 18), (5, 7)]:
+        tile = np.ascontiguousarray(fb[y:y + 8, x:x + 8]).reshape(1, 64)
+        assert np.array_equal(win[y * 19 + x], oracle.features_rgb(tile, None, 1, False)[0])
+
+
+def test_motion_search_finds_a_pure_shift(oracle):
+    """a smooth image shifted by (+3, -2): interior tiles point back at (-3, +2); and the error of a perfect match is NOT 0
+    (CompareEuclideanDCTPtr_asm subtracts block 5 of b from block 6, utils.pas:604-605) but what the quirk leaves"""
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (3, 12, 14)).astype(np.float64)
+    big = np.kron(base, np.ones((8, 8)))  # 96 x 112, piecewise constant -> blur a little
+    for _ in range(3):
+        big = (big + np.roll(big, 1, 1) + np.roll(big, 1, 2) + np.roll(big, 3, 1) + np.roll(big, 5, 2)) / 5
+    img = (big.astype(np.uint32)[0] | (big.astype(np.uint32)[1] << 8) | (big.astype(np.uint32)[2] << 16))
+    prev = np.ascontiguousarray(img[8:72, 8:88])             # 64 x 80 -> tile map 10 x 8
+    cur = np.ascontiguousarray(img[8 - 2:72 - 2, 8 + 3:88 + 3])  # content moved by (-3, +2) in the new frame
+    tm_w, tm_h = 10, 8
+    tiles = np.ascontiguousarray(cur.reshape(tm_h, 8, tm_w, 8).transpose(0, 2, 1, 3).reshape(-1, 64))
+    feats = oracle.features_rgb(tiles, None, 1, False)
+    win = oracle.window_dcts(prev)
+    err, px, py = oracle.motion_search(feats, tm_w, tm_h, win, 8)
+    inner = np.zeros((tm_h, tm_w), bool)
+    inner[1:-1, 1:-1] = True
+    inner = inner.ravel()
+    assert np.mean((px[inner] == 3) & (py[inner] == -2)) > 0.9
+    i = int(np.nonzero(inner & (px == 3) & (py == -2))[0][0])
+    sy, sx = divmod(i, tm_w)
+    hit = win[(sy * 8 - 2) * (tm_w * 8 - 7) + sx * 8 + 3]
+    assert np.array_equal(hit, feats[i])  # the very same vector ...
+    b = hit.astype(np.int64)
+    quirk = 0
+    for half in (0, 96):  # ... leaves sum(b5^2) per half (block 6 term = (a6 - b5 - b6)^2), block 5 itself drops out
+        quirk += int((b[half + 40:half + 48] ** 2).sum())
+    assert int(err[i]) == quirk + 5 and oracle.L.tmo_ssd_i16_sse_quirk(ctypes.c_void_p(hit.ctypes.data), ctypes.c_void_p(hit.ctypes.data)) == quirk
+
+
+def test_solve_tile_count_follows_golden_section(oracle):
+    """independent restatement of GoldenRatioSearch (utils.pas:1044-1072) with a brute-force count"""
+    rng = np.random.default_rng(9)
+    mins = np.sort(rng.uniform(5, 51, 5000))
+    inv_phi = 2 / (1 + 5 ** 0.5)
+    for target in (100, 2500, 4999, 10 ** 6):
+        mn, mx, last, n = 0.0, 10 * np.log(255 * 255 / 0.5) / np.log(10), None, 0
+        while abs(mn - mx) > 1e-6:
+            x = mn + (mx - mn) * (1 - inv_phi)
+            y = int((mins <= x).sum())
+            last, n = x, n + 1
+            if abs(y - target) <= 0.5:
+                break
+            if y < target:
+                mn = x
+            else:
+                mx = x
+        x, probes = oracle.solve_tile_count(mins, target)
+        assert probes == n and abs(x - last) < 1e-12

@@ -252,11 +252,18 @@ static int step_predict_motion(tm_encoder *e) {
   TM_TRY(e->tm_py.alloc((size_t)e->q));
   TM_TRY(e->tm_pred.alloc((size_t)e->q));
   TM_HIP(hipMemsetAsync(e->tm_pred.p, 0, (size_t)e->q, e->stream));
+  const int sf = std::max(0, std::min(e->shard_first, e->nframes));
+  const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
+  if (sf > 0 || sn < e->nframes) {  // frames of other shards stay 0: the host merges shards with all-reduce(SUM)
+    TM_HIP(hipMemsetAsync(e->pm_err.p, 0, (size_t)e->q * 4, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_px.p, 0, (size_t)e->q, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_py.p, 0, (size_t)e->q, e->stream));
+  }
   DevBuf screen, win, cur;
   TM_TRY(screen.alloc((size_t)sw * sh * 4));
   TM_TRY(win.alloc((size_t)nwin * 384));
   TM_TRY(cur.alloc((size_t)per * 384));
-  for (int f = 0; f < e->nframes; f++) {
+  for (int f = sf; f < sf + sn; f++) {
     const int src = f >= 1 ? f - 1 : (e->nframes > 1 ? 1 : -1);
     if (src >= 0) TM_TRY(launch_tiles_to_screen(e->ftiles.as<uint8_t>() + (int64_t)src * per * 256, e->fflags.as<uint8_t>() + (int64_t)src * per, e->tm_w, e->tm_h, screen.p, e->stream));
     else TM_HIP(hipMemsetAsync(screen.p, 0, (size_t)sw * sh * 4, e->stream));  // a single frame is searched in a black buffer
@@ -833,6 +840,7 @@ int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
     case TM_ARRAY_TILEMAP_PRED: *ptr = e->has_pm ? e->tm_pred.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     case TM_ARRAY_TILEMAP_PX: *ptr = e->has_pm ? e->tm_px.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     case TM_ARRAY_TILEMAP_PY: *ptr = e->has_pm ? e->tm_py.p : nullptr; *count = e->has_pm ? e->q : 0; break;
+    case TM_ARRAY_PM_ERR: *ptr = e->has_pm ? e->pm_err.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     default: set_error("bad array id %d", which); return TM_E_INVAL;
   }
   return TM_OK;

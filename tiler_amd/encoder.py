@@ -203,13 +203,15 @@ class TilingEncoder:
         check(self._L.tm_set_query_shard(c_void_p(self._h), first_frame, frame_count))
 
     def DeviceArray(self, which):
-        """int32 torch view of an encoder-owned device array (0 TileIdx, 1 KNN error, 2 PalIdx), no copy"""
+        """torch view of an encoder-owned device array, no copy: 0 TileIdx, 1 error, 2 PalIdx (int32); with motion
+        prediction 3 IsPredicted (uint8), 4/5 PredictedX/Y (int8), 6 PredictMotion's best error (int32)"""
         import torch
         ptr, cnt = c_void_p(), c_int64()
         check(self._L.tm_get_device_array(c_void_p(self._h), which, ctypes.byref(ptr), ctypes.byref(cnt)))
+        typestr = {3: "|u1", 4: "|i1", 5: "|i1"}.get(int(which), "<i4")
 
         class _View:
-            __cuda_array_interface__ = {"shape": (cnt.value,), "typestr": "<i4", "data": (ptr.value, False), "version": 2}
+            __cuda_array_interface__ = {"shape": (cnt.value,), "typestr": typestr, "data": (ptr.value, False), "version": 2}
 
         return torch.as_tensor(_View(), device="cuda")
 
