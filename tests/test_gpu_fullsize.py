@@ -75,6 +75,7 @@ def test_full_size_properties(oracle, name, tmp_path):
     enc.LoadDefaultSettings()
     enc.PaletteCount = npal
     enc.FrameTilingExtendedPaletteUsage = False
+    enc.MotionPredictRadius = 0  # the KNN-only pipeline; motion prediction has its own full-size test below
     enc.SetVideo(w, h, 24.0, nf)
     enc.SetFramesDevice(frames)
     gen = torch.Generator(device="cuda").manual_seed(99)
@@ -216,3 +217,66 @@ def test_kmeans_fixed_point_at_full_size(n, d, k):
             best = dist.min(1).values
             first = (dist == best[:, None]).to(torch.uint8).argmax(1)
             assert torch.equal(first, a64[s:s + (1 << 18)])
+
+
+def test_motion_prediction_at_720p(oracle, tmp_path):
+    """configs[1] with the reference's default MotionPredictRadius = 32: PredictMotion against the oracle on crops (the
+    search is position-relative: a tile whose whole +-32 window lies inside a crop gets the same answer from the crop),
+    the tile budget the threshold search lands on, and the .gtm chain played back"""
+    from tiler_amd import stages
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep as S
+    from tests import gtm_reader
+    w, h, nf, npal = SIZES["720p300"]
+    frames = device_video(w, h, nf)
+    tm_w, tm_h = w // 8, h // 8
+    per = tm_w * tm_h
+    enc = TilingEncoder()
+    enc.LoadDefaultSettings()
+    enc.PaletteCount = npal
+    enc.FrameTilingExtendedPaletteUsage = False
+    assert enc.MotionPredictRadius == 32
+    enc.SetVideo(w, h, 24.0, nf)
+    enc.SetFramesDevice(frames)
+    enc.Run(S.esLoad)
+    enc.Run(S.esPredictMotion)
+    ct = 17  # crop of 17 x 17 tiles: tiles 5..11 keep their full window (33 px up/left, 32 + 7 px down/right)
+    for f, ty0, tx0 in [(0, 0, 0), (1, 20, 60), (150, 73, 143), (299, 40, 3)]:
+        src = f - 1 if f >= 1 else 1
+        crop = lambda k: np.ascontiguousarray(frames[k, ty0 * 8:(ty0 + ct) * 8, tx0 * 8:(tx0 + ct) * 8].cpu().numpy().view(np.uint32))
+        prev_t = oracle.load_from_image(crop(src), ct, ct)
+        cur_t = oracle.load_from_image(crop(f), ct, ct)
+        fb = np.ascontiguousarray(prev_t.reshape(ct, ct, 8, 8).transpose(0, 2, 1, 3).reshape(ct * 8, ct * 8))
+        err, px, py = oracle.motion_search(oracle.features_rgb(cur_t, None, 1, False), ct, ct, oracle.window_dcts(fb), 32)
+        tmap = enc.TileMap(f).reshape(tm_h, tm_w)[ty0:ty0 + ct, tx0:tx0 + ct]
+        # interior of the crop, unless the crop touches the frame border (there the clamped window is the same on both sides)
+        lo_y, hi_y = (0 if ty0 == 0 else 5), (ct if ty0 + ct == tm_h else 12)
+        lo_x, hi_x = (0 if tx0 == 0 else 5), (ct if tx0 + ct == tm_w else 12)
+        sel = np.zeros((ct, ct), bool)
+        sel[lo_y:hi_y, lo_x:hi_x] = True
+        assert np.array_equal(tmap["PredictedX"][sel], px.reshape(ct, ct)[sel])
+        assert np.array_equal(tmap["PredictedY"][sel], py.reshape(ct, ct)[sel])
+        assert np.allclose(tmap["PSNR"][sel], oracle.psnr(err).reshape(ct, ct)[sel], rtol=1e-6)
+    for st in (S.esReduce, S.esPreparePalettes, S.esDither, S.esReconstruct):
+        enc.Run(st)
+    target = int(enc.GlobalTilingTileCount)
+    T = enc.counts()["tiles"]
+    assert 0.9 * target <= T <= 1.1 * target, (T, target)  # the search stops within half a tile of the target unless PSNR ties block it
+    kf = enc.KeyFrames()
+    t0 = enc.TileMap(int(kf[1]))
+    assert not ((t0["Flags"] >> 2) & 1).any()          # a key frame's first frame has no motion candidate (1496)
+    t1 = enc.TileMap(int(kf[1]) + 1)
+    pred = ((t1["Flags"] >> 2) & 1).astype(bool)
+    assert 0.05 < pred.mean() < 0.99
+    assert np.all(np.abs(t1["PredictedX"].astype(int)) <= 32) and np.all(np.abs(t1["PredictedY"].astype(int)) <= 32)
+    enc.Run(S.esReindex)
+    path = str(tmp_path / "mp.gtm")
+    enc.Save(path)
+    hdr, raws = gtm_reader.unpack(oracle, open(path, "rb").read())
+    pl = gtm_reader.Player(max_frames=3)
+    pl.feed(raws[0])
+    kinds = {it[0] for fr in pl.items for it in fr}
+    assert "ps" in kinds or "skip" in kinds
+    hdr_t, px2, _ = enc.Tiles()
+    want0 = gtm_reader.render_expected(px2, enc.Palettes(), np.stack([enc.TileMap(0)]), tm_w, tm_h)
+    assert np.array_equal(pl.frames[0], want0[0])  # frame 0 is all KNN
+    enc.close()

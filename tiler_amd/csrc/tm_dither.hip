@@ -9,6 +9,7 @@
 // |t| <= 255 + 16320*9/100, penalty < 2^29 (the reference uses Int64).
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "tm_common.h"
 #include "tm_internal.h"
@@ -16,6 +17,9 @@
 namespace tmx {
 
 __device__ __forceinline__ int div_trunc_1000(int v) { return v / 1000; }  // Pascal div: toward zero, like C
+// full-rate 24-bit multiplies (32-bit v_mul_lo_u32 is quarter rate); callers guarantee |operands| < 2^23
+__device__ __forceinline__ int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // QuickSort(List[0], 0, last, 1, PlanCompareLuma) of extern.pas:370-418 on one lane's list, iterative form: explicit
 // stack for the "recurse left, loop right" shape; the pivot VALUE is constant during a partition pass because the
@@ -56,8 +60,8 @@ __device__ __forceinline__ void lane_quicksort(uint16_t (*s_list)[64], uint16_t 
 
 __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
                                                   const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
-                                                  int npal, int pal_size, const uint8_t *__restrict__ dither_map,
-                                                  uint8_t *__restrict__ out) {
+                                                  int npal, int pal_size, const uint8_t *__restrict__ cls /* null, or 1 = k_dither_tk_fast's */,
+                                                  const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out) {
   __shared__ int4 s_plan[64];          // r, g, b, luma of live entries (Y2Palette / LumaPal)
   __shared__ uint8_t s_rank[64];       // #entries with strictly smaller luma: order-isomorphic to LumaPal incl. ties
   __shared__ uint8_t s_remap[64];      // Plan.Remap
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
   int cached_pal = -1, cnt = 0;
   for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
     const int pi = pal_idx[t];
+    if (cls && pi >= 0 && pi < npal && cls[pi]) continue;  // the fast kernel's tile
     if (pi != cached_pal) {  // PreparePlan: drop cDitheringNullColor entries, keep order
       __syncthreads();
       int col = TM_NULL_COLOR;
@@ -120,6 +125,125 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
     lane_quicksort(s_list, s_stack, lane, 63);
     const int pick = s_list[map_value][lane] & 0xff;
     out[t * 64 + src] = s_remap[pick];  // re-mirror (2721-2722): natural (y,x) lives at canonical position src
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast Thomas-Knoll path for the common palette shape: 1..16 live colours whose lumas are pairwise distinct.
+//  * The plan is wave-uniform, so it lives in SGPRs (16 x r,g,b,luma) and the 16-way search is fully unrolled; the
+//    argmin is one v_min_u32 per entry on (penalty << 4 | index): penalties stay below 2^28 (|t - p| <= 1723 per
+//    channel because |e| <= 64*255), and the lowest index wins equal penalties exactly like the reference's strict
+//    `<` scan in plan order (2597-2605).
+//  * With distinct lumas the unstable QuickSort of the 64 picks (2611) has only one possible outcome -- picks ordered
+//    by luma, equal picks being the same byte -- so the lane does not sort: it counts its picks per luma rank and
+//    reads position cDitheringMap[..] of the sorted list off the running totals.
+// Palettes with a luma tie between different colours, or more than 16 live colours, take k_dither_tk (literal sort).
+__global__ void k_palette_class(const int32_t *__restrict__ palettes, int npal, int pal_size, uint8_t *__restrict__ cls) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npal) return;
+  int luma[64], cnt = 0;
+  for (int i = 0; i < pal_size; i++) {
+    const int col = palettes[(int64_t)p * pal_size + i];
+    if (col == TM_NULL_COLOR) continue;
+    luma[cnt++] = (col & 0xff) * 299 + ((col >> 8) & 0xff) * 587 + ((col >> 16) & 0xff) * 114;
+  }
+  bool fast = cnt >= 1 && cnt <= 16;
+  for (int i = 0; fast && i < cnt; i++)
+    for (int j = i + 1; j < cnt; j++)
+      if (luma[i] == luma[j]) fast = false;
+  cls[p] = fast ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
+                                                       const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
+                                                       int npal, int pal_size, const uint8_t *__restrict__ cls,
+                                                       const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out) {
+  __shared__ int4 s_plan[16];      // r, g, b, luma rank
+  __shared__ int s_luma[16];
+  __shared__ uint8_t s_remap[16];  // plan index -> palette slot
+  __shared__ uint8_t s_by_rank[16];  // luma rank -> plan index
+  const int lane = threadIdx.x;
+  const int map_value = dither_map[lane];
+  int pr[16], pg[16], pb[16], pl[16];
+  int cached_pal = -1;
+  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
+    const int pi = pal_idx[t];
+    if (pi < 0 || pi >= npal || !cls[pi]) continue;  // wave-uniform
+    if (pi != cached_pal) {  // PreparePlan (2268-2301): drop cDitheringNullColor entries, keep order
+      __syncthreads();
+      int col = TM_NULL_COLOR;
+      if (lane < pal_size) col = palettes[(int64_t)pi * pal_size + lane];
+      const bool live = col != TM_NULL_COLOR;
+      const unsigned long long m = __ballot(live);
+      const int cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      const int r = col & 0xff, g = (col >> 8) & 0xff, b = (col >> 16) & 0xff;
+      if (live) {
+        s_plan[pos] = make_int4(r, g, b, 0);
+        s_luma[pos] = r * 299 + g * 587 + b * 114;
+        s_remap[pos] = (uint8_t)lane;
+      }
+      __syncthreads();
+      if (lane < cnt) {
+        const int my = s_luma[lane];
+        int rk = 0;
+        for (int i = 0; i < cnt; i++) rk += (s_luma[i] < my) ? 1 : 0;
+        s_plan[lane].w = rk;
+        s_by_rank[rk] = (uint8_t)lane;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; i++) {  // entries past the live count repeat entry 0: same penalty, higher index, never chosen
+        const int j = i < cnt ? i : 0;
+        const int4 p = s_plan[j];
+        pr[i] = __builtin_amdgcn_readfirstlane(p.x);
+        pg[i] = __builtin_amdgcn_readfirstlane(p.y);
+        pb[i] = __builtin_amdgcn_readfirstlane(p.z);
+        pl[i] = __builtin_amdgcn_readfirstlane(s_luma[j]);
+      }
+      cached_pal = pi;
+    }
+    const int f = flags ? flags[t] : 0;
+    const int y = lane >> 3, x = lane & 7;
+    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // un-mirror (2696-2697)
+    const uint32_t c = tiles[t * 64 + src];
+    const int s0 = c & 0xff, s1 = (c >> 8) & 0xff, s2 = (c >> 16) & 0xff;
+    int e0 = 0, e1 = 0, e2 = 0;
+    unsigned long long bins_lo = 0, bins_hi = 0;  // 8 bits per luma rank: how many of the 64 picks have that rank
+    for (int k = 0; k < 64; k++) {
+      const int t0 = s0 + (e0 * 9) / 100, t1 = s1 + (e1 * 9) / 100, t2 = s2 + (e2 * 9) / 100;
+      const int lt = t0 * 299 + t1 * 587 + t2 * 114;
+      uint32_t best = 0xffffffffu;
+      const uint32_t ltb = (uint32_t)(lt + (1 << 21));  // |lt| <= 1 723 000: biased so that v_sad_u32 gives |lt - luma|
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        // all factors fit 24 bits (|t - p| <= 1723, sum of squares <= 8.9e6, |luma difference| / 1000 <= 1978): full-rate
+        // v_mad_i32_i24 instead of quarter-rate 32-bit multiplies
+        const int dr = t0 - pr[i], dg = t1 - pg[i], db = t2 - pb[i];
+        const int ssd = mad24(dr, dr, mad24(dg, dg, mul24(db, db)));
+        // |(lt - luma) div 1000| = floor(|lt - luma| / 1000): exact as trunc(fma(a, 0.001f, 0.0005f)) for a < 2^22 (both ends
+        // of every thousand checked in exact arithmetic, monotone in between); only its square is used
+        uint32_t a;
+        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(a) : "v"(ltb), "s"((uint32_t)(pl[i] + (1 << 21))));
+        const int ld = (int)__builtin_fmaf((float)a, 0.001f, 0.0005f);
+        const uint32_t pen = (uint32_t)mad24(ssd, 13, mul24(ld, ld) << 5);
+        best = min(best, (pen << 4) | (uint32_t)i);
+      }
+      const int4 p = s_plan[best & 15u];
+      e0 += s0 - p.x; e1 += s1 - p.y; e2 += s2 - p.z;
+      const unsigned long long one = 1ull << ((p.w & 7) * 8);
+      bins_lo += p.w < 8 ? one : 0ull;
+      bins_hi += p.w < 8 ? 0ull : one;
+    }
+    int acc = 0, pick_rank = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {  // position map_value of the luma-sorted list
+      acc += (int)(((r < 8 ? bins_lo : bins_hi) >> ((r & 7) * 8)) & 0xff);
+      if (!found && acc > map_value) { pick_rank = r; found = true; }
+    }
+    out[t * 64 + src] = s_remap[s_by_rank[pick_rank]];  // re-mirror (2721-2722)
   }
 }
 
@@ -214,10 +338,22 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
   TM_CHECK(use_tk || (y2_mixed >= 1 && y2_mixed <= 16), TM_E_INVAL, "DitheringYliluoma2MixedColors %d outside 1..16 (tilingencoder.pas:2922)", y2_mixed);
   if (n <= 0) return TM_OK;
   int grid = (int)std::min<int64_t>(n, 256 * 40);
-  if (use_tk)
+  if (use_tk) {
+    static const bool literal_only = getenv("TM_DITHER_LITERAL") != nullptr;  // debugging aid: every tile through the literal sort
+    DevBuf cls;
+    if (!literal_only) {
+      TM_TRY(cls.alloc((size_t)npal));
+      hipLaunchKernelGGL(k_palette_class, dim3((npal + 63) / 64), dim3(64), 0, stream, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>());
+      hipLaunchKernelGGL(k_dither_tk_fast, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
+                         (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map,
+                         (uint8_t *)out_pal_px);
+    }
     hipLaunchKernelGGL(k_dither_tk, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
-                       (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, tab->dither_map, (uint8_t *)out_pal_px);
-  else
+                       (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, literal_only ? nullptr : cls.as<uint8_t>(),
+                       tab->dither_map, (uint8_t *)out_pal_px);
+    TM_HIP(hipGetLastError());
+    TM_HIP(hipStreamSynchronize(stream));  // cls is freed on return
+  } else
     hipLaunchKernelGGL(k_dither_yliluoma, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
                        (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, y2_mixed, tab->dither_map,
                        (uint8_t *)out_pal_px);
