@@ -161,6 +161,21 @@ def test_dither_thomas_knoll(tiles_flags, oracle):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("pal_size", [2, 4, 16, 17, 32, 64])
+def test_dither_palette_sizes(tiles_flags, oracle, pal_size):
+    """<= 16 live colours with distinct lumas take the counting kernel, everything else the literal-sort kernel"""
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    tiles, flags = tiles[:64], flags[:64]
+    rng = np.random.default_rng(pal_size)
+    palettes = rng.integers(0, 1 << 24, size=(3, pal_size), dtype=np.int32)
+    palettes[2, pal_size // 2:] = -65281
+    pal_idx = rng.integers(0, 3, size=tiles.shape[0], dtype=np.int32)
+    exp = oracle.dither(tiles, flags, pal_idx, palettes, True)
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
 def test_dedup_reindex(tiles_flags, oracle, kind):
     from tiler_amd import stages

@@ -18,6 +18,7 @@
 #include <rocprim/device/device_run_length_encode.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <climits>
 #include <vector>
 
@@ -35,7 +36,7 @@ struct Seg {      // per segment state, device resident
   int init_done;
   int64_t cur;    // point index chosen as the newest centroid
   int changed;
-  int pad;
+  int full;       // D = 192: 1 = the sums are rebuilt from scratch this iteration (k_accumulate), 0 = k_assign192 applies +/- deltas
 };
 
 // ---- farthest-first ------------------------------------------------------------------------------------------
@@ -150,6 +151,7 @@ __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_
   sg.kk = 0;
   sg.init_done = 0;
   sg.changed = 0;
+  sg.full = 1;
   if (sg.count <= 0 || k <= 0) {
     sg.init_done = 1;
   } else {
@@ -290,6 +292,148 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
   }
 }
 
+// Assignment step for D = 192, register-tiled: every thread scores PPT points against 16 centroids at a time, so each
+// centroid value fetched from LDS (a wave-wide broadcast) feeds PPT x 3 double-precision operations instead of 3 -- the
+// untiled form is bound by LDS return bandwidth, not by the FP64 pipe.  The arithmetic per (point, centroid) is unchanged:
+// sum over dimensions in order of (p - c)^2, one IEEE operation each.  One workgroup per CU-sized slice of the points
+// (rows_per_block <= 256 * PPT, chosen by the host so that the slices fill the chip evenly); the next 8-dimension chunk is
+// fetched into registers while the current one is being scored.
+// The exact integer sums are carried from iteration to iteration: a point that changes cluster adds its row to the new
+// cluster and subtracts it from the old one (u64 arithmetic: exact and order-free), all threads of the workgroup
+// cooperating on one moved row at a time (coalesced read, one dimension per thread), accumulated in LDS and flushed once.
+constexpr int A_DCH = 8;   // dimensions staged per pass
+template <int PPT>
+__global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
+                                                   int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
+                                                   u64 *__restrict__ sums, u64 *__restrict__ cnts, int rows_per_block, int lds_delta) {
+  constexpr int D = 192, ROWS = 256 * PPT, PITCH = A_DCH + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  double(*s_cent)[KCH] = reinterpret_cast<double(*)[KCH]>(s_raw);                       // [A_DCH][KCH]
+  int32_t *s_pts = reinterpret_cast<int32_t *>(s_raw + A_DCH * KCH * 8);               // [ROWS][PITCH]
+  int32_t *s_moved = s_pts + ROWS * PITCH;                                             // [ROWS][3]: row, old, new
+  u64 *s_delta = reinterpret_cast<u64 *>(s_moved + ROWS * 3 + (ROWS & 1));             // [kk][D+1] when lds_delta
+  __shared__ int s_nmoved;
+  const int seg = blockIdx.y;
+  const Seg sg = segs[seg];
+  const int kk = sg.kk, tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nrows = (int)max((int64_t)0, min((int64_t)rows_per_block, sg.count - row0));
+  if (nrows <= 0) return;
+  if (tid == 0) s_nmoved = 0;
+  if (lds_delta)
+    for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
+  double bd[PPT];
+  int bc[PPT];
+#pragma unroll
+  for (int m = 0; m < PPT; m++) { bd[m] = 0.0; bc[m] = -1; }
+  const int4 zero4 = make_int4(0, 0, 0, 0);
+#pragma unroll 1
+  for (int c0 = 0; c0 < kk; c0 += KCH) {
+    double s[PPT][KCH];
+#pragma unroll
+    for (int m = 0; m < PPT; m++)
+#pragma unroll
+      for (int c = 0; c < KCH; c++) s[m][c] = 0.0;
+    int4 pre[2 * PPT];
+    double pre_c = 0.0;
+    auto fetch = [&](int j0) {  // global -> registers: 2 threads x 16 B per row, 128 rows per slot; one centroid value per thread < 128
+#pragma unroll
+      for (int m = 0; m < 2 * PPT; m++) {
+        const int r = (tid >> 1) + 128 * m;
+        pre[m] = r < nrows ? *reinterpret_cast<const int4 *>(pts + (sg.begin + row0 + r) * D + j0 + (tid & 1) * 4) : zero4;
+      }
+      if (tid < A_DCH * KCH) {
+        const int j = tid / KCH, c = tid - j * KCH;
+        pre_c = c0 + c < kk ? cent[((int64_t)seg * k + c0 + c) * D + j0 + j] : 0.0;
+      }
+    };
+    auto stage = [&]() {  // registers -> LDS
+#pragma unroll
+      for (int m = 0; m < 2 * PPT; m++) {
+        int32_t *dst = s_pts + ((tid >> 1) + 128 * m) * PITCH + (tid & 1) * 4;
+        dst[0] = pre[m].x; dst[1] = pre[m].y; dst[2] = pre[m].z; dst[3] = pre[m].w;
+      }
+      if (tid < A_DCH * KCH) s_cent[tid / KCH][tid % KCH] = pre_c;
+    };
+    fetch(0);
+    __syncthreads();  // previous pass (or the zeroing above) done with the buffers
+    stage();
+    __syncthreads();
+#pragma unroll 1
+    for (int j0 = 0; j0 < D; j0 += A_DCH) {
+      if (j0 + A_DCH < D) fetch(j0 + A_DCH);
+#pragma unroll 2
+      for (int j = 0; j < A_DCH; j++) {
+        double pj[PPT];
+#pragma unroll
+        for (int m = 0; m < PPT; m++) pj[m] = (double)s_pts[(tid + 256 * m) * PITCH + j];
+#pragma unroll
+        for (int c = 0; c < KCH; c += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(&s_cent[j][c]);
+#pragma unroll
+          for (int m = 0; m < PPT; m++) {
+            const double t0 = __dsub_rn(pj[m], cv.x), t1 = __dsub_rn(pj[m], cv.y);
+            s[m][c] = __dadd_rn(s[m][c], __dmul_rn(t0, t0));
+            s[m][c + 1] = __dadd_rn(s[m][c + 1], __dmul_rn(t1, t1));
+          }
+        }
+      }
+      __syncthreads();
+      if (j0 + A_DCH < D) stage();
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < PPT; m++)
+#pragma unroll
+      for (int c = 0; c < KCH; c++)
+        if (c0 + c < kk && (bc[m] < 0 || s[m][c] < bd[m])) { bd[m] = s[m][c]; bc[m] = c0 + c; }
+  }
+  // moved points -> list
+#pragma unroll
+  for (int m = 0; m < PPT; m++) {
+    const int r = tid + 256 * m;
+    if (r >= nrows) continue;
+    const int64_t gi = sg.begin + row0 + r;
+    const int old = assign[gi];
+    if (old == bc[m]) continue;
+    assign[gi] = bc[m];
+    const int slot = atomicAdd(&s_nmoved, 1);
+    s_moved[slot * 3] = r; s_moved[slot * 3 + 1] = old; s_moved[slot * 3 + 2] = bc[m];
+  }
+  __syncthreads();
+  const int nmoved = s_nmoved;
+  if (nmoved == 0) return;
+  if (tid == 0) atomicAdd(&segs[seg].changed, nmoved);
+#pragma unroll 2
+  for (int e = 0; e < nmoved; e++) {  // every thread owns one dimension (thread 192: the weight)
+    const int r = s_moved[e * 3], old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+    const int64_t gi = sg.begin + row0 + r;
+    const long long wi = w ? (long long)w[gi] : 1;
+    if (tid <= D) {
+      const u64 v = tid < D ? (u64)(wi * pts[gi * D + tid]) : (u64)wi;
+      if (lds_delta) {
+        atomicAdd(&s_delta[nw * (D + 1) + tid], v);
+        if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + tid], (u64)0 - v);
+      } else {
+        u64 *base = tid < D ? sums + (int64_t)seg * k * D : cnts + (int64_t)seg * k;
+        const int64_t stride = tid < D ? D : 1, off = tid < D ? tid : 0;
+        atomicAdd(&base[nw * stride + off], v);
+        if (old >= 0) atomicAdd(&base[old * stride + off], (u64)0 - v);
+      }
+    }
+  }
+  if (lds_delta) {
+    __syncthreads();
+    for (int e = tid; e < kk * (D + 1); e += 256) {
+      const u64 v = s_delta[e];
+      if (v == 0) continue;
+      const int c = e / (D + 1), j = e - c * (D + 1);
+      if (j == D) atomicAdd(&cnts[(int64_t)seg * k + c], v);
+      else atomicAdd(&sums[((int64_t)seg * k + c) * D + j], v);
+    }
+  }
+}
+
 // exact integer weighted sums: LDS partials per workgroup for up to KCH_ACC clusters x D, flushed with global atomics
 template <int D>
 __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w,
@@ -336,22 +480,42 @@ __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
+  const bool carry = d == 192;  // k_assign192 keeps the sums current with +/- deltas; the D = 3 path rebuilds them every iteration
   const int64_t total = (int64_t)nseg * k * d;
   for (int64_t e = threadIdx.x; e < total; e += 1024) {
     const int64_t sc = e / d;
     const int seg = (int)(sc / k);
     const u64 cn = cnts[sc];
     if (segs[seg].changed && cn > 0) cent[e] = __ddiv_rn((double)(long long)sums[e], (double)(long long)cn);
-    sums[e] = 0;
+    if (!carry) sums[e] = 0;
   }
   __syncthreads();
   for (int seg = threadIdx.x; seg < nseg; seg += 1024) {
     if (segs[seg].changed) s_any = 1;
     segs[seg].changed = 0;
   }
-  for (int64_t sc = threadIdx.x; sc < (int64_t)nseg * k; sc += 1024) cnts[sc] = 0;
+  if (!carry)
+    for (int64_t sc = threadIdx.x; sc < (int64_t)nseg * k; sc += 1024) cnts[sc] = 0;
   __syncthreads();
   if (threadIdx.x == 0 && s_any == 0 && *quiet_iter < 0) *quiet_iter = it;
+}
+
+template <int PPT>
+static void launch_assign192_t(dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const uint32_t *w, Seg *ds, int k, const double *cent,
+                               int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192<PPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
+  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta);
+}
+static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const uint32_t *w, Seg *ds, int k,
+                             const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+  switch (ppt) {
+    case 1: launch_assign192_t<1>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 2: launch_assign192_t<2>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 3: launch_assign192_t<3>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 4: launch_assign192_t<4>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    default: launch_assign192_t<5>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+  }
 }
 
 // ---- driver ----------------------------------------------------------------------------------------------------
@@ -397,6 +561,24 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   const size_t lds_assign = d > 3 ? (size_t)KCH * DCH * 8 + (size_t)256 * (DCH + 1) * 4 : (size_t)KCH * 3 * 8 + (size_t)16 * k * 4 * 8;
   const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
   const bool fuse3 = d == 3 && (size_t)16 * k * 4 * 8 <= 48 * 1024;
+  // D = 192: slices of the largest segment sized so that one round of workgroups fills the chip evenly
+  int ppt192 = 1, nblk192 = 1, rows192 = 256, lds_delta192 = 0;
+  size_t lds192 = 0;
+  if (d == 192) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int occ = getenv("TM_KM_OCC") ? atoi(getenv("TM_KM_OCC")) : 2;  // workgroups per CU the slices are sized for
+    const int64_t slots = std::max<int64_t>(1, (int64_t)cus * occ / std::max(1, std::min(nseg, cus * occ)));  // workgroups per segment in one round
+    const int64_t per_slot = (maxcount + slots - 1) / slots;
+    const int64_t rounds = (per_slot + 256 * 5 - 1) / (256 * 5);
+    rows192 = (int)std::max<int64_t>(1, (per_slot + rounds - 1) / rounds);
+    ppt192 = (rows192 + 255) / 256;
+    nblk192 = (int)((maxcount + rows192 - 1) / rows192);
+    const size_t fixed = (size_t)A_DCH * KCH * 8 + (size_t)256 * ppt192 * (A_DCH + 1) * 4 + (size_t)(256 * ppt192 * 3 + 1) * 4;
+    lds_delta192 = fixed + (size_t)k * 193 * 8 <= 150 * 1024 ? 1 : 0;
+    lds192 = fixed + (lds_delta192 ? (size_t)k * 193 * 8 : 0) + 16;
+  }
   DevBuf quiet;
   TM_TRY(quiet.alloc(4));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
@@ -413,8 +595,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
           hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
         }
       } else {
-        hipLaunchKernelGGL((k_assign<192, false>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
-        hipLaunchKernelGGL(k_accumulate<192>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192);
       }
       hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
