@@ -36,8 +36,22 @@ struct Seg {      // per segment state, device resident
   int init_done;
   int64_t cur;    // point index chosen as the newest centroid
   int changed;
-  int full;       // D = 192: 1 = the sums are rebuilt from scratch this iteration (k_accumulate), 0 = k_assign192 applies +/- deltas
+  int nseg;       // element 0 only: number of segments
+  int blk_first;  // 1-D grids: first workgroup of this segment and how many it owns (proportional to its size)
+  int blk_count;
 };
+
+// 1-D grid -> (segment, workgroup index inside it, workgroups it owns)
+__device__ __forceinline__ int find_seg(const Seg *__restrict__ segs, int &bx, int &nbx) {
+  int lo = 0, hi = segs[0].nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].blk_first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  bx = (int)blockIdx.x - segs[lo].blk_first;
+  nbx = segs[lo].blk_count;
+  return lo;
+}
 
 // ---- farthest-first ------------------------------------------------------------------------------------------
 // best key: larger mindist wins, then lower index.  mindist can reach 2^38 (D=192), indices 2^31: two words.
@@ -50,14 +64,16 @@ template <int D>
 __global__ __launch_bounds__(256) void k_ff_update(const int32_t *__restrict__ pts, Seg *__restrict__ segs, int k,
                                                    long long *__restrict__ mind, BestKey *__restrict__ partial) {
   __shared__ BestKey s_best[4];
-  const int seg = blockIdx.y;
+  int bx, nbx;
+  const int seg = find_seg(segs, bx, nbx);
+  if (nbx <= 0) return;  // only when every segment is empty
   const Seg sg = segs[seg];
   BestKey mine{0, LLONG_MIN};
   if (!sg.init_done && sg.kk <= k) {
     int32_t c[D];
 #pragma unroll
     for (int j = 0; j < D; j++) c[j] = pts[sg.cur * D + j];  // wave-uniform: scalar loads
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bx * 256 + threadIdx.x; i < sg.count; i += (int64_t)nbx * 256) {
       const int32_t *p = pts + (sg.begin + i) * D;
       long long d = 0;
 #pragma unroll
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(256) void k_ff_update(const int32_t *__restrict__ p
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; w++)
       if (better(s_best[w], mine)) mine = s_best[w];
-    partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+    partial[blockIdx.x] = mine;
   }
 }
 
@@ -86,7 +102,9 @@ __global__ __launch_bounds__(256) void k_ff_update_wide(const int32_t *__restric
                                                         long long *__restrict__ mind, BestKey *__restrict__ partial) {
   __shared__ BestKey s_best[4];
   __shared__ int32_t s_c[256];
-  const int seg = blockIdx.y;
+  int bx, nbx;
+  const int seg = find_seg(segs, bx, nbx);
+  if (nbx <= 0) return;  // only when every segment is empty
   const Seg sg = segs[seg];
   BestKey mine{0, LLONG_MIN};
   const bool active = !sg.init_done && sg.kk <= k;
@@ -94,7 +112,7 @@ __global__ __launch_bounds__(256) void k_ff_update_wide(const int32_t *__restric
     for (int j = threadIdx.x; j < d; j += 256) s_c[j] = pts[sg.cur * d + j];
   __syncthreads();
   if (active) {
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bx * 256 + threadIdx.x; i < sg.count; i += (int64_t)nbx * 256) {
       const int4 *p = reinterpret_cast<const int4 *>(pts + (sg.begin + i) * d);
       long long dd = 0;
       for (int j = 0; j < d / 4; j++) {
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(256) void k_ff_update_wide(const int32_t *__restric
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; w++)
       if (better(s_best[w], mine)) mine = s_best[w];
-    partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+    partial[blockIdx.x] = mine;
   }
 }
 
@@ -130,8 +148,8 @@ __global__ void k_ff_pick(Seg *__restrict__ segs, int nseg, int k, const BestKey
   Seg sg = segs[seg];
   if (sg.init_done) return;
   BestKey best{0, LLONG_MIN};
-  for (int b = 0; b < nblk; b++) {
-    const BestKey c = partial[(int64_t)seg * nblk + b];
+  for (int b = sg.blk_first; b < sg.blk_first + sg.blk_count; b++) {
+    const BestKey c = partial[b];
     if (better(c, best)) best = c;
   }
   if (sg.kk >= k || best.dist <= 0) {  // enough centres, or no distinct point left
@@ -151,7 +169,6 @@ __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_
   sg.kk = 0;
   sg.init_done = 0;
   sg.changed = 0;
-  sg.full = 1;
   if (sg.count <= 0 || k <= 0) {
     sg.init_done = 1;
   } else {
@@ -179,7 +196,9 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
   double *s_cent = s_dyn;
   int32_t *s_pts = reinterpret_cast<int32_t *>(s_dyn + KCH * (D > 3 ? DCH : D));
   u64 *s_acc = reinterpret_cast<u64 *>(s_dyn + KCH * D);
-  const int seg = blockIdx.y;
+  int bx, nbx;
+  const int seg = find_seg(segs, bx, nbx);
+  if (nbx <= 0) return;  // only when every segment is empty
   const Seg sg = segs[seg];
   const int kk = sg.kk;
   int changed = 0;
@@ -187,9 +206,9 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
   if (FUSE_ACC) {
     for (int e = threadIdx.x; e < NCOPY * kk * (D + 1); e += 256) s_acc[e] = 0;
   }
-  const int64_t iters = (sg.count + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+  const int64_t iters = (sg.count + (int64_t)nbx * 256 - 1) / ((int64_t)nbx * 256);
   for (int64_t it = 0; it < iters; it++) {
-    const int64_t base = (it * gridDim.x + blockIdx.x) * 256;
+    const int64_t base = (it * nbx + bx) * 256;
     const int64_t i = base + threadIdx.x;
     const bool valid = i < sg.count;
     double bd = 0.0;
@@ -440,7 +459,9 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
                                                     const Seg *__restrict__ segs, int k, const int32_t *__restrict__ assign,
                                                     u64 *__restrict__ sums, u64 *__restrict__ cnts) {
   extern __shared__ u64 s_acc[];  // [kk][D+1] when it fits, else straight to global
-  const int seg = blockIdx.y;
+  int bx, nbx;
+  const int seg = find_seg(segs, bx, nbx);
+  if (nbx <= 0) return;  // only when every segment is empty
   const Seg sg = segs[seg];
   const int kk = sg.kk;
   const bool use_lds = (size_t)kk * (D + 1) * 8 <= 64 * 1024;
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
     for (int e = threadIdx.x; e < kk * (D + 1); e += 256) s_acc[e] = 0;
     __syncthreads();
   }
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < sg.count; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = bx * 256 + threadIdx.x; i < sg.count; i += (int64_t)nbx * 256) {
     const int c = assign[sg.begin + i];
     const long long wi = w ? (long long)w[sg.begin + i] : 1;
     const int32_t *p = pts + (sg.begin + i) * D;
@@ -533,11 +554,23 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   for (int s = 0; s < nseg; s++) { n = std::max(n, seg_begin[s] + seg_count[s]); maxcount = std::max(maxcount, seg_count[s]); }
   std::vector<Seg> hs(nseg);
   for (int s = 0; s < nseg; s++) { memset(&hs[s], 0, sizeof(Seg)); hs[s].begin = seg_begin[s]; hs[s].count = seg_count[s]; }
-  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((maxcount + 255) / 256, nseg >= 8 ? 64 : 512));
+  // workgroups are shared out in proportion to segment size (about 4 per CU in total), so a large palette does not
+  // leave most of the chip idle while its few workgroups loop
+  int64_t total_pts = 0;
+  for (int s = 0; s < nseg; s++) total_pts += seg_count[s];
+  const int64_t rows_per_blk = std::max<int64_t>(256, (total_pts / 1024 + 255) / 256 * 256);
+  int nblk = 0;
+  for (int s = 0; s < nseg; s++) {
+    hs[s].blk_first = nblk;
+    hs[s].blk_count = (int)((seg_count[s] + rows_per_blk - 1) / rows_per_blk);
+    nblk += hs[s].blk_count;
+  }
+  hs[0].nseg = nseg;
+  nblk = std::max(nblk, 1);
   DevBuf dsegs, mind, partial, sums, cnts, flag;
   TM_TRY(dsegs.alloc(sizeof(Seg) * nseg));
   TM_TRY(mind.alloc(std::max<int64_t>(n, 1) * 8));
-  TM_TRY(partial.alloc(sizeof(BestKey) * (size_t)nseg * nblk));
+  TM_TRY(partial.alloc(sizeof(BestKey) * (size_t)nblk));
   TM_TRY(sums.alloc((size_t)nseg * k * d * 8));
   TM_TRY(cnts.alloc((size_t)nseg * k * 8));
   TM_TRY(flag.alloc(4));
@@ -552,9 +585,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   hipLaunchKernelGGL(k_ff_first, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, pts, d, cent);
   for (int c = 1; c < k; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
     if (d == 3)
-      hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk, nseg), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
+      hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
     else
-      hipLaunchKernelGGL(k_ff_update_wide, dim3(nblk, nseg), dim3(256), 0, stream, pts, d, ds, k, mind.as<long long>(), partial.as<BestKey>());
+      hipLaunchKernelGGL(k_ff_update_wide, dim3(nblk), dim3(256), 0, stream, pts, d, ds, k, mind.as<long long>(), partial.as<BestKey>());
     hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
@@ -589,10 +622,10 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     for (int b = 0; b < batch; b++, issued++) {
       if (d == 3) {
         if (fuse3) {
-          hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
         } else {
-          hipLaunchKernelGGL((k_assign<3, false>), dim3(nblk, nseg), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
-          hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk, nseg), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL((k_assign<3, false>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
         }
       } else {
         launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192);
@@ -746,6 +779,7 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
         sc[p] = i - sb[p];
       }
       TM_CHECK(i == (int64_t)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
+      if (getenv("TM_KM_DEBUG")) { fprintf(stderr, "quantize: %u unique colours, per palette:", nu); for (int p = 0; p < npal; p++) fprintf(stderr, " %lld", (long long)sc[p]); fprintf(stderr, "\n"); }
     }
     TM_TRY(pts.alloc((size_t)std::max<unsigned>(nu, 1) * 12));
     TM_TRY(assign.alloc((size_t)std::max<unsigned>(nu, 1) * 4));
