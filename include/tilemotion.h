@@ -140,6 +140,18 @@ TM_API int tm_stage_features_pal(const void *pal_px, const void *pal_idx, int64_
 /* A6 as used by DoPalettization (:4126,:4160): double DCT with UseLAB, Round()ed to int32 [n][192]. */
 TM_API int tm_stage_features_cluster(const void *tiles, int64_t n, int mode, void *out_i32, void *stream);
 
+/* FrameTilingExtendedPaletteUsage (:1559-1610).
+ * ann_kdtree_short_search_multi(k, eps 0) for a batch: the k nearest database rows of every query by true L2, ordered by
+ * (distance, index); out_idx i32 [nq][k] (-1 pads a database smaller than k), out_err u32 [nq][k]. */
+TM_API int tm_stage_knn_topk(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt, int k, void *out_idx, void *out_err,
+                             void *stream);
+/* The re-rank: every unique tile of knn_idx[q][] x every unique palette of those tiles (tile_pal_idx = PalIdx_Initial),
+ * distance = CompareEuclideanDCTPtr_asm as written (utils.pas:559-725); first strict minimum in ascending (tile, palette)
+ * order.  out_tile / out_pal i32 [nq], out_err u32 [nq].  Blocking (builds and frees the ntiles x npal feature table). */
+TM_API int tm_stage_epu_rerank(const void *queries_i16, int64_t nq, const void *knn_idx, int k, const void *pal_px, const void *tile_pal_idx,
+                               int64_t ntiles, const void *palettes, int npal, int pal_size, void *out_tile, void *out_pal, void *out_err,
+                               void *stream);
+
 /* Motion prediction (PredictMotion :1154-1282 and the redo in Reconstruct :1496-1532).
  * DoDCTs: pvsWeightedDCT features of every 8x8 window of a frame buffer [height][width] u32 0x00BBGGRR
  * -> int16 [(height-7)*(width-7)][192], row-major over window positions. */

@@ -1359,3 +1359,49 @@ double tmo_solve_tile_count(const double *sorted_min_psnr, int64_t ngroups, doub
   if (probes) *probes = n;
   return last;
 }
+
+/* =====================================================================================================================
+ * (f)#3 FrameTilingExtendedPaletteUsage: the k = 64 branch of TFrame.Reconstruct.DoXY (tilingencoder.pas:1559-1610).
+ * knn_idx = the 64 nearest database rows of the query (ann_kdtree_short_search_multi, 1563; -1 pads a short list),
+ * tile_pal_idx = PalIdx_Initial per global tile.  Every unique tile index is tried with every unique palette of the
+ * list, in ascending (tile, palette) order, by the asm distance (CompareEuclideanDCTPtr_asm, quirks included); the first
+ * strict minimum wins.  QuickTestEuclideanDCTPtr_asm (1593) cannot change the outcome (its value is one of the
+ * non-negative terms of the distance).
+ * ===================================================================================================================== */
+static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+
+void tmo_epu_rerank(const int16_t *q, const int32_t *knn_idx, int k, const uint8_t *pal_px, const int32_t *tile_pal_idx, int64_t ntiles,
+                    const int32_t *palettes, int pal_size, int32_t *out_tile, int32_t *out_pal, uint32_t *out_err) {
+  int32_t tiles[64], pals[64];
+  if (k > 64) k = 64;
+  for (int i = 0; i < k; i++) {
+    if (knn_idx[i] >= 0 && knn_idx[i] < ntiles) { tiles[i] = knn_idx[i]; pals[i] = tile_pal_idx[knn_idx[i]]; } /* 1565-1574 */
+    else { tiles[i] = -1; pals[i] = -1; }
+  }
+  qsort(tiles, (size_t)k, sizeof(int32_t), cmp_i32); /* QuickSort + CompareIntegers, 1576-1577: any correct sort of integers */
+  qsort(pals, (size_t)k, sizeof(int32_t), cmp_i32);
+  uint32_t best = UINT32_MAX;
+  int32_t bt = -1, bp = -1, prev_t = -1;
+  for (int ti = 0; ti < k; ti++) {
+    if (tiles[ti] == prev_t) continue; /* also skips the -1 pads of a short list (prev starts at -1): the reference would index FTiles[-1] */
+    int32_t prev_p = -1;
+    for (int pi = 0; pi < k; pi++) {
+      if (pals[pi] == prev_p) continue;
+      float cpn[192];
+      int16_t cur[192];
+      tmo_cpn_from_pal(pal_px + (size_t)tiles[ti] * 64, palettes + (size_t)pals[pi] * pal_size, 0, 0, 0, cpn); /* 1590 */
+      tmo_features_i16(cpn, TMO_PVS_WEIGHTED_DCT, cur);
+      const uint32_t err = tmo_ssd_i16_sse_quirk(q, cur); /* 1595 */
+      if (err < best) { best = err; bt = tiles[ti]; bp = pals[pi]; }
+      prev_p = pals[pi];
+    }
+    prev_t = tiles[ti];
+  }
+  *out_tile = bt; *out_pal = bp; *out_err = best;
+}
+
+void tmo_epu_rerank_batch(const int16_t *q, int64_t nq, const int32_t *knn_idx, int k, const uint8_t *pal_px, const int32_t *tile_pal_idx,
+                          int64_t ntiles, const int32_t *palettes, int pal_size, int32_t *out_tile, int32_t *out_pal, uint32_t *out_err) {
+  for (int64_t i = 0; i < nq; i++)
+    tmo_epu_rerank(q + i * 192, knn_idx + i * k, k, pal_px, tile_pal_idx, ntiles, palettes, pal_size, out_tile + i, out_pal + i, out_err + i);
+}

@@ -141,6 +141,12 @@ void tmo_motion_search(const int16_t *cur /* [tm_h*tm_w][192] */, int tm_w, int 
                        uint32_t *best_err, int8_t *px, int8_t *py);
 double tmo_solve_tile_count(const double *sorted_min_psnr, int64_t ngroups, double target, int *probes);
 
+/* ---- (f)#3 FrameTilingExtendedPaletteUsage re-rank (tilingencoder.pas:1559-1610); knn_idx [nq][k] from tmo_knnk ---- */
+void tmo_epu_rerank(const int16_t *q, const int32_t *knn_idx, int k, const uint8_t *pal_px, const int32_t *tile_pal_idx, int64_t ntiles,
+                    const int32_t *palettes, int pal_size, int32_t *out_tile, int32_t *out_pal, uint32_t *out_err);
+void tmo_epu_rerank_batch(const int16_t *q, int64_t nq, const int32_t *knn_idx, int k, const uint8_t *pal_px, const int32_t *tile_pal_idx,
+                          int64_t ntiles, const int32_t *palettes, int pal_size, int32_t *out_tile, int32_t *out_pal, uint32_t *out_err);
+
 /* ---- (f)#2 checker: LZMA-alone decoder (decoders/htmljs/lzma.js:395-576).  Returns the decoded size or -1;
  * props_out (may be NULL) = {props byte, dictionary size, header size field or -1}. ---- */
 int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *consumed, int *props_out);

@@ -176,6 +176,21 @@ class Oracle:
             nu = self.L.tmo_dedup_u32(_p(rows), n, rows.shape[1], _p(u), _p(rep), _p(order), _p(use_out), _p(remap))
         return int(nu), rep, order[:nu].copy(), use_out[:nu].copy(), remap
 
+    def epu_rerank(self, q, knn_idx, pal_px, tile_pal_idx, palettes):
+        """FrameTilingExtendedPaletteUsage (tilingencoder.pas:1559-1610) -> (tile, pal, err) per query"""
+        q = np.ascontiguousarray(q, np.int16)
+        knn_idx = np.ascontiguousarray(knn_idx, np.int32)
+        pal_px = np.ascontiguousarray(pal_px, np.uint8)
+        tile_pal_idx = np.ascontiguousarray(tile_pal_idx, np.int32)
+        palettes = np.ascontiguousarray(palettes, np.int32)
+        nq = q.shape[0]
+        t, p, e = np.zeros(nq, np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.uint32)
+        self.L.tmo_epu_rerank_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.L.tmo_epu_rerank_batch(_p(q), nq, _p(knn_idx), knn_idx.shape[1], _p(pal_px), _p(tile_pal_idx), pal_px.shape[0], _p(palettes),
+                                    palettes.shape[1], _p(t), _p(p), _p(e))
+        return t, p, e
+
     # ---- motion prediction
     def window_dcts(self, fb):
         fb = np.ascontiguousarray(fb, np.uint32)

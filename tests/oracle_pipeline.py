@@ -15,7 +15,7 @@ def _to_screen(tiles_u32, tm_w, tm_h):
 
 
 def run(oracle, frames, fps=24.0, palette_size=16, palette_count=1, dithering_mode=4, quality_tc=7.0, tile_count=0,
-        max_s=15.0, min_s=1.0, lo=0.8, stop_after=None, timings=None, motion_radius=0):
+        max_s=15.0, min_s=1.0, lo=0.8, stop_after=None, timings=None, motion_radius=0, epu=False):
     import time
     nf, h, w = frames.shape
     tm_w, tm_h = (w - 1) // 8 + 1, (h - 1) // 8 + 1
@@ -120,9 +120,15 @@ def run(oracle, frames, fps=24.0, palette_size=16, palette_count=1, dithering_mo
     t0 = time.time()
     db = oracle.features_pal(pal_px, pal_idx, palettes, 1)
     qf = oracle.features_rgb(tiles, None, 1, False)
-    idx, err = oracle.knn1(qf, db)
+    if epu:  # FrameTilingExtendedPaletteUsage (1559-1610): 64 nearest rows, every unique tile x every unique palette of the list
+        idx64, _ = oracle.knnk(qf, db, 64)
+        idx, epu_pal, err = oracle.epu_rerank(qf, idx64, pal_px, pal_idx, palettes)
+        out.update(knn_idx64=idx64)
+    else:
+        idx, err = oracle.knn1(qf, db)
+        epu_pal = pal_idx[idx]
     tm_tile_r = idx.astype(np.int32).copy()
-    tm_pal = pal_idx[idx].astype(np.int32)
+    tm_pal = epu_pal.astype(np.int32).copy()
     tm_err = err.copy()
     is_pred = np.zeros(q, bool)
     px = pm_x.copy() if mp else np.zeros(q, np.int8)

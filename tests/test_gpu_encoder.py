@@ -21,18 +21,21 @@ def _run_encoder(frames, **settings):
     return enc
 
 
-@pytest.mark.parametrize("shape,pc,radius,tc", [((10, 64, 64), 1, 0, 0), ((6, 52, 100), 3, 0, 0), ((10, 64, 64), 1, 32, 0),
-                                                  ((10, 64, 64), 2, 32, 150), ((7, 52, 100), 3, 5, 300), ((1, 32, 32), 1, 32, 0)])
-def test_run_all_matches_oracle(oracle, shape, pc, radius, tc):
+@pytest.mark.parametrize("shape,pc,radius,tc,epu", [((10, 64, 64), 1, 0, 0, False), ((6, 52, 100), 3, 0, 0, False), ((10, 64, 64), 1, 32, 0, False),
+                                                      ((10, 64, 64), 2, 32, 150, False), ((7, 52, 100), 3, 5, 300, False),
+                                                      ((1, 32, 32), 1, 32, 0, False), ((6, 52, 100), 3, 0, 0, True),
+                                                      ((10, 64, 64), 4, 32, 150, True), ((3, 24, 24), 2, 32, 0, True)])
+def test_run_all_matches_oracle(oracle, shape, pc, radius, tc, epu):
     """radius 0 = motion prediction off (the build's switch); radius > 0 = the reference's default path: PredictMotion,
     the PSNR threshold search of Reduce (tc = a GlobalTilingTileCount small enough to make the search bite), the motion
-    redo and KNN-vs-motion decision of Reconstruct"""
+    redo and KNN-vs-motion decision of Reconstruct; epu = FrameTilingExtendedPaletteUsage (k = 64 x palettes re-rank, the
+    (3, 24, 24) case has fewer than 64 global tiles: the padded list)"""
     from tiler_amd import synth
     from tests import oracle_pipeline
     frames = synth.video(*shape[:1], shape[2], shape[1], cut=4)
-    exp = oracle_pipeline.run(oracle, frames, palette_count=pc, min_s=0.1, motion_radius=radius, tile_count=tc)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=pc, min_s=0.1, motion_radius=radius, tile_count=tc, epu=epu)
     kw = dict(GlobalTilingTileCount=tc) if tc else {}
-    enc = _run_encoder(frames, PaletteCount=pc, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, **kw)
+    enc = _run_encoder(frames, PaletteCount=pc, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, FrameTilingExtendedPaletteUsage=epu, **kw)
     c = enc.counts()
     assert np.array_equal(enc.FrameCorrelations().view(np.uint32), exp["correl"].view(np.uint32))
     assert np.array_equal(enc.KeyFrames(), exp["keyframes"])
@@ -90,7 +93,7 @@ def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path, radius)
     frames = synth.video(10, 64, 48, cut=5)
     path = str(tmp_path / "enc.gtm")
     enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, OutputFileName=path, MotionPredictRadius=radius,
-                       GlobalTilingTileCount=120)
+                       GlobalTilingTileCount=120, FrameTilingExtendedPaletteUsage=False)
     data = open(path, "rb").read()
     hdr, pl = gtm_reader.play(oracle, data)
     assert "PaletteCount=2" in pl.settings and "[Dither]" in pl.settings

@@ -371,3 +371,41 @@ def test_motion_search_quirks_and_ties(oracle):
     torch.cuda.synchronize()
     assert np.array_equal(_host_u32(g[0]), e[0]) and np.array_equal(g[1].cpu().numpy(), e[1]) and np.array_equal(g[2].cpu().numpy(), e[2])
     assert np.all(e[1] == 0) and np.all(e[2] == 0)  # all candidates equal: the tile's own position wins
+
+
+# ---- (f)#3 FrameTilingExtendedPaletteUsage -------------------------------------------------------------------------
+@pytest.mark.parametrize("nt,k", [(700, 64), (40, 64), (300, 5)])
+def test_knn_topk(oracle, nt, k):
+    from tiler_amd import stages
+    rng = np.random.default_rng(nt + k)
+    db = _rand_features(rng, nt, 300)
+    db[5] = db[2]; db[9] = db[2]  # equal distances: (distance, index) order
+    q = _rand_features(rng, 150, 300)
+    q[0] = db[2]
+    eidx, eerr = oracle.knnk(q, db, k)
+    idx, err = stages.knn_topk(_dev(q), _dev(db), k)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(_host_u32(err), eerr)
+
+
+def test_epu_rerank(tiles_flags, oracle):
+    from tiler_amd import stages
+    tiles, flags = tiles_flags
+    rng = np.random.default_rng(77)
+    nt, npal = 150, 5
+    palettes = rng.integers(0, 1 << 24, size=(npal, 16), dtype=np.int32)
+    pal_px = rng.integers(0, 16, size=(nt, 64), dtype=np.uint8)
+    pal_px[40] = pal_px[3]                      # same pixels under different palettes
+    tile_pal = rng.integers(0, npal, size=nt, dtype=np.int32)
+    db = oracle.features_pal(pal_px, tile_pal, palettes, 1)
+    q = oracle.features_rgb(tiles[:200], None, 1, False)
+    idx64, _ = oracle.knnk(q, db, 64)
+    idx64[7, 10:] = -1                           # a padded list
+    idx64[8, :] = idx64[8, 0]                    # a single unique tile
+    et, ep, ee = oracle.epu_rerank(q, idx64, pal_px, tile_pal, palettes)
+    t, p, e = stages.epu_rerank(_dev(q), _dev(idx64), _dev(pal_px), _dev(tile_pal), _dev(palettes))
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), et) and np.array_equal(p.cpu().numpy(), ep)
+    assert np.array_equal(_host_u32(e), ee)
+    assert (ep != tile_pal[et]).any()            # the re-rank does move tiles to other palettes

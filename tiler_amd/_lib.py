@@ -30,6 +30,9 @@ SIGNATURES = {
     "tm_stage_features_cluster": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "tm_stage_window_dcts": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "tm_stage_motion_search": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tm_stage_knn_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "tm_stage_epu_rerank": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
     "tm_stage_knn": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "tm_knn_index_create": (c_void_p, [c_void_p, c_int64, c_void_p]),
     "tm_knn_index_destroy": (None, [c_void_p]),

@@ -46,6 +46,23 @@ int tm_stage_motion_search(const void *cur_i16, int tm_w, int tm_h, const void *
   return launch_motion_search(cur_i16, tm_w, tm_h, window_dcts, radius, out_err, out_px, out_py, (hipStream_t)stream);
 }
 
+int tm_stage_knn_topk(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt, int k, void *out_idx, void *out_err, void *stream) {
+  TM_TRY(require_device());
+  return launch_knn_topk(queries_i16, nq, db_i16, nt, k, out_idx, out_err, (hipStream_t)stream);
+}
+
+int tm_stage_epu_rerank(const void *queries_i16, int64_t nq, const void *knn_idx, int k, const void *pal_px, const void *tile_pal_idx,
+                        int64_t ntiles, const void *palettes, int npal, int pal_size, void *out_tile, void *out_pal, void *out_err,
+                        void *stream) {
+  TM_TRY(require_device());
+  DevBuf table;
+  TM_TRY(table.alloc((size_t)std::max<int64_t>(ntiles, 1) * npal * 384));
+  TM_TRY(launch_features_table(pal_px, ntiles, palettes, npal, pal_size, table.p, (hipStream_t)stream));
+  TM_TRY(launch_epu_rerank(queries_i16, nq, knn_idx, k, tile_pal_idx, ntiles, npal, table.p, out_tile, out_pal, out_err, (hipStream_t)stream));
+  TM_HIP(hipStreamSynchronize((hipStream_t)stream));  // the table is freed on return
+  return TM_OK;
+}
+
 tm_knn_index *tm_knn_index_create(const void *db_i16, int64_t nt, void *stream) {
   tm_knn_index_impl *ix = nullptr;
   if (knn_index_create(db_i16, nt, (hipStream_t)stream, &ix) != TM_OK) return nullptr;

@@ -408,6 +408,39 @@ static int step_reconstruct(tm_encoder *e) {
   // Many dithered tiles are byte-identical (Reindex merges them later, MakeTilesUnique(False) at 2014).  Under the
   // lowest-index tie rule the nearest neighbour among ALL rows is the nearest among the DISTINCT rows taken in order of
   // their first occurrence, so only those are searched; indices are mapped back afterwards.
+  const int64_t per = e->tm_size();
+  const int sf = std::max(0, std::min(e->shard_first, e->nframes));
+  const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
+  if (sf > 0 || sn < e->nframes) {  // frames of other shards: TileIdx -1 / err $FFFFFFFF so an all-reduce(MAX) merges shards
+    TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
+  }
+  e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0;
+  const bool epu = e->s.FrameTilingExtendedPaletteUsage;
+  if (epu) {
+    // FrameTilingExtendedPaletteUsage (1559-1610): the 64 nearest rows of the whole database (duplicates included, as
+    // ann_kdtree_short_search_multi sees them), then every unique tile x every unique palette of that list, scored against a
+    // table of all (tile, palette) feature vectors
+    DevBuf table, idx64, err64;
+    const int npal = e->s.PaletteCount;
+    TM_TRY(table.alloc((size_t)e->t * npal * 384));
+    TM_TRY(launch_features_table(e->gpal_px.p, e->t, e->palettes_dev.p, npal, e->s.PaletteSize, table.p, e->stream));
+    progress(e, TM_STEP_RECONSTRUCT, 1, 2);
+    const int chunk_frames = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(sn, 1), ((int64_t)2 << 30) / (per * 384)));
+    TM_TRY(qf.alloc((size_t)chunk_frames * per * 384));
+    TM_TRY(idx64.alloc((size_t)chunk_frames * per * 64 * 4));
+    TM_TRY(err64.alloc((size_t)chunk_frames * per * 64 * 4));
+    for (int f0 = sf; f0 < sf + sn; f0 += chunk_frames) {
+      const int nf = std::min(chunk_frames, sf + sn - f0);
+      const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
+      TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
+      TM_TRY(launch_knn_topk(qf.p, n, db.p, e->t, 64, idx64.p, err64.p, e->stream));
+      TM_TRY(launch_epu_rerank(qf.p, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
+                               e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream));
+    }
+    TM_HIP(hipStreamSynchronize(e->stream));
+  } else {
   DevBuf u_remap, u_order, u_use, udb;
   TM_TRY(u_remap.alloc((size_t)e->t * 4)); TM_TRY(u_order.alloc((size_t)e->t * 4)); TM_TRY(u_use.alloc((size_t)e->t * 4));
   int64_t nu = 0;
@@ -421,14 +454,6 @@ static int step_reconstruct(tm_encoder *e) {
   TM_TRY(knn_index_create(udb.p, nu, e->stream, &ix));
   progress(e, TM_STEP_RECONSTRUCT, 1, 2);
   // query features in frame chunks (bounded scratch for long / 4K clips: streaming through HBM)
-  const int64_t per = e->tm_size();
-  const int sf = std::max(0, std::min(e->shard_first, e->nframes));
-  const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
-  if (sf > 0 || sn < e->nframes) {  // frames of other shards: TileIdx -1 / err $FFFFFFFF so an all-reduce(MAX) merges shards
-    TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
-    TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
-  }
-  e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0;
   int chunk_frames = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(sn, 1), ((int64_t)8 << 30) / (per * 384)));
   int rc = qf.alloc((size_t)chunk_frames * per * 384);
   for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
@@ -448,6 +473,7 @@ static int step_reconstruct(tm_encoder *e) {
   hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
                      e->tm_pal.as<int32_t>());  // TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial (1551)
   TM_HIP(hipGetLastError());
+  }
   if (e->has_pm) {
     // motion branch (1496-1532, 1612-1654): frames in order, each searched in the previous RECONSTRUCTED frame; a key
     // frame's first frame has no motion candidate, so key-frame groups are independent chains.
@@ -478,7 +504,7 @@ static int step_reconstruct(tm_encoder *e) {
         TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, mp.p, e->tm_px.as<int8_t>() + off,
                                     e->tm_py.as<int8_t>() + off, e->stream));
       }
-      TM_TRY(launch_recon_decide(e->tm_w, (int)per, search ? mp.p : nullptr, e->fflags.as<uint8_t>() + off, e->gpal_idx.p, e->gpal_px.p,
+      TM_TRY(launch_recon_decide(e->tm_w, (int)per, epu ? 1 : 0, search ? mp.p : nullptr, e->fflags.as<uint8_t>() + off, e->gpal_idx.p, e->gpal_px.p,
                                  e->palettes_dev.p, e->s.PaletteSize, fb[cb].p, fb[cb ^ 1].p, e->tm_tile.as<int32_t>() + off,
                                  e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->tm_px.as<int8_t>() + off,
                                  e->tm_py.as<int8_t>() + off, e->tm_pred.as<uint8_t>() + off, e->stream));
@@ -849,6 +875,7 @@ int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
 int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial for every item
   TM_CHECK(e, TM_E_INVAL, "null encoder");
   TM_TRY(need(e, TM_STEP_RECONSTRUCT, "Reconstruct"));
+  if (e->s.FrameTilingExtendedPaletteUsage) return TM_OK;  // the item's palette is the re-rank's choice: merged like TileIdx (array 2)
   TM_HIP(hipSetDevice(e->device));
   hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(),
                      e->tm_pal.as<int32_t>());

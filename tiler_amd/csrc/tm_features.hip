@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
 // registers; the 3x64 component planes live in LDS and are read as wave-wide broadcasts.
 // SRC: 0 = RGB tiles, 1 = palette-index tiles through their palette, 2 = every 8x8 window of a frame buffer
 // (PredictMotion.DoDCTs / Reconstruct.DoDCTs, tilingencoder.pas:1157-1182, 1437-1462: `tiles` is the buffer, pal_size its
-// width in pixels, tile t = window at (t mod (width-7), t div (width-7))).
+// width in pixels, tile t = window at (t mod (width-7), t div (width-7))), 3 = every palette-index tile under every palette
+// (row t = tile t div P under palette t mod P, P passed in use_lab: the vectors 1590-1591 recompute per query).
 template <int SRC>
 __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ pal_px,
                                                       const int32_t *__restrict__ pal_idx, const int32_t *__restrict__ palettes,
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
       uint32_t col;
       if (SRC == 1) {
         col = (uint32_t)palettes[(int64_t)pal_idx[t] * pal_size + pal_px[t * 64 + src]];
+      } else if (SRC == 3) {
+        const int64_t tile = t / use_lab;
+        col = (uint32_t)palettes[(t - tile * use_lab) * pal_size + pal_px[tile * 64 + src]];
       } else if (SRC == 2) {
         const int ww = pal_size - 7;
         const int64_t wy = t / ww, wx = t - wy * ww;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         col = tiles[t * 64 + src];
       }
       float yy, uu, vv;
-      if (use_lab)
+      if (use_lab && SRC != 3)
         rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
       else
         rgb_to_yuv(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, yy, uu, vv);
@@ -304,6 +308,19 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
   hipLaunchKernelGGL(k_features_i16<1>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
                      (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_features_table(const void *pal_px, int64_t ntiles, const void *palettes, int npal, int pal_size, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(pal_size >= 1 && pal_size <= 256 && npal >= 1, TM_E_INVAL, "bad palette shape %d x %d", npal, pal_size);
+  const int64_t n = ntiles * npal;
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_i16<3>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px, nullptr,
+                     (const int32_t *)palettes, pal_size, nullptr, n, 1, npal, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights,
+                     tab->snake, tab->srgb_lut, (int16_t *)out);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

@@ -16,6 +16,12 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
 int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream);
+int launch_features_table(const void *pal_px, int64_t ntiles, const void *palettes, int npal, int pal_size, void *out, hipStream_t stream);
+
+// tm_epu.hip: FrameTilingExtendedPaletteUsage (tilingencoder.pas:1559-1610)
+int launch_knn_topk(const void *queries, int64_t nq, const void *db, int64_t nt, int k, void *out_idx, void *out_err, hipStream_t stream);
+int launch_epu_rerank(const void *queries, int64_t nq, const void *knn_idx, int k, const void *tile_pal, int64_t ntiles, int npal,
+                      const void *table, void *out_tile, void *out_pal, void *out_err, hipStream_t stream);
 
 // tm_knn.hip
 struct tm_knn_index_impl;
@@ -40,7 +46,7 @@ int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t 
 int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, int radius, void *best_err, void *px, void *py,
                          hipStream_t stream);
 int launch_tiles_to_screen(const void *tiles, const void *flags, int tm_w, int tm_h, void *screen, hipStream_t stream);
-int launch_recon_decide(int tm_w, int per, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
+int launch_recon_decide(int tm_w, int per, int pal_from_map, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
                         const void *palettes, int pal_size, const void *back, void *front, void *tm_tile, void *tm_pal, void *tm_err,
                         const void *px, const void *py, void *pred, hipStream_t stream);
 int solve_tile_count(const void *group, int64_t ngroups, const void *pm_err, const void *frame_is_kf, int per, int64_t q, double target,

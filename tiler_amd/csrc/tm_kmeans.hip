@@ -665,9 +665,22 @@ int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, in
 }
 
 // ---- DoPalettization -------------------------------------------------------------------------------------------
-__global__ void k_count_assign(const int32_t *__restrict__ assign, int64_t n, u64 *__restrict__ cnt) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&cnt[assign[i]], 1ull);
+__global__ void k_count_assign(const int32_t *__restrict__ assign, int64_t n, int k, u64 *__restrict__ cnt) {
+  extern __shared__ unsigned int s_cnt[];  // per-workgroup histogram when k fits (a handful of hot global counters would serialise)
+  const bool use_lds = k <= 8192;
+  if (use_lds) {
+    for (int e = threadIdx.x; e < k; e += blockDim.x) s_cnt[e] = 0;
+    __syncthreads();
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (use_lds) atomicAdd(&s_cnt[assign[i]], 1u);
+    else atomicAdd(&cnt[assign[i]], 1ull);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < k; e += blockDim.x)
+      if (s_cnt[e]) atomicAdd(&cnt[e], (u64)s_cnt[e]);
+  }
 }
 __global__ void k_apply_lut(const int32_t *__restrict__ assign, int64_t n, const int32_t *__restrict__ lut, int32_t *__restrict__ out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = lut[assign[i]];
@@ -686,8 +699,8 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
   // palettes ranked by number of tiles, descending (tilingencoder.pas:4229-4234); ties keep the initial order
   TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)npal * 8, stream));
-  hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, assign.as<int32_t>(), n,
-                     cnt.as<u64>());
+  hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 512)), dim3(256), npal <= 8192 ? (size_t)npal * 4 : 0, stream,
+                     assign.as<int32_t>(), n, npal, cnt.as<u64>());
   std::vector<u64> hc(npal);
   TM_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)npal * 8, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
@@ -711,6 +724,16 @@ __global__ void k_pixel_keys(const uint32_t *__restrict__ tiles, const int32_t *
     const u64 p = (u64)(uint32_t)pal_idx[i >> 6];
     keys[i] = (p << 24) | ((u64)((c >> 8) & 0xff) << 16) | ((u64)(c & 0xff) << 8) | (u64)((c >> 16) & 0xff);
   }
+}
+__global__ void k_palette_bounds(const u64 *__restrict__ ukeys, int64_t nu, int npal, long long *__restrict__ lb) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // lb[p] = first unique key whose palette field is >= p; lb[npal] = first >= npal
+  if (p > npal) return;
+  int64_t lo = 0, hi = nu;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((long long)(ukeys[mid] >> 24) < (long long)p) lo = mid + 1; else hi = mid;
+  }
+  lb[p] = lo;
 }
 __global__ void k_unpack_colours(const u64 *__restrict__ ukeys, int64_t nu, int32_t *__restrict__ pts) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
@@ -766,19 +789,17 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
     unsigned int nu = 0;
     TM_HIP(hipMemcpyAsync(&nu, nruns.p, 4, hipMemcpyDeviceToHost, stream));
     TM_HIP(hipStreamSynchronize(stream));
-    // segment boundaries per palette: binary search on the host copy of the unique keys' palette field
-    std::vector<u64> hk(nu);
-    TM_HIP(hipMemcpyAsync(hk.data(), ukeys.p, (size_t)nu * 8, hipMemcpyDeviceToHost, stream));
+    // segment boundaries per palette: lower bound of each palette number in the sorted unique keys, found on the device
+    DevBuf dlb;
+    TM_TRY(dlb.alloc((size_t)(npal + 1) * 8));
+    hipLaunchKernelGGL(k_palette_bounds, dim3((npal + 1 + 63) / 64), dim3(64), 0, stream, ukeys.as<u64>(), (int64_t)nu, npal, dlb.as<long long>());
+    std::vector<long long> lb((size_t)npal + 1);
+    TM_HIP(hipMemcpyAsync(lb.data(), dlb.p, lb.size() * 8, hipMemcpyDeviceToHost, stream));
     TM_HIP(hipStreamSynchronize(stream));
     std::vector<int64_t> sb(npal, 0), sc(npal, 0);
     {
-      int64_t i = 0;
-      for (int p = 0; p < npal; p++) {
-        sb[p] = i;
-        while (i < (int64_t)nu && (int)(hk[i] >> 24) == p) i++;
-        sc[p] = i - sb[p];
-      }
-      TM_CHECK(i == (int64_t)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
+      for (int p = 0; p < npal; p++) { sb[p] = lb[p]; sc[p] = lb[p + 1] - lb[p]; }
+      TM_CHECK(lb[npal] == (long long)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
       if (getenv("TM_KM_DEBUG")) { fprintf(stderr, "quantize: %u unique colours, per palette:", nu); for (int p = 0; p < npal; p++) fprintf(stderr, " %lld", (long long)sc[p]); fprintf(stderr, "\n"); }
     }
     TM_TRY(pts.alloc((size_t)std::max<unsigned>(nu, 1) * 12));

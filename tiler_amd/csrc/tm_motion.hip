@@ -145,7 +145,8 @@ __global__ void k_tiles_to_screen(const uint32_t *__restrict__ tiles, const uint
 }
 
 // Reconstruct.DoXY after both searches (1534-1654), one wave per tile-map item, lane = pixel
-__global__ __launch_bounds__(64) void k_recon_decide(int tm_w, int per, const uint32_t *__restrict__ mp_err /* null: key frame start */,
+__global__ __launch_bounds__(64) void k_recon_decide(int tm_w, int per, int pal_from_map /* EPU: the item's own PalIdx, not the tile's */,
+                                                     const uint32_t *__restrict__ mp_err /* null: key frame start */,
                                                      const uint8_t *__restrict__ fflags, const int32_t *__restrict__ gpal_idx,
                                                      const uint8_t *__restrict__ gpal_px, const int32_t *__restrict__ palettes, int pal_size,
                                                      const uint32_t *__restrict__ back, uint32_t *__restrict__ front,
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64) void k_recon_decide(int tm_w, int per, const ui
   int32_t tile = tm_tile[i];
   const uint32_t knn = (perfect || tile < 0) ? 0xffffffffu : tm_err[i];
   if (perfect) tile = -1;
-  const int32_t pal = tile >= 0 ? gpal_idx[tile] : -1;
+  const int32_t pal = tile >= 0 ? (pal_from_map ? tm_pal[i] : gpal_idx[tile]) : -1;
   const int64_t diff = (int64_t)knn - (int64_t)mp;
   const bool knn_best = (diff > 192 || diff < -192) && knn < mp;  // CompareValue(knnErr, mpErr, cTileDCTSize) = LessThanValue
   const int sy = i / tm_w, sx = i - sy * tm_w, sw = tm_w * 8;
@@ -236,10 +237,10 @@ int launch_tiles_to_screen(const void *tiles, const void *flags, int tm_w, int t
   return TM_OK;
 }
 
-int launch_recon_decide(int tm_w, int per, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
+int launch_recon_decide(int tm_w, int per, int pal_from_map, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
                         const void *palettes, int pal_size, const void *back, void *front, void *tm_tile, void *tm_pal, void *tm_err,
                         const void *px, const void *py, void *pred, hipStream_t stream) {
-  hipLaunchKernelGGL(k_recon_decide, dim3(per), dim3(64), 0, stream, tm_w, per, (const uint32_t *)mp_err, (const uint8_t *)fflags,
+  hipLaunchKernelGGL(k_recon_decide, dim3(per), dim3(64), 0, stream, tm_w, per, pal_from_map, (const uint32_t *)mp_err, (const uint8_t *)fflags,
                      (const int32_t *)gpal_idx, (const uint8_t *)gpal_px, (const int32_t *)palettes, pal_size, (const uint32_t *)back,
                      (uint32_t *)front, (int32_t *)tm_tile, (int32_t *)tm_pal, (uint32_t *)tm_err, (const int8_t *)px, (const int8_t *)py,
                      (uint8_t *)pred);

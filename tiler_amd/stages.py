@@ -73,6 +73,26 @@ def motion_search(cur, tm_w, tm_h, win, radius):
     return err, px, py
 
 
+def knn_topk(queries, db, k=64):
+    """ann_kdtree_short_search_multi (tilingencoder.pas:1563) for every query -> (idx int32 [nq][k], err int32-as-uint32 [nq][k])"""
+    nq = queries.shape[0]
+    idx = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+    err = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+    check(lib().tm_stage_knn_topk(_p(queries), nq, _p(db), db.shape[0], k, _p(idx), _p(err), _stream()))
+    return idx, err
+
+
+def epu_rerank(queries, knn_idx, pal_px, tile_pal_idx, palettes):
+    """FrameTilingExtendedPaletteUsage re-rank (tilingencoder.pas:1576-1610) -> (tile int32, pal int32, err int32-as-uint32)"""
+    nq = queries.shape[0]
+    t = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    p = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    e = torch.empty((nq,), dtype=torch.int32, device=queries.device)
+    check(lib().tm_stage_epu_rerank(_p(queries), nq, _p(knn_idx), knn_idx.shape[1], _p(pal_px), _p(tile_pal_idx), pal_px.shape[0],
+                                    _p(palettes), palettes.shape[0], palettes.shape[1], _p(t), _p(p), _p(e), _stream()))
+    return t, p, e
+
+
 def knn(queries, db):
     """ann_kdtree_short_search(eps=0) for every query (tilingencoder.pas:1547) -> (idx int32, err int32-as-uint32)"""
     nq, nt = queries.shape[0], db.shape[0]
