@@ -1383,7 +1383,7 @@ void tmo_epu_rerank(const int16_t *q, const int32_t *knn_idx, int k, const uint8
   uint32_t best = UINT32_MAX;
   int32_t bt = -1, bp = -1, prev_t = -1;
   for (int ti = 0; ti < k; ti++) {
-    if (tiles[ti] == prev_t) continue; /* also skips the -1 pads of a short list (prev starts at -1): the reference would index FTiles[-1] */
+    if (tiles[ti] == prev_t) continue; /* also skips the -1 pads of a short list: prevTileIdx starts at -1 (1582) */
     int32_t prev_p = -1;
     for (int pi = 0; pi < k; pi++) {
       if (pals[pi] == prev_p) continue;

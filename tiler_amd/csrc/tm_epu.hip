@@ -149,8 +149,8 @@ __global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ q
     const int ti = o / nup, pi = o - ti * nup;
     const int32_t tile = s_ut[ti], pal = s_up[pi];
     uint32_t acc = 0;
-    // tile -1 / palette -1 entries are part of the reference's lists too (1572-1573) and would index FTiles[-1]; they only
-    // appear when the database has fewer than k rows, and are skipped here
+    // -1 entries (1572-1573: the pads of a database with fewer than k rows) sort first and are skipped by the reference's
+    // `<> prevTileIdx` / `<> prevPalIdx` tests, which start at -1 (1582-1588)
     const bool ok = tile >= 0 && pal >= 0;
     if (ok) {
       const uint4 *pb = reinterpret_cast<const uint4 *>(table + ((int64_t)tile * npal + pal) * 192) + j8 * 3;
