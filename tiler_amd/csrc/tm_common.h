@@ -42,6 +42,14 @@ const char *get_error();
 // Fails loudly when no gfx950 device can run the kernels (there is no CPU path).
 int require_device();
 
+// Device memory pool: hipMalloc / hipFree of the pipeline's multi-GB temporaries cost ~16 ms per 720p clip (and hipFree
+// synchronises the device), so freed blocks are kept per host thread and handed out again.  A thread drives its encoder on
+// one stream, so reuse is stream-ordered; blocks never migrate between threads.  pool_trim() returns everything to the
+// driver (called when an encoder is destroyed, and automatically when an allocation fails).
+int pool_alloc(void **p, size_t *bytes_inout);
+void pool_free(void *p, size_t bytes);
+void pool_trim();
+
 // RAII device buffer
 struct DevBuf {
   void *p = nullptr;
@@ -56,7 +64,7 @@ struct DevBuf {
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) pool_free(p, bytes);
     p = nullptr;
     bytes = 0;
   }
@@ -64,13 +72,10 @@ struct DevBuf {
     if (n <= bytes && p) return TM_OK;
     release();
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) {
-      p = nullptr;
-      set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
-      return TM_E_NOMEM;
-    }
-    bytes = n;
+    size_t got = n;
+    const int rc = pool_alloc(&p, &got);
+    if (rc != TM_OK) { p = nullptr; return rc; }
+    bytes = got;
     return TM_OK;
   }
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }

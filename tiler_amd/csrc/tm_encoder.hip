@@ -621,7 +621,10 @@ tm_encoder *tm_create(void) {
   return e;
 }
 
-void tm_destroy(tm_encoder *e) { delete e; }
+void tm_destroy(tm_encoder *e) {
+  delete e;
+  pool_trim();  // the calling thread's cached device blocks go back to the driver with the encoder
+}
 
 int tm_set_device(tm_encoder *e, int device) {
   TM_CHECK(e, TM_E_INVAL, "null encoder");

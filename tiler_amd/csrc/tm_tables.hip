@@ -1,5 +1,7 @@
 // tm_tables.hip -- constant tables of the reference + LUT construction, error state, device check.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 #include "tm_common.h"
@@ -15,6 +17,75 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 const char *get_error() { return g_err; }
+
+// ---- device memory pool (see tm_common.h) --------------------------------------------------------------------------
+namespace {
+struct PoolBlock { void *p; size_t bytes; int device; };
+struct Pool {
+  std::vector<PoolBlock> blocks;
+  size_t held = 0;
+  ~Pool() { for (auto &b : blocks) (void)hipFree(b.p); }
+};
+thread_local Pool t_pool;
+size_t pool_cap() {
+  static const size_t cap = [] {
+    const char *e = getenv("TM_POOL_GIB");
+    return (size_t)(e ? atof(e) : 96.0) * ((size_t)1 << 30);
+  }();
+  return cap;
+}
+}  // namespace
+
+void pool_trim() {
+  for (auto &b : t_pool.blocks) (void)hipFree(b.p);
+  t_pool.blocks.clear();
+  t_pool.held = 0;
+}
+
+int pool_alloc(void **p, size_t *bytes) {
+  // size classes: multiples of 1/8 of the next power of two below the size (at most 12.5 % slack), 256-byte floor
+  size_t n = std::max<size_t>(*bytes, 256);
+  size_t step = 256;
+  while (step * 16 <= n) step <<= 1;
+  n = (n + step - 1) / step * step;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int best = -1;
+  for (int i = 0; i < (int)t_pool.blocks.size(); i++) {
+    const PoolBlock &b = t_pool.blocks[i];
+    if (b.device == dev && b.bytes >= n && b.bytes <= n + n / 4 && (best < 0 || b.bytes < t_pool.blocks[best].bytes)) best = i;
+  }
+  if (best >= 0) {
+    *p = t_pool.blocks[best].p;
+    *bytes = t_pool.blocks[best].bytes;
+    t_pool.held -= t_pool.blocks[best].bytes;
+    t_pool.blocks.erase(t_pool.blocks.begin() + best);
+    return TM_OK;
+  }
+  hipError_t e = hipMalloc(p, n);
+  if (e != hipSuccess) {  // give the pooled memory back and try once more
+    (void)hipGetLastError();
+    pool_trim();
+    e = hipMalloc(p, n);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *p = nullptr;
+    set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+    return TM_E_NOMEM;
+  }
+  *bytes = n;
+  return TM_OK;
+}
+
+void pool_free(void *p, size_t bytes) {
+  if (!p) return;
+  if (t_pool.held + bytes > pool_cap()) { (void)hipFree(p); return; }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  t_pool.blocks.push_back({p, bytes, dev});
+  t_pool.held += bytes;
+}
 
 int require_device() {
   int n = 0;
