@@ -819,7 +819,7 @@ int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int 
     cur = bi;
   }
   free(mind);
-  /* Lloyd: double distances summed in dimension order, ties -> lowest centroid; exact integer weighted sums */
+  /* Lloyd: double distances accumulated in dimension order with a fused multiply-add, ties -> lowest centroid; exact integer weighted sums */
   int64_t *sum = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk * d);
   int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk);
   for (int64_t i = 0; i < n; i++) assign[i] = -1;
@@ -835,7 +835,7 @@ int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int 
         double s = 0;
         for (int j = 0; j < d; j++) {
           double t = (double)pts[i * d + j] - cent[(size_t)c * d + j];
-          s = s + t * t;
+          s = fma(t, t, s); /* one fused multiply-add per dimension (the build's rule) */
         }
         if (bc < 0 || s < bd) { bd = s; bc = c; }
       }

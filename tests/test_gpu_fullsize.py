@@ -211,9 +211,9 @@ def test_kmeans_fixed_point_at_full_size(n, d, k):
         for s in range(0, n, 1 << 18):
             p = pts[s:s + (1 << 18)].to(torch.float64)
             dist = torch.zeros((p.shape[0], k), dtype=torch.float64, device="cuda")
-            for j in range(d):  # dimension order matters for the rounding of the running sum
+            for j in range(d):  # dimension order matters for the rounding of the running sum; the build's rule fuses multiply and add
                 diff = p[:, j:j + 1] - cent[None, :, j]
-                dist += diff * diff
+                dist = torch.addcmul(dist, diff, diff)
             best = dist.min(1).values
             first = (dist == best[:, None]).to(torch.uint8).argmax(1)
             assert torch.equal(first, a64[s:s + (1 << 18)])

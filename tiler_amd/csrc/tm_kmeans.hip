@@ -230,12 +230,12 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
             for (int j = 0; j < 3; j++) {
               const double pj = (double)p3[j];
 #pragma unroll
-              for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+              for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __fma_rn(t, t, s[c]); }
             }
           } else {
             for (int j = 0; j < 3; j++) {
               const double pj = (double)p3[j];
-              for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+              for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __fma_rn(t, t, s[c]); }
             }
           }
         }
@@ -262,12 +262,12 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
               for (int j = 0; j < DCH; j++) {
                 const double pj = (double)pr[j];
 #pragma unroll
-                for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+                for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __fma_rn(t, t, s[c]); }
               }
             } else {
               for (int j = 0; j < DCH; j++) {
                 const double pj = (double)pr[j];
-                for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __dadd_rn(s[c], __dmul_rn(t, t)); }
+                for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __fma_rn(t, t, s[c]); }
               }
             }
           }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
 // Assignment step for D = 192, register-tiled: every thread scores PPT points against 16 centroids at a time, so each
 // centroid value fetched from LDS (a wave-wide broadcast) feeds PPT x 3 double-precision operations instead of 3 -- the
 // untiled form is bound by LDS return bandwidth, not by the FP64 pipe.  The arithmetic per (point, centroid) is unchanged:
-// sum over dimensions in order of (p - c)^2, one IEEE operation each.  One workgroup per CU-sized slice of the points
+// sum over dimensions in order of (p - c)^2, one IEEE subtraction and one fused multiply-add each.  One workgroup per CU-sized slice of the points
 // (rows_per_block <= 256 * PPT, chosen by the host so that the slices fill the chip evenly); the next 8-dimension chunk is
 // fetched into registers while the current one is being scored.
 // The exact integer sums are carried from iteration to iteration: a point that changes cluster adds its row to the new
@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
 // cooperating on one moved row at a time (coalesced read, one dimension per thread), accumulated in LDS and flushed once.
 constexpr int A_DCH = 8;   // dimensions staged per pass
 template <int PPT>
-__global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
+__global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
+                                                   const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                    int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
                                                    u64 *__restrict__ sums, u64 *__restrict__ cnts, int rows_per_block, int lds_delta) {
   constexpr int D = 192, ROWS = 256 * PPT, PITCH = A_DCH + 1;
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
 #pragma unroll
       for (int m = 0; m < 2 * PPT; m++) {
         const int r = (tid >> 1) + 128 * m;
-        pre[m] = r < nrows ? *reinterpret_cast<const int4 *>(pts + (sg.begin + row0 + r) * D + j0 + (tid & 1) * 4) : zero4;
+        // chunk-major copy [j0 / 8][point][8]: the workgroup's rows of one chunk are one contiguous block (row-major pts would
+        // give 32 useful bytes per 128-byte line and re-fetch every line four times over the 24 chunks)
+        pre[m] = r < nrows ? *reinterpret_cast<const int4 *>(pts_chunked + ((int64_t)(j0 / A_DCH) * n_total + sg.begin + row0 + r) * A_DCH + (tid & 1) * 4) : zero4;
       }
       if (tid < A_DCH * KCH) {
         const int j = tid / KCH, c = tid - j * KCH;
@@ -392,8 +395,8 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
 #pragma unroll
           for (int m = 0; m < PPT; m++) {
             const double t0 = __dsub_rn(pj[m], cv.x), t1 = __dsub_rn(pj[m], cv.y);
-            s[m][c] = __dadd_rn(s[m][c], __dmul_rn(t0, t0));
-            s[m][c + 1] = __dadd_rn(s[m][c + 1], __dmul_rn(t1, t1));
+            s[m][c] = __fma_rn(t0, t0, s[m][c]);
+            s[m][c + 1] = __fma_rn(t1, t1, s[m][c + 1]);
           }
         }
       }
@@ -450,6 +453,15 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
       if (j == D) atomicAdd(&cnts[(int64_t)seg * k + c], v);
       else atomicAdd(&sums[((int64_t)seg * k + c) * D + j], v);
     }
+  }
+}
+
+__global__ void k_chunk_major(const int32_t *__restrict__ pts, int64_t n, int32_t *__restrict__ out) {  // [n][192] -> [24][n][8]
+  const int64_t total = n * 48;  // int4 elements
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / 48;
+    const int v = (int)(e - i * 48), ch = v >> 1, half = v & 1;
+    reinterpret_cast<int4 *>(out)[((int64_t)ch * n + i) * 2 + half] = reinterpret_cast<const int4 *>(pts)[e];
   }
 }
 
@@ -522,20 +534,20 @@ __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int
 }
 
 template <int PPT>
-static void launch_assign192_t(dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const uint32_t *w, Seg *ds, int k, const double *cent,
-                               int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+static void launch_assign192_t(dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w, Seg *ds,
+                               int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192<PPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
-  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta);
+  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta);
 }
-static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const uint32_t *w, Seg *ds, int k,
-                             const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w,
+                             Seg *ds, int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
   switch (ppt) {
-    case 1: launch_assign192_t<1>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 2: launch_assign192_t<2>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 3: launch_assign192_t<3>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 4: launch_assign192_t<4>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    default: launch_assign192_t<5>(grid, lds, stream, pts, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 1: launch_assign192_t<1>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 2: launch_assign192_t<2>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 3: launch_assign192_t<3>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 4: launch_assign192_t<4>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    default: launch_assign192_t<5>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
   }
 }
 
@@ -597,7 +609,10 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   // D = 192: slices of the largest segment sized so that one round of workgroups fills the chip evenly
   int ppt192 = 1, nblk192 = 1, rows192 = 256, lds_delta192 = 0;
   size_t lds192 = 0;
+  DevBuf ptsc;
   if (d == 192) {
+    TM_TRY(ptsc.alloc((size_t)std::max<int64_t>(n, 1) * 192 * 4));
+    hipLaunchKernelGGL(k_chunk_major, dim3((unsigned)std::min<int64_t>((n * 48 + 255) / 256, 8192)), dim3(256), 0, stream, pts, n, ptsc.as<int32_t>());
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -628,7 +643,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
           hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
         }
       } else {
-        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192);
+        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192);
       }
       hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
