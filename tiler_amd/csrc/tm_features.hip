@@ -230,7 +230,15 @@ __global__ __launch_bounds__(64) void k_pearson_frames(const float *__restrict__
     __syncthreads();
     if (lane < 2) {
       const float *src = lane == 0 ? s_x : s_y;
-      for (int i = 0; i < n; i++) acc = __dadd_rn(acc, (double)src[i]);
+      int i = 0;
+      for (; i + 16 <= n; i += 16) {  // batch the LDS reads; the additions stay one sequential chain
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = src[i + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, (double)v[u]);
+      }
+      for (; i < n; i++) acc = __dadd_rn(acc, (double)src[i]);
     }
   }
   if (lane < 2) s_sum[lane] = acc;
@@ -243,11 +251,18 @@ __global__ __launch_bounds__(64) void k_pearson_frames(const float *__restrict__
     for (int i = lane; i < n; i += 64) { s_x[i] = x[c0 + i]; s_y[i] = y[c0 + i]; }
     __syncthreads();
     if (lane < 3) {
-      for (int i = 0; i < n; i++) {
-        const float dx = __fsub_rn(s_x[i], mx), dy = __fsub_rn(s_y[i], my);
-        const float a = lane == 1 ? dx : (lane == 2 ? dy : dx), b = lane == 1 ? dx : dy;
-        chain = __fadd_rn(chain, __fmul_rn(a, b));
+      // lane 0: sum dx*dy, lane 1: sum dx*dx, lane 2: sum dy*dy
+      const float *pa = lane == 2 ? s_y : s_x, *pb = lane == 1 ? s_x : s_y;
+      const float ma = lane == 2 ? my : mx, mb = lane == 1 ? mx : my;
+      int i = 0;
+      for (; i + 16 <= n; i += 16) {
+        float va[16], vb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) { va[u] = pa[i + u]; vb[u] = pb[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 16; u++) chain = __fadd_rn(chain, __fmul_rn(__fsub_rn(va[u], ma), __fsub_rn(vb[u], mb)));
       }
+      for (; i < n; i++) chain = __fadd_rn(chain, __fmul_rn(__fsub_rn(pa[i], ma), __fsub_rn(pb[i], mb)));
     }
   }
   // the three raw sums go back to the host, which finishes with IEEE sqrt/divide (device __fsqrt_rn is a bare

@@ -207,6 +207,11 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
     for (int e = threadIdx.x; e < NCOPY * kk * (D + 1); e += 256) s_acc[e] = 0;
   }
   const int64_t iters = (sg.count + (int64_t)nbx * 256 - 1) / ((int64_t)nbx * 256);
+  const bool cent_resident = D == 3 && kk <= KCH;  // the usual palette size: the centroids are staged once, not once per 256 points
+  if (cent_resident) {
+    for (int e = threadIdx.x; e < kk * D; e += 256) s_cent[e] = cent[((int64_t)seg * k) * D + e];
+    __syncthreads();
+  }
   for (int64_t it = 0; it < iters; it++) {
     const int64_t base = (it * nbx + bx) * 256;
     const int64_t i = base + threadIdx.x;
@@ -221,9 +226,11 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
 #pragma unroll
       for (int c = 0; c < KCH; c++) s[c] = 0.0;
       if (D == 3) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
-        __syncthreads();
+        if (!cent_resident) {
+          __syncthreads();
+          for (int e = threadIdx.x; e < nc * D; e += 256) s_cent[e] = cent[((int64_t)seg * k + c0) * D + e];
+          __syncthreads();
+        }
         if (valid) {
           if (nc == KCH) {
 #pragma unroll
