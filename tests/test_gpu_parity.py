@@ -409,3 +409,25 @@ def test_epu_rerank(tiles_flags, oracle):
     assert np.array_equal(t.cpu().numpy(), et) and np.array_equal(p.cpu().numpy(), ep)
     assert np.array_equal(_host_u32(e), ee)
     assert (ep != tile_pal[et]).any()            # the re-rank does move tiles to other palettes
+
+
+def test_knn_topk_matches_brute_force_at_scale():
+    """the pruned MFMA collection scan against the exact VALU brute force (TM_TOPK_BRUTE=1) on clustered data with many
+    duplicates and near-duplicates: overflow re-scans and the (distance, index) order at the 64th place get exercised"""
+    import os
+    from tiler_amd import stages
+    rng = np.random.default_rng(123)
+    centres = _rand_features(rng, 300, 400)
+    db = (centres[rng.integers(0, 300, 60000)].astype(np.int32) + rng.integers(-3, 4, (60000, 192))).astype(np.int16)
+    db[1000:1900] = db[999]          # 900 identical rows: more ties than any candidate list holds
+    q = (centres[rng.integers(0, 300, 5000)].astype(np.int32) + rng.integers(-3, 4, (5000, 192))).astype(np.int16)
+    q[:50] = db[999]
+    idx, err = stages.knn_topk(_dev(q), _dev(db), 64)
+    os.environ["TM_TOPK_BRUTE"] = "1"
+    try:
+        bidx, berr = stages.knn_topk(_dev(q), _dev(db), 64)
+    finally:
+        del os.environ["TM_TOPK_BRUTE"]
+    torch.cuda.synchronize()
+    assert torch.equal(err, berr) and torch.equal(idx, bidx)
+    assert int(idx[0, 0]) == 999 and int(err[0, 0]) == 0

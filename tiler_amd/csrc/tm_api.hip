@@ -1,4 +1,6 @@
 // tm_api.hip -- extern "C" surface of libtilemotion.so: stage seam + KNN index + misc (include/tilemotion.h).
+#include <cstdlib>
+
 #include "tm_common.h"
 #include "tm_internal.h"
 
@@ -48,7 +50,12 @@ int tm_stage_motion_search(const void *cur_i16, int tm_w, int tm_h, const void *
 
 int tm_stage_knn_topk(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt, int k, void *out_idx, void *out_err, void *stream) {
   TM_TRY(require_device());
-  return launch_knn_topk(queries_i16, nq, db_i16, nt, k, out_idx, out_err, (hipStream_t)stream);
+  if (getenv("TM_TOPK_BRUTE")) return launch_knn_topk(queries_i16, nq, db_i16, nt, k, out_idx, out_err, (hipStream_t)stream);  // the VALU brute force
+  tm_knn_index_impl *ix = nullptr;
+  TM_TRY(knn_index_create(db_i16, nt, (hipStream_t)stream, &ix));
+  const int rc = knn_index_search_topk(ix, queries_i16, nq, k, out_idx, out_err, (hipStream_t)stream);
+  knn_index_destroy(ix);
+  return rc;
 }
 
 int tm_stage_epu_rerank(const void *queries_i16, int64_t nq, const void *knn_idx, int k, const void *pal_px, const void *tile_pal_idx,

@@ -431,14 +431,20 @@ static int step_reconstruct(tm_encoder *e) {
     TM_TRY(qf.alloc((size_t)chunk_frames * per * 384));
     TM_TRY(idx64.alloc((size_t)chunk_frames * per * 64 * 4));
     TM_TRY(err64.alloc((size_t)chunk_frames * per * 64 * 4));
-    for (int f0 = sf; f0 < sf + sn; f0 += chunk_frames) {
+    tm_knn_index_impl *ix = nullptr;  // over ALL rows: duplicates count, as ann_kdtree_short_search_multi sees them
+    TM_TRY(knn_index_create(db.p, e->t, e->stream, &ix));
+    int rc = TM_OK;
+    for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
       const int nf = std::min(chunk_frames, sf + sn - f0);
       const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
-      TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
-      TM_TRY(launch_knn_topk(qf.p, n, db.p, e->t, 64, idx64.p, err64.p, e->stream));
-      TM_TRY(launch_epu_rerank(qf.p, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
-                               e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream));
+      rc = launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream);
+      if (rc == TM_OK) rc = knn_index_search_topk(ix, qf.p, n, 64, idx64.p, err64.p, e->stream);
+      if (rc == TM_OK)
+        rc = launch_epu_rerank(qf.p, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
+                               e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
     }
+    knn_index_destroy(ix);
+    TM_TRY(rc);
     TM_HIP(hipStreamSynchronize(e->stream));
   } else {
   DevBuf u_remap, u_order, u_use, udb;

@@ -29,6 +29,7 @@ int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_inde
 void knn_index_destroy(tm_knn_index_impl *ix);
 int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream);
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs);
+int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream);
 
 // tm_dither.hip
 int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,

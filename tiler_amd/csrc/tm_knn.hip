@@ -397,6 +397,120 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
   return TM_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k nearest rows (ann_kdtree_short_search_multi, tilingencoder.pas:1563) on the pruned MFMA scan.
+//  1. k_topk_tau: every query's k-th smallest exact SSD among the TOPK_WINDOW database tiles around its position on the
+//     curve = an upper bound tau of its true k-th smallest SSD (any k rows give one).
+//  2. k_knn_mfma<.., TOPK = true>: the scan with those fixed thresholds; every row with d'' <= tau lands in the query's
+//     candidate list (at most `cap` entries, the count keeps running).
+//  3. k_topk_select: exact SSD (d'' + the query norm's parity bit), original row index, rank by (SSD, index), first k out.
+//     A query whose list overflowed lowers its tau to the k-th smallest of what it did store (still a valid bound) and is
+//     scanned again with the other overflowed queries.
+constexpr int TOPK_WINDOW = 8;  // tiles (of 32 rows) sampled for the first threshold
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int topk_dot2(uint32_t a, uint32_t b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+
+// lane = sorted query; the window's rows are wave-uniform (scalar loads); per lane the k smallest distances in LDS [slot][lane]
+__global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ queries, const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ qkey,
+                                                 int64_t nq, const uint32_t *__restrict__ db, const uint32_t *__restrict__ tperm,
+                                                 const uint32_t *__restrict__ tkey, int64_t nt, int64_t ntt, int k, int *__restrict__ tau) {
+  extern __shared__ uint32_t s_d[];  // [k][64]
+  const int lane = threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.x * 64, p = p0 + lane;
+  const int64_t pq = min(p, nq - 1);
+  const uint32_t *qrow = queries + (int64_t)qperm[pq] * 96;
+  uint32_t q[96];
+#pragma unroll
+  for (int j = 0; j < 96; j += 4) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(qrow + j);
+    q[j] = v.x; q[j + 1] = v.y; q[j + 2] = v.z; q[j + 3] = v.w;
+  }
+  uint32_t qn = 0;
+#pragma unroll
+  for (int j = 0; j < 96; j++) qn = (uint32_t)topk_dot2(q[j], q[j], (int)qn);
+  // window: the tiles around the curve position of the wave's first query (as round 0 of the scan does for a workgroup)
+  const uint32_t k0 = qkey[min(p0, nq - 1)];
+  int64_t lo = 0, hi = ntt;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
+  int64_t start = max((int64_t)0, lo - 1 - TOPK_WINDOW / 2);
+  start = min(start, max((int64_t)0, ntt - TOPK_WINDOW));
+  const int64_t r0 = start * 32, r1 = min(nt, (start + TOPK_WINDOW) * 32);
+  int cnt = 0, mslot = 0;
+  uint32_t mx = 0;
+  for (int64_t r = r0; r < r1; r++) {
+    const uint32_t *row = db + (int64_t)tperm[r] * 96;
+    int acc = 0;
+    uint32_t tn = 0;
+#pragma unroll
+    for (int j = 0; j < 96; j++) { acc = topk_dot2(q[j], row[j], acc); tn = (uint32_t)topk_dot2(row[j], row[j], (int)tn); }
+    const uint32_t d = qn + tn - 2u * (uint32_t)acc;
+    if (cnt < k) {
+      s_d[cnt * 64 + lane] = d;
+      if (d > mx || cnt == 0) { mx = d; mslot = cnt; }
+      cnt++;
+    } else if (d < mx) {
+      s_d[mslot * 64 + lane] = d;
+      mx = 0;
+      for (int s = 0; s < k; s++) {
+        const uint32_t v = s_d[s * 64 + lane];
+        if (v > mx) { mx = v; mslot = s; }
+      }
+    }
+  }
+  tau[p] = (cnt >= k && mx < 0x7fffffffu) ? (int)mx : 0x7ffffffe;  // fewer than k rows in the window: everything is a candidate
+}
+
+// one wave per (sorted) query: rank its candidates by (SSD, original index); the first k go out in that order
+__global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *__restrict__ qperm, const uint8_t *__restrict__ qpack, int q_bytes,
+                                                    const uint32_t *__restrict__ tperm, int64_t nt, const uint2 *__restrict__ cand,
+                                                    const int *__restrict__ cand_cnt, int cap, int k, int *__restrict__ tau,
+                                                    const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
+                                                    uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count) {
+  extern __shared__ unsigned long long s_key[];  // [cap]
+  const int64_t p = blockIdx.x;
+  if (p >= nq) return;
+  const int lane = threadIdx.x;
+  const int total = cand_cnt[p], n = min(total, cap);
+  const uint32_t parity = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31] & 1u;
+  for (int i = lane; i < n; i += 64) {
+    const uint2 c = cand[p * cap + i];
+    const int64_t srow = c.y;
+    // padded rows of the last tile replicate row nt-1: they are not rows
+    s_key[i] = srow < nt ? (((unsigned long long)(c.x + parity) << 32) | tperm[srow]) : ~0ull;
+  }
+  __syncthreads();
+  if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
+    unsigned long long kth = ~0ull;
+    for (int i = lane; i < n; i += 64) {
+      const unsigned long long me = s_key[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += s_key[j] < me ? 1 : 0;
+      if (rank == k - 1) kth = me;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kth, o); kth = other < kth ? other : kth; }
+    if (lane == 0) {
+      tau[p] = (int)min((unsigned long long)0x7ffffffeu, kth >> 32);  // SSD bound; d'' <= SSD
+      ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
+    }
+    return;
+  }
+  const int64_t q = out_map ? out_map[p] : qperm[p];
+  for (int i = lane; i < n; i += 64) {
+    const unsigned long long me = s_key[i];
+    if (me == ~0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += s_key[j] < me ? 1 : 0;  // keys are distinct (one per row)
+    if (rank < k) { out_idx[q * k + rank] = (int32_t)(me & 0xffffffffu); out_err[q * k + rank] = (uint32_t)(me >> 32); }
+  }
+}
+__global__ void k_topk_fill(int32_t *__restrict__ out_idx, uint32_t *__restrict__ out_err, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { out_idx[i] = -1; out_err[i] = 0xffffffffu; }
+}
+
 static void launch_mfma(int ht, int hq, const KnnLaunch &a) {
   switch (ht) {
     case 0: knn_launch_ht<0>(hq, a); break;
@@ -427,20 +541,14 @@ int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_inde
 
 void knn_index_destroy(tm_knn_index_impl *ix) { delete ix; }
 
-int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream) {
-  TM_CHECK(ix != nullptr, TM_E_INVAL, "knn: null index");
-  TM_CHECK(nq >= 0, TM_E_INVAL, "knn: negative query count");
-  if (nq == 0) return TM_OK;
-  if (ix->nt == 0) {  // ANN on an empty tree: the caller treats idx outside [0,T) as "none" (tilingencoder.pas:1549-1557)
-    TM_HIP(hipMemsetAsync(out_idx, 0xff, (size_t)nq * 4, stream));
-    TM_HIP(hipMemsetAsync(out_err, 0xff, (size_t)nq * 4, stream));
-    return TM_OK;
-  }
+// everything a search needs before the scan: digit plan (database repacked if the batch widens it), both sides sorted along
+// the curve and packed in MFMA fragment order
+static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream) {
   ColStats qs;
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
-  const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
+  const int64_t ntt = (ix->nt + 31) / 32;
   {  // exactness domain: all arithmetic is mod 2^32 and compared as signed, which needs every SSD < 2^31.  Tile features
      // satisfy it by construction (<= 1.35e9); arbitrary int16 data may not.
     long long bound = 0;
@@ -485,6 +593,20 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   }
   TM_TRY(sort_by_curve(ix, queries, nq, ix->qperm, ix->qkey, stream));
   TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qperm, 0, ix->qpack, stream));
+  return TM_OK;
+}
+
+int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream) {
+  TM_CHECK(ix != nullptr, TM_E_INVAL, "knn: null index");
+  TM_CHECK(nq >= 0, TM_E_INVAL, "knn: negative query count");
+  if (nq == 0) return TM_OK;
+  if (ix->nt == 0) {  // ANN on an empty tree: the caller treats idx outside [0,T) as "none" (tilingencoder.pas:1549-1557)
+    TM_HIP(hipMemsetAsync(out_idx, 0xff, (size_t)nq * 4, stream));
+    TM_HIP(hipMemsetAsync(out_err, 0xff, (size_t)nq * 4, stream));
+    return TM_OK;
+  }
+  TM_TRY(prepare_search(ix, queries, nq, stream));
+  const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
@@ -532,6 +654,106 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
             100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt,
             100.0 * (double)cnt[3] / ((double)((nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW)) * (double)ntt), (long long)ix->last_ties);
   return TM_OK;
+}
+
+
+__global__ void k_topk_sorted_aux(const uint32_t *__restrict__ qperm, int64_t n, int64_t n_pad, const int *__restrict__ tau_by_row,
+                                  const uint32_t *__restrict__ rowmap, int *__restrict__ tau_sorted, uint32_t *__restrict__ map_sorted) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pad; p += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t row = qperm[min(p, n - 1)];
+    if (tau_by_row) tau_sorted[p] = tau_by_row[row];
+    if (p < n) map_sorted[p] = rowmap ? rowmap[row] : row;
+  }
+}
+__global__ void k_topk_gather_sub(const int16_t *__restrict__ feats, const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ list, int64_t n,
+                                  const int *__restrict__ tau_sorted, const uint32_t *__restrict__ map_sorted, int16_t *__restrict__ sub,
+                                  int *__restrict__ sub_tau, uint32_t *__restrict__ sub_map) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * 24; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / 24;
+    const int v = (int)(e - j * 24);
+    const uint32_t p = list[j];
+    reinterpret_cast<uint4 *>(sub)[e] = reinterpret_cast<const uint4 *>(feats + (int64_t)qperm[p] * 192)[v];
+    if (v == 0) { sub_tau[j] = tau_sorted[p]; sub_map[j] = map_sorted[p]; }
+  }
+}
+__global__ void k_topk_scatter(const int32_t *__restrict__ idx, const uint32_t *__restrict__ err, const uint32_t *__restrict__ map, int64_t n, int k,
+                               int32_t *__restrict__ out_idx, uint32_t *__restrict__ out_err) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * k; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / k;
+    out_idx[(int64_t)map[j] * k + (e - j * k)] = idx[e];
+    out_err[(int64_t)map[j] * k + (e - j * k)] = err[e];
+  }
+}
+
+static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+
+// one scan of `n` query rows (feats) with thresholds (tau_by_row, or the curve-window estimate when null); results go to row
+// rowmap[i] (or i) of out_idx / out_err; overflowed queries recurse with their tightened thresholds
+static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
+                     uint32_t *out_err, int depth, hipStream_t stream) {
+  TM_TRY(prepare_search(ix, feats, n, stream));
+  const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
+  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
+  DevBuf tau, map_sorted, cand, cand_cnt, ovf, counter;
+  TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
+  TM_TRY(cand.alloc((size_t)n * cap * 8)); TM_TRY(cand_cnt.alloc((size_t)n * 4));
+  TM_TRY(ovf.alloc((size_t)n * 4)); TM_TRY(counter.alloc(16));
+  TM_HIP(hipMemsetAsync(cand_cnt.p, 0, (size_t)n * 4, stream));
+  TM_HIP(hipMemsetAsync(counter.p, 0, 16, stream));
+  if (!tau_by_row)
+    hipLaunchKernelGGL(k_topk_tau, dim3((unsigned)(n_pad / 64)), dim3(64), (size_t)k * 64 * 4, stream, (const uint32_t *)feats, ix->qperm.as<uint32_t>(),
+                       ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
+                       tau.as<int>());
+  hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, rowmap, tau.as<int>(),
+                     map_sorted.as<uint32_t>());
+  KnnBoxes bx;
+  bx.lo = ix->box_lo.as<int>();
+  bx.hi = ix->box_hi.as<int>();
+  bx.tkey = ix->tkey.as<uint32_t>();
+  for (int d = 0; d < KNN_ND; d++) bx.col[d] = ix->curve.col[d];
+  KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
+              nullptr, nullptr, nullptr, stream};
+  a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap;
+  launch_mfma(ix->plan.ht, ix->plan.hq, a);
+  hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)cap * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
+                     knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
+                     map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>());
+  TM_HIP(hipGetLastError());
+  unsigned int novf = 0;
+  int flag = 0;
+  TM_HIP(hipMemcpyAsync(&novf, counter.p, 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
+  if (getenv("TM_KNN_DEBUG")) fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed\n", k, depth, (long long)n, cap, novf);
+  if (novf == 0) return TM_OK;
+  DevBuf sub, sub_tau, sub_map;
+  TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
+  hipLaunchKernelGGL(k_topk_gather_sub, dim3(gridn_k((int64_t)novf * 24)), dim3(256), 0, stream, feats, ix->qperm.as<uint32_t>(), ovf.as<uint32_t>(),
+                     (int64_t)novf, tau.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_map.as<uint32_t>());
+  TM_HIP(hipGetLastError());
+  cand.release();  // the recursion allocates its own
+  if (depth >= 4) {  // thresholds stopped helping (many rows at exactly the k-th distance): exact brute force for the stragglers
+    DevBuf bi, be;
+    TM_TRY(bi.alloc((size_t)novf * k * 4)); TM_TRY(be.alloc((size_t)novf * k * 4));
+    TM_TRY(launch_knn_topk(sub.p, novf, ix->db, ix->nt, k, bi.p, be.p, stream));
+    hipLaunchKernelGGL(k_topk_scatter, dim3(gridn_k((int64_t)novf * k)), dim3(256), 0, stream, bi.as<int32_t>(), be.as<uint32_t>(), sub_map.as<uint32_t>(),
+                       (int64_t)novf, k, out_idx, out_err);
+    TM_HIP(hipGetLastError());
+    TM_HIP(hipStreamSynchronize(stream));
+    return TM_OK;
+  }
+  return topk_pass(ix, sub.as<int16_t>(), novf, sub_tau.as<int>(), sub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream);
+}
+
+int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream) {
+  TM_CHECK(ix != nullptr, TM_E_INVAL, "knn: null index");
+  TM_CHECK(k >= 1 && k <= 64, TM_E_INVAL, "top-k: k %d outside 1..64", k);
+  if (nq <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_topk_fill, dim3(gridn_k(nq * k)), dim3(256), 0, stream, (int32_t *)out_idx, (uint32_t *)out_err, nq * k);
+  TM_HIP(hipGetLastError());
+  if (ix->nt == 0) return TM_OK;
+  return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream);
 }
 
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs) {

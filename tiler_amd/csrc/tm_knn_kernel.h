@@ -84,13 +84,17 @@ __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ 
   return *s_cnt;
 }
 
-template <int HT, int HQ>
+template <int HT, int HQ, bool TOPK>
 __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__restrict__ tpack, int64_t n_ttiles, KnnBoxes bx,
                                                           const uint8_t *__restrict__ qpack, int64_t n_qtiles,
                                                           const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
                                                           const uint32_t *__restrict__ qkey, int64_t nq, int prune,
                                                           int *__restrict__ best_key, int *__restrict__ best_tile,
-                                                          unsigned long long *__restrict__ visited) {
+                                                          unsigned long long *__restrict__ visited, const int *__restrict__ tau,
+                                                          uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap) {
+  // TOPK: collection mode for the k-nearest search (ann_kdtree_short_search_multi, tilingencoder.pas:1563): every
+  // query has a fixed threshold (an upper bound of its k-th smallest SSD); pruning uses it instead of a running best, and
+  // every row with d'' <= tau is appended to the query's candidate list (d'', sorted row).
   constexpr int NQ = KNN_NQ, NW = KNN_NW, ND = KNN_ND;
   constexpr int KT = 6 + HT, KQ = 6 + HQ, HM = HT < HQ ? HT : HQ;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;  // database tiles carry their box (2*ND ints) too
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
 #pragma unroll
     for (int kc = 0; kc < KQ; kc++) bq[s][kc] = *reinterpret_cast<const v4i *>(qb + (kc * 64 + lane) * 16);
     nq2[s] = reinterpret_cast<const int *>(qb + KQ * 1024)[lane & 31] & ~1;  // 2*(|q-c|^2 >> 1); the parity bit returns in the refine stage
-    best[s] = INT_MAX;
+    best[s] = TOPK ? tau[qt * 32 + (lane & 31)] : INT_MAX;
     bestt[s] = INT_MAX;
     tie[s] = 0;
   }
@@ -148,6 +152,16 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   }
   if (tid < NW * NQ) (&s_smax[0][0])[tid] = INT_MAX;
   __syncthreads();
+  if (TOPK) {  // fixed sub-tile maxima
+#pragma unroll
+    for (int s = 0; s < NQ; s++) {
+      int smax = best[s];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+      if (lane == 0) s_smax[wave][s] = smax;
+    }
+    __syncthreads();
+  }
   const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   int cur = 0;
   int smax_reg[NQ];
 #pragma unroll
-  for (int s = 0; s < NQ; s++) smax_reg[s] = INT_MAX;
+  for (int s = 0; s < NQ; s++) smax_reg[s] = TOPK ? s_smax[wave][s] : INT_MAX;
   bool improved = false;
   while (cur_tile >= 0) {
     nstaged++;
@@ -260,6 +274,19 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
           d[r] = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s]);
           m = min(m, d[r]);
         }
+        if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
+          const int64_t q = qtile[s] * 32 + (lane & 31);
+          if (m <= best[s] && qtile[s] < n_qtiles && q < nq) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+              if (d[r] <= best[s]) {
+                const int slot = atomicAdd(&cand_cnt[q], 1);
+                if (slot < cand_cap)
+                  cand[q * cand_cap + slot] = make_uint2((unsigned)d[r], (unsigned)(((cur_tile & 0x7fffff) << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+              }
+          }
+          continue;
+        }
         if (m == best[s]) tie[s] = 1;  // another tile reaches the same value
         if (m < best[s]) {             // this lane improves: which row, and is it alone?
           int row = 0, cnt = 0;
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     } else if (ob < best[s]) {
       best[s] = ob; bestt[s] = ot; tie[s] = oti;
     }
-    if (lane < 32 && qtile[s] < n_qtiles) {
+    if (!TOPK && lane < 32 && qtile[s] < n_qtiles) {
       const int64_t q = qtile[s] * 32 + lane;
       best_key[q] = best[s];
       best_tile[q] = (bestt[s] & 0x3fffffff) | (tie[s] ? (1 << 30) : 0);  // sorted row of the first minimum; bit 30: tie flag
@@ -312,16 +339,20 @@ struct KnnLaunch {
   const uint8_t *tpack; int64_t n_ttiles; KnnBoxes bx;
   const uint8_t *qpack; int64_t n_qtiles; const int16_t *queries; const uint32_t *qperm, *qkey; int64_t nq; int prune;
   int *best_key, *best_tile; unsigned long long *visited; hipStream_t stream;
+  const int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0;  // collection mode (k nearest)
 };
 
 // one per HT, defined in tm_knn_k<HT>.hip
 template <int HT> void knn_launch_ht(int hq, const KnnLaunch &a);
 
 
-#define TM_KNN_CASE(HT, HQ)                                                                                              \
-  case HQ:                                                                                                               \
-    hipLaunchKernelGGL((k_knn_mfma<HT, HQ>), grid, block, 0, a.stream, a.tpack, a.n_ttiles, a.bx, a.qpack, a.n_qtiles,   \
-                       a.queries, a.qperm, a.qkey, a.nq, a.prune, a.best_key, a.best_tile, a.visited);                   \
+#define TM_KNN_LAUNCH(HT, HQ, TOPK)                                                                                        \
+  hipLaunchKernelGGL((k_knn_mfma<HT, HQ, TOPK>), grid, block, 0, a.stream, a.tpack, a.n_ttiles, a.bx, a.qpack, a.n_qtiles,     \
+                     a.queries, a.qperm, a.qkey, a.nq, a.prune, a.best_key, a.best_tile, a.visited, a.tau, a.cand, a.cand_cnt, \
+                     a.cand_cap)
+#define TM_KNN_CASE(HT, HQ)                                                   \
+  case HQ:                                                                    \
+    if (a.tau) TM_KNN_LAUNCH(HT, HQ, true); else TM_KNN_LAUNCH(HT, HQ, false); \
     break;
 
 #define TM_KNN_DEFINE_HT(HT)                                                              \
@@ -332,8 +363,7 @@ template <int HT> void knn_launch_ht(int hq, const KnnLaunch &a);
       TM_KNN_CASE(HT, 0) TM_KNN_CASE(HT, 1) TM_KNN_CASE(HT, 2) TM_KNN_CASE(HT, 3)          \
       TM_KNN_CASE(HT, 4) TM_KNN_CASE(HT, 5)                                               \
       default:                                                                            \
-        hipLaunchKernelGGL((k_knn_mfma<HT, 6>), grid, block, 0, a.stream, a.tpack, a.n_ttiles, a.bx, a.qpack, a.n_qtiles, \
-                           a.queries, a.qperm, a.qkey, a.nq, a.prune, a.best_key, a.best_tile, a.visited);                 \
+        if (a.tau) TM_KNN_LAUNCH(HT, 6, true); else TM_KNN_LAUNCH(HT, 6, false);          \
     }                                                                                     \
   }
 
