@@ -121,3 +121,24 @@ def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path, radius)
     enc.Save(str(tmp_path / "again.gtm"))  # Save on its own, explicit path
     assert open(str(tmp_path / "again.gtm"), "rb").read() == data
     enc.close()
+
+
+def test_extended_palette_usage_scan_matches_brute_force():
+    """a clip large enough for duplicate-heavy databases, candidate overflows and re-scans: the pruned MFMA k-nearest scan with
+    duplicate expansion gives the same encoder output as the VALU brute force over all rows (TM_TOPK_BRUTE=1)"""
+    import os
+    from tiler_amd import synth
+    frames = synth.video(12, 320, 176, cut=6)
+    outs = []
+    for brute in (False, True):
+        if brute:
+            os.environ["TM_TOPK_BRUTE"] = "1"
+        try:
+            enc = _run_encoder(frames, PaletteCount=8, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0, FrameTilingExtendedPaletteUsage=True)
+        finally:
+            os.environ.pop("TM_TOPK_BRUTE", None)
+        outs.append((np.stack([enc.TileMap(f) for f in range(12)]), enc.Tiles()[1]))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    moved = outs[0][0]["PalIdx"] >= 0
+    assert moved.any()

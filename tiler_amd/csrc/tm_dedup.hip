@@ -194,6 +194,38 @@ int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t 
   return TM_OK;
 }
 
+namespace {
+__global__ void k_iota_u32(uint32_t *__restrict__ v, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+}  // namespace
+
+// member lists of a dedup: off[g] .. off[g+1] index `members`, which holds the rows of group g in ascending row order
+// (remap = row -> group, counts = rows per group, as run_dedup_ex(by_index = 1) returns them)
+int build_groups(const void *remap, int64_t n, const void *counts, int64_t ngroups, void *off, void *members, hipStream_t stream) {
+  TM_CHECK(n >= 0 && n < (int64_t)1 << 31 && ngroups >= 0, TM_E_INVAL, "groups: count out of range");
+  if (n == 0) return TM_OK;
+  DevBuf tmp, keys_out, iota;
+  size_t tb = 0;
+  TM_HIP(rocprim::exclusive_scan(nullptr, tb, (const uint32_t *)counts, (uint32_t *)off, 0u, (size_t)ngroups + 1, rocprim::plus<uint32_t>(), stream));
+  TM_TRY(tmp.alloc(tb));
+  // counts has ngroups entries; the scan's extra input element is read but its value never reaches an output we use
+  TM_HIP(rocprim::exclusive_scan(tmp.p, tb, (const uint32_t *)counts, (uint32_t *)off, 0u, (size_t)ngroups, rocprim::plus<uint32_t>(), stream));
+  const uint32_t total = (uint32_t)n;
+  TM_HIP(hipMemcpyAsync((uint32_t *)off + ngroups, &total, 4, hipMemcpyHostToDevice, stream));
+  TM_TRY(keys_out.alloc((size_t)n * 4)); TM_TRY(iota.alloc((size_t)n * 4));
+  hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, stream, iota.as<uint32_t>(), n);
+  size_t tb2 = 0;
+  TM_HIP(rocprim::radix_sort_pairs(nullptr, tb2, (const uint32_t *)remap, keys_out.as<uint32_t>(), iota.as<uint32_t>(), (uint32_t *)members, (size_t)n, 0,
+                                   32, stream));
+  TM_TRY(tmp.alloc(tb2));
+  TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb2, (const uint32_t *)remap, keys_out.as<uint32_t>(), iota.as<uint32_t>(), (uint32_t *)members, (size_t)n, 0, 32,
+                                   stream));
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(stream));  // `total` is on the stack; temporaries are released on return
+  return TM_OK;
+}
+
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
               int64_t *host_n_unique, hipStream_t stream) {
   return run_dedup_ex(rows, n, row_bytes, use_in, remap, order, use_out, host_n_unique, 0, stream);

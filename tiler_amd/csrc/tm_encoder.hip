@@ -431,14 +431,28 @@ static int step_reconstruct(tm_encoder *e) {
     TM_TRY(qf.alloc((size_t)chunk_frames * per * 384));
     TM_TRY(idx64.alloc((size_t)chunk_frames * per * 64 * 4));
     TM_TRY(err64.alloc((size_t)chunk_frames * per * 64 * 4));
-    tm_knn_index_impl *ix = nullptr;  // over ALL rows: duplicates count, as ann_kdtree_short_search_multi sees them
-    TM_TRY(knn_index_create(db.p, e->t, e->stream, &ix));
+    // the scan runs over the DISTINCT rows; every result is expanded to all its duplicates (they count, as
+    // ann_kdtree_short_search_multi sees them) from member lists
+    DevBuf d_remap, d_order, d_use, ddb, g_off, g_members;
+    TM_TRY(d_remap.alloc((size_t)e->t * 4)); TM_TRY(d_order.alloc((size_t)e->t * 4)); TM_TRY(d_use.alloc((size_t)(e->t + 1) * 4));
+    int64_t nd = 0;
+    TM_TRY(run_dedup_ex(db.p, e->t, 384, nullptr, d_remap.p, d_order.p, d_use.p, &nd, 1, e->stream));
+    TM_TRY(ddb.alloc((size_t)nd * 384));
+    hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(nd * 24)), dim3(256), 0, e->stream, db.as<uint4>(), d_order.as<int32_t>(), nd, 24, ddb.as<uint4>());
+    TM_HIP(hipGetLastError());
+    TM_TRY(g_off.alloc((size_t)(nd + 1) * 4)); TM_TRY(g_members.alloc((size_t)e->t * 4));
+    TM_TRY(build_groups(d_remap.p, e->t, d_use.p, nd, g_off.p, g_members.p, e->stream));
+    e->knn_db_rows = nd;
+    tm_knn_index_impl *ix = nullptr;
+    TM_TRY(knn_index_create(ddb.p, nd, e->stream, &ix));
     int rc = TM_OK;
     for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
       const int nf = std::min(chunk_frames, sf + sn - f0);
       const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
       rc = launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, n, nullptr, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream);
-      if (rc == TM_OK) rc = knn_index_search_topk(ix, qf.p, n, 64, idx64.p, err64.p, e->stream);
+      if (rc == TM_OK)
+        rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qf.p, n, db.p, e->t, 64, idx64.p, err64.p, e->stream)  // debugging aid: VALU brute force over all rows
+                                     : knn_index_search_topk(ix, qf.p, n, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
       if (rc == TM_OK)
         rc = launch_epu_rerank(qf.p, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
                                e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);

@@ -7,8 +7,9 @@
 //                 minimum in ascending (tile, palette) order.  The candidate vectors come from a table of the features of
 //                 EVERY global tile under EVERY palette (T x P rows, built once per Reconstruct with k_features_i16<3>)
 //                 instead of being recomputed per query as 1590-1591 do: same values, 3-4 orders of magnitude fewer DCTs.
-// First version: the top-k scan is an exact VALU brute force (v_dot2c_i32_i16, database rows through the scalar cache);
-// moving it onto the pruned MFMA scan of tm_knn.hip is the planned next step.
+// The shipped top-k runs on the pruned MFMA scan (tm_knn.hip: knn_index_search_topk); k_knn_topk below is the exact VALU
+// brute force (v_dot2c_i32_i16, database rows through the scalar cache) kept as its last-resort fallback and as the
+// independent implementation the tests compare it with (TM_TOPK_BRUTE=1).
 #include <algorithm>
 
 #include "tm_common.h"

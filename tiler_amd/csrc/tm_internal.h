@@ -29,7 +29,10 @@ int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_inde
 void knn_index_destroy(tm_knn_index_impl *ix);
 int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream);
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs);
-int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream);
+// grp_off / grp_members (optional): the index was built over DISTINCT rows; results are expanded to the original rows (member lists
+// as build_groups makes them), full_db = all rows, for the brute-force fallback
+int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream,
+                          const void *grp_off = nullptr, const void *grp_members = nullptr, const void *full_db = nullptr, int64_t full_nt = 0);
 
 // tm_dither.hip
 int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,
@@ -41,6 +44,7 @@ int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, vo
 int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
                  int64_t *host_n_unique, int by_index, hipStream_t stream);
 
+int build_groups(const void *remap, int64_t n, const void *counts, int64_t ngroups, void *off, void *members, hipStream_t stream);
 int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t *host_count, hipStream_t stream);
 
 // tm_motion.hip: motion prediction (tilingencoder.pas:1154-1282, 1496-1654) and Reduce's tile-count search (4014-4046)

@@ -407,7 +407,7 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
 //  3. k_topk_select: exact SSD (d'' + the query norm's parity bit), original row index, rank by (SSD, index), first k out.
 //     A query whose list overflowed lowers its tau to the k-th smallest of what it did store (still a valid bound) and is
 //     scanned again with the other overflowed queries.
-constexpr int TOPK_WINDOW = 8;  // tiles (of 32 rows) sampled for the first threshold
+constexpr int TOPK_WINDOW_DEFAULT = 32;  // tiles (of 32 rows) sampled for the first threshold (8: 1.45 s, 32: 0.99 s, 128: 1.00 s on the bench clip)
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int topk_dot2(uint32_t a, uint32_t b, int c) {
@@ -417,7 +417,7 @@ __device__ __forceinline__ int topk_dot2(uint32_t a, uint32_t b, int c) {
 // lane = sorted query; the window's rows are wave-uniform (scalar loads); per lane the k smallest distances in LDS [slot][lane]
 __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ queries, const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ qkey,
                                                  int64_t nq, const uint32_t *__restrict__ db, const uint32_t *__restrict__ tperm,
-                                                 const uint32_t *__restrict__ tkey, int64_t nt, int64_t ntt, int k, int *__restrict__ tau) {
+                                                 const uint32_t *__restrict__ tkey, int64_t nt, int64_t ntt, int k, int window, int *__restrict__ tau) {
   extern __shared__ uint32_t s_d[];  // [k][64]
   const int lane = threadIdx.x;
   const int64_t p0 = (int64_t)blockIdx.x * 64, p = p0 + lane;
@@ -436,9 +436,9 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
   const uint32_t k0 = qkey[min(p0, nq - 1)];
   int64_t lo = 0, hi = ntt;
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
-  int64_t start = max((int64_t)0, lo - 1 - TOPK_WINDOW / 2);
-  start = min(start, max((int64_t)0, ntt - TOPK_WINDOW));
-  const int64_t r0 = start * 32, r1 = min(nt, (start + TOPK_WINDOW) * 32);
+  int64_t start = max((int64_t)0, lo - 1 - window / 2);
+  start = min(start, max((int64_t)0, ntt - window));
+  const int64_t r0 = start * 32, r1 = min(nt, (start + window) * 32);
   int cnt = 0, mslot = 0;
   uint32_t mx = 0;
   for (int64_t r = r0; r < r1; r++) {
@@ -464,13 +464,18 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
   tau[p] = (cnt >= k && mx < 0x7fffffffu) ? (int)mx : 0x7ffffffe;  // fewer than k rows in the window: everything is a candidate
 }
 
-// one wave per (sorted) query: rank its candidates by (SSD, original index); the first k go out in that order
+// one wave per (sorted) query: rank its candidates by (SSD, original index); the first k go out in that order.  With member
+// lists (grp_off != null) a candidate is a DISTINCT row standing for all its duplicates: every member has the candidate's SSD
+// and its own index, so the output positions of a candidate's members start after all members of strictly nearer candidates and
+// interleave by index with the members of other candidates at exactly the same SSD (rare).
 __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *__restrict__ qperm, const uint8_t *__restrict__ qpack, int q_bytes,
                                                     const uint32_t *__restrict__ tperm, int64_t nt, const uint2 *__restrict__ cand,
                                                     const int *__restrict__ cand_cnt, int cap, int k, int *__restrict__ tau,
                                                     const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
-                                                    uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count) {
-  extern __shared__ unsigned long long s_key[];  // [cap]
+                                                    uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count,
+                                                    const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members) {
+  extern __shared__ unsigned long long s_key[];  // [cap] keys, then [cap] u32 multiplicities
+  uint32_t *s_mult = reinterpret_cast<uint32_t *>(s_key + cap);
   const int64_t p = blockIdx.x;
   if (p >= nq) return;
   const int lane = threadIdx.x;
@@ -480,7 +485,10 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
     const uint2 c = cand[p * cap + i];
     const int64_t srow = c.y;
     // padded rows of the last tile replicate row nt-1: they are not rows
-    s_key[i] = srow < nt ? (((unsigned long long)(c.x + parity) << 32) | tperm[srow]) : ~0ull;
+    const bool real = srow < nt;
+    const uint32_t id = real ? tperm[srow] : 0u;
+    s_key[i] = real ? (((unsigned long long)(c.x + parity) << 32) | id) : ~0ull;
+    s_mult[i] = real ? (grp_off ? grp_off[id + 1] - grp_off[id] : 1u) : 0u;
   }
   __syncthreads();
   if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
@@ -502,9 +510,39 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
   for (int i = lane; i < n; i += 64) {
     const unsigned long long me = s_key[i];
     if (me == ~0ull) continue;
-    int rank = 0;
-    for (int j = 0; j < n; j++) rank += s_key[j] < me ? 1 : 0;  // keys are distinct (one per row)
-    if (rank < k) { out_idx[q * k + rank] = (int32_t)(me & 0xffffffffu); out_err[q * k + rank] = (uint32_t)(me >> 32); }
+    const uint32_t ssd = (uint32_t)(me >> 32), id = (uint32_t)me;
+    uint32_t before = 0;  // members of strictly nearer candidates (without lists: candidates with a smaller key)
+    bool shared = false;  // another candidate at exactly this SSD
+    for (int j = 0; j < n; j++) {
+      const unsigned long long o = s_key[j];
+      const uint32_t os = (uint32_t)(o >> 32);
+      if (grp_off) {
+        if (os < ssd) before += s_mult[j];
+        else if (os == ssd && j != i) shared = true;
+      } else {
+        before += o < me ? 1u : 0u;
+      }
+    }
+    if (before >= (uint32_t)k) continue;
+    if (!grp_off) { out_idx[q * k + before] = (int32_t)id; out_err[q * k + before] = ssd; continue; }
+    const uint32_t o0 = grp_off[id], m = s_mult[i];
+    for (uint32_t a = 0; a < m; a++) {
+      const uint32_t idx = grp_members[o0 + a];
+      uint32_t pos = before + a;
+      if (shared) {  // members of the other candidates at this SSD with a smaller index come first
+        for (int j = 0; j < n; j++) {
+          const unsigned long long o = s_key[j];
+          if (j == i || (uint32_t)(o >> 32) != ssd) continue;
+          const uint32_t oo = grp_off[(uint32_t)o], om = s_mult[j];
+          uint32_t lo = 0, hi = om;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (grp_members[oo + mid] < idx) lo = mid + 1; else hi = mid; }
+          pos += lo;
+        }
+      }
+      if (pos >= (uint32_t)k) { if (!shared) break; else continue; }
+      out_idx[q * k + pos] = (int32_t)idx;
+      out_err[q * k + pos] = ssd;
+    }
   }
 }
 __global__ void k_topk_fill(int32_t *__restrict__ out_idx, uint32_t *__restrict__ out_err, int64_t n) {
@@ -689,8 +727,10 @@ static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_
 
 // one scan of `n` query rows (feats) with thresholds (tau_by_row, or the curve-window estimate when null); results go to row
 // rowmap[i] (or i) of out_idx / out_err; overflowed queries recurse with their tightened thresholds
+struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; const void *full_db = nullptr; int64_t full_nt = 0; };
+
 static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
-                     uint32_t *out_err, int depth, hipStream_t stream) {
+                     uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
   TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
   const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
@@ -703,7 +743,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   if (!tau_by_row)
     hipLaunchKernelGGL(k_topk_tau, dim3((unsigned)(n_pad / 64)), dim3(64), (size_t)k * 64 * 4, stream, (const uint32_t *)feats, ix->qperm.as<uint32_t>(),
                        ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
-                       tau.as<int>());
+                       getenv("TM_TOPK_WINDOW") ? atoi(getenv("TM_TOPK_WINDOW")) : TOPK_WINDOW_DEFAULT, tau.as<int>());
   hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, rowmap, tau.as<int>(),
                      map_sorted.as<uint32_t>());
   KnnBoxes bx;
@@ -715,9 +755,9 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap;
   launch_mfma(ix->plan.ht, ix->plan.hq, a);
-  hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)cap * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
+  hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)cap * 12, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
-                     map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>());
+                     map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members);
   TM_HIP(hipGetLastError());
   unsigned int novf = 0;
   int flag = 0;
@@ -736,24 +776,27 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   if (depth >= 4) {  // thresholds stopped helping (many rows at exactly the k-th distance): exact brute force for the stragglers
     DevBuf bi, be;
     TM_TRY(bi.alloc((size_t)novf * k * 4)); TM_TRY(be.alloc((size_t)novf * k * 4));
-    TM_TRY(launch_knn_topk(sub.p, novf, ix->db, ix->nt, k, bi.p, be.p, stream));
+    TM_TRY(launch_knn_topk(sub.p, novf, ex.full_db ? ex.full_db : (const void *)ix->db, ex.full_db ? ex.full_nt : ix->nt, k, bi.p, be.p, stream));
     hipLaunchKernelGGL(k_topk_scatter, dim3(gridn_k((int64_t)novf * k)), dim3(256), 0, stream, bi.as<int32_t>(), be.as<uint32_t>(), sub_map.as<uint32_t>(),
                        (int64_t)novf, k, out_idx, out_err);
     TM_HIP(hipGetLastError());
     TM_HIP(hipStreamSynchronize(stream));
     return TM_OK;
   }
-  return topk_pass(ix, sub.as<int16_t>(), novf, sub_tau.as<int>(), sub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream);
+  return topk_pass(ix, sub.as<int16_t>(), novf, sub_tau.as<int>(), sub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream, ex);
 }
 
-int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream) {
+int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream,
+                          const void *grp_off, const void *grp_members, const void *full_db, int64_t full_nt) {
   TM_CHECK(ix != nullptr, TM_E_INVAL, "knn: null index");
   TM_CHECK(k >= 1 && k <= 64, TM_E_INVAL, "top-k: k %d outside 1..64", k);
   if (nq <= 0) return TM_OK;
   hipLaunchKernelGGL(k_topk_fill, dim3(gridn_k(nq * k)), dim3(256), 0, stream, (int32_t *)out_idx, (uint32_t *)out_err, nq * k);
   TM_HIP(hipGetLastError());
   if (ix->nt == 0) return TM_OK;
-  return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream);
+  TopkExpand ex;
+  ex.grp_off = (const uint32_t *)grp_off; ex.grp_members = (const uint32_t *)grp_members; ex.full_db = full_db; ex.full_nt = full_nt;
+  return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
 }
 
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs) {
