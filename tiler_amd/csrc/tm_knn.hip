@@ -22,6 +22,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdlib>
 
@@ -417,6 +418,7 @@ __device__ __forceinline__ int topk_dot2(uint32_t a, uint32_t b, int c) {
 // lane = sorted query; the window's rows are wave-uniform (scalar loads); per lane the k smallest distances in LDS [slot][lane]
 __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ queries, const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ qkey,
                                                  int64_t nq, const uint32_t *__restrict__ db, const uint32_t *__restrict__ tperm,
+                                                 const uint32_t *__restrict__ tnorm /* |row|^2 in sorted order */,
                                                  const uint32_t *__restrict__ tkey, int64_t nt, int64_t ntt, int k, int window, int *__restrict__ tau) {
   extern __shared__ uint32_t s_d[];  // [k][64]
   const int lane = threadIdx.x;
@@ -444,10 +446,9 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
   for (int64_t r = r0; r < r1; r++) {
     const uint32_t *row = db + (int64_t)tperm[r] * 96;
     int acc = 0;
-    uint32_t tn = 0;
 #pragma unroll
-    for (int j = 0; j < 96; j++) { acc = topk_dot2(q[j], row[j], acc); tn = (uint32_t)topk_dot2(row[j], row[j], (int)tn); }
-    const uint32_t d = qn + tn - 2u * (uint32_t)acc;
+    for (int j = 0; j < 96; j++) acc = topk_dot2(q[j], row[j], acc);
+    const uint32_t d = qn + tnorm[r] - 2u * (uint32_t)acc;
     if (cnt < k) {
       s_d[cnt * 64 + lane] = d;
       if (d > mx || cnt == 0) { mx = d; mslot = cnt; }
@@ -462,6 +463,15 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
     }
   }
   tau[p] = (cnt >= k && mx < 0x7fffffffu) ? (int)mx : 0x7ffffffe;  // fewer than k rows in the window: everything is a candidate
+}
+
+__global__ void k_sorted_row_norms(const int16_t *__restrict__ rows, const uint32_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ norm) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int16_t *r = rows + (int64_t)perm[i] * 192;
+    uint32_t s = 0;
+    for (int j = 0; j < 192; j++) { const int v = r[j]; s += (uint32_t)(v * v); }
+    norm[i] = s;
+  }
 }
 
 // one wave per (sorted) query: rank its candidates by (SSD, original index); the first k go out in that order.  With member
@@ -731,6 +741,7 @@ struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; c
 
 static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
                      uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
+  const auto t_start = std::chrono::steady_clock::now();
   TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
   const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
@@ -740,10 +751,14 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   TM_TRY(ovf.alloc((size_t)n * 4)); TM_TRY(counter.alloc(16));
   TM_HIP(hipMemsetAsync(cand_cnt.p, 0, (size_t)n * 4, stream));
   TM_HIP(hipMemsetAsync(counter.p, 0, 16, stream));
-  if (!tau_by_row)
+  if (!tau_by_row) {
+    DevBuf tnorm;  // the plan (hence the sort order) can change between passes, so the norms are made per pass: 171 K rows, microseconds
+    TM_TRY(tnorm.alloc((size_t)ix->nt * 4));
+    hipLaunchKernelGGL(k_sorted_row_norms, dim3(gridn_k(ix->nt)), dim3(256), 0, stream, ix->db, ix->tperm.as<uint32_t>(), ix->nt, tnorm.as<uint32_t>());
     hipLaunchKernelGGL(k_topk_tau, dim3((unsigned)(n_pad / 64)), dim3(64), (size_t)k * 64 * 4, stream, (const uint32_t *)feats, ix->qperm.as<uint32_t>(),
-                       ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
+                       ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), tnorm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
                        getenv("TM_TOPK_WINDOW") ? atoi(getenv("TM_TOPK_WINDOW")) : TOPK_WINDOW_DEFAULT, tau.as<int>());
+  }
   hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, rowmap, tau.as<int>(),
                      map_sorted.as<uint32_t>());
   KnnBoxes bx;
@@ -765,7 +780,9 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
-  if (getenv("TM_KNN_DEBUG")) fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed\n", k, depth, (long long)n, cap, novf);
+  if (getenv("TM_KNN_DEBUG"))
+    fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   if (novf == 0) return TM_OK;
   DevBuf sub, sub_tau, sub_map;
   TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
@@ -773,7 +790,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
                      (int64_t)novf, tau.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_map.as<uint32_t>());
   TM_HIP(hipGetLastError());
   cand.release();  // the recursion allocates its own
-  if (depth >= 4) {  // thresholds stopped helping (many rows at exactly the k-th distance): exact brute force for the stragglers
+  if (depth >= 16 || (depth >= 2 && (int64_t)novf * 10 > n * 9)) {  // thresholds stopped helping (many rows at exactly the k-th distance): exact brute force for the stragglers
     DevBuf bi, be;
     TM_TRY(bi.alloc((size_t)novf * k * 4)); TM_TRY(be.alloc((size_t)novf * k * 4));
     TM_TRY(launch_knn_topk(sub.p, novf, ex.full_db ? ex.full_db : (const void *)ix->db, ex.full_db ? ex.full_nt : ix->nt, k, bi.p, be.p, stream));
