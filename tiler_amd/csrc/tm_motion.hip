@@ -23,9 +23,8 @@ __device__ __forceinline__ uint32_t sat_sub2(uint32_t a, uint32_t b) {  // psubs
   const s16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b));
   return __builtin_bit_cast(uint32_t, r);
 }
-__device__ __forceinline__ uint32_t sq2(uint32_t d) {  // pmaddwd of a dword with itself, mod 2^32
-  const int lo = (int)(short)(d & 0xffff), hi = (int)(short)(d >> 16);
-  return (uint32_t)(lo * lo) + (uint32_t)(hi * hi);
+__device__ __forceinline__ uint32_t sq2(uint32_t d) {  // pmaddwd of a dword with itself, mod 2^32: v_dot2c_i32_i16
+  return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, d), 0, false);
 }
 __device__ __forceinline__ uint32_t block_term(const uint4 a, const uint4 b) {
   return sq2(sat_sub2(a.x, b.x)) + sq2(sat_sub2(a.y, b.y)) + sq2(sat_sub2(a.z, b.z)) + sq2(sat_sub2(a.w, b.w));
@@ -73,37 +72,40 @@ __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict
   const int ux0 = max(0, bx * MS_TB * 8 - r - 1), ux1 = min(sw - 8, lx + r);
   const int ucols = ux1 - ux0 + 1, ucount = (uy1 - uy0 + 1) * ucols;
 
+  // branch-free inner loop: the per-lane quirk roles become selects, the 8-lane sums go through DPP (quad swaps, then the
+  // half-row mirror pairs lane i with 7 - i; after the quad steps every lane of a quad holds the quad's sum)
+  const bool r2 = role == 2, r1 = role == 1, l2 = j8 == 2;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   for (int c = grp; c < ucount; c += MS_GROUPS) {
     const int row = c / ucols, oy = uy0 + row, ox = ux0 + (c - row * ucols);
     const uint4 *pb = reinterpret_cast<const uint4 *>(win + ((int64_t)oy * ww + ox) * 192) + j8 * 3;
     const uint4 b0 = pb[0], b1 = pb[1], b2 = pb[2];
-    uint4 b5 = make_uint4(0, 0, 0, 0);
-    if (role == 2) b5 = pb[-1];
+    const uint4 b5raw = pb[r2 ? -1 : 0];
+    const uint4 b5 = r2 ? b5raw : zero4;
 #pragma unroll
     for (int t = 0; t < MS_TB * MS_TB; t++) {
       const bool in = valid[t] && oy >= max(0, dy[t] - r - 1) && oy <= min(sh - 8, dy[t] + r) && ox >= max(0, dx[t] - r - 1) &&
                       ox <= min(sw - 8, dx[t] + r);
-      uint32_t acc = 0;
-      // first block of the lane: for role 2 it is block 6 -> (a6 -sat b5) -sat b6
-      {
-        uint4 d;
-        d.x = sat_sub2(a[t][0].x, b5.x); d.y = sat_sub2(a[t][0].y, b5.y); d.z = sat_sub2(a[t][0].z, b5.z); d.w = sat_sub2(a[t][0].w, b5.w);
-        acc += block_term(d, b0);  // b5 = 0 for the other roles: a -sat 0 = a
-      }
+      // first block of the lane: for role 2 it is block 6 -> (a6 -sat b5) -sat b6; b5 = 0 for the other roles: a -sat 0 = a
+      uint4 d;
+      d.x = sat_sub2(a[t][0].x, b5.x); d.y = sat_sub2(a[t][0].y, b5.y); d.z = sat_sub2(a[t][0].z, b5.z); d.w = sat_sub2(a[t][0].w, b5.w);
+      uint32_t acc = block_term(d, b0);
       // second block: for lane 2 (first half, role 2) it is block 7, whose pair sums come back re-squared in the second half
-      {
-        const uint32_t p0 = sq2(sat_sub2(a[t][1].x, b1.x)), p1 = sq2(sat_sub2(a[t][1].y, b1.y)), p2 = sq2(sat_sub2(a[t][1].z, b1.z)),
-                       p3 = sq2(sat_sub2(a[t][1].w, b1.w));
-        acc += p0 + p1 + p2 + p3;
-        if (j8 == 2) acc += sq2(p0) + sq2(p1) + sq2(p2) + sq2(p3);
-      }
+      const uint32_t p0 = sq2(sat_sub2(a[t][1].x, b1.x)), p1 = sq2(sat_sub2(a[t][1].y, b1.y)), p2 = sq2(sat_sub2(a[t][1].z, b1.z)),
+                     p3 = sq2(sat_sub2(a[t][1].w, b1.w));
+      acc += p0 + p1 + p2 + p3;
+      const uint32_t resq = sq2(p0) + sq2(p1) + sq2(p2) + sq2(p3);
+      acc += l2 ? resq : 0u;
       // third block: block 5 of each half (role 1) never enters
-      if (role != 1) acc += block_term(a[t][2], b2);
-      acc += __shfl_xor(acc, 1);
-      acc += __shfl_xor(acc, 2);
-      acc += __shfl_xor(acc, 4);
+      const uint32_t third = block_term(a[t][2], b2);
+      acc += r1 ? 0u : third;
+      acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+      acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x141, 0xf, 0xf, false);  // row_half_mirror
       const uint32_t err = acc + (uint32_t)(abs(ox - dx[t]) + abs(oy - dy[t]));  // manhattan penalty, 1236
-      if (in && err < best[t]) { best[t] = err; bpos[t] = c; }  // candidates come in raster order: first minimum stays
+      const bool take = in && err < best[t];  // candidates come in raster order: first minimum stays
+      best[t] = take ? err : best[t];
+      bpos[t] = take ? c : bpos[t];
     }
   }
   if (j8 == 0) {
