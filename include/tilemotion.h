@@ -103,6 +103,13 @@ TM_API int tm_write_gtm_host(const char *path, int tm_w, int tm_h, int nframes, 
 /* LZCompress, extern.pas:420-439 (LZMA-alone: lc 8, lp 0, pb 2, 4 MiB dictionary, unknown size, end marker), host
  * buffers.  *out_n = compressed size; TM_E_INVAL (with *out_n set) when cap is too small. */
 TM_API int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n);
+/* LZDecompress, extern.pas:441-458: one stream; *out_n = decoded size (set even when cap is too small -> TM_E_INVAL),
+ * *consumed (optional) = bytes of src the stream occupied, so that the next key frame's stream can follow. */
+TM_API int tm_lz_decompress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n, size_t *consumed);
+/* ReloadGTM, :2059 -> LoadStream, :4880-5175: replaces the encoder's tiles (palette indices only), palettes, tile maps and key
+ * frames with the file's; the video set with tm_set_video must match the file's header (:5021-5032) or TM_E_INVAL comes back.
+ * Afterwards the read-back views and tm_save_gtm work on the loaded state. */
+TM_API int tm_reload_gtm(tm_encoder *, const char *path);
 /* Multi-GPU (one process per GPU): this process matches only frames [first, first+count) in Reconstruct (frames are
  * independent in the KNN branch, DoXY :1464); the host then merges the per-frame results of all processes with an
  * all-reduce(MAX) over the arrays below (other shards hold -1) and calls tm_sync_tilemap before Reindex.

@@ -142,3 +142,61 @@ def test_extended_palette_usage_scan_matches_brute_force():
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     moved = outs[0][0]["PalIdx"] >= 0
     assert moved.any()
+
+
+@pytest.mark.parametrize("radius", [0, 8])
+def test_reload_gtm_round_trip(oracle, tmp_path, radius):
+    """Save -> ReloadGTM into a fresh encoder (LoadStream, tilingencoder.pas:4880): palettes, tile pixels, tile maps and key
+    frames come back (single-use tiles renumbered in order of appearance, as LoadStream does), and saving again gives the
+    same file"""
+    from tiler_amd import synth
+    from tiler_amd.encoder import TilingEncoder
+    from tiler_amd import TileMotionError
+    frames = synth.video(9, 64, 48, cut=3)
+    a = str(tmp_path / "a.gtm")
+    enc = _run_encoder(frames, PaletteCount=3, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, FrameTilingExtendedPaletteUsage=True,
+                       GlobalTilingTileCount=100, OutputFileName=a)
+    per = 8 * 6
+    enc2 = TilingEncoder()
+    enc2.LoadDefaultSettings()
+    for k in ("PaletteCount", "MotionPredictRadius", "GlobalTilingTileCount", "ShotTransMinSecondsPerKF"):
+        setattr(enc2, k, getattr(enc, k))
+    enc2.OutputFileName = a
+    enc2.SetVideo(64, 48, 24.0, 9)
+    enc2.ReloadGTM(a)
+    assert np.array_equal(enc2.KeyFrames(), enc.KeyFrames())
+    pal = enc.Palettes().copy()
+    pal[pal == -65281] = 0xFFFFFF  # the stream stores the null colour as white (5284-5285)
+    assert np.array_equal(enc2.Palettes(), pal)
+    h1, px1, _ = enc.Tiles()
+    h2, px2, _ = enc2.Tiles()
+    assert px1.shape == px2.shape
+    for f in range(9):
+        t1, t2 = enc.TileMap(f), enc2.TileMap(f)
+        pred = ((t1["Flags"] >> 2) & 1).astype(bool)
+        assert np.array_equal(pred, ((t2["Flags"] >> 2) & 1).astype(bool))
+        assert np.array_equal(t1["Flags"][~pred], t2["Flags"][~pred])  # a predicted item's mirrors are not in the stream
+        assert np.array_equal(t1["PredictedX"][pred], t2["PredictedX"][pred]) and np.array_equal(t1["PredictedY"][pred], t2["PredictedY"][pred])
+        ok = ~pred
+        assert np.array_equal(t1["PalIdx"][ok], t2["PalIdx"][ok])
+        assert np.array_equal(px1[t1["TileIdx"][ok]], px2[t2["TileIdx"][ok]])  # same pixels, possibly under another index
+    b = str(tmp_path / "b.gtm")
+    if radius:
+        # a predicted item keeps the KNN's tile index in the encoder and Reindex counts it (2030), but the stream does not carry it:
+        # reloaded use counts are lower and no longer sorted, and SaveStream's TileSet rule (5296-5305) needs them sorted -> Reindex
+        from tiler_amd.encoder import TEncoderStep
+        enc2.Run(TEncoderStep.esReindex)
+    enc2.Save(b)
+    if radius == 0:
+        assert open(a, "rb").read() == open(b, "rb").read()
+    else:
+        from tests import gtm_reader  # some tiles are now single-use and travel as IntraTile: same pictures either way
+        _, pa = gtm_reader.play(oracle, open(a, "rb").read())
+        _, pb = gtm_reader.play(oracle, open(b, "rb").read())
+        assert np.array_equal(np.stack(pa.frames), np.stack(pb.frames))
+    enc3 = TilingEncoder()
+    enc3.SetVideo(64, 48, 24.0, 8)  # one frame short: "Mismatch between GTM and loaded video!" (5021-5032)
+    with pytest.raises(TileMotionError):
+        enc3.ReloadGTM(a)
+    for e in (enc, enc2, enc3):
+        e.close()

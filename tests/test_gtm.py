@@ -17,6 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tiler_amd", "lib", "libtilemotion.so")
 TMI = np.dtype([("TileIdx", "<i4"), ("PalIdx", "<i4"), ("PredictedX", "i1"), ("PredictedY", "i1"), ("PSNR", "<f4"), ("Flags", "<u4")])
 REF_JS = "/root/reference/decoders/htmljs"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _pins():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "gtm_demo_pins.json")))
 
 
 @pytest.fixture(scope="module")
@@ -77,6 +83,41 @@ def test_lz_compress_round_trip(L, oracle, name):
     assert consumed == len(blob)  # the player decodes keyframe streams back to back: no slack bytes allowed
     if name in ("zeros", "text", "long_distance"):
         assert len(blob) < len(data) // 8
+
+
+def decompress(L, blob, cap):
+    L.tm_lz_decompress_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    src = np.frombuffer(blob, np.uint8)
+    dst = np.zeros(max(cap, 1), np.uint8)
+    n, used = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = L.tm_lz_decompress_host(src.ctypes.data, src.size, dst.ctypes.data, cap, ctypes.byref(n), ctypes.byref(used))
+    assert rc == 0, L.tm_last_error()
+    return dst[:n.value].tobytes(), used.value
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_product_lz_decompress_round_trip(L, name):
+    """LZDecompress of the product (tm_lz_decompress_host, what ReloadGTM uses) on the product's own streams"""
+    data = CASES[name]
+    blob = compress(L, data) + b"trailing bytes of the next stream"
+    back, used = decompress(L, blob, len(data) + 16)
+    assert back == data and used == len(blob) - 33
+
+
+def test_product_lz_decompress_reads_reference_stream(L):
+    """... and on the reference's own key-frame stream (football_cif.gtm, committed verbatim): raw size and SHA-256 as pinned"""
+    import hashlib
+    pins = _pins()["football_cif"]
+    blob = open(os.path.join(GOLDEN, "football_cif_kf1.lzma"), "rb").read()
+    raw, used = decompress(L, blob, pins["kf"][1]["raw"] + 16)
+    assert used == len(blob) and len(raw) == pins["kf"][1]["raw"]
+    assert hashlib.sha256(raw).hexdigest() == pins["raw_sha256"][1]
+    bad = bytearray(blob)
+    bad[40000] ^= 0x55
+    src = np.frombuffer(bytes(bad[:50000]), np.uint8)
+    dst = np.zeros(1 << 20, np.uint8)
+    n = ctypes.c_size_t()
+    assert L.tm_lz_decompress_host(src.ctypes.data, src.size, dst.ctypes.data, dst.size, ctypes.byref(n), None) != 0  # corrupt / truncated
 
 
 def test_lz_compress_capacity_error(L):
@@ -208,14 +249,6 @@ def test_reference_lzma_js_reads_our_streams(L, oracle, tmp_path):
 
 
 # ---- the reader itself is pinned by the reference's demo files (docs/demo/*.gtm) ---------------
-GOLDEN = os.path.join(ROOT, "tests", "golden")
-
-
-def _pins():
-    import json
-    return json.load(open(os.path.join(GOLDEN, "gtm_demo_pins.json")))
-
-
 def test_reader_decodes_committed_reference_stream(oracle):
     """football_cif.gtm's second keyframe stream (verbatim reference data): the oracle's LZMA decoder returns the raw size
     its GTMk header states, consumes the stream exactly, and the command walk finds the pinned items"""

@@ -917,6 +917,65 @@ int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *laun
   return TM_OK;
 }
 
+int tm_reload_gtm(tm_encoder *e, const char *path) {  // ReloadGTM, tilingencoder.pas:2059 -> LoadStream, 4880-5175
+  TM_CHECK(e && path, TM_E_INVAL, "null argument");
+  TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
+  GtmLoaded g;
+  TM_TRY(read_gtm(path, &g));
+  // "Mismatch between GTM and loaded video!" (5021-5032)
+  TM_CHECK(g.header_frames < 0 || (g.header_frames == e->nframes && g.header_w == e->tm_w * 8 && g.header_h == e->tm_h * 8), TM_E_INVAL,
+           "mismatch between GTM (%d frames, %dx%d) and loaded video (%d frames, %dx%d)", g.header_frames, g.header_w, g.header_h, e->nframes,
+           e->tm_w * 8, e->tm_h * 8);
+  TM_CHECK(g.nframes == e->nframes && g.tm_w == e->tm_w && g.tm_h == e->tm_h, TM_E_INVAL, "GTM stream does not match the loaded video");
+  TM_HIP(hipSetDevice(e->device));
+  const int64_t q = (int64_t)e->nframes * e->tm_size(), T = (int64_t)g.use.size();
+  e->q = q; e->t = T; e->fps = g.fps;
+  e->s.PaletteSize = g.pal_size; e->s.PaletteCount = std::max(1, g.pal_count);
+  e->kf_start = g.kf_start;
+  e->correl.assign((size_t)e->nframes, 0.0f);
+  e->palettes_host.assign(g.palettes.begin(), g.palettes.end());
+  e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize, 0);
+  TM_TRY(e->palettes_dev.alloc(e->palettes_host.size() * 4));
+  TM_HIP(hipMemcpy(e->palettes_dev.p, e->palettes_host.data(), e->palettes_host.size() * 4, hipMemcpyHostToDevice));
+  TM_TRY(e->gtiles.alloc((size_t)std::max<int64_t>(T, 1) * 256)); TM_TRY(e->gpal_px.alloc((size_t)std::max<int64_t>(T, 1) * 64));
+  TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(T, 1))); TM_TRY(e->guse.alloc((size_t)std::max<int64_t>(T, 1) * 4));
+  TM_TRY(e->gpal_idx.alloc((size_t)std::max<int64_t>(T, 1) * 4));
+  TM_HIP(hipMemset(e->gtiles.p, 0, (size_t)std::max<int64_t>(T, 1) * 256));  // the stream carries no RGB pixels (HasRGBPixels = False, 4937)
+  TM_HIP(hipMemset(e->gflags.p, 0, (size_t)std::max<int64_t>(T, 1)));
+  TM_HIP(hipMemset(e->gpal_idx.p, 0xff, (size_t)std::max<int64_t>(T, 1) * 4));
+  if (T) {
+    TM_HIP(hipMemcpy(e->gpal_px.p, g.pal_px.data(), (size_t)T * 64, hipMemcpyHostToDevice));
+    TM_HIP(hipMemcpy(e->guse.p, g.use.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+  }
+  std::vector<int32_t> ti((size_t)q), pi((size_t)q);
+  std::vector<uint32_t> er((size_t)q, 0xffffffffu);
+  std::vector<int8_t> px((size_t)q), py((size_t)q);
+  std::vector<uint8_t> pr((size_t)q);
+  e->h_fflags.assign((size_t)q, 0);
+  for (int64_t i = 0; i < q; i++) {
+    const tm_tilemap_item &it = g.tilemap[(size_t)i];
+    ti[(size_t)i] = it.TileIdx; pi[(size_t)i] = it.PalIdx; px[(size_t)i] = it.PredictedX; py[(size_t)i] = it.PredictedY;
+    pr[(size_t)i] = (it.Flags & 4) ? 1 : 0;
+    e->h_fflags[(size_t)i] = (uint8_t)(it.Flags & 3);
+  }
+  TM_TRY(e->tm_tile.alloc((size_t)q * 4)); TM_TRY(e->tm_pal.alloc((size_t)q * 4)); TM_TRY(e->tm_err.alloc((size_t)q * 4));
+  TM_TRY(e->tm_px.alloc((size_t)q)); TM_TRY(e->tm_py.alloc((size_t)q)); TM_TRY(e->tm_pred.alloc((size_t)q)); TM_TRY(e->pm_err.alloc((size_t)q * 4));
+  TM_TRY(e->fflags.alloc((size_t)q));
+  TM_HIP(hipMemcpy(e->tm_tile.p, ti.data(), (size_t)q * 4, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->tm_pal.p, pi.data(), (size_t)q * 4, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->tm_err.p, er.data(), (size_t)q * 4, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->pm_err.p, er.data(), (size_t)q * 4, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->tm_px.p, px.data(), (size_t)q, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->tm_py.p, py.data(), (size_t)q, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->tm_pred.p, pr.data(), (size_t)q, hipMemcpyHostToDevice));
+  TM_HIP(hipMemcpy(e->fflags.p, e->h_fflags.data(), (size_t)q, hipMemcpyHostToDevice));
+  e->has_pm = true;
+  e->has_pal_px = true;
+  e->reconstructed = false;  // PSNR is not in the stream
+  e->steps_done = 0xff;      // every step's product is in place: Save / read-back work; running a step recomputes from the frames
+  return TM_OK;
+}
+
 int tm_save_gtm(tm_encoder *e, const char *path) {
   TM_CHECK(e && path, TM_E_INVAL, "null argument");
   return save_to(e, path);

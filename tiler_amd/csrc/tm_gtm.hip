@@ -354,6 +354,280 @@ int write_gtm(const char *path, const GtmInput &in) {
 
 }  // namespace tmx
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// LZDecompress (extern.pas:441-458): one LZMA-alone stream (5 property bytes, 8 size bytes, end marker); returns the bytes
+// consumed so the next key frame's stream can follow.
+namespace tmx {
+namespace {
+struct RangeDecoder {
+  const uint8_t *p, *end;
+  uint32_t range = 0xFFFFFFFFu, code = 0;
+  bool overrun = false;
+  uint8_t next() { if (p < end) return *p++; overrun = true; return 0; }
+  void init() { for (int i = 0; i < 5; i++) code = (code << 8) | next(); }
+  int bit(uint16_t &prob) {
+    const uint32_t bound = (range >> 11) * prob;
+    int b;
+    if (code < bound) { range = bound; prob = (uint16_t)(prob + ((2048 - prob) >> 5)); b = 0; }
+    else { range -= bound; code -= bound; prob = (uint16_t)(prob - (prob >> 5)); b = 1; }
+    if (range < (1u << 24)) { range <<= 8; code = (code << 8) | next(); }
+    return b;
+  }
+  uint32_t direct(int nbits) {
+    uint32_t r = 0;
+    for (int i = 0; i < nbits; i++) {
+      range >>= 1;
+      const uint32_t t = (code - range) >> 31;
+      code -= range & (t - 1);
+      r = (r << 1) | (1 - t);
+      if (range < (1u << 24)) { range <<= 8; code = (code << 8) | next(); }
+    }
+    return r;
+  }
+  uint32_t tree(uint16_t *probs, int nbits) {
+    uint32_t m = 1;
+    for (int i = 0; i < nbits; i++) m = (m << 1) | (uint32_t)bit(probs[m]);
+    return m - (1u << nbits);
+  }
+  uint32_t rtree(uint16_t *probs, int nbits) {
+    uint32_t m = 1, sym = 0;
+    for (int i = 0; i < nbits; i++) { const int b = bit(probs[m]); m = (m << 1) | (uint32_t)b; sym |= (uint32_t)b << i; }
+    return sym;
+  }
+};
+struct LenDecoder {
+  uint16_t choice[2], low[16][8], mid[16][8], high[256];
+  LenDecoder() { uint16_t *q = &choice[0]; for (size_t i = 0; i < sizeof(*this) / 2; i++) q[i] = 1024; }
+  uint32_t decode(RangeDecoder &rc, uint32_t ps) {
+    if (!rc.bit(choice[0])) return rc.tree(low[ps], 3);
+    if (!rc.bit(choice[1])) return 8 + rc.tree(mid[ps], 3);
+    return 16 + rc.tree(high, 8);
+  }
+};
+}  // namespace
+
+int lz_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &dst, size_t *consumed) {
+  TM_CHECK(n >= 18, TM_E_IO, "LZMA stream too short");
+  int props = src[0];
+  const int lc = props % 9; props /= 9;
+  const int lp = props % 5, pb = props / 5;
+  TM_CHECK(pb <= 4, TM_E_IO, "bad LZMA properties");
+  std::vector<uint16_t> lit((size_t)0x300 << (lc + lp), 1024);
+  uint16_t is_match[12 << 4], is_rep0_long[12 << 4], is_rep[12], is_g0[12], is_g1[12], is_g2[12], pos_slot[4][64], pos_dec[128], pos_align[16];
+  auto fill = [](uint16_t *q, size_t cnt) { for (size_t i = 0; i < cnt; i++) q[i] = 1024; };
+  fill(is_match, 12 << 4); fill(is_rep0_long, 12 << 4); fill(is_rep, 12); fill(is_g0, 12); fill(is_g1, 12); fill(is_g2, 12);
+  fill(&pos_slot[0][0], 256); fill(pos_dec, 128); fill(pos_align, 16);
+  LenDecoder len_dec, rep_len_dec;
+  RangeDecoder rc{src + 13, src + n};
+  rc.init();
+  uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
+  uint8_t prev = 0;
+  dst.clear();
+  bool ok = false;
+  while (!rc.overrun) {
+    const size_t pos = dst.size();
+    const uint32_t ps = (uint32_t)pos & ((1u << pb) - 1);
+    if (!rc.bit(is_match[(state << 4) + ps])) {
+      uint16_t *probs = &lit[(size_t)0x300 * ((((uint32_t)pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)))];
+      uint32_t sym = 1;
+      if (state >= 7) {
+        uint32_t mb = dst[pos - rep0 - 1];
+        do {
+          const uint32_t mbit = (mb >> 7) & 1;
+          mb <<= 1;
+          const int b = rc.bit(probs[((1 + mbit) << 8) + sym]);
+          sym = (sym << 1) | (uint32_t)b;
+          if (mbit != (uint32_t)b) { while (sym < 0x100) sym = (sym << 1) | (uint32_t)rc.bit(probs[sym]); break; }
+        } while (sym < 0x100);
+      } else {
+        do sym = (sym << 1) | (uint32_t)rc.bit(probs[sym]); while (sym < 0x100);
+      }
+      prev = (uint8_t)sym;
+      dst.push_back(prev);
+      state = state < 4 ? 0 : state - (state < 10 ? 3 : 6);
+      continue;
+    }
+    uint32_t len;
+    if (rc.bit(is_rep[state])) {
+      len = 0;
+      if (!rc.bit(is_g0[state])) {
+        if (!rc.bit(is_rep0_long[(state << 4) + ps])) { state = state < 7 ? 9 : 11; len = 1; }
+      } else {
+        uint32_t dist;
+        if (!rc.bit(is_g1[state])) dist = rep1;
+        else {
+          if (!rc.bit(is_g2[state])) dist = rep2;
+          else { dist = rep3; rep3 = rep2; }
+          rep2 = rep1;
+        }
+        rep1 = rep0;
+        rep0 = dist;
+      }
+      if (len == 0) { len = 2 + rep_len_dec.decode(rc, ps); state = state < 7 ? 8 : 11; }
+    } else {
+      rep3 = rep2; rep2 = rep1; rep1 = rep0;
+      len = 2 + len_dec.decode(rc, ps);
+      state = state < 7 ? 7 : 10;
+      const uint32_t slot = rc.tree(pos_slot[len <= 5 ? len - 2 : 3], 6);
+      if (slot >= 4) {
+        const int nd = (int)(slot >> 1) - 1;
+        rep0 = (2u | (slot & 1)) << nd;
+        if (slot < 14) rep0 += rc.rtree(pos_dec + ((int)rep0 - (int)slot - 1), nd);
+        else {
+          rep0 += rc.direct(nd - 4) << 4;
+          rep0 += rc.rtree(pos_align, 4);
+          if (rep0 == 0xFFFFFFFFu) { ok = true; break; }  // end marker
+        }
+      } else rep0 = slot;
+    }
+    if ((size_t)rep0 >= dst.size()) break;  // corrupt
+    for (uint32_t i = 0; i < len; i++) dst.push_back(dst[dst.size() - rep0 - 1]);
+    prev = dst.back();
+  }
+  TM_CHECK(ok && !rc.overrun, TM_E_IO, "corrupt LZMA stream");
+  if (consumed) *consumed = (size_t)(rc.p - src);
+  return TM_OK;
+}
+
+// LoadStream (tilingencoder.pas:4880-5175): the command streams of all key frames back into tables
+int read_gtm(const char *path, GtmLoaded *out) {
+  FILE *fp = fopen(path, "rb");
+  TM_CHECK(fp != nullptr, TM_E_IO, "cannot open %s", path);
+  std::vector<uint8_t> file;
+  {
+    uint8_t buf[1 << 16];
+    size_t r;
+    while ((r = fread(buf, 1, sizeof(buf), fp)) > 0) file.insert(file.end(), buf, buf + r);
+    fclose(fp);
+  }
+  auto le32 = [&](size_t at) { return (uint32_t)file[at] | ((uint32_t)file[at + 1] << 8) | ((uint32_t)file[at + 2] << 16) | ((uint32_t)file[at + 3] << 24); };
+  size_t pos = 0;
+  out->header_frames = -1;
+  if (file.size() >= 40 && memcmp(file.data(), "GTMv", 4) == 0) {  // 5015-5033
+    out->header_w = (int)le32(16); out->header_h = (int)le32(20); out->header_frames = (int)le32(28);
+    pos = le32(8);
+  }
+  int frm = -1, tm_pos = 0, last_tile = -1, loaded = 0;
+  bool frame_open = false;
+  std::vector<uint8_t> kf;
+  while (pos < file.size()) {
+    size_t used = 0;
+    TM_TRY(lz_decompress(file.data() + pos, file.size() - pos, kf, &used));
+    pos += used;
+    out->kf_start.push_back(loaded);
+    size_t p = 0;
+    auto need = [&](size_t k) { return p + k <= kf.size(); };
+    auto u8 = [&]() { return (uint32_t)kf[p++]; };
+    auto u16 = [&]() { const uint32_t v = kf[p] | (kf[p + 1] << 8); p += 2; return v; };
+    auto u32 = [&]() { const uint32_t v = (uint32_t)kf[p] | ((uint32_t)kf[p + 1] << 8) | ((uint32_t)kf[p + 2] << 16) | ((uint32_t)kf[p + 3] << 24); p += 4; return v; };
+    auto item = [&]() -> tm_tilemap_item * {  // "next frame if needed" (5091-5093 ...)
+      if (!frame_open) { frm++; out->tilemap.resize((size_t)(frm + 1) * out->tm_w * out->tm_h); frame_open = true; }
+      tm_tilemap_item *it = &out->tilemap[(size_t)frm * out->tm_w * out->tm_h + tm_pos];
+      memset(it, 0, sizeof(*it));
+      it->TileIdx = -1; it->PalIdx = -1;
+      return it;
+    };
+    bool kf_end = false;
+    while (!kf_end) {
+      TM_CHECK(need(2), TM_E_IO, "%s: truncated command stream", path);
+      const uint32_t w = u16(), cmd = w & 15, data = w >> 4;
+      switch (cmd) {
+        case gtExtended: { TM_CHECK(need(4), TM_E_IO, "truncated"); const uint32_t k = u32(); TM_CHECK(need(k), TM_E_IO, "truncated"); if (data == 0) out->settings.assign((const char *)&kf[p], k); p += k; break; }
+        case gtSetDimensions: {
+          TM_CHECK(need(12), TM_E_IO, "truncated");
+          out->tm_w = (int)u16(); out->tm_h = (int)u16();
+          const uint32_t ns = u32();
+          out->fps = 1000.0 * 1000 * 1000 / ns;
+          const uint32_t tc = u32();
+          TM_CHECK(out->tm_w > 0 && out->tm_h > 0 && ns > 0, TM_E_IO, "bad dimensions");
+          out->pal_px.assign((size_t)tc * 64, 0);
+          out->use.assign(tc, 0);
+          break;
+        }
+        case gtTileSet: {
+          TM_CHECK(need(8), TM_E_IO, "truncated");
+          const uint32_t a = u32(), b = u32();
+          TM_CHECK(b >= a && (size_t)b < out->use.size() && need((size_t)(b - a + 1) * 64), TM_E_IO, "bad tile set");
+          memcpy(&out->pal_px[(size_t)a * 64], &kf[p], (size_t)(b - a + 1) * 64);
+          p += (size_t)(b - a + 1) * 64;
+          last_tile = std::max(last_tile, (int)b);
+          out->pal_size = (int)data;
+          break;
+        }
+        case gtLoadPalette: {
+          TM_CHECK(need(2 + (size_t)out->pal_size * 4), TM_E_IO, "truncated");
+          const uint32_t pi = u16();
+          if (out->palettes.size() < (size_t)(pi + 1) * out->pal_size) out->palettes.resize((size_t)(pi + 1) * out->pal_size, 0);
+          for (int c = 0; c < out->pal_size; c++) out->palettes[(size_t)pi * out->pal_size + c] = (int32_t)(u32() & 0xffffff);
+          break;
+        }
+        case gtFrameEnd:
+          TM_CHECK(tm_pos == out->tm_w * out->tm_h, TM_E_IO, "incomplete tile map");
+          tm_pos = 0;
+          frame_open = false;
+          loaded++;
+          kf_end = (data & 1) != 0;
+          break;
+        case gtSkip:
+          for (uint32_t k = 0; k <= data; k++) {
+            TM_CHECK(out->tm_w > 0 && tm_pos < out->tm_w * out->tm_h, TM_E_IO, "skip past the tile map");
+            tm_tilemap_item *it = item();
+            it->Flags = 4;
+            tm_pos++;
+          }
+          break;
+        case gtShortShort: case gtLongShort: case gtLongLong: {
+          TM_CHECK(out->tm_w > 0 && tm_pos < out->tm_w * out->tm_h && need(cmd == gtShortShort ? 2 : (cmd == gtLongShort ? 4 : 6)), TM_E_IO, "bad tile-map item");
+          uint32_t pal = cmd == gtLongLong ? u16() : (data >> 2) & 1023;
+          const uint32_t tile = cmd == gtShortShort ? u16() : u32();
+          tm_tilemap_item *it = item();
+          it->TileIdx = (int32_t)tile; it->PalIdx = (int32_t)pal; it->Flags = data & 3;
+          if ((size_t)tile < out->use.size()) out->use[tile]++;
+          tm_pos++;
+          break;
+        }
+        case gtPredShort: {
+          TM_CHECK(out->tm_w > 0 && tm_pos < out->tm_w * out->tm_h, TM_E_IO, "bad tile-map item");
+          tm_tilemap_item *it = item();
+          it->PredictedX = (int8_t)((int)(data & 31) - (int)(data & 32));
+          it->PredictedY = (int8_t)((int)((data >> 6) & 31) - (int)((data >> 6) & 32));
+          it->Flags = 4;
+          tm_pos++;
+          break;
+        }
+        case gtPredLong: {
+          TM_CHECK(out->tm_w > 0 && tm_pos < out->tm_w * out->tm_h && need(2), TM_E_IO, "bad tile-map item");
+          tm_tilemap_item *it = item();
+          it->PredictedX = (int8_t)u8(); it->PredictedY = (int8_t)u8();
+          it->Flags = 4;
+          tm_pos++;
+          break;
+        }
+        case gtIntra: {
+          TM_CHECK(out->tm_w > 0 && tm_pos < out->tm_w * out->tm_h && need(66), TM_E_IO, "bad intra tile");
+          const uint32_t pal = u16();
+          last_tile++;
+          TM_CHECK((size_t)last_tile < out->use.size(), TM_E_IO, "more intra tiles than the tile count allows");
+          memcpy(&out->pal_px[(size_t)last_tile * 64], &kf[p], 64);
+          p += 64;
+          tm_tilemap_item *it = item();
+          it->TileIdx = last_tile; it->PalIdx = (int32_t)pal; it->Flags = data & 3;
+          out->use[(size_t)last_tile]++;
+          tm_pos++;
+          break;
+        }
+        default: set_error("%s: unknown command %u", path, cmd); return TM_E_IO;
+      }
+    }
+  }
+  out->nframes = loaded;
+  out->pal_count = out->pal_size > 0 ? (int)(out->palettes.size() / out->pal_size) : 0;
+  TM_CHECK(out->tilemap.size() == (size_t)loaded * out->tm_w * out->tm_h, TM_E_IO, "%s: frame count mismatch", path);
+  return TM_OK;
+}
+}  // namespace tmx
+
 extern "C" int tm_write_gtm_host(const char *path, int tm_w, int tm_h, int nframes, double fps, const int32_t *kf_start, int nkf,
                                  const uint8_t *pal_px, const uint32_t *use, int64_t ntiles, const int32_t *palettes, int pal_count,
                                  int pal_size, const tm_tilemap_item *tilemap, const char *settings) {
@@ -376,6 +650,17 @@ extern "C" int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, s
   tmx::lz_compress(raw, out);
   *out_n = out.size();
   if (!dst || cap < out.size()) { tmx::set_error("tm_lz_compress_host: %zu bytes needed, %zu given", out.size(), cap); return TM_E_INVAL; }
+  memcpy(dst, out.data(), out.size());
+  return TM_OK;
+}
+
+// LZDecompress (extern.pas:441-458) on host buffers; *out_n = decoded size (also when cap is too small), *consumed = stream bytes
+extern "C" int tm_lz_decompress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n, size_t *consumed) {
+  if (!src || !out_n) { tmx::set_error("tm_lz_decompress_host: null argument"); return TM_E_INVAL; }
+  std::vector<uint8_t> out;
+  TM_TRY(tmx::lz_decompress(src, n, out, consumed));
+  *out_n = out.size();
+  if (!dst || cap < out.size()) { tmx::set_error("tm_lz_decompress_host: %zu bytes needed, %zu given", out.size(), cap); return TM_E_INVAL; }
   memcpy(dst, out.data(), out.size());
   return TM_OK;
 }

@@ -83,5 +83,19 @@ struct GtmInput {
 };
 int write_gtm(const char *path, const GtmInput &in);
 void lz_compress(const std::vector<uint8_t> &raw, std::vector<uint8_t> &dst);
+int lz_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &dst, size_t *consumed);
+// LoadStream (tilingencoder.pas:4880-5175)
+struct GtmLoaded {
+  int header_w = 0, header_h = 0, header_frames = -1;  // from the GTMv header (-1: headerless stream)
+  int tm_w = 0, tm_h = 0, nframes = 0, pal_size = 0, pal_count = 0;
+  double fps = 0;
+  std::vector<int32_t> kf_start;
+  std::vector<uint8_t> pal_px;      // [tiles][64]
+  std::vector<uint32_t> use;        // UseCount as SetTMI counts it (4968-4969)
+  std::vector<int32_t> palettes;    // [pal_count][pal_size], alpha stripped (4951)
+  std::vector<tm_tilemap_item> tilemap;  // [nframes][tm_h*tm_w]
+  std::string settings;
+};
+int read_gtm(const char *path, GtmLoaded *out);
 
 }  // namespace tmx

@@ -64,6 +64,7 @@ _ENC_SIGS = {
     "tm_get_frame_correlations": (c_int, [c_void_p, c_void_p]),
     "tm_get_stage_ms": (c_int, [c_void_p, c_void_p]),
     "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
+    "tm_reload_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
@@ -221,6 +222,10 @@ class TilingEncoder:
             self.Run(TEncoderStep.esSave)
         else:
             check(self._L.tm_save_gtm(c_void_p(self._h), os.fsencode(path)))
+
+    def ReloadGTM(self, path):
+        """ReloadGTM (tilingencoder.pas:2059) -> LoadStream (:4880): tiles, palettes, tile maps, key frames from a .gtm"""
+        check(self._L.tm_reload_gtm(c_void_p(self._h), os.fsencode(path)))
 
     def SyncTileMap(self):
         check(self._L.tm_sync_tilemap(c_void_p(self._h)))
