@@ -181,20 +181,17 @@ __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_
 
 // ---- Lloyd ---------------------------------------------------------------------------------------------------
 constexpr int KCH = 16;  // centroids scored per pass (register accumulators)
-constexpr int DCH = 32;  // dimensions staged per pass (D = 192): 256 points x 32 dims, padded rows
 
-// Assignment step.  D = 192: points and centroids are staged chunk by chunk through LDS (coalesced 16-byte loads,
-// padded rows, broadcast centroid reads).  D = 3 (FUSE_ACC): points are read directly and the exact integer sums of the
-// new assignment are accumulated in LDS in the same pass.
+// Assignment step for D = 3 (pixel colours; D = 192 has its own kernel, k_assign192): points are read directly and, with
+// FUSE_ACC, the exact integer sums of the new assignment are accumulated in LDS in the same pass.
 template <int D, bool FUSE_ACC>
 __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                 int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
                                                 u64 *__restrict__ sums, u64 *__restrict__ cnts) {
   extern __shared__ double s_dyn[];
-  // D > 3:  [KCH][DCH] centroid chunk (double) | [256][DCH+1] points (int32)
-  // D == 3: [KCH][3] centroid chunk (double)   | [kk][4] u64 partial sums (FUSE_ACC)
+  // [KCH][3] centroid chunk (double) | [NCOPY][kk][4] u64 partial sums (FUSE_ACC)
+  static_assert(D == 3, "k_assign is the pixel kernel");
   double *s_cent = s_dyn;
-  int32_t *s_pts = reinterpret_cast<int32_t *>(s_dyn + KCH * (D > 3 ? DCH : D));
   u64 *s_acc = reinterpret_cast<u64 *>(s_dyn + KCH * D);
   int bx, nbx;
   const int seg = find_seg(segs, bx, nbx);
@@ -243,39 +240,6 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
             for (int j = 0; j < 3; j++) {
               const double pj = (double)p3[j];
               for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * 3 + j]); s[c] = __fma_rn(t, t, s[c]); }
-            }
-          }
-        }
-      } else {
-        for (int j0 = 0; j0 < D; j0 += DCH) {
-          __syncthreads();  // previous chunk fully consumed
-          for (int e = threadIdx.x; e < nc * DCH; e += 256) {
-            const int c = e / DCH, j = e - c * DCH;
-            s_cent[e] = cent[((int64_t)seg * k + c0 + c) * D + j0 + j];
-          }
-          // coalesced: 8 threads x 16 B cover one row's 32 dims; 32 rows per pass
-          for (int r = threadIdx.x >> 3; r < 256; r += 32) {
-            const int64_t pi = base + r;
-            int4 v = make_int4(0, 0, 0, 0);
-            if (pi < sg.count) v = *reinterpret_cast<const int4 *>(pts + (sg.begin + pi) * D + j0 + (threadIdx.x & 7) * 4);
-            int32_t *dst = s_pts + r * (DCH + 1) + (threadIdx.x & 7) * 4;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-          }
-          __syncthreads();
-          if (valid) {
-            const int32_t *pr = s_pts + threadIdx.x * (DCH + 1);
-            if (nc == KCH) {  // full chunk: branch-free, KCH independent accumulation chains
-#pragma unroll 4
-              for (int j = 0; j < DCH; j++) {
-                const double pj = (double)pr[j];
-#pragma unroll
-                for (int c = 0; c < KCH; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __fma_rn(t, t, s[c]); }
-              }
-            } else {
-              for (int j = 0; j < DCH; j++) {
-                const double pj = (double)pr[j];
-                for (int c = 0; c < nc; c++) { const double t = __dsub_rn(pj, s_cent[c * DCH + j]); s[c] = __fma_rn(t, t, s[c]); }
-              }
             }
           }
         }
@@ -610,7 +574,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
-  const size_t lds_assign = d > 3 ? (size_t)KCH * DCH * 8 + (size_t)256 * (DCH + 1) * 4 : (size_t)KCH * 3 * 8 + (size_t)16 * k * 4 * 8;
+  const size_t lds_assign = (size_t)KCH * 3 * 8 + (size_t)16 * k * 4 * 8;
   const size_t lds_acc = std::min<size_t>((size_t)k * (d + 1) * 8, 64 * 1024);
   const bool fuse3 = d == 3 && (size_t)16 * k * 4 * 8 <= 48 * 1024;
   // D = 192: slices of the largest segment sized so that one round of workgroups fills the chip evenly
