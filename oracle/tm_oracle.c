@@ -1316,7 +1316,8 @@ void tmo_motion_search(const int16_t *cur, int tm_w, int tm_h, const int16_t *wi
    * tmo_window_dcts of the back buffer (screen = tm_w*8 x tm_h*8), radius = the MotionPredictRadius setting (the
    * reference decrements it first, 1271/1666).  err = CompareEuclideanDCTPtr_asm(cur, prev) + manhattan distance to
    * the tile's own position; first strict minimum in raster order wins.  The QuickTest early-out (1230, 1513) cannot
-   * change the outcome: its value is one of the non-negative terms of err. */
+   * change the outcome: its value is one of the non-negative terms of err (true while no err wraps past 2^32; tile features
+   * of 8-bit images stay far below, for arbitrary int16 data this restatement is "minimum of the wrapped values"). */
   const int sw = tm_w * 8, sh = tm_h * 8, ww = sw - 7, r = radius - 1;
   for (int sy = 0; sy < tm_h; sy++)
     for (int sx = 0; sx < tm_w; sx++) {
