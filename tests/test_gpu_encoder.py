@@ -200,3 +200,33 @@ def test_reload_gtm_round_trip(oracle, tmp_path, radius):
         enc3.ReloadGTM(a)
     for e in (enc, enc2, enc3):
         e.close()
+
+
+def test_device_array_aliases_encoder_memory():
+    """the multi-GPU merge all-reduces these views in place (tiler_amd/distributed.py): they must alias the encoder's arrays"""
+    from tiler_amd import synth
+    frames = synth.video(3, 32, 32, cut=2)
+    enc = _run_encoder(frames, PaletteCount=1, MotionPredictRadius=4, FrameTilingExtendedPaletteUsage=False)
+    t = enc.DeviceArray(0)
+    assert t.dtype == torch.int32 and t.numel() == 3 * 16
+    before = enc.TileMap(1)["TileIdx"].copy()
+    t[16:32] += 1000
+    torch.cuda.synchronize()
+    assert np.array_equal(enc.TileMap(1)["TileIdx"], before + 1000)
+    p = enc.DeviceArray(3)
+    assert p.dtype == torch.uint8 and p.numel() == 3 * 16
+    x = enc.DeviceArray(4)
+    assert x.dtype == torch.int8
+    x[16:32] = -7
+    torch.cuda.synchronize()
+    assert np.all(enc.TileMap(1)["PredictedX"] == -7)
+    # a 1-rank "all_reduce" through the same code path as the bench
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    assert np.array_equal(enc.TileMap(1)["TileIdx"], before + 1000)
+    dist.destroy_process_group()
+    enc.close()

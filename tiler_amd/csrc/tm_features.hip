@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
 // (PredictMotion.DoDCTs / Reconstruct.DoDCTs, tilingencoder.pas:1157-1182, 1437-1462: `tiles` is the buffer, pal_size its
 // width in pixels, tile t = window at (t mod (width-7), t div (width-7))), 3 = every palette-index tile under every palette
 // (row t = tile t div P under palette t mod P, P passed in use_lab: the vectors 1590-1591 recompute per query).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int SRC>
 __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ pal_px,
                                                       const int32_t *__restrict__ pal_idx, const int32_t *__restrict__ palettes,
@@ -134,19 +136,19 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int k = 0; k < 64; k += 16) {  // DCTInner_asm, one 16-element step (utils.pas:892-921)
-          float p[16];
+          // packed fp32 (v_pk_mul_f32 / v_pk_add_f32): two IEEE operations per instruction, each rounded on its own like the
+          // reference's mulps / addps lanes (-ffp-contract=off: nothing fuses)
+          f32x2 p[8];
 #pragma unroll
           for (int q = 0; q < 16; q += 4) {
             const float4 cv = *reinterpret_cast<const float4 *>(cp + k + q);
-            p[q] = __fmul_rn(cv.x, l[k + q]);
-            p[q + 1] = __fmul_rn(cv.y, l[k + q + 1]);
-            p[q + 2] = __fmul_rn(cv.z, l[k + q + 2]);
-            p[q + 3] = __fmul_rn(cv.w, l[k + q + 3]);
+            p[q >> 1] = f32x2{cv.x, cv.y} * f32x2{l[k + q], l[k + q + 1]};
+            p[(q >> 1) + 1] = f32x2{cv.z, cv.w} * f32x2{l[k + q + 2], l[k + q + 3]};
           }
-          const float s0 = __fadd_rn(p[0], p[4]), s1 = __fadd_rn(p[1], p[5]), s2 = __fadd_rn(p[2], p[6]), s3 = __fadd_rn(p[3], p[7]);
-          const float t0 = __fadd_rn(p[8], p[12]), t1 = __fadd_rn(p[9], p[13]), t2 = __fadd_rn(p[10], p[14]), t3 = __fadd_rn(p[11], p[15]);
-          const double a0 = __dadd_rn(__dadd_rn((double)s0, (double)t0), __dadd_rn((double)s2, (double)t2));
-          const double a1 = __dadd_rn(__dadd_rn((double)s1, (double)t1), __dadd_rn((double)s3, (double)t3));
+          const f32x2 s01 = p[0] + p[2], s23 = p[1] + p[3];  // (p0+p4, p1+p5), (p2+p6, p3+p7)
+          const f32x2 t01 = p[4] + p[6], t23 = p[5] + p[7];  // (p8+p12, p9+p13), (p10+p14, p11+p15)
+          const double a0 = __dadd_rn(__dadd_rn((double)s01.x, (double)t01.x), __dadd_rn((double)s23.x, (double)t23.x));
+          const double a1 = __dadd_rn(__dadd_rn((double)s01.y, (double)t01.y), __dadd_rn((double)s23.y, (double)t23.y));
           acc0 = __dadd_rn(acc0, a0);
           acc1 = __dadd_rn(acc1, a1);
         }
