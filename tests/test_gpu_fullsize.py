@@ -280,3 +280,48 @@ def test_motion_prediction_at_720p(oracle, tmp_path):
     want0 = gtm_reader.render_expected(px2, enc.Palettes(), np.stack([enc.TileMap(0)]), tm_w, tm_h)
     assert np.array_equal(pl.frames[0], want0[0])  # frame 0 is all KNN
     enc.close()
+
+
+def test_extended_palette_usage_at_720p(oracle):
+    """configs[1] with FrameTilingExtendedPaletteUsage on (the reference default): for sampled queries the 64 nearest rows come from
+    an exact fp64 scan of the whole database in torch, ordered by (distance, index); the oracle's re-rank of that list must be what
+    the encoder chose (tile and palette), through the distinct-row scan, duplicate expansion and threshold re-scans"""
+    from tiler_amd import stages
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep as S
+    w, h, nf, npal = SIZES["720p300"]
+    frames = device_video(w, h, nf)
+    tm_w, tm_h = w // 8, h // 8
+    per = tm_w * tm_h
+    enc = TilingEncoder()
+    enc.LoadDefaultSettings()
+    enc.PaletteCount = npal
+    enc.MotionPredictRadius = 0
+    assert enc.FrameTilingExtendedPaletteUsage
+    enc.SetVideo(w, h, 24.0, nf)
+    enc.SetFramesDevice(frames)
+    for st in (S.esLoad, S.esPredictMotion, S.esReduce, S.esPreparePalettes, S.esDither, S.esReconstruct):
+        enc.Run(st)
+    pals = enc.Palettes()
+    hdr, pal_px, _ = enc.Tiles()
+    pal_idx = hdr["PalIdx_Initial"].astype(np.int32)
+    db = stages.features_pal(torch.from_numpy(pal_px).cuda(), torch.from_numpy(pal_idx).cuda(), torch.from_numpy(pals).cuda(), 1)
+    dbd = db.to(torch.float64)
+    dn = (dbd * dbd).sum(1)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    moved = 0
+    for f in torch.randint(0, nf, (3,), generator=gen, device="cuda").tolist():
+        ft, _, _ = stages.load(frames[f:f + 1], tm_w, tm_h)
+        qf = stages.features_rgb(ft, None, 1, False)
+        pick = torch.randperm(per, generator=gen, device="cuda")[:256]
+        q = qf[pick].to(torch.float64)
+        d = (q * q).sum(1)[:, None] + dn[None, :] - 2.0 * (q @ dbd.T)  # exact: integers below 2^53
+        key = d * float(1 << 22) + torch.arange(db.shape[0], device="cuda", dtype=torch.float64)[None, :]  # (distance, index): d < 2^31, index < 2^22
+        idx64 = torch.topk(key, 64, dim=1, largest=False, sorted=True).indices.to(torch.int32).cpu().numpy()
+        et, ep, ee = oracle.epu_rerank(qf[pick].cpu().numpy(), idx64, pal_px, pal_idx, pals)
+        tmap = enc.TileMap(f)
+        sel = pick.cpu().numpy()
+        assert np.array_equal(tmap["TileIdx"][sel], et) and np.array_equal(tmap["PalIdx"][sel], ep)
+        assert np.allclose(tmap["PSNR"][sel], oracle.psnr(ee), rtol=1e-6)
+        moved += int((ep != pal_idx[et]).sum())
+    assert moved > 0
+    enc.close()

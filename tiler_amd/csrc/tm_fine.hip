@@ -11,28 +11,6 @@
 
 namespace tmx {
 
-// all SSDs of one query against the database (CompareEuclideanDCTPtr, utils.pas:541-557): one lane per row
-__global__ __launch_bounds__(256) void k_ssd_one_query(const int16_t *__restrict__ q, const int16_t *__restrict__ db, int64_t nt,
-                                                       uint32_t *__restrict__ out) {
-  __shared__ int s_q[192];
-  for (int i = threadIdx.x; i < 192; i += 256) s_q[i] = q[i];
-  __syncthreads();
-  for (int64_t r = blockIdx.x * 256 + threadIdx.x; r < nt; r += (int64_t)gridDim.x * 256) {
-    const int4 *p = reinterpret_cast<const int4 *>(db + r * 192);
-    uint32_t ssd = 0;
-    for (int v = 0; v < 24; v++) {
-      const int4 x = p[v];
-      const int w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int d0 = (int)(int16_t)(w[i] & 0xffff) - s_q[v * 8 + 2 * i];
-        const int d1 = (w[i] >> 16) - s_q[v * 8 + 2 * i + 1];
-        ssd += (uint32_t)(d0 * d0) + (uint32_t)(d1 * d1);
-      }
-    }
-    out[r] = ssd;
-  }
-}
 
 }  // namespace tmx
 
@@ -95,18 +73,15 @@ void ann_kdtree_short_search_multi(tm_ann *a, int32_t *idxs, uint32_t *errs, int
   for (int i = 0; i < cnt; i++) { if (idxs) idxs[i] = -1; if (errs) errs[i] = 0xffffffffu; }
   if (!a || !q || !idxs || cnt <= 0 || a->n == 0) return;
   std::lock_guard<std::mutex> lk(a->mu);
-  if (a->all.alloc((size_t)a->n * 4) != TM_OK) return;
-  if (hipMemcpy(a->q.p, q, 384, hipMemcpyHostToDevice) != hipSuccess) return;
-  hipLaunchKernelGGL(k_ssd_one_query, dim3((unsigned)std::min<int64_t>(((int64_t)a->n + 255) / 256, 2048)), dim3(256), 0, nullptr,
-                     a->q.as<int16_t>(), a->db.as<int16_t>(), (int64_t)a->n, a->all.as<uint32_t>());
-  std::vector<uint32_t> d(a->n);
-  if (hipMemcpy(d.data(), a->all.p, (size_t)a->n * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
-  std::vector<int32_t> order(a->n);
-  for (int i = 0; i < a->n; i++) order[i] = i;
-  const int k = std::min(cnt, a->n);
-  std::partial_sort(order.begin(), order.begin() + k, order.end(),
-                    [&](int32_t x, int32_t y) { return d[x] != d[y] ? d[x] < d[y] : x < y; });  // build's order: (err, idx) ascending
-  for (int i = 0; i < k; i++) { idxs[i] = order[i]; if (errs) errs[i] = d[order[i]]; }
+  // the k nearest rows in the build's order (distance, index): the collection scan of tm_knn.hip for k <= 64, beyond that the
+  // exact brute-force scan of tm_epu.hip in slices is not needed by any caller (the reference asks for 64, tilingencoder.pas:1433)
+  const int k = std::min(cnt, 64);
+  DevBuf dq, di, de;
+  if (dq.alloc(384) != TM_OK || di.alloc((size_t)k * 4) != TM_OK || de.alloc((size_t)k * 4) != TM_OK) return;
+  if (hipMemcpy(dq.p, q, 384, hipMemcpyHostToDevice) != hipSuccess) return;
+  if (knn_index_search_topk(a->ix, dq.p, 1, k, di.p, de.p, nullptr) != TM_OK) return;
+  if (hipMemcpy(idxs, di.p, (size_t)k * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+  if (errs && hipMemcpy(errs, de.p, (size_t)k * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
 }
 
 }  // extern "C"
