@@ -484,75 +484,87 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
                                                     const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
                                                     uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count,
                                                     const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members) {
-  extern __shared__ unsigned long long s_key[];  // [cap] keys, then [cap] u32 multiplicities
-  uint32_t *s_mult = reinterpret_cast<uint32_t *>(s_key + cap);
+  extern __shared__ unsigned long long s_key[];  // [cap rounded up to a power of two]
+  __shared__ uint32_t s_mult[64];
   const int64_t p = blockIdx.x;
   if (p >= nq) return;
   const int lane = threadIdx.x;
   const int total = cand_cnt[p], n = min(total, cap);
+  int n2 = 64;
+  while (n2 < n) n2 <<= 1;
   const uint32_t parity = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31] & 1u;
-  for (int i = lane; i < n; i += 64) {
-    const uint2 c = cand[p * cap + i];
-    const int64_t srow = c.y;
-    // padded rows of the last tile replicate row nt-1: they are not rows
-    const bool real = srow < nt;
-    const uint32_t id = real ? tperm[srow] : 0u;
-    s_key[i] = real ? (((unsigned long long)(c.x + parity) << 32) | id) : ~0ull;
-    s_mult[i] = real ? (grp_off ? grp_off[id + 1] - grp_off[id] : 1u) : 0u;
+  for (int i = lane; i < n2; i += 64) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const uint2 c = cand[p * cap + i];
+      const int64_t srow = c.y;
+      if (srow < nt) key = ((unsigned long long)(c.x + parity) << 32) | tperm[srow];  // padded rows of the last tile replicate row nt-1: not rows
+    }
+    s_key[i] = key;
   }
   __syncthreads();
-  if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
-    unsigned long long kth = ~0ull;
-    for (int i = lane; i < n; i += 64) {
-      const unsigned long long me = s_key[i];
-      int rank = 0;
-      for (int j = 0; j < n; j++) rank += s_key[j] < me ? 1 : 0;
-      if (rank == k - 1) kth = me;
+  // bitonic sort of the keys (one wave): (SSD, index of the row / of the distinct row's first occurrence) ascending
+  for (int ks = 2; ks <= n2; ks <<= 1)
+    for (int j = ks >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < n2; i += 64) {
+        const int o = i ^ j;
+        if (o > i) {
+          const unsigned long long a = s_key[i], b = s_key[o];
+          const bool up = (i & ks) == 0;
+          if ((a > b) == up) { s_key[i] = b; s_key[o] = a; }
+        }
+      }
+      __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kth, o); kth = other < kth ? other : kth; }
+  if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
     if (lane == 0) {
-      tau[p] = (int)min((unsigned long long)0x7ffffffeu, kth >> 32);  // SSD bound; d'' <= SSD
+      tau[p] = (int)min((unsigned long long)0x7ffffffeu, s_key[k - 1] >> 32);  // SSD bound; d'' <= SSD
       ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
     }
     return;
   }
   const int64_t q = out_map ? out_map[p] : qperm[p];
-  for (int i = lane; i < n; i += 64) {
-    const unsigned long long me = s_key[i];
-    if (me == ~0ull) continue;
-    const uint32_t ssd = (uint32_t)(me >> 32), id = (uint32_t)me;
-    uint32_t before = 0;  // members of strictly nearer candidates (without lists: candidates with a smaller key)
-    bool shared = false;  // another candidate at exactly this SSD
-    for (int j = 0; j < n; j++) {
-      const unsigned long long o = s_key[j];
-      const uint32_t os = (uint32_t)(o >> 32);
-      if (grp_off) {
-        if (os < ssd) before += s_mult[j];
-        else if (os == ssd && j != i) shared = true;
-      } else {
-        before += o < me ? 1u : 0u;
+  // The k nearest ROWS come from the first k candidates: a member of a later candidate has at least k members before it.
+  const int m = min(n, k);
+  unsigned long long me = ~0ull;
+  if (lane < m) me = s_key[lane];
+  const bool real = me != ~0ull;
+  const uint32_t ssd = (uint32_t)(me >> 32), id = (uint32_t)me;
+  if (lane < 64) s_mult[lane] = real ? (grp_off ? grp_off[id + 1] - grp_off[id] : 1u) : 0u;
+  __syncthreads();
+  if (!real) return;
+  uint32_t before = 0;  // members of strictly nearer candidates (without lists: the candidate's own rank)
+  bool shared = false;  // another candidate at exactly this SSD
+  for (int j = 0; j < m; j++) {
+    const unsigned long long o = s_key[j];
+    if (o == ~0ull) continue;
+    const uint32_t os = (uint32_t)(o >> 32);
+    if (grp_off) {
+      if (os < ssd) before += s_mult[j];
+      else if (os == ssd && j != lane) shared = true;
+    } else {
+      before += j < lane ? 1u : 0u;
+    }
+  }
+  if (before >= (uint32_t)k) return;
+  if (!grp_off) { out_idx[q * k + before] = (int32_t)id; out_err[q * k + before] = ssd; return; }
+  const uint32_t o0 = grp_off[id], mult = s_mult[lane];
+  for (uint32_t a = 0; a < mult; a++) {
+    const uint32_t idx = grp_members[o0 + a];
+    uint32_t pos = before + a;
+    if (shared) {  // members of the other candidates at this SSD with a smaller index come first
+      for (int j = 0; j < m; j++) {
+        const unsigned long long o = s_key[j];
+        if (j == lane || o == ~0ull || (uint32_t)(o >> 32) != ssd) continue;
+        const uint32_t oo = grp_off[(uint32_t)o], om = s_mult[j];
+        uint32_t lo = 0, hi = om;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (grp_members[oo + mid] < idx) lo = mid + 1; else hi = mid; }
+        pos += lo;
       }
     }
-    if (before >= (uint32_t)k) continue;
-    if (!grp_off) { out_idx[q * k + before] = (int32_t)id; out_err[q * k + before] = ssd; continue; }
-    const uint32_t o0 = grp_off[id], m = s_mult[i];
-    for (uint32_t a = 0; a < m; a++) {
-      const uint32_t idx = grp_members[o0 + a];
-      uint32_t pos = before + a;
-      if (shared) {  // members of the other candidates at this SSD with a smaller index come first
-        for (int j = 0; j < n; j++) {
-          const unsigned long long o = s_key[j];
-          if (j == i || (uint32_t)(o >> 32) != ssd) continue;
-          const uint32_t oo = grp_off[(uint32_t)o], om = s_mult[j];
-          uint32_t lo = 0, hi = om;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (grp_members[oo + mid] < idx) lo = mid + 1; else hi = mid; }
-          pos += lo;
-        }
-      }
-      if (pos >= (uint32_t)k) { if (!shared) break; else continue; }
-      out_idx[q * k + pos] = (int32_t)idx;
-      out_err[q * k + pos] = ssd;
-    }
+    if (pos >= (uint32_t)k) { if (!shared) break; else continue; }
+    out_idx[q * k + pos] = (int32_t)idx;
+    out_err[q * k + pos] = ssd;
   }
 }
 __global__ void k_topk_fill(int32_t *__restrict__ out_idx, uint32_t *__restrict__ out_err, int64_t n) {
@@ -733,6 +745,7 @@ __global__ void k_topk_scatter(const int32_t *__restrict__ idx, const uint32_t *
   }
 }
 
+static int topk_pow2(int v) { int r = 64; while (r < v) r <<= 1; return r; }
 static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
 
 // one scan of `n` query rows (feats) with thresholds (tau_by_row, or the curve-window estimate when null); results go to row
@@ -770,7 +783,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap;
   launch_mfma(ix->plan.ht, ix->plan.hq, a);
-  hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)cap * 12, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
+  hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members);
   TM_HIP(hipGetLastError());
