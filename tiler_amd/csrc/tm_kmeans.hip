@@ -187,7 +187,8 @@ constexpr int KCH = 16;  // centroids scored per pass (register accumulators)
 template <int D, bool FUSE_ACC>
 __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                 int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
-                                                u64 *__restrict__ sums, u64 *__restrict__ cnts) {
+                                                u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet) {
+  if (*quiet >= 0) return;  // converged earlier in this batch of launches (the host polls every few iterations)
   extern __shared__ double s_dyn[];
   // [KCH][3] centroid chunk (double) | [NCOPY][kk][4] u64 partial sums (FUSE_ACC)
   static_assert(D == 3, "k_assign is the pixel kernel");
@@ -296,7 +297,9 @@ template <int PPT>
 __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
                                                    const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                    int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
-                                                   u64 *__restrict__ sums, u64 *__restrict__ cnts, int rows_per_block, int lds_delta) {
+                                                   u64 *__restrict__ sums, u64 *__restrict__ cnts, int rows_per_block, int lds_delta,
+                                                   const int *__restrict__ quiet) {
+  if (*quiet >= 0) return;  // converged earlier in this batch of launches
   constexpr int D = 192, ROWS = 256 * PPT, PITCH = A_DCH + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   double(*s_cent)[KCH] = reinterpret_cast<double(*)[KCH]>(s_raw);                       // [A_DCH][KCH]
@@ -440,7 +443,8 @@ __global__ void k_chunk_major(const int32_t *__restrict__ pts, int64_t n, int32_
 template <int D>
 __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w,
                                                     const Seg *__restrict__ segs, int k, const int32_t *__restrict__ assign,
-                                                    u64 *__restrict__ sums, u64 *__restrict__ cnts) {
+                                                    u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet) {
+  if (*quiet >= 0) return;
   extern __shared__ u64 s_acc[];  // [kk][D+1] when it fits, else straight to global
   int bx, nbx;
   const int seg = find_seg(segs, bx, nbx);
@@ -481,6 +485,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
 __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int nseg, int k, int d, u64 *__restrict__ sums,
                                                      u64 *__restrict__ cnts, double *__restrict__ cent, int it,
                                                      int *__restrict__ quiet_iter) {
+  if (*quiet_iter >= 0) return;
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
@@ -506,19 +511,19 @@ __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int
 
 template <int PPT>
 static void launch_assign192_t(dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w, Seg *ds,
-                               int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+                               int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192<PPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
-  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta);
+  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet);
 }
 static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w,
-                             Seg *ds, int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta) {
+                             Seg *ds, int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet) {
   switch (ppt) {
-    case 1: launch_assign192_t<1>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 2: launch_assign192_t<2>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 3: launch_assign192_t<3>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    case 4: launch_assign192_t<4>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
-    default: launch_assign192_t<5>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta); break;
+    case 1: launch_assign192_t<1>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
+    case 2: launch_assign192_t<2>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
+    case 3: launch_assign192_t<3>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
+    case 4: launch_assign192_t<4>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
+    default: launch_assign192_t<5>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
   }
 }
 
@@ -602,19 +607,19 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   TM_TRY(quiet.alloc(4));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
   int it = 0, issued = 0;
-  const int poll_every = 8;  // iterations after convergence are idempotent, so polling late costs time only
+  const int poll_every = 16;  // launches after convergence return at once (quiet flag), so polling late costs little
   while (issued < max_iter) {
     const int batch = std::min(poll_every, max_iter - issued);
     for (int b = 0; b < batch; b++, issued++) {
       if (d == 3) {
         if (fuse3) {
-          hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), quiet.as<int>());
         } else {
-          hipLaunchKernelGGL((k_assign<3, false>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>());
-          hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>());
+          hipLaunchKernelGGL((k_assign<3, false>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), quiet.as<int>());
+          hipLaunchKernelGGL(k_accumulate<3>, dim3(nblk), dim3(256), lds_acc, stream, pts, w, ds, k, assign, sums.as<u64>(), cnts.as<u64>(), quiet.as<int>());
         }
       } else {
-        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192);
+        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192, quiet.as<int>());
       }
       hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
