@@ -210,14 +210,32 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
     for (int e = threadIdx.x; e < kk * D; e += 256) s_cent[e] = cent[((int64_t)seg * k) * D + e];
     __syncthreads();
   }
+  // the next point's loads are issued before the current one is scored (each thread walks ~9 points; without this every step
+  // waits out a full memory round trip)
+  int32_t n3[3] = {0, 0, 0};
+  long long nwi = 1;
+  int nold = -1;
+  bool nvalid = false;
+  auto fetch = [&](int64_t it) {
+    const int64_t i = (it * nbx + bx) * 256 + threadIdx.x;
+    nvalid = it < iters && i < sg.count;
+    if (nvalid) {
+      n3[0] = pts[(sg.begin + i) * 3]; n3[1] = pts[(sg.begin + i) * 3 + 1]; n3[2] = pts[(sg.begin + i) * 3 + 2];
+      nwi = w ? (long long)w[sg.begin + i] : 1;
+      nold = assign[sg.begin + i];
+    }
+  };
+  fetch(0);
   for (int64_t it = 0; it < iters; it++) {
     const int64_t base = (it * nbx + bx) * 256;
     const int64_t i = base + threadIdx.x;
-    const bool valid = i < sg.count;
+    const bool valid = nvalid;
+    const int32_t p3[3] = {n3[0], n3[1], n3[2]};
+    const long long cur_w = nwi;
+    const int cur_old = nold;
+    fetch(it + 1);
     double bd = 0.0;
     int bc = -1;
-    int32_t p3[3] = {0, 0, 0};
-    if (D == 3 && valid) { p3[0] = pts[(sg.begin + i) * 3]; p3[1] = pts[(sg.begin + i) * 3 + 1]; p3[2] = pts[(sg.begin + i) * 3 + 2]; }
     for (int c0 = 0; c0 < kk; c0 += KCH) {
       const int nc = min(KCH, kk - c0);
       double s[KCH];
@@ -257,9 +275,9 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
       }
     }
     if (valid) {
-      if (assign[sg.begin + i] != bc) { assign[sg.begin + i] = bc; changed++; }
+      if (cur_old != bc) { assign[sg.begin + i] = bc; changed++; }
       if (FUSE_ACC) {
-        const long long wi = w ? (long long)w[sg.begin + i] : 1;
+        const long long wi = cur_w;
         u64 *acc = s_acc + ((threadIdx.x & (NCOPY - 1)) * kk + bc) * (D + 1);
         atomicAdd(&acc[D], (u64)wi);
 #pragma unroll
@@ -546,7 +564,8 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   // leave most of the chip idle while its few workgroups loop
   int64_t total_pts = 0;
   for (int s = 0; s < nseg; s++) total_pts += seg_count[s];
-  const int64_t rows_per_blk = std::max<int64_t>(256, (total_pts / 1024 + 255) / 256 * 256);
+  static const int blk_target = getenv("TM_KM_BLOCKS") ? atoi(getenv("TM_KM_BLOCKS")) : 768;
+  const int64_t rows_per_blk = std::max<int64_t>(256, (total_pts / blk_target + 255) / 256 * 256);
   int nblk = 0;
   for (int s = 0; s < nseg; s++) {
     hs[s].blk_first = nblk;
