@@ -26,8 +26,14 @@ __device__ __forceinline__ uint32_t sat_sub2(uint32_t a, uint32_t b) {  // psubs
 __device__ __forceinline__ uint32_t sq2(uint32_t d) {  // pmaddwd of a dword with itself, mod 2^32: v_dot2c_i32_i16
   return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, d), 0, false);
 }
-__device__ __forceinline__ uint32_t block_term(const uint4 a, const uint4 b) {
-  return sq2(sat_sub2(a.x, b.x)) + sq2(sat_sub2(a.y, b.y)) + sq2(sat_sub2(a.z, b.z)) + sq2(sat_sub2(a.w, b.w));
+__device__ __forceinline__ uint32_t sq2acc(uint32_t d, uint32_t acc) {  // acc + pmaddwd(d, d): v_dot2c accumulates in place
+  return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, d), (int)acc, false);
+}
+__device__ __forceinline__ uint32_t block_term(const uint4 a, const uint4 b, uint32_t acc = 0) {  // acc + the block's eight squared saturated differences
+  acc = sq2acc(sat_sub2(a.x, b.x), acc);
+  acc = sq2acc(sat_sub2(a.y, b.y), acc);
+  acc = sq2acc(sat_sub2(a.z, b.z), acc);
+  return sq2acc(sat_sub2(a.w, b.w), acc);
 }
 
 constexpr int MS_TB = 2;        // MS_TB x MS_TB tiles per workgroup share one sweep over the union of their windows
@@ -66,7 +72,16 @@ __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict
       a[t][0] = a[t][1] = a[t][2] = make_uint4(0, 0, 0, 0);
     }
   }
-  // union of the windows (1218-1221: oymn = max(0, dy - r - 1), oymx = min(sh - 8, dy + r); same in x)
+  // each tile's window (1218-1221: oymn = max(0, dy - r - 1), oymx = min(sh - 8, dy + r); same in x) as start + unsigned
+  // extent: one subtract-and-compare per axis in the loop; an absent tile gets an empty window
+  unsigned wy0[MS_TB * MS_TB], wyr[MS_TB * MS_TB], wx0[MS_TB * MS_TB], wxr[MS_TB * MS_TB];
+#pragma unroll
+  for (int t = 0; t < MS_TB * MS_TB; t++) {
+    const int y0 = max(0, dy[t] - r - 1), y1 = min(sh - 8, dy[t] + r), x0 = max(0, dx[t] - r - 1), x1 = min(sw - 8, dx[t] + r);
+    wy0[t] = (unsigned)y0; wyr[t] = valid[t] ? (unsigned)(y1 - y0) : 0u;
+    wx0[t] = valid[t] ? (unsigned)x0 : 0x40000000u; wxr[t] = (unsigned)(x1 - x0);
+  }
+  // union of the windows
   const int ly = std::min(by * MS_TB + MS_TB - 1, tm_h - 1) * 8, lx = std::min(bx * MS_TB + MS_TB - 1, tm_w - 1) * 8;
   const int uy0 = max(0, by * MS_TB * 8 - r - 1), uy1 = min(sh - 8, ly + r);
   const int ux0 = max(0, bx * MS_TB * 8 - r - 1), ux1 = min(sw - 8, lx + r);
@@ -84,25 +99,24 @@ __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict
     const uint4 b5 = r2 ? b5raw : zero4;
 #pragma unroll
     for (int t = 0; t < MS_TB * MS_TB; t++) {
-      const bool in = valid[t] && oy >= max(0, dy[t] - r - 1) && oy <= min(sh - 8, dy[t] + r) && ox >= max(0, dx[t] - r - 1) &&
-                      ox <= min(sw - 8, dx[t] + r);
+      const bool in = (unsigned)oy - wy0[t] <= wyr[t] && (unsigned)ox - wx0[t] <= wxr[t];
       // first block of the lane: for role 2 it is block 6 -> (a6 -sat b5) -sat b6; b5 = 0 for the other roles: a -sat 0 = a
       uint4 d;
       d.x = sat_sub2(a[t][0].x, b5.x); d.y = sat_sub2(a[t][0].y, b5.y); d.z = sat_sub2(a[t][0].z, b5.z); d.w = sat_sub2(a[t][0].w, b5.w);
-      uint32_t acc = block_term(d, b0);
       // second block: for lane 2 (first half, role 2) it is block 7, whose pair sums come back re-squared in the second half
       const uint32_t p0 = sq2(sat_sub2(a[t][1].x, b1.x)), p1 = sq2(sat_sub2(a[t][1].y, b1.y)), p2 = sq2(sat_sub2(a[t][1].z, b1.z)),
                      p3 = sq2(sat_sub2(a[t][1].w, b1.w));
-      acc += p0 + p1 + p2 + p3;
-      const uint32_t resq = sq2(p0) + sq2(p1) + sq2(p2) + sq2(p3);
-      acc += l2 ? resq : 0u;
+      const uint32_t resq = sq2acc(p3, sq2acc(p2, sq2acc(p1, sq2(p0))));
       // third block: block 5 of each half (role 1) never enters
       const uint32_t third = block_term(a[t][2], b2);
-      acc += r1 ? 0u : third;
+      uint32_t acc = block_term(d, b0, (p0 + p1) + (p2 + p3));
+      acc += (l2 ? resq : 0u) + (r1 ? 0u : third);
       acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
       acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
       acc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x141, 0xf, 0xf, false);  // row_half_mirror
-      const uint32_t err = acc + (uint32_t)(abs(ox - dx[t]) + abs(oy - dy[t]));  // manhattan penalty, 1236
+      uint32_t err;  // + manhattan penalty (1236): two v_sad_u32 (|ox - dx| + |oy - dy| + acc; all four coordinates are >= 0)
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(ox), "v"(dx[t]), "v"(acc));
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(oy), "v"(dy[t]), "v"(err));
       const bool take = in && err < best[t];  // candidates come in raster order: first minimum stays
       best[t] = take ? err : best[t];
       bpos[t] = take ? c : bpos[t];
