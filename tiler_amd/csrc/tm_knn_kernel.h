@@ -91,10 +91,12 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
                                                           const uint32_t *__restrict__ qkey, int64_t nq, int prune,
                                                           int *__restrict__ best_key, int *__restrict__ best_tile,
                                                           unsigned long long *__restrict__ visited, const int *__restrict__ tau,
-                                                          uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap) {
+                                                          uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap, int cand_k) {
   // TOPK: collection mode for the k-nearest search (ann_kdtree_short_search_multi, tilingencoder.pas:1563): every
   // query has a fixed threshold (an upper bound of its k-th smallest SSD); pruning uses it instead of a running best, and
-  // every row with d'' <= tau is appended to the query's candidate list (d'', sorted row).
+  // every row with d'' <= tau is appended to the query's candidate list (d'', sorted row).  The threshold also walks down a
+  // ladder tau0 * (8 - j) / 8 while the scan runs: once cand_k rows with d'' <= a rung have been seen, the k-th smallest SSD
+  // is at most that rung + 1 (parity), which becomes the threshold for the rest of the scan.
   constexpr int NQ = KNN_NQ, NW = KNN_NW, ND = KNN_ND;
   constexpr int KT = 6 + HT, KQ = 6 + HQ, HM = HT < HQ ? HT : HQ;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;  // database tiles carry their box (2*ND ints) too
@@ -207,6 +209,13 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   int smax_reg[NQ];
 #pragma unroll
   for (int s = 0; s < NQ; s++) smax_reg[s] = TOPK ? s_smax[wave][s] : INT_MAX;
+  int lad_step[NQ], lad_cnt[NQ][7];  // collection mode: rung spacing (tau0 / 8) and rows seen at or below rung j + 1
+#pragma unroll
+  for (int s = 0; s < NQ; s++) {
+    lad_step[s] = TOPK ? best[s] >> 3 : 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) lad_cnt[s][j] = 0;
+  }
   bool improved = false;
   while (cur_tile >= 0) {
     nstaged++;
@@ -276,14 +285,31 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
         }
         if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
           const int64_t q = qtile[s] * 32 + (lane & 31);
-          if (m <= best[s] && qtile[s] < n_qtiles && q < nq) {
+          const bool hit = m <= best[s] && qtile[s] < n_qtiles && q < nq;
+          if (hit) {
+            // rung j (1..7) = (8 - j) * step <= tau0 - j * tau0 / 8; the last database tile pads with copies of its last row,
+            // which must not be counted
+            const bool countable = (cur_tile & 0x7fffff) != (int)n_ttiles - 1;
 #pragma unroll
             for (int r = 0; r < 16; r++)
               if (d[r] <= best[s]) {
                 const int slot = atomicAdd(&cand_cnt[q], 1);
                 if (slot < cand_cap)
                   cand[q * cand_cap + slot] = make_uint2((unsigned)d[r], (unsigned)(((cur_tile & 0x7fffff) << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+#pragma unroll
+                for (int j = 1; j <= 7; j++) lad_cnt[s][j - 1] += (countable && d[r] <= (8 - j) * lad_step[s]) ? 1 : 0;
               }
+          }
+          if (__builtin_amdgcn_ballot_w64(hit)) {  // both lanes of a query take part: the counts of its two row halves add up
+            int rung = 0;
+#pragma unroll
+            for (int j = 1; j <= 7; j++) {
+              const int c = lad_cnt[s][j - 1] + __shfl_xor(lad_cnt[s][j - 1], 32);
+              if (c >= cand_k) rung = j;
+            }
+            // cand_k rows have d'' <= rung, i.e. SSD <= rung + 1: no row beyond that can be among the k nearest
+            const int t = (8 - rung) * lad_step[s] + 1;
+            if (rung > 0 && lad_step[s] > 0 && t < best[s]) { best[s] = t; improved = true; }
           }
           continue;
         }
@@ -339,7 +365,7 @@ struct KnnLaunch {
   const uint8_t *tpack; int64_t n_ttiles; KnnBoxes bx;
   const uint8_t *qpack; int64_t n_qtiles; const int16_t *queries; const uint32_t *qperm, *qkey; int64_t nq; int prune;
   int *best_key, *best_tile; unsigned long long *visited; hipStream_t stream;
-  const int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0;  // collection mode (k nearest)
+  const int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0, cand_k = 0;  // collection mode (k nearest)
 };
 
 // one per HT, defined in tm_knn_k<HT>.hip
@@ -349,7 +375,7 @@ template <int HT> void knn_launch_ht(int hq, const KnnLaunch &a);
 #define TM_KNN_LAUNCH(HT, HQ, TOPK)                                                                                        \
   hipLaunchKernelGGL((k_knn_mfma<HT, HQ, TOPK>), grid, block, 0, a.stream, a.tpack, a.n_ttiles, a.bx, a.qpack, a.n_qtiles,     \
                      a.queries, a.qperm, a.qkey, a.nq, a.prune, a.best_key, a.best_tile, a.visited, a.tau, a.cand, a.cand_cnt, \
-                     a.cand_cap)
+                     a.cand_cap, a.cand_k)
 #define TM_KNN_CASE(HT, HQ)                                                   \
   case HQ:                                                                    \
     if (a.tau) TM_KNN_LAUNCH(HT, HQ, true); else TM_KNN_LAUNCH(HT, HQ, false); \
