@@ -16,9 +16,10 @@ class OracleEncoder:
     oracle.  With motion prediction the whole clip is computed once and each rank only EXPOSES its shard (zeros / -1
     elsewhere, like the encoder), so what is tested is the orchestration: shard choice, merges, their order."""
 
-    def __init__(self, oracle, frames, palette_count, motion_radius=0, min_s=1.0):
+    def __init__(self, oracle, frames, palette_count, motion_radius=0, min_s=1.0, epu=False):
         self.o, self.frames, self.pc = oracle, frames, palette_count
         self.MotionPredictRadius = motion_radius
+        self.FrameTilingExtendedPaletteUsage = epu
         self.min_s = min_s
         self.shard = (0, frames.shape[0])
         self.st = {}
@@ -42,7 +43,8 @@ class OracleEncoder:
         step = int(step)
         mp = self.MotionPredictRadius > 0
         if step == 0:
-            self.st = oracle_pipeline.run(self.o, self.frames, palette_count=self.pc, min_s=self.min_s, motion_radius=self.MotionPredictRadius)
+            self.st = oracle_pipeline.run(self.o, self.frames, palette_count=self.pc, min_s=self.min_s, motion_radius=self.MotionPredictRadius,
+                                           epu=self.FrameTilingExtendedPaletteUsage)
         elif step == 1 and mp:
             self.arr[6] = self._mask(self.st["pm_err"].view(np.int32), 0)
             self.arr[4] = self._mask(self.st["pm_x"], 0)
@@ -55,13 +57,15 @@ class OracleEncoder:
             f0, n = self.shard
             sl = slice(f0 * per, (f0 + n) * per)
             q = self.frames.shape[0] * per
-            if mp:
-                assert n == 0 or f0 in self.st["keyframes"], "a shard must start on a key frame"
+            if mp or self.FrameTilingExtendedPaletteUsage:
+                assert not mp or n == 0 or f0 in self.st["keyframes"], "a shard must start on a key frame"
+                self.arr[2] = self._mask(self.st["tm_pal"].astype(np.int32), -1)
                 self.arr[0] = self._mask(self.st["tm_tile_recon"], -1)
                 self.arr[1] = self._mask(self.st["tm_err"].view(np.int32), -1)
-                self.arr[3] = self._mask(self.st["is_predicted"].astype(np.uint8), 0)
-                self.arr[4] = self._mask(self.st["pred_x"], 0)
-                self.arr[5] = self._mask(self.st["pred_y"], 0)
+                if mp:
+                    self.arr[3] = self._mask(self.st["is_predicted"].astype(np.uint8), 0)
+                    self.arr[4] = self._mask(self.st["pred_x"], 0)
+                    self.arr[5] = self._mask(self.st["pred_y"], 0)
             else:
                 self.arr[0] = torch.full((q,), -1, dtype=torch.int32)
                 self.arr[1] = torch.full((q,), -1, dtype=torch.int32)
@@ -76,7 +80,8 @@ class OracleEncoder:
             nu, rep, order, use, remap = self.o.dedup(self.st["pal_px"], hist)
             self.final = dict(T=nu, use=use, tm=np.where(tm >= 0, remap[np.maximum(tm, 0)], -1).astype(np.int32),
                               pred=self.arr[3].numpy().copy() if mp else None, px=self.arr[4].numpy().copy() if mp else None,
-                              py=self.arr[5].numpy().copy() if mp else None, err=self.arr[1].numpy().copy())
+                              py=self.arr[5].numpy().copy() if mp else None, err=self.arr[1].numpy().copy(),
+                              pal=self.arr[2].numpy().copy() if self.FrameTilingExtendedPaletteUsage else None)
 
     def DeviceArray(self, which):
         return self.arr[int(which)]
@@ -85,7 +90,7 @@ class OracleEncoder:
         pass
 
 
-def _worker(rank, world, port, q, motion_radius=0):
+def _worker(rank, world, port, q, motion_radius=0, epu=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -94,15 +99,15 @@ def _worker(rank, world, port, q, motion_radius=0):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     oracle = Oracle(os.path.join(ROOT, "oracle", "libtm_oracle.so"))
     frames = synth.video(9, 48, 32, cut=3) if motion_radius else synth.video(5, 48, 32)
-    enc = OracleEncoder(oracle, frames, 2, motion_radius, 0.1 if motion_radius else 1.0)
+    enc = OracleEncoder(oracle, frames, 2, motion_radius, 0.1 if motion_radius else 1.0, epu)
     distributed.run_all(enc, frames.shape[0], rank, world)
     q.put((rank, enc.final))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("motion_radius", [0, 8])
-def test_two_ranks_equal_one(oracle, motion_radius):
+@pytest.mark.parametrize("motion_radius,epu", [(0, False), (8, False), (0, True), (8, True)])
+def test_two_ranks_equal_one(oracle, motion_radius, epu):
     import torch.multiprocessing as mp
     from tests import oracle_pipeline
     from tiler_amd import synth
@@ -112,7 +117,7 @@ def test_two_ranks_equal_one(oracle, motion_radius):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, motion_radius)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, motion_radius, epu)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -120,15 +125,17 @@ def test_two_ranks_equal_one(oracle, motion_radius):
         p.join(timeout=60)
         assert p.exitcode == 0
     if motion_radius:
-        exp = oracle_pipeline.run(oracle, synth.video(9, 48, 32, cut=3), palette_count=2, min_s=0.1, motion_radius=motion_radius)
+        exp = oracle_pipeline.run(oracle, synth.video(9, 48, 32, cut=3), palette_count=2, min_s=0.1, motion_radius=motion_radius, epu=epu)
         assert len(exp["keyframes"]) >= 3 and exp["is_predicted"].any()
     else:
-        exp = oracle_pipeline.run(oracle, synth.video(5, 48, 32), palette_count=2)
+        exp = oracle_pipeline.run(oracle, synth.video(5, 48, 32), palette_count=2, epu=epu)
     for rank, fin in res:
         assert fin["T"] == exp["final_T"]
         assert np.array_equal(fin["use"], exp["final_use"])
         assert np.array_equal(fin["tm"], exp["final_tm_tile"])
         assert np.array_equal(fin["err"].view(np.uint32), exp["tm_err"])
+        if epu:
+            assert np.array_equal(fin["pal"], exp["tm_pal"])
         if motion_radius:
             assert np.array_equal(fin["pred"].astype(bool), exp["is_predicted"])
             assert np.array_equal(fin["px"], exp["pred_x"]) and np.array_equal(fin["py"], exp["pred_y"])

@@ -230,3 +230,77 @@ def test_device_array_aliases_encoder_memory():
     assert np.array_equal(enc.TileMap(1)["TileIdx"], before + 1000)
     dist.destroy_process_group()
     enc.close()
+
+
+class _FakeDist:
+    """torch.distributed stand-in for ranks that are threads of one process sharing one GPU: all_reduce with MAX / SUM over the
+    tensors the ranks pass in the same call order (what RCCL would do across GPUs)"""
+
+    class ReduceOp:
+        MAX, SUM = "max", "sum"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.local = threading.local()
+
+    def all_reduce(self, t, op=None, group=None):
+        r = self.local.rank
+        self.slots[r] = t
+        self.bar.wait()
+        if r == 0:
+            acc = self.slots[0].clone()
+            for o in self.slots[1:]:
+                acc = torch.maximum(acc, o) if op == "max" else acc + o
+            for o in self.slots:
+                o.copy_(acc)
+            torch.cuda.synchronize()
+        self.bar.wait()
+
+
+@pytest.mark.parametrize("radius,epu", [(0, False), (0, True), (8, False), (8, True)])
+def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu):
+    """tiler_amd.distributed.run_all with REAL encoders: two ranks (threads, one GPU) shard PredictMotion / Reconstruct, merge through
+    all-reduces, and must end with exactly the single-process result"""
+    import threading
+    from tiler_amd import synth, distributed
+    from tiler_amd.encoder import TilingEncoder
+    frames = synth.video(12, 64, 48, cut=3)
+    kw = dict(PaletteCount=3, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, FrameTilingExtendedPaletteUsage=epu, GlobalTilingTileCount=150)
+    ref = _run_encoder(frames, **kw)
+    want = (np.stack([ref.TileMap(f) for f in range(12)]), ref.Tiles())
+    ref.close()
+    fake = _FakeDist(2)
+    monkeypatch.setattr(distributed, "dist", fake)
+    out, errs = [None, None], []
+
+    def rank_main(r):
+        try:
+            fake.local.rank = r
+            torch.cuda.set_device(0)
+            enc = TilingEncoder()
+            enc.LoadDefaultSettings()
+            for k, v in kw.items():
+                setattr(enc, k, v)
+            enc.SetVideo(64, 48, 24.0, 12)
+            for f in range(12):
+                enc.PushFrame(f, frames[f])
+            distributed.run_all(enc, 12, r, 2)
+            out[r] = (np.stack([enc.TileMap(f) for f in range(12)]), enc.Tiles())
+            enc.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            fake.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for r in range(2):
+        assert np.array_equal(out[r][0], want[0])
+        for a, b in zip(out[r][1], want[1]):
+            assert np.array_equal(a, b)

@@ -4,7 +4,8 @@ Where the path shards: the frame tiles are independent qu
 TFrame.Reconstruct (DoXY, tilingencoder.pas:1464-1659), >95 % of the work.  Every rank therefore runs Load..Dither on
 the whole clip (small, deterministic, bit-identical on all ranks -- no collective needed to agree on the global tile
 set, palettes or dithered tiles), matches only ITS frame range against the full database, and the per-frame results
-are merged with one all-reduce(MAX) (other ranks hold -1) over RCCL/xGMI: 2 x Q x 4 bytes.  Reindex then runs
+are merged with one all-reduce(MAX) (other ranks hold -1) over RCCL/xGMI: 2 x Q x 4 bytes (3 x with the extended-palette
+re-rank, whose PalIdx is per item).  Reindex then runs
 everywhere on the merged tile maps.  With motion prediction on, PredictMotion is sharded by frame too (merged with
 all-reduce(SUM), other ranks hold 0) and Reconstruct by whole key-frame groups, the unit that chains (1496).  The collective calls go through `torch.distributed`, so the same code is
 exercised on CPU with gloo in tests/test_distributed_cpu.py (there with an oracle-backed stand-in for the encoder).
@@ -51,7 +52,10 @@ def run_all(enc, nframes, rank=0, world=1, group=None):
         enc.SetQueryShard(first, count)
     enc.Run(S.esReconstruct)
     if world > 1:
-        for which in (0, 1):  # TileIdx, error: owner holds values >= 0 (errors < 2^31) or -1 (perfect prediction), everyone else -1
+        # TileIdx, error: owner holds values >= 0 (errors < 2^31) or -1 (perfect prediction), everyone else -1.  With
+        # FrameTilingExtendedPaletteUsage the item's palette is the re-rank's own choice (1591-1608), not the tile's: merged the same way
+        epu = bool(getattr(enc, "FrameTilingExtendedPaletteUsage", False))
+        for which in (0, 1, 2) if epu else (0, 1):
             dist.all_reduce(enc.DeviceArray(which), op=dist.ReduceOp.MAX, group=group)
         if motion:
             for which in (3, 4, 5):  # IsPredicted, PredictedX/Y of the redo: everyone else 0
