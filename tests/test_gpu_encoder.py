@@ -260,10 +260,10 @@ class _FakeDist:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("radius,epu", [(0, False), (0, True), (8, False), (8, True)])
-def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu):
+@pytest.mark.parametrize("radius,epu,world", [(0, False, 2), (0, True, 2), (8, False, 2), (8, True, 2), (8, True, 3), (8, False, 6), (0, False, 5)])
+def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
     """tiler_amd.distributed.run_all with REAL encoders: two ranks (threads, one GPU) shard PredictMotion / Reconstruct, merge through
-    all-reduces, and must end with exactly the single-process result"""
+    all-reduces, and must end with exactly the single-process result.  With 6 ranks on 4 key frames some ranks own no frame at all."""
     import threading
     from tiler_amd import synth, distributed
     from tiler_amd.encoder import TilingEncoder
@@ -272,9 +272,9 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu):
     ref = _run_encoder(frames, **kw)
     want = (np.stack([ref.TileMap(f) for f in range(12)]), ref.Tiles())
     ref.close()
-    fake = _FakeDist(2)
+    fake = _FakeDist(world)
     monkeypatch.setattr(distributed, "dist", fake)
-    out, errs = [None, None], []
+    out, errs = [None] * world, []
 
     def rank_main(r):
         try:
@@ -287,20 +287,20 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu):
             enc.SetVideo(64, 48, 24.0, 12)
             for f in range(12):
                 enc.PushFrame(f, frames[f])
-            distributed.run_all(enc, 12, r, 2)
+            distributed.run_all(enc, 12, r, world)
             out[r] = (np.stack([enc.TileMap(f) for f in range(12)]), enc.Tiles())
             enc.close()
         except Exception as e:  # noqa: BLE001
             errs.append(e)
             fake.bar.abort()
 
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
         t.join(timeout=120)
     assert not errs, errs
-    for r in range(2):
+    for r in range(world):
         assert np.array_equal(out[r][0], want[0])
         for a, b in zip(out[r][1], want[1]):
             assert np.array_equal(a, b)
