@@ -6,6 +6,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
+    variant = os.environ.get("TM_LIB_VARIANT")  # development builds of tools/build_variant.sh
+    if variant:
+        return os.path.join(_HERE, "lib", "variants", "libtilemotion_%s.so" % variant)
     return os.path.join(_HERE, "lib", "libtilemotion.so")
 
 

@@ -670,8 +670,8 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
-  TM_TRY(ix->counters.alloc(32));
-  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 32, stream));
+  TM_TRY(ix->counters.alloc(128));  // [4..15]: phase stamps of a TM_KNN_STAMPS diagnostic build
+  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 128, stream));
   const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
   TM_HIP(hipEventRecord(ix->ev0, stream));
   int *bt = ix->best_tile.as<int>();
@@ -697,9 +697,9 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     TM_HIP(hipGetLastError());
   }
   int flag = 0;
-  unsigned long long cnt[4] = {0, 0, 0, 0};
+  unsigned long long cnt[16] = {0};
   TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 32, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 128, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   float ms = 0;
@@ -713,6 +713,13 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     fprintf(stderr, "[tm_knn] kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (workgroups staged %.3f%% of tiles), %lld tie settlements\n", ms,
             100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt,
             100.0 * (double)cnt[3] / ((double)((nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW)) * (double)ntt), (long long)ix->last_ties);
+#if TM_KNN_STAMPS
+  {
+    static const char *names[10] = {"prologue", "wait data", "barrier", "issue", "box re-test", "MFMA + epilogue", "best refresh", "total", "next tile", "(list builds)"};
+    for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn stamps] %-18s %8.1f cycles per staged tile per wave (%5.1f %%)\n", names[i],
+                                        (double)cnt[4 + i] / ((double)cnt[3] * KNN_NW), 100.0 * (double)cnt[4 + i] / (double)cnt[11]);
+  }
+#endif
   return TM_OK;
 }
 

@@ -11,8 +11,33 @@ namespace tmx {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int KNN_NQ = 2;  // query sub-tiles (32 queries each) per wave
-constexpr int KNN_NW = 2;  // waves per workgroup (128 queries; four workgroups share a CU)
+// Shape of a workgroup (build-time; measured on the 720p x 300 clip): NQ=2, NW=2 at two waves per SIMD is the
+// fastest; NQ=1, NW=4 (same 128 queries per staged tile, 168 registers, three waves per SIMD) is 11 % slower pruned and 6 % dense.
+#ifndef TM_KNN_NQ
+#define TM_KNN_NQ 2
+#endif
+#ifndef TM_KNN_NW
+#define TM_KNN_NW 2
+#endif
+#ifndef TM_KNN_OCC
+#define TM_KNN_OCC 2
+#endif
+#ifndef TM_KNN_NBUF
+#define TM_KNN_NBUF 3
+#endif
+#ifndef TM_KNN_STAMPS
+#define TM_KNN_STAMPS 0  // diagnostic build: s_memtime stamps around the phases of the scan loop, summed into visited[2..9]
+#endif
+#if TM_KNN_STAMPS
+#define TM_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define TM_STAMP(i) do { } while (0)
+#endif
+#ifndef TM_KNN_DIRECT
+#define TM_KNN_DIRECT 0  // experiment: 1 = tiles are read from global memory (L2) as MFMA operands, no LDS ring (use with NW=1)
+#endif
+constexpr int KNN_NQ = TM_KNN_NQ;  // query sub-tiles (32 queries each) per wave
+constexpr int KNN_NW = TM_KNN_NW;  // waves per workgroup (NQ * NW * 32 = 128 queries share every staged tile)
 
 // Database tiles (32 rows): [6 low chunks | HT high chunks] x [64 lanes] x 16 B, then 32 u32 norms |t-c|^2.
 // Query tiles (32 queries): [6 low chunks | HQ high chunks] of the NEGATED centred values, then 32 u32 (|q-c|^2 >> 1).
@@ -51,6 +76,27 @@ __device__ __forceinline__ bool knn_box_may_matter(const int *tlo, const int *th
   return lb <= (int)(((unsigned)smax + 1u) >> 2);
 }
 
+// max over the 64 lanes of a wave: DPP inside rows of 16, then one lane of each row through SGPRs
+__device__ __forceinline__ int knn_wave_max(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));  // row_mirror
+  return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
+             max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+
+// s_waitcnt vmcnt(behind * NST) for a run-time `behind` in [0, MAXB]: this wave's pieces of the oldest tile in flight have landed
+template <int NST, int MAXB>
+__device__ __forceinline__ void knn_wait_vm(int behind) {
+  if constexpr (MAXB == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (behind >= MAXB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXB * NST) : "memory");
+    else knn_wait_vm<NST, MAXB - 1>(behind);
+  }
+}
+
 // Compacts into s_list / s_mask the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
 // workgroup can still use (bit = wave * NQ + sub-tile), judged with that sub-tile's largest running best (d'' = SSD -
 // parity, so SSD <= d'' + 1).  Kept out of line so its registers do not count against the MFMA loop.
@@ -85,7 +131,7 @@ __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ 
 }
 
 template <int HT, int HQ, bool TOPK>
-__global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__restrict__ tpack, int64_t n_ttiles, KnnBoxes bx,
+__global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint8_t *__restrict__ tpack, int64_t n_ttiles, KnnBoxes bx,
                                                           const uint8_t *__restrict__ qpack, int64_t n_qtiles,
                                                           const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
                                                           const uint32_t *__restrict__ qkey, int64_t nq, int prune,
@@ -104,14 +150,18 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   constexpr int NT = NW * 64;
   constexpr int NST = (TILE_VEC + NT - 1) / NT;       // LDS-DMA pieces (64 lanes x 16 B) each wave issues per tile
   constexpr int BUF_BYTES = NST * NW * 1024;          // >= T_BYTES: the tail is padding that clamped lanes land in
-  constexpr int NBUF = 3;                             // ring: tile i is read while tiles i+1 and i+2 are in flight
-  __shared__ __attribute__((aligned(16))) uint8_t lds[NBUF][BUF_BYTES];
+  constexpr int NBUF = TM_KNN_NBUF;                   // ring: tile i is read while tiles i+1 .. i+NBUF-1 are in flight
+  __shared__ __attribute__((aligned(16))) uint8_t lds[TM_KNN_DIRECT ? 1 : NBUF][TM_KNN_DIRECT ? 16 : BUF_BYTES];
   __shared__ int s_smax[NW][NQ];     // largest running best of each query sub-tile
   __shared__ int s_box[2][NW][NQ][ND];  // [lo|hi][wave][sub-tile][dim] query boxes
   __shared__ int s_ctl[4];
   __shared__ uint16_t s_list[KNN_CHUNK];
   __shared__ uint8_t s_mask[KNN_CHUNK];  // which sub-tiles wanted the listed tile (bit = wave * NQ + sub-tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+#if TM_KNN_STAMPS
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_begin, st_build = 0;
+#endif
   constexpr int QT_PER_WG = NW * NQ;
   // Workgroup -> query tile: identity.  XCD-contiguous ranges were measured (profiles/README.md): whole ranges per XCD
   // lose 25 % to load imbalance (window sizes vary along the curve), runs of 32 per XCD tie with identity.
@@ -121,7 +171,7 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   int64_t qtile[NQ];
 #pragma unroll
   for (int s = 0; s < NQ; s++) {
-    qtile[s] = wgt * QT_PER_WG + wave * NQ + s;
+    qtile[s] = wgt * QT_PER_WG + s * NW + wave;  // interleaved: curve neighbours (which want the same tiles) sit in different waves
     const int64_t qt = qtile[s] < n_qtiles ? qtile[s] : n_qtiles - 1;
     const uint8_t *qb = qpack + qt * (int64_t)Q_BYTES;
 #pragma unroll
@@ -133,15 +183,15 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   }
   // bounding boxes: per query sub-tile (lanes 0..31 / 32..63 hold sub-tile 0 / 1) and for the whole workgroup
   {
-    static_assert(NQ == 2, "lane <-> query mapping below assumes two sub-tiles per wave");
-    const int64_t p = min(wgt * QT_PER_WG * 32 + (int64_t)wave * NQ * 32 + lane, nq - 1);
+    static_assert(NQ == 1 || NQ == 2, "lane <-> query mapping: one sub-tile (both half-waves hold it) or two per wave");
+    const int64_t p = min((wgt * QT_PER_WG + (NQ == 2 ? half : 0) * NW + wave) * 32 + (lane & 31), nq - 1);
     const int16_t *row = queries + (int64_t)qperm[p] * 192;
 #pragma unroll
     for (int d = 0; d < ND; d++) {
       int lo = row[bx.col[d]], hi = lo;
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-      if ((lane & 31) == 0) { s_box[0][wave][half][d] = lo; s_box[1][wave][half][d] = hi; }
+      if ((lane & 31) == 0 && (NQ == 2 || half == 0)) { s_box[0][wave][NQ == 2 ? half : 0][d] = lo; s_box[1][wave][NQ == 2 ? half : 0][d] = hi; }
     }
   }
   if (tid == 0) {  // position of the workgroup's first query on the curve: last tile whose first key <= it
@@ -157,18 +207,21 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   if (TOPK) {  // fixed sub-tile maxima
 #pragma unroll
     for (int s = 0; s < NQ; s++) {
-      int smax = best[s];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+      const int smax = knn_wave_max(best[s]);
       if (lane == 0) s_smax[wave][s] = smax;
     }
     __syncthreads();
   }
-  const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)
+  // box re-test, lane-parallel: lane 8 * s + d holds dimension d of sub-tile s of this wave (other lanes hold an empty box: gap 0)
+  const int bx_s = lane >> 3, bx_d = lane & 7;
+  const bool bx_on = bx_s < NQ && bx_d < ND;
+  const int bx_qlo = bx_on ? s_box[0][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MIN / 2;
+  const int bx_qhi = bx_on ? s_box[1][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MAX / 2;
+  const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
-  int phase = 0, r0next = r0a, chunk_base = 0, list_n = 0, list_i = 0;
+  int phase = 0, r0next = r0a, chunk_base = 0, list_n = 0, list_i = 0, list_pre = 0;  // list_pre: entry list_i, read one call early
   auto next_tile = [&]() -> int {  // called by every thread at the same point (contains barriers)
     while (true) {
       if (phase == 0) {
@@ -177,12 +230,25 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
         chunk_base = -KNN_CHUNK;
         list_n = list_i = 0;
       }
-      if (list_i < list_n) { const int k = list_i++; return (chunk_base + s_list[k]) | ((int)s_mask[k] << 23); }
+      if (list_i < list_n) {
+        const int r = chunk_base + list_pre;
+        list_i++;
+        const int k = min(list_i, KNN_CHUNK - 1);  // the entry of the next call: its LDS latency hides behind this tile's work
+        list_pre = (int)s_list[k] | ((int)s_mask[k] << 23);
+        return r;
+      }
       chunk_base += KNN_CHUNK;
       if (chunk_base >= n_ttiles) return -1;
+#if TM_KNN_STAMPS
+      const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+#endif
       list_n = knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0], &s_box[1][0][0][0],
                               &s_smax[0][0], s_list, s_mask, &s_ctl[1]);
+#if TM_KNN_STAMPS
+      st_build += __builtin_amdgcn_s_memtime() - tb_;
+#endif
       list_i = 0;
+      list_pre = (int)s_list[0] | ((int)s_mask[0] << 23);
     }
   };
 
@@ -191,19 +257,22 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   auto issue = [&](int tile, int buf) {
     const uint8_t *src = tpack + (tile & 0x7fffff) * (int64_t)T_BYTES;
 #pragma unroll
-    for (int i = 0; i < NST; i++) {
+    for (int i = 0; i < (TM_KNN_DIRECT ? 0 : NST); i++) {
       const int piece = wave + i * NW;
       const int v = min(piece * 64 + lane, TILE_VEC - 1);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + v * 16),
                                        (__attribute__((address_space(3))) void *)(&lds[buf][piece * 1024]), 16, 0, 0);
     }
   };
-  int cur_tile = next_tile(), nxt_tile = -1;
-  if (cur_tile >= 0) {
-    issue(cur_tile, 0);
-    nxt_tile = next_tile();
-    if (nxt_tile >= 0) issue(nxt_tile, 1);
+  // ring of NBUF LDS buffers: tile q[0] is read while tiles q[1..NBUF-2] are in flight
+  int q[NBUF - 1];
+  bool more = true;  // the candidate stream has not ended
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; i++) {
+    q[i] = more ? next_tile() : -1;
+    if (q[i] >= 0) issue(q[i], i); else more = false;
   }
+  int cur_tile = q[0];
 
   int cur = 0;
   int smax_reg[NQ];
@@ -217,30 +286,55 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
     for (int j = 0; j < 7; j++) lad_cnt[s][j] = 0;
   }
   bool improved = false;
+  TM_STAMP(0);
   while (cur_tile >= 0) {
     nstaged++;
     // tile `cur_tile` landed?  Only this wave's own pieces are counted; the barrier publishes everyone's.  It also
     // fences the previous iteration's LDS reads (buffer reuse) and s_smax writes.
-    if (nxt_tile >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int nn_tile = nxt_tile >= 0 ? next_tile() : -1;  // two ahead, chosen with the bests as they are now
-    if (nn_tile >= 0) issue(nn_tile, cur >= 1 ? cur - 1 : NBUF - 1);  // buffer (cur + 2) % 3: read last in the previous iteration
-    const uint8_t *L = lds[cur];
+    if (!TM_KNN_DIRECT) {
+      int behind = 0;  // tiles in flight behind the current one
+#pragma unroll
+      for (int i = 1; i < NBUF - 1; i++) behind += q[i] >= 0 ? 1 : 0;
+      knn_wait_vm<NST, NBUF - 2>(behind);
+    }
+    TM_STAMP(1);
+    if (!TM_KNN_DIRECT || NW > 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    TM_STAMP(2);
+    int nn_tile = -1;  // NBUF - 1 ahead, chosen with the bests as they are now
+    if (more) { nn_tile = next_tile(); more = nn_tile >= 0; }
+    TM_STAMP(7);
+    if (nn_tile >= 0) issue(nn_tile, cur >= 1 ? cur - 1 : NBUF - 1);  // buffer (cur + NBUF - 1) % NBUF: read last in the previous iteration
+    TM_STAMP(3);
+    const uint8_t *L = TM_KNN_DIRECT ? tpack + (cur_tile & 0x7fffff) * (int64_t)T_BYTES : lds[cur];
     // sub-tile level skip: the list round already judged every (tile, sub-tile) pair with the bests of that time;
     // pairs it kept are re-judged against the current best with the tile's box (it rides in LDS behind the norms)
     bool do_sub[NQ];
     bool do_tile = false;
-#pragma unroll
-    for (int s = 0; s < NQ; s++) {
-      do_sub[s] = ((cur_tile >> (23 + wave * NQ + s)) & 1) != 0;
-      if (do_sub[s] && prune) {
+    {
+      unsigned long long ok = ~0ull;
+      if (prune) {
         const int *tb = reinterpret_cast<const int *>(L + KT * 1024 + 128);
-        do_sub[s] = knn_box_may_matter(tb, tb + ND, &s_box[0][wave][s][0], &s_box[1][wave][s][0], smax_reg[s]);
+        const int tlo = tb[bx_on ? bx_d : 0], thi = tb[ND + (bx_on ? bx_d : 0)];
+        const int g = max(0, max(tlo - bx_qhi, bx_qlo - thi)) >> 1;
+        int lb = g * g;
+        lb += __builtin_amdgcn_update_dpp(0, lb, 0xB1, 0xf, 0xf, false);   // the 8 lanes of a sub-tile: quad, quad, half row
+        lb += __builtin_amdgcn_update_dpp(0, lb, 0x4E, 0xf, 0xf, false);
+        lb += __builtin_amdgcn_update_dpp(0, lb, 0x141, 0xf, 0xf, false);
+        int thr = smax_reg[0];
+#pragma unroll
+        for (int s = 1; s < NQ; s++) thr = bx_s == s ? smax_reg[s] : thr;
+        ok = __builtin_amdgcn_ballot_w64(lb <= (int)(((unsigned)thr + 1u) >> 2));
       }
-      do_tile |= do_sub[s];
+#pragma unroll
+      for (int s = 0; s < NQ; s++) {
+        do_sub[s] = ((cur_tile >> (23 + wave * NQ + s)) & 1) != 0 && ((ok >> (8 * s)) & 1) != 0;
+        do_tile |= do_sub[s];
+      }
     }
+    TM_STAMP(4);
     if (do_tile) {
       // accumulator row of register r: (r&3) + 8*(r>>2) + 4*half  -> norms as four 16-byte reads
       int nt[16];
@@ -326,20 +420,22 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
         }
       }
     }
+    TM_STAMP(5);
     if (__builtin_amdgcn_ballot_w64(improved)) {  // some lane has a new best: refresh the sub-tile maxima
       improved = false;
 #pragma unroll
       for (int s = 0; s < NQ; s++) {
-        int smax = best[s];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) smax = max(smax, __shfl_xor(smax, o));
+        const int smax = knn_wave_max(best[s]);
         smax_reg[s] = smax;
         if (lane == 0) s_smax[wave][s] = smax;
       }
     }
+    TM_STAMP(6);
     cur = cur == NBUF - 1 ? 0 : cur + 1;
-    cur_tile = nxt_tile;
-    nxt_tile = nn_tile;
+#pragma unroll
+    for (int i = 0; i < NBUF - 2; i++) q[i] = q[i + 1];
+    q[NBUF - 2] = nn_tile;
+    cur_tile = q[0];
   }
 
 #pragma unroll
@@ -359,6 +455,14 @@ __global__ __launch_bounds__(KNN_NW * 64, 2) void k_knn_mfma(const uint8_t *__re
   }
   if (visited && lane == 0) atomicAdd(visited, (unsigned long long)nvisit);
   if (visited && tid == 0) atomicAdd(visited + 1, (unsigned long long)nstaged);
+#if TM_KNN_STAMPS
+  if (visited && lane == 0) {
+    for (int i = 0; i < 7; i++) atomicAdd(visited + 2 + i, st_acc[i]);
+    atomicAdd(visited + 9, __builtin_amdgcn_s_memtime() - st_begin);
+    atomicAdd(visited + 10, st_acc[7]);
+    atomicAdd(visited + 11, st_build);
+  }
+#endif
 }
 
 struct KnnLaunch {
