@@ -718,6 +718,8 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     static const char *names[10] = {"prologue", "wait data", "barrier", "issue", "box re-test", "MFMA + epilogue", "best refresh", "total", "next tile", "(list builds)"};
     for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn stamps] %-18s %8.1f cycles per staged tile per wave (%5.1f %%)\n", names[i],
                                         (double)cnt[4 + i] / ((double)cnt[3] * KNN_NW), 100.0 * (double)cnt[4 + i] / (double)cnt[11]);
+    fprintf(stderr, "[tm_knn stamps] per staged tile and wave: %.3f sub-tiles listed, %.3f evaluated, wave idle on %.1f %% of staged tiles\n",
+            (double)cnt[14] / ((double)cnt[3] * KNN_NW), (double)cnt[2] / ((double)cnt[3] * KNN_NW), 100.0 * (double)cnt[15] / ((double)cnt[3] * KNN_NW));
   }
 #endif
   return TM_OK;

@@ -55,8 +55,14 @@ constexpr int KNN_NW = TM_KNN_NW;  // waves per workgroup (NQ * NW * 32 = 128 qu
 // skipped when bound > best + 1); when a second tile reaches the same value the lane raises a tie flag and the refine
 // stage settles the lowest-index rule.
 constexpr int KNN_ND = 6;        // bounding-box columns
-constexpr int KNN_K0 = 8;        // tiles visited first, around the workgroup's position on the curve
-constexpr int KNN_CHUNK = 1024;  // tiles tested per compaction round (bests are re-read for each round)
+#ifndef TM_KNN_K0
+#define TM_KNN_K0 8
+#endif
+constexpr int KNN_K0 = TM_KNN_K0;        // tiles visited first, around the workgroup's position on the curve
+#ifndef TM_KNN_CHUNK
+#define TM_KNN_CHUNK 1024
+#endif
+constexpr int KNN_CHUNK = TM_KNN_CHUNK;  // tiles tested per compaction round (bests are re-read for each round)
 
 struct KnnBoxes {
   const int *lo, *hi;   // [KNN_ND][n_ttiles] bounding boxes of the database tiles
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
 #if TM_KNN_STAMPS
   const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_begin, st_build = 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_begin, st_build = 0, st_listed = 0, st_idle = 0;
 #endif
   constexpr int QT_PER_WG = NW * NQ;
   // Workgroup -> query tile: identity.  XCD-contiguous ranges were measured (profiles/README.md): whole ranges per XCD
@@ -221,13 +227,14 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   long long nvisit = 0, nstaged = 0;
 
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
-  int phase = 0, r0next = r0a, chunk_base = 0, list_n = 0, list_i = 0, list_pre = 0;  // list_pre: entry list_i, read one call early
+  // Chunks are visited outwards from the one the workgroup sits in (home, home + 1, home - 1, ...): near tiles tighten the bests first.
+  const int n_chunks = (int)((n_ttiles + KNN_CHUNK - 1) / KNN_CHUNK), home_chunk = r0a / KNN_CHUNK;
+  int phase = 0, r0next = r0a, chunk_base = 0, chunk_j = 0, chunks_done = 0, list_n = 0, list_i = 0, list_pre = 0;  // list_pre: entry list_i, read one call early
   auto next_tile = [&]() -> int {  // called by every thread at the same point (contains barriers)
     while (true) {
       if (phase == 0) {
         if (r0next < r0b) return (r0next++) | (0xff << 23);
         phase = 1;
-        chunk_base = -KNN_CHUNK;
         list_n = list_i = 0;
       }
       if (list_i < list_n) {
@@ -237,8 +244,14 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
         list_pre = (int)s_list[k] | ((int)s_mask[k] << 23);
         return r;
       }
-      chunk_base += KNN_CHUNK;
-      if (chunk_base >= n_ttiles) return -1;
+      if (chunks_done >= n_chunks) return -1;
+      int c;
+      do {  // j = 0, 1, 2, 3, ... -> home, home + 1, home - 1, home + 2, ...; out-of-range ones are skipped
+        c = home_chunk + ((chunk_j & 1) ? (chunk_j + 1) >> 1 : -(chunk_j >> 1));
+        chunk_j++;
+      } while (c < 0 || c >= n_chunks);
+      chunks_done++;
+      chunk_base = c * KNN_CHUNK;
 #if TM_KNN_STAMPS
       const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -335,6 +348,14 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       }
     }
     TM_STAMP(4);
+#if TM_KNN_STAMPS
+    {
+      int listed = 0;
+      for (int s = 0; s < NQ; s++) listed += (cur_tile >> (23 + wave * NQ + s)) & 1;
+      st_listed += listed;
+      st_idle += do_tile ? 0 : 1;
+    }
+#endif
     if (do_tile) {
       // accumulator row of register r: (r&3) + 8*(r>>2) + 4*half  -> norms as four 16-byte reads
       int nt[16];
@@ -461,6 +482,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
     atomicAdd(visited + 9, __builtin_amdgcn_s_memtime() - st_begin);
     atomicAdd(visited + 10, st_acc[7]);
     atomicAdd(visited + 11, st_build);
+    atomicAdd(visited + 12, st_listed);
+    atomicAdd(visited + 13, st_idle);
   }
 #endif
 }
