@@ -161,6 +161,59 @@ static void lab_core(int ir, int ig, int ib, int det, float *ol, float *oa, floa
   *ob = (float)(200 * (double)(float)(y - z));
 }
 
+/* The form the HIP kernels execute (tm_device.h): no division.  x^(-1/3) by four Newton steps in multiplications and fma, the root as
+ * x a a with one multiplicative correction; the / 0.17697 of utils.pas:391-393 as a reciprocal product refined by two fma.  It is NOT
+ * a definition of its own: tmo_lab_domain_check proves it equal to tmo_rgb_to_lab_det on every one of the 2^24 colours. */
+static double cbrt_mul(double x) {
+  union { double d; uint64_t u; } c;
+  c.d = x;
+  c.u = 0x553EF0FF289DD796ull - c.u / 3; /* exponent / -3 seed */
+  double a = c.d;
+  for (int i = 0; i < 4; i++) {
+    double e = fma(-x, a * a * a, 1.0);
+    a = fma(a * e, 1.0 / 3, a);
+  }
+  double y = x * a * a;
+  return fma(fma(-y * y, y, x) * (a * a), 1.0 / 3, y);
+}
+
+static double div_k(double n) {
+  const double k = 1.0 / 0.17697;
+  double q = n * k;
+  return fma(fma(-q, 0.17697, n), k, q);
+}
+
+void tmo_rgb_to_lab_fast(int ir, int ig, int ib, float *ol, float *oa, float *ob) {
+  init_luts();
+  float r = g_srgb_lut[ir], g = g_srgb_lut[ig], b = g_srgb_lut[ib];
+  float v[3];
+  v[0] = (float)div_k((double)r * 0.49000 + (double)g * 0.31000 + (double)b * 0.20000);
+  v[1] = (float)div_k((double)r * 0.17697 + (double)g * 0.81240 + (double)b * 0.01063);
+  v[2] = (float)div_k((double)r * 0.00000 + (double)g * 0.01000 + (double)b * 0.99000);
+  v[0] = (float)((double)v[0] * (1 / (96.6797 / 100)));
+  v[1] = (float)((double)v[1] * (1 / (100.000 / 100)));
+  v[2] = (float)((double)v[2] * (1 / (82.5188 / 100)));
+  for (int i = 0; i < 3; i++)
+    v[i] = (double)v[i] > 0.008856 ? (float)cbrt_mul((double)v[i]) : (float)((7.787 * (double)v[i]) + 16.0 / 116);
+  *ol = (float)((116 * (double)v[1]) - 16);
+  *oa = (float)(500 * (double)(float)(v[0] - v[1]));
+  *ob = (float)(200 * (double)(float)(v[1] - v[2]));
+}
+
+/* every 24-bit colour: out[0] = colours where the deterministic form differs from libm pow (the reference's power(), utils.pas:403),
+ * out[1] = colours where the kernels' division-free form differs from the deterministic form */
+void tmo_lab_domain_check(int64_t *out) {
+  out[0] = out[1] = 0;
+  for (int c = 0; c < (1 << 24); c++) {
+    float p[3], d[3], f[3];
+    lab_core(c & 255, (c >> 8) & 255, c >> 16, 0, &p[0], &p[1], &p[2]);
+    lab_core(c & 255, (c >> 8) & 255, c >> 16, 1, &d[0], &d[1], &d[2]);
+    tmo_rgb_to_lab_fast(c & 255, (c >> 8) & 255, c >> 16, &f[0], &f[1], &f[2]);
+    if (memcmp(p, d, 12)) out[0]++;
+    if (memcmp(f, d, 12)) out[1]++;
+  }
+}
+
 void tmo_rgb_to_lab(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 0, ol, oa, ob); }
 void tmo_rgb_to_lab_det(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 1, ol, oa, ob); }
 

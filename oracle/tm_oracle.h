@@ -50,6 +50,8 @@ void tmo_rgb_to_lab_det(int r, int g, int b, float *ol, float *oa, float *ob);  
 int32_t tmo_lab_to_rgb(float l, float a, float b);
 void tmo_rgb_to_hsv(uint32_t col, uint8_t *h, uint8_t *s, uint8_t *v);
 double tmo_cbrt_det(double x);
+void tmo_rgb_to_lab_fast(int r, int g, int b, float *ol, float *oa, float *ob);  /* the kernels' division-free form of _det */
+void tmo_lab_domain_check(int64_t *out);  /* all 2^24 colours: [0] det != libm pow, [1] fast != det */
 
 /* ---- A1-A3 load side ---- */
 void tmo_load_from_image(const uint32_t *img, int img_w, int img_h, int tm_w, int tm_h, uint32_t *tiles);

@@ -42,6 +42,15 @@ def test_det_cbrt_is_correctly_rounded_enough(oracle):
         assert oracle.rgb_to_lab(r, g, b) == oracle.rgb_to_lab(r, g, b, det=True)
 
 
+def test_lab_forms_agree_on_every_colour(oracle):
+    """the whole domain, not a sample: over all 2^24 colours RGBToLAB through libm pow (the reference's power(), utils.pas:403), through
+    the deterministic Newton root (the oracle's definition) and through the division-free form the kernels run give the same Singles"""
+    import ctypes
+    out = (ctypes.c_int64 * 2)()
+    oracle.L.tmo_lab_domain_check(out)
+    assert list(out) == [0, 0]
+
+
 def test_tables(oracle):
     import ctypes
     snake = np.frombuffer((ctypes.c_uint8 * 64).in_dll(oracle.L, "tmo_dct_snake"), np.uint8)

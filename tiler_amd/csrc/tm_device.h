@@ -21,18 +21,30 @@ __device__ __forceinline__ void rgb_to_yuv(int r, int g, int b, float &y, float 
   y = yy;
 }
 
-// +,-,*,/-only cube root (integer exponent/3 seed + 6 Newton steps): the build's stand-in for power(x, 1/3)
-// at utils.pas:403-405, bit-identical on host and device.
+// The build's stand-in for power(x, 1/3) at utils.pas:403-405.  The oracle defines it as an integer-seeded Newton root in +,-,*,/
+// (tmo_cbrt_det); this is the same function on RGBToLAB's domain, computed without a division: x^(-1/3) by four Newton steps in multiplications and fma, the root as x a a with one
+// multiplicative correction.  oracle/tm_oracle.c restates this form (tmo_rgb_to_lab_fast) and proves it equal to the oracle's
+// deterministic root -- and to libm pow, the reference's power() (utils.pas:403) -- after narrowing to Single on every one of the
+// 2^24 colours (tests/test_oracle_pins.py), so RGBToLAB keeps its values; the 21 double divisions per pixel it replaces were 90 %
+// of k_load_tiles.
 __device__ __forceinline__ double cbrt_det(double x) {
   unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  u = u / 3ull + 0x2A9F7893782DA1CEull;
-  double y = __longlong_as_double((long long)u);
+  u = 0x553EF0FF289DD796ull - u / 3ull;
+  double a = __longlong_as_double((long long)u);
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
-    const double y2 = __dmul_rn(y, y);
-    y = __dsub_rn(y, __ddiv_rn(__dsub_rn(__dmul_rn(y2, y), x), __dmul_rn(3.0, y2)));
+  for (int i = 0; i < 4; i++) {
+    const double e = __fma_rn(-x, __dmul_rn(__dmul_rn(a, a), a), 1.0);
+    a = __fma_rn(__dmul_rn(a, e), 1.0 / 3, a);
   }
-  return y;
+  const double y = __dmul_rn(__dmul_rn(x, a), a);
+  return __fma_rn(__dmul_rn(__fma_rn(-__dmul_rn(y, y), y, x), __dmul_rn(a, a)), 1.0 / 3, y);
+}
+
+// n / 0.17697 (utils.pas:391-393) as a reciprocal product refined by two fma; same whole-domain proof as cbrt_det
+__device__ __forceinline__ double div_xyz(double n) {
+  const double k = 1.0 / 0.17697;
+  const double q = __dmul_rn(n, k);
+  return __fma_rn(__fma_rn(-q, 0.17697, n), k, q);
 }
 
 __device__ __forceinline__ float lab_f(float t) {
@@ -44,9 +56,9 @@ __device__ __forceinline__ float lab_f(float t) {
 __device__ __forceinline__ void rgb_to_lab_det(int ir, int ig, int ib, const float *__restrict__ srgb_lut, float &ol, float &oa,
                                                float &ob) {
   const double r = (double)srgb_lut[ir], g = (double)srgb_lut[ig], b = (double)srgb_lut[ib];
-  float x = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.49000), __dmul_rn(g, 0.31000)), __dmul_rn(b, 0.20000)), 0.17697);
-  float y = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.17697), __dmul_rn(g, 0.81240)), __dmul_rn(b, 0.01063)), 0.17697);
-  float z = (float)__ddiv_rn(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.00000), __dmul_rn(g, 0.01000)), __dmul_rn(b, 0.99000)), 0.17697);
+  float x = (float)div_xyz(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.49000), __dmul_rn(g, 0.31000)), __dmul_rn(b, 0.20000)));
+  float y = (float)div_xyz(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.17697), __dmul_rn(g, 0.81240)), __dmul_rn(b, 0.01063)));
+  float z = (float)div_xyz(__dadd_rn(__dadd_rn(__dmul_rn(r, 0.00000), __dmul_rn(g, 0.01000)), __dmul_rn(b, 0.99000)));
   x = (float)__dmul_rn((double)x, 1 / (96.6797 / 100));
   y = (float)__dmul_rn((double)y, 1 / (100.000 / 100));
   z = (float)__dmul_rn((double)z, 1 / (82.5188 / 100));

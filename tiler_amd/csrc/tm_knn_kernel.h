@@ -229,7 +229,9 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
   // Chunks are visited outwards from the one the workgroup sits in (home, home + 1, home - 1, ...): near tiles tighten the bests first.
   const int n_chunks = (int)((n_ttiles + KNN_CHUNK - 1) / KNN_CHUNK), home_chunk = r0a / KNN_CHUNK;
-  int phase = 0, r0next = r0a, chunk_base = 0, chunk_j = 0, chunks_done = 0, list_n = 0, list_i = 0, list_pre = 0;  // list_pre: entry list_i, read one call early
+  int phase = 0, r0next = r0a, chunk_base = 0, chunk_j = 0, chunks_done = 0, list_n = 0, list_i = 0;
+  uint16_t pre_k = 0;  // entry list_i, read one call early and only combined when it is used
+  uint8_t pre_m = 0;
   auto next_tile = [&]() -> int {  // called by every thread at the same point (contains barriers)
     while (true) {
       if (phase == 0) {
@@ -238,10 +240,11 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
         list_n = list_i = 0;
       }
       if (list_i < list_n) {
-        const int r = chunk_base + list_pre;
+        const int r = chunk_base + ((int)pre_k | ((int)pre_m << 23));
         list_i++;
         const int k = min(list_i, KNN_CHUNK - 1);  // the entry of the next call: its LDS latency hides behind this tile's work
-        list_pre = (int)s_list[k] | ((int)s_mask[k] << 23);
+        pre_k = s_list[k];
+        pre_m = s_mask[k];
         return r;
       }
       if (chunks_done >= n_chunks) return -1;
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       st_build += __builtin_amdgcn_s_memtime() - tb_;
 #endif
       list_i = 0;
-      list_pre = (int)s_list[0] | ((int)s_mask[0] << 23);
+      pre_k = s_list[0];
+      pre_m = s_mask[0];
     }
   };
 
