@@ -11,61 +11,62 @@
 namespace tmx {
 
 // ---------------------------------------------------------------------------------------------------------------
-// A1+A2+A3: one wave per tile, one lane per pixel.
+// A1+A2+A3: one wave per tile, one lane per pixel; a wave works through LT_BATCH tiles, then 3 * LT_BATCH of its lanes add up the Lab
+// planes -- each sum is 64 Single additions in raster order (1349-1362), a dependent chain that would hold a whole wave per tile.
 // LoadFromImage (tilingencoder.pas:1293-1320) -> PrepareInterFrameData (1329-1367) -> mirror heuristics
 // (4865-4878) + H/V flip (1393-1411).
+constexpr int LT_BATCH = 16, LT_TILE = 195, LT_PLANE = 65;  // strides in floats: lane (tile, plane) of the summing phase reads bank 3 * tile + plane
 __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__ frames, int nframes, int img_w, int img_h,
                                                     int tm_w, int tm_h, const float *__restrict__ srgb_lut,
                                                     uint32_t *__restrict__ tiles, uint8_t *__restrict__ flags,
                                                     float *__restrict__ lab_means) {
-  __shared__ float s_lab[4][3][64];
+  __shared__ float s_lab[4][LT_BATCH * LT_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tiles_per_frame = (int64_t)tm_w * tm_h;
   const int64_t total = tiles_per_frame * nframes;
-  const int64_t nblk_iter = (total + 3) / 4;
-  for (int64_t it = blockIdx.x; it < nblk_iter; it += gridDim.x) {
-    const int64_t t = it * 4 + wave;
-    const bool valid = t < total;
-    uint32_t px = 0;
-    if (valid) {
+  const int64_t nbatch = (total + 4 * LT_BATCH - 1) / (4 * LT_BATCH);
+  float *lab = s_lab[wave];  // a wave only touches its own part: no workgroup barrier
+  for (int64_t it = blockIdx.x; it < nbatch; it += gridDim.x) {
+    const int64_t base = (it * 4 + wave) * LT_BATCH;
+    for (int j = 0; j < LT_BATCH; j++) {
+      const int64_t t = base + j;
+      if (t >= total) break;
       const int64_t f = t / tiles_per_frame;
       const int ti = (int)(t - f * tiles_per_frame);
       const int sy = ti / tm_w, sx = ti - sy * tm_w;
-      const int j = sy * 8 + (lane >> 3), i = sx * 8 + (lane & 7);
-      if (j < img_h && i < img_w) px = swap_rb(frames[(f * img_h + j) * (int64_t)img_w + i]);
+      const int y = lane >> 3, x = lane & 7;
+      const int jj = sy * 8 + y, ii = sx * 8 + x;
+      uint32_t px = 0;
+      if (jj < img_h && ii < img_w) px = swap_rb(frames[(f * img_h + jj) * (int64_t)img_w + ii]);
       float l, a, b;
       rgb_to_lab_det(px & 0xff, (px >> 8) & 0xff, (px >> 16) & 0xff, srgb_lut, l, a, b);
-      s_lab[wave][0][lane] = l;
-      s_lab[wave][1][lane] = a;
-      s_lab[wave][2][lane] = b;
-    }
-    __syncthreads();
-    if (valid) {
-      // Result[di+c] += lab, 64 Singles in raster order, then *= 1/64 (1349-1362): sequential on lanes 0..2
-      if (lane < 3) {
-        float s = 0.0f;
-        for (int p = 0; p < 64; p++) s = __fadd_rn(s, s_lab[wave][lane][p]);
-        lab_means[t * 3 + lane] = __fmul_rn(s, 1.0f / 64);
-      }
-      // quadrant luma sums (GetTileZoneSum, 4842-4863): integer, order free -> wave reduction
-      const int luma = (int)(px & 0xff) * 299 + (int)((px >> 8) & 0xff) * 587 + (int)((px >> 16) & 0xff) * 114;
-      const bool right = (lane & 4) != 0, bottom = (lane & 32) != 0;
-      int left_s = right ? 0 : luma, right_s = right ? luma : 0, top_s = bottom ? 0 : luma, bot_s = bottom ? luma : 0;
-      for (int o = 32; o > 0; o >>= 1) {
-        left_s += __shfl_xor(left_s, o);
-        right_s += __shfl_xor(right_s, o);
-        top_s += __shfl_xor(top_s, o);
-        bot_s += __shfl_xor(bot_s, o);
-      }
-      const bool hm = left_s < right_s;  // q00+q10 < q01+q11
-      const bool vm = top_s < bot_s;     // q00+q01 < q10+q11
-      const int y = lane >> 3, x = lane & 7;
+      lab[j * LT_TILE + lane] = l;
+      lab[j * LT_TILE + LT_PLANE + lane] = a;
+      lab[j * LT_TILE + 2 * LT_PLANE + lane] = b;
+      // quadrant luma sums (GetTileZoneSum, 4842-4863): integer, order free -> sums of 4 pixels by DPP, the 16 of them through SGPRs
+      int luma = (int)(px & 0xff) * 299 + (int)((px >> 8) & 0xff) * 587 + (int)((px >> 16) & 0xff) * 114;
+      luma += __builtin_amdgcn_update_dpp(0, luma, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+      luma += __builtin_amdgcn_update_dpp(0, luma, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+      int q[2][2] = {{0, 0}, {0, 0}};  // [bottom][right]
+#pragma unroll
+      for (int g = 0; g < 16; g++) q[g >> 3][g & 1] += __builtin_amdgcn_readlane(luma, g * 4);  // lanes 4g..4g+3: row g / 2, half g & 1
+      const bool hm = q[0][0] + q[1][0] < q[0][1] + q[1][1];  // q00+q10 < q01+q11
+      const bool vm = q[0][0] + q[0][1] < q[1][0] + q[1][1];  // q00+q01 < q10+q11
       const int src = ((vm ? 7 - y : y) << 3) | (hm ? 7 - x : x);
       const uint32_t canon = __shfl(px, src);
       tiles[t * 64 + lane] = canon;
       if (lane == 0) flags[t] = (uint8_t)((hm ? 1 : 0) | (vm ? 2 : 0));
     }
-    __syncthreads();
+    // Result[di+c] += lab, 64 Singles in raster order, then *= 1/64 (1349-1362): one lane per (tile, plane)
+    if (lane < 3 * LT_BATCH) {
+      const int j = lane / 3, c = lane - j * 3;
+      if (base + j < total) {
+        const float *p = lab + j * LT_TILE + c * LT_PLANE;
+        float s = 0.0f;
+        for (int k = 0; k < 64; k++) s = __fadd_rn(s, p[k]);
+        lab_means[(base + j) * 3 + c] = __fmul_rn(s, 1.0f / 64);
+      }
+    }
   }
 }
 
@@ -295,7 +296,7 @@ int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w,
   TM_CHECK(nframes >= 0 && img_w > 0 && img_h > 0 && tm_w > 0 && tm_h > 0, TM_E_INVAL, "tm_stage_load: bad dimensions");
   const int64_t total = (int64_t)nframes * tm_w * tm_h;
   if (total == 0) return TM_OK;
-  hipLaunchKernelGGL(k_load_tiles, dim3(grid_for(total, 4)), dim3(256), 0, stream, (const uint32_t *)frames, nframes, img_w,
+  hipLaunchKernelGGL(k_load_tiles, dim3(grid_for(total, 4 * LT_BATCH)), dim3(256), 0, stream, (const uint32_t *)frames, nframes, img_w,
                      img_h, tm_w, tm_h, tab->srgb_lut, (uint32_t *)tiles, (uint8_t *)flags, (float *)lab_means);
   TM_HIP(hipGetLastError());
   return TM_OK;
