@@ -176,9 +176,16 @@ def test_dither_palette_sizes(tiles_flags, oracle, pal_size):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("path", ["hash", "hash-collisions", "plain"])
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
-def test_dedup_reindex(tiles_flags, oracle, kind):
+def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):
+    """three ways through the kernel: rows grouped by their 64-bit hash; the hash cut to 2 bits, so that different rows collide and the
+    call has to notice and take the plain path; the plain path (merge sort of all rows) asked for outright"""
     from tiler_amd import stages
+    if path == "hash-collisions":
+        monkeypatch.setenv("TM_DEDUP_DEGRADE_HASH", "1")
+    if path == "plain":
+        monkeypatch.setenv("TM_DEDUP_PLAIN", "1")
     tiles, _ = tiles_flags
     rng = np.random.default_rng(5)
     if kind == "rgb":

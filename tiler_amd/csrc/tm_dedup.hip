@@ -6,11 +6,14 @@
 // 584-599).  Content order is CompareDWord on the 64 RGB dwords (unsigned) or CompareByte on the 64 palette
 // indices (940-948).
 //
-// GPU form: one stable merge sort of row indices with a comparator that reads the rows (rocPRIM sort primitive;
-// the comparator, run detection, merge bookkeeping and ranking kernels are ours), run heads by neighbour compare,
-// integer atomics for the merged use counts (order free), then a stable radix sort on ~UseCount.  Representative
-// of a run = its lowest original index (the reference's choice among byte-identical tiles is implementation
-// defined).
+// GPU form: rows are first GROUPED by a 64-bit content hash (stable radix sort of (hash, index): equal rows become
+// neighbours, lowest index first); every non-head row is compared in full with its predecessor, so a hash collision
+// cannot merge different rows -- it only sends the call down the plain path, a stable merge sort of all row indices
+// with a comparator that reads the rows.  Only the distinct rows are then merge-sorted by content (the order ReindexTiles
+// needs), run bookkeeping uses integer atomics for the merged use counts (order free), and a stable radix sort on
+// ~UseCount finishes.  rocPRIM supplies the sort and scan primitives; the hash, comparator, run detection, merge
+// bookkeeping and ranking kernels are ours.  Representative of a run = its lowest original index (the reference's
+// choice among byte-identical tiles is implementation defined).
 #include <cstring>
 
 #include <rocprim/device/device_merge_sort.hpp>
@@ -47,6 +50,40 @@ struct RowLess {
   }
   __device__ bool operator()(const uint32_t &a, const uint32_t &b) const { return cmp(a, b) < 0; }
 };
+
+// 64-bit content hash: 16 lanes per row, one uint4 each per 256 bytes; position enters every term, the terms add up
+__global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade,
+                                                  unsigned long long *__restrict__ hash) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {  // a block covers 16 rows per pass
+    const int64_t row = r0 + (threadIdx.x >> 4);
+    unsigned long long h = 0;
+    if (row < n)
+      for (int v = sub; v < dwords / 4; v += 16) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(rows + row * dwords + v * 4);
+        unsigned long long a = ((unsigned long long)x.y << 32 | x.x) + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * v + 1);
+        unsigned long long b = ((unsigned long long)x.w << 32 | x.z) + 0xC2B2AE3D27D4EB4Full * (unsigned long long)(2 * v + 2);
+        a ^= a >> 32; a *= 0xD6E8FEB86659FD93ull; a ^= a >> 32;
+        b ^= b >> 29; b *= 0xBF58476D1CE4E5B9ull; b ^= b >> 32;
+        h += a * 0x94D049BB133111EBull + b;
+      }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if (row < n && sub == 0) hash[row] = degrade ? (h & 3) : h;  // degrade: test hook that forces collisions
+  }
+}
+
+// runs of equal hash: head flags as k_mark_heads writes them; a non-head row that differs from its predecessor is a collision
+__global__ void k_mark_heads_hash(const uint32_t *__restrict__ sorted, const unsigned long long *__restrict__ hsorted, int64_t n,
+                                  RowLess less, uint32_t *__restrict__ head, uint32_t *__restrict__ headpos, int *__restrict__ collision) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool h = (i == 0) || hsorted[i] != hsorted[i - 1];
+    if (!h && less.cmp(sorted[i - 1], sorted[i]) != 0) *collision = 1;
+    head[i] = h ? 1u : 0u;
+    headpos[i] = h ? (uint32_t)i : 0u;
+  }
+}
 
 __global__ void k_iota(uint32_t *p, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
@@ -118,12 +155,34 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   TM_TRY(head_excl.alloc(n * 4)); TM_TRY(hps.alloc(n * 4)); TM_TRY(rep.alloc(n * 4)); TM_TRY(use_rep.alloc(n * 4)); TM_TRY(uniq.alloc(n * 4));
   TM_TRY(key.alloc(n * 4)); TM_TRY(key2.alloc(n * 4)); TM_TRY(ord2.alloc(n * 4)); TM_TRY(pos.alloc(n * 4)); TM_TRY(cnt.alloc(16));
   hipLaunchKernelGGL(k_iota, dim3(gridn(n)), dim3(256), 0, stream, idx.as<uint32_t>(), n);
-  size_t tb = 0;
-  TM_HIP(rocprim::merge_sort(nullptr, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
-  TM_TRY(tmp.alloc(tb));
-  TM_HIP(rocprim::merge_sort(tmp.p, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
-  hipLaunchKernelGGL(k_mark_heads, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), n, less, head.as<uint32_t>(),
-                     headpos.as<uint32_t>());
+  bool grouped = false;  // true: `sorted` is in hash order (runs of equal rows, lowest index first), not yet in content order
+  if (!getenv("TM_DEDUP_PLAIN")) {
+    DevBuf hkey, hkey2, flag;
+    TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8)); TM_TRY(flag.alloc(4));
+    TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_row_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, n,
+                       row_bytes / 4, getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0, hkey.as<unsigned long long>());
+    size_t tbh = 0;
+    TM_HIP(rocprim::radix_sort_pairs(nullptr, tbh, hkey.as<unsigned long long>(), hkey2.as<unsigned long long>(), idx.as<uint32_t>(),
+                                     sorted.as<uint32_t>(), (size_t)n, 0, 64, stream));
+    TM_TRY(tmp.alloc(tbh));
+    TM_HIP(rocprim::radix_sort_pairs(tmp.p, tbh, hkey.as<unsigned long long>(), hkey2.as<unsigned long long>(), idx.as<uint32_t>(),
+                                     sorted.as<uint32_t>(), (size_t)n, 0, 64, stream));
+    hipLaunchKernelGGL(k_mark_heads_hash, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), hkey2.as<unsigned long long>(), n, less,
+                       head.as<uint32_t>(), headpos.as<uint32_t>(), flag.as<int>());
+    int collision = 0;
+    TM_HIP(hipMemcpyAsync(&collision, flag.p, 4, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    grouped = collision == 0;
+  }
+  if (!grouped) {
+    size_t tb = 0;
+    TM_HIP(rocprim::merge_sort(nullptr, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+    TM_TRY(tmp.alloc(tb));
+    TM_HIP(rocprim::merge_sort(tmp.p, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+    hipLaunchKernelGGL(k_mark_heads, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), n, less, head.as<uint32_t>(),
+                       headpos.as<uint32_t>());
+  }
   size_t tb2 = 0;
   TM_HIP(rocprim::inclusive_scan(nullptr, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
   size_t tb3 = 0;
@@ -141,6 +200,15 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   TM_HIP(hipMemcpyAsync(&last_head, head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   const int64_t nu = (int64_t)last_excl + last_head;
+  if (grouped) {  // the distinct rows, now in hash order -> content order (what the stable ranking sort below relies on)
+    DevBuf uniq2;
+    TM_TRY(uniq2.alloc((size_t)nu * 4));
+    size_t tbu = 0;
+    TM_HIP(rocprim::merge_sort(nullptr, tbu, uniq.as<uint32_t>(), uniq2.as<uint32_t>(), (size_t)nu, less, stream));
+    TM_TRY(tmp.alloc(tbu));
+    TM_HIP(rocprim::merge_sort(tmp.p, tbu, uniq.as<uint32_t>(), uniq2.as<uint32_t>(), (size_t)nu, less, stream));
+    std::swap(uniq, uniq2);  // the old buffer goes back to the pool; everything later is ordered behind the sort on this stream
+  }
   TM_HIP(hipMemsetAsync(cnt.p, 0, 16, stream));
   hipLaunchKernelGGL(k_rank_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), by_index,
                      key.as<uint32_t>(), cnt.as<unsigned long long>());
