@@ -85,6 +85,30 @@ __global__ void k_mark_heads_hash(const uint32_t *__restrict__ sorted, const uns
   }
 }
 
+// sort key of a distinct row: its first two dwords in comparison order ride along, so that most comparisons never touch the rows
+struct PrefixKey {
+  unsigned long long prefix;
+  uint32_t row, pad;
+};
+struct PrefixLess {
+  RowLess less;
+  __device__ bool operator()(const PrefixKey &a, const PrefixKey &b) const {
+    if (a.prefix != b.prefix) return a.prefix < b.prefix;
+    return less.cmp(a.row, b.row) < 0;
+  }
+};
+__global__ void k_prefix_keys(const uint32_t *__restrict__ uniq, int64_t nu, RowLess less, PrefixKey *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = uniq[i];
+    const uint2 d = *reinterpret_cast<const uint2 *>(less.rows + (int64_t)r * less.dwords);
+    const uint32_t d0 = less.bytewise ? __builtin_bswap32(d.x) : d.x, d1 = less.bytewise ? __builtin_bswap32(d.y) : d.y;
+    out[i] = PrefixKey{((unsigned long long)d0 << 32) | d1, r, 0u};
+  }
+}
+__global__ void k_prefix_rows(const PrefixKey *__restrict__ keys, int64_t nu, uint32_t *__restrict__ uniq) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) uniq[i] = keys[i].row;
+}
+
 __global__ void k_iota(uint32_t *p, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (uint32_t)i;
 }
@@ -201,13 +225,16 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   TM_HIP(hipStreamSynchronize(stream));
   const int64_t nu = (int64_t)last_excl + last_head;
   if (grouped) {  // the distinct rows, now in hash order -> content order (what the stable ranking sort below relies on)
-    DevBuf uniq2;
-    TM_TRY(uniq2.alloc((size_t)nu * 4));
+    DevBuf pk, pk2;
+    TM_TRY(pk.alloc((size_t)nu * sizeof(PrefixKey))); TM_TRY(pk2.alloc((size_t)nu * sizeof(PrefixKey)));
+    hipLaunchKernelGGL(k_prefix_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, less, pk.as<PrefixKey>());
+    const PrefixLess pless{less};
     size_t tbu = 0;
-    TM_HIP(rocprim::merge_sort(nullptr, tbu, uniq.as<uint32_t>(), uniq2.as<uint32_t>(), (size_t)nu, less, stream));
+    TM_HIP(rocprim::merge_sort(nullptr, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)nu, pless, stream));
     TM_TRY(tmp.alloc(tbu));
-    TM_HIP(rocprim::merge_sort(tmp.p, tbu, uniq.as<uint32_t>(), uniq2.as<uint32_t>(), (size_t)nu, less, stream));
-    std::swap(uniq, uniq2);  // the old buffer goes back to the pool; everything later is ordered behind the sort on this stream
+    TM_HIP(rocprim::merge_sort(tmp.p, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)nu, pless, stream));
+    hipLaunchKernelGGL(k_prefix_rows, dim3(gridn(nu)), dim3(256), 0, stream, pk2.as<PrefixKey>(), nu, uniq.as<uint32_t>());
+    // pk / pk2 go back to the pool here; later users are ordered behind these kernels on the same stream (as with `tmp`)
   }
   TM_HIP(hipMemsetAsync(cnt.p, 0, 16, stream));
   hipLaunchKernelGGL(k_rank_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), by_index,
