@@ -374,32 +374,45 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       for (int s = 0; s < NQ; s++) {
         if (!do_sub[s]) continue;
         nvisit++;
-        v16i acc0, acc1, acc2;
+        // One accumulator, three phases: the products of the high digits come first and are shifted up by one digit before the mixed
+        // products are added onto them, and again before the low ones (acc = ((T_H.Q_H << 8) + T_L.Q_H + T_H.Q_L) << 8) + T_L.Q_L, exact
+        // mod 2^32).  Chunks are read from LDS once per phase that uses them; 16 accumulator registers instead of 48.
+        v16i acc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; acc2[r] = 0; }
+        for (int r = 0; r < 16; r++) acc[r] = 0;
+        if (HM > 0) {
 #pragma unroll
-        for (int kc = 0; kc < 6; kc++) {
-          const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);  // T_L chunk
-          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc0, 0, 0, 0);                    // T_L . Q_L
-          if (kc < HQ) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc1, 0, 0, 0);  // T_L . Q_H
+          for (int kc = 0; kc < HM; kc++) {
+            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_H . Q_H
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+        }
+        if (HT + HQ > 0) {
+#pragma unroll
+          for (int kc = 0; kc < HQ; kc++) {
+            const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);          // T_L chunk
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_L . Q_H
+          }
+#pragma unroll
+          for (int kc = 0; kc < HT; kc++) {
+            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);          // T_H . Q_L
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
         }
 #pragma unroll
-        for (int kc = 0; kc < HT; kc++) {
-          const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
-          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc1, 0, 0, 0);                    // T_H . Q_L
-          if (kc < HM) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc2, 0, 0, 0);  // T_H . Q_H
+        for (int kc = 0; kc < 6; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);            // T_L chunk
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);            // T_L . Q_L
         }
         int d[16];
         int m = INT_MAX;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          unsigned x = (unsigned)acc0[r];
-          if (HT + HQ > 0) {
-            unsigned hi = (unsigned)acc1[r];
-            if (HM > 0) hi += (unsigned)acc2[r] << 8;
-            x += hi << 8;
-          }
-          d[r] = (int)((x << 1) + (unsigned)nt[r] + (unsigned)nq2[s]);
+          d[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)nt[r] + (unsigned)nq2[s]);
           m = min(m, d[r]);
         }
         if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
