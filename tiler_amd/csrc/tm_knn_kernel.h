@@ -3,6 +3,7 @@
 // high-chunk count HQ (the per-side digit plan makes both data dependent).
 #pragma once
 #include <climits>
+#include <type_traits>
 
 #include "tm_common.h"
 
@@ -232,22 +233,15 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   int phase = 0, r0next = r0a, chunk_base = 0, chunk_j = 0, chunks_done = 0, list_n = 0, list_i = 0;
   uint16_t pre_k = 0;  // entry list_i, read one call early and only combined when it is used
   uint8_t pre_m = 0;
-  auto next_tile = [&]() -> int {  // called by every thread at the same point (contains barriers)
-    while (true) {
-      if (phase == 0) {
-        if (r0next < r0b) return (r0next++) | (0xff << 23);
-        phase = 1;
-        list_n = list_i = 0;
-      }
-      if (list_i < list_n) {
-        const int r = chunk_base + ((int)pre_k | ((int)pre_m << 23));
-        list_i++;
-        const int k = min(list_i, KNN_CHUNK - 1);  // the entry of the next call: its LDS latency hides behind this tile's work
-        pre_k = s_list[k];
-        pre_m = s_mask[k];
-        return r;
-      }
-      if (chunks_done >= n_chunks) return -1;
+  // refill(): called by every thread at the same point (contains barriers) -- makes sure the next pop has an entry unless the stream
+  // has ended; pop(): no calls, no barriers (it runs beside the MFMAs)
+  auto refill = [&]() {
+    if (phase == 0) {
+      if (r0next < r0b) return;
+      phase = 1;
+      list_n = list_i = 0;
+    }
+    while (list_i >= list_n && chunks_done < n_chunks) {
       int c;
       do {  // j = 0, 1, 2, 3, ... -> home, home + 1, home - 1, home + 2, ...; out-of-range ones are skipped
         c = home_chunk + ((chunk_j & 1) ? (chunk_j + 1) >> 1 : -(chunk_j >> 1));
@@ -268,6 +262,16 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       pre_m = s_mask[0];
     }
   };
+  auto pop = [&]() -> int {
+    if (phase == 0) return (r0next++) | (0xff << 23);
+    if (list_i >= list_n) return -1;
+    const int r = chunk_base + ((int)pre_k | ((int)pre_m << 23));
+    list_i++;
+    const int k = min(list_i, KNN_CHUNK - 1);  // the entry of the next call: its LDS latency hides behind this tile's work
+    pre_k = s_list[k];
+    pre_m = s_mask[k];
+    return r;
+  };
 
   // async staging: every wave copies NST pieces of a tile straight into LDS (global_load_lds, no registers); lanes
   // past the end of the tile re-read its last vector into the buffer padding so all waves issue the same count
@@ -286,7 +290,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   bool more = true;  // the candidate stream has not ended
 #pragma unroll
   for (int i = 0; i < NBUF - 1; i++) {
-    q[i] = more ? next_tile() : -1;
+    if (more) refill();
+    q[i] = more ? pop() : -1;
     if (q[i] >= 0) issue(q[i], i); else more = false;
   }
   int cur_tile = q[0];
@@ -320,11 +325,17 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       __builtin_amdgcn_s_barrier();
     }
     TM_STAMP(2);
+    if (more) refill();
     int nn_tile = -1;  // NBUF - 1 ahead, chosen with the bests as they are now
-    if (more) { nn_tile = next_tile(); more = nn_tile >= 0; }
-    TM_STAMP(7);
-    if (nn_tile >= 0) issue(nn_tile, cur >= 1 ? cur - 1 : NBUF - 1);  // buffer (cur + NBUF - 1) % NBUF: read last in the previous iteration
-    TM_STAMP(3);
+    // Picking and staging the tile NBUF - 1 ahead is pure bookkeeping (list pop, address arithmetic, LDS-DMA issue).  It runs after this
+    // wave's first MFMA chain has been issued, so that it executes while the matrix pipe works; buffer (cur + NBUF - 1) % NBUF was read
+    // last in the previous iteration.
+    auto stage_ahead = [&]() {
+      if (more) { nn_tile = pop(); more = nn_tile >= 0; }
+      TM_STAMP(7);
+      if (nn_tile >= 0) issue(nn_tile, cur >= 1 ? cur - 1 : NBUF - 1);
+      TM_STAMP(3);
+    };
     const uint8_t *L = TM_KNN_DIRECT ? tpack + (cur_tile & 0x7fffff) * (int64_t)T_BYTES : lds[cur];
     // sub-tile level skip: the list round already judged every (tile, sub-tile) pair with the bests of that time;
     // pairs it kept are re-judged against the current best with the tile's box (it rides in LDS behind the norms)
@@ -360,103 +371,115 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       st_idle += do_tile ? 0 : 1;
     }
 #endif
-    if (do_tile) {
-      // accumulator row of register r: (r&3) + 8*(r>>2) + 4*half  -> norms as four 16-byte reads
+    // one query sub-tile at a time (the other wave of the SIMD overlaps its MFMAs with this wave's VALU epilogue)
+    v16i acc;
+    auto run_mfma = [&](auto S) {
+      constexpr int s = decltype(S)::value;
+      nvisit++;
+      // One accumulator, three phases: the products of the high digits come first and are shifted up by one digit before the mixed
+      // products are added onto them, and again before the low ones (acc = ((T_H.Q_H << 8) + T_L.Q_H + T_H.Q_L) << 8) + T_L.Q_L, exact
+      // mod 2^32).  Chunks are read from LDS once per phase that uses them; 16 accumulator registers instead of 48.
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0;
+      if (HM > 0) {
+#pragma unroll
+        for (int kc = 0; kc < HM; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_H . Q_H
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+      }
+      if (HT + HQ > 0) {
+#pragma unroll
+        for (int kc = 0; kc < HQ; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);          // T_L chunk
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_L . Q_H
+        }
+#pragma unroll
+        for (int kc = 0; kc < HT; kc++) {
+          const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);          // T_H . Q_L
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+      }
+#pragma unroll
+      for (int kc = 0; kc < 6; kc++) {
+        const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);            // T_L chunk
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);            // T_L . Q_L
+      }
+    };
+    auto run_epilogue = [&](auto S) {
+      constexpr int s = decltype(S)::value;
+      // accumulator row of register r: (r&3) + 8*(r>>2) + 4*half  -> norms as four 16-byte reads (here, not before the MFMAs: the
+      // registers are free while the chain and the staging run)
       int nt[16];
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const v4i x = *reinterpret_cast<const v4i *>(L + KT * 1024 + (g * 8 + half * 4) * 4);
         nt[g * 4] = x[0]; nt[g * 4 + 1] = x[1]; nt[g * 4 + 2] = x[2]; nt[g * 4 + 3] = x[3];
       }
-      // one query sub-tile at a time (a single accumulator set keeps the kernel out of scratch; the other wave of the
-      // SIMD overlaps its MFMAs with this wave's VALU epilogue)
+      // d'' = 2 acc + |t-c|^2 + 2 (|q-c|^2 >> 1): the query's own term is the same for the 16 rows of a lane, so the minimum is taken
+      // without it (every d'' is below 2^31 and so is the query term: no wrap between the two orders), and the rows' values are only
+      // formed on the rare paths that need them
+      int t[16];
+      int tm = INT_MAX;
 #pragma unroll
-      for (int s = 0; s < NQ; s++) {
-        if (!do_sub[s]) continue;
-        nvisit++;
-        // One accumulator, three phases: the products of the high digits come first and are shifted up by one digit before the mixed
-        // products are added onto them, and again before the low ones (acc = ((T_H.Q_H << 8) + T_L.Q_H + T_H.Q_L) << 8) + T_L.Q_L, exact
-        // mod 2^32).  Chunks are read from LDS once per phase that uses them; 16 accumulator registers instead of 48.
-        v16i acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0;
-        if (HM > 0) {
-#pragma unroll
-          for (int kc = 0; kc < HM; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_H . Q_H
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
-        }
-        if (HT + HQ > 0) {
-#pragma unroll
-          for (int kc = 0; kc < HQ; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);          // T_L chunk
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][6 + kc], acc, 0, 0, 0);      // T_L . Q_H
-          }
-#pragma unroll
-          for (int kc = 0; kc < HT; kc++) {
-            const v4i a = *reinterpret_cast<const v4i *>(L + ((6 + kc) * 64 + lane) * 16);  // T_H chunk
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);          // T_H . Q_L
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
-        }
-#pragma unroll
-        for (int kc = 0; kc < 6; kc++) {
-          const v4i a = *reinterpret_cast<const v4i *>(L + (kc * 64 + lane) * 16);            // T_L chunk
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[s][kc], acc, 0, 0, 0);            // T_L . Q_L
-        }
-        int d[16];
-        int m = INT_MAX;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          d[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)nt[r] + (unsigned)nq2[s]);
-          m = min(m, d[r]);
-        }
-        if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
-          const int64_t q = qtile[s] * 32 + (lane & 31);
-          const bool hit = m <= best[s] && qtile[s] < n_qtiles && q < nq;
-          if (hit) {
-            // rung j (1..7) = (8 - j) * step <= tau0 - j * tau0 / 8; the last database tile pads with copies of its last row,
-            // which must not be counted
-            const bool countable = (cur_tile & 0x7fffff) != (int)n_ttiles - 1;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-              if (d[r] <= best[s]) {
-                const int slot = atomicAdd(&cand_cnt[q], 1);
-                if (slot < cand_cap)
-                  cand[q * cand_cap + slot] = make_uint2((unsigned)d[r], (unsigned)(((cur_tile & 0x7fffff) << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
-#pragma unroll
-                for (int j = 1; j <= 7; j++) lad_cnt[s][j - 1] += (countable && d[r] <= (8 - j) * lad_step[s]) ? 1 : 0;
-              }
-          }
-          if (__builtin_amdgcn_ballot_w64(hit)) {  // both lanes of a query take part: the counts of its two row halves add up
-            int rung = 0;
-#pragma unroll
-            for (int j = 1; j <= 7; j++) {
-              const int c = lad_cnt[s][j - 1] + __shfl_xor(lad_cnt[s][j - 1], 32);
-              if (c >= cand_k) rung = j;
-            }
-            // cand_k rows have d'' <= rung, i.e. SSD <= rung + 1: no row beyond that can be among the k nearest
-            const int t = (8 - rung) * lad_step[s] + 1;
-            if (rung > 0 && lad_step[s] > 0 && t < best[s]) { best[s] = t; improved = true; }
-          }
-          continue;
-        }
-        if (m == best[s]) tie[s] = 1;  // another tile reaches the same value
-        if (m < best[s]) {             // this lane improves: which row, and is it alone?
-          int row = 0, cnt = 0;
-#pragma unroll
-          for (int r = 15; r >= 0; r--)
-            if (d[r] == m) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
-          best[s] = m;
-          bestt[s] = ((cur_tile & 0x7fffff) << 5) | row;
-          improved = true;
-          tie[s] = cnt > 1;
-        }
+      for (int r = 0; r < 16; r++) {
+        t[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)nt[r]);
+        tm = min(tm, t[r]);
       }
+      const int m = (int)((unsigned)tm + (unsigned)nq2[s]);
+#define TM_KNN_D(r) ((int)((unsigned)t[r] + (unsigned)nq2[s]))
+      if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
+        const int64_t q = qtile[s] * 32 + (lane & 31);
+        const bool hit = m <= best[s] && qtile[s] < n_qtiles && q < nq;
+        if (hit) {
+          // rung j (1..7) = (8 - j) * step <= tau0 - j * tau0 / 8; the last database tile pads with copies of its last row,
+          // which must not be counted
+          const bool countable = (cur_tile & 0x7fffff) != (int)n_ttiles - 1;
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (TM_KNN_D(r) <= best[s]) {
+              const int slot = atomicAdd(&cand_cnt[q], 1);
+              if (slot < cand_cap)
+                cand[q * cand_cap + slot] = make_uint2((unsigned)TM_KNN_D(r), (unsigned)(((cur_tile & 0x7fffff) << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+#pragma unroll
+              for (int j = 1; j <= 7; j++) lad_cnt[s][j - 1] += (countable && TM_KNN_D(r) <= (8 - j) * lad_step[s]) ? 1 : 0;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(hit)) {  // both lanes of a query take part: the counts of its two row halves add up
+          int rung = 0;
+#pragma unroll
+          for (int j = 1; j <= 7; j++) {
+            const int c = lad_cnt[s][j - 1] + __shfl_xor(lad_cnt[s][j - 1], 32);
+            if (c >= cand_k) rung = j;
+          }
+          // cand_k rows have d'' <= rung, i.e. SSD <= rung + 1: no row beyond that can be among the k nearest
+          const int t = (8 - rung) * lad_step[s] + 1;
+          if (rung > 0 && lad_step[s] > 0 && t < best[s]) { best[s] = t; improved = true; }
+        }
+        return;
+      }
+      if (m == best[s]) tie[s] = 1;  // another tile reaches the same value
+      if (m < best[s]) {             // this lane improves: which row, and is it alone?
+        int row = 0, cnt = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--)
+          if (t[r] == tm) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
+        best[s] = m;
+        bestt[s] = ((cur_tile & 0x7fffff) << 5) | row;
+        improved = true;
+        tie[s] = cnt > 1;
+      }
+#undef TM_KNN_D
+    };
+    if (do_sub[0]) run_mfma(std::integral_constant<int, 0>{});
+    stage_ahead();
+    if (do_sub[0]) run_epilogue(std::integral_constant<int, 0>{});
+    if constexpr (NQ == 2) {
+      if (do_sub[1]) { run_mfma(std::integral_constant<int, 1>{}); run_epilogue(std::integral_constant<int, 1>{}); }
     }
     TM_STAMP(5);
     if (__builtin_amdgcn_ballot_w64(improved)) {  // some lane has a new best: refresh the sub-tile maxima
