@@ -224,7 +224,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   const bool bx_on = bx_s < NQ && bx_d < ND;
   const int bx_qlo = bx_on ? s_box[0][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MIN / 2;
   const int bx_qhi = bx_on ? s_box[1][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MAX / 2;
-  const int r0a = s_ctl[0], r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)  // round-0 tiles [r0a, r0b)
+  // (readfirstlane: the loop state below is uniform; saying so moves its arithmetic and branches to the scalar unit)
+  const int r0a = __builtin_amdgcn_readfirstlane(s_ctl[0]), r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
@@ -252,8 +253,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
 #if TM_KNN_STAMPS
       const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
-      list_n = knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0], &s_box[1][0][0][0],
-                              &s_smax[0][0], s_list, s_mask, &s_ctl[1]);
+      list_n = __builtin_amdgcn_readfirstlane(knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0],
+                                                             &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
 #if TM_KNN_STAMPS
       st_build += __builtin_amdgcn_s_memtime() - tb_;
 #endif
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   auto pop = [&]() -> int {
     if (phase == 0) return (r0next++) | (0xff << 23);
     if (list_i >= list_n) return -1;
-    const int r = chunk_base + ((int)pre_k | ((int)pre_m << 23));
+    const int r = chunk_base + __builtin_amdgcn_readfirstlane((int)pre_k | ((int)pre_m << 23));
     list_i++;
     const int k = min(list_i, KNN_CHUNK - 1);  // the entry of the next call: its LDS latency hides behind this tile's work
     pre_k = s_list[k];
