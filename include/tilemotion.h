@@ -118,9 +118,15 @@ TM_API int tm_reload_gtm(tm_encoder *, const char *path);
 enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL = 2,
        /* with motion prediction: uint8 IsPredicted, int8 PredictedX, int8 PredictedY (1 byte per item; other shards hold 0: merge with SUM) */
        TM_ARRAY_TILEMAP_PRED = 3, TM_ARRAY_TILEMAP_PX = 4, TM_ARRAY_TILEMAP_PY = 5,
-       TM_ARRAY_PM_ERR = 6 /* uint32 best error of PredictMotion per item; other shards hold 0 */ };
+       TM_ARRAY_PM_ERR = 6 /* uint32 best error of PredictMotion per item; other shards hold 0 */,
+       TM_ARRAY_TILE_PALPX = 7 /* uint8 [tiles][64] dithered palette indices (DitherTile's output, :2690-2724); tiles of other
+                                  dither shards hold 0: merge with SUM, as bytes or as count/4 32-bit words (count is a multiple of 64) */ };
 TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
-TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* elements: int32 for 0-2 and 6, bytes for 3-5 */);
+/* Dither (DoDither :1873-1907, one independent DitherTile per global tile): this process dithers tiles
+ * [T * rank / world, T * (rank + 1) / world) only (T = global tiles after Reduce) and zeroes the rest; the host merges
+ * TM_ARRAY_TILE_PALPX with an all-reduce(SUM) before Reconstruct.  (0, 1) = every tile (default). */
+TM_API int tm_set_dither_shard(tm_encoder *, int rank, int world);
+TM_API int tm_get_device_array(tm_encoder *, int which, void **dev_ptr, int64_t *count /* elements: int32 for 0-2 and 6, bytes for 3-5 and 7 */);
 TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */

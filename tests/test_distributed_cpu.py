@@ -28,6 +28,9 @@ class OracleEncoder:
     def SetQueryShard(self, first, count):
         self.shard = (first, count)
 
+    def SetDitherShard(self, rank, world):
+        self.dshard = (rank, world)
+
     def KeyFrames(self):
         return self.st["keyframes"]
 
@@ -52,7 +55,15 @@ class OracleEncoder:
         elif step == 2 and mp:  # Reduce needs the merged PredictMotion results on every rank
             assert np.array_equal(self.arr[6].numpy().view(np.uint32), self.st["pm_err"])
             assert np.array_equal(self.arr[4].numpy(), self.st["pm_x"]) and np.array_equal(self.arr[5].numpy(), self.st["pm_y"])
+        elif step == 4:  # Dither: only this rank's share of the global tiles, as 32-bit words; the others 0
+            px = self.st["pal_px"]
+            r, w = self.dshard
+            t0, t1 = px.shape[0] * r // w, px.shape[0] * (r + 1) // w
+            own = np.zeros_like(px)
+            own[t0:t1] = px[t0:t1]
+            self.arr[7] = torch.from_numpy(own.reshape(-1).view(np.int32).copy())
         elif step == 5:  # Reconstruct: only this rank's frames
+            assert np.array_equal(self.arr[7].numpy().view(np.uint8).reshape(self.st["pal_px"].shape), self.st["pal_px"]), "dither shards not merged"
             per = self.st["per"]
             f0, n = self.shard
             sl = slice(f0 * per, (f0 + n) * per)

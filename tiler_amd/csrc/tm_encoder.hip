@@ -108,6 +108,7 @@ struct tm_encoder {
   std::vector<uint8_t> h_fflags;
   double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int shard_first = 0, shard_count = -1;  // query frames this process matches in Reconstruct (multi-GPU: one shard per rank)
+  int dither_rank = 0, dither_world = 1;  // tiles this process dithers: [t * rank / world, t * (rank + 1) / world)
   double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
@@ -389,8 +390,12 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
 static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
   TM_TRY(need(e, TM_STEP_PREPARE_PALETTES, "PreparePalettes"));
   TM_TRY(e->gpal_px.alloc((size_t)e->t * 64));
-  TM_TRY(launch_dither(e->gtiles.p, e->gflags.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteCount, e->s.PaletteSize,
-                       e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors, e->gpal_px.p, e->stream));
+  const int64_t t0 = e->t * e->dither_rank / e->dither_world, t1 = e->t * (e->dither_rank + 1) / e->dither_world;
+  if (e->dither_world > 1) TM_HIP(hipMemsetAsync(e->gpal_px.p, 0, (size_t)e->t * 64, e->stream));  // other shards' tiles: 0, merged with SUM
+  if (t1 > t0)
+    TM_TRY(launch_dither(e->gtiles.as<uint8_t>() + t0 * 256, e->gflags.as<uint8_t>() + t0, e->gpal_idx.as<uint8_t>() + t0 * 4, t1 - t0, e->palettes_dev.p,
+                         e->s.PaletteCount, e->s.PaletteSize, e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors,
+                         e->gpal_px.as<uint8_t>() + t0 * 64, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   e->has_pal_px = true;
   progress(e, TM_STEP_DITHER, 2, 2);
@@ -880,6 +885,14 @@ int tm_set_query_shard(tm_encoder *e, int first_frame, int frame_count) {
   return TM_OK;
 }
 
+int tm_set_dither_shard(tm_encoder *e, int rank, int world) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(world >= 1 && rank >= 0 && rank < world, TM_E_INVAL, "bad dither shard %d of %d", rank, world);
+  e->dither_rank = rank;
+  e->dither_world = world;
+  return TM_OK;
+}
+
 int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
   TM_CHECK(e && ptr && count, TM_E_INVAL, "null argument");
   switch (which) {
@@ -890,6 +903,7 @@ int tm_get_device_array(tm_encoder *e, int which, void **ptr, int64_t *count) {
     case TM_ARRAY_TILEMAP_PX: *ptr = e->has_pm ? e->tm_px.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     case TM_ARRAY_TILEMAP_PY: *ptr = e->has_pm ? e->tm_py.p : nullptr; *count = e->has_pm ? e->q : 0; break;
     case TM_ARRAY_PM_ERR: *ptr = e->has_pm ? e->pm_err.p : nullptr; *count = e->has_pm ? e->q : 0; break;
+    case TM_ARRAY_TILE_PALPX: *ptr = e->has_pal_px ? e->gpal_px.p : nullptr; *count = e->has_pal_px ? e->t * 64 : 0; break;
     default: set_error("bad array id %d", which); return TM_E_INVAL;
   }
   return TM_OK;

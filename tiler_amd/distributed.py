@@ -6,7 +6,8 @@ the whole clip (small, deterministic, bit-identical on all ranks -- no collectiv
 set, palettes or dithered tiles), matches only ITS frame range against the full database, and the per-frame results
 are merged with one all-reduce(MAX) (other ranks hold -1) over RCCL/xGMI: 2 x Q x 4 bytes (3 x with the extended-palette
 re-rank, whose PalIdx is per item).  Reindex then runs
-everywhere on the merged tile maps.  With motion prediction on, PredictMotion is sharded by frame too (merged with
+everywhere on the merged tile maps.  Dither is sharded by global tile (its tiles are independent: every rank dithers a
+contiguous share, one all-reduce(SUM) of the 64-byte index tiles puts the whole set on every rank).  With motion prediction on, PredictMotion is sharded by frame too (merged with
 all-reduce(SUM), other ranks hold 0) and Reconstruct by whole key-frame groups, the unit that chains (1496).  The collective calls go through `torch.distributed`, so the same code is
 exercised on CPU with gloo in tests/test_distributed_cpu.py (there with an oracle-backed stand-in for the encoder).
 """
@@ -45,8 +46,13 @@ def run_all(enc, nframes, rank=0, world=1, group=None):
     if world > 1 and motion:
         for which in (6, 4, 5):  # best error, PredictedX, PredictedY: owner holds the value, everyone else 0
             dist.all_reduce(enc.DeviceArray(which), op=dist.ReduceOp.SUM, group=group)
-    for step in (S.esReduce, S.esPreparePalettes, S.esDither):
+    for step in (S.esReduce, S.esPreparePalettes):
         enc.Run(step)
+    # DitherTile is independent per global tile (2690): every rank dithers a contiguous share of the tiles, the others stay 0
+    enc.SetDitherShard(rank, world)
+    enc.Run(S.esDither)
+    if world > 1:
+        dist.all_reduce(enc.DeviceArray(7), op=dist.ReduceOp.SUM, group=group)
     if motion:
         first, count = keyframe_shard(enc.KeyFrames(), nframes, rank, world)
         enc.SetQueryShard(first, count)

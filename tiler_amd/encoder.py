@@ -66,6 +66,7 @@ _ENC_SIGS = {
     "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_reload_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
+    "tm_set_dither_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
     "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
@@ -203,16 +204,22 @@ class TilingEncoder:
     def SetQueryShard(self, first_frame, frame_count):
         check(self._L.tm_set_query_shard(c_void_p(self._h), first_frame, frame_count))
 
+    def SetDitherShard(self, rank, world):
+        """Dither only tiles [T * rank / world, T * (rank + 1) / world); the others stay 0 in DeviceArray(7) for an all-reduce(SUM)"""
+        check(self._L.tm_set_dither_shard(c_void_p(self._h), rank, world))
+
     def DeviceArray(self, which):
         """torch view of an encoder-owned device array, no copy: 0 TileIdx, 1 error, 2 PalIdx (int32); with motion
-        prediction 3 IsPredicted (uint8), 4/5 PredictedX/Y (int8), 6 PredictMotion's best error (int32)"""
+        prediction 3 IsPredicted (uint8), 4/5 PredictedX/Y (int8), 6 PredictMotion's best error (int32); 7 the dithered
+        tiles' palette indices, seen as int32 words (64 bytes = 16 words per tile) so that any backend can add them"""
         import torch
         ptr, cnt = c_void_p(), c_int64()
         check(self._L.tm_get_device_array(c_void_p(self._h), which, ctypes.byref(ptr), ctypes.byref(cnt)))
         typestr = {3: "|u1", 4: "|i1", 5: "|i1"}.get(int(which), "<i4")
+        n = cnt.value // 4 if int(which) == 7 else cnt.value
 
         class _View:
-            __cuda_array_interface__ = {"shape": (cnt.value,), "typestr": typestr, "data": (ptr.value, False), "version": 2}
+            __cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr.value, False), "version": 2}
 
         return torch.as_tensor(_View(), device="cuda")
 
