@@ -191,6 +191,19 @@ def main():
                      "pairs_per_launch": knn_pairs / max(knn_launches, 1),
                      "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair; the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }
+    if world == 1 and rank == 0:
+        # the peaks measured on this very device: a bare loop of the kernel's MFMA instruction and an HBM stream triad
+        import ctypes
+        from tiler_amd import lib as _lib_fn
+        from tiler_amd._lib import check as _check
+        tops, gbs = ctypes.c_double(), ctypes.c_double()
+        _check(_lib_fn().tm_probe_mfma_i8(0.3, ctypes.byref(tops)))
+        _check(_lib_fn().tm_probe_hbm_triad(1 << 30, ctypes.byref(gbs)))
+        out["measured_peaks"] = {"mfma_i8_tops": tops.value, "hbm_triad_gb_s": gbs.value,
+                                 "note": "bare v_mfma_i32_32x32x32_i8 loop (two waves per SIMD, operands in registers) and a = b + s*c over 3 x 1 GiB; "
+                                         "roofline.frac stays against the 5000 TOP/s vendor figure"}
+        out["roofline"]["frac_of_measured_peak"] = achieved / tops.value if tops.value > 0 else None
+        out["roofline"]["mfma_pipe_frac_of_measured_peak"] = achieved * (2 * ks["k_bytes"] / 384.0) / tops.value if tops.value > 0 else None
     if world == 1:
         # diagnostic, outside the timed region: the same kernel with pruning off = a dense Q x T_distinct distance GEMM,
         # which is what the MFMA roofline is really about (the shipped path skips >95 % of it)
@@ -204,6 +217,7 @@ def main():
         dense = 384.0 * kd["pairs"] / max(kd["launches"], 1) / (kd["kernel_ms"] / max(kd["launches"], 1) * 1e-3) / 1e12
         out["roofline_dense"] = {"bound": "mfma", "achieved": dense, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": dense / I8_DENSE_PEAK_TOPS,
                                  "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
+                                 "mfma_pipe_frac_of_measured_peak": (dense * (2 * kd["k_bytes"] / 384.0) / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
                                  "launch_ms": kd["kernel_ms"] / max(kd["launches"], 1), "pairs_per_launch": kd["pairs"] / max(kd["launches"], 1),
                                  "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated"}
     if world == 1 and args.motion_radius == 0 and not args.no_motion_extra:

@@ -59,6 +59,11 @@ typedef struct { int32_t TileIdx; int32_t PalIdx; int8_t PredictedX; int8_t Pred
 TM_API const char *tm_last_error(void);
 TM_API int tm_device_count(void);           /* usable gfx950 devices, 0 if none */
 TM_API const char *tm_version(void);
+/* The peaks a roofline divides by, measured on this device: a bare loop of the int8 MFMA the KNN kernel issues
+ * (two waves per SIMD, operands in registers; about `seconds_hint` seconds) in TOP/s, and a stream triad a = b + s c over three
+ * arrays of `bytes_per_array` in GB/s.  Diagnostics for bench.py; nothing in the product path calls them. */
+TM_API int tm_probe_mfma_i8(double seconds_hint, double *tops);
+TM_API int tm_probe_hbm_triad(int64_t bytes_per_array, double *gb_per_s);
 
 /* ======================================================================================= coarse seam */
 typedef struct tm_encoder tm_encoder;

@@ -27,6 +27,8 @@ SIGNATURES = {
     "tm_last_error": (c_char_p, []),
     "tm_device_count": (c_int, []),
     "tm_version": (c_char_p, []),
+    "tm_probe_mfma_i8": (c_int, [c_double, ctypes.POINTER(c_double)]),
+    "tm_probe_hbm_triad": (c_int, [c_int64, ctypes.POINTER(c_double)]),
     "tm_stage_load": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tm_stage_features_rgb": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "tm_stage_features_pal": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
