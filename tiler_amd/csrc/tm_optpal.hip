@@ -15,14 +15,13 @@
 namespace tmx {
 namespace {
 
-using Fn1 = std::function<double(double)>;
-using FnN = std::function<double(const std::vector<double> &)>;
+// the objective and the line functions are template parameters (no std::function indirection: the whole search inlines)
 
 double sign_of(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0); }
 
 struct Bracketed { double xa, xb, xc; };
 
-Bracketed bracket(const Fn1 &f, double xa, double xb) {  // Bracket, powell.pas:56-147
+template <class Fn1> Bracketed bracket(const Fn1 &f, double xa, double xb) {  // Bracket, powell.pas:56-147
   const double gold = (1 + std::sqrt(5.0)) / 2, small = 1e-21, grow_limit = 110;
   double fa = f(xa), fb = f(xb);
   if (fa < fb) { std::swap(xa, xb); std::swap(fa, fb); }
@@ -61,7 +60,7 @@ Bracketed bracket(const Fn1 &f, double xa, double xb) {  // Bracket, powell.pas:
 
 struct LineMin { double x, fx; };
 
-LineMin brent(const Fn1 &f, double xtol, int maxiter) {  // Brent + BrentHelper, powell.pas:149-266, bracket seed (0, 1)
+template <class Fn1> LineMin brent(const Fn1 &f, double xtol, int maxiter) {  // Brent + BrentHelper, powell.pas:149-266, bracket seed (0, 1)
   const double cg = (3 - std::sqrt(5.0)) / 2;
   const Bracketed br = bracket(f, 0, 1);
   double a = br.xa, x = br.xb, b = br.xc, fx = f(x);
@@ -106,9 +105,8 @@ LineMin brent(const Fn1 &f, double xtol, int maxiter) {  // Brent + BrentHelper,
   return {x, fx};
 }
 
-double linesearch(const FnN &f, std::vector<double> &p, double *xi, double xtol) {  // LinesearchPowell, powell.pas:285-314
+template <class FnN> double linesearch(const FnN &f, std::vector<double> &p, double *xi, double xtol, std::vector<double> &ray) {  // LinesearchPowell, powell.pas:285-314
   const size_t n = p.size();
-  std::vector<double> ray(n);
   double sos = 0;
   for (size_t i = 0; i < n; i++) sos += xi[i] * xi[i];
   const double sqsos = std::sqrt(sos);
@@ -123,10 +121,10 @@ double linesearch(const FnN &f, std::vector<double> &p, double *xi, double xtol)
   return m.fx;
 }
 
-double powell_minimize(const FnN &f, std::vector<double> &x, double scale, double xtol, double ftol, int maxiter) {
+template <class FnN> double powell_minimize(const FnN &f, std::vector<double> &x, double scale, double xtol, double ftol, int maxiter) {
   // PowellMinimize, powell.pas:316-384; rows are pointers because the reference's rows alias after a replacement
   const size_t n = x.size();
-  std::vector<double> store((n + 1) * n, 0.0), tmp(n), x1(x);
+  std::vector<double> store((n + 1) * n, 0.0), tmp(n), x1(x), ray(n);
   std::vector<double *> direc(n);
   for (size_t i = 0; i < n; i++) { direc[i] = &store[i * n]; direc[i][i] = scale; }
   double *direc1 = &store[n * n];
@@ -137,7 +135,7 @@ double powell_minimize(const FnN &f, std::vector<double> &x, double scale, doubl
     size_t bigind = 0;
     for (size_t i = 0; i < n; i++) {
       const double before = fval;
-      fval = linesearch(f, x, direc[i], xtol);
+      fval = linesearch(f, x, direc[i], xtol, ray);
       if (before - fval > delta) { delta = before - fval; bigind = i; }
     }
     ++iter;
@@ -150,7 +148,7 @@ double powell_minimize(const FnN &f, std::vector<double> &x, double scale, doubl
       temp = fx - fx2;
       t = t - delta * temp * temp;
       if (t < 0) {
-        fval = linesearch(f, x, direc1, xtol);
+        fval = linesearch(f, x, direc1, xtol, ray);
         direc[bigind] = direc[n - 1];
         direc[n - 1] = direc1;
       }
@@ -186,7 +184,12 @@ int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_si
         struct Item { int count, index; } perm[64];
         perm[0] = {0, 0};
         for (int i = 1; i < pal_size; i++) perm[i] = {(int)llrint(x[i - 1] * 1000), i};
-        std::sort(perm, perm + pal_size, [](const Item &l, const Item &r) { return l.count != r.count ? l.count < r.count : l.index < r.index; });
+        for (int i = 1; i < pal_size; i++) {  // insertion sort by (count, index): a total order, so any sort gives this result
+          const Item it = perm[i];
+          int j = i - 1;
+          while (j >= 0 && (perm[j].count != it.count ? perm[j].count > it.count : perm[j].index > it.index)) { perm[j + 1] = perm[j]; j--; }
+          perm[j + 1] = it;
+        }
         uint64_t sd[3] = {0, 0, 0};
         for (int i = 0; i < pal_size; i++) {
           const uint32_t c = (uint32_t)pals[(size_t)a * pal_size + perm[i].index];
