@@ -141,25 +141,40 @@ __global__ __launch_bounds__(256) void k_ff_update_wide(const int32_t *__restric
 }
 
 // one thread per segment: fold block partials, append the next centre (or finish)
-__global__ void k_ff_pick(Seg *__restrict__ segs, int nseg, int k, const BestKey *__restrict__ partial, int nblk,
-                          const int32_t *__restrict__ pts, int d, double *__restrict__ cent) {
-  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+// one workgroup per segment: the blocks' partial bests are reduced by 256 threads (`better` is a total order, so the reduction tree
+// gives the same winner as a serial scan), then the picked point becomes the next centre
+__global__ __launch_bounds__(256) void k_ff_pick(Seg *__restrict__ segs, int nseg, int k, const BestKey *__restrict__ partial, int nblk,
+                                                 const int32_t *__restrict__ pts, int d, double *__restrict__ cent) {
+  __shared__ BestKey s_best[256];
+  __shared__ int64_t s_cur;
+  const int seg = blockIdx.x, tid = threadIdx.x;
   if (seg >= nseg) return;
   Seg sg = segs[seg];
-  if (sg.init_done) return;
+  if (sg.init_done) return;  // uniform over the workgroup
   BestKey best{0, LLONG_MIN};
-  for (int b = sg.blk_first; b < sg.blk_first + sg.blk_count; b++) {
+  for (int b = sg.blk_first + tid; b < sg.blk_first + sg.blk_count; b += 256) {
     const BestKey c = partial[b];
     if (better(c, best)) best = c;
   }
-  if (sg.kk >= k || best.dist <= 0) {  // enough centres, or no distinct point left
-    sg.init_done = 1;
-  } else {
-    sg.cur = sg.begin + (-best.negidx);
-    for (int j = 0; j < d; j++) cent[((int64_t)seg * k + sg.kk) * d + j] = (double)pts[sg.cur * d + j];
-    sg.kk++;
+  s_best[tid] = best;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o && better(s_best[tid + o], s_best[tid])) s_best[tid] = s_best[tid + o];
+    __syncthreads();
   }
-  segs[seg] = sg;
+  best = s_best[0];
+  const bool done = sg.kk >= k || best.dist <= 0;  // enough centres, or no distinct point left
+  if (tid == 0) s_cur = done ? -1 : sg.begin + (-best.negidx);
+  __syncthreads();
+  if (!done) {
+    const int64_t cur = s_cur;
+    for (int j = tid; j < d; j += 256) cent[((int64_t)seg * k + sg.kk) * d + j] = (double)pts[cur * d + j];
+  }
+  if (tid == 0) {
+    if (done) sg.init_done = 1;
+    else { sg.cur = s_cur; sg.kk++; }
+    segs[seg] = sg;
+  }
 }
 
 __global__ void k_ff_first(Seg *__restrict__ segs, int nseg, int k, const int32_t *__restrict__ pts, int d, double *__restrict__ cent) {
@@ -595,7 +610,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
     else
       hipLaunchKernelGGL(k_ff_update_wide, dim3(nblk), dim3(256), 0, stream, pts, d, ds, k, mind.as<long long>(), partial.as<BestKey>());
-    hipLaunchKernelGGL(k_ff_pick, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
+    hipLaunchKernelGGL(k_ff_pick, dim3(nseg), dim3(256), 0, stream, ds, nseg, k, partial.as<BestKey>(), nblk, pts, d, cent);
   }
   TM_HIP(hipGetLastError());
   const size_t lds_assign = (size_t)KCH * 3 * 8 + (size_t)16 * k * 4 * 8;
