@@ -69,7 +69,7 @@ __global__ __launch_bounds__(192) void k_col_minmax(const int16_t *__restrict__ 
   if (a != INT_MAX) { atomicMin(&mn[c], a); atomicMax(&mx[c], b); }
 }
 
-struct CurveSpec { int col[KNN_ND]; int lo[3]; int range[3]; };
+struct CurveSpec { int col[KNN_NC]; int lo[3]; int range[3]; float rlo, rscale; /* radial coordinate: 8-bit step = (log2(R + 1) - rlo) * rscale */ };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Pack n rows into MFMA fragment order: per 32-row tile [kc][64 lanes][16 B] (lane = half*32 + row) followed by
@@ -125,9 +125,25 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       uint32_t s = 0;
       for (int p = 0; p < 192; p++) { const int v = s_v[threadIdx.x][p]; s += (uint32_t)(v * v); }
       reinterpret_cast<uint32_t *>(obase + kch * 1024)[threadIdx.x] = s;  // |v-c|^2 (the kernel drops the query side's parity bit)
+      if (with_box) {  // radial box dimension: |v-c| over the columns that are not box columns, rounded outwards, min/max over the rows
+        int64_t row = std::min<int64_t>(tile * 32 + threadIdx.x, n - 1);
+        if (rowperm) row = rowperm[row];
+        long long boxsq = 0;
+        for (int d = 0; d < KNN_NC; d++) { const long long c = (long long)feat[row * 192 + cs.col[d]] - centre[cs.col[d]]; boxsq += c * c; }
+        const long long rest = std::max(0ll, (long long)s - boxsq);
+        int lo = max(0, (int)floor(sqrt((double)rest)) - 1), hi = (int)ceil(sqrt((double)rest)) + 1;
+        for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if (threadIdx.x == 0) {
+          int *tb = reinterpret_cast<int *>(obase + kch * 1024 + 128);
+          tb[KNN_NC] = lo;
+          tb[KNN_ND + KNN_NC] = hi;
+          box_lo[(int64_t)KNN_NC * ntiles + tile] = lo;
+          box_hi[(int64_t)KNN_NC * ntiles + tile] = hi;
+        }
+      }
     }
     if (bad) atomicOr(err_flag, 1);
-    if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + KNN_ND) {  // bounding box of the tile over the box columns (raw values)
+    if (with_box && threadIdx.x >= 64 && threadIdx.x < 64 + KNN_NC) {  // bounding box of the tile over the box columns (raw values)
       const int d = threadIdx.x - 64;
       int a = INT_MAX, b = INT_MIN;
       for (int r = 0; r < 32; r++) {
@@ -156,17 +172,64 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every 
   return v;
 }
 
-// Morton key of the three widest columns (10 bits each over the union range), value = row index
-__global__ void k_curve_keys(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, uint32_t *__restrict__ key,
-                             uint32_t *__restrict__ idx) {
+__device__ __forceinline__ uint32_t spread8(uint32_t v) {  // 8 bits -> every fourth bit
+  v &= 0xff;
+  v = (v | (v << 12)) & 0x000f000f;
+  v = (v | (v << 6)) & 0x03030303;
+  v = (v | (v << 3)) & 0x11111111;
+  return v;
+}
+
+// log2(R + 1) of every row, R = |v - c| over the columns that are not box columns (the radial box dimension of tm_knn_kernel.h),
+// and its range over the rows (floats >= 0: their bit patterns order like the values).  8 lanes per row, 48 bytes each.
+__global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const int16_t *__restrict__ centre,
+                                                    float *__restrict__ out, unsigned int *__restrict__ range /* [0] min, [1] max */) {
+  const int j8 = threadIdx.x & 7;
+  unsigned int lmin = 0x7f800000u, lmax = 0u;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < n; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + (threadIdx.x >> 3);
+    long long sq = 0;
+    if (i < n) {
+      const v4i *rp = reinterpret_cast<const v4i *>(feat + i * 192) + j8 * 3;
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        const v4i x = rp[v];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int col = (j8 * 3 + v) * 8 + 2 * j;
+          const int c0 = (int)(int16_t)(x[j] & 0xffff) - centre[col], c1 = (x[j] >> 16) - centre[col + 1];
+          sq += (long long)c0 * c0 + (long long)c1 * c1;
+        }
+      }
+      if (j8 == 0)
+        for (int d = 0; d < KNN_NC; d++) { const long long c = (long long)feat[i * 192 + cs.col[d]] - centre[cs.col[d]]; sq -= c * c; }
+    }
+    sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+    if (i < n && j8 == 0) {
+      const float lr = log2f(sqrtf((float)max(sq, 0ll)) + 1.0f);
+      out[i] = lr;
+      lmin = min(lmin, __float_as_uint(lr));
+      lmax = max(lmax, __float_as_uint(lr));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { lmin = min(lmin, (unsigned)__shfl_xor((int)lmin, o)); lmax = max(lmax, (unsigned)__shfl_xor((int)lmax, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lmin); atomicMax(&range[1], lmax); }
+}
+
+// Morton key, value = row index: the three widest columns at 8 bits each over the union range, plus 8 bits of the radial coordinate
+// over ITS range, so that the rows of a tile are alike in texture energy as well as in mean colour -- which is what the radial
+// box dimension needs in order to prune (30 % fewer evaluated pairs on the bench clip than a 3 x 10-bit curve of the columns alone).
+__global__ void k_curve_keys(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const float *__restrict__ radial,
+                             uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint32_t k = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
       long long v = (long long)feat[i * 192 + cs.col[d]] - cs.lo[d];
       v = v < 0 ? 0 : (v > cs.range[d] ? cs.range[d] : v);
-      k |= spread10((uint32_t)(v * 1023 / max(cs.range[d], 1))) << d;
+      k |= spread8((uint32_t)(v * 255 / max(cs.range[d], 1))) << d;
     }
+    k |= spread8((uint32_t)min(255.0f, max(0.0f, (radial[i] - cs.rlo) * cs.rscale))) << 3;
     key[i] = k;
     idx[i] = (uint32_t)i;
   }
@@ -224,16 +287,16 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
     const int64_t q = qperm[p];
     const int16_t *qrow = queries + q * 192;
     const uint32_t best = out_err[q];
-    int qv[KNN_ND];
+    int qv[KNN_NC];  // the tie rescan prunes with the column boxes only
 #pragma unroll
-    for (int d = 0; d < KNN_ND; d++) qv[d] = qrow[bx.col[d]];
+    for (int d = 0; d < KNN_NC; d++) qv[d] = qrow[bx.col[d]];
     if (threadIdx.x == 0) s_min = 0xffffffffu;
     __syncthreads();
     unsigned int mine = 0xffffffffu;
     for (int64_t t = threadIdx.x; t < n_ttiles; t += 256) {
       long long lb = 0;
 #pragma unroll
-      for (int d = 0; d < KNN_ND; d++) {
+      for (int d = 0; d < KNN_NC; d++) {
         const long long g = max(0, max(bx.lo[(int64_t)d * n_ttiles + t] - qv[d], qv[d] - bx.hi[(int64_t)d * n_ttiles + t]));
         lb += g * g;
       }
@@ -345,6 +408,7 @@ struct tm_knn_index_impl {
   DevBuf tpack, qpack, plan_dev, scratch, best_key, best_tile, err_flag;
   DevBuf tperm, tkey, box_lo, box_hi;               // database sorted along the curve, per-tile boxes
   DevBuf qperm, qkey, skey, skey2, sidx, sort_tmp;  // queries sorted along the curve
+  DevBuf rrange, tradial, qradial;                  // radial coordinate of the rows (curve key) and its range
   CurveSpec curve;
   DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
   int64_t last_visited = 0, last_ties = 0;
@@ -369,18 +433,28 @@ static int upload_plan(tm_knn_index_impl *ix, hipStream_t stream) {
 }
 
 // rows sorted along the Morton curve: perm (row order) and the sorted keys
-static int sort_by_curve(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &perm, DevBuf &keys_sorted, hipStream_t stream) {
+// log2(R + 1) per row into `radial` and the running range into ix->rrange (two uint32, reset by the caller)
+static int row_radial(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &radial, hipStream_t stream) {
+  TM_TRY(radial.alloc((size_t)std::max<int64_t>(n, 1) * 4));
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_row_radial, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 8192)), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve,
+                     ix->plan_dev.as<int16_t>(), radial.as<float>(), ix->rrange.as<unsigned int>());
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+static int sort_by_curve(tm_knn_index_impl *ix, const void *feat, int64_t n, const DevBuf &radial, DevBuf &perm, DevBuf &keys_sorted, hipStream_t stream) {
   TM_TRY(ix->skey.alloc((size_t)n * 4)); TM_TRY(ix->sidx.alloc((size_t)n * 4));
   TM_TRY(perm.alloc((size_t)n * 4)); TM_TRY(keys_sorted.alloc((size_t)n * 4));
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_curve_keys, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve, ix->skey.as<uint32_t>(),
-                     ix->sidx.as<uint32_t>());
+  hipLaunchKernelGGL(k_curve_keys, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve, radial.as<float>(),
+                     ix->skey.as<uint32_t>(), ix->sidx.as<uint32_t>());
   size_t tb = 0;
   TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, ix->skey.as<uint32_t>(), keys_sorted.as<uint32_t>(), ix->sidx.as<uint32_t>(),
-                                   perm.as<uint32_t>(), (size_t)n, 0, 30, stream));
+                                   perm.as<uint32_t>(), (size_t)n, 0, 32, stream));
   TM_TRY(ix->sort_tmp.alloc(tb));
   TM_HIP(rocprim::radix_sort_pairs(ix->sort_tmp.p, tb, ix->skey.as<uint32_t>(), keys_sorted.as<uint32_t>(), ix->sidx.as<uint32_t>(),
-                                   perm.as<uint32_t>(), (size_t)n, 0, 30, stream));
+                                   perm.as<uint32_t>(), (size_t)n, 0, 32, stream));
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -605,6 +679,7 @@ void knn_index_destroy(tm_knn_index_impl *ix) { delete ix; }
 // the curve and packed in MFMA fragment order
 static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream) {
   ColStats qs;
+  bool fresh_radial = false;  // the queries' radial coordinates were computed while the index was being built
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
@@ -636,14 +711,31 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
         return hi >= lo ? hi - lo : 0;
       };
       std::stable_sort(order, order + 192, [&](int a, int b) { return urange(a) > urange(b); });
-      for (int d = 0; d < KNN_ND; d++) ix->curve.col[d] = order[d];
+      for (int d = 0; d < KNN_NC; d++) ix->curve.col[d] = order[d];
       for (int d = 0; d < 3; d++) {
         const int c = order[d];
         ix->curve.lo[d] = std::min(ix->tstats.mn[c], qs.mn[c]);
         ix->curve.range[d] = std::max(1, urange(c));
       }
     }
-    TM_TRY(sort_by_curve(ix, ix->db, ix->nt, ix->tperm, ix->skey2, stream));
+    {  // radial coordinate of every database row and of this batch of queries; its range (fixed with the index) scales the key's 8 bits
+      TM_TRY(ix->rrange.alloc(8));
+      const unsigned int init[2] = {0x7f800000u, 0u};
+      TM_HIP(hipMemcpyAsync(ix->rrange.p, init, 8, hipMemcpyHostToDevice, stream));
+      TM_TRY(row_radial(ix, ix->db, ix->nt, ix->tradial, stream));
+      TM_TRY(row_radial(ix, queries, nq, ix->qradial, stream));
+      unsigned int rr[2];
+      TM_HIP(hipMemcpyAsync(rr, ix->rrange.p, 8, hipMemcpyDeviceToHost, stream));
+      TM_HIP(hipStreamSynchronize(stream));
+      float lo, hi;
+      memcpy(&lo, &rr[0], 4); memcpy(&hi, &rr[1], 4);
+      if (!(hi > lo)) { lo = 0.0f; hi = 1.0f; }
+      ix->curve.rlo = lo;
+      ix->curve.rscale = 255.999f / (hi - lo);
+      fresh_radial = true;
+    }
+    TM_TRY(sort_by_curve(ix, ix->db, ix->nt, ix->tradial, ix->tperm, ix->skey2, stream));
+    ix->tradial.release();
     TM_TRY(ix->tkey.alloc((size_t)ntt * 4));
     TM_HIP(hipMemcpy2DAsync(ix->tkey.p, 4, ix->skey2.p, 128, 4, (size_t)ntt, hipMemcpyDeviceToDevice, stream));  // key of each tile's first row
     TM_TRY(ix->box_lo.alloc((size_t)ntt * KNN_ND * 4));
@@ -651,7 +743,8 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
     TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->plan.ht, ix->tperm, 1, ix->tpack, stream));
     ix->packed = true;
   }
-  TM_TRY(sort_by_curve(ix, queries, nq, ix->qperm, ix->qkey, stream));
+  if (!fresh_radial) TM_TRY(row_radial(ix, queries, nq, ix->qradial, stream));  // a later batch on a built index (its range result is not used)
+  TM_TRY(sort_by_curve(ix, queries, nq, ix->qradial, ix->qperm, ix->qkey, stream));
   TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qperm, 0, ix->qpack, stream));
   return TM_OK;
 }
@@ -679,7 +772,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   bx.lo = ix->box_lo.as<int>();
   bx.hi = ix->box_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
-  for (int d = 0; d < KNN_ND; d++) bx.col[d] = ix->curve.col[d];
+  for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   launch_mfma(ix->plan.ht, ix->plan.hq,
               KnnLaunch{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
                         ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt,
@@ -787,7 +880,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   bx.lo = ix->box_lo.as<int>();
   bx.hi = ix->box_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
-  for (int d = 0; d < KNN_ND; d++) bx.col[d] = ix->curve.col[d];
+  for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;

@@ -55,7 +55,11 @@ constexpr int KNN_NW = TM_KNN_NW;  // waves per workgroup (NQ * NW * 32 = 128 qu
 // skips the MFMAs of a staged tile its own queries rule out.  Exactness: the minimum VALUE is exact (a tile is only
 // skipped when bound > best + 1); when a second tile reaches the same value the lane raises a tie flag and the refine
 // stage settles the lowest-index rule.
-constexpr int KNN_ND = 6;        // bounding-box columns
+constexpr int KNN_NC = 6;        // bounding-box columns
+// One more box dimension, radial: R = |v - c| over all the OTHER columns.  |R(q) - R(t)|^2 <= the squared distance over those
+// columns (reverse triangle inequality), so its gap adds to the lower bound like a column's; it tells a noisy tile from a smooth
+// one of the same mean colour, which the widest (low-frequency) columns cannot.  Stored as integers rounded outwards.
+constexpr int KNN_ND = KNN_NC + 1;
 #ifndef TM_KNN_K0
 #define TM_KNN_K0 8
 #endif
@@ -68,7 +72,8 @@ constexpr int KNN_CHUNK = TM_KNN_CHUNK;  // tiles tested per compaction round (b
 struct KnnBoxes {
   const int *lo, *hi;   // [KNN_ND][n_ttiles] bounding boxes of the database tiles
   const uint32_t *tkey; // [n_ttiles] curve key of each tile's first row (ascending)
-  int col[KNN_ND];      // source feature column of each box dimension
+  int col[KNN_NC];      // source feature column of each box dimension
+  int cen[KNN_NC];      // the digit plan's centre of that column (the radial dimension is measured from the centres)
 };
 
 // Conservative int32 form of the box bound: sum over the box columns of (gap >> 1)^2 <= (best + 1) >> 2 is implied by
@@ -193,9 +198,20 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
     static_assert(NQ == 1 || NQ == 2, "lane <-> query mapping: one sub-tile (both half-waves hold it) or two per wave");
     const int64_t p = min((wgt * QT_PER_WG + (NQ == 2 ? half : 0) * NW + wave) * 32 + (lane & 31), nq - 1);
     const int16_t *row = queries + (int64_t)qperm[p] * 192;
+    long long boxsq = 0;  // squared distance from the centre over the box columns
 #pragma unroll
     for (int d = 0; d < ND; d++) {
-      int lo = row[bx.col[d]], hi = lo;
+      int lo, hi;
+      if (d < KNN_NC) {
+        lo = hi = row[bx.col[d]];
+        const long long c = lo - bx.cen[d];
+        boxsq += c * c;
+      } else {
+        // radial: |q-c|^2 over the other columns = the packed norm (known up to its dropped parity bit) minus the box columns' part
+        const long long n2 = (long long)(unsigned)(NQ == 2 && half ? nq2[NQ - 1] : nq2[0]);
+        lo = max(0, (int)floor(sqrt((double)max(0ll, n2 - boxsq))) - 1);
+        hi = (int)ceil(sqrt((double)max(0ll, n2 + 1 - boxsq))) + 1;
+      }
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
       if ((lane & 31) == 0 && (NQ == 2 || half == 0)) { s_box[0][wave][NQ == 2 ? half : 0][d] = lo; s_box[1][wave][NQ == 2 ? half : 0][d] = hi; }
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
     // sub-tile level skip: the list round already judged every (tile, sub-tile) pair with the bests of that time;
     // pairs it kept are re-judged against the current best with the tile's box (it rides in LDS behind the norms)
     bool do_sub[NQ];
-    bool do_tile = false;
+    [[maybe_unused]] bool do_tile = false;  // read by the TM_KNN_STAMPS build only
     {
       unsigned long long ok = ~0ull;
       if (prune) {
