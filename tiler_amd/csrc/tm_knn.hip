@@ -69,7 +69,13 @@ __global__ __launch_bounds__(192) void k_col_minmax(const int16_t *__restrict__ 
   if (a != INT_MAX) { atomicMin(&mn[c], a); atomicMax(&mx[c], b); }
 }
 
-struct CurveSpec { int col[KNN_NC]; int lo[3]; int range[3]; float rlo, rscale; /* radial coordinate: 8-bit step = (log2(R + 1) - rlo) * rscale */ };
+struct CurveSpec {
+  int col[KNN_NC];
+  int lo[3], range[3];      // the three curve columns: union range
+  float scale[4], off[4];   // quantised coordinate of dimension d (three columns, radial) = (value - off) * scale, clamped to its bits
+  int bits[4];
+  int rlog;                 // radial coordinate taken as log2(R + 1) instead of R
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // Pack n rows into MFMA fragment order: per 32-row tile [kc][64 lanes][16 B] (lane = half*32 + row) followed by
@@ -180,7 +186,7 @@ __device__ __forceinline__ uint32_t spread8(uint32_t v) {  // 8 bits -> every fo
   return v;
 }
 
-// log2(R + 1) of every row, R = |v - c| over the columns that are not box columns (the radial box dimension of tm_knn_kernel.h),
+// R of every row, R = |v - c| over the columns that are not box columns (the radial box dimension of tm_knn_kernel.h),
 // and its range over the rows (floats >= 0: their bit patterns order like the values).  8 lanes per row, 48 bytes each.
 __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const int16_t *__restrict__ centre,
                                                     float *__restrict__ out, unsigned int *__restrict__ range /* [0] min, [1] max */) {
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
     }
     sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
     if (i < n && j8 == 0) {
-      const float lr = log2f(sqrtf((float)max(sq, 0ll)) + 1.0f);
+      const float lr = sqrtf((float)max(sq, 0ll));
       out[i] = lr;
       lmin = min(lmin, __float_as_uint(lr));
       lmax = max(lmax, __float_as_uint(lr));
@@ -222,14 +228,18 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
 __global__ void k_curve_keys(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const float *__restrict__ radial,
                              uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t k = 0;
+    // per-dimension bit counts, interleaved from the top: a dimension with more bits splits first
+    uint32_t q[4];
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-      long long v = (long long)feat[i * 192 + cs.col[d]] - cs.lo[d];
-      v = v < 0 ? 0 : (v > cs.range[d] ? cs.range[d] : v);
-      k |= spread8((uint32_t)(v * 255 / max(cs.range[d], 1))) << d;
+    for (int d = 0; d < 4; d++) {
+      const float v = d < 3 ? (float)feat[i * 192 + cs.col[d]] : (cs.rlog ? log2f(radial[i] + 1.0f) : radial[i]);
+      q[d] = (uint32_t)min((float)((1u << cs.bits[d]) - 1u), max(0.0f, (v - cs.off[d]) * cs.scale[d]));
     }
-    k |= spread8((uint32_t)min(255.0f, max(0.0f, (radial[i] - cs.rlo) * cs.rscale))) << 3;
+    uint32_t k = 0;
+    for (int b = 15; b >= 0; b--)
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+        if (cs.bits[d] > b) k = (k << 1) | ((q[d] >> b) & 1u);
     key[i] = k;
     idx[i] = (uint32_t)i;
   }
@@ -677,7 +687,7 @@ void knn_index_destroy(tm_knn_index_impl *ix) { delete ix; }
 
 // everything a search needs before the scan: digit plan (database repacked if the batch widens it), both sides sorted along
 // the curve and packed in MFMA fragment order
-static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream) {
+static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream, bool for_topk = false) {
   ColStats qs;
   bool fresh_radial = false;  // the queries' radial coordinates were computed while the index was being built
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
@@ -727,11 +737,39 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
       unsigned int rr[2];
       TM_HIP(hipMemcpyAsync(rr, ix->rrange.p, 8, hipMemcpyDeviceToHost, stream));
       TM_HIP(hipStreamSynchronize(stream));
-      float lo, hi;
-      memcpy(&lo, &rr[0], 4); memcpy(&hi, &rr[1], 4);
-      if (!(hi > lo)) { lo = 0.0f; hi = 1.0f; }
-      ix->curve.rlo = lo;
-      ix->curve.rscale = 255.999f / (hi - lo);
+      float rlo, rhi;
+      memcpy(&rlo, &rr[0], 4); memcpy(&rhi, &rr[1], 4);
+      if (!(rhi > rlo)) { rlo = 0.0f; rhi = 1.0f; }
+      CurveSpec &cs = ix->curve;
+      // Measured on the bench clip (column ranges 20262 / 13399 / 13118, R in 2566..5284): every dimension over its own range with
+      // 8, 7, 7, 8 bits and log2 R -- R cells of 0.3 % -- evaluates 15.3 G pairs (scan 18.4 ms); 8, 8, 8, 8: 14.7 G but 20.0 ms;
+      // isotropic cells (TM_KNN_CURVE=iso: 9, 8, 8, 6 bits, linear R): 18.6 G, 21.4 ms; columns only (10, 10, 10): 28.9 G, 30.2 ms.
+      // The k-nearest scans (thresholds at the 64th neighbour, where the radial gap decides little) do better on the columns-only
+      // curve: 10, 10, 10, 0 bits (reference-defaults run on the bench clip: first collection pass 163 ms against 207 ms).
+      const char *mode = getenv("TM_KNN_CURVE");
+      if (!(mode && !strcmp(mode, "iso"))) {
+        const int nb_nn[4] = {8, 7, 7, 8}, nb_topk[4] = {10, 10, 10, 0};
+        const int *nb = for_topk ? nb_topk : nb_nn;
+        cs.rlog = 1;
+        for (int d = 0; d < 3; d++) { cs.bits[d] = nb[d]; cs.off[d] = (float)cs.lo[d]; cs.scale[d] = (float)((1 << nb[d]) - 1) / (float)cs.range[d]; }
+        cs.bits[3] = nb[3]; cs.off[3] = log2f(rlo + 1.0f);
+        cs.scale[3] = ((float)(1 << nb[3]) - 0.001f) / std::max(1e-6f, log2f(rhi + 1.0f) - log2f(rlo + 1.0f));
+      } else {
+        // isotropic cells: one cell width w for the three columns and the radial coordinate, the smallest power of two at which the
+        // four bit counts fit the 32-bit key
+        cs.rlog = 0;
+        const float ext[4] = {(float)cs.range[0], (float)cs.range[1], (float)cs.range[2], rhi - rlo};
+        float w = 1.0f / 64;
+        for (;; w *= 2) {
+          int total = 0;
+          for (int d = 0; d < 4; d++) { cs.bits[d] = std::max(1, std::min(16, (int)std::ceil(std::log2(ext[d] / w + 1.0f)))); total += cs.bits[d]; }
+          if (total <= 32) break;
+        }
+        for (int d = 0; d < 4; d++) { cs.off[d] = d < 3 ? (float)cs.lo[d] : rlo; cs.scale[d] = 1.0f / w; }
+      }
+      if (getenv("TM_KNN_DEBUG"))
+        fprintf(stderr, "[tm_knn] curve: column ranges %d %d %d, radial %.1f..%.1f -> bits %d %d %d %d (%s)\n", cs.range[0], cs.range[1], cs.range[2], rlo, rhi,
+                cs.bits[0], cs.bits[1], cs.bits[2], cs.bits[3], cs.rlog ? "own ranges, log radial" : "isotropic cells");
       fresh_radial = true;
     }
     TM_TRY(sort_by_curve(ix, ix->db, ix->nt, ix->tradial, ix->tperm, ix->skey2, stream));
@@ -857,7 +895,7 @@ struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; c
 static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
                      uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
   const auto t_start = std::chrono::steady_clock::now();
-  TM_TRY(prepare_search(ix, feats, n, stream));
+  TM_TRY(prepare_search(ix, feats, n, stream, true));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
   const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
   DevBuf tau, map_sorted, cand, cand_cnt, ovf, counter;
@@ -884,6 +922,10 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
+  {  // few queries left: their few workgroups would each stage most of the database one after the other -- share the tile list
+    const int64_t wgs = (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW);
+    a.split = wgs >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(wgs, 1)));
+  }
   launch_mfma(ix->plan.ht, ix->plan.hq, a);
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),

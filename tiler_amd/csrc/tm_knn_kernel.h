@@ -111,9 +111,9 @@ __device__ __forceinline__ void knn_wait_vm(int behind) {
 
 // Compacts into s_list / s_mask the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
 // workgroup can still use (bit = wave * NQ + sub-tile), judged with that sub-tile's largest running best (d'' = SSD -
-// parity, so SSD <= d'' + 1).  Kept out of line so its registers do not count against the MFMA loop.
-__device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
-                                                        int chunk_base, int r0a, int r0b, int prune, const int *s_box_lo,
+// parity, so SSD <= d'' + 1).
+__device__ __forceinline__ int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
+                                                        int chunk_base, int r0a, int r0b, int split, int split_idx, int prune, const int *s_box_lo,
                                                         const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask,
                                                         int *s_cnt) {
   constexpr int NS = KNN_NW * KNN_NQ, ND = KNN_ND, NT = KNN_NW * 64;
@@ -124,6 +124,7 @@ __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ 
   for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT) {
     const int t = chunk_base + k;
     if (t >= r0a && t < r0b) continue;  // done in round 0
+    if (split > 1 && t % split != split_idx) continue;  // another workgroup of this query group scans that tile
     unsigned mask = prune ? 0u : 0xffu;
     if (prune) {
       int tlo[ND], thi[ND];
@@ -140,6 +141,16 @@ __device__ __attribute__((noinline)) int knn_build_list(const int *__restrict__ 
   }
   __syncthreads();
   return *s_cnt;
+}
+
+// Out-of-line copy for the nearest-neighbour kernel, whose loop is faster that way (20.4 -> 18.3 ms on the bench clip) although the
+// call costs it two spilled operand quads; the collection kernel inlines the build: with its ladder counters live, the calling
+// convention (values across a call must sit in the callee-saved half of the file) spilled 100-190 bytes, and every reload's
+// s_waitcnt vmcnt(0) also waited for the tiles in flight (first collection pass of the reference-defaults run: 230 -> 160 ms).
+__device__ __attribute__((noinline)) int knn_build_list_call(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
+                                                             int chunk_base, int r0a, int r0b, int prune, const int *s_box_lo,
+                                                             const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask, int *s_cnt) {
+  return knn_build_list(box_lo, box_hi, n_ttiles, chunk_base, r0a, r0b, 1, 0, prune, s_box_lo, s_box_hi, s_smax, s_list, s_mask, s_cnt);
 }
 
 template <int HT, int HQ, bool TOPK>
@@ -180,14 +191,28 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   const int64_t wgt = blockIdx.x;
   v4i bq[NQ][KQ];
   int nq2[NQ], best[NQ], bestt[NQ], tie[NQ];  // bestt = tile << 5 | row of the first minimum
-  int64_t qtile[NQ];
+  // query tile of sub-tile s: a function of uniform values, recomputed where it is needed instead of living in four registers
+  auto qtile_of = [&](int s) -> int64_t { return wgt * QT_PER_WG + s * NW + __builtin_amdgcn_readfirstlane(wave); };
+  // The 20 operand quads of the queries.  The nearest-neighbour kernel reads them AGAIN after every out-of-line list build (six
+  // times per workgroup, from L2): a value that is rewritten after a call is dead across it, which takes 80 registers out of what
+  // must survive the call in the callee-saved half of the file -- without that the allocator sits on the edge of spilling two quads,
+  // and a reload's s_waitcnt vmcnt(0) in the MFMA chain also waits for the tiles in flight (18.3 ms with no spill, 19.9 with two).
+  auto load_bq = [&]() {
+#pragma unroll
+    for (int s = 0; s < NQ; s++) {
+      const int64_t qt = qtile_of(s) < n_qtiles ? qtile_of(s) : n_qtiles - 1;
+      const uint8_t *qb = qpack + qt * (int64_t)Q_BYTES;
+      asm volatile("" : "+v"(qb));  // a pointer the compiler cannot match with the earlier loads
+#pragma unroll
+      for (int kc = 0; kc < KQ; kc++) bq[s][kc] = *reinterpret_cast<const v4i *>(qb + (kc * 64 + lane) * 16);
+    }
+  };
+  load_bq();
 #pragma unroll
   for (int s = 0; s < NQ; s++) {
-    qtile[s] = wgt * QT_PER_WG + s * NW + wave;  // interleaved: curve neighbours (which want the same tiles) sit in different waves
-    const int64_t qt = qtile[s] < n_qtiles ? qtile[s] : n_qtiles - 1;
+    // interleaved: curve neighbours (which want the same tiles) sit in different waves
+    const int64_t qt = qtile_of(s) < n_qtiles ? qtile_of(s) : n_qtiles - 1;
     const uint8_t *qb = qpack + qt * (int64_t)Q_BYTES;
-#pragma unroll
-    for (int kc = 0; kc < KQ; kc++) bq[s][kc] = *reinterpret_cast<const v4i *>(qb + (kc * 64 + lane) * 16);
     nq2[s] = reinterpret_cast<const int *>(qb + KQ * 1024)[lane & 31] & ~1;  // 2*(|q-c|^2 >> 1); the parity bit returns in the refine stage
     best[s] = TOPK ? tau[qt * 32 + (lane & 31)] : INT_MAX;
     bestt[s] = INT_MAX;
@@ -241,7 +266,10 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
   const int bx_qlo = bx_on ? s_box[0][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MIN / 2;
   const int bx_qhi = bx_on ? s_box[1][wave][bx_on ? bx_s : 0][bx_on ? bx_d : 0] : INT_MAX / 2;
   // (readfirstlane: the loop state below is uniform; saying so moves its arithmetic and branches to the scalar unit)
-  const int r0a = __builtin_amdgcn_readfirstlane(s_ctl[0]), r0b = (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)  // round-0 tiles [r0a, r0b)
+  // gridDim.y > 1 (collection passes over few queries): the workgroups of one query group share the tile list, tile t goes to
+  // workgroup t mod gridDim.y; the seed round is dropped (its tiles come through the lists like all others)
+  const int split = TOPK ? (int)gridDim.y : 1, split_idx = TOPK ? (int)blockIdx.y : 0;  // constants in the nearest-neighbour kernel
+  const int r0a = __builtin_amdgcn_readfirstlane(s_ctl[0]), r0b = split > 1 ? r0a : (int)min((int64_t)r0a + KNN_K0, n_ttiles);  // round-0 tiles [r0a, r0b)
   long long nvisit = 0, nstaged = 0;
 
   // candidate iterator: round 0 = [r0a, r0b); then chunks of the tile list, compacted into s_list by all threads
@@ -269,8 +297,15 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
 #if TM_KNN_STAMPS
       const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
-      list_n = __builtin_amdgcn_readfirstlane(knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0],
-                                                             &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
+      if constexpr (TOPK)
+        list_n = __builtin_amdgcn_readfirstlane(knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, split, split_idx, prune, &s_box[0][0][0][0],
+                                                               &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
+      else
+      {
+        list_n = __builtin_amdgcn_readfirstlane(knn_build_list_call(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0],
+                                                                    &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
+        load_bq();
+      }
 #if TM_KNN_STAMPS
       st_build += __builtin_amdgcn_s_memtime() - tb_;
 #endif
@@ -450,8 +485,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       const int m = (int)((unsigned)tm + (unsigned)nq2[s]);
 #define TM_KNN_D(r) ((int)((unsigned)t[r] + (unsigned)nq2[s]))
       if (TOPK) {  // collection mode: every row within the query's threshold is a candidate
-        const int64_t q = qtile[s] * 32 + (lane & 31);
-        const bool hit = m <= best[s] && qtile[s] < n_qtiles && q < nq;
+        const int64_t q = qtile_of(s) * 32 + (lane & 31);
+        const bool hit = m <= best[s] && qtile_of(s) < n_qtiles && q < nq;
         if (hit) {
           // rung j (1..7) = (8 - j) * step <= tau0 - j * tau0 / 8; the last database tile pads with copies of its last row,
           // which must not be counted
@@ -525,8 +560,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
     } else if (ob < best[s]) {
       best[s] = ob; bestt[s] = ot; tie[s] = oti;
     }
-    if (!TOPK && lane < 32 && qtile[s] < n_qtiles) {
-      const int64_t q = qtile[s] * 32 + lane;
+    if (!TOPK && lane < 32 && qtile_of(s) < n_qtiles) {
+      const int64_t q = qtile_of(s) * 32 + lane;
       best_key[q] = best[s];
       best_tile[q] = (bestt[s] & 0x3fffffff) | (tie[s] ? (1 << 30) : 0);  // sorted row of the first minimum; bit 30: tie flag
     }
@@ -550,6 +585,7 @@ struct KnnLaunch {
   const uint8_t *qpack; int64_t n_qtiles; const int16_t *queries; const uint32_t *qperm, *qkey; int64_t nq; int prune;
   int *best_key, *best_tile; unsigned long long *visited; hipStream_t stream;
   const int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0, cand_k = 0;  // collection mode (k nearest)
+  int split = 1;  // collection mode: workgroups per query group (they share its tile list)
 };
 
 // one per HT, defined in tm_knn_k<HT>.hip
@@ -568,7 +604,7 @@ template <int HT> void knn_launch_ht(int hq, const KnnLaunch &a);
 #define TM_KNN_DEFINE_HT(HT)                                                              \
   template <> void knn_launch_ht<HT>(int hq, const KnnLaunch &a) {                        \
     const int64_t wg_tiles = (a.n_qtiles + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW);      \
-    const dim3 grid((unsigned)wg_tiles), block(KNN_NW * 64);                              \
+    const dim3 grid((unsigned)wg_tiles, (unsigned)(a.tau ? a.split : 1)), block(KNN_NW * 64);  \
     switch (hq) {                                                                         \
       TM_KNN_CASE(HT, 0) TM_KNN_CASE(HT, 1) TM_KNN_CASE(HT, 2) TM_KNN_CASE(HT, 3)          \
       TM_KNN_CASE(HT, 4) TM_KNN_CASE(HT, 5)                                               \
