@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 I8_DENSE_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: bf16 dense ~2.5 PF, i8 MFMA = 2x bf16 per clock
 # HBM-side bytes per launch of the dominant kernel on the default workload, from the separate rocprofv3 --pmc passes of
 # profiles/r01_pmc_knn.md: 2 x FETCH_SIZE (gfx950 counts half of a 16-B/lane stream) + WRITE_SIZE, in bytes
-PMC_TRAFFIC_BYTES = 2 * 82019637 * 1024 + 36914 * 1024
+PMC_TRAFFIC_BYTES = 2 * 33385770 * 1024 + 36914 * 1024
 
 
 def cpu_baseline(width, height, nframes, palette_count, t_global, seconds_budget=20.0):
