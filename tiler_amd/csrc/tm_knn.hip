@@ -169,6 +169,18 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
   }
 }
 
+// second-level boxes: min / max of the tile boxes over runs of KNN_GROUP tiles, per box dimension
+__global__ void k_group_boxes(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t ntiles, int64_t ngroups, int *__restrict__ grp_lo,
+                              int *__restrict__ grp_hi) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < ngroups * KNN_ND; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t d = i / ngroups, g = i - d * ngroups;
+    int a = INT_MAX, b = INT_MIN;
+    for (int64_t t = g * KNN_GROUP; t < std::min<int64_t>((g + 1) * KNN_GROUP, ntiles); t++) { a = min(a, box_lo[d * ntiles + t]); b = max(b, box_hi[d * ntiles + t]); }
+    grp_lo[i] = a;
+    grp_hi[i] = b;
+  }
+}
+
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
   v &= 0x3ff;
   v = (v | (v << 16)) & 0x030000ff;
@@ -416,7 +428,7 @@ struct tm_knn_index_impl {
   KnnPlan plan;
   bool packed = false;
   DevBuf tpack, qpack, plan_dev, scratch, best_key, best_tile, err_flag;
-  DevBuf tperm, tkey, box_lo, box_hi;               // database sorted along the curve, per-tile boxes
+  DevBuf tperm, tkey, box_lo, box_hi, grp_lo, grp_hi;  // database sorted along the curve, per-tile boxes, boxes of runs of KNN_GROUP tiles
   DevBuf qperm, qkey, skey, skey2, sidx, sort_tmp;  // queries sorted along the curve
   DevBuf rrange, tradial, qradial;                  // radial coordinate of the rows (curve key) and its range
   CurveSpec curve;
@@ -779,6 +791,13 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
     TM_TRY(ix->box_lo.alloc((size_t)ntt * KNN_ND * 4));
     TM_TRY(ix->box_hi.alloc((size_t)ntt * KNN_ND * 4));
     TM_TRY(run_pack(ix, ix->db, ix->nt, 0, ix->plan.ht, ix->tperm, 1, ix->tpack, stream));
+    {
+      const int64_t ng = (ntt + KNN_GROUP - 1) / KNN_GROUP;
+      TM_TRY(ix->grp_lo.alloc((size_t)ng * KNN_ND * 4)); TM_TRY(ix->grp_hi.alloc((size_t)ng * KNN_ND * 4));
+      hipLaunchKernelGGL(k_group_boxes, dim3((unsigned)std::min<int64_t>((ng * KNN_ND + 255) / 256, 1024)), dim3(256), 0, stream, ix->box_lo.as<int>(),
+                         ix->box_hi.as<int>(), ntt, ng, ix->grp_lo.as<int>(), ix->grp_hi.as<int>());
+      TM_HIP(hipGetLastError());
+    }
     ix->packed = true;
   }
   if (!fresh_radial) TM_TRY(row_radial(ix, queries, nq, ix->qradial, stream));  // a later batch on a built index (its range result is not used)
@@ -809,6 +828,8 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
   bx.hi = ix->box_hi.as<int>();
+  bx.glo = ix->grp_lo.as<int>();
+  bx.ghi = ix->grp_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   launch_mfma(ix->plan.ht, ix->plan.hq,
@@ -917,6 +938,8 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
   bx.hi = ix->box_hi.as<int>();
+  bx.glo = ix->grp_lo.as<int>();
+  bx.ghi = ix->grp_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,

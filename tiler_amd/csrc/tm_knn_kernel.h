@@ -60,6 +60,7 @@ constexpr int KNN_NC = 6;        // bounding-box columns
 // columns (reverse triangle inequality), so its gap adds to the lower bound like a column's; it tells a noisy tile from a smooth
 // one of the same mean colour, which the widest (low-frequency) columns cannot.  Stored as integers rounded outwards.
 constexpr int KNN_ND = KNN_NC + 1;
+constexpr int KNN_GROUP = 128;   // tiles per second-level box = threads of a workgroup: one pass of the list build's loop
 #ifndef TM_KNN_K0
 #define TM_KNN_K0 8
 #endif
@@ -71,6 +72,7 @@ constexpr int KNN_CHUNK = TM_KNN_CHUNK;  // tiles tested per compaction round (b
 
 struct KnnBoxes {
   const int *lo, *hi;   // [KNN_ND][n_ttiles] bounding boxes of the database tiles
+  const int *glo, *ghi; // [KNN_ND][ceil(n_ttiles / KNN_GROUP)] boxes of runs of KNN_GROUP tiles: a run no sub-tile can use is skipped whole
   const uint32_t *tkey; // [n_ttiles] curve key of each tile's first row (ascending)
   int col[KNN_NC];      // source feature column of each box dimension
   int cen[KNN_NC];      // the digit plan's centre of that column (the radial dimension is measured from the centres)
@@ -112,16 +114,34 @@ __device__ __forceinline__ void knn_wait_vm(int behind) {
 // Compacts into s_list / s_mask the tiles of [chunk_base, chunk_base + KNN_CHUNK) that at least one query sub-tile of the
 // workgroup can still use (bit = wave * NQ + sub-tile), judged with that sub-tile's largest running best (d'' = SSD -
 // parity, so SSD <= d'' + 1).
-__device__ __forceinline__ int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
-                                                        int chunk_base, int r0a, int r0b, int split, int split_idx, int prune, const int *s_box_lo,
-                                                        const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask,
-                                                        int *s_cnt) {
+__device__ __forceinline__ int knn_build_list(const int *__restrict__ box_lo, const int *__restrict__ box_hi, const int *__restrict__ grp_lo,
+                                              const int *__restrict__ grp_hi, int64_t n_ttiles, int chunk_base, int r0a, int r0b, int split, int split_idx,
+                                              int prune, const int *s_box_lo, const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask,
+                                              int *s_cnt /* [0] list length, [1] group mask */) {
   constexpr int NS = KNN_NW * KNN_NQ, ND = KNN_ND, NT = KNN_NW * 64;
+  constexpr bool GROUPS = NT == KNN_GROUP && KNN_CHUNK % KNN_GROUP == 0;  // pass i of the loop below = group chunk_base / KNN_GROUP + i
   const int tid = threadIdx.x;
   __syncthreads();
-  if (tid == 0) *s_cnt = 0;
+  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
   __syncthreads();
-  for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT) {
+  unsigned gmask = ~0u;
+  if (GROUPS && prune) {  // second level: one thread per group of the chunk tests the group's box against the sub-tiles
+    const int64_t n_groups = (n_ttiles + KNN_GROUP - 1) / KNN_GROUP;
+    const int64_t g = chunk_base / KNN_GROUP + tid;
+    if (tid < KNN_CHUNK / KNN_GROUP && g < n_groups) {
+      int tlo[ND], thi[ND];
+#pragma unroll
+      for (int d = 0; d < ND; d++) { tlo[d] = grp_lo[(int64_t)d * n_groups + g]; thi[d] = grp_hi[(int64_t)d * n_groups + g]; }
+      bool any = false;
+      for (int q = 0; q < NS; q++) any |= knn_box_may_matter(tlo, thi, s_box_lo + q * ND, s_box_hi + q * ND, s_smax[q]);
+      if (any) atomicOr(&s_cnt[1], 1 << tid);
+    }
+    __syncthreads();
+    gmask = (unsigned)s_cnt[1];
+  }
+  int pass = 0;
+  for (int k = tid; k < KNN_CHUNK && chunk_base + k < n_ttiles; k += NT, pass++) {
+    if (GROUPS && !((gmask >> pass) & 1u)) continue;
     const int t = chunk_base + k;
     if (t >= r0a && t < r0b) continue;  // done in round 0
     if (split > 1 && t % split != split_idx) continue;  // another workgroup of this query group scans that tile
@@ -147,10 +167,11 @@ __device__ __forceinline__ int knn_build_list(const int *__restrict__ box_lo, co
 // call costs it two spilled operand quads; the collection kernel inlines the build: with its ladder counters live, the calling
 // convention (values across a call must sit in the callee-saved half of the file) spilled 100-190 bytes, and every reload's
 // s_waitcnt vmcnt(0) also waited for the tiles in flight (first collection pass of the reference-defaults run: 230 -> 160 ms).
-__device__ __attribute__((noinline)) int knn_build_list_call(const int *__restrict__ box_lo, const int *__restrict__ box_hi, int64_t n_ttiles,
-                                                             int chunk_base, int r0a, int r0b, int prune, const int *s_box_lo,
-                                                             const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask, int *s_cnt) {
-  return knn_build_list(box_lo, box_hi, n_ttiles, chunk_base, r0a, r0b, 1, 0, prune, s_box_lo, s_box_hi, s_smax, s_list, s_mask, s_cnt);
+__device__ __attribute__((noinline)) int knn_build_list_call(const int *__restrict__ box_lo, const int *__restrict__ box_hi, const int *__restrict__ grp_lo,
+                                                             const int *__restrict__ grp_hi, int64_t n_ttiles, int chunk_base, int r0a, int r0b, int prune,
+                                                             const int *s_box_lo, const int *s_box_hi, const int *s_smax, uint16_t *s_list, uint8_t *s_mask,
+                                                             int *s_cnt) {
+  return knn_build_list(box_lo, box_hi, grp_lo, grp_hi, n_ttiles, chunk_base, r0a, r0b, 1, 0, prune, s_box_lo, s_box_hi, s_smax, s_list, s_mask, s_cnt);
 }
 
 template <int HT, int HQ, bool TOPK>
@@ -298,11 +319,11 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
       if constexpr (TOPK)
-        list_n = __builtin_amdgcn_readfirstlane(knn_build_list(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, split, split_idx, prune, &s_box[0][0][0][0],
+        list_n = __builtin_amdgcn_readfirstlane(knn_build_list(bx.lo, bx.hi, bx.glo, bx.ghi, n_ttiles, chunk_base, r0a, r0b, split, split_idx, prune, &s_box[0][0][0][0],
                                                                &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
       else
       {
-        list_n = __builtin_amdgcn_readfirstlane(knn_build_list_call(bx.lo, bx.hi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0],
+        list_n = __builtin_amdgcn_readfirstlane(knn_build_list_call(bx.lo, bx.hi, bx.glo, bx.ghi, n_ttiles, chunk_base, r0a, r0b, prune, &s_box[0][0][0][0],
                                                                     &s_box[1][0][0][0], &s_smax[0][0], s_list, s_mask, &s_ctl[1]));
         load_bq();
       }
