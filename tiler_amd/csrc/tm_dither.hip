@@ -18,6 +18,7 @@ namespace tmx {
 
 __device__ __forceinline__ int div_trunc_1000(int v) { return v / 1000; }  // Pascal div: toward zero, like C
 // full-rate 24-bit multiplies (32-bit v_mul_lo_u32 is quarter rate); callers guarantee |operands| < 2^23
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
   __shared__ uint8_t s_by_rank[16];  // luma rank -> plan index
   const int lane = threadIdx.x;
   const int map_value = dither_map[lane];
-  int pr[16], pg[16], pb[16], pl[16];
+  int prg[16], pb[16], pl[16];  // prg: red | green << 16 (two int16), for the packed subtraction
   int cached_pal = -1;
   for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
     const int pi = pal_idx[t];
@@ -197,8 +198,7 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
       for (int i = 0; i < 16; i++) {  // entries past the live count repeat entry 0: same penalty, higher index, never chosen
         const int j = i < cnt ? i : 0;
         const int4 p = s_plan[j];
-        pr[i] = __builtin_amdgcn_readfirstlane(p.x);
-        pg[i] = __builtin_amdgcn_readfirstlane(p.y);
+        prg[i] = __builtin_amdgcn_readfirstlane(p.x | (p.y << 16));
         pb[i] = __builtin_amdgcn_readfirstlane(p.z);
         pl[i] = __builtin_amdgcn_readfirstlane(s_luma[j]);
       }
@@ -214,14 +214,17 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
     for (int k = 0; k < 64; k++) {
       const int t0 = s0 + (e0 * 9) / 100, t1 = s1 + (e1 * 9) / 100, t2 = s2 + (e2 * 9) / 100;
       const int lt = t0 * 299 + t1 * 587 + t2 * 114;
+      const s16x2 t01 = __builtin_bit_cast(s16x2, (uint32_t)(t0 & 0xffff) | ((uint32_t)t1 << 16));
       uint32_t best = 0xffffffffu;
       const uint32_t ltb = (uint32_t)(lt + (1 << 21));  // |lt| <= 1 723 000: biased so that v_sad_u32 gives |lt - luma|
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         // all factors fit 24 bits (|t - p| <= 1723, sum of squares <= 8.9e6, |luma difference| / 1000 <= 1978): full-rate
         // v_mad_i32_i24 instead of quarter-rate 32-bit multiplies
-        const int dr = t0 - pr[i], dg = t1 - pg[i], db = t2 - pb[i];
-        const int ssd = mad24(dr, dr, mad24(dg, dg, mul24(db, db)));
+        // red and green differences as one packed int16 subtraction, their squares and the blue one summed by one dot2 (|t - p| <= 1723)
+        const s16x2 drg = t01 - __builtin_bit_cast(s16x2, prg[i]);
+        const int db = t2 - pb[i];
+        const int ssd = __builtin_amdgcn_sdot2(drg, drg, mul24(db, db), false);
         // |(lt - luma) div 1000| = floor(|lt - luma| / 1000): exact as trunc(fma(a, 0.001f, 0.0005f)) for a < 2^22 (both ends
         // of every thousand checked in exact arithmetic, monotone in between); only its square is used
         uint32_t a;
