@@ -230,8 +230,8 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
         uint32_t a;
         asm("v_sad_u32 %0, %1, %2, 0" : "=v"(a) : "v"(ltb), "s"((uint32_t)(pl[i] + (1 << 21))));
         const int ld = (int)__builtin_fmaf((float)a, 0.001f, 0.0005f);
-        const uint32_t pen = (uint32_t)mad24(ssd, 13, mul24(ld, ld) << 5);
-        best = min(best, (pen << 4) | (uint32_t)i);
+        // (13 ssd + 32 ld^2) << 4 | i as two multiply-adds: 208 ssd + i, then + 512 ld^2 (ssd < 2^24, ld^2 < 2^22: 24-bit factors)
+        best = min(best, (uint32_t)mad24(mul24(ld, ld), 512, mad24(ssd, 208, i)));
       }
       const int4 p = s_plan[best & 15u];
       e0 += s0 - p.x; e1 += s1 - p.y; e2 += s2 - p.z;
