@@ -122,6 +122,51 @@ def test_knn_exact(oracle, nq, nt, spread):
     assert np.array_equal(idx.cpu().numpy(), eidx)
 
 
+def _torch_nn(q, db):
+    """exact nearest row by (SSD, index) in int64 on the GPU, 2048 queries at a time"""
+    dq, dd = torch.from_numpy(q).cuda().to(torch.float64), torch.from_numpy(db).cuda().to(torch.float64)  # |values| < 2^15: products and sums exact
+    nd = (dd * dd).sum(1)
+    idx, err = [], []
+    for a in range(0, q.shape[0], 2048):
+        x = dq[a:a + 2048]
+        d = (x * x).sum(1)[:, None] + nd[None, :] - 2.0 * (x @ dd.T)
+        e, i = torch.min(d, dim=1)  # first minimum = lowest index
+        first = (d == e[:, None]).to(torch.uint8).argmax(dim=1)
+        idx.append(first.cpu().numpy())
+        err.append(e.cpu().numpy())
+    return np.concatenate(idx).astype(np.int32), np.concatenate(err).astype(np.uint64).astype(np.uint32)
+
+
+@pytest.mark.parametrize("case", ["near-domain-limit", "norm-shells", "all-equal", "one-hot-columns"])
+def test_knn_radial_bound_on_hostile_data(case):
+    """the radial box dimension (norm over the non-box columns, rounded outwards) must never exclude the true neighbour: data built to
+    stress its rounding -- norms next to the 2^31 domain limit, rows on a few thin norm shells (queries between them), a database of
+    identical rows (R range of width zero), and rows whose energy sits in single columns"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(len(case))
+    nq, nt = 6000, 9000
+    if case == "near-domain-limit":  # per-column range 2 * 2350: 192 * 4700^2 = 4.2e9 would be refused, so 120 wide columns + 72 narrow
+        wide = rng.integers(-2100, 2101, size=(nt + nq, 120))
+        narrow = rng.integers(-40, 41, size=(nt + nq, 72))
+        allv = np.concatenate([wide, narrow], axis=1).astype(np.int16)
+    elif case == "norm-shells":
+        dirs = rng.normal(size=(nt + nq, 192))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        radii = np.concatenate([rng.choice([500.0, 1500.0, 1501.0, 4000.0], size=nt), rng.choice([499.0, 1000.0, 1500.5, 2750.0, 4001.0], size=nq)])
+        allv = np.rint(dirs * radii[:, None]).astype(np.int16)
+    elif case == "all-equal":
+        allv = np.tile(rng.integers(-300, 301, size=(1, 192)), (nt + nq, 1)).astype(np.int16)
+        allv[nt:] += rng.integers(-3, 4, size=(nq, 192)).astype(np.int16)
+    else:
+        allv = np.zeros((nt + nq, 192), np.int16)
+        allv[np.arange(nt + nq), rng.integers(0, 192, size=nt + nq)] = rng.integers(-1600, 1601, size=nt + nq).astype(np.int16)
+    db, q = np.ascontiguousarray(allv[:nt]), np.ascontiguousarray(allv[nt:])
+    eidx, eerr = _torch_nn(q, db)
+    idx, err = stages.knn(_dev(q), _dev(db))
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+
+
 def test_knn_refuses_out_of_domain_data():
     """arbitrary int16 rows can reach SSD >= 2^31, where mod-2^32 arithmetic stops being exact: refuse loudly"""
     from tiler_amd import stages, TileMotionError
