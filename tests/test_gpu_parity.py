@@ -441,6 +441,23 @@ def test_knn_topk(oracle, nt, k):
     assert np.array_equal(_host_u32(err), eerr)
 
 
+def test_knn_topk_on_norm_shells(oracle):
+    """k nearest rows where the radial box dimension is most selective (rows on thin norm shells, queries between them)"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(64)
+    nt, nq = 4000, 300
+    dirs = rng.normal(size=(nt + nq, 192))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    radii = np.concatenate([rng.choice([500.0, 1500.0, 1501.0, 4000.0], size=nt), rng.choice([499.0, 1000.0, 1500.5, 2750.0, 4001.0], size=nq)])
+    allv = np.rint(dirs * radii[:, None]).astype(np.int16)
+    db, q = np.ascontiguousarray(allv[:nt]), np.ascontiguousarray(allv[nt:])
+    eidx, eerr = oracle.knnk(q, db, 64)
+    idx, err = stages.knn_topk(_dev(q), _dev(db), 64)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(_host_u32(err), eerr)
+
+
 def test_epu_rerank(tiles_flags, oracle):
     from tiler_amd import stages
     tiles, flags = tiles_flags
