@@ -579,25 +579,36 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
                                                     const int *__restrict__ cand_cnt, int cap, int k, int *__restrict__ tau,
                                                     const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
                                                     uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count,
-                                                    const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members) {
+                                                    const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members, int nofilter) {
   extern __shared__ unsigned long long s_key[];  // [cap rounded up to a power of two]
   __shared__ uint32_t s_mult[64];
   const int64_t p = blockIdx.x;
   if (p >= nq) return;
   const int lane = threadIdx.x;
-  const int total = cand_cnt[p], n = min(total, cap);
-  int n2 = 64;
-  while (n2 < n) n2 <<= 1;
+  const int total = cand_cnt[p], stored = min(total, cap);
+  // The scan left its final threshold in tau (it walks down the ladder while rows come in): stored candidates above it cannot be among
+  // the k nearest, and dropping them before the sort shrinks it (a full list of 512 typically keeps about a hundred).
+  const int th = nofilter ? INT_MAX : tau[p];
   const uint32_t parity = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31] & 1u;
-  for (int i = lane; i < n2; i += 64) {
+  int n = 0;
+  for (int base = 0; base < stored; base += 64) {
+    const int i = base + lane;
     unsigned long long key = ~0ull;
-    if (i < n) {
+    bool valid = false;
+    if (i < stored) {
       const uint2 c = cand[p * cap + i];
       const int64_t srow = c.y;
-      if (srow < nt) key = ((unsigned long long)(c.x + parity) << 32) | tperm[srow];  // padded rows of the last tile replicate row nt-1: not rows
+      // signed, like the scan's own test: d'' = SSD - parity is -1 for an exact match of a query with an odd norm
+      valid = (int)c.x <= th && srow < nt;  // padded rows of the last tile replicate row nt-1: not rows
+      if (valid) key = ((unsigned long long)(c.x + parity) << 32) | tperm[srow];
     }
-    s_key[i] = key;
+    const unsigned long long m = __ballot(valid);
+    if (valid) s_key[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    n += __popcll(m);
   }
+  int n2 = 64;
+  while (n2 < n) n2 <<= 1;
+  for (int i = n + lane; i < n2; i += 64) s_key[i] = ~0ull;
   __syncthreads();
   // bitonic sort of the keys (one wave): (SSD, index of the row / of the distinct row's first occurrence) ascending
   for (int ks = 2; ks <= n2; ks <<= 1)
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
     }
   if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
     if (lane == 0) {
-      tau[p] = (int)min((unsigned long long)0x7ffffffeu, s_key[k - 1] >> 32);  // SSD bound; d'' <= SSD
+      tau[p] = (int)min((unsigned long long)min(th, 0x7ffffffe), s_key[k - 1] >> 32);  // SSD bound (d'' <= SSD), never above the scan's own
       ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
     }
     return;
@@ -952,7 +963,8 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   launch_mfma(ix->plan.ht, ix->plan.hq, a);
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
-                     map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members);
+                     map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
+                     getenv("TM_TOPK_NOFILTER") ? 1 : 0);
   TM_HIP(hipGetLastError());
   unsigned int novf = 0;
   int flag = 0;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
                                                           const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
                                                           const uint32_t *__restrict__ qkey, int64_t nq, int prune,
                                                           int *__restrict__ best_key, int *__restrict__ best_tile,
-                                                          unsigned long long *__restrict__ visited, const int *__restrict__ tau,
+                                                          unsigned long long *__restrict__ visited, int *__restrict__ tau,
                                                           uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap, int cand_k) {
   // TOPK: collection mode for the k-nearest search (ann_kdtree_short_search_multi, tilingencoder.pas:1563): every
   // query has a fixed threshold (an upper bound of its k-th smallest SSD); pruning uses it instead of a running best, and
@@ -581,6 +581,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
     } else if (ob < best[s]) {
       best[s] = ob; bestt[s] = ot; tie[s] = oti;
     }
+    if (TOPK && lane < 32 && qtile_of(s) < n_qtiles) atomicMin(&tau[qtile_of(s) * 32 + lane], best[s]);  // the final threshold: k_topk_select drops what lies above it
     if (!TOPK && lane < 32 && qtile_of(s) < n_qtiles) {
       const int64_t q = qtile_of(s) * 32 + lane;
       best_key[q] = best[s];
@@ -605,7 +606,7 @@ struct KnnLaunch {
   const uint8_t *tpack; int64_t n_ttiles; KnnBoxes bx;
   const uint8_t *qpack; int64_t n_qtiles; const int16_t *queries; const uint32_t *qperm, *qkey; int64_t nq; int prune;
   int *best_key, *best_tile; unsigned long long *visited; hipStream_t stream;
-  const int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0, cand_k = 0;  // collection mode (k nearest)
+  int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0, cand_k = 0;  // collection mode (k nearest)
   int split = 1;  // collection mode: workgroups per query group (they share its tile list)
 };
 
