@@ -710,7 +710,7 @@ void knn_index_destroy(tm_knn_index_impl *ix) { delete ix; }
 
 // everything a search needs before the scan: digit plan (database repacked if the batch widens it), both sides sorted along
 // the curve and packed in MFMA fragment order
-static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream, bool for_topk = false) {
+static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream) {
   ColStats qs;
   bool fresh_radial = false;  // the queries' radial coordinates were computed while the index was being built
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
@@ -767,12 +767,11 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
       // Measured on the bench clip (column ranges 20262 / 13399 / 13118, R in 2566..5284): every dimension over its own range with
       // 8, 7, 7, 8 bits and log2 R -- R cells of 0.3 % -- evaluates 15.3 G pairs (scan 18.4 ms); 8, 8, 8, 8: 14.7 G but 20.0 ms;
       // isotropic cells (TM_KNN_CURVE=iso: 9, 8, 8, 6 bits, linear R): 18.6 G, 21.4 ms; columns only (10, 10, 10): 28.9 G, 30.2 ms.
-      // The k-nearest scans (thresholds at the 64th neighbour, where the radial gap decides little) do better on the columns-only
-      // curve: 10, 10, 10, 0 bits (reference-defaults run on the bench clip: first collection pass 163 ms against 207 ms).
+      // The k-nearest scans use the same curve (measured after their kernel stopped spilling: first collection pass of the
+      // extended-palette run 112 ms on this curve, 146 ms on 10, 10, 10 bits of the columns alone).
       const char *mode = getenv("TM_KNN_CURVE");
       if (!(mode && !strcmp(mode, "iso"))) {
-        const int nb_nn[4] = {8, 7, 7, 8}, nb_topk[4] = {10, 10, 10, 0};
-        const int *nb = for_topk ? nb_topk : nb_nn;
+        const int nb[4] = {8, 7, 7, 8};
         cs.rlog = 1;
         for (int d = 0; d < 3; d++) { cs.bits[d] = nb[d]; cs.off[d] = (float)cs.lo[d]; cs.scale[d] = (float)((1 << nb[d]) - 1) / (float)cs.range[d]; }
         cs.bits[3] = nb[3]; cs.off[3] = log2f(rlo + 1.0f);
@@ -927,7 +926,7 @@ struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; c
 static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
                      uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
   const auto t_start = std::chrono::steady_clock::now();
-  TM_TRY(prepare_search(ix, feats, n, stream, true));
+  TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
   const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
   DevBuf tau, map_sorted, cand, cand_cnt, ovf, counter;
