@@ -291,12 +291,21 @@ __global__ __launch_bounds__(256) void k_assign(const int32_t *__restrict__ pts,
     }
     if (valid) {
       if (cur_old != bc) { assign[sg.begin + i] = bc; changed++; }
-      if (FUSE_ACC) {
+      if (FUSE_ACC && cur_old != bc) {
+        // The exact integer sums are carried from iteration to iteration, as in k_assign192: only a point that changes cluster touches
+        // them -- its weighted row is added to the new cluster and subtracted from the old one (u64 arithmetic: exact, order-free).
+        // After the first few iterations almost no point moves, and the LDS atomics, which bounded this kernel, are gone.
         const long long wi = cur_w;
         u64 *acc = s_acc + ((threadIdx.x & (NCOPY - 1)) * kk + bc) * (D + 1);
         atomicAdd(&acc[D], (u64)wi);
 #pragma unroll
         for (int j = 0; j < 3; j++) atomicAdd(&acc[j], (u64)(wi * p3[j]));
+        if (cur_old >= 0) {
+          u64 *old = s_acc + ((threadIdx.x & (NCOPY - 1)) * kk + cur_old) * (D + 1);
+          atomicAdd(&old[D], (u64)0 - (u64)wi);
+#pragma unroll
+          for (int j = 0; j < 3; j++) atomicAdd(&old[j], (u64)0 - (u64)(wi * p3[j]));
+        }
       }
     }
   }
@@ -515,14 +524,14 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
 
 // One block: centroid = sum / weight where weight > 0 (segments that changed), reset sums/counts/changed, and latch the
 // first iteration in which nothing changed anywhere (so the host can poll rarely).
-__global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int nseg, int k, int d, u64 *__restrict__ sums,
+__global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int nseg, int k, int d, int carry, u64 *__restrict__ sums,
                                                      u64 *__restrict__ cnts, double *__restrict__ cent, int it,
                                                      int *__restrict__ quiet_iter) {
   if (*quiet_iter >= 0) return;
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
-  const bool carry = d == 192;  // k_assign192 keeps the sums current with +/- deltas; the D = 3 path rebuilds them every iteration
+  // carry: the assignment kernels (k_assign192, fused k_assign<3>) keep the sums current with +/- deltas; the unfused D = 3 path rebuilds them
   const int64_t total = (int64_t)nseg * k * d;
   for (int64_t e = threadIdx.x; e < total; e += 1024) {
     const int64_t sc = e / d;
@@ -655,7 +664,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       } else {
         launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192, quiet.as<int>());
       }
-      hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
+      hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, (d == 192 || fuse3) ? 1 : 0, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
     int q = -1;
     TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
