@@ -202,11 +202,19 @@ __device__ __forceinline__ uint32_t spread8(uint32_t v) {  // 8 bits -> every fo
 // and its range over the rows (floats >= 0: their bit patterns order like the values).  8 lanes per row, 48 bytes each.
 __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const int16_t *__restrict__ centre,
                                                     float *__restrict__ out, unsigned int *__restrict__ range /* [0] min, [1] max */) {
+  // this R only places the row on the curve (the box dimension gets its exact, outward-rounded values in k_knn_pack and in the scan's
+  // prologue), so single precision is enough: the lane's 24 centres live in registers and every element is one subtract and one fma
   const int j8 = threadIdx.x & 7;
+  float cen[24];
+#pragma unroll
+  for (int e = 0; e < 24; e++) cen[e] = (float)centre[j8 * 24 + e];
+  float boxc[KNN_NC];
+#pragma unroll
+  for (int d = 0; d < KNN_NC; d++) boxc[d] = (float)centre[cs.col[d]];
   unsigned int lmin = 0x7f800000u, lmax = 0u;
   for (int64_t base = (int64_t)blockIdx.x * 32; base < n; base += (int64_t)gridDim.x * 32) {
     const int64_t i = base + (threadIdx.x >> 3);
-    long long sq = 0;
+    float sq = 0.0f;
     if (i < n) {
       const v4i *rp = reinterpret_cast<const v4i *>(feat + i * 192) + j8 * 3;
 #pragma unroll
@@ -214,17 +222,17 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
         const v4i x = rp[v];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int col = (j8 * 3 + v) * 8 + 2 * j;
-          const int c0 = (int)(int16_t)(x[j] & 0xffff) - centre[col], c1 = (x[j] >> 16) - centre[col + 1];
-          sq += (long long)c0 * c0 + (long long)c1 * c1;
+          const float c0 = (float)(int16_t)(x[j] & 0xffff) - cen[v * 8 + 2 * j], c1 = (float)(x[j] >> 16) - cen[v * 8 + 2 * j + 1];
+          sq = fmaf(c0, c0, fmaf(c1, c1, sq));
         }
       }
       if (j8 == 0)
-        for (int d = 0; d < KNN_NC; d++) { const long long c = (long long)feat[i * 192 + cs.col[d]] - centre[cs.col[d]]; sq -= c * c; }
+#pragma unroll
+        for (int d = 0; d < KNN_NC; d++) { const float c = (float)feat[i * 192 + cs.col[d]] - boxc[d]; sq -= c * c; }
     }
     sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
     if (i < n && j8 == 0) {
-      const float lr = sqrtf((float)max(sq, 0ll));
+      const float lr = sqrtf(fmaxf(sq, 0.0f));
       out[i] = lr;
       lmin = min(lmin, __float_as_uint(lr));
       lmax = max(lmax, __float_as_uint(lr));
