@@ -88,17 +88,25 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   int *__restrict__ err_flag) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ int s_v[32][193];
+  __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
   const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch, with_box);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    // the 32 rows come in as 16-byte vectors (three per thread) and are permuted out of LDS: the column permutation would otherwise
+    // turn the read into 6 144 two-byte loads per tile
+    for (int i = threadIdx.x; i < 32 * 24; i += 256) {
+      const int r = i / 24, v = i - r * 24;
+      int64_t row = tile * 32 + r;
+      if (row >= n) row = n - 1;
+      if (rowperm) row = rowperm[row];  // rows are packed in curve order
+      *reinterpret_cast<uint4 *>(&s_raw[r][v * 8]) = *reinterpret_cast<const uint4 *>(feat + row * 192 + v * 8);
+    }
+    __syncthreads();
     // centred, permuted values of the 32 rows
     for (int i = threadIdx.x; i < 32 * 192; i += 256) {
       const int r = i / 192, p = i - r * 192;
-      int64_t row = tile * 32 + r;
-      if (row >= n) row = n - 1;
-      if (rowperm) row = rowperm[row];  // rows are packed in DC-sorted order
-      const int v = (int)feat[row * 192 + s_p[p]] - (int)s_c[p];
+      const int v = (int)s_raw[r][s_p[p]] - (int)s_c[p];
       s_v[r][p] = negate ? -v : v;
     }
     __syncthreads();
