@@ -167,6 +167,101 @@ def test_knn_radial_bound_on_hostile_data(case):
     assert np.array_equal(idx.cpu().numpy(), eidx)
 
 
+def _hostile(case, rng, nq, nt):
+    if case == "near-domain-limit":
+        wide = rng.integers(-2100, 2101, size=(nt + nq, 120))
+        narrow = rng.integers(-40, 41, size=(nt + nq, 72))
+        allv = np.concatenate([wide, narrow], axis=1).astype(np.int16)
+    elif case == "norm-shells":
+        dirs = rng.normal(size=(nt + nq, 192))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        radii = np.concatenate([rng.choice([500.0, 1500.0, 1501.0, 4000.0], size=nt), rng.choice([499.0, 1000.0, 1500.5, 2750.0, 4001.0], size=nq)])
+        allv = np.rint(dirs * radii[:, None]).astype(np.int16)
+    elif case == "all-equal":
+        allv = np.tile(rng.integers(-300, 301, size=(1, 192)), (nt + nq, 1)).astype(np.int16)
+        allv[nt:] += rng.integers(-3, 4, size=(nq, 192)).astype(np.int16)
+    elif case == "one-hot-columns":
+        allv = np.zeros((nt + nq, 192), np.int16)
+        allv[np.arange(nt + nq), rng.integers(0, 192, size=nt + nq)] = rng.integers(-1600, 1601, size=nt + nq).astype(np.int16)
+    else:  # "features": rows shaped like tile features, with planted duplicates on both sides
+        allv = _rand_features(rng, nt + nq, 250)
+        allv[nt // 2] = allv[3]
+        allv[nt - 1] = allv[3]
+        allv[nt + 5] = allv[3]
+        allv[nt + nq - 1] = allv[nt - 2]
+    return np.ascontiguousarray(allv[:nt]), np.ascontiguousarray(allv[nt:])
+
+
+@pytest.mark.parametrize("case", ["features", "near-domain-limit", "norm-shells", "all-equal", "one-hot-columns"])
+def test_knn_dense_mode(case, monkeypatch):
+    """BASELINE config 3: the scan with pruning off (TM_KNN_NOPRUNE=1) is a dense Q x T distance GEMM on the int8 MFMA pipe.  Same
+    answers as the pruned scan and as an exact fp64 brute force, and it reports exactly nq x nt evaluated pairs (padding rows of the
+    last tiles are not pairs)."""
+    from tiler_amd import stages
+    monkeypatch.setenv("TM_KNN_NOPRUNE", "1")
+    rng = np.random.default_rng(len(case) + 77)
+    nq, nt = 5003, 3001  # neither a multiple of 32 nor of a group's size
+    db, q = _hostile(case, rng, nq, nt)
+    eidx, eerr = _torch_nn(q, db)
+    ix = stages.KnnIndex(_dev(db))
+    idx, err = ix.search(_dev(q))
+    _, _, pairs = ix.last_stats()
+    ix.close()
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert pairs == nq * nt
+
+
+def test_knn_dense_mode_large(monkeypatch):
+    """dense mode over >= 60 k database rows (several list rounds per workgroup), against the pruned scan and the exact brute force"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(4242)
+    nq, nt = 4100, 66000
+    db, q = _hostile("features", rng, nq, nt)
+    eidx, eerr = _torch_nn(q, db)
+    pidx, perr = stages.knn(_dev(q), _dev(db))
+    monkeypatch.setenv("TM_KNN_NOPRUNE", "1")
+    ix = stages.KnnIndex(_dev(db))
+    idx, err = ix.search(_dev(q))
+    _, _, pairs = ix.last_stats()
+    ix.close()
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr) and np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(perr.cpu().numpy().view(np.uint32), eerr) and np.array_equal(pidx.cpu().numpy(), eidx)
+    assert pairs == nq * nt
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_knn_first_scan_shape_still_exact(dense, monkeypatch):
+    """TM_KNN_V1=1 selects the first scan shape (tm_knn_kernel.h: the k-nearest collection scans still run on it)"""
+    from tiler_amd import stages
+    monkeypatch.setenv("TM_KNN_V1", "1")
+    if dense:
+        monkeypatch.setenv("TM_KNN_NOPRUNE", "1")
+    rng = np.random.default_rng(99)
+    db, q = _hostile("features", rng, 3000, 9000)
+    eidx, eerr = _torch_nn(q, db)
+    idx, err = stages.knn(_dev(q), _dev(db))
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+
+
+def test_knn_many_groups_clustered():
+    """the shipped (pruned) scan on clustered rows: many query groups, long tile lists, ties between tiles (identical rows far apart
+    in index), queries that are database rows"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(31337)
+    centres = _rand_features(rng, 40, 600).astype(np.int32)
+    nt, nq = 50000, 20011
+    db = (centres[rng.integers(0, 40, size=nt)] + rng.integers(-60, 61, size=(nt, 192))).astype(np.int16)
+    q = (centres[rng.integers(0, 40, size=nq)] + rng.integers(-60, 61, size=(nq, 192))).astype(np.int16)
+    db[40000:40100] = db[100:200]  # identical rows in far-apart tiles of the sorted order? (same content -> same key -> neighbours; still ties)
+    q[:300] = db[rng.integers(0, nt, size=300)]
+    eidx, eerr = _torch_nn(q, db)
+    idx, err = stages.knn(_dev(q), _dev(db))
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+
+
 def test_knn_refuses_out_of_domain_data():
     """arbitrary int16 rows can reach SSD >= 2^31, where mod-2^32 arithmetic stops being exact: refuse loudly"""
     from tiler_amd import stages, TileMotionError

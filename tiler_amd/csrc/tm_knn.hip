@@ -29,6 +29,7 @@
 #include "tm_common.h"
 #include "tm_internal.h"
 #include "tm_knn_kernel.h"
+#include "tm_knn2_kernel.h"
 
 namespace tmx {
 
@@ -449,6 +450,8 @@ struct tm_knn_index_impl {
   DevBuf rrange, tradial, qradial;                  // radial coordinate of the rows (curve key) and its range
   CurveSpec curve;
   DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
+  DevBuf qmeta;                                     // per query sub-tile: box + home tile (second scan shape)
+  int64_t last_blocks = 0, last_loads = 0, last_listed = 0;
   int64_t last_visited = 0, last_ties = 0;
   double last_ms = 0;
   int last_kbytes = 0;
@@ -706,6 +709,57 @@ static void launch_mfma(int ht, int hq, const KnnLaunch &a) {
   }
 }
 
+// per query sub-tile: bounding box over the box columns + the radial dimension (as the first scan shape computes it in its
+// prologue), and the database tile the sub-tile's first query falls into on the curve
+__global__ __launch_bounds__(256) void k_knn_qmeta(const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
+                                                   const uint32_t *__restrict__ qkey, int64_t nq, int64_t n_qtiles,
+                                                   const uint8_t *__restrict__ qpack, int q_bytes, KnnBoxes bx, int64_t n_ttiles,
+                                                   int *__restrict__ qmeta) {
+  const int lane32 = threadIdx.x & 31;
+  for (int64_t st = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); st < n_qtiles; st += (int64_t)gridDim.x * 8) {
+    const int64_t p = min(st * 32 + lane32, nq - 1);
+    const int16_t *row = queries + (int64_t)qperm[p] * 192;
+    const unsigned norm = reinterpret_cast<const unsigned *>(qpack + st * (int64_t)q_bytes + q_bytes - 128)[lane32] & ~1u;
+    long long boxsq = 0;
+    int *out = qmeta + st * 16;
+#pragma unroll
+    for (int d = 0; d < KNN_ND; d++) {
+      int lo, hi;
+      if (d < KNN_NC) {
+        lo = hi = row[bx.col[d]];
+        const long long c = lo - bx.cen[d];
+        boxsq += c * c;
+      } else {
+        const long long n2 = (long long)norm;
+        lo = max(0, (int)floor(sqrt((double)max(0ll, n2 - boxsq))) - 1);
+        hi = (int)ceil(sqrt((double)max(0ll, n2 + 1 - boxsq))) + 1;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+      if (lane32 == 0) { out[d] = lo; out[8 + d] = hi; }
+    }
+    if (lane32 == 0) {  // last tile whose first key <= the sub-tile's first key
+      const uint32_t k0 = qkey[st * 32];
+      int64_t lo = 0, hi = n_ttiles;
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (bx.tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
+      out[7] = (int)max((int64_t)0, lo - 1);
+      out[15] = 0;
+    }
+  }
+}
+
+static void launch_scan2(int ht, int hq, const Knn2Args &a, hipStream_t stream) {
+  switch (ht) {
+    case 0: knn2_launch_ht<0>(hq, a, stream); break;
+    case 1: knn2_launch_ht<1>(hq, a, stream); break;
+    case 2: knn2_launch_ht<2>(hq, a, stream); break;
+    case 3: knn2_launch_ht<3>(hq, a, stream); break;
+    case 4: knn2_launch_ht<4>(hq, a, stream); break;
+    case 5: knn2_launch_ht<5>(hq, a, stream); break;
+    default: knn2_launch_ht<6>(hq, a, stream); break;
+  }
+}
+
 int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_index_impl **out) {
   TM_TRY(require_device());
   TM_CHECK(nt >= 0, TM_E_INVAL, "knn: negative row count");
@@ -849,7 +903,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->counters.alloc(128));  // [4..15]: phase stamps of a TM_KNN_STAMPS diagnostic build
   TM_HIP(hipMemsetAsync(ix->counters.p, 0, 128, stream));
   const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
-  TM_HIP(hipEventRecord(ix->ev0, stream));
+  const bool v1 = getenv("TM_KNN_V1") != nullptr;  // the first scan shape (tm_knn_kernel.h), kept for A/B runs; the k-nearest scans still use it
   int *bt = ix->best_tile.as<int>();
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
@@ -858,10 +912,28 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   bx.ghi = ix->grp_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
+  unsigned long long *stats = reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16);
+  if (!v1) {
+    TM_TRY(ix->qmeta.alloc((size_t)nqt * 16 * 4));
+    hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 7) / 8, 8192)), dim3(256), 0, stream, (const int16_t *)queries,
+                       ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), nq, nqt, ix->qpack.as<uint8_t>(), knn_tile_bytes(ix->plan.hq, 0), bx, ntt,
+                       ix->qmeta.as<int>());
+    TM_HIP(hipGetLastError());
+  }
+  TM_HIP(hipEventRecord(ix->ev0, stream));
+  if (!v1) {
+    const int ns = knn2_sub_tiles(ix->plan.hq);
+    Knn2Args a;
+    a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
+    a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
+    a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
+    a.prune = prune; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
+    a.n_groups = (nqt + ns - 1) / ns;
+    launch_scan2(ix->plan.ht, ix->plan.hq, a, stream);
+  } else
   launch_mfma(ix->plan.ht, ix->plan.hq,
               KnnLaunch{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
-                        ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt,
-                        reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16), stream});
+                        ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt, stats, stream});
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
@@ -886,11 +958,15 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   ix->last_kbytes = 192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
   ix->last_visited = (int64_t)cnt[2];
   ix->last_ties = (int64_t)(cnt[0] & 0xffffffffull);
-  ix->last_pairs = ix->last_visited * 1024;  // (database tile, query sub-tile) blocks of 32 x 32 pairs actually evaluated
-  if (getenv("TM_KNN_DEBUG"))
-    fprintf(stderr, "[tm_knn] kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (workgroups staged %.3f%% of tiles), %lld tie settlements\n", ms,
-            100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt,
-            100.0 * (double)cnt[3] / ((double)((nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW)) * (double)ntt), (long long)ix->last_ties);
+  // pairs actually evaluated: exact (real query, real row) pairs from the second scan shape; the first counts whole 32 x 32 blocks
+  ix->last_pairs = v1 ? ix->last_visited * 1024 : (int64_t)cnt[4];
+  ix->last_blocks = (int64_t)cnt[2]; ix->last_loads = (int64_t)cnt[3]; ix->last_listed = v1 ? 0 : (int64_t)cnt[5];
+  if (getenv("TM_KNN_DEBUG")) {
+    const int64_t groups = v1 ? (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW) : (nqt + knn2_sub_tiles(ix->plan.hq) - 1) / knn2_sub_tiles(ix->plan.hq);
+    fprintf(stderr, "[tm_knn] %s kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (%lld blocks; workgroups read %.3f%% of tiles, %.1f per group; %.1f list entries per group), %lld tie settlements\n",
+            v1 ? "v1" : "v2", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)cnt[2],
+            100.0 * (double)cnt[3] / ((double)groups * (double)ntt), (double)cnt[3] / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);
+  }
 #if TM_KNN_STAMPS
   {
     static const char *names[10] = {"prologue", "wait data", "barrier", "issue", "box re-test", "MFMA + epilogue", "best refresh", "total", "next tile", "(list builds)"};
@@ -1028,5 +1104,7 @@ void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pa
   if (kbytes) *kbytes = ix->last_kbytes;
   if (pairs) *pairs = ix->last_pairs;
 }
+
+int knn2_sub_tiles(int hq) { return k2_ns(6 + std::min(std::max(hq, 0), 6)); }
 
 }  // namespace tmx

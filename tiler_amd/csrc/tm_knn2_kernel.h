@@ -1,0 +1,413 @@
+// tm_knn2_kernel.h -- the nearest-neighbour scan of the KNN stage, second shape ("KNN").
+//
+// Same arithmetic as tm_knn_kernel.h (exact SSD through int8 digit products on v_mfma_i32_32x32x32_i8, one accumulator shifted
+// between three phases) and the same packed operands, boxes and curve; what changed is who holds what:
+//   * A workgroup is a whole CU's worth of waves (16, four per SIMD, <= 128 registers each) and owns NS consecutive query
+//     sub-tiles (32 queries each, NS = 10..16 by the queries' digit plan).  Their MFMA B operands sit in LDS for the whole
+//     launch of the group (up to 144 KB), their running minima too (one 64-bit word per query: d''+1 | sorted row, updated with
+//     ds_min_rtn_u64).
+//   * Database tiles never touch LDS.  A wave takes the next entry of the group's tile list (one LDS atomic), reads the tile's
+//     11-12 KB straight into registers as MFMA A operands (global_load_dwordx4, 1 KB contiguous per instruction) and runs one
+//     19-MFMA chain per sub-tile that still wants the tile.  Waves never wait for each other inside a list: no per-tile barrier,
+//     no staging ring, and the matrix pipe of a SIMD is fed by whichever of its four waves has a tile in registers.
+//   * The list carries, per entry and sub-tile, the box lower bound of that pair as a 16-bit square root (rounded down), made
+//     once by all threads.  Re-judging a pair against the sub-tile's current largest best is then one compare of two 16-bit
+//     values instead of a 7-dimensional box test.
+//   * Workgroup -> query group mapping keeps the 32 groups that run together on one XCD consecutive on the curve, so the tiles
+//     they stream are the same ones and come from that XCD's L2.
+// Exactness is unchanged: a pair is skipped only when its lower bound exceeds the sub-tile's largest best + 1 (both sides of the
+// 16-bit compare are rounded the safe way), the minimum VALUE is exact, and a second row reaching the same value raises the tie
+// flag that k_knn_ties settles by original index.
+#pragma once
+#include "tm_knn_kernel.h"
+
+namespace tmx {
+
+#ifndef TM_KNN2_WAVES
+#define TM_KNN2_WAVES 16  // 16: one workgroup per CU; 8: two (half the LDS each, fewer sub-tiles per group)
+#endif
+constexpr int K2_NW = TM_KNN2_WAVES;
+constexpr int K2_NT = K2_NW * 64;
+constexpr int K2_LDS = 163840 / (16 / K2_NW);
+constexpr int K2_LCAP = K2_NT;        // list entries: one chunk of tile slots always fits
+constexpr int K2_SEEDS = 8;           // tiles around the group's position on the curve, visited first by every sub-tile
+constexpr int K2_XCD_RUN = 32 * (16 / K2_NW);  // workgroups that run together on one XCD
+
+constexpr int k2_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 128 + K2_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
+constexpr int k2_ns(int kq) {
+  int ns = 16;
+  while (ns > 1 && k2_lds_bytes(ns, kq) > K2_LDS) ns--;
+  return ns;
+}
+
+struct Knn2Args {
+  const uint8_t *tpack; int64_t n_ttiles, nt_rows;
+  const int *box_lo, *box_hi, *grp_lo, *grp_hi;  // database tile boxes [KNN_ND][n_ttiles], boxes of runs of KNN_GROUP tiles
+  const uint8_t *qpack; int64_t n_qtiles, nq;
+  const int *qmeta;   // [n_qtiles][16]: box lo[7], home tile, box hi[7], pad
+  int prune;
+  int *best_key, *best_tile;
+  unsigned long long *stats;  // [0] (tile, sub-tile) blocks evaluated, [1] tiles read, [2] exact (query, row) pairs, [3] list entries
+  int64_t n_groups;
+};
+
+__device__ __forceinline__ unsigned k2_wave_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+  return max(max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
+             max((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
+}
+
+// a fresh look at an LDS word other waves update (relaxed workgroup-scope load: a plain ds_read_b32 the compiler may not cache)
+__device__ __forceinline__ unsigned k2_peek(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// largest r with r * r <= x (x < 2^31)
+__device__ __forceinline__ unsigned k2_isqrt(unsigned x) {
+  unsigned r = (unsigned)sqrtf((float)x);
+  r -= (r * r > x) ? 1u : 0u;
+  r -= (r * r > x) ? 1u : 0u;
+  return r;
+}
+
+template <int HT, int HQ>
+__global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
+  constexpr int KT = 6 + HT, KQ = 6 + HQ, HM = HT < HQ ? HT : HQ, ND = KNN_ND;
+  constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
+  constexpr int NS = k2_ns(KQ), NSP = (NS + 1) & ~1, NW = K2_NW, NT = K2_NT, LCAP = K2_LCAP;
+  // one LDS object, carved by hand (16-byte aligned pieces)
+  constexpr int OFF_QN = NS * KQ * 1024, OFF_BEST = OFF_QN + NS * 128, OFF_TIE = OFF_BEST + NS * 256, OFF_QBOX = OFF_TIE + NS * 128,
+                OFF_SMAX = OFF_QBOX + NS * 64, OFF_CTL = OFF_SMAX + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
+                LDS_TOTAL = OFF_LLB + LCAP * NSP * 2;
+  static_assert(LDS_TOTAL == k2_lds_bytes(NS, KQ) && LDS_TOTAL <= K2_LDS, "LDS carve");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
+  int *const s_qn = reinterpret_cast<int *>(lds + OFF_QN);                                  // [NS][32] 2 * (|q-c|^2 >> 1)
+  unsigned long long *const s_best = reinterpret_cast<unsigned long long *>(lds + OFF_BEST);  // [NS][32] (d'' + 1) << 32 | sorted row
+  unsigned *const s_tie = reinterpret_cast<unsigned *>(lds + OFF_TIE);                      // [NS][32] smallest d'' + 1 seen twice
+  int *const s_qbox = reinterpret_cast<int *>(lds + OFF_QBOX);                              // [NS][16] lo[8] | hi[8]
+  unsigned *const s_smax = reinterpret_cast<unsigned *>(lds + OFF_SMAX);                    // [16] upper bound of sqrt(largest best + 1)
+  int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor
+  unsigned *const s_ltile = reinterpret_cast<unsigned *>(lds + OFF_LTILE);                  // [LCAP]
+  uint16_t *const s_llb = reinterpret_cast<uint16_t *>(lds + OFF_LLB);                      // [LCAP][NSP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+  // workgroup -> query group: runs of K2_XCD_RUN consecutive groups per XCD (blocks b and b + 8 share an XCD: speed only)
+  int64_t g;
+  {
+    const unsigned b = blockIdx.x, xcd = b & 7u, i = b >> 3;
+    g = ((int64_t)(i / K2_XCD_RUN) * 8 + xcd) * K2_XCD_RUN + (i % K2_XCD_RUN);
+  }
+  if (g >= a.n_groups) return;
+  const int64_t st0 = g * NS;
+  const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
+  const int64_t n_ttiles = a.n_ttiles;
+
+  // ---- prologue: the group's query operands, norms, boxes
+  for (int piece = wave; piece < NS * KQ; piece += NW) {
+    const int s = piece / KQ, kc = piece - s * KQ;
+    const int64_t st = min(st0 + s, a.n_qtiles - 1);
+    const uint8_t *src = a.qpack + st * (int64_t)Q_BYTES + kc * 1024 + lane * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(lds + piece * 1024), 16, 0, 0);
+  }
+  for (int i = tid; i < NS * 32; i += NT) {
+    const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
+    s_qn[i] = reinterpret_cast<const int *>(a.qpack + st * (int64_t)Q_BYTES + KQ * 1024)[i & 31] & ~1;
+    s_best[i] = ~0ull;
+    s_tie[i] = ~0u;
+  }
+  for (int i = tid; i < NS * 16; i += NT) s_qbox[i] = a.qmeta[min(st0 + (i >> 4), a.n_qtiles - 1) * 16 + (i & 15)];
+  if (tid < 16) s_smax[tid] = 0xFFFEu;
+  if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+  __syncthreads();  // (waits for the LDS-DMA pieces too)
+
+  const int prune = a.prune;
+  const int home = prune ? s_qbox[7] : 0;
+  const int r0a = prune ? (int)max((int64_t)0, min((int64_t)home - 3, n_ttiles - K2_SEEDS)) : 0;
+  const int r0b = prune ? (int)min((int64_t)r0a + K2_SEEDS, n_ttiles) : 0;
+  const int64_t total_slots = prune ? 2 * max((int64_t)home, n_ttiles - 1 - home) + 1 : n_ttiles;
+  const int n_chunks = (int)((total_slots + NT - 1) / NT);
+
+  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0;
+  int chunk = 0;
+  int round = prune ? -1 : 0;
+  for (;;) {
+    // ---------------------------------------------------------------- the group's tile list
+    if (round < 0) {  // seeds: every sub-tile visits the tiles around the group's position, lower bound 0
+      if (tid < r0b - r0a) {
+        s_ltile[tid] = (unsigned)(r0a + tid);
+        for (int p = 0; p < NSP; p++) s_llb[tid * NSP + p] = p < nvalid ? 0 : 0xFFFF;
+      }
+      if (tid == 0) { s_ctl[0] = r0b - r0a; s_ctl[1] = 0; }
+      __syncthreads();
+    } else {
+      if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+      __syncthreads();
+      while (chunk < n_chunks) {
+        const int n0 = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
+        if (n0 >= LCAP) break;  // full: consume first (a chunk that does not fit behind the earlier ones is dropped and built again, below)
+        // slot -> tile: outwards from the group's home tile (home, home + 1, home - 1, ...), near tiles tighten the bests first
+        const int64_t j = (int64_t)chunk * NT + tid;
+        int64_t tile;
+        bool valid;
+        if (prune) {
+          const int64_t off = (j + 1) >> 1;
+          tile = (j & 1) ? home + off : home - off;
+          valid = j < total_slots && tile >= 0 && tile < n_ttiles && !(tile >= r0a && tile < r0b);
+        } else {
+          tile = j;
+          valid = tile < n_ttiles;
+        }
+        // 16-bit lower bounds of this lane's tile against the 16 sub-tile slots: a 256-bit shift register, one value pushed per
+        // slot (so the loop stays rolled: no run-time register index), slot s ends in bits 16 * (s & 1) of lbw[s >> 1]
+        unsigned lbw[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) lbw[p] = 0xFFFFFFFFu;
+        auto push = [&](unsigned v16) {
+#pragma unroll
+          for (int p = 0; p < 7; p++) lbw[p] = __builtin_amdgcn_alignbit(lbw[p + 1], lbw[p], 16);
+          lbw[7] = (lbw[7] >> 16) | (v16 << 16);
+        };
+        bool any = false;
+        if (!prune) {
+#pragma unroll 1
+          for (int s = 0; s < 16; s++) push(s < nvalid ? 0u : 0xFFFFu);
+          any = valid;
+        } else {
+          // second level first, per wave: the wave's 64 slots lie in at most two runs of KNN_GROUP tiles on each side of home;
+          // lane = run * 16 + sub-tile judges one (run, sub-tile) pair
+          const int64_t jw = (int64_t)chunk * NT + wave * 64;
+          const int64_t off_lo = (jw + 1) >> 1, off_hi = (jw + 64) >> 1;
+          const int n_grp = (int)((n_ttiles + KNN_GROUP - 1) / KNN_GROUP);
+          const int gi4[4] = {(int)((home + off_lo) / KNN_GROUP), (int)((home + off_hi) / KNN_GROUP),
+                              (home - off_hi) >= 0 ? (int)((home - off_hi) / KNN_GROUP) : -1, (home - off_lo) >= 0 ? (int)((home - off_lo) / KNN_GROUP) : -1};
+          unsigned long long gpass;
+          {
+            const int gsel = lane >> 4, s = lane & 15;
+            const int grp = gsel == 0 ? gi4[0] : gsel == 1 ? gi4[1] : gsel == 2 ? gi4[2] : gi4[3];
+            bool pass = false;
+            if (grp >= 0 && grp < n_grp && s < nvalid) {
+              unsigned lbq = 0;
+#pragma unroll
+              for (int d = 0; d < ND; d++) {
+                const int tlo = a.grp_lo[d * n_grp + grp], thi = a.grp_hi[d * n_grp + grp];
+                const int gap = max(0, max(tlo - s_qbox[s * 16 + 8 + d], s_qbox[s * 16 + d] - thi)) >> 1;
+                lbq += (unsigned)(gap * gap);
+              }
+              pass = 2u * k2_isqrt(lbq) <= k2_peek(&s_smax[s]);
+            }
+            gpass = __builtin_amdgcn_ballot_w64(pass);
+          }
+          // this lane's tile: which run is it in, which sub-tiles survived there
+          unsigned smask = 0;
+          if (valid) {
+            const int grp = (int)(tile / KNN_GROUP);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (grp == gi4[k]) smask |= (unsigned)(gpass >> (16 * k)) & 0xFFFFu;
+          }
+          unsigned ub = 0;  // union over the wave of the surviving sub-tiles
+          {
+            unsigned x = smask;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x |= (unsigned)__shfl_xor((int)x, o);
+            ub = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+          }
+          if (ub) {
+            int tlo[ND], thi[ND];
+            const int64_t tc = valid ? tile : 0;
+#pragma unroll
+            for (int d = 0; d < ND; d++) { tlo[d] = a.box_lo[(int64_t)d * n_ttiles + tc]; thi[d] = a.box_hi[(int64_t)d * n_ttiles + tc]; }
+#pragma unroll 1
+            for (int s = 0; s < 16; s++) {
+              unsigned v16 = 0xFFFFu;
+              if ((ub >> s) & 1u) {  // uniform
+                const v4i q0 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16]), q1 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 4]),
+                          q2 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 8]), q3 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 12]);
+                const int qlo[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                const int qhi[8] = {q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+                unsigned lbq = 0;
+#pragma unroll
+                for (int d = 0; d < ND; d++) {
+                  const int gap = max(0, max(tlo[d] - qhi[d], qlo[d] - thi[d])) >> 1;
+                  lbq += (unsigned)(gap * gap);
+                }
+                const unsigned lb16 = min(0xFFFEu, 2u * k2_isqrt(lbq));
+                if (((smask >> s) & 1u) && lb16 <= k2_peek(&s_smax[s])) { v16 = lb16; any = true; }
+              }
+              push(v16);
+            }
+          }
+        }
+        {  // ordered append inside the wave, one LDS atomic per wave
+          const unsigned long long pb = __builtin_amdgcn_ballot_w64(any);
+          int base = 0;
+          if (pb) {
+            if (lane == 0) base = atomicAdd(&s_ctl[0], __popcll(pb));
+            base = __builtin_amdgcn_readfirstlane(base);
+          }
+          const int idx = base + __popcll(pb & ((1ull << lane) - 1ull));
+          if (any && idx < LCAP) {
+            s_ltile[idx] = (unsigned)tile;
+#pragma unroll
+            for (int p = 0; p < NSP / 2; p++) reinterpret_cast<unsigned *>(s_llb)[idx * (NSP / 2) + p] = lbw[p];
+          }
+        }
+        __syncthreads();
+        const int n1 = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
+        if (n1 > LCAP) {  // did not fit behind the earlier chunks: drop it, consume, build it again
+          __syncthreads();
+          if (tid == 0) s_ctl[0] = n0;
+          __syncthreads();
+          break;
+        }
+        chunk++;
+        __syncthreads();  // everyone has read n1 before the next chunk's atomics move it
+      }
+    }
+    // ---------------------------------------------------------------- consume: every wave on its own
+    {
+      const int list_n = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
+      nlisted += (wave == 0) ? list_n : 0;
+      auto next_entry = [&](int &tile_o, int &lb_o, unsigned &mask_o) -> bool {
+        for (;;) {
+          int j = 0;
+          if (lane == 0) j = atomicAdd(&s_ctl[1], 1);
+          j = __builtin_amdgcn_readfirstlane(j);
+          if (j >= list_n) return false;
+          const int t = (int)s_ltile[j];
+          const int lb = lane < NSP ? (int)s_llb[j * NSP + lane] : 0xFFFF;
+          const int sm = lane < NS ? (int)k2_peek(&s_smax[lane]) : -1;
+          const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lb <= sm);
+          if (m) { tile_o = __builtin_amdgcn_readfirstlane(t); lb_o = lb; mask_o = m; return true; }
+        }
+      };
+      int tile = 0, lbv = 0;
+      unsigned mask = 0;
+      bool have = next_entry(tile, lbv, mask);
+      while (have) {
+        // the tile's MFMA A operands and norms, straight into registers
+        const uint8_t *tb = a.tpack + (int64_t)tile * T_BYTES;
+        v4i T[KT];
+#pragma unroll
+        for (int kc = 0; kc < KT; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
+        int ntr[16];  // |t-c|^2 of accumulator row r: (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+          const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
+          ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
+        }
+        nloads++;
+        // the entry after this one is chosen while the loads fly
+        int ntile = 0, nlb = 0;
+        unsigned nmask = 0;
+        const bool nhave = next_entry(ntile, nlb, nmask);
+        const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
+        while (mask) {
+          const int s = __builtin_ctz(mask);
+          mask &= mask - 1;
+          // the sub-tile's best may have tightened since the entry was popped
+          const int lbs = __builtin_amdgcn_readlane(lbv, s);
+          const int sms = __builtin_amdgcn_readfirstlane((int)k2_peek(&s_smax[s]));
+          if (lbs > sms) continue;
+          const uint8_t *qb = lds + s * (KQ * 1024) + lane * 16;
+          v16i acc;
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[r] = 0;
+          if (HM > 0) {
+#pragma unroll
+            for (int kc = 0; kc < HM; kc++)
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+          }
+          if (HT + HQ > 0) {
+#pragma unroll
+            for (int kc = 0; kc < HQ; kc++)
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
+#pragma unroll
+            for (int kc = 0; kc < HT; kc++)
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+          }
+#pragma unroll
+          for (int kc = 0; kc < 6; kc++)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), acc, 0, 0, 0);              // T_L . Q_L
+          // d'' = 2 acc + |t-c|^2 + 2 (|q-c|^2 >> 1) = SSD - parity; the row minimum is taken without the query's own term
+          int t[16];
+          int tm = INT_MAX;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            t[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
+            tm = min(tm, t[r]);
+          }
+          const int qi = s * 32 + (lane & 31);
+          const unsigned key_hi = (unsigned)tm + (unsigned)s_qn[qi] + 1u;  // d'' + 1 >= 0
+          const unsigned cur_hi = k2_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1);
+          bool improved = false;
+          if (key_hi <= cur_hi) {
+            int row = 0, cnt = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; r--)
+              if (t[r] == tm) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
+            const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
+            const unsigned long long pre = atomicMin(&s_best[qi], key);
+            const unsigned pre_hi = (unsigned)(pre >> 32);
+            if (pre_hi == key_hi || cnt > 1) atomicMin(&s_tie[qi], key_hi);  // the value was reached a second time
+            improved = key_hi < pre_hi;
+          }
+          if (__builtin_amdgcn_ballot_w64(improved)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
+            const unsigned h = k2_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1);
+            const unsigned mx = k2_wave_umax(h);  // = largest d'' + 1 = the SSD bound the box test compares with
+            if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], min(0xFFFEu, (unsigned)sqrtf((float)mx) + 2u));
+          }
+          nblocks++;
+          npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+        }
+        tile = ntile; lbv = nlb; mask = nmask; have = nhave;
+      }
+    }
+    __syncthreads();
+    if (round >= 0 && chunk >= n_chunks) break;
+    round++;
+  }
+
+  // ---- results, in the first scan shape's format (k_knn_refine / k_knn_ties read them)
+  for (int i = tid; i < NS * 32; i += NT) {
+    const int64_t st = st0 + (i >> 5);
+    if (st >= a.n_qtiles) continue;
+    const unsigned long long k = s_best[i];
+    const unsigned hi = (unsigned)(k >> 32);
+    const int64_t q = st * 32 + (i & 31);
+    a.best_key[q] = (int)(hi - 1u);
+    a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
+  }
+  if (a.stats && lane == 0) {
+    atomicAdd(a.stats, (unsigned long long)nblocks);
+    atomicAdd(a.stats + 1, (unsigned long long)nloads);
+    atomicAdd(a.stats + 2, (unsigned long long)npairs);
+    if (wave == 0) atomicAdd(a.stats + 3, (unsigned long long)nlisted);
+  }
+}
+
+// one per HT, defined in tm_knn2_k<HT>.hip
+template <int HT> void knn2_launch_ht(int hq, const Knn2Args &a, hipStream_t stream);
+int knn2_sub_tiles(int hq);  // NS of the queries' digit plan
+
+#define TM_KNN2_CASE(HT, HQ) \
+  case HQ: hipLaunchKernelGGL((k_knn_scan2<HT, HQ>), grid, block, 0, stream, a); break;
+
+#define TM_KNN2_DEFINE_HT(HT)                                                                         \
+  template <> void knn2_launch_ht<HT>(int hq, const Knn2Args &a, hipStream_t stream) {               \
+    const int64_t per = 8 * K2_XCD_RUN;                                                               \
+    const dim3 grid((unsigned)(((a.n_groups + per - 1) / per) * per)), block(K2_NT);                  \
+    switch (hq) {                                                                                     \
+      TM_KNN2_CASE(HT, 0) TM_KNN2_CASE(HT, 1) TM_KNN2_CASE(HT, 2) TM_KNN2_CASE(HT, 3)                 \
+      TM_KNN2_CASE(HT, 4) TM_KNN2_CASE(HT, 5)                                                         \
+      default: hipLaunchKernelGGL((k_knn_scan2<HT, 6>), grid, block, 0, stream, a);                   \
+    }                                                                                                 \
+  }
+
+}  // namespace tmx
