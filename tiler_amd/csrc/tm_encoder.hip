@@ -3,8 +3,8 @@
 // Mirrors TTilingEncoder (tilingencoder.pas:308-568): settings with the reference's clamps (2919-3047) and INI keys
 // (3745-3770), Run(step) walking esLoad..esSave (5529-5554), read-only Tiles/Frames/Palettes views.  Everything a
 // step computes stays resident in HBM between steps; only small control data (correlations, digit plans, palette
-// colours, counts) crosses to the host.  What is not built yet (motion prediction, EPU re-rank, OptimizePalettes,
-// .gtm writer) is listed in DESIGN.md "Scope" and fails or no-ops loudly below.
+// colours, counts) crosses to the host.  Every step of Run(esAll) is built (motion prediction, the extended-palette
+// re-rank, OptimizePalettes, the .gtm writer and reader included); what stays outside the path is listed in DESIGN.md "Scope".
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -101,6 +101,7 @@ struct tm_encoder {
   int reduce_probes = 0;
   int64_t q = 0, t = 0;
   bool has_pal_px = false, reconstructed = false;
+  bool gtiles_have_rgb = false;  // false after ReloadGTM until Reduce has run again
   // host state
   std::vector<float> correl;
   std::vector<int32_t> kf_start;
@@ -208,11 +209,25 @@ static int need(tm_encoder *e, int step_bit, const char *what) {
   return TM_OK;
 }
 
+// Steps that read the frame tiles / the global tiles' RGB pixels: ReloadGTM brings neither (the stream holds palette indices
+// only, HasRGBPixels = False at tilingencoder.pas:4937), so after a reload these steps need Load (and Reduce) to have run again.
+static int need_frame_tiles(tm_encoder *e, const char *step) {
+  TM_CHECK(e->ftiles.p != nullptr && e->fflags.p != nullptr && e->flab.p != nullptr && e->q > 0, TM_E_INVAL,
+           "step order: %s needs the frame tiles, which are not in memory (run Load first; ReloadGTM does not bring them)", step);
+  return TM_OK;
+}
+static int need_global_rgb(tm_encoder *e, const char *step) {
+  TM_CHECK(e->gtiles_have_rgb && e->gtiles.p != nullptr, TM_E_INVAL,
+           "step order: %s needs the global tiles' RGB pixels (run Reduce first; a reloaded .gtm holds palette indices only)", step);
+  return TM_OK;
+}
+
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
   e->drop_prefetch();  // features of the previous frame tiles
   TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
   TM_CHECK(e->frames != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device first");
   e->q = (int64_t)e->nframes * e->tm_size();
+  TM_CHECK(e->q < (1ll << 31), TM_E_UNSUPPORTED, "%lld tile-map items: the index arrays are 32-bit (TileIdx is an Integer, tilingencoder.pas:179)", (long long)e->q);
   TM_TRY(e->ftiles.alloc((size_t)e->q * 256));
   TM_TRY(e->fflags.alloc((size_t)e->q));
   TM_TRY(e->flab.alloc((size_t)e->q * 12));
@@ -264,6 +279,7 @@ static int step_predict_motion(tm_encoder *e) {
   TM_TRY(need(e, TM_STEP_LOAD, "Load"));
   e->has_pm = false;
   if (e->s.MotionPredictRadius <= 0) return TM_OK;  // 1972
+  TM_TRY(need_frame_tiles(e, "PredictMotion"));
   const int64_t per = e->tm_size();
   const int sw = e->tm_w * 8, sh = e->tm_h * 8;
   const int64_t nwin = (int64_t)(sw - 7) * (sh - 7);
@@ -351,11 +367,14 @@ static int step_reduce_motion(tm_encoder *e) {
 }
 
 static int step_reduce(tm_encoder *e) {
-  // Reduce, tilingencoder.pas:1909-1926 = SolveTileCount (4043) + ReindexTiles(True).  With motion prediction not
-  // built no tile-map item is predicted, so TransferTiles (4048) moves every frame tile; MakeTilesUnique(True)+
+  // Reduce, tilingencoder.pas:1909-1926 = SolveTileCount (4043) + ReindexTiles(True).  After PredictMotion the threshold
+  // search of step_reduce_motion runs.  With motion prediction switched off (MotionPredictRadius = 0, the benchmark's headline
+  // configuration) no tile-map item is predicted, so TransferTiles (4048) moves every frame tile; MakeTilesUnique(True) +
   // ReindexTiles(True) are exact; the tile budget is then met by keeping the first GlobalTilingTileCount tiles of
-  // that order (most used first) -- the build's stand-in for the PSNR threshold search, see DESIGN.md "Scope".
+  // that order (most used first), see DESIGN.md "Scope".
   TM_TRY(need(e, TM_STEP_LOAD, "Load"));
+  TM_TRY(need_frame_tiles(e, "Reduce"));
+  e->gtiles_have_rgb = true;
   if (e->has_pm) return step_reduce_motion(e);
   DevBuf remap, order, use;
   TM_TRY(remap.alloc((size_t)e->q * 4));
@@ -428,6 +447,7 @@ static int query_features(tm_encoder *e, int f0, int nf, bool epu, DevBuf &qf, v
 
 static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingencoder.pas:1843-1871
   TM_TRY(need(e, TM_STEP_REDUCE, "Reduce"));
+  TM_TRY(need_global_rgb(e, "PreparePalettes"));
   TM_CHECK(e->t > 0, TM_E_INVAL, "no global tiles");
   DevBuf feat;
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
@@ -452,6 +472,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
 
 static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
   TM_TRY(need(e, TM_STEP_PREPARE_PALETTES, "PreparePalettes"));
+  TM_TRY(need_global_rgb(e, "Dither"));
   TM_TRY(e->gpal_px.alloc((size_t)e->t * 64));
   const int64_t t0 = e->t * e->dither_rank / e->dither_world, t1 = e->t * (e->dither_rank + 1) / e->dither_world;
   if (e->dither_world > 1) TM_HIP(hipMemsetAsync(e->gpal_px.p, 0, (size_t)e->t * 64, e->stream));  // other shards' tiles: 0, merged with SUM
@@ -467,9 +488,10 @@ static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
 
 static int step_reconstruct(tm_encoder *e) {
   // Reconstruct, tilingencoder.pas:1928-1962: PrepareReconstruct (4566) builds the int16 database of all global
-  // tiles; TFrame.Reconstruct.DoXY (1464-1659) matches every frame tile.  KNN branch only (motion branch not built):
-  // the nearest-neighbour part does not depend on the previous reconstructed frame, so all frames go in one batch.
+  // tiles; TFrame.Reconstruct.DoXY (1464-1659) matches every frame tile.  The nearest-neighbour part does not depend on the
+  // previous reconstructed frame, so all frames go in one batch; the motion branch (below) then walks the frames in order.
   TM_TRY(need(e, TM_STEP_DITHER, "Dither"));
+  TM_TRY(need_frame_tiles(e, "Reconstruct"));
   DevBuf db, qf;
   TM_TRY(db.alloc((size_t)e->t * 384));
   TM_TRY(launch_features_pal(e->gpal_px.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteSize, TM_PVS_WEIGHTED_DCT, db.p, e->stream));
@@ -1052,7 +1074,11 @@ int tm_reload_gtm(tm_encoder *e, const char *path) {  // ReloadGTM, tilingencode
   e->has_pm = true;
   e->has_pal_px = true;
   e->reconstructed = false;  // PSNR is not in the stream
-  e->steps_done = 0xff;      // every step's product is in place: Save / read-back work; running a step recomputes from the frames
+  e->gtiles_have_rgb = false;
+  e->drop_prefetch();
+  // every step's product the stream holds is in place: Save, Reindex and the read-back views work.  Steps that compute from the frame
+  // tiles or from RGB pixels check for them (need_frame_tiles / need_global_rgb) and ask for Load / Reduce when they are missing.
+  e->steps_done = 0xff;
   return TM_OK;
 }
 

@@ -900,8 +900,8 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
-  TM_TRY(ix->counters.alloc(128));  // [4..15]: phase stamps of a TM_KNN_STAMPS diagnostic build
-  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 128, stream));
+  TM_TRY(ix->counters.alloc(256));  // [4..15]: phase stamps of a diagnostic build; bytes 128..159: the second scan shape's group tickets
+  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256, stream));
   const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
   const bool v1 = getenv("TM_KNN_V1") != nullptr;  // the first scan shape (tm_knn_kernel.h), kept for A/B runs; the k-nearest scans still use it
   int *bt = ix->best_tile.as<int>();
@@ -929,6 +929,18 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
     a.prune = prune; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
     a.n_groups = (nqt + ns - 1) / ns;
+    {
+      static int ncu = 0;  // one persistent workgroup per CU
+      if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TM_HIP(hipGetDevice(&dev));
+        TM_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = std::max(1, prop.multiProcessorCount);
+      }
+      a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)ncu * (16 / K2_NW));
+    }
+    a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
     launch_scan2(ix->plan.ht, ix->plan.hq, a, stream);
   } else
   launch_mfma(ix->plan.ht, ix->plan.hq,
@@ -967,6 +979,13 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
             v1 ? "v1" : "v2", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)cnt[2],
             100.0 * (double)cnt[3] / ((double)groups * (double)ntt), (double)cnt[3] / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);
   }
+#if TM_KNN2_STAMPS
+  if (!v1) {
+    static const char *names2[10] = {"prologue", "list building", "consume seeds", "consume lists", "end-of-list wait (seeds)", "end-of-list wait (lists)",
+                                     "  of consume: pop next", "  of consume: pop + tile landed", "results", "total"};
+    for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn2 stamps] %-32s %6.2f %% of wave time\n", names2[i], 100.0 * (double)cnt[6 + i] / (double)cnt[15]);
+  }
+#endif
 #if TM_KNN_STAMPS
   {
     static const char *names[10] = {"prologue", "wait data", "barrier", "issue", "box re-test", "MFMA + epilogue", "best refresh", "total", "next tile", "(list builds)"};

@@ -30,10 +30,24 @@ constexpr int K2_NW = TM_KNN2_WAVES;
 constexpr int K2_NT = K2_NW * 64;
 constexpr int K2_LDS = 163840 / (16 / K2_NW);
 constexpr int K2_LCAP = K2_NT;        // list entries: one chunk of tile slots always fits
-constexpr int K2_SEEDS = 8;           // tiles around the group's position on the curve, visited first by every sub-tile
+#ifndef TM_KNN2_BREAK
+#define TM_KNN2_BREAK (K2_LCAP / 2)
+#endif
+#ifndef TM_KNN2_SEEDS
+#define TM_KNN2_SEEDS 8
+#endif
+constexpr int K2_SEEDS = TM_KNN2_SEEDS;  // tiles around the group's position on the curve, visited first by every sub-tile
 constexpr int K2_XCD_RUN = 32 * (16 / K2_NW);  // workgroups that run together on one XCD
+#ifndef TM_KNN2_STAMPS
+#define TM_KNN2_STAMPS 0  // diagnostic build: s_memtime spans of the phases, summed over all waves into stats[4..]
+#endif
+#if TM_KNN2_STAMPS
+#define K2_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
 
-constexpr int k2_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 128 + K2_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
+constexpr int k2_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 64 + 576 + K2_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
 constexpr int k2_ns(int kq) {
   int ns = 16;
   while (ns > 1 && k2_lds_bytes(ns, kq) > K2_LDS) ns--;
@@ -49,6 +63,8 @@ struct Knn2Args {
   int *best_key, *best_tile;
   unsigned long long *stats;  // [0] (tile, sub-tile) blocks evaluated, [1] tiles read, [2] exact (query, row) pairs, [3] list entries
   int64_t n_groups;
+  int grid_blocks;    // persistent workgroups: one per CU (two with 8-wave workgroups)
+  unsigned *tickets;  // [8] zeroed before the launch: next run-slot of each XCD's share of the groups
 };
 
 __device__ __forceinline__ unsigned k2_wave_umax(unsigned x) {
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   constexpr int NS = k2_ns(KQ), NSP = (NS + 1) & ~1, NW = K2_NW, NT = K2_NT, LCAP = K2_LCAP;
   // one LDS object, carved by hand (16-byte aligned pieces)
   constexpr int OFF_QN = NS * KQ * 1024, OFF_BEST = OFF_QN + NS * 128, OFF_TIE = OFF_BEST + NS * 256, OFF_QBOX = OFF_TIE + NS * 128,
-                OFF_SMAX = OFF_QBOX + NS * 64, OFF_CTL = OFF_SMAX + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
+                OFF_SMAX = OFF_QBOX + NS * 64, OFF_CTL = OFF_SMAX + 64, OFF_LTILE = OFF_CTL + 576, OFF_LLB = OFF_LTILE + LCAP * 4,
                 LDS_TOTAL = OFF_LLB + LCAP * NSP * 2;
   static_assert(LDS_TOTAL == k2_lds_bytes(NS, KQ) && LDS_TOTAL <= K2_LDS, "LDS carve");
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
@@ -87,18 +103,39 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   unsigned *const s_tie = reinterpret_cast<unsigned *>(lds + OFF_TIE);                      // [NS][32] smallest d'' + 1 seen twice
   int *const s_qbox = reinterpret_cast<int *>(lds + OFF_QBOX);                              // [NS][16] lo[8] | hi[8]
   unsigned *const s_smax = reinterpret_cast<unsigned *>(lds + OFF_SMAX);                    // [16] upper bound of sqrt(largest best + 1)
-  int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor
+  int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor, [2] surviving runs
+  unsigned *const s_rmask = reinterpret_cast<unsigned *>(lds + OFF_CTL + 64);               // [64] sub-tiles that want a run of the batch
+  unsigned *const s_runs = reinterpret_cast<unsigned *>(lds + OFF_CTL + 320);               // [64] surviving runs: run << 16 | sub-tile mask
   unsigned *const s_ltile = reinterpret_cast<unsigned *>(lds + OFF_LTILE);                  // [LCAP]
   uint16_t *const s_llb = reinterpret_cast<uint16_t *>(lds + OFF_LLB);                      // [LCAP][NSP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
-  // workgroup -> query group: runs of K2_XCD_RUN consecutive groups per XCD (blocks b and b + 8 share an XCD: speed only)
-  int64_t g;
-  {
-    const unsigned b = blockIdx.x, xcd = b & 7u, i = b >> 3;
-    g = ((int64_t)(i / K2_XCD_RUN) * 8 + xcd) * K2_XCD_RUN + (i % K2_XCD_RUN);
+#if TM_KNN2_STAMPS
+  unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = st_last;
+#endif
+  // Persistent workgroups (one per CU): a workgroup draws query groups until none is left, so that no CU waits for a 16-wave
+  // workgroup with 155 KB of LDS to be launched 44 times over.  Groups are dealt in runs of K2_XCD_RUN consecutive groups per XCD (the
+  // id is read from the hardware: placement is a matter of speed only), so that the groups running together on one XCD are
+  // neighbours on the curve and stream the same tiles through that XCD's L2; an XCD whose share is exhausted helps the next one.
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0;
+  for (;;) {
+  __syncthreads();  // the previous group's LDS is no longer read
+  if (tid == 0) {
+    int64_t gsel = -1;
+    for (int k = 0; k < 8 && gsel < 0; k++) {
+      const unsigned x = (xcc + k) & 7u;
+      const unsigned t = atomicAdd(&a.tickets[x], 1u);
+      const int64_t gg = ((int64_t)(t / K2_XCD_RUN) * 8 + x) * K2_XCD_RUN + (t % K2_XCD_RUN);
+      if (gg < a.n_groups) gsel = gg;
+    }
+    s_ctl[3] = (int)gsel;
   }
-  if (g >= a.n_groups) return;
+  __syncthreads();
+  const int64_t g = __builtin_amdgcn_readfirstlane(s_ctl[3]);
+  if (g < 0) break;
   const int64_t st0 = g * NS;
   const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
   const int64_t n_ttiles = a.n_ttiles;
@@ -122,122 +159,121 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
   __syncthreads();  // (waits for the LDS-DMA pieces too)
 
+  K2_STAMP(0);  // prologue
   const int prune = a.prune;
   const int home = prune ? s_qbox[7] : 0;
-  const int r0a = prune ? (int)max((int64_t)0, min((int64_t)home - 3, n_ttiles - K2_SEEDS)) : 0;
+  const int r0a = prune ? (int)max((int64_t)0, min((int64_t)home - (K2_SEEDS / 2 - 1), n_ttiles - K2_SEEDS)) : 0;
   const int r0b = prune ? (int)min((int64_t)r0a + K2_SEEDS, n_ttiles) : 0;
   const int64_t total_slots = prune ? 2 * max((int64_t)home, n_ttiles - 1 - home) + 1 : n_ttiles;
   const int n_chunks = (int)((total_slots + NT - 1) / NT);
 
-  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0;
   int chunk = 0;
+  // pruned lists: runs of KNN_GROUP tiles in outward order from the home tile's run, NT / 16 runs per batch
+  const int n_grp = (int)((n_ttiles + KNN_GROUP - 1) / KNN_GROUP), home_run = home / KNN_GROUP;
+  const int total_run_slots = 2 * max(home_run, n_grp - 1 - home_run) + 1, n_run_batches = (total_run_slots + NT / 16 - 1) / (NT / 16);
+  int run_batch = 0, run_k = 0, run_alive = 0;
   int round = prune ? -1 : 0;
   for (;;) {
     // ---------------------------------------------------------------- the group's tile list
-    if (round < 0) {  // seeds: every sub-tile visits the tiles around the group's position, lower bound 0
-      if (tid < r0b - r0a) {
-        s_ltile[tid] = (unsigned)(r0a + tid);
+    if (round < 0) {  // seeds: every sub-tile visits the tiles around the group's position, lower bound 0; two entries per tile (each
+                      // with half of the sub-tiles), so that all the waves of the workgroup get one
+      if (tid < 2 * (r0b - r0a)) {
+        s_ltile[tid] = (unsigned)(r0a + (tid >> 1));
+        const int h0 = (tid & 1) ? (nvalid + 1) / 2 : 0, h1 = (tid & 1) ? nvalid : (nvalid + 1) / 2;
+        for (int p = 0; p < NSP; p++) s_llb[tid * NSP + p] = (p >= h0 && p < h1) ? 0 : 0xFFFF;
+      }
+      if (tid == 0) { s_ctl[0] = 2 * (r0b - r0a); s_ctl[1] = 0; }
+      __syncthreads();
+    } else if (!prune) {  // dense: every tile, every sub-tile, one chunk of NT tiles per list
+      const int64_t tile = (int64_t)chunk * NT + tid;
+      if (tile < n_ttiles) {
+        s_ltile[tid] = (unsigned)tile;
         for (int p = 0; p < NSP; p++) s_llb[tid * NSP + p] = p < nvalid ? 0 : 0xFFFF;
       }
-      if (tid == 0) { s_ctl[0] = r0b - r0a; s_ctl[1] = 0; }
+      if (tid == 0) { s_ctl[0] = (int)min((int64_t)NT, n_ttiles - (int64_t)chunk * NT); s_ctl[1] = 0; }
+      chunk++;
       __syncthreads();
     } else {
+      // Pruned.  Runs of KNN_GROUP tiles are judged first, RB of them at a time in outward order from the home run (one thread per
+      // (run, sub-tile) pair); then only the tiles of surviving runs are tested, 128 threads per run, against the sub-tiles that
+      // survived the run's box.  A step that does not fit behind the earlier entries is dropped and repeated after the consume.
+      constexpr int RB = NT / 16, RS = NT / KNN_GROUP;  // runs per batch, runs per tile-test step
+      static_assert(KNN_GROUP == 128 && RB <= 64, "run batches are compacted by one wave");
       if (tid == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
       __syncthreads();
-      while (chunk < n_chunks) {
-        const int n0 = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
-        if (n0 >= LCAP) break;  // full: consume first (a chunk that does not fit behind the earlier ones is dropped and built again, below)
-        // slot -> tile: outwards from the group's home tile (home, home + 1, home - 1, ...), near tiles tighten the bests first
-        const int64_t j = (int64_t)chunk * NT + tid;
-        int64_t tile;
-        bool valid;
-        if (prune) {
-          const int64_t off = (j + 1) >> 1;
-          tile = (j & 1) ? home + off : home - off;
-          valid = j < total_slots && tile >= 0 && tile < n_ttiles && !(tile >= r0a && tile < r0b);
-        } else {
-          tile = j;
-          valid = tile < n_ttiles;
+      for (;;) {
+        if (run_k >= run_alive) {  // next batch of runs
+          if (run_batch >= n_run_batches) break;
+          if (tid < RB) s_rmask[tid] = 0;
+          __syncthreads();
+          {
+            const int jr = run_batch * RB + (tid >> 4), s = tid & 15;
+            const int off = (jr + 1) >> 1, run = (jr & 1) ? home_run + off : home_run - off;
+            if (jr < total_run_slots && run >= 0 && run < n_grp && s < nvalid) {
+              unsigned lbq = 0;
+#pragma unroll
+              for (int d = 0; d < ND; d++) {
+                const int tlo = a.grp_lo[d * n_grp + run], thi = a.grp_hi[d * n_grp + run];
+                const int gap = max(0, max(tlo - s_qbox[s * 16 + 8 + d], s_qbox[s * 16 + d] - thi)) >> 1;
+                lbq += (unsigned)(gap * gap);
+              }
+              if (2u * k2_isqrt(lbq) <= k2_peek(&s_smax[s])) atomicOr(&s_rmask[tid >> 4], 1u << s);
+            }
+          }
+          __syncthreads();
+          if (wave == 0) {  // surviving runs of the batch, in outward order
+            const int jr = run_batch * RB + lane;
+            const int off = (jr + 1) >> 1, run = (jr & 1) ? home_run + off : home_run - off;
+            const unsigned m = lane < RB ? s_rmask[lane] : 0u;
+            const unsigned long long alive = __builtin_amdgcn_ballot_w64(m != 0);
+            if (m) s_runs[__popcll(alive & ((1ull << lane) - 1ull))] = ((unsigned)run << 16) | m;
+            if (lane == 0) s_ctl[2] = __popcll(alive);
+          }
+          __syncthreads();
+          run_alive = __builtin_amdgcn_readfirstlane(s_ctl[2]);
+          run_k = 0;
+          run_batch++;
+          continue;
         }
+        const int n0 = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
+        if (n0 >= TM_KNN2_BREAK) break;  // enough for now: what comes later is judged with tighter bests
+        // tile tests: RS surviving runs per step, thread = (run, tile of the run); the run's sub-tile mask is uniform in a wave
+        const int k = run_k + (tid >> 7);
+        const unsigned rm = k < run_alive ? s_runs[k] : 0u;
+        const unsigned rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(rm & 0xFFFFu));
+        const int64_t tile = (int64_t)(rm >> 16) * KNN_GROUP + (tid & 127);
+        const bool valid = rmask != 0 && tile < n_ttiles && !(tile >= r0a && tile < r0b);
         // 16-bit lower bounds of this lane's tile against the 16 sub-tile slots: a 256-bit shift register, one value pushed per
         // slot (so the loop stays rolled: no run-time register index), slot s ends in bits 16 * (s & 1) of lbw[s >> 1]
         unsigned lbw[8];
 #pragma unroll
         for (int p = 0; p < 8; p++) lbw[p] = 0xFFFFFFFFu;
-        auto push = [&](unsigned v16) {
-#pragma unroll
-          for (int p = 0; p < 7; p++) lbw[p] = __builtin_amdgcn_alignbit(lbw[p + 1], lbw[p], 16);
-          lbw[7] = (lbw[7] >> 16) | (v16 << 16);
-        };
         bool any = false;
-        if (!prune) {
+        if (rmask) {
+          int tlo[ND], thi[ND];
+          const int64_t tc = valid ? tile : 0;
+#pragma unroll
+          for (int d = 0; d < ND; d++) { tlo[d] = a.box_lo[(int64_t)d * n_ttiles + tc]; thi[d] = a.box_hi[(int64_t)d * n_ttiles + tc]; }
 #pragma unroll 1
-          for (int s = 0; s < 16; s++) push(s < nvalid ? 0u : 0xFFFFu);
-          any = valid;
-        } else {
-          // second level first, per wave: the wave's 64 slots lie in at most two runs of KNN_GROUP tiles on each side of home;
-          // lane = run * 16 + sub-tile judges one (run, sub-tile) pair
-          const int64_t jw = (int64_t)chunk * NT + wave * 64;
-          const int64_t off_lo = (jw + 1) >> 1, off_hi = (jw + 64) >> 1;
-          const int n_grp = (int)((n_ttiles + KNN_GROUP - 1) / KNN_GROUP);
-          const int gi4[4] = {(int)((home + off_lo) / KNN_GROUP), (int)((home + off_hi) / KNN_GROUP),
-                              (home - off_hi) >= 0 ? (int)((home - off_hi) / KNN_GROUP) : -1, (home - off_lo) >= 0 ? (int)((home - off_lo) / KNN_GROUP) : -1};
-          unsigned long long gpass;
-          {
-            const int gsel = lane >> 4, s = lane & 15;
-            const int grp = gsel == 0 ? gi4[0] : gsel == 1 ? gi4[1] : gsel == 2 ? gi4[2] : gi4[3];
-            bool pass = false;
-            if (grp >= 0 && grp < n_grp && s < nvalid) {
+          for (int s = 0; s < 16; s++) {
+            unsigned v16 = 0xFFFFu;
+            if ((rmask >> s) & 1u) {  // uniform
+              const v4i q0 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16]), q1 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 4]),
+                        q2 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 8]), q3 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 12]);
+              const int qlo[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+              const int qhi[8] = {q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
               unsigned lbq = 0;
 #pragma unroll
               for (int d = 0; d < ND; d++) {
-                const int tlo = a.grp_lo[d * n_grp + grp], thi = a.grp_hi[d * n_grp + grp];
-                const int gap = max(0, max(tlo - s_qbox[s * 16 + 8 + d], s_qbox[s * 16 + d] - thi)) >> 1;
+                const int gap = max(0, max(tlo[d] - qhi[d], qlo[d] - thi[d])) >> 1;
                 lbq += (unsigned)(gap * gap);
               }
-              pass = 2u * k2_isqrt(lbq) <= k2_peek(&s_smax[s]);
+              const unsigned lb16 = min(0xFFFEu, 2u * k2_isqrt(lbq));
+              if (valid && lb16 <= k2_peek(&s_smax[s])) { v16 = lb16; any = true; }
             }
-            gpass = __builtin_amdgcn_ballot_w64(pass);
-          }
-          // this lane's tile: which run is it in, which sub-tiles survived there
-          unsigned smask = 0;
-          if (valid) {
-            const int grp = (int)(tile / KNN_GROUP);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-              if (grp == gi4[k]) smask |= (unsigned)(gpass >> (16 * k)) & 0xFFFFu;
-          }
-          unsigned ub = 0;  // union over the wave of the surviving sub-tiles
-          {
-            unsigned x = smask;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x |= (unsigned)__shfl_xor((int)x, o);
-            ub = (unsigned)__builtin_amdgcn_readfirstlane((int)x);
-          }
-          if (ub) {
-            int tlo[ND], thi[ND];
-            const int64_t tc = valid ? tile : 0;
-#pragma unroll
-            for (int d = 0; d < ND; d++) { tlo[d] = a.box_lo[(int64_t)d * n_ttiles + tc]; thi[d] = a.box_hi[(int64_t)d * n_ttiles + tc]; }
-#pragma unroll 1
-            for (int s = 0; s < 16; s++) {
-              unsigned v16 = 0xFFFFu;
-              if ((ub >> s) & 1u) {  // uniform
-                const v4i q0 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16]), q1 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 4]),
-                          q2 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 8]), q3 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 12]);
-                const int qlo[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                const int qhi[8] = {q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
-                unsigned lbq = 0;
-#pragma unroll
-                for (int d = 0; d < ND; d++) {
-                  const int gap = max(0, max(tlo[d] - qhi[d], qlo[d] - thi[d])) >> 1;
-                  lbq += (unsigned)(gap * gap);
-                }
-                const unsigned lb16 = min(0xFFFEu, 2u * k2_isqrt(lbq));
-                if (((smask >> s) & 1u) && lb16 <= k2_peek(&s_smax[s])) { v16 = lb16; any = true; }
-              }
-              push(v16);
-            }
+            for (int p = 0; p < 7; p++) lbw[p] = __builtin_amdgcn_alignbit(lbw[p + 1], lbw[p], 16);
+            lbw[7] = (lbw[7] >> 16) | (v16 << 16);
           }
         }
         {  // ordered append inside the wave, one LDS atomic per wave
@@ -256,16 +292,17 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
         }
         __syncthreads();
         const int n1 = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
-        if (n1 > LCAP) {  // did not fit behind the earlier chunks: drop it, consume, build it again
+        if (n1 > LCAP) {  // did not fit behind the earlier steps: drop it, consume, do it again
           __syncthreads();
           if (tid == 0) s_ctl[0] = n0;
           __syncthreads();
           break;
         }
-        chunk++;
-        __syncthreads();  // everyone has read n1 before the next chunk's atomics move it
+        run_k += RS;
+        __syncthreads();  // everyone has read n1 before the next step's atomics move it
       }
     }
+    K2_STAMP(1);  // list building (with its barriers)
     // ---------------------------------------------------------------- consume: every wave on its own
     {
       const int list_n = __builtin_amdgcn_readfirstlane((int)k2_peek(reinterpret_cast<unsigned *>(&s_ctl[0])));
@@ -302,7 +339,15 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
         // the entry after this one is chosen while the loads fly
         int ntile = 0, nlb = 0;
         unsigned nmask = 0;
+#if TM_KNN2_STAMPS
+        const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
         const bool nhave = next_entry(ntile, nlb, nmask);
+#if TM_KNN2_STAMPS
+        st_acc[6] += __builtin_amdgcn_s_memtime() - tp0;  // popping the next entry
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_acc[7] += __builtin_amdgcn_s_memtime() - tp0;  // ... until the tile has landed
+#endif
         const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
         while (mask) {
           const int s = __builtin_ctz(mask);
@@ -369,8 +414,10 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
         tile = ntile; lbv = nlb; mask = nmask; have = nhave;
       }
     }
+    K2_STAMP(round < 0 ? 2 : 3);  // consuming: seeds / lists
     __syncthreads();
-    if (round >= 0 && chunk >= n_chunks) break;
+    K2_STAMP(round < 0 ? 4 : 5);  // waiting for the other waves at the end of a list
+    if (round >= 0 && (prune ? (run_batch >= n_run_batches && run_k >= run_alive) : chunk >= n_chunks)) break;
     round++;
   }
 
@@ -384,6 +431,14 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
     a.best_key[q] = (int)(hi - 1u);
     a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
   }
+  }  // next query group
+#if TM_KNN2_STAMPS
+  K2_STAMP(8);  // results
+  if (a.stats && lane == 0) {
+    for (int i = 0; i < 9; i++) atomicAdd(a.stats + 4 + i, st_acc[i]);
+    atomicAdd(a.stats + 13, __builtin_amdgcn_s_memtime() - st_begin);
+  }
+#endif
   if (a.stats && lane == 0) {
     atomicAdd(a.stats, (unsigned long long)nblocks);
     atomicAdd(a.stats + 1, (unsigned long long)nloads);
@@ -401,8 +456,7 @@ int knn2_sub_tiles(int hq);  // NS of the queries' digit plan
 
 #define TM_KNN2_DEFINE_HT(HT)                                                                         \
   template <> void knn2_launch_ht<HT>(int hq, const Knn2Args &a, hipStream_t stream) {               \
-    const int64_t per = 8 * K2_XCD_RUN;                                                               \
-    const dim3 grid((unsigned)(((a.n_groups + per - 1) / per) * per)), block(K2_NT);                  \
+    const dim3 grid((unsigned)a.grid_blocks), block(K2_NT);                                           \
     switch (hq) {                                                                                     \
       TM_KNN2_CASE(HT, 0) TM_KNN2_CASE(HT, 1) TM_KNN2_CASE(HT, 2) TM_KNN2_CASE(HT, 3)                 \
       TM_KNN2_CASE(HT, 4) TM_KNN2_CASE(HT, 5)                                                         \

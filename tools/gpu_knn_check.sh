@@ -1,14 +1,19 @@
 #!/bin/bash
-# development aid: KNN tests, then the KNN micro-benchmark for both scan shapes (run on the GPU box through gpurun)
+# development aid: KNN tests, then the headline bench with the scan's debug line, then the phase stamps of a diagnostic build
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "knn" > gpurun_out/knn_tests.log 2>&1
 rc=$?
-tail -5 gpurun_out/knn_tests.log
+tail -3 gpurun_out/knn_tests.log
 [ $rc -ne 0 ] && exit $rc
-TM_KNN_DEBUG=1 timeout -k 10 300 python tools/knn_bench.py 60 > gpurun_out/knn_bench_v2.log 2>&1 || { tail -20 gpurun_out/knn_bench_v2.log; exit 1; }
-grep -v "^\[tm_knn\] nq\|curve" gpurun_out/knn_bench_v2.log | tail -8
-TM_KNN_V1=1 TM_KNN_DEBUG=1 timeout -k 10 300 python tools/knn_bench.py 60 > gpurun_out/knn_bench_v1.log 2>&1
-grep -v "^\[tm_knn\] nq\|curve" gpurun_out/knn_bench_v1.log | tail -8
-(rocprofv3 -L 2>/dev/null | grep -i "mfma\|SQ_BUSY_CY\|SQ_WAVE_CYCLES\|SQ_INSTS_VALU \|SQ_WAIT_ANY\|SQ_ACTIVE_INST_ANY\|LDS_BANK" | head -60) > gpurun_out/counters.txt 2>&1
-wc -l gpurun_out/counters.txt
+TM_KNN_DEBUG=1 timeout -k 10 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra > gpurun_out/bench_dbg.json 2> gpurun_out/bench_dbg.err || { tail -5 gpurun_out/bench_dbg.err; exit 1; }
+python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/bench_dbg.json").read().strip().splitlines()[-1])
+print("fps=%.0f ms=%.2f stages=%s knn_ms=%.2f frac=%.4f dense_ms=%.1f dense_pipe=%.3f" % (j["value"], j["ms_per_step"], j["stage_ms"], j["roofline"]["launch_ms"], j["roofline"]["frac"], j["roofline_dense"]["launch_ms"], j["roofline_dense"]["mfma_pipe_frac"]))
+PY
+grep "kernel" gpurun_out/bench_dbg.err | tail -2
+if [ -f tiler_amd/lib/variants/libtilemotion_stamps.so ]; then
+  TM_LIB_VARIANT=stamps TM_KNN_DEBUG=1 timeout -k 10 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra > gpurun_out/bench_st.json 2> gpurun_out/bench_st.err
+  grep "stamps\|kernel" gpurun_out/bench_st.err | head -11
+fi
