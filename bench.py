@@ -3,8 +3,10 @@
 per-frame tile pipeline on the 720p, 300-frame, 16-palette synthetic clip (configs[1]).
 
 A step = one TTilingEncoder.Run(esAll) pass (Load -> Reduce -> PreparePalettes -> Dither -> Reconstruct -> Reindex)
-over the whole clip with the RGB frames already resident in HBM.  N > 1: one process per GPU (torch.distributed, RCCL);
-the clip is ONE job split over the ranks (strong scaling), see tiler_amd/distributed.py.  Prints one JSON line.
+over the whole clip.  `value` is measured with the RGB frames already resident in HBM; `with_h2d` repeats the same K steps with
+the clip in page-locked HOST memory, so that every step also moves it across PCIe (SURVEY.md 8d's "H2D included" reading).
+N > 1: one process per GPU (torch.distributed, RCCL); the clip is ONE job split over the ranks (strong scaling), see
+tiler_amd/distributed.py.  Prints one JSON line.
 """
 import argparse
 import ctypes
@@ -19,69 +21,118 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 I8_DENSE_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: bf16 dense ~2.5 PF, i8 MFMA = 2x bf16 per clock
-# HBM-side bytes per launch of the dominant kernel on the default workload, from the separate rocprofv3 --pmc passes of
-# profiles/r01_pmc_knn.md: 2 x FETCH_SIZE (gfx950 counts half of a 16-B/lane stream) + WRITE_SIZE, in bytes
-PMC_TRAFFIC_BYTES = 2 * 33385770 * 1024 + 36914 * 1024
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+INT32_VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # one int32 operation per lane and clock: 78.6 Tops/s
+STAGES = ["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"]
 
 
-def cpu_baseline(width, height, nframes, palette_count, t_global, seconds_budget=20.0):
-    """The oracle (CPU restatement, kind 'port', 1 thread) on a bounded sample, scaled to frames/s of the same workload."""
+def _traffic_from_profiles(kernel_build):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r02_pmc_knn_traffic.json), only when
+    they were taken on this build of the kernel; null otherwise -- the figure is never a constant of this file."""
+    p = os.path.join(ROOT, "profiles", "r02_pmc_knn_traffic.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+    except OSError:
+        return None, "no PMC pass committed for this build"
+    if t.get("kernel_build") != kernel_build:
+        return None, "profiles/r02_pmc_knn_traffic.json was taken on build %r, this is %r" % (t.get("kernel_build"), kernel_build)
+    return t["traffic_bytes"], "2 x FETCH_SIZE + WRITE_SIZE of one pruned launch, separate --pmc passes (%s)" % t.get("source", "profiles/")
+
+
+def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, scaled to frames/s.  Three legs:
+    1 thread with the brute-force search; every host core (one oracle call per thread: ctypes drops the GIL) with the brute force;
+    every host core with the exact kd-tree (bucket 32) the reference searches with.  `value` is the fastest of them."""
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     so = os.path.join(ROOT, "oracle", "libtm_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libtm_oracle.so"])
     from tests.oracle_binding import Oracle
     from tiler_amd import synth
     o = Oracle(so)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     tm_w, tm_h = (width - 1) // 8 + 1, (height - 1) // 8 + 1
     per = tm_w * tm_h
     fr = synth.video(2, width, height)
+    rng = np.random.default_rng(0)
+
+    def par(fn, parts, threads):
+        if threads == 1:
+            t0 = time.time()
+            out = [fn(p) for p in parts]
+            return time.time() - t0, out
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.time()
+            out = list(ex.map(fn, parts))
+            return time.time() - t0, out
+
+    # one frame: tile scatter + Lab means + mirrors (per frame, serial per frame in the reference: one thread per frame)
     t0 = time.time()
     tiles = o.load_from_image(fr[0], tm_w, tm_h)
     o.inter_frame_data(tiles)
     canon, flags = o.canonicalise(tiles)
     t_load = time.time() - t0
-    sample = canon[: per // 8]
-    t0 = time.time()
-    qf = o.features_rgb(sample, None, 1, False)
-    t_feat = (time.time() - t0) * per / sample.shape[0]
-    # global-tile stages are paid once per clip for T tiles: amortised per frame = cost(T) / nframes
-    gs = canon[:256]
-    rng = np.random.default_rng(0)
+    # query features of one frame's tiles
+    feat_parts = np.array_split(canon[: per // 4], max(cores, 1))
+    t_feat1, _ = par(lambda p: o.features_rgb(p, None, 1, False), [canon[: per // 16]], 1)
+    t_feat1 *= 16
+    t_featn, qparts = par(lambda p: o.features_rgb(p, None, 1, False), feat_parts, cores)
+    t_featn *= 4
+    qf = np.concatenate(qparts)
+    # global-tile stages, paid once per clip for T tiles: cluster features + Thomas-Knoll dither + database features
+    gs = canon[:512]
     pal_idx = rng.integers(0, palette_count, size=gs.shape[0]).astype(np.int32)
     palettes = rng.integers(0, 1 << 24, size=(palette_count, 16)).astype(np.int32)
-    t0 = time.time()
-    o.features_cluster(gs, 4)
-    pp = o.dither(gs, flags[:256], pal_idx, palettes, True)
-    db_small = o.features_pal(pp, pal_idx, palettes, 1)
-    t_global_per_tile = (time.time() - t0) / gs.shape[0]
-    # exact dedup: sort of 256-byte keys, n log n; sample then scale by n log n
+
+    def global_stage(sl):
+        o.features_cluster(gs[sl], 4)
+        pp = o.dither(gs[sl], flags[:512][sl], pal_idx[sl], palettes, True)
+        return o.features_pal(pp, pal_idx[sl], palettes, 1)
+    t_g1, _ = par(global_stage, [slice(0, 64)], 1)
+    t_g1 = t_g1 / 64
+    gparts = [slice(i * 512 // cores, (i + 1) * 512 // cores) for i in range(cores)]
+    t_gn, dbparts = par(global_stage, gparts, cores)
+    t_gn = t_gn / 512
+    db_small = np.concatenate(dbparts)
+    # exact dedup of the clip's frame tiles: comparison sort of 256-byte keys, single-threaded in the reference (TFPList.Sort)
     ds = np.concatenate([canon, canon[: per // 2]])
     t0 = time.time()
     o.dedup(ds, None)
     n_s, n_full = ds.shape[0], per * nframes
     t_dedup_clip = (time.time() - t0) * (n_full * np.log2(n_full)) / (n_s * np.log2(n_s))
-    # KNN: the scalar SSD loop of utils.pas:541-557 over the full database for a handful of queries
-    db = rng.integers(-300, 300, size=(t_global, 192)).astype(np.int16)
+    # KNN against the distinct database rows (what both the reference's tree and the GPU scan search)
+    db = rng.integers(-300, 300, size=(t_distinct, 192)).astype(np.int16)
+    db[:, 0] = rng.integers(0, 13000, size=t_distinct)
     db[: db_small.shape[0]] = db_small
-    nq = 8
+    nq1 = 16
+    t_knn1, _ = par(lambda q: o.knn1(q, db), [qf[:nq1]], 1)
+    nqn = 16 * cores
+    t_knnn, _ = par(lambda q: o.knn1(q, db), np.array_split(qf[:nqn], cores), cores)
     t0 = time.time()
-    o.knn1(qf[:nq], db)
-    dt = time.time() - t0
-    while dt < seconds_budget / 4 and nq < 512:
-        nq *= 4
-        t0 = time.time()
-        o.knn1(qf[:nq], db)
-        dt = time.time() - t0
-    t_knn_frame = dt * per / nq
-    sec_per_frame = t_load + t_feat + t_knn_frame + (t_global_per_tile * t_global + t_dedup_clip) / nframes
+    tree = o.kdtree_build(db, 32)
+    t_tree_build = time.time() - t0
+    t_kd, res = par(lambda q: o.kdtree_search1(tree, q), np.array_split(qf[:nqn], cores), cores)
+    visited = sum(r[2] for r in res)
+    o.kdtree_free(tree)
+
+    def fps(load, feat, knn_per_query, glob_per_tile, extra_clip=0.0):
+        return 1.0 / (load + feat + knn_per_query * per + (glob_per_tile * t_global + t_dedup_clip + extra_clip) / nframes)
+    one = fps(t_load, t_feat1, t_knn1 / nq1, t_g1)
+    allb = fps(t_load / cores, t_featn, t_knnn / nqn, t_gn)          # frames load on separate threads in the reference (1326)
+    allk = fps(t_load / cores, t_featn, t_kd / nqn, t_gn, t_tree_build)
+    best = max(allb, allk)
     return {
-        "value": 1.0 / sec_per_frame, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": (f"oracle (C restatement, gcc -O3, 1 thread) timed on: 1 frame load+Lab+mirrors, {sample.shape[0]} query feature "
-                   f"vectors, 256 global tiles (cluster features + Thomas-Knoll dither + database features), exact dedup of "
-                   f"{n_s} tiles (scaled n log n), brute-force KNN of {nq} queries x full {t_global}-tile database; scaled linearly to "
-                   f"{per} tiles/frame; k-means stages excluded (favours the CPU)"),
-        "tiles_matched_per_sec": per / t_knn_frame,
+        "value": best, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle (C restatement, gcc -O3) timed on: 1 frame load+Lab+mirrors, {per // 4} query feature vectors, 512 global tiles "
+                   f"(cluster features + Thomas-Knoll dither + database features), exact dedup of {n_s} tiles (scaled n log n, one thread as "
+                   f"TFPList.Sort), KNN of {nqn} queries x {t_distinct} distinct rows; scaled linearly to {per} tiles/frame and {t_global} "
+                   f"global tiles; k-means stages excluded (favours the CPU)"),
+        "legs": {"one_thread_brute_force": one, "all_cores_brute_force": allb, "all_cores_kdtree_bucket32": allk},
+        "kdtree": {"build_s": t_tree_build, "rows_visited_fraction": visited / float(nqn * t_distinct),
+                   "note": "exact kd-tree (ANN's published standard split and search, eps 0): in 192 dimensions it degenerates towards a brute force"},
+        "tiles_matched_per_sec": nqn / min(t_knnn, t_kd),
     }
 
 
@@ -99,13 +150,16 @@ def main():
                     help="MotionPredictRadius for the timed steps; 0 (default) = the headline definition of SURVEY.md 8(d): motion prediction excluded")
     ap.add_argument("--no-motion-extra", action="store_true", help="skip the untimed extra pass with MotionPredictRadius=32")
     ap.add_argument("--no-defaults-extra", action="store_true",
-                    help="skip the untimed extra pass with the reference's default settings (motion prediction + extended palette usage)")
+                    help="skip the untimed extra passes with the extended palette usage on (alone, and with motion prediction)")
+    ap.add_argument("--no-h2d-extra", action="store_true", help="skip the second timed region with the clip in host memory")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from tiler_amd import synth, distributed
-    from tiler_amd.encoder import TilingEncoder
+    from tiler_amd import synth, distributed, stages
+    from tiler_amd import lib as _lib_fn
+    from tiler_amd._lib import check as _check
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +171,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, F = args.width, args.height, args.frames
-    # synthetic clip, generated on the host in slabs and parked in HBM before any timing
-    frames = torch.empty((F, H, W), dtype=torch.int32, device="cuda")
+    # synthetic clip, generated on the host into page-locked memory, then parked in HBM before any timing
+    host_frames = torch.empty((F, H, W), dtype=torch.int32, pin_memory=True)
     rng = np.random.Generator(np.random.PCG64(synth.SEED))
+    hv = host_frames.numpy()
     for f in range(F):
-        frames[f] = torch.from_numpy(synth.frame(f, W, H, rng).view(np.int32)).cuda()
+        hv[f] = synth.frame(f, W, H, rng).view(np.int32)
+    frames = host_frames.cuda()
     torch.cuda.synchronize()
 
     enc = TilingEncoder()
@@ -142,31 +198,39 @@ def main():
     def step():
         distributed.run_all(enc, F, rank, world)
 
+    def timed(nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        knn = dict(ms=0.0, pairs=0, launches=0)
+        stage_ms = np.zeros(8)
+        for _ in range(nsteps):
+            step()
+            ks = enc.KnnStats()
+            knn["ms"] += ks["kernel_ms"]; knn["pairs"] += ks["pairs"]; knn["launches"] += ks["launches"]
+            stage_ms += enc.StageMs()
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), knn, stage_ms
+
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    knn_ms = knn_pairs = knn_launches = 0
-    stage_ms = np.zeros(8)
-    for _ in range(args.steps):
-        step()
-        ks = enc.KnnStats()
-        knn_ms += ks["kernel_ms"]; knn_pairs += ks["pairs"]; knn_launches += ks["launches"]
-        stage_ms += enc.StageMs()
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, knn, stage_ms = timed(args.steps)
 
     c = enc.counts()
     ks = enc.KnnStats()
-    per_launch_ms = knn_ms / max(knn_launches, 1)
-    alg_ops_per_launch = 384.0 * knn_pairs / max(knn_launches, 1)  # 2*192 integer ops per (query, tile) pair
+    per_launch_ms = knn["ms"] / max(knn["launches"], 1)
+    alg_ops_per_launch = 384.0 * knn["pairs"] / max(knn["launches"], 1)  # 2*192 integer ops per (query, tile) pair
     achieved = alg_ops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
-    q_total = F * c["tm_w"] * c["tm_h"]
+    per = c["tm_w"] * c["tm_h"]
+    q_total = F * per
+    T = int(enc.GlobalTilingTileCount)
+    kernel_build = _lib_fn().tm_version().decode()
+    traffic, traffic_note = _traffic_from_profiles(kernel_build) if (W, H, F, args.palettes) == (1280, 720, 300, 16) else (None, "not the profiled workload")
+    st = {n: float(v) / args.steps for n, v in zip(STAGES, stage_ms)}
     out = {
         "metric": "encoded frames/sec + tiles-matched/sec, 720p 8x8 tiles, 1/2/4/8 MI355X",
         "value": F * args.steps / dt,
@@ -180,22 +244,33 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
                                f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else ""),
-                   "frames": F, "tiles_per_frame": c["tm_w"] * c["tm_h"], "query_tiles": q_total, "global_tiles_T": int(enc.GlobalTilingTileCount),
+                   "frames": F, "tiles_per_frame": per, "query_tiles": q_total, "global_tiles_T": T,
                    "distinct_database_rows": int(ks["db_rows"]), "final_tiles_after_reindex": int(c["tiles"]),
-                   "parallelism": f"frames sharded over {world} GPU(s) for Reconstruct; other steps replicated"},
-        "tiles_matched_per_sec": q_total / (float(stage_ms[5]) / args.steps * 1e-3) if stage_ms[5] > 0 else None,
-        "stage_ms": {n: round(float(v) / args.steps, 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], stage_ms)},
-        "nominal_pairs": float(q_total) * float(enc.GlobalTilingTileCount),
+                   "input": "RGB frames resident in HBM when the timed region starts (with_h2d: in page-locked host memory)",
+                   "parallelism": distributed.describe(world)},
+        "tiles_matched_per_sec": q_total / (st["reconstruct"] * 1e-3) if st["reconstruct"] > 0 else None,
+        "stage_ms": {n: round(v, 3) for n, v in st.items()},
+        "nominal_pairs": float(q_total) * float(T),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_DENSE_PEAK_TOPS,
-                     "traffic": PMC_TRAFFIC_BYTES if (W, H, F, args.palettes) == (1280, 720, 300, 16) else None, "kernel": "k_knn_mfma", "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
-                     "pairs_per_launch": knn_pairs / max(knn_launches, 1),
-                     "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair; the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
+                     "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_knn_scan2", "kernel_build": kernel_build,
+                     "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
+                     "pairs_per_launch": knn["pairs"] / max(knn["launches"], 1),
+                     "mfma_pipe_frac": achieved * (2 * ks["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
+                     "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair (exact count: padding rows are not pairs); "
+                             "the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }
+    if world == 1 and not args.no_h2d_extra:
+        # the same K steps with the clip in host memory: every Load moves 4*W*H*F bytes across PCIe (chunks beside its own kernel)
+        enc.SetFramesHost(host_frames)
+        step()
+        dth, _, sth = timed(args.steps)
+        enc.SetFramesDevice(frames)
+        out["with_h2d"] = {"value": F * args.steps / dth, "unit": "frames/s", "ms_per_step": dth / args.steps * 1e3,
+                           "h2d_bytes_per_step": 4 * W * H * F, "load_ms": float(sth[0]) / args.steps,
+                           "pcie_gb_s_in_load": 4.0 * W * H * F / (float(sth[0]) / args.steps * 1e-3) / 1e9 if sth[0] > 0 else None,
+                           "note": "tm_set_frames_host: pinned host memory -> HBM inside Load (SURVEY.md 8d's H2D-included reading); never `value`"}
     if world == 1 and rank == 0:
         # the peaks measured on this very device: a bare loop of the kernel's MFMA instruction and an HBM stream triad
-        import ctypes
-        from tiler_amd import lib as _lib_fn
-        from tiler_amd._lib import check as _check
         tops, gbs = ctypes.c_double(), ctypes.c_double()
         _check(_lib_fn().tm_probe_mfma_i8(0.3, ctypes.byref(tops)))
         _check(_lib_fn().tm_probe_hbm_triad(1 << 30, ctypes.byref(gbs)))
@@ -205,13 +280,52 @@ def main():
         out["roofline"]["frac_of_measured_peak"] = achieved / tops.value if tops.value > 0 else None
         out["roofline"]["mfma_pipe_frac_of_measured_peak"] = achieved * (2 * ks["k_bytes"] / 384.0) / tops.value if tops.value > 0 else None
     if world == 1:
-        # diagnostic, outside the timed region: the same kernel with pruning off = a dense Q x T_distinct distance GEMM,
-        # which is what the MFMA roofline is really about (the shipped path skips >95 % of it)
+        # per-stage rooflines: the streaming kernels timed on their own (torch events on the stream the stage seam
+        # launches on) on the clip's own data; Dither and the k-means stage from the step's wall time
+        def ev_time(fn, reps=3):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, r
+        sr = {}
+        ms, (tiles, flags, lab) = ev_time(lambda: stages.load(frames, c["tm_w"], c["tm_h"]))
+        b = q_total * (256 + 256 + 1 + 12)
+        sr["load"] = {"bound": "hbm", "kernel": "k_load_tiles", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                      "ms": ms, "algorithmic_bytes": b, "note": "256 B pixels in, 256 B canonical tile + 1 B mirror flags + 12 B Lab means out per tile"}
+        del lab
+        ms, feats = ev_time(lambda: stages.features_rgb(tiles, None, 1, False))
+        b = q_total * 640
+        sr["features"] = {"bound": "hbm", "kernel": "k_features_i16<0>", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                          "ms": ms, "algorithmic_bytes": b, "flops": q_total * 24576.0, "tflops": q_total * 24576.0 / ms / 1e9,
+                          "note": "640 B and 24 576 flop per tile in the summation order DCTInner_asm fixes (fp32 products, fp64 accumulation)"}
+        del feats
+        ms, _ = ev_time(lambda: stages.dedup(tiles), reps=2)
+        b = q_total * 260
+        sr["dedup"] = {"bound": "hbm", "kernel": "run_dedup (hash, radix sorts, compare, merge sort of distinct rows)", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": b, "note": "one 256 B key read + one 4 B index written per tile; blocking call (host reads the distinct count)"}
+        del tiles, flags
+        ops = T * 64.0 * 64.0 * 16.0 * 12.0  # 64 pixels x 64 error-feedback steps x PaletteSize colours per tile, 12 int32 operations per compare
+        sr["dither"] = {"bound": "int32 valu", "kernel": "k_dither_tk_fast", "achieved": ops / st["dither"] / 1e9, "peak": INT32_VALU_PEAK_TOPS, "unit": "Tops/s",
+                        "frac": ops / st["dither"] / 1e9 / INT32_VALU_PEAK_TOPS, "ms": st["dither"], "hbm_gb_s": T * 320 / st["dither"] / 1e6,
+                        "note": "64 x 64 x PaletteSize colour compares per tile at 12 int32 operations each (DESIGN.md section 5); HBM traffic is negligible"}
+        it = enc.KmeansIters() if hasattr(enc, "KmeansIters") else None
+        if it:
+            b = 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * T * it["tile_iters"]
+            sr["kmeans"] = {"bound": "hbm", "kernel": "palettize (192-D) + quantize (3-D) Lloyd iterations", "achieved": b / st["prepare_palettes"] / 1e6, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": b / st["prepare_palettes"] / 1e6 / HBM_PEAK_GBS, "ms": st["prepare_palettes"], "algorithmic_bytes": b, **it,
+                            "note": "3 B per colour point and 768 B per tile point per iteration; the stage is bound by dependent launches, not bytes"}
+        sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms")}
+        out["stage_rooflines"] = sr
+    if world == 1:
+        # diagnostic, outside the timed region: the same kernel with pruning off = a dense Q x T_distinct distance GEMM (BASELINE config 3)
         os.environ["TM_KNN_NOPRUNE"] = "1"
-        from tiler_amd.encoder import TEncoderStep
-        for st in (TEncoderStep.esLoad, TEncoderStep.esPredictMotion, TEncoderStep.esReduce, TEncoderStep.esPreparePalettes,
+        for s_ in (TEncoderStep.esLoad, TEncoderStep.esPredictMotion, TEncoderStep.esReduce, TEncoderStep.esPreparePalettes,
                    TEncoderStep.esDither, TEncoderStep.esReconstruct):
-            enc.Run(st)
+            enc.Run(s_)
         del os.environ["TM_KNN_NOPRUNE"]
         kd = enc.KnnStats()
         dense = 384.0 * kd["pairs"] / max(kd["launches"], 1) / (kd["kernel_ms"] / max(kd["launches"], 1) * 1e-3) / 1e12
@@ -219,63 +333,45 @@ def main():
                                  "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
                                  "mfma_pipe_frac_of_measured_peak": (dense * (2 * kd["k_bytes"] / 384.0) / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
                                  "launch_ms": kd["kernel_ms"] / max(kd["launches"], 1), "pairs_per_launch": kd["pairs"] / max(kd["launches"], 1),
-                                 "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated"}
+                                 "pairs_expected": float(q_total) * float(kd["db_rows"]),
+                                 "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated; parity-tested in tests/test_gpu_parity.py::test_knn_dense_mode*"}
+    psnr = enc.PSNR() if hasattr(enc, "PSNR") else None
+    if psnr:
+        out["quality"] = psnr
+
+    def extra(label, warm=True, **settings):
+        saved = {k: getattr(enc, k) for k in settings}
+        for k, v in settings.items():
+            setattr(enc, k, v)
+        if warm:
+            enc.Run()  # untimed: the first pass of a configuration grows the memory pool (hipMalloc: 40-800 ms, by box)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        enc.Run()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        sm = enc.StageMs()
+        r = {"value": F / dt1, "unit": "frames/s", "ms": dt1 * 1e3, "settings": settings,
+             "stage_ms": {n: round(float(v), 3) for n, v in zip(STAGES, sm)}, "global_tiles": int(enc.counts()["tiles"])}
+        if hasattr(enc, "PSNR"):
+            r["quality"] = enc.PSNR()
+        out[label] = r
+        for k, v in saved.items():
+            setattr(enc, k, v)
+        return r
+
     if world == 1 and args.motion_radius == 0 and not args.no_motion_extra:
-        # second number, outside the timed region: the reference's default path with motion prediction (radius 32)
-        enc.MotionPredictRadius = 32
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        enc.Run()
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        sm = enc.StageMs()
-        pred = 0
-        for f in range(0, F, max(1, F // 10)):
-            pred += int(((enc.TileMap(f)["Flags"] >> 2) & 1).sum())
-        out["with_motion_prediction"] = {"value": F / dt1, "unit": "frames/s", "ms": dt1 * 1e3, "radius": 32,
-                                         "stage_ms": {n: round(float(v), 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], sm)},
-                                         "global_tiles": int(enc.counts()["tiles"]),
-                                         "predicted_fraction_sampled": pred / float(len(range(0, F, max(1, F // 10))) * c["tm_w"] * c["tm_h"])}
-        enc.MotionPredictRadius = 0
+        r = extra("with_motion_prediction", warm=False, MotionPredictRadius=32)
+        r["note"] = "the headline settings plus MotionPredictRadius=32 (PredictMotion + the motion branch of Reconstruct); not part of `value`"
     if world == 1 and args.motion_radius == 0 and not args.no_defaults_extra:
-        # third number, outside the timed region: the reference's own defaults (MotionPredictRadius 32, FrameTilingExtendedPaletteUsage on)
-        enc.MotionPredictRadius = 32
-        enc.FrameTilingExtendedPaletteUsage = True
-        enc.Run()  # untimed: the first pass of this configuration grows the memory pool by ~10 GB (hipMalloc: 40-800 ms, by box)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        enc.Run()
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        sm = enc.StageMs()
-        moved = 0
-        hdr_e, _, _ = enc.Tiles()
-        for f in range(0, F, max(1, F // 10)):
-            tm_e = enc.TileMap(f)
-            ok = tm_e["TileIdx"] >= 0
-            moved += int((tm_e["PalIdx"][ok] != hdr_e["PalIdx_Initial"][tm_e["TileIdx"][ok]]).sum())
-        out["with_reference_defaults"] = {"value": F / dt1, "unit": "frames/s", "ms": dt1 * 1e3,
-                                          "stage_ms": {n: round(float(v), 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], sm)},
-                                          "items_on_another_palette_sampled": moved}
-        enc.MotionPredictRadius = 0
-        enc.FrameTilingExtendedPaletteUsage = False
-    if world == 1 and args.motion_radius == 0 and not args.no_defaults_extra:
-        # SURVEY.md 8d's "second number": the headline configuration with FrameTilingExtendedPaletteUsage on (k = 64 + re-rank), motion prediction excluded
-        enc.FrameTilingExtendedPaletteUsage = True
-        enc.Run()  # untimed warm-up of this configuration (grows the memory pool)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        enc.Run()
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
-        sm = enc.StageMs()
-        out["with_extended_palette_usage"] = {"value": F / dt1, "unit": "frames/s", "ms": dt1 * 1e3,
-                                              "tiles_matched_per_sec": q_total / (float(sm[5]) * 1e-3) if sm[5] > 0 else None,
-                                              "stage_ms": {n: round(float(v), 3) for n, v in zip(["load", "predict_motion", "reduce", "prepare_palettes", "dither", "reconstruct", "reindex", "save"], sm)}}
-        enc.FrameTilingExtendedPaletteUsage = False
+        r = extra("with_extended_palette_usage", FrameTilingExtendedPaletteUsage=True)
+        r["tiles_matched_per_sec"] = q_total / (r["stage_ms"]["reconstruct"] * 1e-3) if r["stage_ms"]["reconstruct"] > 0 else None
+        r["note"] = "SURVEY.md 8d's second number: k = 64 nearest rows + the tile x palette re-rank, motion prediction excluded"
+        r = extra("with_motion_and_extended_palette_usage", MotionPredictRadius=32, FrameTilingExtendedPaletteUsage=True)
+        r["note"] = ("the reference's default code paths (motion prediction radius 32 + extended palette usage) at the benchmark's %d palettes; "
+                     "the reference's default PaletteCount is 1024 (tilingencoder.pas:3826)" % args.palettes)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, int(enc.GlobalTilingTileCount))
-        out["config"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, T, int(ks["db_rows"]))
     if rank == 0:
         print(json.dumps(out), flush=True)
     enc.close()

@@ -89,6 +89,10 @@ TM_API int tm_set_video(tm_encoder *, int width, int height, double fps, int fra
 TM_API int tm_push_frame_rgb32(tm_encoder *, int index, const uint32_t *pixels, int stride_px);
 /* Same, but the frames already sit in device memory as [frame_count][height][width] uint32 (bench path). */
 TM_API int tm_set_frames_device(tm_encoder *, const void *dev_frames);
+/* Same, with the whole clip in HOST memory as [frame_count][height][width] uint32 (the batch form of the frame callback for a
+ * host that holds the decoded clip; borrowed until the next Load has run).  Load then moves it across PCIe in chunks, each
+ * chunk's copy running beside the Load kernel of the chunk before; page-locked memory makes the copies asynchronous. */
+TM_API int tm_set_frames_host(tm_encoder *, const uint32_t *host_frames);
 TM_API int tm_run(tm_encoder *, int step);          /* Run(AStep), :5529-5554; blocking */
 /* read-back views (copy-out) */
 TM_API int tm_get_counts(tm_encoder *, int64_t *tiles, int *frames, int *palettes, int *tm_w, int *tm_h, int *keyframes);

@@ -610,6 +610,103 @@ void tmo_knnk(const int16_t *q, int64_t nq, const int16_t *db, int64_t nt, int k
   }
 }
 
+/* ------------------------------------------------------------------ kd-tree (what the reference searches with)
+ * ann_kdtree_short_create(rows, T, 192, bucket 32, ANN_KD_STD) + ann_kdtree_short_search(eps 0), tilingencoder.pas:4600, 1547.
+ * ANN.dll's source is not in the tree, so this is the published algorithm of Mount & Arya's ANN
+ * ("standard" kd split rule: cut the dimension of maximum spread at the median; standard search with incremental
+ * box-distance updates), not a restatement of a reference file.  With eps = 0 the answer is the exact nearest neighbour, so
+ * it must equal tmo_knn1 (build's tie rule: lowest index).  Used as the CPU baseline the reference actually runs (bench.py). */
+typedef struct { int32_t dim; int32_t cut; int32_t left, right; int64_t lo, hi; } tmo_kdnode;
+struct tmo_kdtree { const int16_t *db; int64_t n; int32_t *perm; tmo_kdnode *nodes; int64_t nnodes, cap; int bucket; };
+
+static int64_t kd_build(tmo_kdtree *t, int64_t lo, int64_t hi) {
+  if (t->nnodes == t->cap) { t->cap = t->cap ? t->cap * 2 : 1024; t->nodes = (tmo_kdnode *)realloc(t->nodes, (size_t)t->cap * sizeof(tmo_kdnode)); }
+  const int64_t me = t->nnodes++;
+  tmo_kdnode nd = {-1, 0, -1, -1, lo, hi};
+  if (hi - lo > t->bucket) {
+    int best_dim = 0, best_spread = -1;
+    for (int d = 0; d < 192; d++) {
+      int mn = 32767, mx = -32768;
+      for (int64_t i = lo; i < hi; i++) { const int v = t->db[(int64_t)t->perm[i] * 192 + d]; if (v < mn) mn = v; if (v > mx) mx = v; }
+      if (mx - mn > best_spread) { best_spread = mx - mn; best_dim = d; }
+    }
+    if (best_spread > 0) {
+      /* median by quickselect on the chosen coordinate (ties between equal coordinates: by index, so the tree is deterministic) */
+      const int64_t mid = lo + (hi - lo) / 2;
+      int64_t a = lo, b = hi - 1;
+      while (a < b) {
+        const int32_t pv = t->perm[a + (b - a) / 2];
+        const int pk = t->db[(int64_t)pv * 192 + best_dim];
+        int64_t i = a, j = b;
+        while (i <= j) {
+          for (;;) { const int32_t x = t->perm[i]; const int xk = t->db[(int64_t)x * 192 + best_dim]; if (xk < pk || (xk == pk && x < pv)) i++; else break; }
+          for (;;) { const int32_t x = t->perm[j]; const int xk = t->db[(int64_t)x * 192 + best_dim]; if (xk > pk || (xk == pk && x > pv)) j--; else break; }
+          if (i <= j) { const int32_t tmp = t->perm[i]; t->perm[i] = t->perm[j]; t->perm[j] = tmp; i++; j--; }
+        }
+        if (mid <= j) b = j; else if (mid >= i) a = i; else break;
+      }
+      nd.dim = best_dim;
+      nd.cut = t->db[(int64_t)t->perm[mid] * 192 + best_dim];
+      t->nodes[me] = nd;
+      const int64_t l = kd_build(t, lo, mid), r = kd_build(t, mid, hi);
+      t->nodes[me].left = (int32_t)l;
+      t->nodes[me].right = (int32_t)r;
+      return me;
+    }
+  }
+  t->nodes[me] = nd;
+  return me;
+}
+
+tmo_kdtree *tmo_kdtree_build(const int16_t *db, int64_t n, int bucket) {
+  tmo_kdtree *t = (tmo_kdtree *)calloc(1, sizeof(tmo_kdtree));
+  t->db = db; t->n = n; t->bucket = bucket > 0 ? bucket : 32;
+  t->perm = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  for (int64_t i = 0; i < n; i++) t->perm[i] = (int32_t)i;
+  if (n > 0) kd_build(t, 0, n);
+  return t;
+}
+void tmo_kdtree_free(tmo_kdtree *t) { if (t) { free(t->perm); free(t->nodes); free(t); } }
+
+typedef struct { const tmo_kdtree *t; const int16_t *q; int64_t off[192]; uint32_t best; int32_t bi; int64_t visited; } kd_search;
+
+static void kd_visit(kd_search *s, int64_t node, int64_t rd /* squared distance from q to the node's box */) {
+  const tmo_kdnode *nd = &s->t->nodes[node];
+  if (nd->dim < 0) {
+    for (int64_t i = nd->lo; i < nd->hi; i++) {
+      const int32_t r = s->t->perm[i];
+      const uint32_t d = tmo_ssd_i16(s->q, s->t->db + (int64_t)r * 192);
+      s->visited++;
+      if (s->bi < 0 || d < s->best || (d == s->best && r < s->bi)) { s->best = d; s->bi = r; }
+    }
+    return;
+  }
+  const int64_t diff = (int64_t)s->q[nd->dim] - nd->cut;  /* left holds coordinates <= cut (by index among equals), right >= cut */
+  const int64_t near = diff < 0 ? nd->left : nd->right, far = diff < 0 ? nd->right : nd->left;
+  kd_visit(s, near, rd);
+  const int64_t old = s->off[nd->dim];
+  const int64_t nrd = rd - old * old + diff * diff;  /* incremental box distance (Arya & Mount) */
+  if (s->bi < 0 || nrd <= (int64_t)s->best) {        /* <=: an equally near row with a lower index may sit on the far side */
+    s->off[nd->dim] = diff;
+    kd_visit(s, far, nrd);
+    s->off[nd->dim] = old;
+  }
+}
+
+int64_t tmo_kdtree_search1(const tmo_kdtree *t, const int16_t *q, int64_t nq, int32_t *idx, uint32_t *err) {
+  int64_t visited = 0;
+  for (int64_t i = 0; i < nq; i++) {
+    kd_search s;
+    memset(&s, 0, sizeof(s));
+    s.t = t; s.q = q + i * 192; s.bi = -1; s.best = UINT32_MAX;
+    if (t->n > 0) kd_visit(&s, 0, 0);
+    idx[i] = s.bi;
+    err[i] = s.best;
+    visited += s.visited;
+  }
+  return visited;  /* rows whose distance was computed: how far the tree is from a brute force */
+}
+
 /* ------------------------------------------------------------------ QuickSort (extern.pas:370-418) */
 
 void tmo_quicksort(void *data, int64_t first, int64_t last, int isz, tmo_cmp_fn cmp, void *user) {

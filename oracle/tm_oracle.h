@@ -88,6 +88,11 @@ float tmo_euclidean_to_psnr(uint32_t e);                                  /* uti
 /* ---- A13/A14 KNN (exact brute force, lowest index wins ties) ---- */
 void tmo_knn1(const int16_t *queries, int64_t nq, const int16_t *db, int64_t nt, int32_t *idx, uint32_t *err);
 /* k smallest by (err asc, idx asc) */
+/* exact kd-tree (ANN's published standard split + standard search, eps 0): what the reference's CPU path searches with */
+typedef struct tmo_kdtree tmo_kdtree;
+tmo_kdtree *tmo_kdtree_build(const int16_t *db, int64_t n, int bucket);
+void tmo_kdtree_free(tmo_kdtree *t);
+int64_t tmo_kdtree_search1(const tmo_kdtree *t, const int16_t *queries, int64_t nq, int32_t *idx, uint32_t *err);
 void tmo_knnk(const int16_t *queries, int64_t nq, const int16_t *db, int64_t nt, int k, int32_t *idx, uint32_t *err);
 
 /* ---- generic QuickSort, extern.pas:370-418 ---- */

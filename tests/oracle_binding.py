@@ -141,6 +141,24 @@ class Oracle:
         self.L.tmo_knn1(_p(q), q.shape[0], _p(db), db.shape[0], _p(idx), _p(err))
         return idx, err
 
+    def kdtree_build(self, db, bucket=32):
+        """exact kd-tree over db (kept alive by the returned handle's reference to the array)"""
+        db = np.ascontiguousarray(db, np.int16)
+        self.L.tmo_kdtree_build.restype = ctypes.c_void_p
+        h = self.L.tmo_kdtree_build(_p(db), ctypes.c_int64(db.shape[0]), ctypes.c_int(bucket))
+        return (ctypes.c_void_p(h), db)
+
+    def kdtree_search1(self, tree, q):
+        q = np.ascontiguousarray(q, np.int16)
+        idx = np.zeros(q.shape[0], np.int32)
+        err = np.zeros(q.shape[0], np.uint32)
+        self.L.tmo_kdtree_search1.restype = ctypes.c_int64
+        visited = self.L.tmo_kdtree_search1(tree[0], _p(q), ctypes.c_int64(q.shape[0]), _p(idx), _p(err))
+        return idx, err, visited
+
+    def kdtree_free(self, tree):
+        self.L.tmo_kdtree_free(tree[0])
+
     def knnk(self, q, db, k):
         q = np.ascontiguousarray(q, np.int16)
         db = np.ascontiguousarray(db, np.int16)

@@ -129,3 +129,24 @@ def test_equal_quality_tile_count(oracle):
     assert 7 * f(4320000.0) == 320705  # 720p x 300
     assert 7 * f(32400000.0) == 994105  # 1080p x 1000
     assert min(7 * f(640.0), 640) == 640  # 64x64 x 10
+
+
+def test_kdtree_equals_brute_force(oracle):
+    """the baseline's kd-tree (ANN's published standard split and search, eps 0, bucket 32) returns what the brute force returns,
+    lowest index among equal distances included"""
+    rng = np.random.default_rng(7)
+    db = rng.integers(-300, 301, size=(3000, 192)).astype(np.int16)
+    db[:, 0] = rng.integers(0, 13000, size=3000)
+    db[1500] = db[7]
+    db[2999] = db[7]
+    q = rng.integers(-300, 301, size=(200, 192)).astype(np.int16)
+    q[:, 0] = rng.integers(0, 13000, size=200)
+    q[0] = db[7]
+    q[1] = db[2999]
+    tree = oracle.kdtree_build(db, 32)
+    idx, err, visited = oracle.kdtree_search1(tree, q)
+    oracle.kdtree_free(tree)
+    eidx, eerr = oracle.knn1(q, db)
+    assert np.array_equal(idx, eidx) and np.array_equal(err, eerr)
+    assert idx[0] == 7 and idx[1] == 7 and err[0] == 0
+    assert 0 < visited <= q.shape[0] * db.shape[0]

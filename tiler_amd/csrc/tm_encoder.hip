@@ -92,6 +92,9 @@ struct tm_encoder {
   // device state
   DevBuf frames_owned;
   const void *frames = nullptr;  // [nframes][height][width] RGB32
+  const void *frames_host = nullptr;  // the same in HOST memory (tm_set_frames_host): Load copies it over in chunks beside its own kernel
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> copy_events;
   DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
   DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
   DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, error behind PSNR (KNN or motion)
@@ -127,6 +130,8 @@ struct tm_encoder {
     drop_prefetch();
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
+    for (hipEvent_t ev : copy_events) (void)hipEventDestroy(ev);
+    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
   }
   double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
   int64_t knn_pairs = 0;
@@ -225,12 +230,37 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
   e->drop_prefetch();  // features of the previous frame tiles
   TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
-  TM_CHECK(e->frames != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device first");
+  TM_CHECK(e->frames != nullptr || e->frames_host != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device / tm_set_frames_host first");
   e->q = (int64_t)e->nframes * e->tm_size();
   TM_CHECK(e->q < (1ll << 31), TM_E_UNSUPPORTED, "%lld tile-map items: the index arrays are 32-bit (TileIdx is an Integer, tilingencoder.pas:179)", (long long)e->q);
   TM_TRY(e->ftiles.alloc((size_t)e->q * 256));
   TM_TRY(e->fflags.alloc((size_t)e->q));
   TM_TRY(e->flab.alloc((size_t)e->q * 12));
+  if (e->frames_host) {
+    // The clip sits in host memory: chunks of frames cross PCIe on a copy stream while the Load kernel works on the chunk before
+    // (pinned memory makes the copies asynchronous; pageable memory still works, serialised by the runtime).
+    const size_t fbytes = (size_t)e->width * e->height * 4;
+    const int64_t per = e->tm_size();
+    TM_TRY(e->frames_owned.alloc(fbytes * e->nframes));
+    e->frames = e->frames_owned.p;
+    if (!e->copy_stream) TM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    const int chunk = (int)std::max<size_t>(1, ((size_t)48 << 20) / fbytes);
+    const int nchunks = (e->nframes + chunk - 1) / chunk;
+    while ((int)e->copy_events.size() < nchunks) {
+      hipEvent_t ev;
+      TM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->copy_events.push_back(ev);
+    }
+    TM_HIP(hipStreamSynchronize(e->stream));  // the destination may have been handed out by the pool a moment ago
+    for (int c = 0; c < nchunks; c++) {
+      const int f0 = c * chunk, nf = std::min(chunk, e->nframes - f0);
+      TM_HIP(hipMemcpyAsync(e->frames_owned.as<uint8_t>() + fbytes * f0, (const uint8_t *)e->frames_host + fbytes * f0, fbytes * nf, hipMemcpyHostToDevice, e->copy_stream));
+      TM_HIP(hipEventRecord(e->copy_events[c], e->copy_stream));
+      TM_HIP(hipStreamWaitEvent(e->stream, e->copy_events[c], 0));
+      TM_TRY(launch_load(e->frames_owned.as<uint8_t>() + fbytes * f0, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + (int64_t)f0 * per * 256,
+                         e->fflags.as<uint8_t>() + (int64_t)f0 * per, e->flab.as<uint8_t>() + (int64_t)f0 * per * 12, e->stream));
+    }
+  } else
   TM_TRY(launch_load(e->frames, e->nframes, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.p, e->fflags.p, e->flab.p, e->stream));
   progress(e, TM_STEP_LOAD, 1, 3);
   // inter-frame correlation: one GPU thread per frame runs the reference's sequential Single sums (order matters)
@@ -449,21 +479,35 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(need(e, TM_STEP_REDUCE, "Reduce"));
   TM_TRY(need_global_rgb(e, "PreparePalettes"));
   TM_CHECK(e->t > 0, TM_E_INVAL, "no global tiles");
+  const bool dbg = getenv("TM_PP_DEBUG") != nullptr;  // wall time of the sub-steps (adds stream synchronisations)
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg) return;
+    (void)hipStreamSynchronize(e->stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tm_pp] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   DevBuf feat;
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
   TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
+  lap("cluster features");
   TM_TRY(e->gpal_idx.alloc((size_t)e->t * 4));
   TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
+  lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
   TM_TRY(e->palettes_dev.alloc((size_t)e->s.PaletteCount * e->s.PaletteSize * 4));
   TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream));
+  lap("palette colours (3-D)");
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
   TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
   TM_TRY(prefetch_query_features(e));  // the GPU has nothing to do while the host searches: Reconstruct's query features run now
+  lap("prefetch launch");
   // OptimizePalettes (4309-4432): slot permutation by Powell on the host (P x PaletteSize colours)
   TM_TRY(optimize_palettes_host(e->palettes_host, e->s.PaletteCount, e->s.PaletteSize, nullptr));
+  lap("OptimizePalettes (host)");
   TM_HIP(hipMemcpyAsync(e->palettes_dev.p, e->palettes_host.data(), e->palettes_host.size() * 4, hipMemcpyHostToDevice, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 3, 3);
@@ -818,6 +862,7 @@ int tm_set_video(tm_encoder *e, int width, int height, double fps, int frame_cou
   e->tm_w = (width - 1) / 8 + 1;   // ReframeUI((DstWidth - 1) div cTileWidth + 1, ...), tilingencoder.pas:1776
   e->tm_h = (height - 1) / 8 + 1;
   e->frames = nullptr;
+  e->frames_host = nullptr;
   e->frames_owned.release();
   e->steps_done = 0;
   if (e->auto_tile_count) recompute_auto_tile_count(e);
@@ -830,6 +875,7 @@ int tm_push_frame_rgb32(tm_encoder *e, int index, const uint32_t *pixels, int st
   TM_CHECK(index >= 0 && index < e->nframes && stride_px >= e->width, TM_E_INVAL, "bad frame index/stride");
   TM_HIP(hipSetDevice(e->device));
   const size_t fbytes = (size_t)e->width * e->height * 4;
+  e->frames_host = nullptr;
   if (!e->frames_owned.p || e->frames != e->frames_owned.p) {
     TM_TRY(e->frames_owned.alloc(fbytes * e->nframes));
     TM_HIP(hipMemsetAsync(e->frames_owned.p, 0, fbytes * e->nframes, e->stream));
@@ -846,6 +892,15 @@ int tm_set_frames_device(tm_encoder *e, const void *dev_frames) {
   TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
   e->frames_owned.release();
   e->frames = dev_frames;
+  e->frames_host = nullptr;
+  return TM_OK;
+}
+
+int tm_set_frames_host(tm_encoder *e, const uint32_t *host_frames) {
+  TM_CHECK(e && host_frames, TM_E_INVAL, "null argument");
+  TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
+  e->frames_host = host_frames;
+  e->frames = nullptr;
   return TM_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <rocprim/device/device_run_length_encode.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <climits>
 #include <vector>
@@ -569,6 +570,314 @@ static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream,
   }
 }
 
+// ---- D = 3, one launch for the whole clustering -----------------------------------------------------------------
+// The pixel k-means of QuantizeUsingYakmo (tilingencoder.pas:4434-4532) runs ~180 Lloyd iterations over a few hundred thousand
+// distinct colours per palette: a few microseconds of arithmetic per iteration, so as separate launches (two per iteration, two per
+// farthest-first pick) it was bound by launch latency alone.  Here every workgroup keeps its 4096 points in REGISTERS for the whole
+// clustering (packed colour, weight, assignment), the workgroups of one segment (= one palette) meet at a barrier of their own once
+// per iteration (a counter in global memory: agent-scope release / acquire around a relaxed poll), and the segments run their own
+// number of iterations side by side.  Everything that crosses workgroups is an integer atomic -- the carried sums and counts
+// (exact, order-free), the farthest-first pick (64-bit max of distance << 32 | ~index: largest distance, then lowest index), the
+// changed-points counter -- so the result is the one the multi-launch path and the oracle give, bit for bit.
+constexpr int P3_G = 4;  // points scored together against each centroid (registers: 8 spill)
+constexpr int P3_PPT = 16, P3_NT = 256, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 8;
+
+struct Seg3 {
+  int64_t begin, count;
+  int blk_first, blk_count;
+  int kk, iters;        // out
+  int nseg;             // element 0 only
+  int pad;
+};
+struct Seg3State {      // zeroed before the launch
+  u64 sums[P3_MAXK][3];
+  u64 cnts[P3_MAXK];
+  u64 pick[P3_MAXK];
+  unsigned bar, changed[3], timeout, pad[3];
+};
+
+__device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsigned nblk, unsigned *timeout) {
+  // every thread of the workgroup calls it; false: the spin gave up (a workgroup of the segment is not resident), the caller leaves
+  __shared__ int s_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    epoch++;
+    const unsigned target = epoch * nblk;
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+      __builtin_amdgcn_s_sleep(4);
+      if (spins > (1u << 24) || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+__global__ __launch_bounds__(P3_NT, 4) void k_kmeans3_persistent(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg3 *__restrict__ segs,
+                                                             Seg3State *__restrict__ state, int k, int max_iter, int32_t *__restrict__ assign,
+                                                             double *__restrict__ cent) {
+  // the workgroup's points stay on chip for the whole clustering: packed colour and assignment in LDS (slot m * NT + tid: no bank
+  // conflicts), so the loops over a thread's points stay rolled and the register file holds only the P3_G points in flight
+  __shared__ double s_cent[P3_MAXK][3];
+  __shared__ double s_thr[P3_MAXK];    // (1 - 1e-9) x a quarter of the squared distance to the nearest other centroid
+  __shared__ uint32_t s_col[P3_ROWS];   // 0xffffffff: slot past the end of the segment
+  __shared__ uint8_t s_asg[P3_ROWS];    // 0xff: none yet
+  __shared__ union { int md[P3_ROWS]; u64 acc[P3_NCOPY][P3_MAXK][4]; } s_u;  // farthest-first distances, then the sums' deltas
+  __shared__ u64 s_red[P3_NT / 64];
+  __shared__ int s_chg;
+  static_assert(sizeof(s_u.md) == sizeof(s_u.acc), "union halves");
+  const int tid = threadIdx.x;
+  int seg;
+  {
+    int lo = 0, hi = segs[0].nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (segs[mid].blk_first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    seg = lo;
+  }
+  const Seg3 sg = segs[seg];
+  const int bx = (int)blockIdx.x - sg.blk_first;
+  const unsigned nbx = (unsigned)sg.blk_count;
+  Seg3State *st = state + seg;
+  unsigned epoch = 0;
+  const int64_t base = (int64_t)bx * P3_ROWS;
+  for (int r = tid; r < P3_ROWS; r += P3_NT) {
+    uint32_t cc = 0xffffffffu;
+    if (base + r < sg.count) {
+      const int32_t *p = pts + (sg.begin + base + r) * 3;
+      cc = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    }
+    s_col[r] = cc;
+    s_asg[r] = 0xff;
+    s_u.md[r] = INT_MAX;
+  }
+  // ---- farthest-first from the segment's first point
+  int kk = 1;
+  int cr, cg, cb;
+  {
+    const int32_t *p0 = pts + sg.begin * 3;
+    cr = p0[0]; cg = p0[1]; cb = p0[2];
+  }
+  if (tid < 3) s_cent[0][tid] = (double)(tid == 0 ? cr : tid == 1 ? cg : cb);
+  for (int c = 1; c < k; c++) {
+    u64 best = 0;
+    for (int r = tid; r < P3_ROWS; r += P3_NT) {  // (each thread only ever touches its own slots: no barrier needed for s_col / md)
+      const uint32_t cc = s_col[r];
+      if (cc == 0xffffffffu) continue;
+      const int dr = (int)(cc & 0xff) - cr, dg = (int)((cc >> 8) & 0xff) - cg, db = (int)((cc >> 16) & 0xff) - cb;
+      const int m = min(s_u.md[r], dr * dr + dg * dg + db * db);
+      s_u.md[r] = m;
+      const u64 key = ((u64)(uint32_t)m << 32) | (u64)(0xffffffffu - (uint32_t)(base + r));
+      best = key > best ? key : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const u64 other = __shfl_xor(best, o); best = other > best ? other : best; }
+    if ((tid & 63) == 0) s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      for (int wv = 1; wv < P3_NT / 64; wv++) best = s_red[wv] > best ? s_red[wv] : best;
+      if (best >> 32) atomicMax(&st->pick[c], best);
+    }
+    if (!p3_barrier(&st->bar, epoch, nbx, &st->timeout)) return;
+    const u64 win = __hip_atomic_load(&st->pick[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((win >> 32) == 0) break;  // no distinct point left
+    const int32_t *pc = pts + (sg.begin + (int64_t)(0xffffffffu - (uint32_t)win)) * 3;
+    cr = pc[0]; cg = pc[1]; cb = pc[2];
+    if (tid < 3) s_cent[kk][tid] = (double)(tid == 0 ? cr : tid == 1 ? cg : cb);
+    kk++;
+  }
+  // ---- Lloyd
+  int it = 0;
+  for (;;) {
+    __syncthreads();  // s_cent of this iteration is in place; the init (or the previous flush) is done with the union
+    for (int e = tid; e < P3_NCOPY * P3_MAXK * 4; e += P3_NT) (&s_u.acc[0][0][0])[e] = 0;
+    if (tid == 0) s_chg = 0;
+    __syncthreads();
+    // A point whose squared distance to its own centroid a is below a quarter of the squared distance from a to the nearest other
+    // centroid cannot be nearer to any other one (triangle inequality; the 1e-9 margin dwarfs the rounding of both sides, so the
+    // order of the COMPUTED distances is the same and strict): it keeps its assignment without being scored against the rest.
+    // Colours are sorted, so the 64 consecutive points of a wave's pass are neighbours in colour space and mostly agree; a pass is
+    // skipped only when all its points can be, and the others are scored in full as before -- the result is unchanged.
+    if (tid < kk) {
+      double best = 1.0e300;
+      for (int c = 0; c < kk; c++) {
+        if (c == tid) continue;
+        const double t0 = s_cent[tid][0] - s_cent[c][0], t1 = s_cent[tid][1] - s_cent[c][1], t2 = s_cent[tid][2] - s_cent[c][2];
+        best = fmin(best, t0 * t0 + t1 * t1 + t2 * t2);
+      }
+      s_thr[tid] = kk > 1 ? best * 0.25 * (1.0 - 1.0e-9) : 1.0e300;
+    }
+    __syncthreads();
+    unsigned need = 0;  // bit m: some point of this wave's pass m has to be scored against every centroid (uniform in the wave)
+#pragma unroll 1
+    for (int m = 0; m < P3_PPT; m++) {
+      const int r = m * P3_NT + tid;
+      const uint32_t cc = s_col[r];
+      const int a = s_asg[r];
+      bool full = cc != 0xffffffffu;
+      if (full && a != 0xff) {
+        const double t0 = __dsub_rn((double)(int)(cc & 0xff), s_cent[a][0]), t1 = __dsub_rn((double)(int)((cc >> 8) & 0xff), s_cent[a][1]),
+                     t2 = __dsub_rn((double)(int)((cc >> 16) & 0xff), s_cent[a][2]);
+        full = !(__fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0))) < s_thr[a]);
+      }
+      if (__builtin_amdgcn_ballot_w64(full)) need |= 1u << m;
+    }
+    int changed = 0;
+    // P3_G points at a time against one centroid after the other: a centroid read from LDS (a broadcast) serves P3_G points.
+    // Per (point, centroid): sum over dimensions in order of (p - c)^2, one IEEE subtraction and one fused multiply-add each;
+    // ties -> lowest centroid.
+    while (need) {
+      int mi[P3_G];
+#pragma unroll
+      for (int g = 0; g < P3_G; g++) {  // the next P3_G passes that need scoring (a short last group repeats its last pass: harmless)
+        mi[g] = need ? __builtin_ctz(need) : (g ? mi[g - 1] : 0);
+        need &= need - 1;
+      }
+      double px[P3_G][3], bd[P3_G];
+      int bc[P3_G];
+      uint32_t cc[P3_G];
+#pragma unroll
+      for (int m = 0; m < P3_G; m++) {
+        cc[m] = s_col[mi[m] * P3_NT + tid];
+        px[m][0] = (double)(int)(cc[m] & 0xff); px[m][1] = (double)(int)((cc[m] >> 8) & 0xff); px[m][2] = (double)(int)((cc[m] >> 16) & 0xff);
+        bd[m] = 0.0;
+        bc[m] = -1;
+      }
+#pragma unroll 1
+      for (int c = 0; c < kk; c++) {
+        const double c0 = s_cent[c][0], c1 = s_cent[c][1], c2 = s_cent[c][2];
+#pragma unroll
+        for (int m = 0; m < P3_G; m++) {
+          const double t0 = __dsub_rn(px[m][0], c0), t1 = __dsub_rn(px[m][1], c1), t2 = __dsub_rn(px[m][2], c2);
+          const double sd = __fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0)));
+          if (bc[m] < 0 || sd < bd[m]) { bd[m] = sd; bc[m] = c; }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < P3_G; m++) {
+        const int r = mi[m] * P3_NT + tid;
+        if (cc[m] == 0xffffffffu || (m > 0 && mi[m] == mi[m - 1])) continue;
+        const int old = s_asg[r];
+        if (old == bc[m]) continue;
+        // only a point that changes cluster touches the carried sums
+        const long long wi = w ? (long long)w[sg.begin + base + r] : 1;
+        const int pi[3] = {(int)(cc[m] & 0xff), (int)((cc[m] >> 8) & 0xff), (int)((cc[m] >> 16) & 0xff)};
+        u64 *acc = &s_u.acc[tid & (P3_NCOPY - 1)][bc[m]][0];
+        atomicAdd(&acc[3], (u64)wi);
+#pragma unroll
+        for (int j = 0; j < 3; j++) atomicAdd(&acc[j], (u64)(wi * pi[j]));
+        if (old != 0xff) {
+          u64 *oacc = &s_u.acc[tid & (P3_NCOPY - 1)][old][0];
+          atomicAdd(&oacc[3], (u64)0 - (u64)wi);
+#pragma unroll
+          for (int j = 0; j < 3; j++) atomicAdd(&oacc[j], (u64)0 - (u64)(wi * pi[j]));
+        }
+        s_asg[r] = (uint8_t)bc[m];
+        changed++;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
+    if ((tid & 63) == 0 && changed) atomicAdd(&s_chg, changed);
+    __syncthreads();
+    for (int e = tid; e < kk * 4; e += P3_NT) {
+      u64 v = 0;
+#pragma unroll
+      for (int cp = 0; cp < P3_NCOPY; cp++) v += s_u.acc[cp][e >> 2][e & 3];
+      if (v == 0) continue;
+      if ((e & 3) == 3) atomicAdd(&st->cnts[e >> 2], v); else atomicAdd(&st->sums[e >> 2][e & 3], v);
+    }
+    if (tid == 0 && s_chg) atomicAdd(&st->changed[it % 3], (unsigned)s_chg);
+    if (!p3_barrier(&st->bar, epoch, nbx, &st->timeout)) return;
+    const unsigned tot = __hip_atomic_load(&st->changed[it % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bx == 0 && tid == 0) __hip_atomic_store(&st->changed[(it + 2) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // last read two barriers ago
+    if (tot == 0) break;
+    // new centroids: exact integer sum / weight, one IEEE division; an empty cluster keeps its centroid
+    if (tid < kk * 3) {
+      const int c = tid / 3, j = tid - c * 3;
+      const u64 cn = __hip_atomic_load(&st->cnts[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cn > 0) s_cent[c][j] = __ddiv_rn((double)(long long)__hip_atomic_load(&st->sums[c][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (double)(long long)cn);
+    }
+    it++;
+    if (it >= max_iter) break;
+  }
+  __syncthreads();
+  for (int r = tid; r < P3_ROWS; r += P3_NT)
+    if (base + r < sg.count) assign[sg.begin + base + r] = (int32_t)s_asg[r];
+  if (bx == 0) {
+    for (int e = tid; e < kk * 3; e += P3_NT) cent[((int64_t)seg * k + e / 3) * 3 + e % 3] = s_cent[e / 3][e % 3];
+    if (tid == 0) { segs[seg].kk = kk; segs[seg].iters = it; }
+  }
+}
+
+// host side of the above; *used = 0 when the shape does not fit one resident launch (the caller then takes the multi-launch path)
+static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::vector<int64_t> &seg_begin, const std::vector<int64_t> &seg_count, int k,
+                              int max_iter, int32_t *assign, double *cent, std::vector<int> *host_kk, int *host_iters, hipStream_t stream, int *used) {
+  *used = 0;
+  const int nseg = (int)seg_begin.size();
+  if (k > P3_MAXK || getenv("TM_KM_LEGACY")) return TM_OK;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  std::vector<Seg3> hs;  // empty segments take no workgroup and are answered on the host
+  std::vector<int> which;
+  int nblk = 0;
+  for (int s = 0; s < nseg; s++) {
+    if (seg_count[s] <= 0) continue;
+    Seg3 g;
+    memset(&g, 0, sizeof(g));
+    g.begin = seg_begin[s]; g.count = seg_count[s];
+    g.blk_first = nblk;
+    g.blk_count = (int)((seg_count[s] + P3_ROWS - 1) / P3_ROWS);
+    nblk += g.blk_count;
+    hs.push_back(g);
+    which.push_back(s);
+  }
+  if (nblk > 3 * cus) return TM_OK;  // all workgroups must be resident together (four fit a CU; three are asked for)
+  if (host_kk) host_kk->assign(nseg, 0);
+  if (host_iters) *host_iters = 0;
+  *used = 1;
+  if (hs.empty()) return TM_OK;
+  hs[0].nseg = (int)hs.size();
+  DevBuf dsegs, dstate, dcent;
+  TM_TRY(dsegs.alloc(sizeof(Seg3) * hs.size()));
+  TM_TRY(dstate.alloc(sizeof(Seg3State) * hs.size()));
+  TM_TRY(dcent.alloc(sizeof(double) * hs.size() * k * 3));
+  TM_HIP(hipMemcpyAsync(dsegs.p, hs.data(), sizeof(Seg3) * hs.size(), hipMemcpyHostToDevice, stream));
+  TM_HIP(hipMemsetAsync(dstate.p, 0, sizeof(Seg3State) * hs.size(), stream));
+  TM_HIP(hipMemsetAsync(dcent.p, 0, sizeof(double) * hs.size() * k * 3, stream));
+  hipLaunchKernelGGL(k_kmeans3_persistent, dim3(nblk), dim3(P3_NT), 0, stream, pts, w, dsegs.as<Seg3>(), dstate.as<Seg3State>(), k, max_iter, assign,
+                     dcent.as<double>());
+  TM_HIP(hipGetLastError());
+  std::vector<Seg3State> hstate(hs.size());
+  std::vector<double> hcent(hs.size() * (size_t)k * 3);
+  TM_HIP(hipMemcpyAsync(hs.data(), dsegs.p, sizeof(Seg3) * hs.size(), hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(hstate.data(), dstate.p, sizeof(Seg3State) * hs.size(), hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(hcent.data(), dcent.p, hcent.size() * 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  int iters = 0;
+  for (size_t i = 0; i < hs.size(); i++) {
+    TM_CHECK(hstate[i].timeout == 0, TM_E_HIP, "k-means: the workgroups of a segment did not all become resident (barrier gave up)");
+    if (host_kk) (*host_kk)[which[i]] = hs[i].kk;
+    iters = std::max(iters, hs[i].iters);
+  }
+  if (host_iters) *host_iters = iters;
+  // centroids back in the caller's [nseg][k][3] layout (device)
+  std::vector<double> full((size_t)nseg * k * 3, 0.0);
+  for (size_t i = 0; i < hs.size(); i++) memcpy(&full[(size_t)which[i] * k * 3], &hcent[i * (size_t)k * 3], sizeof(double) * k * 3);
+  TM_HIP(hipMemcpyAsync(cent, full.data(), full.size() * 8, hipMemcpyHostToDevice, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  return TM_OK;
+}
+
 // ---- driver ----------------------------------------------------------------------------------------------------
 // Batched k-means over nseg contiguous segments.  seg_begin/seg_count are host arrays.  Outputs assign (global point
 // order), cent [nseg][k][d], host_kk[nseg] live centroid counts.
@@ -580,6 +889,11 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   const int nseg = (int)seg_begin.size();
   if (host_iters) *host_iters = 0;
   if (nseg == 0) return TM_OK;
+  if (d == 3) {  // the whole clustering in one launch when its workgroups fit the chip together
+    int used = 0;
+    TM_TRY(kmeans3_persistent(pts, w, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, &used));
+    if (used) return TM_OK;
+  }
   int64_t n = 0, maxcount = 0;
   for (int s = 0; s < nseg; s++) { n = std::max(n, seg_begin[s] + seg_count[s]); maxcount = std::max(maxcount, seg_count[s]); }
   std::vector<Seg> hs(nseg);
@@ -843,8 +1157,15 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
                        ukeys.as<u64>(), (int64_t)nu, pts.as<int32_t>());
     std::vector<int> kk;
     int iters = 0;
+    const bool dbg = getenv("TM_PP_DEBUG") != nullptr;
+    const auto t_km = std::chrono::steady_clock::now();
+    if (dbg) (void)hipStreamSynchronize(stream);
+    const auto t_km0 = std::chrono::steady_clock::now();
     TM_TRY(kmeans_batched(pts.as<int32_t>(), ucnt.as<uint32_t>(), 3, sb, sc, pal_size, max_iter, assign.as<int32_t>(), cent.as<double>(),
                           &kk, &iters, stream));
+    if (dbg) fprintf(stderr, "[tm_pp]   colour keys + sort + runs %7.3f ms, k-means of %u colours %7.3f ms (%d iterations)\n",
+                     std::chrono::duration<double, std::milli>(t_km0 - t_km).count() , nu,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_km0).count(), iters);
     std::vector<double> hc((size_t)npal * pal_size * 3);
     TM_HIP(hipMemcpyAsync(hc.data(), cent.p, hc.size() * 8, hipMemcpyDeviceToHost, stream));
     TM_HIP(hipStreamSynchronize(stream));

@@ -5,8 +5,12 @@
 // libm sqrt and the same evaluation order as the reference, including powell.pas's dynamic-array aliasing of the
 // direction set (direc[n-1] := direc1 shares storage in FreePascal).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "tm_common.h"
@@ -157,6 +161,75 @@ template <class FnN> double powell_minimize(const FnN &f, std::vector<double> &x
   return fval;
 }
 
+// Helper threads that outlive the call: the palettes of one sweep are independent tasks (DoPal runs under
+// ProcThreadPool.DoParallelLocalProc in the reference, tilingencoder.pas:4415), but threads made per call lose to their own creation
+// cost inside a process that already runs other runtimes' threads -- so they are made once, sleep on a condition variable between
+// sweeps and are joined when the library goes away.
+class HelperPool {
+ public:
+  static HelperPool &get() { static HelperPool p; return p; }
+  template <class F> void run(int ntasks, const F &f) {  // f(task) for task in [0, ntasks); the caller works too
+    if (ntasks <= 1 || workers_.empty()) { for (int t = 0; t < ntasks; t++) f(t); return; }
+    std::lock_guard<std::mutex> one_job(run_m_);  // encoders on other threads take their turn
+    std::function<void(int)> job = f;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job; next_ = 0; total_ = ntasks; pending_ = ntasks; ++generation_;
+    }
+    cv_work_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr; total_ = 0;
+  }
+
+ private:
+  HelperPool() {
+    const char *env = getenv("TM_HOST_THREADS");
+    int n = env ? atoi(env) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    for (int i = 0; i < n - 1; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~HelperPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_work_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void drain() {  // tasks are claimed under the lock (they run for tens of microseconds: the lock is noise)
+    for (;;) {
+      int t;
+      const std::function<void(int)> *j;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (next_ >= total_) return;
+        t = next_++;
+        j = job_;
+      }
+      (*j)(t);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+  }
+  void loop() {
+    unsigned seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+      }
+      drain();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, run_m_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)> *job_ = nullptr;
+  int next_ = 0, total_ = 0, pending_ = 0;
+  unsigned generation_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_size, int *sweeps_out) {
@@ -172,7 +245,8 @@ int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_si
   do {
     prev = std::max(fsum, prev);
     ++sweeps;
-    for (int a = 0; a < pal_count; a++) {  // DoPal (4315-4375): every palette against the others as they stood before the sweep
+    // DoPal (4315-4375): every palette against the others as they stood before the sweep -- independent tasks (4415)
+    HelperPool::get().run(pal_count, [&](int a) {
       uint64_t acc[3][64] = {};
       for (int p = 0; p < pal_count; p++)
         if (p != a)
@@ -204,7 +278,7 @@ int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_si
       for (int i = 1; i < pal_size; i++) x[i - 1] = i;
       powell_minimize(objective, x, 1.0, 1.0, 1.0, 2147483647);
       fbest[a] = -objective(x);
-    }
+    });
     fsum = 0;
     for (double v : fbest) fsum += v;
     pals = newpal;

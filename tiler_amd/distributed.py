@@ -34,6 +34,14 @@ def keyframe_shard(keyframes, nframes, rank, world):
     return cuts[rank], cuts[rank + 1] - cuts[rank]
 
 
+def describe(world):
+    """what bench.py prints as config.parallelism"""
+    if world <= 1:
+        return "1 GPU"
+    return ("%d ranks, one per GPU: PredictMotion / Dither / Reconstruct sharded (frames, global tiles, frames); merges by all-reduce over RCCL; "
+            "Load, Reduce, PreparePalettes and the database side of Reconstruct replicated") % world
+
+
 def run_all(enc, nframes, rank=0, world=1, group=None):
     """Run(esAll) over `world` processes.  `enc` needs Run/SetQueryShard/DeviceArray/SyncTileMap/KeyFrames and the
     MotionPredictRadius setting (TilingEncoder or a stand-in)."""

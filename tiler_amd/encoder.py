@@ -54,6 +54,7 @@ _ENC_SIGS = {
     "tm_set_video": (c_int, [c_void_p, c_int, c_int, c_double, c_int]),
     "tm_push_frame_rgb32": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "tm_set_frames_device": (c_int, [c_void_p, c_void_p]),
+    "tm_set_frames_host": (c_int, [c_void_p, c_void_p]),
     "tm_run": (c_int, [c_void_p, c_int]),
     "tm_get_counts": (c_int, [c_void_p, ctypes.POINTER(c_int64)] + [ctypes.POINTER(c_int)] * 5),
     "tm_get_tile": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -100,12 +101,20 @@ class TilingEncoder:
             check(-2)
         self._frames_ref = None
 
-    def close(self):
-        if self._h:
-            self._L.tm_destroy(c_void_p(self._h))
-            self._h = None
+    _h = None  # class-level default: close() / __del__ are safe on an instance whose __init__ failed early
+    _L = None
 
-    __del__ = close
+    def close(self):
+        h = self.__dict__.get("_h")
+        if h:
+            self._L.tm_destroy(c_void_p(h))
+            object.__setattr__(self, "_h", None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass
 
     # -- settings (properties named like the Pascal ones)
     def __getattr__(self, name):
@@ -150,6 +159,13 @@ class TilingEncoder:
         """frames: torch int32 CUDA tensor [F][H][W] holding RGB32; borrowed until the encoder is closed"""
         self._frames_ref = frames
         check(self._L.tm_set_frames_device(c_void_p(self._h), c_void_p(frames.data_ptr())))
+
+    def SetFramesHost(self, frames):
+        """frames: torch int32 CPU tensor (ideally pinned) or numpy uint32 array [F][H][W] holding RGB32; borrowed: Load copies it to
+        the device in chunks beside its own kernel"""
+        self._frames_ref = frames
+        ptr = frames.data_ptr() if hasattr(frames, "data_ptr") else frames.ctypes.data
+        check(self._L.tm_set_frames_host(c_void_p(self._h), c_void_p(ptr)))
 
     def Run(self, step=TEncoderStep.esAll):
         check(self._L.tm_run(c_void_p(self._h), int(step)))
