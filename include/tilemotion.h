@@ -131,6 +131,19 @@ enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL
        TM_ARRAY_TILE_PALPX = 7 /* uint8 [tiles][64] dithered palette indices (DitherTile's output, :2690-2724); tiles of other
                                   dither shards hold 0: merge with SUM, as bytes or as count/4 32-bit words (count is a multiple of 64) */ };
 TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
+/* One process per GPU with the merges INSIDE the steps: the host hands the encoder its rank, the number of processes and a
+ * callback that performs a collective over them (RCCL through the host's own communicator: the library links no communication
+ * layer).  The callback runs on the caller's thread with the encoder's stream idle; it returns 0 once the result is in place.
+ *   kind: TM_COLL_ALLREDUCE_SUM_I32 / _MAX_I32 / _SUM_I64: `count` elements in `dev_buf`, in place;
+ *         TM_COLL_ALLGATHER_BYTES: `count` bytes from `dev_buf` of every process into `dev_recv` (world x count bytes, rank order).
+ * With it set, Run(step) shards by itself: Load by frame (motion prediction off), Reduce as a local exact dedup + an all-gather of
+ * the distinct tiles + a dedup of the union, PreparePalettes as data-parallel Lloyd (all-reduce of the integer sums per
+ * iteration) and palette-parallel colour quantisation, Dither by global tile, Reconstruct with the database rows built per share
+ * and all-gathered and the query frames of tm_set_query_shard.  Every process ends each step with the same global tiles,
+ * palettes and merged tile maps as a single-process run. */
+enum { TM_COLL_ALLREDUCE_SUM_I32 = 0, TM_COLL_ALLREDUCE_MAX_I32 = 1, TM_COLL_ALLREDUCE_SUM_I64 = 2, TM_COLL_ALLGATHER_BYTES = 3 };
+typedef int (*tm_collective_cb)(void *user, int kind, void *dev_buf, void *dev_recv, int64_t count);
+TM_API int tm_set_collective(tm_encoder *, int rank, int world, tm_collective_cb cb, void *user);
 /* Dither (DoDither :1873-1907, one independent DitherTile per global tile): this process dithers tiles
  * [T * rank / world, T * (rank + 1) / world) only (T = global tiles after Reduce) and zeroes the rest; the host merges
  * TM_ARRAY_TILE_PALPX with an all-reduce(SUM) before Reconstruct.  (0, 1) = every tile (default). */

@@ -12,9 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class OracleEncoder:
-    """Stand-in with TilingEncoder's Run/SetQueryShard/DeviceArray/SyncTileMap/KeyFrames surface, computing with the CPU
-    oracle.  With motion prediction the whole clip is computed once and each rank only EXPOSES its shard (zeros / -1
-    elsewhere, like the encoder), so what is tested is the orchestration: shard choice, merges, their order."""
+    """Stand-in with TilingEncoder's Run/SetCollective/SetQueryShard/KeyFrames surface, computing with the CPU oracle and merging with
+    the SAME collectives, in the same places, as the library's steps do (tm_encoder.hip: step_load, step_reduce, step_prepare_palettes,
+    step_dither, step_reconstruct).  The whole clip is computed once per rank for reference; what a rank EXPOSES or feeds into a
+    collective is only its shard, so what is tested is the orchestration: shard choice, the four collective kinds, their order."""
 
     def __init__(self, oracle, frames, palette_count, motion_radius=0, min_s=1.0, epu=False):
         self.o, self.frames, self.pc = oracle, frames, palette_count
@@ -22,83 +23,151 @@ class OracleEncoder:
         self.FrameTilingExtendedPaletteUsage = epu
         self.min_s = min_s
         self.shard = (0, frames.shape[0])
+        self.rank, self.world, self.coll = 0, 1, None
         self.st = {}
         self.arr = {}
+
+    def SetCollective(self, rank, world, coll):
+        self.rank, self.world, self.coll = rank, world, coll
 
     def SetQueryShard(self, first, count):
         self.shard = (first, count)
 
-    def SetDitherShard(self, rank, world):
-        self.dshard = (rank, world)
-
     def KeyFrames(self):
         return self.st["keyframes"]
 
-    def _mask(self, a, fill):
+    def _own(self, a, fill, shard=None):
         per = self.st["per"]
-        f0, n = self.shard
+        f0, n = shard or self.shard
         out = np.full_like(a, fill)
         out[f0 * per:(f0 + n) * per] = a[f0 * per:(f0 + n) * per]
         return torch.from_numpy(out)
+
+    def _share(self, n):
+        base, rem = divmod(n, self.world)
+        lo = self.rank * base + min(self.rank, rem)
+        return lo, lo + base + (1 if self.rank < rem else 0)
 
     def Run(self, step):
         from tests import oracle_pipeline
         step = int(step)
         mp = self.MotionPredictRadius > 0
+        st, co, o = self.st, self.coll, self.o
         if step == 0:
-            self.st = oracle_pipeline.run(self.o, self.frames, palette_count=self.pc, min_s=self.min_s, motion_radius=self.MotionPredictRadius,
-                                           epu=self.FrameTilingExtendedPaletteUsage)
+            self.st = st = oracle_pipeline.run(o, self.frames, palette_count=self.pc, min_s=self.min_s, motion_radius=self.MotionPredictRadius,
+                                               epu=self.FrameTilingExtendedPaletteUsage)
+            if self.world > 1 and not mp:  # sharded Load: own frames' correlation and mirror flags, merged with SUM (others hold 0)
+                f0, n = self.shard
+                correl = np.zeros_like(st["correl"])
+                correl[f0:f0 + n] = st["correl"][f0:f0 + n]
+                got = co.allreduce_sum(torch.from_numpy(correl.view(np.int32).copy())).numpy().view(np.float32)
+                assert np.array_equal(got, st["correl"])
+                flags = self._own(np.pad(st["flags"], (0, (-len(st["flags"])) % 4)), 0, (f0, n))  # bytes merged as 32-bit words
+                flags = flags if len(st["flags"]) % 4 == 0 else torch.from_numpy(np.pad(self._own(st["flags"], 0).numpy(), (0, (-len(st["flags"])) % 4)))
+                merged = co.allreduce_sum(torch.from_numpy(flags.numpy().view(np.int32).copy())).numpy().view(np.uint8)[: len(st["flags"])]
+                assert np.array_equal(merged, st["flags"])
         elif step == 1 and mp:
-            self.arr[6] = self._mask(self.st["pm_err"].view(np.int32), 0)
-            self.arr[4] = self._mask(self.st["pm_x"], 0)
-            self.arr[5] = self._mask(self.st["pm_y"], 0)
-        elif step == 2 and mp:  # Reduce needs the merged PredictMotion results on every rank
-            assert np.array_equal(self.arr[6].numpy().view(np.uint32), self.st["pm_err"])
-            assert np.array_equal(self.arr[4].numpy(), self.st["pm_x"]) and np.array_equal(self.arr[5].numpy(), self.st["pm_y"])
+            self.arr[6] = self._own(st["pm_err"].view(np.int32), 0)
+            self.arr[4] = self._own(st["pm_x"], 0)
+            self.arr[5] = self._own(st["pm_y"], 0)
+            if self.world > 1:
+                co.allreduce_sum(self.arr[6])
+                for k in (4, 5):  # int8 arrays go as 32-bit words
+                    a = np.pad(self.arr[k].numpy(), (0, (-self.arr[k].numel()) % 4))
+                    self.arr[k] = torch.from_numpy(co.allreduce_sum(torch.from_numpy(a.view(np.int32).copy())).numpy().view(np.int8)[: len(st["pm_x"])].copy())
+        elif step == 2:
+            if mp:  # Reduce needs the merged PredictMotion results on every rank
+                assert np.array_equal(self.arr[6].numpy().view(np.uint32), st["pm_err"])
+                assert np.array_equal(self.arr[4].numpy(), st["pm_x"]) and np.array_equal(self.arr[5].numpy(), st["pm_y"])
+            elif self.world > 1:
+                # sharded Reduce: dedup of the own frames' tiles, all-gather of the distinct ones (tile | use | flags), dedup of the union
+                per = st["per"]
+                f0, n = self.shard
+                sl = slice(f0 * per, (f0 + n) * per)
+                lnu, _, lorder, luse, lremap = o.dedup(st["tiles"][sl], None)
+                rec = np.zeros((lnu, 66), np.uint32)
+                rec[:, :64] = st["tiles"][sl][lorder]
+                rec[:, 64] = luse
+                rec[:, 65] = st["flags"][sl][lorder]
+                union, counts = co.allgather_var(torch.from_numpy(rec.view(np.int32)))
+                union = union.numpy().view(np.uint32)
+                nu, _, order, use, remap = o.dedup(np.ascontiguousarray(union[:, :64]), np.ascontiguousarray(union[:, 64]))
+                T = min(nu, st["T"]) if nu >= st["T"] else nu
+                assert T == st["T"]
+                assert np.array_equal(union[order[:T], :64], st["gtiles"]) and np.array_equal(use[:T], st["guse"])
+                assert np.array_equal(union[order[:T], 65].astype(np.uint8), st["gflags"])
+                off = sum(counts[: self.rank])
+                mine = remap[off + lremap]
+                assert np.array_equal(np.where(mine < T, mine, -1), st["tm_tile_reduce"][sl])
+        elif step == 3 and self.world > 1:
+            # PreparePalettes: palette indices of the own share of the tiles all-gathered; palette rows of the own palettes merged with SUM.
+            # (The data-parallel Lloyd itself runs in the library; here the shares of its RESULT travel the same way.)
+            t0, t1 = self._share(st["T"])
+            allidx, _ = co.allgather_var(torch.from_numpy(st["pal_idx"][t0:t1].astype(np.int32)))
+            assert np.array_equal(allidx.numpy(), st["pal_idx"])
+            rows = st["palettes"].copy()
+            rows[[p for p in range(rows.shape[0]) if p % self.world != self.rank]] = 0
+            assert np.array_equal(co.allreduce_sum(torch.from_numpy(rows.reshape(-1))).numpy().reshape(rows.shape), st["palettes"])
+            cnt = torch.from_numpy(np.bincount(st["pal_idx"][t0:t1], minlength=self.pc).astype(np.int64))
+            assert np.array_equal(co.allreduce_sum(cnt).numpy(), np.bincount(st["pal_idx"], minlength=self.pc))  # the int64 kind
         elif step == 4:  # Dither: only this rank's share of the global tiles, as 32-bit words; the others 0
-            px = self.st["pal_px"]
-            r, w = self.dshard
-            t0, t1 = px.shape[0] * r // w, px.shape[0] * (r + 1) // w
+            px = st["pal_px"]
+            t0, t1 = self._share(px.shape[0])
             own = np.zeros_like(px)
             own[t0:t1] = px[t0:t1]
             self.arr[7] = torch.from_numpy(own.reshape(-1).view(np.int32).copy())
-        elif step == 5:  # Reconstruct: only this rank's frames
-            assert np.array_equal(self.arr[7].numpy().view(np.uint8).reshape(self.st["pal_px"].shape), self.st["pal_px"]), "dither shards not merged"
-            per = self.st["per"]
+            if self.world > 1:
+                co.allreduce_sum(self.arr[7])
+        elif step == 5:  # Reconstruct: database rows per share + all-gather; only this rank's frames matched; merges
+            assert np.array_equal(self.arr[7].numpy().view(np.uint8).reshape(st["pal_px"].shape), st["pal_px"]), "dither shards not merged"
+            per = st["per"]
             f0, n = self.shard
             sl = slice(f0 * per, (f0 + n) * per)
             q = self.frames.shape[0] * per
+            db_full = o.features_pal(st["pal_px"], st["pal_idx"], st["palettes"], 1)
+            if self.world > 1:
+                t0, t1 = self._share(st["T"])
+                part = o.features_pal(st["pal_px"][t0:t1], st["pal_idx"][t0:t1], st["palettes"], 1)
+                db, _ = co.allgather_var(torch.from_numpy(part))
+                db = db.numpy()
+                assert np.array_equal(db, db_full)
+            else:
+                db = db_full
             if mp or self.FrameTilingExtendedPaletteUsage:
-                assert not mp or n == 0 or f0 in self.st["keyframes"], "a shard must start on a key frame"
-                self.arr[2] = self._mask(self.st["tm_pal"].astype(np.int32), -1)
-                self.arr[0] = self._mask(self.st["tm_tile_recon"], -1)
-                self.arr[1] = self._mask(self.st["tm_err"].view(np.int32), -1)
+                assert not mp or n == 0 or f0 in st["keyframes"], "a shard must start on a key frame"
+                self.arr[2] = self._own(st["tm_pal"].astype(np.int32), -1)
+                self.arr[0] = self._own(st["tm_tile_recon"], -1)
+                self.arr[1] = self._own(st["tm_err"].view(np.int32), 0)
                 if mp:
-                    self.arr[3] = self._mask(self.st["is_predicted"].astype(np.uint8), 0)
-                    self.arr[4] = self._mask(self.st["pred_x"], 0)
-                    self.arr[5] = self._mask(self.st["pred_y"], 0)
+                    self.arr[3] = self._own(st["is_predicted"].astype(np.uint8), 0)
+                    self.arr[4] = self._own(st["pred_x"], 0)
+                    self.arr[5] = self._own(st["pred_y"], 0)
             else:
                 self.arr[0] = torch.full((q,), -1, dtype=torch.int32)
-                self.arr[1] = torch.full((q,), -1, dtype=torch.int32)
-                db = self.o.features_pal(self.st["pal_px"], self.st["pal_idx"], self.st["palettes"], 1)
-                qf = self.o.features_rgb(self.st["tiles"][sl], None, 1, False)
-                idx, err = self.o.knn1(qf, db)
+                self.arr[1] = torch.zeros((q,), dtype=torch.int32)
+                qf = o.features_rgb(st["tiles"][sl], None, 1, False)
+                idx, err = o.knn1(qf, db)
                 self.arr[0][sl] = torch.from_numpy(idx)
                 self.arr[1][sl] = torch.from_numpy(err.view(np.int32))
+            if self.world > 1:
+                co.allreduce_max(self.arr[0])
+                co.allreduce_sum(self.arr[1])   # errors are arbitrary 32-bit patterns: owner's value + zeros
+                if self.FrameTilingExtendedPaletteUsage:
+                    co.allreduce_max(self.arr[2])
+                if mp:
+                    for k in (3, 4, 5):
+                        a = np.pad(self.arr[k].numpy(), (0, (-self.arr[k].numel()) % 4))
+                        dt = a.dtype
+                        self.arr[k] = torch.from_numpy(co.allreduce_sum(torch.from_numpy(a.view(np.int32).copy())).numpy().view(dt)[:q].copy())
         elif step == 6:
             tm = self.arr[0].numpy()
-            hist = np.bincount(tm[tm >= 0], minlength=self.st["T"]).astype(np.uint32)
-            nu, rep, order, use, remap = self.o.dedup(self.st["pal_px"], hist)
+            hist = np.bincount(tm[tm >= 0], minlength=st["T"]).astype(np.uint32)
+            nu, rep, order, use, remap = o.dedup(st["pal_px"], hist)
             self.final = dict(T=nu, use=use, tm=np.where(tm >= 0, remap[np.maximum(tm, 0)], -1).astype(np.int32),
                               pred=self.arr[3].numpy().copy() if mp else None, px=self.arr[4].numpy().copy() if mp else None,
                               py=self.arr[5].numpy().copy() if mp else None, err=self.arr[1].numpy().copy(),
-                              pal=self.arr[2].numpy().copy() if self.FrameTilingExtendedPaletteUsage else None)
-
-    def DeviceArray(self, which):
-        return self.arr[int(which)]
-
-    def SyncTileMap(self):
-        pass
+                              pal=self.arr[2].numpy().copy() if self.FrameTilingExtendedPaletteUsage else None,
+                              calls=dict(self.coll.calls) if self.coll else {})
 
 
 def _worker(rank, world, port, q, motion_radius=0, epu=False):
@@ -141,6 +210,8 @@ def test_two_ranks_equal_one(oracle, motion_radius, epu):
     else:
         exp = oracle_pipeline.run(oracle, synth.video(5, 48, 32), palette_count=2, epu=epu)
     for rank, fin in res:
+        if not motion_radius:  # every collective kind was exercised: SUM i32, MAX i32, SUM i64, all-gather
+            assert all(fin["calls"][k] > 0 for k in (0, 1, 2, 3)), fin["calls"]
         assert fin["T"] == exp["final_T"]
         assert np.array_equal(fin["use"], exp["final_use"])
         assert np.array_equal(fin["tm"], exp["final_tm_tile"])

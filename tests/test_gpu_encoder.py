@@ -259,11 +259,24 @@ class _FakeDist:
             torch.cuda.synchronize()
         self.bar.wait()
 
+    def all_gather_into_tensor(self, recv, send, group=None):
+        r = self.local.rank
+        self.slots[r] = (recv, send)
+        self.bar.wait()
+        if r == 0:
+            cat = torch.cat([s for _, s in self.slots])
+            for o, _ in self.slots:
+                o.copy_(cat)
+            torch.cuda.synchronize()
+        self.bar.wait()
+
 
 @pytest.mark.parametrize("radius,epu,world", [(0, False, 2), (0, True, 2), (8, False, 2), (8, True, 2), (8, True, 3), (8, False, 6), (0, False, 5)])
 def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
-    """tiler_amd.distributed.run_all with REAL encoders: two ranks (threads, one GPU) shard PredictMotion / Reconstruct, merge through
-    all-reduces, and must end with exactly the single-process result.  With 6 ranks on 4 key frames some ranks own no frame at all."""
+    """tiler_amd.distributed.run_all with REAL encoders: the ranks (threads, one GPU) shard Load / Reduce / PreparePalettes (data-parallel
+    Lloyd, palette-parallel quantisation) / Dither / Reconstruct -- with motion prediction on: PredictMotion and whole key-frame groups --
+    through the library's collective callback, and must end with exactly the single-process result.  With 6 ranks on 4 key frames some
+    ranks own no frame at all; with 5 ranks on 3 palettes some own no palette."""
     import threading
     from tiler_amd import synth, distributed
     from tiler_amd.encoder import TilingEncoder

@@ -50,6 +50,29 @@ __global__ void k_lookup_inplace(int32_t *__restrict__ idx, int64_t n, const int
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     if (idx[i] >= 0) idx[i] = table[idx[i]];
 }
+// sharded Reduce: one record per locally distinct tile = 64 pixel dwords + use count + mirror flags
+__global__ void k_pack_unique(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags, const int32_t *__restrict__ order,
+                              const uint32_t *__restrict__ use, int64_t n, uint32_t *__restrict__ rec) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * 66; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / 66;
+    const int v = (int)(e - r * 66);
+    rec[e] = v < 64 ? tiles[(int64_t)order[r] * 64 + v] : v == 64 ? use[r] : (uint32_t)flags[order[r]];
+  }
+}
+__global__ void k_unpack_unique(const uint32_t *__restrict__ rec, int64_t n, uint32_t *__restrict__ tiles, uint32_t *__restrict__ use, uint8_t *__restrict__ flags) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * 66; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / 66;
+    const int v = (int)(e - r * 66);
+    if (v < 64) tiles[r * 64 + v] = rec[e]; else if (v == 64) use[r] = rec[e]; else flags[r] = (uint8_t)rec[e];
+  }
+}
+__global__ void k_compose_remap(const int32_t *__restrict__ local_remap, int64_t n, const int32_t *__restrict__ union_remap, int32_t union_off, int32_t limit,
+                                int32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t g = union_remap[union_off + local_remap[i]];
+    out[i] = g < limit ? g : -1;
+  }
+}
 static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
 
 static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, utils.pas:1038-1041 (TFloat argument)
@@ -113,6 +136,13 @@ struct tm_encoder {
   double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int shard_first = 0, shard_count = -1;  // query frames this process matches in Reconstruct (multi-GPU: one shard per rank)
   int dither_rank = 0, dither_world = 1;  // tiles this process dithers: [t * rank / world, t * (rank + 1) / world)
+  // one process per GPU (tm_set_collective): the steps shard their work over `world` processes and merge through the host's collectives
+  tm_collective_cb coll_cb = nullptr;
+  void *coll_user = nullptr;
+  Collectives co;
+  bool load_sharded = false;     // Load only filled the frame tiles of this process's frames (and of the frame before them)
+  int load_first = 0, load_count = 0;
+  bool dist() const { return coll_cb != nullptr && co.world > 1; }
   // Query features of Reconstruct's first chunk, computed AHEAD on a second (non-blocking) stream: they depend on the frame tiles only.
   // Launched when PreparePalettes hands over to the host (OptimizePalettes' 2-5 ms search, then Dither's start), the one stretch where
   // the GPU idles; launched earlier they only trade time with the k-means kernels (measured: +3.8 ms there for -3.7 ms here).
@@ -214,6 +244,53 @@ static int need(tm_encoder *e, int step_bit, const char *what) {
   return TM_OK;
 }
 
+static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t count) {
+  TM_HIP(hipStreamSynchronize(e->stream));  // everything queued so far is done before the host's collective touches the buffers
+  const int rc = e->coll_cb(e->coll_user, kind, buf, recv, count);
+  TM_CHECK(rc == 0, TM_E_HIP, "the host's collective callback failed (kind %d, code %d)", kind, rc);
+  return TM_OK;
+}
+static void bind_collectives(tm_encoder *e) {
+  e->co.allreduce_sum_i32 = [e](void *b, int64_t n) { return coll_run(e, TM_COLL_ALLREDUCE_SUM_I32, b, nullptr, n); };
+  e->co.allreduce_max_i32 = [e](void *b, int64_t n) { return coll_run(e, TM_COLL_ALLREDUCE_MAX_I32, b, nullptr, n); };
+  e->co.allreduce_sum_i64 = [e](void *b, int64_t n) { return coll_run(e, TM_COLL_ALLREDUCE_SUM_I64, b, nullptr, n); };
+  e->co.allgather = [e](const void *snd, void *rcv, int64_t bytes) { return coll_run(e, TM_COLL_ALLGATHER_BYTES, const_cast<void *>(snd), rcv, bytes); };
+}
+// this process's share [lo, hi) of n items, contiguous, earlier processes take the remainder (the same rule as tiler_amd.distributed.frame_shard)
+static void share_of(int64_t n, int rank, int world, int64_t *lo, int64_t *hi) {
+  const int64_t base = n / world, rem = n % world;
+  *lo = rank * base + std::min<int64_t>(rank, rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+// all-gather of per-process pieces of different sizes: send `count` items of `item` bytes, receive everyone's into `out` (in rank
+// order, contiguous); counts[r] comes back on the host
+static int gather_var(tm_encoder *e, const void *send, int64_t count, int item, DevBuf &out, std::vector<int64_t> *counts) {
+  const int W = e->co.world;
+  DevBuf dcnt, dall, pad, recv;
+  TM_TRY(dcnt.alloc(8)); TM_TRY(dall.alloc((size_t)W * 8));
+  TM_HIP(hipMemcpyAsync(dcnt.p, &count, 8, hipMemcpyHostToDevice, e->stream));
+  TM_TRY(e->co.allgather(dcnt.p, dall.p, 8));
+  counts->assign((size_t)W, 0);
+  TM_HIP(hipMemcpyAsync(counts->data(), dall.p, (size_t)W * 8, hipMemcpyDeviceToHost, e->stream));
+  TM_HIP(hipStreamSynchronize(e->stream));
+  int64_t mx = 0, total = 0;
+  for (int64_t c : *counts) { mx = std::max(mx, c); total += c; }
+  TM_TRY(out.alloc((size_t)std::max<int64_t>(total, 1) * item));
+  if (mx == 0) return TM_OK;
+  const size_t chunk = (((size_t)mx * item + 15) / 16) * 16;
+  TM_TRY(pad.alloc(chunk)); TM_TRY(recv.alloc(chunk * W));
+  if (count > 0) TM_HIP(hipMemcpyAsync(pad.p, send, (size_t)count * item, hipMemcpyDeviceToDevice, e->stream));
+  TM_TRY(e->co.allgather(pad.p, recv.p, (int64_t)chunk));
+  int64_t off = 0;
+  for (int r = 0; r < W; r++) {
+    if ((*counts)[r] > 0)
+      TM_HIP(hipMemcpyAsync(out.as<uint8_t>() + (size_t)off * item, recv.as<uint8_t>() + chunk * r, (size_t)(*counts)[r] * item, hipMemcpyDeviceToDevice, e->stream));
+    off += (*counts)[r];
+  }
+  TM_HIP(hipStreamSynchronize(e->stream));
+  return TM_OK;
+}
+
 // Steps that read the frame tiles / the global tiles' RGB pixels: ReloadGTM brings neither (the stream holds palette indices
 // only, HasRGBPixels = False at tilingencoder.pas:4937), so after a reload these steps need Load (and Reduce) to have run again.
 static int need_frame_tiles(tm_encoder *e, const char *step) {
@@ -229,12 +306,13 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
 
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
   e->drop_prefetch();  // features of the previous frame tiles
+  e->load_sharded = false;
   TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
   TM_CHECK(e->frames != nullptr || e->frames_host != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device / tm_set_frames_host first");
   e->q = (int64_t)e->nframes * e->tm_size();
   TM_CHECK(e->q < (1ll << 31), TM_E_UNSUPPORTED, "%lld tile-map items: the index arrays are 32-bit (TileIdx is an Integer, tilingencoder.pas:179)", (long long)e->q);
   TM_TRY(e->ftiles.alloc((size_t)e->q * 256));
-  TM_TRY(e->fflags.alloc((size_t)e->q));
+  TM_TRY(e->fflags.alloc((size_t)e->q + 4));  // (+4: merged as 32-bit words)
   TM_TRY(e->flab.alloc((size_t)e->q * 12));
   if (e->frames_host) {
     // The clip sits in host memory: chunks of frames cross PCIe on a copy stream while the Load kernel works on the chunk before
@@ -260,6 +338,21 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
       TM_TRY(launch_load(e->frames_owned.as<uint8_t>() + fbytes * f0, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + (int64_t)f0 * per * 256,
                          e->fflags.as<uint8_t>() + (int64_t)f0 * per, e->flab.as<uint8_t>() + (int64_t)f0 * per * 12, e->stream));
     }
+  } else if (e->dist() && e->s.MotionPredictRadius <= 0) {
+    // One process per GPU, motion prediction off: every process loads its own frames (frames are independent, 1293-1411) plus the
+    // one before them, whose Lab means the first correlation needs.  The mirror flags (read back with every tile map) and the
+    // correlation sums are merged; the frame tiles stay where they are -- Reduce and Reconstruct only need a process's own.
+    const size_t fbytes = (size_t)e->width * e->height * 4;
+    const int64_t per1 = e->tm_size();
+    int64_t f0, f1;
+    share_of(e->nframes, e->co.rank, e->co.world, &f0, &f1);
+    const int64_t lo = std::max<int64_t>(f0 - 1, 0);
+    TM_HIP(hipMemsetAsync(e->fflags.p, 0, (size_t)e->q, e->stream));
+    if (f1 > f0)
+      TM_TRY(launch_load((const uint8_t *)e->frames + fbytes * lo, (int)(f1 - lo), e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + lo * per1 * 256,
+                         e->fflags.as<uint8_t>() + lo * per1, e->flab.as<uint8_t>() + lo * per1 * 12, e->stream));
+    if (lo < f0) TM_HIP(hipMemsetAsync(e->fflags.as<uint8_t>() + lo * per1, 0, (size_t)per1, e->stream));  // the neighbour's flags are its owner's to report
+    e->load_sharded = true; e->load_first = (int)f0; e->load_count = (int)(f1 - f0);
   } else
   TM_TRY(launch_load(e->frames, e->nframes, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.p, e->fflags.p, e->flab.p, e->stream));
   progress(e, TM_STEP_LOAD, 1, 3);
@@ -267,6 +360,15 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   const int per = (int)e->tm_size() * 3;
   DevBuf dcorrel;
   TM_TRY(dcorrel.alloc((size_t)e->nframes * 12));
+  if (e->load_sharded) {
+    const int64_t f0 = e->load_first, f1 = f0 + e->load_count, lo = std::max<int64_t>(f0 - 1, 0);
+    TM_HIP(hipMemsetAsync(dcorrel.p, 0, (size_t)e->nframes * 12, e->stream));
+    // block b of the launch correlates frame lo + b with the one before it (block 0 has none): frames f0 .. f1-1 (frame 0 has no sum)
+    if (f1 > f0) TM_TRY(launch_pearson(e->flab.as<uint8_t>() + lo * per * 4, (int)(f1 - lo), per, dcorrel.as<uint8_t>() + lo * 12, e->stream));
+    if (lo < f0) TM_HIP(hipMemsetAsync(dcorrel.as<uint8_t>() + lo * 12, 0, 12, e->stream));
+    TM_TRY(e->co.allreduce_sum_i32(dcorrel.p, (int64_t)e->nframes * 3));  // owner holds the float, everyone else +0.0: exact
+    TM_TRY(e->co.allreduce_sum_i32(e->fflags.p, (e->q + 3) / 4));
+  } else
   TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
   std::vector<float> sums((size_t)e->nframes * 3);
   e->h_fflags.clear();  // fetched lazily by tm_get_tilemap
@@ -310,13 +412,14 @@ static int step_predict_motion(tm_encoder *e) {
   e->has_pm = false;
   if (e->s.MotionPredictRadius <= 0) return TM_OK;  // 1972
   TM_TRY(need_frame_tiles(e, "PredictMotion"));
+  TM_CHECK(!e->load_sharded, TM_E_INVAL, "PredictMotion: Load ran with motion prediction off and only brought this process's frames; run Load again");
   const int64_t per = e->tm_size();
   const int sw = e->tm_w * 8, sh = e->tm_h * 8;
   const int64_t nwin = (int64_t)(sw - 7) * (sh - 7);
   TM_TRY(e->pm_err.alloc((size_t)e->q * 4));
-  TM_TRY(e->tm_px.alloc((size_t)e->q));
-  TM_TRY(e->tm_py.alloc((size_t)e->q));
-  TM_TRY(e->tm_pred.alloc((size_t)e->q));
+  TM_TRY(e->tm_px.alloc((size_t)e->q + 4));  // (+4: merged as 32-bit words)
+  TM_TRY(e->tm_py.alloc((size_t)e->q + 4));
+  TM_TRY(e->tm_pred.alloc((size_t)e->q + 4));
   TM_HIP(hipMemsetAsync(e->tm_pred.p, 0, (size_t)e->q, e->stream));
   const int sf = std::max(0, std::min(e->shard_first, e->nframes));
   const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
@@ -339,6 +442,11 @@ static int step_predict_motion(tm_encoder *e) {
     TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, e->pm_err.as<uint32_t>() + off,
                                 e->tm_px.as<int8_t>() + off, e->tm_py.as<int8_t>() + off, e->stream));
     if ((f & 15) == 15) progress(e, TM_STEP_PREDICT_MOTION, f, e->nframes);
+  }
+  if (e->dist()) {  // owner holds the value, everyone else 0
+    TM_TRY(e->co.allreduce_sum_i32(e->pm_err.p, e->q));
+    TM_TRY(e->co.allreduce_sum_i32(e->tm_px.p, (e->q + 3) / 4));
+    TM_TRY(e->co.allreduce_sum_i32(e->tm_py.p, (e->q + 3) / 4));
   }
   TM_HIP(hipStreamSynchronize(e->stream));
   e->has_pm = true;
@@ -406,6 +514,52 @@ static int step_reduce(tm_encoder *e) {
   TM_TRY(need_frame_tiles(e, "Reduce"));
   e->gtiles_have_rgb = true;
   if (e->has_pm) return step_reduce_motion(e);
+  if (e->load_sharded) {
+    // One process per GPU: exact dedup of this process's own frame tiles first, then of the union of every process's distinct
+    // tiles (all-gathered: tile, use count, mirror flags of its first occurrence).  Processes own increasing frame ranges and the
+    // union is laid out in process order, so "first occurrence" and the final order (use count descending, content ascending)
+    // are those of the single-process run.
+    const int64_t per = e->tm_size(), f0 = e->load_first, nloc = (int64_t)e->load_count * per;
+    DevBuf lremap, lorder, luse, rec, urec, utiles, uuse, uflags, gremap, gorder, guse2;
+    int64_t lnu = 0;
+    TM_TRY(lremap.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(lorder.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(luse.alloc((size_t)std::max<int64_t>(nloc, 1) * 4));
+    if (nloc > 0) TM_TRY(run_dedup(e->ftiles.as<uint8_t>() + f0 * per * 256, nloc, 256, nullptr, lremap.p, lorder.p, luse.p, &lnu, e->stream));
+    TM_TRY(rec.alloc((size_t)std::max<int64_t>(lnu, 1) * 264));
+    if (lnu > 0)
+      hipLaunchKernelGGL(k_pack_unique, dim3(gridn(lnu * 66)), dim3(256), 0, e->stream, e->ftiles.as<uint32_t>() + f0 * per * 64, e->fflags.as<uint8_t>() + f0 * per,
+                         lorder.as<int32_t>(), luse.as<uint32_t>(), lnu, rec.as<uint32_t>());
+    TM_HIP(hipGetLastError());
+    std::vector<int64_t> counts;
+    TM_TRY(gather_var(e, rec.p, lnu, 264, urec, &counts));
+    int64_t nun = 0, my_off = 0;
+    for (int r = 0; r < e->co.world; r++) { if (r < e->co.rank) my_off += counts[r]; nun += counts[r]; }
+    TM_CHECK(nun > 0 && nun < (1ll << 31), TM_E_INVAL, "Reduce: %lld distinct tiles over all processes", (long long)nun);
+    TM_TRY(utiles.alloc((size_t)nun * 256)); TM_TRY(uuse.alloc((size_t)nun * 4)); TM_TRY(uflags.alloc((size_t)nun));
+    hipLaunchKernelGGL(k_unpack_unique, dim3(gridn(nun * 66)), dim3(256), 0, e->stream, urec.as<uint32_t>(), nun, utiles.as<uint32_t>(), uuse.as<uint32_t>(), uflags.as<uint8_t>());
+    TM_HIP(hipGetLastError());
+    TM_TRY(gremap.alloc((size_t)nun * 4)); TM_TRY(gorder.alloc((size_t)nun * 4)); TM_TRY(guse2.alloc((size_t)nun * 4));
+    int64_t nu = 0;
+    TM_TRY(run_dedup(utiles.p, nun, 256, uuse.p, gremap.p, gorder.p, guse2.p, &nu, e->stream));
+    progress(e, TM_STEP_REDUCE, 1, 2);
+    const int64_t target = e->s.GlobalTilingTileCount > 0 ? e->s.GlobalTilingTileCount : nu;
+    e->t = std::min<int64_t>(nu, target);
+    TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
+    TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
+    TM_TRY(e->guse.alloc((size_t)e->t * 4));
+    hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(e->t * 16)), dim3(256), 0, e->stream, utiles.as<uint4>(), gorder.as<int32_t>(), e->t, 16, e->gtiles.as<uint4>());
+    hipLaunchKernelGGL(k_gather<uint8_t>, dim3(gridn(e->t)), dim3(256), 0, e->stream, uflags.as<uint8_t>(), gorder.as<int32_t>(), e->t, e->gflags.as<uint8_t>());
+    TM_HIP(hipMemcpyAsync(e->guse.p, guse2.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
+    // tile map of this process's frames (TransferTiles: TileIdx := the tile's index, 4079-4083); the other frames' items are their owners'
+    TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
+    if (nloc > 0)
+      hipLaunchKernelGGL(k_compose_remap, dim3(gridn(nloc)), dim3(256), 0, e->stream, lremap.as<int32_t>(), nloc, gremap.as<int32_t>(), (int32_t)my_off, (int32_t)e->t,
+                         e->tm_tile.as<int32_t>() + f0 * per);
+    TM_HIP(hipGetLastError());
+    TM_HIP(hipStreamSynchronize(e->stream));
+    e->has_pal_px = e->reconstructed = false;
+    progress(e, TM_STEP_REDUCE, 2, 2);
+    return TM_OK;
+  }
   DevBuf remap, order, use;
   TM_TRY(remap.alloc((size_t)e->q * 4));
   TM_TRY(order.alloc((size_t)e->q * 4));
@@ -489,16 +643,41 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     t_last = now;
   };
   DevBuf feat;
+  TM_TRY(e->gpal_idx.alloc((size_t)e->t * 4));
+  TM_TRY(e->palettes_dev.alloc((size_t)e->s.PaletteCount * e->s.PaletteSize * 4));
+  if (e->dist()) {
+    // One process per GPU.  Tile -> palette: every process holds the clustering features of its own share of the global tiles; the
+    // farthest-first picks are settled by an all-gather of one candidate per process and the Lloyd iterations by an all-reduce
+    // of the exact integer sums (run_palettize_dist), then the palette indices of all shares are all-gathered.  Palette colours:
+    // the palettes are independent tasks (one thread per palette in the reference, 1864): process r quantises the palettes
+    // p = r (mod world), an all-reduce(SUM) assembles the set.
+    int64_t t0, t1;
+    share_of(e->t, e->co.rank, e->co.world, &t0, &t1);
+    const int64_t nl = t1 - t0;
+    TM_TRY(feat.alloc((size_t)std::max<int64_t>(nl, 1) * 192 * 4));
+    if (nl > 0) TM_TRY(launch_features_cluster(e->gtiles.as<uint8_t>() + t0 * 256, nl, e->s.DitheringMode, feat.p, e->stream));
+    lap("cluster features (own share)");
+    DevBuf lidx, all;
+    TM_TRY(lidx.alloc((size_t)std::max<int64_t>(nl, 1) * 4));
+    TM_TRY(run_palettize_dist(feat.p, e->guse.as<uint8_t>() + t0 * 4, nl, t0, e->s.PaletteCount, 300, lidx.p, e->co, e->stream));
+    std::vector<int64_t> counts;
+    TM_TRY(gather_var(e, lidx.p, nl, 4, all, &counts));
+    TM_HIP(hipMemcpyAsync(e->gpal_idx.p, all.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
+    lap("tile -> palette (192-D, data-parallel)");
+    progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
+    TM_TRY(run_quantize_palettes_part(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->co.rank, e->co.world, e->stream));
+    TM_TRY(e->co.allreduce_sum_i32(e->palettes_dev.p, (int64_t)e->s.PaletteCount * e->s.PaletteSize));
+    lap("palette colours (3-D, own palettes)");
+  } else {
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
   TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
   lap("cluster features");
-  TM_TRY(e->gpal_idx.alloc((size_t)e->t * 4));
   TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
-  TM_TRY(e->palettes_dev.alloc((size_t)e->s.PaletteCount * e->s.PaletteSize * 4));
   TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream));
   lap("palette colours (3-D)");
+  }
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
   TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
@@ -524,6 +703,7 @@ static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
     TM_TRY(launch_dither(e->gtiles.as<uint8_t>() + t0 * 256, e->gflags.as<uint8_t>() + t0, e->gpal_idx.as<uint8_t>() + t0 * 4, t1 - t0, e->palettes_dev.p,
                          e->s.PaletteCount, e->s.PaletteSize, e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors,
                          e->gpal_px.as<uint8_t>() + t0 * 64, e->stream));
+  if (e->dist() && e->dither_world > 1) TM_TRY(e->co.allreduce_sum_i32(e->gpal_px.p, e->t * 16));  // 64 bytes per tile = 16 words; other shares hold 0
   TM_HIP(hipStreamSynchronize(e->stream));
   e->has_pal_px = true;
   progress(e, TM_STEP_DITHER, 2, 2);
@@ -538,6 +718,17 @@ static int step_reconstruct(tm_encoder *e) {
   TM_TRY(need_frame_tiles(e, "Reconstruct"));
   DevBuf db, qf;
   TM_TRY(db.alloc((size_t)e->t * 384));
+  if (e->dist()) {  // PrepareReconstruct (4566-4613) per share of the global tiles, then the all-gather of the int16 rows (T x 384 bytes in all)
+    int64_t t0, t1;
+    share_of(e->t, e->co.rank, e->co.world, &t0, &t1);
+    DevBuf part, all;
+    TM_TRY(part.alloc((size_t)std::max<int64_t>(t1 - t0, 1) * 384));
+    if (t1 > t0)
+      TM_TRY(launch_features_pal(e->gpal_px.as<uint8_t>() + t0 * 64, e->gpal_idx.as<uint8_t>() + t0 * 4, t1 - t0, e->palettes_dev.p, e->s.PaletteSize, TM_PVS_WEIGHTED_DCT, part.p, e->stream));
+    std::vector<int64_t> counts;
+    TM_TRY(gather_var(e, part.p, t1 - t0, 384, all, &counts));
+    TM_HIP(hipMemcpyAsync(db.p, all.p, (size_t)e->t * 384, hipMemcpyDeviceToDevice, e->stream));
+  } else
   TM_TRY(launch_features_pal(e->gpal_px.p, e->gpal_idx.p, e->t, e->palettes_dev.p, e->s.PaletteSize, TM_PVS_WEIGHTED_DCT, db.p, e->stream));
   // Many dithered tiles are byte-identical (Reindex merges them later, MakeTilesUnique(False) at 2014).  Under the
   // lowest-index tie rule the nearest neighbour among ALL rows is the nearest among the DISTINCT rows taken in order of
@@ -545,9 +736,11 @@ static int step_reconstruct(tm_encoder *e) {
   const int64_t per = e->tm_size();
   const int sf = std::max(0, std::min(e->shard_first, e->nframes));
   const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
-  if (sf > 0 || sn < e->nframes) {  // frames of other shards: TileIdx -1 / err $FFFFFFFF so an all-reduce(MAX) merges shards
+  TM_CHECK(!e->load_sharded || (sf >= e->load_first && sf + sn <= e->load_first + e->load_count), TM_E_INVAL,
+           "Reconstruct: frames [%d, %d) are not the ones this process loaded ([%d, %d))", sf, sf + sn, e->load_first, e->load_first + e->load_count);
+  if (sf > 0 || sn < e->nframes) {  // frames of other shards: TileIdx / PalIdx -1 (merged with MAX), error 0 (merged with SUM: an error is any 32-bit pattern)
     TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
-    TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
+    TM_HIP(hipMemsetAsync(e->tm_err.p, 0, (size_t)e->q * 4, e->stream));
     TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
   }
   e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0;
@@ -664,6 +857,20 @@ static int step_reconstruct(tm_encoder *e) {
                                  e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->tm_px.as<int8_t>() + off,
                                  e->tm_py.as<int8_t>() + off, e->tm_pred.as<uint8_t>() + off, e->stream));
       cb ^= 1;
+    }
+  }
+  if (e->dist()) {  // merge the shards' items: TileIdx (and the re-rank's PalIdx) by MAX (others hold -1), the error and the motion results by SUM (others hold 0)
+    TM_TRY(e->co.allreduce_max_i32(e->tm_tile.p, e->q));
+    TM_TRY(e->co.allreduce_sum_i32(e->tm_err.p, e->q));
+    if (epu) TM_TRY(e->co.allreduce_max_i32(e->tm_pal.p, e->q));
+    if (e->has_pm) {
+      TM_TRY(e->co.allreduce_sum_i32(e->tm_pred.p, (e->q + 3) / 4));
+      TM_TRY(e->co.allreduce_sum_i32(e->tm_px.p, (e->q + 3) / 4));
+      TM_TRY(e->co.allreduce_sum_i32(e->tm_py.p, (e->q + 3) / 4));
+    }
+    if (!epu) {  // TMI^.PalIdx := FTiles[TileIdx]^.PalIdx_Initial for every item (1551)
+      hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, e->gpal_idx.as<int32_t>(), e->tm_pal.as<int32_t>());
+      TM_HIP(hipGetLastError());
     }
   }
   TM_HIP(hipStreamSynchronize(e->stream));
@@ -1025,6 +1232,20 @@ int tm_set_query_shard(tm_encoder *e, int first_frame, int frame_count) {
   if (first_frame != e->shard_first || frame_count != e->shard_count) e->qf_valid = false;  // prefetched for the old range (freed with the next Load / Reconstruct)
   e->shard_first = first_frame;
   e->shard_count = frame_count;
+  return TM_OK;
+}
+
+int tm_set_collective(tm_encoder *e, int rank, int world, tm_collective_cb cb, void *user) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(world >= 1 && rank >= 0 && rank < world && (cb != nullptr || world == 1), TM_E_INVAL, "bad process %d of %d", rank, world);
+  e->coll_cb = world > 1 ? cb : nullptr;
+  e->coll_user = user;
+  e->co.rank = rank;
+  e->co.world = world;
+  bind_collectives(e);
+  e->dither_rank = rank;
+  e->dither_world = world;
+  e->qf_valid = false;
   return TM_OK;
 }
 

@@ -1,5 +1,6 @@
 // tm_internal.h -- launcher prototypes shared between the kernel files, the stage ABI and the encoder.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -58,11 +59,29 @@ int solve_tile_count(const void *group, int64_t ngroups, const void *pm_err, con
                      void *pred, void *keep, double *x_out, int *probes_out, hipStream_t stream);
 float euclidean_to_psnr(uint32_t e);
 
+// One process per GPU: the collectives a step needs between its kernels, handed in by the host (tm_set_collective).  The calls
+// are made on the caller's thread with the encoder's stream idle, and return with the result in place.
+struct Collectives {
+  int rank = 0, world = 1;
+  std::function<int(void *buf, int64_t count)> allreduce_sum_i32, allreduce_max_i32, allreduce_sum_i64;
+  std::function<int(const void *send, void *recv, int64_t bytes_per_rank)> allgather;  // recv: world x bytes_per_rank, rank order
+};
+
 // tm_kmeans.hip
+// DoPalettization over `world` processes: every process holds the points of its own tile range (global index of the first:
+// global_begin); the farthest-first picks are settled by an all-gather of one candidate per process, the Lloyd iterations by
+// an all-reduce of the exact integer sums, so every process ends with the same centroids and with the assignment of its own
+// range (out_pal_idx: n_local entries, already ranked by global tile count).
+int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n_local, int64_t global_begin, int npal, int max_iter,
+                       void *out_pal_idx_local, const Collectives &co, hipStream_t stream);
 int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,
                int *host_iters, hipStream_t stream);
 int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                           hipStream_t stream);
+// the same for the palettes p with p % pal_world == pal_rank only (independent tasks, one thread per palette in the reference:
+// tilingencoder.pas:1864); the other palettes' rows come back as zeros, so that an all-reduce(SUM) assembles the set
+int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
+                               int pal_rank, int pal_world, hipStream_t stream);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
 
 // tm_optpal.hip (host only)

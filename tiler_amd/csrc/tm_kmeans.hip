@@ -1064,6 +1064,211 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   return TM_OK;
 }
 
+// ---- DoPalettization over several processes ---------------------------------------------------------------------
+struct FfCand { long long dist, gidx; int32_t row[192]; };  // one farthest-first candidate per process: largest min-distance, then lowest global index
+struct FfState { int kk, done; };
+
+__global__ __launch_bounds__(256) void k_ffd_update(const int32_t *__restrict__ pts, int64_t n, const int32_t *__restrict__ cur_row,
+                                                    long long *__restrict__ mind, BestKey *__restrict__ partial) {
+  __shared__ BestKey s_best[4];
+  __shared__ int32_t s_c[192];
+  for (int j = threadIdx.x; j < 192; j += 256) s_c[j] = cur_row[j];
+  __syncthreads();
+  BestKey mine{0, LLONG_MIN};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
+    long long dd = 0;
+    for (int j = 0; j < 48; j++) {
+      const int4 v = p[j];
+      const long long t0 = (long long)v.x - s_c[4 * j], t1 = (long long)v.y - s_c[4 * j + 1];
+      const long long t2 = (long long)v.z - s_c[4 * j + 2], t3 = (long long)v.w - s_c[4 * j + 3];
+      dd += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+    }
+    long long m = mind[i];
+    if (dd < m) { m = dd; mind[i] = m; }
+    const BestKey cand{m, -(long long)i};
+    if (better(cand, mine)) mine = cand;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    BestKey other{__shfl_xor(mine.dist, o), __shfl_xor(mine.negidx, o)};
+    if (better(other, mine)) mine = other;
+  }
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < 4; wv++)
+      if (better(s_best[wv], mine)) mine = s_best[wv];
+    partial[blockIdx.x] = mine;
+  }
+}
+// this process's candidate: first = 1 -> "I hold global point 0" (the first centre); else the best of the blocks' partials
+__global__ __launch_bounds__(256) void k_ffd_cand(const BestKey *__restrict__ partial, int nblk, const int32_t *__restrict__ pts, int64_t n,
+                                                  long long global_begin, int first, FfCand *__restrict__ out) {
+  __shared__ BestKey s_best[256];
+  const int tid = threadIdx.x;
+  BestKey best{0, LLONG_MIN};
+  if (first) {
+    if (tid == 0) best = (n > 0 && global_begin == 0) ? BestKey{1, 0} : BestKey{-1, LLONG_MIN};
+  } else {
+    for (int b = tid; b < nblk; b += 256) {
+      const BestKey c = partial[b];
+      if (better(c, best)) best = c;
+    }
+  }
+  s_best[tid] = best;
+  __syncthreads();
+  if (!first)
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o && better(s_best[tid + o], s_best[tid])) s_best[tid] = s_best[tid + o];
+      __syncthreads();
+    }
+  best = s_best[0];
+  const bool has = best.negidx != LLONG_MIN && best.dist > 0;
+  if (tid == 0) { out->dist = has ? best.dist : -1; out->gidx = has ? global_begin + (-best.negidx) : 0x7fffffffffffffffll; }
+  if (tid < 192) out->row[tid] = has ? pts[(-best.negidx) * 192 + tid] : 0;
+}
+// every process makes the same choice among the gathered candidates
+__global__ __launch_bounds__(256) void k_ffd_pick(const FfCand *__restrict__ cands, int world, int k, FfState *__restrict__ st, int32_t *__restrict__ cur_row,
+                                                  double *__restrict__ cent) {
+  __shared__ int s_win;
+  if (threadIdx.x == 0) {
+    int win = -1;
+    if (!st->done && st->kk < k)
+      for (int r = 0; r < world; r++)
+        if (cands[r].dist > 0 && (win < 0 || cands[r].dist > cands[win].dist || (cands[r].dist == cands[win].dist && cands[r].gidx < cands[win].gidx))) win = r;
+    s_win = win;
+    if (win < 0) st->done = 1;
+  }
+  __syncthreads();
+  const int win = s_win;
+  if (win < 0) return;
+  const int kk = st->kk;
+  if (threadIdx.x < 192) {
+    cur_row[threadIdx.x] = cands[win].row[threadIdx.x];
+    cent[(int64_t)kk * 192 + threadIdx.x] = (double)cands[win].row[threadIdx.x];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) st->kk = kk + 1;
+}
+__global__ void k_kmd_pack(const u64 *__restrict__ sums, const u64 *__restrict__ cnts, const Seg *__restrict__ segs, int k, u64 *__restrict__ red) {
+  const int total = k * 192 + k + 1;  // sums | counts | number of points that changed cluster
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
+    red[e] = e < k * 192 ? sums[e] : e < k * 192 + k ? cnts[e - k * 192] : (u64)(long long)segs[0].changed;
+}
+__global__ __launch_bounds__(1024) void k_kmd_update(const u64 *__restrict__ red, Seg *__restrict__ segs, int k, double *__restrict__ cent) {
+  const bool changed = red[k * 192 + k] != 0;
+  if (changed)
+    for (int e = threadIdx.x; e < k * 192; e += 1024) {
+      const u64 cn = red[k * 192 + e / 192];
+      if (cn > 0) cent[e] = __ddiv_rn((double)(long long)red[e], (double)(long long)cn);
+    }
+  if (threadIdx.x == 0) segs[0].changed = 0;
+}
+
+int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n, int64_t global_begin, int npal, int max_iter, void *out_pal_idx_local,
+                       const Collectives &co, hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536 (tilingencoder.pas:2959)", npal);
+  TM_CHECK(co.world >= 1 && co.allgather && co.allreduce_sum_i64, TM_E_INVAL, "palettize: collectives missing");
+  const int k = npal, d = 192;
+  const int32_t *pts = (const int32_t *)feat_local;
+  const uint32_t *w = (const uint32_t *)use_local;
+  const int64_t n1 = std::max<int64_t>(n, 1);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  DevBuf dsegs, mind, partial, sums, cnts, cent, assign, cur_row, cand, cands, state, red, ptsc, quiet;
+  Seg hs;
+  memset(&hs, 0, sizeof(hs));
+  hs.begin = 0; hs.count = n; hs.nseg = 1; hs.blk_first = 0; hs.blk_count = 1;
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+  TM_TRY(dsegs.alloc(sizeof(Seg))); TM_TRY(mind.alloc((size_t)n1 * 8)); TM_TRY(partial.alloc(sizeof(BestKey) * (size_t)nblk));
+  TM_TRY(sums.alloc((size_t)k * d * 8)); TM_TRY(cnts.alloc((size_t)k * 8)); TM_TRY(cent.alloc((size_t)k * d * 8)); TM_TRY(assign.alloc((size_t)n1 * 4));
+  TM_TRY(cur_row.alloc(192 * 4)); TM_TRY(cand.alloc(sizeof(FfCand))); TM_TRY(cands.alloc(sizeof(FfCand) * (size_t)co.world)); TM_TRY(state.alloc(sizeof(FfState)));
+  TM_TRY(red.alloc((size_t)(k * d + k + 1) * 8)); TM_TRY(quiet.alloc(4));
+  TM_HIP(hipMemsetAsync(mind.p, 0x7f, (size_t)n1 * 8, stream));
+  TM_HIP(hipMemsetAsync(sums.p, 0, (size_t)k * d * 8, stream));
+  TM_HIP(hipMemsetAsync(cnts.p, 0, (size_t)k * 8, stream));
+  TM_HIP(hipMemsetAsync(cent.p, 0, (size_t)k * d * 8, stream));
+  TM_HIP(hipMemsetAsync(assign.p, 0xff, (size_t)n1 * 4, stream));
+  TM_HIP(hipMemsetAsync(state.p, 0, sizeof(FfState), stream));
+  TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
+  // farthest-first: point 0 of the whole set, then k - 1 picks, each settled among one candidate per process
+  FfState hst{0, 0};
+  for (int c = 0; c < k; c++) {
+    if (c > 0)
+      hipLaunchKernelGGL(k_ffd_update, dim3(nblk), dim3(256), 0, stream, pts, n, cur_row.as<int32_t>(), mind.as<long long>(), partial.as<BestKey>());
+    hipLaunchKernelGGL(k_ffd_cand, dim3(1), dim3(256), 0, stream, partial.as<BestKey>(), nblk, pts, n, (long long)global_begin, c == 0 ? 1 : 0, cand.as<FfCand>());
+    TM_HIP(hipGetLastError());
+    TM_TRY(co.allgather(cand.p, cands.p, (int64_t)sizeof(FfCand)));
+    hipLaunchKernelGGL(k_ffd_pick, dim3(1), dim3(256), 0, stream, cands.as<FfCand>(), co.world, k, state.as<FfState>(), cur_row.as<int32_t>(), cent.as<double>());
+    TM_HIP(hipGetLastError());
+    if ((c & 3) == 3 || c == k - 1) {  // "no distinct point left" ends the picks early; looked at every few picks
+      TM_HIP(hipMemcpyAsync(&hst, state.p, sizeof(FfState), hipMemcpyDeviceToHost, stream));
+      TM_HIP(hipStreamSynchronize(stream));
+      if (hst.done) break;
+    }
+  }
+  TM_HIP(hipMemcpyAsync(&hst, state.p, sizeof(FfState), hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  hs.kk = hst.kk;
+  hs.init_done = 1;
+  TM_CHECK(hs.kk >= 1, TM_E_INVAL, "palettize: no point anywhere");
+  TM_HIP(hipMemcpyAsync(dsegs.p, &hs, sizeof(Seg), hipMemcpyHostToDevice, stream));
+  // Lloyd: local assignment (the sums of this process's points are carried with +/- deltas), all-reduce, identical update everywhere
+  TM_TRY(ptsc.alloc((size_t)n1 * 192 * 4));
+  if (n > 0) hipLaunchKernelGGL(k_chunk_major, dim3((unsigned)std::min<int64_t>((n * 48 + 255) / 256, 8192)), dim3(256), 0, stream, pts, n, ptsc.as<int32_t>());
+  int ppt192 = 1, nblk192 = 1, rows192 = 256, lds_delta192 = 0;
+  size_t lds192 = 0;
+  {
+    const int64_t slots = std::max<int64_t>(1, (int64_t)cus * 2);
+    const int64_t per_slot = (n1 + slots - 1) / slots;
+    const int64_t rounds = (per_slot + 256 * 5 - 1) / (256 * 5);
+    rows192 = (int)std::max<int64_t>(1, (per_slot + rounds - 1) / rounds);
+    ppt192 = (rows192 + 255) / 256;
+    nblk192 = (int)((n1 + rows192 - 1) / rows192);
+    const size_t fixed = (size_t)A_DCH * KCH * 8 + (size_t)256 * ppt192 * (A_DCH + 1) * 4 + (size_t)(256 * ppt192 * 3 + 1) * 4;
+    lds_delta192 = fixed + (size_t)k * 193 * 8 <= 150 * 1024 ? 1 : 0;
+    lds192 = fixed + (lds_delta192 ? (size_t)k * 193 * 8 : 0) + 16;
+  }
+  for (int it = 0; it < max_iter; it++) {
+    if (n > 0)
+      launch_assign192(ppt192, dim3(nblk192, 1), lds192, stream, pts, ptsc.as<int32_t>(), n, w, dsegs.as<Seg>(), k, cent.as<double>(), assign.as<int32_t>(),
+                       sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192, quiet.as<int>());
+    hipLaunchKernelGGL(k_kmd_pack, dim3(32), dim3(256), 0, stream, sums.as<u64>(), cnts.as<u64>(), dsegs.as<Seg>(), k, red.as<u64>());
+    TM_HIP(hipGetLastError());
+    TM_TRY(co.allreduce_sum_i64(red.p, (int64_t)k * d + k + 1));
+    hipLaunchKernelGGL(k_kmd_update, dim3(1), dim3(1024), 0, stream, red.as<u64>(), dsegs.as<Seg>(), k, cent.as<double>());
+    u64 changed = 0;
+    TM_HIP(hipMemcpyAsync(&changed, red.as<u64>() + (size_t)k * d + k, 8, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    if (changed == 0) break;
+  }
+  // palettes ranked by number of tiles over all processes, descending (tilingencoder.pas:4229-4234); ties keep the initial order
+  DevBuf cnt, lut;
+  TM_TRY(cnt.alloc((size_t)npal * 8)); TM_TRY(lut.alloc((size_t)npal * 4));
+  TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)npal * 8, stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 512)), dim3(256), npal <= 8192 ? (size_t)npal * 4 : 0, stream,
+                       assign.as<int32_t>(), n, npal, cnt.as<u64>());
+  TM_HIP(hipGetLastError());
+  TM_TRY(co.allreduce_sum_i64(cnt.p, npal));
+  std::vector<u64> hc(npal);
+  TM_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)npal * 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  std::vector<int> ord(npal), hl(npal);
+  for (int i = 0; i < npal; i++) ord[i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hc[a] > hc[b]; });
+  for (int i = 0; i < npal; i++) hl[ord[i]] = i;
+  TM_HIP(hipMemcpyAsync(lut.p, hl.data(), (size_t)npal * 4, hipMemcpyHostToDevice, stream));
+  if (n > 0)
+    hipLaunchKernelGGL(k_apply_lut, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, assign.as<int32_t>(), n, lut.as<int32_t>(),
+                       (int32_t *)out_pal_idx_local);
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(stream));
+  return TM_OK;
+}
+
 // ---- QuantizeUsingYakmo + DoQuantization -----------------------------------------------------------------------
 // pixel key = palette << 24 | G << 16 | R << 8 | B  (CompareDSPixel: G, then R, then B; tilingencoder.pas:1046-1056)
 __global__ void k_pixel_keys(const uint32_t *__restrict__ tiles, const int32_t *__restrict__ pal_idx, int64_t n, u64 *__restrict__ keys) {
@@ -1113,7 +1318,13 @@ static void rgb_to_hsv_bytes(int rr, int gg, int bb, int &h, int &s, int &v) {  
 
 int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                           hipStream_t stream) {
+  return run_quantize_palettes_part(tiles, pal_idx, n, npal, pal_size, max_iter, out_palettes, 0, 1, stream);
+}
+
+int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
+                               int pal_rank, int pal_world, hipStream_t stream) {
   TM_TRY(require_device());
+  TM_CHECK(pal_world >= 1 && pal_rank >= 0 && pal_rank < pal_world, TM_E_INVAL, "quantize: bad palette share %d of %d", pal_rank, pal_world);
   TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536", npal);
   TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
   std::vector<int32_t> hpal((size_t)npal * pal_size, TM_NULL_COLOR);  // unused slots: cDitheringNullColor (4557-4558)
@@ -1146,7 +1357,7 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
     TM_HIP(hipStreamSynchronize(stream));
     std::vector<int64_t> sb(npal, 0), sc(npal, 0);
     {
-      for (int p = 0; p < npal; p++) { sb[p] = lb[p]; sc[p] = lb[p + 1] - lb[p]; }
+      for (int p = 0; p < npal; p++) { sb[p] = lb[p]; sc[p] = p % pal_world == pal_rank ? lb[p + 1] - lb[p] : 0; }  // other processes' palettes: empty segments
       TM_CHECK(lb[npal] == (long long)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
       if (getenv("TM_KM_DEBUG")) { fprintf(stderr, "quantize: %u unique colours, per palette:", nu); for (int p = 0; p < npal; p++) fprintf(stderr, " %lld", (long long)sc[p]); fprintf(stderr, "\n"); }
     }
@@ -1196,6 +1407,10 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
       for (size_t i = 0; i < items.size(); i++) hpal[(size_t)p * pal_size + i] = (items[i].b << 16) | (items[i].g << 8) | items[i].r;
     }
   }
+  if (pal_world > 1)
+    for (int p = 0; p < npal; p++)
+      if (p % pal_world != pal_rank)
+        for (int i = 0; i < pal_size; i++) hpal[(size_t)p * pal_size + i] = 0;
   TM_HIP(hipMemcpyAsync(out_palettes, hpal.data(), hpal.size() * 4, hipMemcpyHostToDevice, stream));
   TM_HIP(hipStreamSynchronize(stream));
   return TM_OK;

@@ -1,17 +1,33 @@
 """One process per GPU orchestration of TTilingEncoder.Run(esAll) (tilingencoder.pas:5529-5554).
 
-Where the path shards: the frame tiles are independent queries of the KNN branch of
-TFrame.Reconstruct (DoXY, tilingencoder.pas:1464-1659), >95 % of the work.  Every rank therefore runs Load..Dither on
-the whole clip (small, deterministic, bit-identical on all ranks -- no collective needed to agree on the global tile
-set, palettes or dithered tiles), matches only ITS frame range against the full database, and the per-frame results
-are merged with one all-reduce(MAX) (other ranks hold -1) over RCCL/xGMI: 2 x Q x 4 bytes (3 x with the extended-palette
-re-rank, whose PalIdx is per item).  Reindex then runs
-everywhere on the merged tile maps.  Dither is sharded by global tile (its tiles are independent: every rank dithers a
-contiguous share, one all-reduce(SUM) of the 64-byte index tiles puts the whole set on every rank).  With motion prediction on, PredictMotion is sharded by frame too (merged with
-all-reduce(SUM), other ranks hold 0) and Reconstruct by whole key-frame groups, the unit that chains (1496).  The collective calls go through `torch.distributed`, so the same code is
-exercised on CPU with gloo in tests/test_distributed_cpu.py (there with an oracle-backed stand-in for the encoder).
+Where the path shards, with `world` processes on one node and RCCL over xGMI underneath torch.distributed:
+
+  Load            frames are independent (1293-1411): every process loads its own contiguous frame range (+ the frame before it, for the
+                  first correlation); mirror flags and Pearson sums are merged with all-reduce(SUM) (owner holds the value, others 0).
+  Reduce          exact dedup of the process's own frame tiles, ALL-GATHER of every process's distinct tiles (tile, use count, mirror flags),
+                  exact dedup of the union on every process (identical result everywhere).
+  PreparePalettes tile -> palette clustering as data-parallel Lloyd over each process's share of the global tiles: farthest-first picks
+                  settled by an all-gather of one candidate per process, one all-reduce(SUM) of the exact integer sums + counts per
+                  iteration; palette colours by palette (independent tasks, 1864), assembled with an all-reduce(SUM); the host search of
+                  OptimizePalettes is replicated (P x 16 colours).
+  Dither          by share of the global tiles (one DitherTile per tile, 2690), all-reduce(SUM) of the 64-byte index tiles.
+  Reconstruct     database rows (int16 features of the dithered tiles) built per share and ALL-GATHERED (T x 384 bytes: the north star's
+                  all-gather); every process then matches ITS frames against the whole database; the items are merged by all-reduce.
+  Reindex         replicated on the merged tile maps (small).
+
+The merges live INSIDE the library's steps (tm_set_collective): this module hands the encoder a callback that runs each collective
+with torch.distributed and keeps the shard arithmetic.  With motion prediction on, Load and Reduce stay replicated (the threshold
+search of Reduce needs every frame's prediction error), PredictMotion shards by frame and Reconstruct by whole key-frame groups,
+the unit that chains (1496).  The same code runs under gloo on CPU tensors in tests/test_distributed_cpu.py (there with an
+oracle-backed stand-in for the encoder).
 """
+import ctypes
+
+import torch
 import torch.distributed as dist
+
+KIND_SUM_I32, KIND_MAX_I32, KIND_SUM_I64, KIND_ALLGATHER = 0, 1, 2, 3
+_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 
 
 def frame_shard(nframes, rank, world):
@@ -38,41 +54,107 @@ def describe(world):
     """what bench.py prints as config.parallelism"""
     if world <= 1:
         return "1 GPU"
-    return ("%d ranks, one per GPU: PredictMotion / Dither / Reconstruct sharded (frames, global tiles, frames); merges by all-reduce over RCCL; "
-            "Load, Reduce, PreparePalettes and the database side of Reconstruct replicated") % world
+    return ("%d ranks, one per GPU: Load / Reduce / PreparePalettes / Dither / Reconstruct sharded (frames; local dedup + all-gather of distinct tiles; "
+            "data-parallel Lloyd with an all-reduce per iteration + palette-parallel quantisation; global tiles; all-gather of the database rows + "
+            "query frames); Reindex and the host search of OptimizePalettes replicated") % world
+
+
+class Collective:
+    """The collectives the library asks for, over a torch.distributed group (NCCL = RCCL on ROCm, or gloo on CPU tensors)."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.calls = {KIND_SUM_I32: 0, KIND_MAX_I32: 0, KIND_SUM_I64: 0, KIND_ALLGATHER: 0}
+        self.bytes = 0
+        self._cb = _CB(self._from_library)  # kept alive with the object
+
+    # ---- tensor level (also used by the CPU stand-in of the tests)
+    def allreduce_sum(self, t):
+        self.calls[KIND_SUM_I64 if t.dtype == torch.int64 else KIND_SUM_I32] += 1
+        self.bytes += t.numel() * t.element_size()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def allreduce_max(self, t):
+        self.calls[KIND_MAX_I32] += 1
+        self.bytes += t.numel() * t.element_size()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def allgather(self, send, recv=None):
+        """equal-sized pieces: recv = world x send"""
+        self.calls[KIND_ALLGATHER] += 1
+        if recv is None:
+            recv = torch.empty((self.world * send.numel(),), dtype=send.dtype, device=send.device)
+        self.bytes += recv.numel() * recv.element_size()
+        # as bytes: what travels is opaque to the collective (and gloo has no 16-bit integer types)
+        dist.all_gather_into_tensor(recv.reshape(-1).view(torch.uint8), send.contiguous().reshape(-1).view(torch.uint8), group=self.group)
+        return recv
+
+    def allgather_var(self, send):
+        """pieces of different lengths along dim 0 -> their concatenation in rank order (what the library's gather_var does)"""
+        n = torch.tensor([send.shape[0]], dtype=torch.int64, device=send.device)
+        counts = self.allgather(n).tolist()
+        mx = max(counts)
+        if mx == 0:
+            return send[:0], counts
+        pad = torch.zeros((mx,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        pad[: send.shape[0]] = send
+        got = self.allgather(pad).reshape((self.world, mx) + tuple(send.shape[1:]))
+        return torch.cat([got[r, : counts[r]] for r in range(self.world)]), counts
+
+    # ---- pointer level: what tm_set_collective calls
+    @staticmethod
+    def _view(ptr, count, typestr):
+        class _V:
+            __cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(_V(), device="cuda")
+
+    def _from_library(self, user, kind, buf, recv, count):
+        try:
+            if kind == KIND_SUM_I32:
+                self.allreduce_sum(self._view(buf, count, "<i4"))
+            elif kind == KIND_MAX_I32:
+                self.allreduce_max(self._view(buf, count, "<i4"))
+            elif kind == KIND_SUM_I64:
+                self.allreduce_sum(self._view(buf, count, "<i8"))
+            elif kind == KIND_ALLGATHER:
+                self.allgather(self._view(buf, count, "|u1"), self._view(recv, count * self.world, "|u1"))
+            else:
+                return -1
+            # the library's stream is not torch's: the result must be in place before the library's next kernel reads it
+            torch.cuda.current_stream().synchronize()
+            return 0
+        except Exception as exc:  # noqa: BLE001  (must not unwind through the C frame)
+            import traceback
+            traceback.print_exc()
+            self.error = exc
+            return -2
+
+    @property
+    def callback(self):
+        return self._cb
 
 
 def run_all(enc, nframes, rank=0, world=1, group=None):
-    """Run(esAll) over `world` processes.  `enc` needs Run/SetQueryShard/DeviceArray/SyncTileMap/KeyFrames and the
-    MotionPredictRadius setting (TilingEncoder or a stand-in)."""
+    """Run(esAll) over `world` processes.  `enc` needs Run/SetCollective/SetQueryShard/KeyFrames and the MotionPredictRadius
+    setting (TilingEncoder or a stand-in)."""
     from .encoder import TEncoderStep as S
-    enc.Run(S.esLoad)
+    coll = getattr(enc, "_collective", None)
+    if coll is None or coll.world != world or coll.rank != rank or coll.group is not group:
+        coll = Collective(rank, world, group)
+        enc.SetCollective(rank, world, coll)  # world == 1: plain single-process run
+        enc._collective = coll
     motion = int(enc.MotionPredictRadius) > 0
     first, count = frame_shard(nframes, rank, world)
     enc.SetQueryShard(first, count)
+    enc.Run(S.esLoad)
     enc.Run(S.esPredictMotion)  # frames are independent (each is searched in the source pixels of its neighbour)
-    if world > 1 and motion:
-        for which in (6, 4, 5):  # best error, PredictedX, PredictedY: owner holds the value, everyone else 0
-            dist.all_reduce(enc.DeviceArray(which), op=dist.ReduceOp.SUM, group=group)
-    for step in (S.esReduce, S.esPreparePalettes):
-        enc.Run(step)
-    # DitherTile is independent per global tile (2690): every rank dithers a contiguous share of the tiles, the others stay 0
-    enc.SetDitherShard(rank, world)
+    enc.Run(S.esReduce)
+    enc.Run(S.esPreparePalettes)
     enc.Run(S.esDither)
-    if world > 1:
-        dist.all_reduce(enc.DeviceArray(7), op=dist.ReduceOp.SUM, group=group)
     if motion:
         first, count = keyframe_shard(enc.KeyFrames(), nframes, rank, world)
         enc.SetQueryShard(first, count)
     enc.Run(S.esReconstruct)
-    if world > 1:
-        # TileIdx, error: owner holds values >= 0 (errors < 2^31) or -1 (perfect prediction), everyone else -1.  With
-        # FrameTilingExtendedPaletteUsage the item's palette is the re-rank's own choice (1591-1608), not the tile's: merged the same way
-        epu = bool(getattr(enc, "FrameTilingExtendedPaletteUsage", False))
-        for which in (0, 1, 2) if epu else (0, 1):
-            dist.all_reduce(enc.DeviceArray(which), op=dist.ReduceOp.MAX, group=group)
-        if motion:
-            for which in (3, 4, 5):  # IsPredicted, PredictedX/Y of the redo: everyone else 0
-                dist.all_reduce(enc.DeviceArray(which), op=dist.ReduceOp.SUM, group=group)
-        enc.SyncTileMap()
     enc.Run(S.esReindex)

@@ -68,6 +68,7 @@ _ENC_SIGS = {
     "tm_reload_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_set_dither_shard": (c_int, [c_void_p, c_int, c_int]),
+    "tm_set_collective": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
     "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
@@ -219,6 +220,12 @@ class TilingEncoder:
     # -- multi-GPU plumbing (one process per GPU; collectives stay in the host, see tiler_amd/distributed.py)
     def SetQueryShard(self, first_frame, frame_count):
         check(self._L.tm_set_query_shard(c_void_p(self._h), first_frame, frame_count))
+
+    def SetCollective(self, rank, world, coll):
+        """one process per GPU: `coll` (tiler_amd.distributed.Collective) runs the collectives the steps ask for; world == 1 clears it"""
+        self._coll_ref = coll  # the ctypes callback must outlive the encoder's use of it
+        cb = ctypes.cast(coll.callback, c_void_p) if (coll is not None and world > 1) else None
+        check(self._L.tm_set_collective(c_void_p(self._h), int(rank), int(world), cb, None))
 
     def SetDitherShard(self, rank, world):
         """Dither only tiles [T * rank / world, T * (rank + 1) / world); the others stay 0 in DeviceArray(7) for an all-reduce(SUM)"""
