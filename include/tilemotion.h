@@ -235,6 +235,17 @@ TM_API int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, in
 TM_API int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx,
                               void *stream);
 
+/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094; unreachable in the reference snapshot, named by the north star): k-modes on rows
+ * of cKModesFeatureCount = 80 bytes (kmodes.pas:15; the reference's asm hard-codes 80, :338-342), dissimilarity = sum |a-b| + 2048 per
+ * differing byte (:248-259), farthest-first initialisation from a starting point (:694-772), Huang's online mode update (:774-803),
+ * empty-cluster repair with the LCG of :88-92 seeded $42381337 (:933), stop on cost non-decrease with three graces (:1040-1049).
+ * HOST pointers, like the Pascal arrays: rows [n][80] with values < num_modalities, labels int32 [n] (0-based, as the code returns
+ * them), centroids [num_clusters][80].  num_init <= 0: one run from point -num_init; > 0: that many runs from spread starting points
+ * (:952-964), the cheapest kept.  max_iter < 0: no limit (aMaxIter = -1).  The dissimilarity scans run on the GPU (v_sad_u8), the
+ * serial bookkeeping on the calling thread. */
+TM_API int tm_stage_kmodes(const uint8_t *host_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *host_labels,
+                           uint8_t *host_centroids, uint64_t *host_cost, int *host_iters, void *stream);
+
 /* A11: OptimizePalettes (:4309-4432), host arithmetic on HOST memory (P x PaletteSize colours); in place. */
 TM_API int tm_optimize_palettes_host(int32_t *palettes, int pal_count, int pal_size, int *sweeps);
 

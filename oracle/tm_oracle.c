@@ -1556,3 +1556,167 @@ void tmo_epu_rerank_batch(const int16_t *q, int64_t nq, const int32_t *knn_idx, 
   for (int64_t i = 0; i < nq; i++)
     tmo_epu_rerank(q + i * 192, knn_idx + i * k, k, pal_px, tile_pal_idx, ntiles, palettes, pal_size, out_tile + i, out_pal + i, out_err + i);
 }
+
+/* ------------------------------------------------------------------ A17 k-modes (kmodes.pas; unreachable in the reference, named by north_star)
+ * TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of cKModesFeatureCount = 80 bytes (the asm paths hard-code 80: 338-342).
+ * Restated step by step: MatchingDissim (248-259: sum |a-b| + 2048 per differing byte), GetMinMatchingDissim (the LAST minimum
+ * wins: `dis <= best`, 272 / asm `ja worst` 414), InitFarthestFirst (694-772: the LAST largest min-distance among unused points wins,
+ * `>=` at 759), the initial assignment and modes (978-1011: first largest count wins, GetMaxValueIndex 155-167; an empty
+ * cluster draws one RandInt per attribute), KModesIter (851-921: bins of 960 points scored against the centroids as they stand at
+ * the start of the bin, then moved one by one with Huang's online mode update MovePointCat 774-803 and the empty-cluster repair
+ * with the LCG RandInt 88-92), the stopping rule (1040-1049: cost not below the previous one, with three graces while within
+ * prevcost div 1000) and the best-cost bookkeeping (1051-1057).  Parity unpinned: the reference holds no vector for it. */
+static uint32_t kmodes_randint(uint32_t range, uint32_t *seed) { /* kmodes.pas:88-92 */
+  *seed = (uint32_t)((int32_t)(*seed * 0x08088405u) + 1);
+  return (uint32_t)(((uint64_t)*seed * (uint64_t)range) >> 32);
+}
+static uint64_t kmodes_dissim(const uint8_t *a, const uint8_t *b) { /* kmodes.pas:248-259 */
+  uint64_t r = 0;
+  for (int i = 0; i < 80; i++) {
+    if (a[i] != b[i]) r += (uint64_t)1 << 11;
+    r += (uint64_t)llabs((long long)a[i] - (long long)b[i]);
+  }
+  return r;
+}
+static int kmodes_argmin(const uint8_t *cent, int k, const uint8_t *row, uint64_t *best_out) { /* kmodes.pas:263-281 */
+  int res = -1;
+  uint64_t best = UINT64_MAX;
+  for (int i = 0; i < k; i++) {
+    const uint64_t d = kmodes_dissim(cent + (size_t)i * 80, row);
+    if (d <= best) { best = d; res = i; }
+  }
+  *best_out = best;
+  return res;
+}
+typedef struct {
+  const uint8_t *x; int64_t n; int k, nmod;
+  int32_t *memb; int64_t *members; uint8_t *cent; int32_t *freq; /* [k][80][nmod] */
+} kmodes_t;
+static int kmodes_maxidx(const int32_t *arr, int n) { /* GetMaxValueIndex, kmodes.pas:155-167 */
+  int res = -1, best = INT32_MIN;
+  for (int i = 0; i < n; i++) if (arr[i] > best) { best = arr[i]; res = i; }
+  return res;
+}
+static void kmodes_move(kmodes_t *s, int64_t ipoint, int to, int from) { /* MovePointCat, kmodes.pas:774-803 */
+  const uint8_t *p = s->x + ipoint * 80;
+  s->memb[ipoint] = to;
+  s->members[to]++;
+  s->members[from]--;
+  for (int a = 0; a < 80; a++) {
+    const int cur = p[a];
+    int32_t *tc = s->freq + ((size_t)to * 80 + a) * s->nmod, *fc = s->freq + ((size_t)from * 80 + a) * s->nmod;
+    tc[cur]++;
+    if (tc[s->cent[(size_t)to * 80 + a]] < tc[cur]) s->cent[(size_t)to * 80 + a] = (uint8_t)cur;
+    fc[cur]--;
+    if (s->cent[(size_t)from * 80 + a] == cur) s->cent[(size_t)from * 80 + a] = (uint8_t)kmodes_maxidx(fc, s->nmod);
+  }
+}
+int tmo_kmodes(const uint8_t *x, int64_t n, int k, int num_init, int nmod, int max_iter, int32_t *labels_out, uint8_t *cent_out, uint64_t *cost_out,
+               int *iters_out) {
+  uint32_t seed = 0x42381337u;
+  if (n <= 0 || k <= 0) return 0;
+  if (max_iter < 0) max_iter = INT32_MAX;
+  const int nruns = num_init <= 0 ? 1 : num_init;
+  int64_t *starts = (int64_t *)malloc(sizeof(int64_t) * (size_t)nruns);
+  if (num_init <= 0) starts[0] = -num_init;
+  else { /* 952-964: Single arithmetic */
+    const float ratio = (float)pow((double)n, 1.0 / (double)num_init); /* power(NumPoints, 1 / ANumInit) narrowed to Single */
+    float acc = 1.0f;
+    for (int i = 0; i < nruns; i++) {
+      starts[i] = (int64_t)pas_round((double)acc) - 1;
+      if (i > 0 && starts[i] <= starts[i - 1]) starts[i] = starts[i - 1] + 1 < n - 1 ? starts[i - 1] + 1 : n - 1;
+      acc = acc * ratio;
+    }
+  }
+  kmodes_t s;
+  s.x = x; s.n = n; s.k = k; s.nmod = nmod;
+  s.memb = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  s.members = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k + 1)) + 1; /* members[-1]: points not assigned yet */
+  s.cent = (uint8_t *)malloc((size_t)k * 80);
+  s.freq = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * 80 * nmod);
+  int32_t *clust = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *bestm = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  uint64_t *dis = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n), *mind = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  uint8_t *used = (uint8_t *)malloc((size_t)n), *bestc = (uint8_t *)malloc((size_t)k * 80);
+  uint64_t all_best = UINT64_MAX;
+  int all_iters = 0;
+  for (int run = 0; run < nruns; run++) {
+    /* InitFarthestFirst, 694-772 */
+    memset(s.cent, 0xff, (size_t)k * 80);
+    memset(used, 0, (size_t)n);
+    for (int64_t i = 0; i < n; i++) mind[i] = UINT64_MAX;
+    int64_t far = starts[run];
+    for (int c = 0; c < k; c++) {
+      if (c > 0) {
+        uint64_t mx = 0;
+        far = starts[run];
+        for (int64_t i = 0; i < n; i++) if (mind[i] >= mx && !used[i]) { mx = mind[i]; far = i; }
+      }
+      memcpy(s.cent + (size_t)c * 80, x + far * 80, 80);
+      used[far] = 1;
+      for (int64_t i = 0; i < n; i++) if (!used[i]) { const uint64_t d = kmodes_dissim(x + far * 80, x + i * 80); if (d < mind[i]) mind[i] = d; }
+    }
+    /* initial assignment and modes, 978-1011 */
+    memset(s.freq, 0, sizeof(int32_t) * (size_t)k * 80 * nmod);
+    for (int c = -1; c < k; c++) s.members[c] = 0;
+    for (int64_t i = 0; i < n; i++) {
+      uint64_t d;
+      s.memb[i] = kmodes_argmin(s.cent, k, x + i * 80, &d);
+      s.members[s.memb[i]]++;
+      for (int a = 0; a < 80; a++) s.freq[((size_t)s.memb[i] * 80 + a) * nmod + x[i * 80 + a]]++;
+    }
+    for (int c = 0; c < k; c++) {
+      if (s.members[c] == 0) { for (int a = 0; a < 80; a++) s.cent[(size_t)c * 80 + a] = x[(int64_t)kmodes_randint((uint32_t)n, &seed) * 80 + a]; }
+      else for (int a = 0; a < 80; a++) s.cent[(size_t)c * 80 + a] = (uint8_t)kmodes_maxidx(s.freq + ((size_t)c * 80 + a) * nmod, nmod);
+    }
+    int itr = 0, converged = 0, worse = 0, bestitr = 0;
+    uint64_t prevcost = UINT64_MAX, bestcost = UINT64_MAX;
+    while (itr < max_iter && !converged) {
+      itr++;
+      /* KModesIter, 851-921 */
+      int moves = 0;
+      uint64_t cost = 0;
+      for (int64_t b0 = 0; b0 < n; b0 += 960) {
+        const int64_t b1 = b0 + 960 < n ? b0 + 960 : n;
+        for (int64_t i = b0; i < b1; i++) clust[i] = kmodes_argmin(s.cent, k, x + i * 80, &dis[i]);
+        for (int64_t i = b0; i < b1; i++) {
+          cost += dis[i];
+          if (s.memb[i] != clust[i]) {
+            moves++;
+            const int old = s.memb[i];
+            kmodes_move(&s, i, clust[i], old);
+            if (s.members[old] == 0) { /* CountClusterMembers(old_clust) = 0 */
+              int from = 0;
+              int64_t mc = 0;
+              for (int c = 0; c < k; c++) if (s.members[c] >= mc) { mc = s.members[c]; from = c; } /* GetMaxClusterMembers: last largest */
+              const uint32_t pick = kmodes_randint((uint32_t)mc, &seed);
+              int64_t r = -1, cnt = 0;
+              for (int64_t j = 0; j < n; j++) if (s.memb[j] == from) { if (cnt == (int64_t)pick) { r = j; break; } cnt++; }
+              kmodes_move(&s, r, old, from);
+            }
+          }
+        }
+      }
+      converged = cost >= prevcost;
+      if (converged) { /* SameValue(cost, prevcost, prevcost div 1000) in floating point, 1041 */
+        const double a = (double)cost, b = (double)prevcost;
+        double eps = (double)(prevcost / 1000);
+        if (eps == 0) { const double m = fabs(a) < fabs(b) ? fabs(a) : fabs(b); eps = m * 1e-12 > 1e-12 ? m * 1e-12 : 1e-12; }
+        const int same = a > b ? (a - b) <= eps : (b - a) <= eps;
+        if (same) { worse++; if (worse < 3) converged = 0; }
+      }
+      converged = converged || moves == 0;
+      if (cost < bestcost) { bestitr = itr; bestcost = cost; memcpy(bestm, s.memb, sizeof(int32_t) * (size_t)n); memcpy(bestc, s.cent, (size_t)k * 80); }
+      prevcost = cost;
+    }
+    if (bestcost < all_best) { /* 1078-1085: the first run with the strictly smallest cost */
+      all_best = bestcost;
+      all_iters = bestitr;
+      memcpy(labels_out, bestm, sizeof(int32_t) * (size_t)n);
+      memcpy(cent_out, bestc, (size_t)k * 80);
+    }
+  }
+  if (cost_out) *cost_out = all_best;
+  if (iters_out) *iters_out = all_iters;
+  free(starts); free(s.memb); free(s.members - 1); free(s.cent); free(s.freq); free(clust); free(bestm); free(dis); free(mind); free(used); free(bestc);
+  return k;
+}

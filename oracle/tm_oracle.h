@@ -23,6 +23,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
+int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
+               uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
+
 #endif
 
 enum { TMO_TILE_W = 8, TMO_TILE_PX = 64, TMO_CPNS = 3, TMO_DCT = 192 };
@@ -160,5 +164,13 @@ int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, 
 
 #ifdef __cplusplus
 }
+/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
+int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
+               uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
+
 #endif
+/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
+int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
+               uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
+
 #endif

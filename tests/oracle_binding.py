@@ -141,6 +141,14 @@ class Oracle:
         self.L.tmo_knn1(_p(q), q.shape[0], _p(db), db.shape[0], _p(idx), _p(err))
         return idx, err
 
+    def kmodes(self, rows, k, num_init=0, nmod=256, max_iter=-1):
+        rows = np.ascontiguousarray(rows, np.uint8)
+        labels = np.zeros(rows.shape[0], np.int32)
+        cent = np.zeros((k, 80), np.uint8)
+        cost, iters = ctypes.c_uint64(), ctypes.c_int()
+        self.L.tmo_kmodes(_p(rows), ctypes.c_int64(rows.shape[0]), k, num_init, nmod, max_iter, _p(labels), _p(cent), ctypes.byref(cost), ctypes.byref(iters))
+        return labels, cent, cost.value, iters.value
+
     def kdtree_build(self, db, bucket=32):
         """exact kd-tree over db (kept alive by the returned handle's reference to the array)"""
         db = np.ascontiguousarray(db, np.int16)

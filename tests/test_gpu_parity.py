@@ -595,3 +595,36 @@ def test_knn_topk_matches_brute_force_at_scale():
     torch.cuda.synchronize()
     assert torch.equal(err, berr) and torch.equal(idx, bidx)
     assert int(idx[0, 0]) == 999 and int(err[0, 0]) == 0
+
+
+def _kmodes_rows(case, rng):
+    if case == "clusters":  # six well separated prototypes + per-byte noise: the usual shape
+        proto = rng.integers(0, 32, size=(6, 80))
+        rows = proto[rng.integers(0, 6, size=6000)].copy()
+        noise = rng.random(rows.shape) < 0.15
+        rows[noise] = rng.integers(0, 32, size=int(noise.sum()))
+        return rows.astype(np.uint8), 8, 32
+    if case == "uniform":   # no structure: many moves, long runs, modes change in almost every bin
+        return rng.integers(0, 256, size=(3000, 80)).astype(np.uint8), 12, 256
+    if case == "identical":  # every row the same: k - 1 clusters start empty -> RandInt modes, empty-cluster repairs
+        return np.tile(rng.integers(0, 8, size=(1, 80)), (2500, 1)).astype(np.uint8), 5, 8
+    if case == "few-points":  # fewer points than clusters: the farthest-first pick runs out of unused points
+        return rng.integers(0, 4, size=(3, 80)).astype(np.uint8), 6, 4
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("num_init", [0, -7, 3])
+@pytest.mark.parametrize("case", ["clusters", "uniform", "identical", "few-points"])
+def test_kmodes(oracle, case, num_init):
+    """A17: TKModes.ComputeKModes (kmodes.pas:923-1094) -- labels, modes, cost and the best run's iteration count equal the oracle's
+    restatement on structured, structureless and degenerate inputs, from point 0, from point 7 and over three spread starting points"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(len(case) * 10 + 3)
+    rows, k, nmod = _kmodes_rows(case, rng)
+    if num_init < 0 and rows.shape[0] <= -num_init:
+        pytest.skip("starting point outside the data")
+    exp_labels, exp_cent, exp_cost, exp_iters = oracle.kmodes(rows, k, num_init, nmod, 60)
+    labels, cent, cost, iters = stages.kmodes(rows, k, num_init, nmod, 60)
+    assert cost == exp_cost and iters == exp_iters
+    assert np.array_equal(cent, exp_cent)
+    assert np.array_equal(labels, exp_labels)

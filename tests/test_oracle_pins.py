@@ -150,3 +150,22 @@ def test_kdtree_equals_brute_force(oracle):
     assert np.array_equal(idx, eidx) and np.array_equal(err, eerr)
     assert idx[0] == 7 and idx[1] == 7 and err[0] == 0
     assert 0 < visited <= q.shape[0] * db.shape[0]
+
+
+def test_kmodes_restatement_properties(oracle):
+    """A17 has no vector in the reference (parity unpinned); what can be checked of the restatement on the CPU: it recovers planted
+    prototypes exactly when the noise is small, every point sits with its nearest mode of the final modes by the reference's
+    dissimilarity (sum |a-b| + 2048 per differing byte, kmodes.pas:248-259), and the run is reproducible (the LCG is seeded, :933)"""
+    rng = np.random.default_rng(5)
+    proto = np.stack([np.full(80, v, np.uint8) for v in (3, 90, 200)])
+    truth = rng.integers(0, 3, size=900)
+    rows = proto[truth].copy()
+    flip = rng.random(rows.shape) < 0.05
+    rows[flip] = rng.integers(0, 256, size=int(flip.sum()))
+    labels, cent, cost, iters = oracle.kmodes(rows, 3, 0, 256, -1)
+    assert sorted(map(bytes, cent)) == sorted(map(bytes, proto))
+    d = (np.abs(rows[:, None, :].astype(np.int64) - cent[None].astype(np.int64)).sum(2) + 2048 * (rows[:, None, :] != cent[None]).sum(2))
+    assert np.array_equal(d.min(1), d[np.arange(900), labels])
+    assert len(set(zip(truth.tolist(), labels.tolist()))) == 3
+    again = oracle.kmodes(rows, 3, 0, 256, -1)
+    assert np.array_equal(again[0], labels) and again[2] == cost and iters >= 1

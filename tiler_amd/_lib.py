@@ -48,6 +48,7 @@ SIGNATURES = {
                                 ctypes.POINTER(c_int), c_void_p]),
     "tm_stage_quantize_palettes": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tm_stage_palettize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "tm_stage_kmodes": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_int), c_void_p]),
     "tm_stage_dither": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -84,6 +84,10 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
                                int pal_rank, int pal_world, hipStream_t stream);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
 
+// tm_kmodes.hip: A17, TKModes.ComputeKModes (kmodes.pas:923-1094); host pointers
+int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, int max_iter, int32_t *labels_out, uint8_t *cent_out, uint64_t *cost_out,
+               int *iters_out, hipStream_t stream);
+
 // tm_optpal.hip (host only)
 int optimize_palettes_host(std::vector<int32_t> &pals, int pal_count, int pal_size, int *sweeps_out);
 

@@ -179,3 +179,17 @@ def palettize(feat, use, npal, max_iter=300):
     out = torch.empty((feat.shape[0],), dtype=torch.int32, device=feat.device)
     check(lib().tm_stage_palettize(_p(feat), _p(use), feat.shape[0], npal, max_iter, _p(out), _stream()))
     return out
+
+
+def kmodes(rows, num_clusters, num_init=0, num_modalities=256, max_iter=-1):
+    """TKModes.ComputeKModes (kmodes.pas:923-1094): rows uint8 numpy [n][80] (host, like the Pascal arrays) ->
+    (labels int32 [n], centroids uint8 [k][80], cost, iterations of the best run)"""
+    import numpy as np
+    rows = np.ascontiguousarray(rows, np.uint8)
+    assert rows.ndim == 2 and rows.shape[1] == 80
+    labels = np.zeros(rows.shape[0], np.int32)
+    cent = np.zeros((num_clusters, 80), np.uint8)
+    cost, iters = ctypes.c_uint64(), ctypes.c_int()
+    check(lib().tm_stage_kmodes(rows.ctypes.data_as(ctypes.c_void_p), rows.shape[0], num_clusters, num_init, num_modalities, max_iter,
+                                labels.ctypes.data_as(ctypes.c_void_p), cent.ctypes.data_as(ctypes.c_void_p), ctypes.byref(cost), ctypes.byref(iters), _stream()))
+    return labels, cent, cost.value, iters.value
