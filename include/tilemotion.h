@@ -102,6 +102,9 @@ TM_API int tm_get_tilemap(tm_encoder *, int frame, tm_tilemap_item *items /* tm_
 TM_API int tm_get_palette(tm_encoder *, int i, int32_t *rgb /* PaletteSize */);
 TM_API int tm_get_keyframes(tm_encoder *, int32_t *start_frames /* keyframes */);
 TM_API int tm_get_frame_correlations(tm_encoder *, float *correl /* frames */);
+/* TKeyFrame.LogPSNR (:1006-1028): mean "PSNR-HVS (by tile)" of every key frame (the items' PSNR summed in a Double, divided by tile-map
+ * size x frames of the key frame) and of the whole clip; what the reference prints after Reconstruct.  Either pointer may be NULL. */
+TM_API int tm_get_psnr(tm_encoder *, double *per_keyframe /* keyframes */, double *global_mean);
 TM_API int tm_get_stage_ms(tm_encoder *, double ms[8]); /* wall ms of the last run of each step (ProgressRedraw, :3925) */
 TM_API int tm_save_gtm(tm_encoder *, const char *path);  /* Save, :2040 -> SaveStream, :5177 */
 /* The same writer on HOST arrays (no device needed): tiles in their final (Reindex) order with use counts, palettes
@@ -228,6 +231,11 @@ TM_API int tm_stage_dedup(const void *rows, int64_t n, int row_bytes, const void
  * weights u32 [n] or NULL.  assign i32 [n], centroids f64 [k][d] (device).  Returns live centroid count in *host_k. */
 TM_API int tm_stage_kmeans(const void *pts_i32, const void *weights, int64_t n, int d, int k, int max_iter,
                            void *assign, void *centroids, int *host_k, int *host_iters, void *stream);
+/* The same Lloyd iterations from the caller's own initial centres: host_init_idx[k] = indices of the points to start from (-1: none)
+ * instead of the farthest-first picks -- the seam an experiment with another seeding rule (k-means++ and the like) goes through;
+ * yakmo's own k-means++ draws cannot be reproduced. */
+TM_API int tm_stage_kmeans_seeded(const void *pts_i32, const void *weights, int64_t n, int d, int k, const int64_t *host_init_idx, int max_iter,
+                                  void *assign, void *centroids, int *host_k, int *host_iters, void *stream);
 /* QuantizeUsingYakmo + DoQuantization (:4434-4564) for every palette at once: pixels of tiles grouped by pal_idx. */
 TM_API int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter,
                                       void *out_palettes, void *stream);
@@ -251,6 +259,16 @@ TM_API int tm_optimize_palettes_host(int32_t *palettes, int pal_count, int pal_s
 
 /* ======================================================================================= fine seam
  * extern.pas:182-185 (ANN_short.dll), :198-203 (yakmo.dll), :218-223 (BICO.dll).  Host pointers. */
+/* ANN.dll (extern.pas:178-180; call sites tilingencoder.pas:4128, 4183-4187): double coordinates, any dimension.  These are the
+ * DLL's own export names.  ANN_short.dll exports the SAME names for its int16 build (the `_short` suffix exists on the Pascal
+ * side only: `external 'ANN_short.dll' name 'ann_kdtree_create'`, extern.pas:182-185); one shared object cannot export one
+ * name twice, so the int16 set is exported as ann_kdtree_short_* and the import unit names those.
+ * Exact nearest row (eps is ignored: the reference passes 0), squared distance in *err, ties -> lowest index. */
+typedef struct tm_annd tm_annd;
+TM_API tm_annd *ann_kdtree_create(double **rows, int n, int dd, int bs, int split);
+TM_API void ann_kdtree_destroy(tm_annd *);
+TM_API int ann_kdtree_search(tm_annd *, const double *q, double eps, double *err);
+TM_API int ann_kdtree_search_batch(tm_annd *, const double *queries, int nq, int32_t *idxs, double *errs);
 typedef struct tm_ann tm_ann;
 TM_API tm_ann *ann_kdtree_short_create(int16_t **rows, int n, int dd, int bs, int split);
 TM_API void ann_kdtree_short_destroy(tm_ann *);

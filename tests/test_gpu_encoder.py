@@ -57,7 +57,64 @@ def test_run_all_matches_oracle(oracle, shape, pc, radius, tc, epu):
         assert np.array_equal(tm["PredictedX"], exp["pred_x"][sl]) and np.array_equal(tm["PredictedY"], exp["pred_y"][sl])
         psnr = np.array([oracle.L.tmo_euclidean_to_psnr(int(e)) for e in exp["tm_err"][sl]], np.float32)
         assert np.allclose(tm["PSNR"], psnr, rtol=1e-6)  # PSNR goes through log10: tolerance 1e-6 relative
+    # TKeyFrame.LogPSNR (1006-1028): mean PSNR by tile per key frame and over the clip
+    q = enc.PSNR()
+    allp = np.array([oracle.L.tmo_euclidean_to_psnr(int(e)) for e in exp["tm_err"]], np.float64)
+    kf = list(exp["keyframes"]) + [shape[0]]
+    assert np.allclose(q["per_keyframe"], [allp[a * per:b * per].mean() for a, b in zip(kf[:-1], kf[1:])], rtol=1e-6)
+    assert np.isclose(q["global"], allp.mean(), rtol=1e-6)
     enc.close()
+
+
+def test_reference_default_palette_count_with_extended_palette_usage(oracle):
+    """LoadDefaultSettings + Run on a small clip: PaletteCount = 1024 and FrameTilingExtendedPaletteUsage = True (tilingencoder.pas:3826,
+    3840).  The table of every tile under every palette is out of the question there (T x 1024 rows), so the re-rank builds the rows its
+    queries name; the result must be the oracle's."""
+    from tiler_amd import synth
+    from tests import oracle_pipeline
+    frames = synth.video(5, 64, 48, cut=3)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=1024, min_s=0.1, motion_radius=0, epu=True)
+    import os
+    os.environ["TM_EPU_TABLE_GIB"] = "0.01"  # (240 tiles x 1024 palettes would still fit a real budget)
+    try:
+        enc = _run_encoder(frames, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0)  # PaletteCount / EPU: the defaults
+    finally:
+        del os.environ["TM_EPU_TABLE_GIB"]
+    assert enc.PaletteCount == 1024 and enc.FrameTilingExtendedPaletteUsage
+    assert np.array_equal(enc.Palettes(), exp["palettes"])
+    per = exp["per"]
+    for f in range(5):
+        tm = enc.TileMap(f)
+        sl = slice(f * per, (f + 1) * per)
+        assert np.array_equal(tm["TileIdx"], exp["final_tm_tile"][sl]) and np.array_equal(tm["PalIdx"], exp["tm_pal"][sl])
+    enc.close()
+
+
+def test_steps_after_reload_without_load_fail_cleanly(oracle, tmp_path):
+    """ReloadGTM brings palette indices, palettes and tile maps, not the frame tiles or the RGB pixels: steps that compute from those
+    must say so (TM_E_INVAL) instead of launching kernels on buffers that do not exist"""
+    from tiler_amd import synth, TileMotionError
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep
+    frames = synth.video(4, 32, 32)
+    a = str(tmp_path / "a.gtm")
+    enc = _run_encoder(frames, PaletteCount=2, MotionPredictRadius=0, FrameTilingExtendedPaletteUsage=False, OutputFileName=a)
+    enc.close()
+    enc2 = TilingEncoder()
+    enc2.LoadDefaultSettings()
+    enc2.PaletteCount = 2
+    enc2.SetVideo(32, 32, 24.0, 4)
+    enc2.ReloadGTM(a)
+    for step in (TEncoderStep.esPredictMotion, TEncoderStep.esReduce, TEncoderStep.esPreparePalettes, TEncoderStep.esDither, TEncoderStep.esReconstruct):
+        with pytest.raises(TileMotionError) as ei:
+            enc2.Run(step)
+        assert ei.value.code == -1
+    enc2.Run(TEncoderStep.esReindex)  # works on what the stream holds
+    for f in range(4):
+        enc2.PushFrame(f, frames[f])
+    enc2.MotionPredictRadius = 0
+    enc2.FrameTilingExtendedPaletteUsage = False
+    enc2.Run()  # with the frames in, everything runs again
+    enc2.close()
 
 
 def test_step_order_and_errors():

@@ -575,6 +575,31 @@ def test_epu_rerank(tiles_flags, oracle):
     assert (ep != tile_pal[et]).any()            # the re-rank does move tiles to other palettes
 
 
+def test_epu_rerank_without_the_table(tiles_flags, oracle, monkeypatch):
+    """the same re-rank when the table of every tile under every palette does not fit (TM_EPU_TABLE_GIB=0 forces it; PaletteCount = 1024,
+    the reference's default, needs it): only the (tile, palette) pairs the queries name get a feature row, through a sorted pair list"""
+    from tiler_amd import stages
+    monkeypatch.setenv("TM_EPU_TABLE_GIB", "0")
+    tiles, flags = tiles_flags
+    rng = np.random.default_rng(78)
+    nt, npal = 400, 37
+    palettes = rng.integers(0, 1 << 24, size=(npal, 16), dtype=np.int32)
+    pal_px = rng.integers(0, 16, size=(nt, 64), dtype=np.uint8)
+    pal_px[41] = pal_px[5]
+    tile_pal = rng.integers(0, npal, size=nt, dtype=np.int32)
+    db = oracle.features_pal(pal_px, tile_pal, palettes, 1)
+    q = oracle.features_rgb(tiles[:250], None, 1, False)
+    idx64, _ = oracle.knnk(q, db, 64)
+    idx64[7, 10:] = -1
+    idx64[8, :] = idx64[8, 0]
+    idx64[9, :] = -1                             # nothing at all: TileIdx / PalIdx -1, error $FFFFFFFF
+    et, ep, ee = oracle.epu_rerank(q, idx64, pal_px, tile_pal, palettes)
+    t, p, e = stages.epu_rerank(_dev(q), _dev(idx64), _dev(pal_px), _dev(tile_pal), _dev(palettes))
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), et) and np.array_equal(p.cpu().numpy(), ep)
+    assert np.array_equal(_host_u32(e), ee)
+
+
 def test_knn_topk_matches_brute_force_at_scale():
     """the pruned MFMA collection scan against the exact VALU brute force (TM_TOPK_BRUTE=1) on clustered data with many
     duplicates and near-duplicates: overflow re-scans and the (distance, index) order at the 64th place get exercised"""
@@ -628,3 +653,44 @@ def test_kmodes(oracle, case, num_init):
     assert cost == exp_cost and iters == exp_iters
     assert np.array_equal(cent, exp_cent)
     assert np.array_equal(labels, exp_labels)
+
+
+def test_fine_seam_ann_double():
+    """ANN.dll's own entry points (extern.pas:178-180) as DoPalettization calls them (tilingencoder.pas:4128, 4183-4187): an array of row
+    pointers to double[192] centroids, one double query per call, the squared distance back through *err.  Checked against numpy's
+    float64 arithmetic in the same summation order; ties -> lowest index."""
+    import ctypes
+    from tiler_amd import lib
+    L = lib()
+    rng = np.random.default_rng(21)
+    n, dd = 700, 192
+    cent = rng.normal(0, 300, size=(n, dd))
+    cent[500] = cent[20]  # an exact duplicate: the lower index must win
+    q = np.concatenate([cent[[20, 3]] + rng.normal(0, 1e-3, size=(2, dd)), rng.normal(0, 300, size=(30, dd)), cent[[20]]])
+    rows = (ctypes.c_void_p * n)(*[cent[i].ctypes.data for i in range(n)])
+    L.ann_kdtree_create.restype = ctypes.c_void_p
+    L.ann_kdtree_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    tree = L.ann_kdtree_create(rows, n, dd, 32, 0)
+    assert tree
+    L.ann_kdtree_search.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    L.ann_kdtree_search.restype = ctypes.c_int
+
+    def ref(x):
+        d = np.zeros(n)
+        for j in range(dd):  # one subtraction, one multiplication, one addition per dimension, in order
+            t = x[j] - cent[:, j]
+            d = d + t * t
+        i = int(np.argmin(d))  # first minimum = lowest index
+        return i, d[i]
+    for i in range(q.shape[0]):
+        err = ctypes.c_double()
+        got = L.ann_kdtree_search(tree, q[i].ctypes.data, 0.0, ctypes.byref(err))
+        ei, ed = ref(q[i])
+        assert got == ei and err.value == ed
+    idx = np.zeros(q.shape[0], np.int32)
+    errs = np.zeros(q.shape[0], np.float64)
+    L.ann_kdtree_search_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert L.ann_kdtree_search_batch(tree, q.ctypes.data, q.shape[0], idx.ctypes.data, errs.ctypes.data) == 0
+    assert idx[0] == 20 and idx[-1] == 20 and errs[-1] == 0.0 and idx[1] == 3
+    L.ann_kdtree_destroy.argtypes = [ctypes.c_void_p]
+    L.ann_kdtree_destroy(tree)

@@ -46,6 +46,8 @@ SIGNATURES = {
     "tm_stage_dedup": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     "tm_stage_kmeans": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                 ctypes.POINTER(c_int), c_void_p]),
+    "tm_stage_kmeans_seeded": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
+                                       ctypes.POINTER(c_int), c_void_p]),
     "tm_stage_quantize_palettes": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tm_stage_palettize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "tm_stage_kmodes": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_int), c_void_p]),

@@ -63,6 +63,9 @@ int tm_stage_epu_rerank(const void *queries_i16, int64_t nq, const void *knn_idx
                         int64_t ntiles, const void *palettes, int npal, int pal_size, void *out_tile, void *out_pal, void *out_err,
                         void *stream) {
   TM_TRY(require_device());
+  const double table_gib = getenv("TM_EPU_TABLE_GIB") ? atof(getenv("TM_EPU_TABLE_GIB")) : 6.0;
+  if ((double)ntiles * npal * 384.0 > table_gib * 1073741824.0)  // no room for every tile under every palette: only the rows the queries name
+    return launch_epu_rerank_ondemand(queries_i16, nq, knn_idx, k, tile_pal_idx, ntiles, pal_px, palettes, npal, pal_size, out_tile, out_pal, out_err, (hipStream_t)stream);
   DevBuf table;
   TM_TRY(table.alloc((size_t)std::max<int64_t>(ntiles, 1) * npal * 384));
   TM_TRY(launch_features_table(pal_px, ntiles, palettes, npal, pal_size, table.p, (hipStream_t)stream));
@@ -111,6 +114,12 @@ int tm_stage_dedup(const void *rows, int64_t n, int row_bytes, const void *use_i
 int tm_stage_kmeans(const void *pts_i32, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids,
                     int *host_k, int *host_iters, void *stream) {
   return run_kmeans(pts_i32, weights, n, d, k, max_iter, assign, centroids, host_k, host_iters, (hipStream_t)stream);
+}
+
+int tm_stage_kmeans_seeded(const void *pts_i32, const void *weights, int64_t n, int d, int k, const int64_t *host_init_idx, int max_iter, void *assign,
+                           void *centroids, int *host_k, int *host_iters, void *stream) {
+  TM_CHECK(host_init_idx != nullptr, TM_E_INVAL, "kmeans: null initial centres");
+  return run_kmeans_seeded(pts_i32, weights, n, d, k, host_init_idx, max_iter, assign, centroids, host_k, host_iters, (hipStream_t)stream);
 }
 
 int tm_stage_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter,

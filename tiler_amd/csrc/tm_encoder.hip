@@ -751,8 +751,14 @@ static int step_reconstruct(tm_encoder *e) {
     // table of all (tile, palette) feature vectors
     DevBuf table, idx64, err64;
     const int npal = e->s.PaletteCount;
-    TM_TRY(table.alloc((size_t)e->t * npal * 384));
-    TM_TRY(launch_features_table(e->gpal_px.p, e->t, e->palettes_dev.p, npal, e->s.PaletteSize, table.p, e->stream));
+    // the table of every tile under every palette while it fits (T x P x 384 bytes: 2 GB at 16 palettes); with the reference's default
+    // of 1024 palettes it would be tens of terabytes, and the re-rank builds just the rows its queries name instead
+    const double table_gib = getenv("TM_EPU_TABLE_GIB") ? atof(getenv("TM_EPU_TABLE_GIB")) : 6.0;
+    const bool use_table = (double)e->t * npal * 384.0 <= table_gib * 1073741824.0;
+    if (use_table) {
+      TM_TRY(table.alloc((size_t)e->t * npal * 384));
+      TM_TRY(launch_features_table(e->gpal_px.p, e->t, e->palettes_dev.p, npal, e->s.PaletteSize, table.p, e->stream));
+    }
     progress(e, TM_STEP_RECONSTRUCT, 1, 2);
     const int chunk_frames = recon_chunk_frames(e, sn, true);
     TM_TRY(idx64.alloc((size_t)chunk_frames * per * 64 * 4));
@@ -781,8 +787,10 @@ static int step_reconstruct(tm_encoder *e) {
         rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qfp, n, db.p, e->t, 64, idx64.p, err64.p, e->stream)  // debugging aid: VALU brute force over all rows
                                      : knn_index_search_topk(ix, qfp, n, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
       if (rc == TM_OK)
-        rc = launch_epu_rerank(qfp, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
-                               e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
+        rc = use_table ? launch_epu_rerank(qfp, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
+                                           e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream)
+                       : launch_epu_rerank_ondemand(qfp, n, idx64.p, 64, e->gpal_idx.p, e->t, e->gpal_px.p, e->palettes_dev.p, npal, e->s.PaletteSize,
+                                                    e->tm_tile.as<int32_t>() + off, e->tm_pal.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
     }
     knn_index_destroy(ix);
     TM_TRY(rc);
@@ -1217,6 +1225,27 @@ int tm_get_keyframes(tm_encoder *e, int32_t *start_frames) {
 int tm_get_frame_correlations(tm_encoder *e, float *correl) {
   TM_CHECK(e && correl, TM_E_INVAL, "null argument");
   memcpy(correl, e->correl.data(), e->correl.size() * 4);
+  return TM_OK;
+}
+
+int tm_get_psnr(tm_encoder *e, double *per_keyframe, double *global_mean) {  // TKeyFrame.LogPSNR, tilingencoder.pas:1006-1028
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_CHECK(e->reconstructed && e->tm_err.p && !e->kf_start.empty(), TM_E_INVAL, "PSNR: Reconstruct has not been run");
+  TM_HIP(hipSetDevice(e->device));
+  // ReconstructPSNRCml = sum of the items' PSNR (Single, 1619 / 1644) in a Double (1657); the reference adds in thread order, here
+  // in item order.  Per key frame: / (TileMapSize x FrameCount) (1014); all: / (TileMapSize x frames) (1024).
+  std::vector<uint32_t> er((size_t)e->q);
+  TM_HIP(hipMemcpy(er.data(), e->tm_err.p, (size_t)e->q * 4, hipMemcpyDeviceToHost));
+  const int64_t per = e->tm_size();
+  double all = 0;
+  for (size_t k = 0; k < e->kf_start.size(); k++) {
+    const int64_t f0 = e->kf_start[k], f1 = k + 1 < e->kf_start.size() ? e->kf_start[k + 1] : e->nframes;
+    double cml = 0;
+    for (int64_t i = f0 * per; i < f1 * per; i++) cml += (double)euclidean_to_psnr(er[(size_t)i]);
+    if (per_keyframe) per_keyframe[k] = f1 > f0 ? cml / (double)(per * (f1 - f0)) : 0.0;
+    all += cml;
+  }
+  if (global_mean) *global_mean = all / (double)(per * e->nframes);
   return TM_OK;
 }
 

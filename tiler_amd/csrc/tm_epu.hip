@@ -12,6 +12,9 @@
 // independent implementation the tests compare it with (TM_TOPK_BRUTE=1).
 #include <algorithm>
 
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "tm_common.h"
 #include "tm_internal.h"
 
@@ -99,17 +102,13 @@ __device__ __forceinline__ uint32_t block_term(const uint4 a, const uint4 b) {
   return sq2(sat_sub2(a.x, b.x)) + sq2(sat_sub2(a.y, b.y)) + sq2(sat_sub2(a.z, b.z)) + sq2(sat_sub2(a.w, b.w));
 }
 
-// One wave per query.  Lane s holds list slot s; the two lists are sorted and made unique across the wave, then 8 lanes
-// share a (tile, palette) pair exactly as k_motion_search's lanes share a candidate (same quirk handling).
-__global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ queries, int64_t nq, const int32_t *__restrict__ knn_idx, int k,
-                                                   const int32_t *__restrict__ tile_pal, int64_t ntiles, int npal,
-                                                   const int16_t *__restrict__ table /* [ntiles][npal][192] */, int32_t *__restrict__ out_tile,
-                                                   int32_t *__restrict__ out_pal, uint32_t *__restrict__ out_err) {
-  __shared__ int32_t s_t[64], s_p[64], s_ut[64], s_up[64];
-  __shared__ int s_nut, s_nup;
-  const int64_t qi = blockIdx.x;
-  if (qi >= nq) return;
-  const int lane = threadIdx.x, j8 = lane & 7, grp = lane >> 3, role = j8 & 3;
+// The two lists of a query (1565-1577): the tile indices of its k nearest rows and the palettes of those tiles, each sorted and
+// made unique across the wave (lane s holds list slot s).  -1 entries (the pads of a database with fewer than k rows, 1572-1573)
+// sort first.  Every kernel that walks a query's (tile, palette) pairs builds the lists with this one function, so they agree on
+// the order o = tile slot * nup + palette slot.
+__device__ __forceinline__ void epu_lists(const int32_t *__restrict__ knn_idx, int64_t qi, int k, const int32_t *__restrict__ tile_pal, int64_t ntiles,
+                                          int32_t *s_t, int32_t *s_p, int32_t *s_ut, int32_t *s_up, int *s_n /* [2]: nut, nup */) {
+  const int lane = threadIdx.x;
   int32_t t = -1, p = -1;
   if (lane < k) {
     t = knn_idx[qi * k + lane];
@@ -117,31 +116,47 @@ __global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ q
   }
   s_t[lane] = lane < k ? t : 0x7fffffff;  // padding sorts last and is dropped
   s_p[lane] = lane < k ? p : 0x7fffffff;
-  if (lane == 0) { s_nut = 0; s_nup = 0; }
+  if (lane == 0) { s_n[0] = 0; s_n[1] = 0; }
   __syncthreads();
   // rank sort (64 values): position = number of smaller values, ties by slot; then unique
-  {
-    const int32_t mt = s_t[lane], mp = s_p[lane];
-    int rt = 0, rp = 0;
-    for (int i = 0; i < 64; i++) {
-      const int32_t ot = s_t[i], op = s_p[i];
-      rt += (ot < mt || (ot == mt && i < lane)) ? 1 : 0;
-      rp += (op < mp || (op == mp && i < lane)) ? 1 : 0;
-    }
-    __syncthreads();
-    s_t[rt] = mt;
-    s_p[rp] = mp;
-    __syncthreads();
-    const int32_t vt = s_t[lane], vp = s_p[lane];
-    const bool ft = vt != 0x7fffffff && (lane == 0 || s_t[lane - 1] != vt);
-    const bool fp = vp != 0x7fffffff && (lane == 0 || s_p[lane - 1] != vp);
-    const unsigned long long bt = __ballot(ft), bp = __ballot(fp);
-    if (ft) s_ut[__popcll(bt & ((1ull << lane) - 1ull))] = vt;
-    if (fp) s_up[__popcll(bp & ((1ull << lane) - 1ull))] = vp;
-    if (lane == 0) { s_nut = __popcll(bt); s_nup = __popcll(bp); }
-    __syncthreads();
+  const int32_t mt = s_t[lane], mp = s_p[lane];
+  int rt = 0, rp = 0;
+  for (int i = 0; i < 64; i++) {
+    const int32_t ot = s_t[i], op = s_p[i];
+    rt += (ot < mt || (ot == mt && i < lane)) ? 1 : 0;
+    rp += (op < mp || (op == mp && i < lane)) ? 1 : 0;
   }
-  const int nut = s_nut, nup = s_nup, npairs = nut * nup;
+  __syncthreads();
+  s_t[rt] = mt;
+  s_p[rp] = mp;
+  __syncthreads();
+  const int32_t vt = s_t[lane], vp = s_p[lane];
+  const bool ft = vt != 0x7fffffff && (lane == 0 || s_t[lane - 1] != vt);
+  const bool fp = vp != 0x7fffffff && (lane == 0 || s_p[lane - 1] != vp);
+  const unsigned long long bt = __ballot(ft), bp = __ballot(fp);
+  if (ft) s_ut[__popcll(bt & ((1ull << lane) - 1ull))] = vt;
+  if (fp) s_up[__popcll(bp & ((1ull << lane) - 1ull))] = vp;
+  if (lane == 0) { s_n[0] = __popcll(bt); s_n[1] = __popcll(bp); }
+  __syncthreads();
+}
+
+// One wave per query; 8 lanes share a (tile, palette) pair exactly as k_motion_search's lanes share a candidate (same quirk
+// handling).  The pair's feature vector comes either from the table of every tile under every palette (ntiles x npal rows), or --
+// when that table would not fit (PaletteCount = 1024, the reference's default: T x P x 384 bytes is tens of terabytes) -- from the
+// rows made for just the pairs this batch of queries names: row_of[pair_off[q] + o].
+template <bool ONDEMAND>
+__global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ queries, int64_t nq, const int32_t *__restrict__ knn_idx, int k,
+                                                   const int32_t *__restrict__ tile_pal, int64_t ntiles, int npal,
+                                                   const int16_t *__restrict__ table /* [ntiles][npal][192], or the on-demand rows */,
+                                                   const unsigned long long *__restrict__ pair_off, const uint32_t *__restrict__ row_of,
+                                                   int32_t *__restrict__ out_tile, int32_t *__restrict__ out_pal, uint32_t *__restrict__ out_err) {
+  __shared__ int32_t s_t[64], s_p[64], s_ut[64], s_up[64];
+  __shared__ int s_n[2];
+  const int64_t qi = blockIdx.x;
+  if (qi >= nq) return;
+  const int lane = threadIdx.x, j8 = lane & 7, grp = lane >> 3, role = j8 & 3;
+  epu_lists(knn_idx, qi, k, tile_pal, ntiles, s_t, s_p, s_ut, s_up, s_n);
+  const int nut = s_n[0], nup = s_n[1], npairs = nut * nup;
   const uint4 *pq = reinterpret_cast<const uint4 *>(queries + qi * 192) + j8 * 3;
   const uint4 a0 = pq[0], a1 = pq[1], a2 = pq[2];
   uint32_t best = 0xffffffffu;
@@ -150,11 +165,11 @@ __global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ q
     const int ti = o / nup, pi = o - ti * nup;
     const int32_t tile = s_ut[ti], pal = s_up[pi];
     uint32_t acc = 0;
-    // -1 entries (1572-1573: the pads of a database with fewer than k rows) sort first and are skipped by the reference's
-    // `<> prevTileIdx` / `<> prevPalIdx` tests, which start at -1 (1582-1588)
+    // -1 entries sort first and are skipped by the reference's `<> prevTileIdx` / `<> prevPalIdx` tests, which start at -1 (1582-1588)
     const bool ok = tile >= 0 && pal >= 0;
     if (ok) {
-      const uint4 *pb = reinterpret_cast<const uint4 *>(table + ((int64_t)tile * npal + pal) * 192) + j8 * 3;
+      const int64_t row = ONDEMAND ? (int64_t)row_of[pair_off[qi] + (unsigned long long)o] : (int64_t)tile * npal + pal;
+      const uint4 *pb = reinterpret_cast<const uint4 *>(table + row * 192) + j8 * 3;
       const uint4 b0 = pb[0], b1 = pb[1], b2 = pb[2];
       uint4 b5 = make_uint4(0, 0, 0, 0);
       if (role == 2) b5 = pb[-1];
@@ -183,6 +198,44 @@ __global__ __launch_bounds__(64) void k_epu_rerank(const int16_t *__restrict__ q
   }
 }
 
+// ---- the on-demand rows: which (tile, palette) pairs does a batch of queries name?
+__global__ __launch_bounds__(64) void k_epu_count(int64_t nq, const int32_t *__restrict__ knn_idx, int k, const int32_t *__restrict__ tile_pal, int64_t ntiles,
+                                                  unsigned long long *__restrict__ count) {
+  __shared__ int32_t s_t[64], s_p[64], s_ut[64], s_up[64];
+  __shared__ int s_n[2];
+  const int64_t qi = blockIdx.x;
+  if (qi >= nq) return;
+  epu_lists(knn_idx, qi, k, tile_pal, ntiles, s_t, s_p, s_ut, s_up, s_n);
+  if (threadIdx.x == 0) count[qi] = (unsigned long long)(s_n[0] * s_n[1]);
+}
+__global__ __launch_bounds__(64) void k_epu_emit(int64_t nq, const int32_t *__restrict__ knn_idx, int k, const int32_t *__restrict__ tile_pal, int64_t ntiles,
+                                                 const unsigned long long *__restrict__ pair_off, unsigned long long *__restrict__ keys, uint32_t *__restrict__ pos) {
+  __shared__ int32_t s_t[64], s_p[64], s_ut[64], s_up[64];
+  __shared__ int s_n[2];
+  const int64_t qi = blockIdx.x;
+  if (qi >= nq) return;
+  epu_lists(knn_idx, qi, k, tile_pal, ntiles, s_t, s_p, s_ut, s_up, s_n);
+  const int nup = s_n[1], npairs = s_n[0] * nup;
+  const unsigned long long off = pair_off[qi];
+  for (int o = threadIdx.x; o < npairs; o += 64) {
+    const int ti = o / nup, pi = o - ti * nup;
+    const int32_t tile = s_ut[ti], pal = s_up[pi];
+    keys[off + o] = (tile >= 0 && pal >= 0) ? ((unsigned long long)(uint32_t)tile << 32) | (uint32_t)pal : ~0ull;  // a pad pair: no row
+    pos[off + o] = (uint32_t)(off + o);
+  }
+}
+__global__ void k_epu_heads(const unsigned long long *__restrict__ keys, int64_t n, uint32_t *__restrict__ head) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ void k_epu_rows(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ rank_incl, int64_t n,
+                           uint32_t *__restrict__ row_of, unsigned long long *__restrict__ ukeys) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = rank_incl[i] - 1u;
+    row_of[pos[i]] = r;
+    if (i == 0 || keys[i] != keys[i - 1]) ukeys[r] = keys[i];
+  }
+}
+
 }  // namespace
 
 int launch_knn_topk(const void *queries, int64_t nq, const void *db, int64_t nt, int k, void *out_idx, void *out_err, hipStream_t stream) {
@@ -205,9 +258,61 @@ int launch_epu_rerank(const void *queries, int64_t nq, const void *knn_idx, int 
                       const void *table, void *out_tile, void *out_pal, void *out_err, hipStream_t stream) {
   TM_CHECK(k >= 1 && k <= 64 && npal >= 1, TM_E_INVAL, "epu: bad arguments");
   if (nq <= 0) return TM_OK;
-  hipLaunchKernelGGL(k_epu_rerank, dim3((unsigned)nq), dim3(64), 0, stream, (const int16_t *)queries, nq, (const int32_t *)knn_idx, k,
-                     (const int32_t *)tile_pal, ntiles, npal, (const int16_t *)table, (int32_t *)out_tile, (int32_t *)out_pal, (uint32_t *)out_err);
+  hipLaunchKernelGGL(k_epu_rerank<false>, dim3((unsigned)nq), dim3(64), 0, stream, (const int16_t *)queries, nq, (const int32_t *)knn_idx, k,
+                     (const int32_t *)tile_pal, ntiles, npal, (const int16_t *)table, nullptr, nullptr, (int32_t *)out_tile, (int32_t *)out_pal, (uint32_t *)out_err);
   TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+// The re-rank without the T x P table: the (tile, palette) pairs the queries of the batch name are collected, sorted and made unique,
+// the feature vectors of exactly those pairs are built (k_features_i16<4>), and the re-rank reads them through a per-pair row index.
+// Same vectors, same order, same result as with the table.  The batch is cut so that the pair arrays stay within `budget` bytes.
+int launch_epu_rerank_ondemand(const void *queries, int64_t nq, const void *knn_idx, int k, const void *tile_pal, int64_t ntiles, const void *pal_px,
+                               const void *palettes, int npal, int pal_size, void *out_tile, void *out_pal, void *out_err, hipStream_t stream) {
+  TM_CHECK(k >= 1 && k <= 64 && npal >= 1, TM_E_INVAL, "epu: bad arguments");
+  const int64_t step = std::max<int64_t>(1, std::min<int64_t>(nq, ((int64_t)1 << 26) / ((int64_t)k * k)));  // at most 64 M pairs per batch (k x k per query)
+  for (int64_t q0 = 0; q0 < nq; q0 += step) {
+    const int64_t n = std::min(step, nq - q0);
+    const int32_t *idx = (const int32_t *)knn_idx + q0 * k;
+    DevBuf cnt, off, tmp, keys, keys2, pos, pos2, head, rank, row_of, ukeys, feat;
+    TM_TRY(cnt.alloc((size_t)(n + 1) * 8)); TM_TRY(off.alloc((size_t)(n + 1) * 8));
+    TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)(n + 1) * 8, stream));
+    hipLaunchKernelGGL(k_epu_count, dim3((unsigned)n), dim3(64), 0, stream, n, idx, k, (const int32_t *)tile_pal, ntiles, cnt.as<unsigned long long>());
+    size_t tb = 0;
+    TM_HIP(rocprim::exclusive_scan(nullptr, tb, cnt.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)(n + 1), rocprim::plus<unsigned long long>(), stream));
+    TM_TRY(tmp.alloc(tb));
+    TM_HIP(rocprim::exclusive_scan(tmp.p, tb, cnt.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)(n + 1), rocprim::plus<unsigned long long>(), stream));
+    unsigned long long m = 0;
+    TM_HIP(hipMemcpyAsync(&m, off.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    if (m > 0) {
+      TM_CHECK(m < (1ull << 32), TM_E_NOMEM, "epu: %llu pairs in one batch", m);
+      TM_TRY(keys.alloc((size_t)m * 8)); TM_TRY(keys2.alloc((size_t)m * 8)); TM_TRY(pos.alloc((size_t)m * 4)); TM_TRY(pos2.alloc((size_t)m * 4));
+      TM_TRY(head.alloc((size_t)m * 4)); TM_TRY(rank.alloc((size_t)m * 4)); TM_TRY(row_of.alloc((size_t)m * 4));
+      hipLaunchKernelGGL(k_epu_emit, dim3((unsigned)n), dim3(64), 0, stream, n, idx, k, (const int32_t *)tile_pal, ntiles, off.as<unsigned long long>(),
+                         keys.as<unsigned long long>(), pos.as<uint32_t>());
+      TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.as<unsigned long long>(), keys2.as<unsigned long long>(), pos.as<uint32_t>(), pos2.as<uint32_t>(), (size_t)m, 0, 64, stream));
+      TM_TRY(tmp.alloc(tb));
+      TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, keys.as<unsigned long long>(), keys2.as<unsigned long long>(), pos.as<uint32_t>(), pos2.as<uint32_t>(), (size_t)m, 0, 64, stream));
+      const int g = (int)std::min<unsigned long long>((m + 255) / 256, 8192);
+      hipLaunchKernelGGL(k_epu_heads, dim3(g), dim3(256), 0, stream, keys2.as<unsigned long long>(), (int64_t)m, head.as<uint32_t>());
+      TM_HIP(rocprim::inclusive_scan(nullptr, tb, head.as<uint32_t>(), rank.as<uint32_t>(), (size_t)m, rocprim::plus<uint32_t>(), stream));
+      TM_TRY(tmp.alloc(tb));
+      TM_HIP(rocprim::inclusive_scan(tmp.p, tb, head.as<uint32_t>(), rank.as<uint32_t>(), (size_t)m, rocprim::plus<uint32_t>(), stream));
+      uint32_t nu = 0;
+      TM_HIP(hipMemcpyAsync(&nu, rank.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, stream));
+      TM_HIP(hipStreamSynchronize(stream));
+      TM_TRY(ukeys.alloc((size_t)nu * 8)); TM_TRY(feat.alloc((size_t)nu * 384));
+      hipLaunchKernelGGL(k_epu_rows, dim3(g), dim3(256), 0, stream, keys2.as<unsigned long long>(), pos2.as<uint32_t>(), rank.as<uint32_t>(), (int64_t)m, row_of.as<uint32_t>(),
+                         ukeys.as<unsigned long long>());
+      TM_HIP(hipGetLastError());
+      TM_TRY(launch_features_pairs(pal_px, ukeys.p, nu, palettes, pal_size, feat.p, stream));
+    }
+    hipLaunchKernelGGL(k_epu_rerank<true>, dim3((unsigned)n), dim3(64), 0, stream, (const int16_t *)queries + q0 * 192, n, idx, k, (const int32_t *)tile_pal, ntiles, npal,
+                       feat.as<int16_t>(), off.as<unsigned long long>(), row_of.as<uint32_t>(), (int32_t *)out_tile + q0, (int32_t *)out_pal + q0, (uint32_t *)out_err + q0);
+    TM_HIP(hipGetLastError());
+    TM_HIP(hipStreamSynchronize(stream));  // the batch's buffers go back to the pool
+  }
   return TM_OK;
 }
 

@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
       } else if (SRC == 3) {
         const int64_t tile = t / use_lab;
         col = (uint32_t)palettes[(t - tile * use_lab) * pal_size + pal_px[tile * 64 + src]];
+      } else if (SRC == 4) {  // row t = the (tile, palette) pair pairs[t] = tile << 32 | palette (all ones: a pad, black)
+        const unsigned long long pr = reinterpret_cast<const unsigned long long *>(tiles)[t];
+        col = pr == ~0ull ? 0u : (uint32_t)palettes[(int64_t)(uint32_t)pr * pal_size + pal_px[(int64_t)(pr >> 32) * 64 + src]];
       } else if (SRC == 2) {
         const int ww = pal_size - 7;
         const int64_t wy = t / ww, wx = t - wy * ww;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         col = tiles[t * 64 + src];
       }
       float yy, uu, vv;
-      if (use_lab && SRC != 3)
+      if (use_lab && SRC != 3 && SRC != 4)
         rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
       else
         rgb_to_yuv(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, yy, uu, vv);
@@ -326,6 +329,16 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
   hipLaunchKernelGGL(k_features_i16<1>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
                      (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_features_pairs(const void *pal_px, const void *pairs, int64_t n, const void *palettes, int pal_size, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_i16<4>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)pairs, (const uint8_t *)pal_px, nullptr,
+                     (const int32_t *)palettes, pal_size, nullptr, n, 1, 0, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

@@ -11,10 +11,46 @@
 
 namespace tmx {
 
+// ANN.dll (double coordinates): exact nearest row by squared Euclidean distance, summed over the dimensions in order with one IEEE
+// multiplication and one addition each (what a plain loop compiles to without FMA contraction); ties -> lowest index (the build's
+// rule: ANN's traversal order is not recoverable).  One workgroup per query, threads over the rows; the trees of the one call site
+// (DoPalettization, tilingencoder.pas:4128, 4183-4187) hold at most PaletteCount x 8 BICO centroids.
+__global__ __launch_bounds__(256) void k_ann_f64(const double *__restrict__ rows, int n, int dd, const double *__restrict__ queries, int32_t *__restrict__ out_idx,
+                                                 double *__restrict__ out_err) {
+  __shared__ double s_d[256];
+  __shared__ int s_i[256];
+  const double *q = queries + (int64_t)blockIdx.x * dd;
+  double best = 0.0;
+  int bi = -1;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const double *p = rows + (int64_t)r * dd;
+    double s = 0.0;
+    for (int j = 0; j < dd; j++) { const double t = __dsub_rn(q[j], p[j]); s = __dadd_rn(s, __dmul_rn(t, t)); }
+    if (bi < 0 || s < best) { best = s; bi = r; }
+  }
+  s_d[threadIdx.x] = best; s_i[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const int oi = s_i[threadIdx.x + o];
+      const double od = s_d[threadIdx.x + o];
+      const int mi = s_i[threadIdx.x];
+      if (oi >= 0 && (mi < 0 || od < s_d[threadIdx.x] || (od == s_d[threadIdx.x] && oi < mi))) { s_d[threadIdx.x] = od; s_i[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out_idx[blockIdx.x] = s_i[0]; out_err[blockIdx.x] = s_i[0] >= 0 ? s_d[0] : 0.0; }
+}
 
 }  // namespace tmx
 
 using namespace tmx;
+
+struct tm_annd {
+  DevBuf rows;
+  int n = 0, dd = 0;
+  std::mutex mu;
+};
 
 struct tm_ann {
   DevBuf db, q, idx, err, all;
@@ -26,6 +62,48 @@ struct tm_ann {
 
 extern "C" {
 
+// ---- ANN.dll (extern.pas:178-180): double coordinates, any dimension
+tm_annd *ann_kdtree_create(double **rows, int n, int dd, int bs, int split) {
+  (void)bs; (void)split;  // bucket size / split rule shape a kd-tree; the exact answer does not depend on them
+  if (require_device() != TM_OK) return nullptr;
+  if (dd < 1 || n < 0 || (n > 0 && !rows)) { set_error("ann_kdtree_create: bad arguments (n %d, dd %d)", n, dd); return nullptr; }
+  tm_annd *a = new tm_annd();
+  a->n = n; a->dd = dd;
+  std::vector<double> flat((size_t)n * dd);
+  for (int i = 0; i < n; i++) memcpy(&flat[(size_t)i * dd], rows[i], (size_t)dd * 8);  // copied: no borrowed host pointers
+  if (a->rows.alloc(std::max<size_t>(flat.size(), 1) * 8) != TM_OK || (n && hipMemcpy(a->rows.p, flat.data(), flat.size() * 8, hipMemcpyHostToDevice) != hipSuccess)) {
+    delete a;
+    return nullptr;
+  }
+  return a;
+}
+
+void ann_kdtree_destroy(tm_annd *a) { delete a; }
+
+int ann_kdtree_search_batch(tm_annd *a, const double *queries, int nq, int32_t *idxs, double *errs) {
+  TM_CHECK(a && (nq == 0 || (queries && idxs)), TM_E_INVAL, "null argument");
+  if (nq <= 0) return TM_OK;
+  std::lock_guard<std::mutex> lk(a->mu);
+  DevBuf q, i, e;
+  TM_TRY(q.alloc((size_t)nq * a->dd * 8)); TM_TRY(i.alloc((size_t)nq * 4)); TM_TRY(e.alloc((size_t)nq * 8));
+  TM_HIP(hipMemcpy(q.p, queries, (size_t)nq * a->dd * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ann_f64, dim3((unsigned)nq), dim3(256), 0, nullptr, a->rows.as<double>(), a->n, a->dd, q.as<double>(), i.as<int32_t>(), e.as<double>());
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipMemcpy(idxs, i.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+  if (errs) TM_HIP(hipMemcpy(errs, e.p, (size_t)nq * 8, hipMemcpyDeviceToHost));
+  return TM_OK;
+}
+
+int ann_kdtree_search(tm_annd *a, const double *q, double eps, double *err) {
+  (void)eps;  // the reference passes 0.0 (exact, tilingencoder.pas:4128)
+  int32_t idx = -1;
+  double e = 0.0;
+  if (!a || !q || ann_kdtree_search_batch(a, q, 1, &idx, &e) != TM_OK) idx = -1;
+  if (err) *err = e;
+  return idx;
+}
+
+// ---- ANN_short.dll (extern.pas:182-185): the same export names in ANN_short.dll, `_short` on the Pascal side
 tm_ann *ann_kdtree_short_create(int16_t **rows, int n, int dd, int bs, int split) {
   (void)bs; (void)split;  // bucket size / split rule shape a kd-tree; the exact answer does not depend on them
   if (require_device() != TM_OK) return nullptr;

@@ -17,10 +17,14 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
 int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream);
+// int16 features of the (tile, palette) pairs pairs[i] = tile << 32 | palette (the rows the extended-palette re-rank asks for)
+int launch_features_pairs(const void *pal_px, const void *pairs, int64_t n, const void *palettes, int pal_size, void *out, hipStream_t stream);
 int launch_features_table(const void *pal_px, int64_t ntiles, const void *palettes, int npal, int pal_size, void *out, hipStream_t stream);
 
 // tm_epu.hip: FrameTilingExtendedPaletteUsage (tilingencoder.pas:1559-1610)
 int launch_knn_topk(const void *queries, int64_t nq, const void *db, int64_t nt, int k, void *out_idx, void *out_err, hipStream_t stream);
+int launch_epu_rerank_ondemand(const void *queries, int64_t nq, const void *knn_idx, int k, const void *tile_pal, int64_t ntiles, const void *pal_px,
+                               const void *palettes, int npal, int pal_size, void *out_tile, void *out_pal, void *out_err, hipStream_t stream);
 int launch_epu_rerank(const void *queries, int64_t nq, const void *knn_idx, int k, const void *tile_pal, int64_t ntiles, int npal,
                       const void *table, void *out_tile, void *out_pal, void *out_err, hipStream_t stream);
 
@@ -76,6 +80,9 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n_
                        void *out_pal_idx_local, const Collectives &co, hipStream_t stream);
 int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,
                int *host_iters, hipStream_t stream);
+// the same Lloyd iterations from the caller's own initial centres (k point indices, -1 = none) instead of the farthest-first picks
+int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, int k, const int64_t *host_init_idx, int max_iter, void *assign, void *centroids,
+                      int *host_k, int *host_iters, hipStream_t stream);
 int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                           hipStream_t stream);
 // the same for the palettes p with p % pal_world == pal_rank only (independent tasks, one thread per palette in the reference:

@@ -881,15 +881,31 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
 // ---- driver ----------------------------------------------------------------------------------------------------
 // Batched k-means over nseg contiguous segments.  seg_begin/seg_count are host arrays.  Outputs assign (global point
 // order), cent [nseg][k][d], host_kk[nseg] live centroid counts.
+// the caller's own initial centres instead of the farthest-first picks: point indices (relative to the segment), -1 = none
+__global__ void k_seed_centres(Seg *__restrict__ segs, int nseg, int k, const int32_t *__restrict__ pts, int d, const long long *__restrict__ idx, double *__restrict__ cent) {
+  const int seg = blockIdx.x;
+  if (seg >= nseg) return;
+  Seg sg = segs[seg];
+  int kk = 0;
+  for (int c = 0; c < k; c++) {
+    const long long i = idx[(int64_t)seg * k + c];
+    if (i < 0 || i >= sg.count) continue;  // uniform over the workgroup
+    for (int j = threadIdx.x; j < d; j += blockDim.x) cent[((int64_t)seg * k + kk) * d + j] = (double)pts[(sg.begin + i) * d + j];
+    kk++;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { sg.kk = kk; sg.init_done = 1; sg.changed = 0; segs[seg] = sg; }
+}
+
 static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const std::vector<int64_t> &seg_begin,
                           const std::vector<int64_t> &seg_count, int k, int max_iter, int32_t *assign, double *cent,
-                          std::vector<int> *host_kk, int *host_iters, hipStream_t stream) {
+                          std::vector<int> *host_kk, int *host_iters, hipStream_t stream, const int64_t *init_idx = nullptr) {
   TM_CHECK(d == 3 || d == 192, TM_E_INVAL, "kmeans: only d = 3 (pixels) or 192 (tile features) are built");
   TM_CHECK(k >= 1 && k <= 65536, TM_E_INVAL, "kmeans: k out of range");
   const int nseg = (int)seg_begin.size();
   if (host_iters) *host_iters = 0;
   if (nseg == 0) return TM_OK;
-  if (d == 3) {  // the whole clustering in one launch when its workgroups fit the chip together
+  if (d == 3 && !init_idx) {  // the whole clustering in one launch when its workgroups fit the chip together
     int used = 0;
     TM_TRY(kmeans3_persistent(pts, w, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, &used));
     if (used) return TM_OK;
@@ -927,8 +943,14 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   TM_HIP(hipMemsetAsync(cent, 0, (size_t)nseg * k * d * 8, stream));
   Seg *ds = dsegs.as<Seg>();
   const int sg_grid = (nseg + 63) / 64;
+  DevBuf didx;
+  if (init_idx) {
+    TM_TRY(didx.alloc((size_t)nseg * k * 8));
+    TM_HIP(hipMemcpyAsync(didx.p, init_idx, (size_t)nseg * k * 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_seed_centres, dim3(nseg), dim3(64), 0, stream, ds, nseg, k, pts, d, didx.as<long long>(), cent);
+  } else
   hipLaunchKernelGGL(k_ff_first, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, pts, d, cent);
-  for (int c = 1; c < k; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
+  for (int c = 1; c < k && !init_idx; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
     if (d == 3)
       hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
     else
@@ -999,6 +1021,11 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
 
 int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, int max_iter, void *assign, void *centroids, int *host_k,
                int *host_iters, hipStream_t stream) {
+  return run_kmeans_seeded(pts, weights, n, d, k, nullptr, max_iter, assign, centroids, host_k, host_iters, stream);
+}
+
+int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, int k, const int64_t *host_init_idx, int max_iter, void *assign, void *centroids,
+                      int *host_k, int *host_iters, hipStream_t stream) {
   TM_TRY(require_device());
   TM_CHECK(n >= 0, TM_E_INVAL, "kmeans: negative point count");
   if (host_k) *host_k = 0;
@@ -1007,7 +1034,7 @@ int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, in
   std::vector<int64_t> b{0}, c{n};
   std::vector<int> kk;
   TM_TRY(kmeans_batched((const int32_t *)pts, (const uint32_t *)weights, d, b, c, k, max_iter, (int32_t *)assign, (double *)centroids,
-                        &kk, host_iters, stream));
+                        &kk, host_iters, stream, host_init_idx));
   if (host_k) *host_k = kk[0];
   return TM_OK;
 }

@@ -64,6 +64,7 @@ _ENC_SIGS = {
     "tm_get_keyframes": (c_int, [c_void_p, c_void_p]),
     "tm_get_frame_correlations": (c_int, [c_void_p, c_void_p]),
     "tm_get_stage_ms": (c_int, [c_void_p, c_void_p]),
+    "tm_get_psnr": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_double)]),
     "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_reload_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
@@ -211,6 +212,14 @@ class TilingEncoder:
         out = np.zeros(self.counts()["frames"], np.float32)
         check(self._L.tm_get_frame_correlations(c_void_p(self._h), out.ctypes.data_as(c_void_p)))
         return out
+
+    def PSNR(self):
+        """TKeyFrame.LogPSNR (tilingencoder.pas:1006-1028): {"per_keyframe": [...], "global": mean PSNR-HVS by tile}"""
+        n = self.counts()["keyframes"]
+        per = np.zeros(max(n, 1), np.float64)
+        g = c_double()
+        check(self._L.tm_get_psnr(c_void_p(self._h), per.ctypes.data_as(c_void_p), ctypes.byref(g)))
+        return {"per_keyframe": [float(v) for v in per[:n]], "global": g.value, "unit": "dB, PSNR-HVS by tile (LogPSNR)"}
 
     def StageMs(self):
         out = np.zeros(8, np.float64)

@@ -167,6 +167,20 @@ def kmeans(pts, weights, k, max_iter=300):
     return hk.value, assign, cent, hi.value
 
 
+def kmeans_seeded(pts, weights, k, init_idx, max_iter=300):
+    """the same Lloyd iterations from the caller's own initial centres (init_idx: k point indices, -1 = none)"""
+    import numpy as np
+    n, d = pts.shape
+    assign = torch.empty((n,), dtype=torch.int32, device=pts.device)
+    cent = torch.zeros((k, d), dtype=torch.float64, device=pts.device)
+    idx = np.full(k, -1, np.int64)
+    idx[: len(init_idx)] = np.asarray(init_idx, np.int64)[:k]
+    hk, hi = ctypes.c_int(), ctypes.c_int()
+    check(lib().tm_stage_kmeans_seeded(_p(pts), _p(weights), n, d, k, idx.ctypes.data_as(ctypes.c_void_p), max_iter, _p(assign), _p(cent),
+                                       ctypes.byref(hk), ctypes.byref(hi), _stream()))
+    return hk.value, assign, cent, hi.value
+
+
 def quantize_palettes(tiles, pal_idx, npal, pal_size, max_iter=300):
     """QuantizeUsingYakmo + DoQuantization for every palette (tilingencoder.pas:4434-4564) -> int32 [npal][pal_size]"""
     out = torch.empty((npal, pal_size), dtype=torch.int32, device=tiles.device)
