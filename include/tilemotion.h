@@ -118,6 +118,13 @@ TM_API int tm_lz_compress_host(const uint8_t *src, size_t n, uint8_t *dst, size_
 /* LZDecompress, extern.pas:441-458: one stream; *out_n = decoded size (set even when cap is too small -> TM_E_INVAL),
  * *consumed (optional) = bytes of src the stream occupied, so that the next key frame's stream can follow. */
 TM_API int tm_lz_decompress_host(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *out_n, size_t *consumed);
+/* GenerateY4M (:2126-2199) and GeneratePNGs (:2075-2124): the frames as Render draws them with the constructor's defaults
+ * (predicted items copied from the previous output frame, tiles through the item's palette and mirrors; :3573-3640, :5505-5507), or the
+ * source frames (input != 0).  Y4M: 'YUV4MPEG2 W.. H.. F..:1000000 Ip C444', full-resolution Y, U + 128, V + 128 planes from RGBToYUV
+ * (utils.pas:478-490), rounded and clamped.  PNGs: <OutputFileName without extension>_NNNN.png (24-bit RGB) + <...>.txt with the
+ * palettes, one 'FFBBGGRR' line per colour.  Host code (export tooling). */
+TM_API int tm_generate_y4m(tm_encoder *, const char *path, int input);
+TM_API int tm_generate_pngs(tm_encoder *, int input);
 /* ReloadGTM, :2059 -> LoadStream, :4880-5175: replaces the encoder's tiles (palette indices only), palettes, tile maps and key
  * frames with the file's; the video set with tm_set_video must match the file's header (:5021-5032) or TM_E_INVAL comes back.
  * Afterwards the read-back views and tm_save_gtm work on the loaded state. */

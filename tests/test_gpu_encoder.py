@@ -374,3 +374,82 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
         assert np.array_equal(out[r][0], want[0])
         for a, b in zip(out[r][1], want[1]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("radius", [0, 8])
+def test_y4m_and_png_export_show_what_the_player_shows(oracle, tmp_path, radius):
+    """GenerateY4M / GeneratePNGs (tilingencoder.pas:2126-2199, 2075-2124): the rendered output frames must be the pictures the reference's
+    player (gtm.player.js semantics, tests/gtm_reader.py, pinned by the demo streams) decodes from the saved .gtm -- as RGB in the PNGs,
+    as RGBToYUV (utils.pas:478-490) rounded planes in the .y4m; the input export gives back the source frames"""
+    import zlib
+    from tiler_amd import synth
+    from tests import gtm_reader
+    frames = synth.video(6, 64, 48, cut=3)
+    out = str(tmp_path / "clip.gtm")
+    enc = _run_encoder(frames, PaletteCount=3, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, FrameTilingExtendedPaletteUsage=False,
+                       GlobalTilingTileCount=120, OutputFileName=out)
+    _, player = gtm_reader.play(oracle, open(out, "rb").read())
+    shown = [np.asarray(f) & 0xFFFFFF for f in player.frames]
+    assert len(shown) == 6
+    if radius:
+        assert any(((enc.TileMap(f)["Flags"] >> 2) & 1).any() for f in range(6))  # some items are motion predicted
+
+    def png_rgb(path):
+        b = open(path, "rb").read()
+        assert b[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, w, h = 8, b"", 0, 0
+        while pos < len(b):
+            n = int.from_bytes(b[pos:pos + 4], "big")
+            typ, data = b[pos + 4:pos + 8], b[pos + 8:pos + 8 + n]
+            assert zlib.crc32(typ + data) == int.from_bytes(b[pos + 8 + n:pos + 12 + n], "big")
+            if typ == b"IHDR":
+                w, h = int.from_bytes(data[:4], "big"), int.from_bytes(data[4:8], "big")
+                assert data[8:] == bytes([8, 2, 0, 0, 0])
+            if typ == b"IDAT":
+                idat += data
+            pos += 12 + n
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 3)
+        assert (raw[:, 0] == 0).all()
+        px = raw[:, 1:].reshape(h, w, 3).astype(np.uint32)
+        return px[:, :, 0] | (px[:, :, 1] << 8) | (px[:, :, 2] << 16)
+
+    enc.GeneratePNGs(False)
+    for f in range(6):
+        assert np.array_equal(png_rgb(str(tmp_path / ("clip_%04d.png" % f))), shown[f])
+    pal_lines = open(str(tmp_path / "clip.txt")).read().split()
+    assert pal_lines == ["%08X" % (0xFF000000 | (int(c) & 0xFFFFFFFF)) for c in enc.Palettes().reshape(-1)]
+
+    def y4m_frames(path):
+        b = open(path, "rb").read()
+        head, rest = b.split(b"\n", 1)
+        assert head == b"YUV4MPEG2 W64 H48 F24000000:1000000 Ip C444"
+        out_f, n = [], 64 * 48 * 3
+        while rest:
+            assert rest[:7] == b"FRAME \n"
+            out_f.append(np.frombuffer(rest[7:7 + n], np.uint8).reshape(3, 48, 64))
+            rest = rest[7 + n:]
+        return out_f
+
+    def to_yuv(img):
+        import ctypes
+        o = np.zeros((3,) + img.shape, np.uint8)
+        y, u, v = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        for (yy, xx), c in np.ndenumerate(img):
+            oracle.L.tmo_rgb_to_yuv(int(c) & 255, (int(c) >> 8) & 255, (int(c) >> 16) & 255, ctypes.byref(y), ctypes.byref(u), ctypes.byref(v))
+            for k, val in enumerate((y.value, u.value + np.float32(128), v.value + np.float32(128))):
+                o[k, yy, xx] = min(255, max(0, int(np.rint(np.float32(val)))))
+        return o
+
+    y4 = str(tmp_path / "out.y4m")
+    enc.GenerateY4M(y4, False)
+    got = y4m_frames(y4)
+    assert len(got) == 6
+    for f in range(6):
+        assert np.array_equal(got[f], to_yuv(shown[f]))
+    y4i = str(tmp_path / "in.y4m")
+    enc.GenerateY4M(y4i, True)
+    src = [((frames[f] & 0xFF) << 16) | (frames[f] & 0xFF00) | ((frames[f] >> 16) & 0xFF) for f in range(6)]  # RGB32 -> 0x00BBGGRR
+    got = y4m_frames(y4i)
+    for f in range(6):
+        assert np.array_equal(got[f], to_yuv(np.asarray(src[f], np.uint32)))
+    enc.close()

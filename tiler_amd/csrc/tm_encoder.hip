@@ -960,6 +960,174 @@ static int save_to(tm_encoder *e, const char *path) {  // Save, tilingencoder.pa
   return write_gtm(path, in);
 }
 
+// ---- GenerateY4M / GeneratePNGs (tilingencoder.pas:2126-2199, 2075-2124): the frames as Render (3455-3640) draws them with the
+// constructor's defaults (FRenderPredicted, FRenderMirrored, FRenderOutputDithered on, no gamma: 5505-5507).  Host code: export tooling.
+namespace {
+struct FrameRenderer {
+  tm_encoder *e;
+  int sw, sh;
+  std::vector<uint8_t> pal_px, fflags;
+  std::vector<uint32_t> front, back, in_tiles;  // 0x00BBGGRR
+  int init(bool input) {
+    sw = e->tm_w * 8; sh = e->tm_h * 8;
+    front.assign((size_t)sw * sh, 0); back.assign((size_t)sw * sh, 0);
+    if (input) {
+      TM_CHECK(e->ftiles.p && !e->load_sharded, TM_E_INVAL, "input frames: the frame tiles are not in memory (run Load)");
+      in_tiles.resize((size_t)e->tm_size() * 64);
+      fflags.resize((size_t)e->q);
+      TM_HIP(hipMemcpy(fflags.data(), e->fflags.p, (size_t)e->q, hipMemcpyDeviceToHost));
+    } else {
+      TM_CHECK(e->has_pal_px && (e->steps_done & (1 << TM_STEP_RECONSTRUCT)), TM_E_INVAL, "output frames: Reconstruct (or ReloadGTM) has not been run");
+      pal_px.resize((size_t)std::max<int64_t>(e->t, 1) * 64);
+      if (e->t) TM_HIP(hipMemcpy(pal_px.data(), e->gpal_px.p, (size_t)e->t * 64, hipMemcpyDeviceToHost));
+    }
+    return TM_OK;
+  }
+  int render(int f, bool input) {  // -> front
+    const int64_t per = e->tm_size();
+    if (input) {  // "Input" tab (3537-3570): the frame's tiles back in their original orientation
+      TM_HIP(hipMemcpy(in_tiles.data(), e->ftiles.as<uint8_t>() + (int64_t)f * per * 256, (size_t)per * 256, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < per; i++) {
+        const int sx = (int)(i % e->tm_w), sy = (int)(i / e->tm_w), fl = fflags[(size_t)(f * per + i)];
+        for (int ty = 0; ty < 8; ty++)
+          for (int tx = 0; tx < 8; tx++)
+            front[(size_t)(sy * 8 + ty) * sw + sx * 8 + tx] = in_tiles[(size_t)i * 64 + ((fl & 2) ? 7 - ty : ty) * 8 + ((fl & 1) ? 7 - tx : tx)] & 0xffffffu;
+      }
+      return TM_OK;
+    }
+    std::vector<tm_tilemap_item> tmi((size_t)per);
+    TM_TRY(tm_get_tilemap(e, f, tmi.data()));
+    std::swap(front, back);  // FRenderBackBuffer := the previous output frame (3575-3576)
+    std::fill(front.begin(), front.end(), 0u);
+    for (int64_t i = 0; i < per; i++) {
+      const tm_tilemap_item &it = tmi[(size_t)i];
+      const int sx = (int)(i % e->tm_w), sy = (int)(i / e->tm_w);
+      if (it.Flags & 4) {  // predicted: 8 x 8 pixels of the back buffer at the predicted offset (3595-3606)
+        for (int ty = 0; ty < 8; ty++)
+          for (int tx = 0; tx < 8; tx++) {
+            const int by = std::min(std::max(sy * 8 + it.PredictedY + ty, 0), sh - 1), bx = std::min(std::max(sx * 8 + it.PredictedX + tx, 0), sw - 1);
+            front[(size_t)(sy * 8 + ty) * sw + sx * 8 + tx] = back[(size_t)by * sw + bx];
+          }
+      } else if (it.TileIdx >= 0 && it.TileIdx < e->t && it.PalIdx >= 0 && it.PalIdx < e->s.PaletteCount) {
+        const uint8_t *px = &pal_px[(size_t)it.TileIdx * 64];
+        const int32_t *pal = &e->palettes_host[(size_t)it.PalIdx * e->s.PaletteSize];
+        for (int ty = 0; ty < 8; ty++)
+          for (int tx = 0; tx < 8; tx++)
+            front[(size_t)(sy * 8 + ty) * sw + sx * 8 + tx] = (uint32_t)pal[px[((it.Flags & 2) ? 7 - ty : ty) * 8 + ((it.Flags & 1) ? 7 - tx : tx)]] & 0xffffffu;
+      }
+    }
+    return TM_OK;
+  }
+};
+
+uint32_t crc32_of(const uint8_t *p, size_t n, uint32_t crc) {
+  static uint32_t table[256];
+  static bool made = false;
+  if (!made) {
+    for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+    made = true;
+  }
+  crc = ~crc;
+  for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+  return ~crc;
+}
+void png_chunk(std::vector<uint8_t> &out, const char *type, const std::vector<uint8_t> &data) {
+  auto be32 = [&](uint32_t v) { out.push_back(v >> 24); out.push_back(v >> 16); out.push_back(v >> 8); out.push_back(v); };
+  be32((uint32_t)data.size());
+  const size_t at = out.size();
+  out.insert(out.end(), type, type + 4);
+  out.insert(out.end(), data.begin(), data.end());
+  be32(crc32_of(out.data() + at, out.size() - at, 0));
+}
+// 24-bit RGB PNG (pf24bit, 2086); the image data travels in stored deflate blocks: valid for every decoder, no codec dependency
+int write_png(const std::string &path, const std::vector<uint32_t> &img, int w, int h) {
+  std::vector<uint8_t> raw((size_t)h * (1 + (size_t)w * 3));
+  for (int y = 0; y < h; y++) {
+    uint8_t *row = &raw[(size_t)y * (1 + (size_t)w * 3)];
+    row[0] = 0;  // filter: none
+    for (int x = 0; x < w; x++) { const uint32_t c = img[(size_t)y * w + x]; row[1 + x * 3] = c & 0xff; row[2 + x * 3] = (c >> 8) & 0xff; row[3 + x * 3] = (c >> 16) & 0xff; }
+  }
+  std::vector<uint8_t> z = {0x78, 0x01};
+  uint32_t a = 1, b = 0;
+  for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
+  for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+    const size_t n = std::min<size_t>(65535, raw.size() - off);
+    z.push_back(off + n >= raw.size() ? 1 : 0);
+    z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+    z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+    if (raw.empty()) break;
+  }
+  z.push_back(b >> 8); z.push_back(b); z.push_back(a >> 8); z.push_back(a);
+  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  std::vector<uint8_t> ihdr = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 2, 0, 0, 0};
+  png_chunk(out, "IHDR", ihdr);
+  png_chunk(out, "IDAT", z);
+  png_chunk(out, "IEND", {});
+  std::ofstream f(path, std::ios::binary);
+  TM_CHECK(f.good(), TM_E_IO, "cannot write %s", path.c_str());
+  f.write((const char *)out.data(), (std::streamsize)out.size());
+  return TM_OK;
+}
+std::string strip_ext(const std::string &p) {  // ChangeFileExt(name, '')
+  const size_t dot = p.find_last_of('.'), sep = p.find_last_of("/\\");
+  return (dot != std::string::npos && (sep == std::string::npos || dot > sep)) ? p.substr(0, dot) : p;
+}
+}  // namespace
+
+static int generate_y4m(tm_encoder *e, const char *path, bool input) {  // GenerateY4M, tilingencoder.pas:2126-2199
+  TM_CHECK(path && *path, TM_E_INVAL, "GenerateY4M: no file name");
+  TM_HIP(hipSetDevice(e->device));
+  FrameRenderer r{e};
+  TM_TRY(r.init(input));
+  std::ofstream f(path, std::ios::binary);
+  TM_CHECK(f.good(), TM_E_IO, "cannot write %s", path);
+  char hdr[128];
+  snprintf(hdr, sizeof(hdr), "YUV4MPEG2 W%d H%d F%lld:1000000 Ip C444\n", r.sw, r.sh, (long long)std::nearbyint(e->fps * 1000000.0));  // 2146
+  f << hdr;
+  const size_t plane = (size_t)r.sw * r.sh;
+  std::vector<uint8_t> yuv(plane * 3);
+  auto rnd = [](float v, float add) { const long long q = (long long)std::nearbyint((double)(v + add)); return (uint8_t)std::min<long long>(255, std::max<long long>(0, q)); };
+  for (int fr = 0; fr < e->nframes; fr++) {
+    TM_TRY(r.render(fr, input));
+    f << "FRAME \n";  // (with the space, 2161)
+    for (size_t i = 0; i < plane; i++) {
+      const uint32_t c = r.front[i];
+      const int rr = c & 0xff, gg = (c >> 8) & 0xff, bb = (c >> 16) & 0xff;
+      // RGBToYUV, utils.pas:478-490: the decimal constants are doubles, every right-hand side narrows to Single once
+      const float yy = (float)(rr * (299.0 / 1000) + gg * (587.0 / 1000) + bb * (114.0 / 1000));
+      const float uu = (float)(((double)bb - (double)yy) * 0.492), vv = (float)(((double)rr - (double)yy) * 0.877);
+      yuv[i] = rnd(yy, 0.0f);
+      yuv[plane + i] = rnd(uu, 128.0f);      // uf - Low(ShortInt)
+      yuv[2 * plane + i] = rnd(vv, 128.0f);
+    }
+    f.write((const char *)yuv.data(), (std::streamsize)yuv.size());
+    if ((fr & 15) == 15) progress(e, TM_STEP_SAVE, fr, e->nframes);
+  }
+  TM_CHECK(f.good(), TM_E_IO, "write to %s failed", path);
+  return TM_OK;
+}
+
+static int generate_pngs(tm_encoder *e, bool input) {  // GeneratePNGs, tilingencoder.pas:2075-2124
+  TM_CHECK(!e->s.OutputFileName.empty(), TM_E_INVAL, "GeneratePNGs: OutputFileName is not set");
+  TM_HIP(hipSetDevice(e->device));
+  FrameRenderer r{e};
+  TM_TRY(r.init(input));
+  const std::string base = strip_ext(e->s.OutputFileName);
+  {
+    std::ofstream pf(base + ".txt");  // the palettes, one colour per line: IntToHex($ff000000 or PaletteRGB, 8) (2101-2104)
+    TM_CHECK(pf.good(), TM_E_IO, "cannot write %s.txt", base.c_str());
+    char line[16];
+    for (int32_t c : e->palettes_host) { snprintf(line, sizeof(line), "%08X", 0xff000000u | (uint32_t)c); pf << line << "\n"; }
+  }
+  for (int fr = 0; fr < e->nframes; fr++) {
+    TM_TRY(r.render(fr, input));
+    char name[32];
+    snprintf(name, sizeof(name), "_%04d.png", fr);
+    TM_TRY(write_png(base + name, r.front, r.sw, r.sh));
+  }
+  return TM_OK;
+}
+
 static int run_step(tm_encoder *e, int step) {
   TM_HIP(hipSetDevice(e->device));
   const auto t0 = std::chrono::steady_clock::now();
@@ -1385,6 +1553,16 @@ int tm_reload_gtm(tm_encoder *e, const char *path) {  // ReloadGTM, tilingencode
   // tiles or from RGB pixels check for them (need_frame_tiles / need_global_rgb) and ask for Load / Reduce when they are missing.
   e->steps_done = 0xff;
   return TM_OK;
+}
+
+int tm_generate_y4m(tm_encoder *e, const char *path, int input) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  return generate_y4m(e, path, input != 0);
+}
+
+int tm_generate_pngs(tm_encoder *e, int input) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  return generate_pngs(e, input != 0);
 }
 
 int tm_save_gtm(tm_encoder *e, const char *path) {

@@ -67,6 +67,8 @@ _ENC_SIGS = {
     "tm_get_psnr": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_double)]),
     "tm_save_gtm": (c_int, [c_void_p, c_char_p]),
     "tm_reload_gtm": (c_int, [c_void_p, c_char_p]),
+    "tm_generate_y4m": (c_int, [c_void_p, c_char_p, c_int]),
+    "tm_generate_pngs": (c_int, [c_void_p, c_int]),
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_set_dither_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_set_collective": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -261,6 +263,14 @@ class TilingEncoder:
             self.Run(TEncoderStep.esSave)
         else:
             check(self._L.tm_save_gtm(c_void_p(self._h), os.fsencode(path)))
+
+    def GenerateY4M(self, path, input=False):
+        """GenerateY4M (tilingencoder.pas:2126): the rendered output frames (or the source frames) as a C444 .y4m"""
+        check(self._L.tm_generate_y4m(c_void_p(self._h), os.fsencode(path), int(bool(input))))
+
+    def GeneratePNGs(self, input=False):
+        """GeneratePNGs (tilingencoder.pas:2075): <OutputFileName>_NNNN.png per frame + the palettes as <OutputFileName>.txt"""
+        check(self._L.tm_generate_pngs(c_void_p(self._h), int(bool(input))))
 
     def ReloadGTM(self, path):
         """ReloadGTM (tilingencoder.pas:2059) -> LoadStream (:4880): tiles, palettes, tile maps, key frames from a .gtm"""
