@@ -365,6 +365,31 @@ def test_kmeans(oracle, n, d, k):
     assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64)), "centroids must match bit for bit"
 
 
+@pytest.mark.parametrize("case", ["lattice-ties", "tight-clusters", "one-cluster-far"])
+def test_kmeans_192_skipping_iterations_are_exact(oracle, case):
+    """the iterations that skip points whose bounds prove their assignment (k_h_bounds / k_h_full) against the oracle's plain Lloyd on data
+    that stresses them: lattice points with many EXACTLY equal distances (ties go to the lowest centroid), clusters tighter than the
+    margins of any sloppy bound, and one far cluster (large centroid displacements in the first iterations)"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(len(case))
+    n, d, k = 6000, 192, 16
+    if case == "lattice-ties":
+        pts = (rng.integers(-1, 2, size=(n, d)) * 100).astype(np.int32)
+        pts[:, 8:] = 0  # 3^8 lattice points, each many times: equal distances everywhere
+    elif case == "tight-clusters":
+        centres = rng.integers(-2000, 2000, size=(24, d))
+        pts = (centres[rng.integers(0, 24, size=n)] + rng.integers(-2, 3, size=(n, d))).astype(np.int32)
+    else:
+        pts = rng.integers(-50, 51, size=(n, d)).astype(np.int32)
+        pts[:40] += 20000
+    w = rng.integers(1, 9, size=n).astype(np.uint32)
+    kk, assign, cent, iters = oracle.kmeans(pts, w, k)
+    g_kk, g_assign, g_cent, g_iters = stages.kmeans(_dev(pts), _dev(w), k)
+    assert g_kk == kk and g_iters == iters
+    assert np.array_equal(g_assign.cpu().numpy(), assign)
+    assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64))
+
+
 def test_quantize_and_palettize(tiles_flags, oracle):
     from tiler_amd import stages
     tiles, _ = tiles_flags

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
                                                    const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                    int k, const double *__restrict__ cent, int32_t *__restrict__ assign,
                                                    u64 *__restrict__ sums, u64 *__restrict__ cnts, int rows_per_block, int lds_delta,
-                                                   const int *__restrict__ quiet) {
+                                                   const int *__restrict__ quiet, double *__restrict__ ub = nullptr, double *__restrict__ lb = nullptr) {
   if (*quiet >= 0) return;  // converged earlier in this batch of launches
   constexpr int D = 192, ROWS = 256 * PPT, PITCH = A_DCH + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -359,10 +359,10 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
   if (tid == 0) s_nmoved = 0;
   if (lds_delta)
     for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
-  double bd[PPT];
+  double bd[PPT], bd2[PPT];  // smallest and second smallest distance (the second only feeds the bounds of the later iterations)
   int bc[PPT];
 #pragma unroll
-  for (int m = 0; m < PPT; m++) { bd[m] = 0.0; bc[m] = -1; }
+  for (int m = 0; m < PPT; m++) { bd[m] = 0.0; bd2[m] = 1.0e300; bc[m] = -1; }
   const int4 zero4 = make_int4(0, 0, 0, 0);
 #pragma unroll 1
   for (int c0 = 0; c0 < kk; c0 += KCH) {
@@ -425,7 +425,20 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
     for (int m = 0; m < PPT; m++)
 #pragma unroll
       for (int c = 0; c < KCH; c++)
-        if (c0 + c < kk && (bc[m] < 0 || s[m][c] < bd[m])) { bd[m] = s[m][c]; bc[m] = c0 + c; }
+        if (c0 + c < kk) {
+          if (bc[m] < 0 || s[m][c] < bd[m]) { if (bc[m] >= 0) bd2[m] = bd[m]; bd[m] = s[m][c]; bc[m] = c0 + c; }
+          else if (s[m][c] < bd2[m]) bd2[m] = s[m][c];
+        }
+  }
+  if (ub) {  // Euclidean bounds for the skipping iterations, rounded the safe way: ub >= the distance to the own centroid, lb <= to any other
+#pragma unroll
+    for (int m = 0; m < PPT; m++) {
+      const int r = tid + 256 * m;
+      if (r >= nrows) continue;
+      const int64_t gi = sg.begin + row0 + r;
+      ub[gi] = sqrt(bd[m]) * (1.0 + 1e-12);
+      lb[gi] = sqrt(bd2[m]) * (1.0 - 1e-12);
+    }
   }
   // moved points -> list
 #pragma unroll
@@ -444,18 +457,19 @@ __global__ __launch_bounds__(256) void k_assign192(const int32_t *__restrict__ p
   if (nmoved == 0) return;
   if (tid == 0) atomicAdd(&segs[seg].changed, nmoved);
 #pragma unroll 2
-  for (int e = 0; e < nmoved; e++) {  // every thread owns one dimension (thread 192: the weight)
+  for (int e = tid >> 6; e < nmoved; e += 4) {  // a wave per moved row (four rows in flight, eight with the unrolling): lane -> dimensions lane, +64, +128; 192 = the weight
     const int r = s_moved[e * 3], old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
     const int64_t gi = sg.begin + row0 + r;
     const long long wi = w ? (long long)w[gi] : 1;
-    if (tid <= D) {
-      const u64 v = tid < D ? (u64)(wi * pts[gi * D + tid]) : (u64)wi;
+#pragma unroll
+    for (int j = tid & 63; j <= D; j += 64) {
+      const u64 v = j < D ? (u64)(wi * pts[gi * D + j]) : (u64)wi;
       if (lds_delta) {
-        atomicAdd(&s_delta[nw * (D + 1) + tid], v);
-        if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + tid], (u64)0 - v);
+        atomicAdd(&s_delta[nw * (D + 1) + j], v);
+        if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
       } else {
-        u64 *base = tid < D ? sums + (int64_t)seg * k * D : cnts + (int64_t)seg * k;
-        const int64_t stride = tid < D ? D : 1, off = tid < D ? tid : 0;
+        u64 *base = j < D ? sums + (int64_t)seg * k * D : cnts + (int64_t)seg * k;
+        const int64_t stride = j < D ? D : 1, off = j < D ? j : 0;
         atomicAdd(&base[nw * stride + off], v);
         if (old >= 0) atomicAdd(&base[old * stride + off], (u64)0 - v);
       }
@@ -554,19 +568,245 @@ __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int
 
 template <int PPT>
 static void launch_assign192_t(dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w, Seg *ds,
-                               int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet) {
+                               int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet, double *ub, double *lb) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192<PPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr_set = true; }
-  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet);
+  hipLaunchKernelGGL(k_assign192<PPT>, grid, dim3(256), lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb);
 }
 static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream, const int32_t *pts, const int32_t *ptsc, int64_t ntot, const uint32_t *w,
-                             Seg *ds, int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet) {
+                             Seg *ds, int k, const double *cent, int32_t *assign, u64 *sums, u64 *cnts, int rows, int lds_delta, const int *quiet,
+                             double *ub = nullptr, double *lb = nullptr) {
   switch (ppt) {
-    case 1: launch_assign192_t<1>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
-    case 2: launch_assign192_t<2>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
-    case 3: launch_assign192_t<3>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
-    case 4: launch_assign192_t<4>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
-    default: launch_assign192_t<5>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet); break;
+    case 1: launch_assign192_t<1>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb); break;
+    case 2: launch_assign192_t<2>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb); break;
+    case 3: launch_assign192_t<3>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb); break;
+    case 4: launch_assign192_t<4>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb); break;
+    default: launch_assign192_t<5>(grid, lds, stream, pts, ptsc, ntot, w, ds, k, cent, assign, sums, cnts, rows, lds_delta, quiet, ub, lb); break;
+  }
+}
+
+// ---- D = 192: iterations that skip what cannot change (Hamerly's bounds, made exact) ------------------------------------------
+// After a few full iterations most tiles sit firmly in their cluster and the centroids barely move, yet the assignment step costs
+// the same 16 x 192 double-precision distance terms per tile every time.  Per point two Euclidean bounds are kept: ub >= its distance
+// to its own centroid, lb <= its distance to every other one; a centroid update moves them by the centroids' displacements.  While
+//      ub < max(lb, half the distance from the own centroid to the nearest other one)
+// holds WITH a relative margin of 1e-9 on both sides, the own centroid is strictly the nearest by a margin six orders of magnitude above
+// the rounding of the distance arithmetic (192 fused multiply-adds: relative error below 1e-13) and of the bound bookkeeping (every
+// step rounds the safe way, with margins of 1e-12), so the assignment the full computation would make -- computed distances, ties to
+// the lowest index -- is the one the point already has: it is skipped.  Otherwise the distance to the own centroid is computed
+// (tightening ub), and if the test still fails the point is listed and goes through k_assign192 itself, which reads its rows through the list.
+// The result is therefore bit for bit that of the plain iterations (and of the oracle); only the work differs.
+constexpr int H_MAXK = 64;       // centroids kept in LDS by the skipping kernels
+constexpr double H_ETA = 1e-9;   // margin of the skip test
+constexpr int H_SLICE = 1024;    // points per workgroup of k_h_bounds
+__global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pts, int64_t n, const Seg *__restrict__ segs, const double *__restrict__ cent,
+                                                  const int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb,
+                                                  const double *__restrict__ cmove /* [k] displacement of each centroid, then the largest, the second largest, whose */,
+                                                  const double *__restrict__ shalf /* [k] half the distance to the nearest other centroid */, int k,
+                                                  int32_t *__restrict__ need, unsigned *__restrict__ need_cnt, const int *__restrict__ quiet) {
+  if (*quiet >= 0) return;
+  extern __shared__ double s_c[];  // [192][kk]: lanes of a wave read different centroids of one dimension -> different banks
+  __shared__ int s_list[H_SLICE];
+  __shared__ int s_nlist;
+  const int kk = segs[0].kk, tid = threadIdx.x;
+  for (int e = tid; e < kk * 192; e += 256) { const int c = e / 192, j = e - c * 192; s_c[j * kk + c] = cent[e]; }
+  if (tid == 0) s_nlist = 0;
+  __syncthreads();
+  const double dmax = cmove[k], dmax2 = cmove[k + 1];
+  const int amax = (int)cmove[k + 2];
+  const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
+  // pass 1, every point of the slice: move the bounds with the centroids; the points whose loosened bounds no longer prove them -> LDS list
+#pragma unroll
+  for (int r = 0; r < H_SLICE / 256; r++) {
+    const int64_t i = i0 + r * 256 + tid;
+    if (i >= n) break;
+    const int a = assign[i];
+    const double u = (ub[i] + cmove[a]) * (1.0 + 1e-15);
+    double l = lb[i] - (a == amax ? dmax2 : dmax);  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+    l -= fabs(l) * 1e-15;
+    ub[i] = u;
+    lb[i] = l;
+    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], l) * (1.0 - H_ETA))) s_list[atomicAdd(&s_nlist, 1)] = r * 256 + tid;
+  }
+  __syncthreads();
+  // pass 2, the listed ones (dense lanes): the distance to the own centroid in the arithmetic of the full computation; its square root
+  // bounds it from above.  Still unproven -> the global list
+  const int nlist = s_nlist;
+  for (int t = tid; t < nlist; t += 256) {
+    const int64_t i = i0 + s_list[t];
+    const int a = assign[i];
+    const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
+    const double *c = s_c + a;
+    double sd = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < 48; j++) {
+      const int4 v = p[j];
+      double d0 = __dsub_rn((double)v.x, c[(4 * j) * kk]); sd = __fma_rn(d0, d0, sd);
+      d0 = __dsub_rn((double)v.y, c[(4 * j + 1) * kk]); sd = __fma_rn(d0, d0, sd);
+      d0 = __dsub_rn((double)v.z, c[(4 * j + 2) * kk]); sd = __fma_rn(d0, d0, sd);
+      d0 = __dsub_rn((double)v.w, c[(4 * j + 3) * kk]); sd = __fma_rn(d0, d0, sd);
+    }
+    const double u = sqrt(sd) * (1.0 + 1e-12);
+    ub[i] = u;
+    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], lb[i]) * (1.0 - H_ETA))) need[atomicAdd(need_cnt, 1u)] = (int32_t)i;
+  }
+}
+
+// The listed points through the full computation: k_assign192's arithmetic (sum over dimensions in order of (p - c)^2, one IEEE subtraction
+// and one fused multiply-add each, ties -> lowest centroid) and its carried sums, shaped for FEW points: one point per lane read straight
+// from the chunk-major copy (32 bytes per chunk, the next chunk in flight), the centroids broadcast from LDS (staged from the transposed
+// copy k_h_update leaves; reading them as scalar operands through the scalar cache instead measured 20 % slower: 24 KB of centroids do
+// not stay in it), workgroups of NT points so that a short list still spreads over the chip.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
+                                                       const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
+                                                       int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
+                                                       double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
+                                                       const unsigned *__restrict__ need_cnt) {
+  if (*quiet >= 0) return;
+  constexpr int D = 192;
+  const unsigned cnt = *need_cnt, row0 = blockIdx.x * (unsigned)NT;
+  if (row0 >= cnt) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ int s_nmoved;
+  const int kk = segs[0].kk, tid = threadIdx.x;
+  double *s_c = reinterpret_cast<double *>(s_raw);                    // [D][KCH]
+  u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);       // [kk][D + 1]
+  int32_t *s_moved = reinterpret_cast<int32_t *>(s_delta + kk * (D + 1));  // [NT][3]: point, old, new
+  const bool active = row0 + tid < cnt;
+  const int64_t gi = need[active ? row0 + tid : row0];
+  for (int e = tid; e < kk * (D + 1); e += NT) s_delta[e] = 0;
+  if (tid == 0) s_nmoved = 0;
+  double bd = 0.0, bd2 = 1.0e300;
+  int bc = -1;
+  const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
+  const int64_t chunk_stride = n_total * (A_DCH / 4);  // int4 units between chunks
+#pragma unroll 1
+  for (int c0 = 0; c0 < kk; c0 += KCH) {
+    __syncthreads();
+    for (int e = tid; e < D * KCH; e += NT) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + c0 + (e % KCH)];
+    __syncthreads();
+    double s[KCH];
+#pragma unroll
+    for (int c = 0; c < KCH; c++) s[c] = 0.0;
+    int4 cur0 = src[0], cur1 = src[1];
+#pragma unroll 1
+    for (int ch = 0; ch < D / A_DCH; ch++) {
+      int4 nx0 = cur0, nx1 = cur1;
+      if (ch + 1 < D / A_DCH) { nx0 = src[(ch + 1) * chunk_stride]; nx1 = src[(ch + 1) * chunk_stride + 1]; }
+      const int v[A_DCH] = {cur0.x, cur0.y, cur0.z, cur0.w, cur1.x, cur1.y, cur1.z, cur1.w};
+#pragma unroll
+      for (int j = 0; j < A_DCH; j++) {
+        const double pj = (double)v[j];
+        const double *cj = s_c + (ch * A_DCH + j) * KCH;
+#pragma unroll
+        for (int c = 0; c < KCH; c += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
+          const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
+          s[c] = __fma_rn(t0, t0, s[c]);
+          s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
+        }
+      }
+      cur0 = nx0; cur1 = nx1;
+    }
+#pragma unroll
+    for (int c = 0; c < KCH; c++)
+      if (c0 + c < kk) {
+        if (bc < 0 || s[c] < bd) { if (bc >= 0) bd2 = bd; bd = s[c]; bc = c0 + c; }
+        else if (s[c] < bd2) bd2 = s[c];
+      }
+  }
+  if (active) {
+    ub[gi] = sqrt(bd) * (1.0 + 1e-12);
+    lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
+    const int old = assign[gi];
+    if (old != bc) {
+      assign[gi] = bc;
+      const int slot = atomicAdd(&s_nmoved, 1);
+      s_moved[slot * 3] = tid; s_moved[slot * 3 + 1] = old; s_moved[slot * 3 + 2] = bc;
+    }
+  }
+  __syncthreads();
+  const int nmoved = s_nmoved;
+  if (nmoved == 0) return;
+  if (tid == 0) atomicAdd(&segs[0].changed, nmoved);
+#pragma unroll 2
+  for (int e = tid >> 6; e < nmoved; e += NT / 64) {  // a wave per moved row between the carried sums (coalesced read, three dimensions per lane)
+    const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+    const int64_t mi = need[row0 + s_moved[e * 3]];
+    const long long wi = w ? (long long)w[mi] : 1;
+#pragma unroll
+    for (int j = tid & 63; j <= D; j += 64) {
+      const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
+      atomicAdd(&s_delta[nw * (D + 1) + j], v);
+      if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < kk * (D + 1); e += NT) {
+    const u64 v = s_delta[e];
+    if (v == 0) continue;
+    const int c = e / (D + 1), j = e - c * (D + 1);
+    if (j == D) atomicAdd(&cnts[c], v);
+    else atomicAdd(&sums[(int64_t)c * D + j], v);
+  }
+}
+
+// k_update_all for one segment, plus what the bounds need: how far every centroid moved (rounded up) and half its distance to the
+// nearest other centroid (rounded down)
+__global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k, u64 *__restrict__ sums, u64 *__restrict__ cnts, double *__restrict__ cent,
+                                                   double *__restrict__ cent_t /* [192][kt], zero beyond kk */, int kt, double *__restrict__ cmove,
+                                                   double *__restrict__ shalf, unsigned *__restrict__ need_cnt, int it, int *__restrict__ quiet_iter) {
+  if (*quiet_iter >= 0) return;
+  extern __shared__ double s_new[];  // [kk][193] (odd pitch: the pair loop reads two rows at once)
+  __shared__ unsigned long long s_min[H_MAXK];
+  __shared__ double s_move[H_MAXK];
+  const int kk = segs[0].kk, tid = threadIdx.x;
+  const bool changed = segs[0].changed != 0;
+  const int wave = tid >> 6, lane = tid & 63;
+  auto wave_sum = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+  if (tid < H_MAXK) s_min[tid] = 0x7ff0000000000000ull;  // +inf
+  if (tid == 0) *need_cnt = 0;
+  // a wave per centroid, 3 dimensions per lane: new position, displacement (the sums only feed the bounds, margins of 1e-9: their order is free)
+  for (int c = wave; c < kk; c += 16) {
+    const u64 cn = cnts[c];
+    double sd = 0.0;
+    for (int j = lane; j < 192; j += 64) {
+      const double old = cent[c * 192 + j];
+      double nw = old;
+      if (changed && cn > 0) { nw = __ddiv_rn((double)(long long)sums[c * 192 + j], (double)(long long)cn); cent[c * 192 + j] = nw; }
+      s_new[c * 193 + j] = nw;
+      cent_t[(int64_t)j * kt + c] = nw;
+      const double t = nw - old;
+      sd += t * t;
+    }
+    sd = wave_sum(sd);
+    if (lane == 0) { const double mv = sqrt(sd) * (1.0 + 1e-9); cmove[c] = mv; s_move[c] = mv; }
+  }
+  __syncthreads();
+  for (int pr = wave; pr < kk * kk; pr += 16) {  // pairwise distances: the smallest per centroid (non-negative doubles order like their bit patterns)
+    const int a = pr / kk, b = pr - a * kk;
+    if (a >= b) continue;
+    double sd = 0.0;
+    for (int j = lane; j < 192; j += 64) { const double t = s_new[a * 193 + j] - s_new[b * 193 + j]; sd += t * t; }
+    sd = wave_sum(sd);
+    if (lane == 0) {
+      atomicMin(&s_min[a], (unsigned long long)__double_as_longlong(sd));
+      atomicMin(&s_min[b], (unsigned long long)__double_as_longlong(sd));
+    }
+  }
+  __syncthreads();
+  if (tid < kk) shalf[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
+  if (tid == 0) {
+    double mx = 0.0, mx2 = 0.0;  // the largest displacement, the largest among the others, and whose the largest is
+    int amx = 0;
+    for (int c = 0; c < kk; c++) {
+      const double v = s_move[c];
+      if (v > mx) { mx2 = mx; mx = v; amx = c; } else if (v > mx2) mx2 = v;
+    }
+    cmove[k] = mx; cmove[k + 1] = mx2; cmove[k + 2] = (double)amx;
+    if (!changed && *quiet_iter < 0) *quiet_iter = it;
+    segs[0].changed = 0;
   }
 }
 
@@ -985,11 +1225,59 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   DevBuf quiet;
   TM_TRY(quiet.alloc(4));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
+  // D = 192, one segment, centroids that fit LDS: after H_WARM plain iterations the assignment step only touches the points whose
+  // bounds do not prove their assignment (k_h_bounds, then k_assign192 over the list); the arithmetic, hence the result, is unchanged
+  static const int h_warm = getenv("TM_KM_WARM") ? atoi(getenv("TM_KM_WARM")) : 5;
+  const bool skipping = d == 192 && nseg == 1 && k <= H_MAXK && !getenv("TM_KM_NOSKIP");
+  DevBuf hub, hlb, hcent_t, hmove, hhalf, hneed, hcnt;
+  static const int h_nt = getenv("TM_KM_HNT") ? atoi(getenv("TM_KM_HNT")) : 256;  // points per workgroup of the list kernel
+  const size_t h_lds = (size_t)192 * KCH * 8 + (size_t)k * 193 * 8 + (size_t)256 * 3 * 4 + 16;
+  const int h_kt = (k + KCH - 1) / KCH * KCH;  // row pitch of the transposed centroids (hcent_t)
+  if (skipping) {
+    TM_TRY(hub.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hlb.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hcent_t.alloc((size_t)h_kt * 192 * 8));
+    TM_TRY(hmove.alloc((size_t)(k + 3) * 8)); TM_TRY(hhalf.alloc((size_t)k * 8)); TM_TRY(hneed.alloc((size_t)std::max<int64_t>(n, 1) * 4)); TM_TRY(hcnt.alloc(4));
+    TM_HIP(hipMemsetAsync(hcnt.p, 0, 4, stream));
+    TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
+    if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
+    if ((size_t)k * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, k * 192 * 8);
+    if (h_lds > 48 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
+    }
+  }
   int it = 0, issued = 0;
   const int poll_every = 16;  // launches after convergence return at once (quiet flag), so polling late costs little
   while (issued < max_iter) {
     const int batch = std::min(poll_every, max_iter - issued);
     for (int b = 0; b < batch; b++, issued++) {
+      if (skipping) {
+        if (issued < h_warm) {
+          const bool last_plain = issued == h_warm - 1;
+          launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
+                           quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
+        } else {
+          const int gb = (int)((n + H_SLICE - 1) / H_SLICE);
+          hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)k * 192 * 8, stream, pts, n, ds, cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
+                             hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
+          if (h_nt == 64) hipLaunchKernelGGL(k_assign192_list<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                                             cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
+          else if (h_nt == 128) hipLaunchKernelGGL(k_assign192_list<128>, dim3((unsigned)((n + 127) / 128)), dim3(128), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                                                   cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
+          else hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                                  cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
+        }
+        if (getenv("TM_KM_DEBUG") && issued >= h_warm) {
+          unsigned c = 0; Seg hsd; std::vector<double> mv((size_t)k + 1);
+          (void)hipMemcpyAsync(&c, hcnt.p, 4, hipMemcpyDeviceToHost, stream);
+          (void)hipMemcpyAsync(&hsd, dsegs.p, sizeof(Seg), hipMemcpyDeviceToHost, stream);
+          (void)hipStreamSynchronize(stream);
+          fprintf(stderr, "[tm_km] iteration %d: %u of %lld points through the full computation, %d moved\n", issued, c, (long long)n, hsd.changed);
+        }
+        hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
+                           hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>());
+        continue;
+      }
       if (d == 3) {
         if (fuse3) {
           hipLaunchKernelGGL((k_assign<3, true>), dim3(nblk), dim3(256), lds_assign, stream, pts, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), quiet.as<int>());
