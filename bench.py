@@ -40,6 +40,21 @@ def _traffic_from_profiles(kernel_build):
     return t["traffic_bytes"], "2 x FETCH_SIZE + WRITE_SIZE of one pruned launch, separate --pmc passes (%s)" % t.get("source", "profiles/")
 
 
+def _host_threads(visible):
+    """threads of the all-cores legs = what this process may really use: TM_BENCH_THREADS if set, else the cgroup's CPU quota if there
+    is one, else the affinity mask capped at 16 (a one-GPU box of the pool exposes every CPU of the node in its mask but owns a
+    16-CPU share of it)"""
+    if os.environ.get("TM_BENCH_THREADS"):
+        return max(1, int(os.environ["TM_BENCH_THREADS"]))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, min(visible, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(visible, 16))
+
+
 def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, scaled to frames/s.  Three legs:
     1 thread with the brute-force search; every host core (one oracle call per thread: ctypes drops the GIL) with the brute force;
@@ -52,7 +67,8 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     from tests.oracle_binding import Oracle
     from tiler_amd import synth
     o = Oracle(so)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _host_threads(visible)
     tm_w, tm_h = (width - 1) // 8 + 1, (height - 1) // 8 + 1
     per = tm_w * tm_h
     fr = synth.video(2, width, height)
@@ -124,7 +140,7 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     allk = fps(t_load / cores, t_featn, t_kd / nqn, t_gn, t_tree_build)
     best = max(allb, allk)
     return {
-        "value": best, "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": best, "unit": "frames/s", "cores": cores, "kind": "port", "host_cpus_visible": visible,
         "sample": (f"oracle (C restatement, gcc -O3) timed on: 1 frame load+Lab+mirrors, {per // 4} query feature vectors, 512 global tiles "
                    f"(cluster features + Thomas-Knoll dither + database features), exact dedup of {n_s} tiles (scaled n log n, one thread as "
                    f"TFPList.Sort), KNN of {nqn} queries x {t_distinct} distinct rows; scaled linearly to {per} tiles/frame and {t_global} "
@@ -152,6 +168,8 @@ def main():
     ap.add_argument("--no-defaults-extra", action="store_true",
                     help="skip the untimed extra passes with the extended palette usage on (alone, and with motion prediction)")
     ap.add_argument("--no-h2d-extra", action="store_true", help="skip the second timed region with the clip in host memory")
+    ap.add_argument("--no-dense-extra", action="store_true",
+                    help="skip the dense diagnostic launch of the KNN kernel (under rocprofv3 --stats it would share the kernel's row with the pruned launches)")
     args = ap.parse_args()
 
     import torch
@@ -166,9 +184,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libtilemotion has no CPU path")
+    # rehearsal on a one-GPU box (TM_BENCH_REHEARSE=1): every rank on cuda:0 over gloo -- the whole multi-process path except RCCL itself
+    rehearse = os.environ.get("TM_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, F = args.width, args.height, args.frames
     # synthetic clip, generated on the host into page-locked memory, then parked in HBM before any timing
@@ -320,7 +345,7 @@ def main():
                             "note": "3 B per colour point and 768 B per tile point per iteration; the stage is bound by dependent launches, not bytes"}
         sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms")}
         out["stage_rooflines"] = sr
-    if world == 1:
+    if world == 1 and not args.no_dense_extra:
         # diagnostic, outside the timed region: the same kernel with pruning off = a dense Q x T_distinct distance GEMM (BASELINE config 3)
         os.environ["TM_KNN_NOPRUNE"] = "1"
         for s_ in (TEncoderStep.esLoad, TEncoderStep.esPredictMotion, TEncoderStep.esReduce, TEncoderStep.esPreparePalettes,

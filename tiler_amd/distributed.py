@@ -88,7 +88,13 @@ class Collective:
             recv = torch.empty((self.world * send.numel(),), dtype=send.dtype, device=send.device)
         self.bytes += recv.numel() * recv.element_size()
         # as bytes: what travels is opaque to the collective (and gloo has no 16-bit integer types)
-        dist.all_gather_into_tensor(recv.reshape(-1).view(torch.uint8), send.contiguous().reshape(-1).view(torch.uint8), group=self.group)
+        rb, sb = recv.reshape(-1).view(torch.uint8), send.contiguous().reshape(-1).view(torch.uint8)
+        if sb.is_cuda and dist.get_backend(self.group) == "gloo":  # gloo gathers host tensors only (rehearsals of the GPU path without RCCL)
+            host = torch.empty(rb.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, sb.cpu(), group=self.group)
+            rb.copy_(host)
+        else:
+            dist.all_gather_into_tensor(rb, sb, group=self.group)
         return recv
 
     def allgather_var(self, send):

@@ -6,7 +6,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra"
+BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-h2d-extra"
 run() {  # name, counters...
   local name=$1; shift
   timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-include-regex "k_knn_scan2|k_knn_mfma" --output-format csv -d $OUT/$name -- $BENCH > $OUT/$name.json 2> $OUT/$name.err || { tail -5 $OUT/$name.err; return 1; }
