@@ -12,6 +12,7 @@
 // Callers: tm_stage_kmeans (one segment), run_palettize (DoPalettization, tilingencoder.pas:4105-4245, D = 192) and
 // run_quantize_palettes (QuantizeUsingYakmo + DoQuantization, 4434-4564, D = 3, one segment per palette, run on the
 // (G,R,B)-sorted colour histogram of each palette's pixels).
+#include <type_traits>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -819,8 +820,16 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
 // number of iterations side by side.  Everything that crosses workgroups is an integer atomic -- the carried sums and counts
 // (exact, order-free), the farthest-first pick (64-bit max of distance << 32 | ~index: largest distance, then lowest index), the
 // changed-points counter -- so the result is the one the multi-launch path and the oracle give, bit for bit.
-constexpr int P3_G = 4;  // points scored together against each centroid (registers: 8 spill)
-constexpr int P3_PPT = 16, P3_NT = 256, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 8;
+#ifndef TM_KM3_STAMPS
+#define TM_KM3_STAMPS 0
+#endif
+#if TM_KM3_STAMPS
+#define P3_STAMP(i) do { if (bx == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); st->stamps[i] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define P3_STAMP(i) do { } while (0)
+#endif
+constexpr int P3_PPT = 16, P3_NT = 256, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 4;
+constexpr int P3_UNIT = 128;  // the per-point distance bounds are 16-bit fixed point, 1/128 of a colour step (distances stay below 442)
 
 struct Seg3 {
   int64_t begin, count;
@@ -834,6 +843,9 @@ struct Seg3State {      // zeroed before the launch
   u64 cnts[P3_MAXK];
   u64 pick[P3_MAXK];
   unsigned bar, changed[3], timeout, pad[3];
+#if TM_KM3_STAMPS
+  u64 stamps[8];  // diagnostic build: s_memtime spans of workgroup 0's phases, summed over the iterations
+#endif
 };
 
 __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsigned nblk, unsigned *timeout) {
@@ -847,9 +859,9 @@ __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsig
     const unsigned target = epoch * nblk;
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
-    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
-      __builtin_amdgcn_s_sleep(4);
-      if (spins > (1u << 24) || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    for (unsigned spins = 1; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((spins & 255u) == 0 && (spins > (1u << 24) || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  // (a second round trip: rarely)
         __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
@@ -862,19 +874,22 @@ __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsig
   return s_ok != 0;
 }
 
-__global__ __launch_bounds__(P3_NT, 4) void k_kmeans3_persistent(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg3 *__restrict__ segs,
+__global__ __launch_bounds__(P3_NT, 3) void k_kmeans3_persistent(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg3 *__restrict__ segs,
                                                              Seg3State *__restrict__ state, int k, int max_iter, int32_t *__restrict__ assign,
                                                              double *__restrict__ cent) {
   // the workgroup's points stay on chip for the whole clustering: packed colour and assignment in LDS (slot m * NT + tid: no bank
   // conflicts), so the loops over a thread's points stay rolled and the register file holds only the P3_G points in flight
   __shared__ double s_cent[P3_MAXK][3];
-  __shared__ double s_thr[P3_MAXK];    // (1 - 1e-9) x a quarter of the squared distance to the nearest other centroid
-  __shared__ uint32_t s_col[P3_ROWS];   // 0xffffffff: slot past the end of the segment
-  __shared__ uint8_t s_asg[P3_ROWS];    // 0xff: none yet
-  __shared__ union { int md[P3_ROWS]; u64 acc[P3_NCOPY][P3_MAXK][4]; } s_u;  // farthest-first distances, then the sums' deltas
+  __shared__ double s_dsq[P3_MAXK][3];  // squared displacement of each centroid coordinate in the last update
+  __shared__ int s_half[P3_MAXK];      // half the distance to the nearest other centroid, rounded down (P3_UNIT)
+  __shared__ int s_move[P3_MAXK + 3];  // displacement of each centroid in the last update, rounded up; then the largest, the second largest, whose
+  __shared__ uint32_t s_col[P3_ROWS];   // colour | assignment << 24 (0xff: none yet, 0xfe: slot past the end of the segment)
+  // farthest-first distances, then the points' bounds: ub >= the distance to the own centroid, lb <= the distance to every other one
+  __shared__ union { int md[P3_ROWS]; uint32_t bnd[P3_ROWS]; } s_u;  // bnd: ub | lb << 16
+  __shared__ u64 s_acc[P3_NCOPY][P3_MAXK][4];                      // the sums' deltas of one iteration
+  __shared__ uint16_t s_list[P3_NT / 64][P3_ROWS / (P3_NT / 64)];  // every wave's list of the points it has to score
   __shared__ u64 s_red[P3_NT / 64];
   __shared__ int s_chg;
-  static_assert(sizeof(s_u.md) == sizeof(s_u.acc), "union halves");
   const int tid = threadIdx.x;
   int seg;
   {
@@ -892,13 +907,12 @@ __global__ __launch_bounds__(P3_NT, 4) void k_kmeans3_persistent(const int32_t *
   unsigned epoch = 0;
   const int64_t base = (int64_t)bx * P3_ROWS;
   for (int r = tid; r < P3_ROWS; r += P3_NT) {
-    uint32_t cc = 0xffffffffu;
+    uint32_t cc = 0xfe000000u;
     if (base + r < sg.count) {
       const int32_t *p = pts + (sg.begin + base + r) * 3;
-      cc = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+      cc = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xff000000u;
     }
     s_col[r] = cc;
-    s_asg[r] = 0xff;
     s_u.md[r] = INT_MAX;
   }
   // ---- farthest-first from the segment's first point
@@ -913,7 +927,7 @@ __global__ __launch_bounds__(P3_NT, 4) void k_kmeans3_persistent(const int32_t *
     u64 best = 0;
     for (int r = tid; r < P3_ROWS; r += P3_NT) {  // (each thread only ever touches its own slots: no barrier needed for s_col / md)
       const uint32_t cc = s_col[r];
-      if (cc == 0xffffffffu) continue;
+      if ((cc >> 24) == 0xfeu) continue;
       const int dr = (int)(cc & 0xff) - cr, dg = (int)((cc >> 8) & 0xff) - cg, db = (int)((cc >> 16) & 0xff) - cb;
       const int m = min(s_u.md[r], dr * dr + dg * dg + db * db);
       s_u.md[r] = m;
@@ -936,122 +950,209 @@ __global__ __launch_bounds__(P3_NT, 4) void k_kmeans3_persistent(const int32_t *
     kk++;
   }
   // ---- Lloyd
+  // Per point two bounds are kept (Hamerly): ub >= its distance to its own centroid, lb <= its distance to every other one; a centroid
+  // update loosens them by the centroids' displacements.  While ub <= max(lb, half the distance from the own centroid to the nearest
+  // other one) the own centroid is strictly the nearest -- every bound is rounded the safe way to 1/128 and carries a margin of a
+  // whole unit, six orders of magnitude above the rounding of the distance arithmetic, so the order of the COMPUTED distances is the
+  // same and strict -- and the point keeps its assignment without being scored.  A point that fails first gets its ub tightened
+  // (distance to its own centroid, in the arithmetic of the scoring); if it still fails it goes on its wave's list and is scored
+  // against every centroid as before.  Each wave compacts and scores its own 1024 points: no barrier between the two.
   int it = 0;
+#if TM_KM3_STAMPS
+  u64 st_last = __builtin_amdgcn_s_memtime();
+#endif
+  const int wave = tid >> 6, lane = tid & 63;
+  if (tid < P3_MAXK) { s_move[tid] = 0; s_half[tid] = 0; }
+  if (tid < 3) s_move[P3_MAXK + tid] = 0;
   for (;;) {
-    __syncthreads();  // s_cent of this iteration is in place; the init (or the previous flush) is done with the union
-    for (int e = tid; e < P3_NCOPY * P3_MAXK * 4; e += P3_NT) (&s_u.acc[0][0][0])[e] = 0;
+    __syncthreads();  // s_cent, s_move, s_half of this iteration are in place; the farthest-first pass is done with the union; the previous flush with s_acc
+    for (int e = tid; e < P3_NCOPY * P3_MAXK * 4; e += P3_NT) (&s_acc[0][0][0])[e] = 0;
     if (tid == 0) s_chg = 0;
     __syncthreads();
-    // A point whose squared distance to its own centroid a is below a quarter of the squared distance from a to the nearest other
-    // centroid cannot be nearer to any other one (triangle inequality; the 1e-9 margin dwarfs the rounding of both sides, so the
-    // order of the COMPUTED distances is the same and strict): it keeps its assignment without being scored against the rest.
-    // Colours are sorted, so the 64 consecutive points of a wave's pass are neighbours in colour space and mostly agree; a pass is
-    // skipped only when all its points can be, and the others are scored in full as before -- the result is unchanged.
-    if (tid < kk) {
-      double best = 1.0e300;
-      for (int c = 0; c < kk; c++) {
-        if (c == tid) continue;
-        const double t0 = s_cent[tid][0] - s_cent[c][0], t1 = s_cent[tid][1] - s_cent[c][1], t2 = s_cent[tid][2] - s_cent[c][2];
-        best = fmin(best, t0 * t0 + t1 * t1 + t2 * t2);
-      }
-      s_thr[tid] = kk > 1 ? best * 0.25 * (1.0 - 1.0e-9) : 1.0e300;
-    }
-    __syncthreads();
-    unsigned need = 0;  // bit m: some point of this wave's pass m has to be scored against every centroid (uniform in the wave)
+    P3_STAMP(0);  // zeroing
+    const int mv1 = s_move[P3_MAXK], mv2 = s_move[P3_MAXK + 1], amax = s_move[P3_MAXK + 2];
+    int nlist = 0;  // uniform in the wave
+    uint16_t *const mylist = s_list[wave];
+    constexpr int PU = 4;  // passes in flight: their LDS round trips overlap
 #pragma unroll 1
-    for (int m = 0; m < P3_PPT; m++) {
-      const int r = m * P3_NT + tid;
-      const uint32_t cc = s_col[r];
-      const int a = s_asg[r];
-      bool full = cc != 0xffffffffu;
-      if (full && a != 0xff) {
-        const double t0 = __dsub_rn((double)(int)(cc & 0xff), s_cent[a][0]), t1 = __dsub_rn((double)(int)((cc >> 8) & 0xff), s_cent[a][1]),
-                     t2 = __dsub_rn((double)(int)((cc >> 16) & 0xff), s_cent[a][2]);
-        full = !(__fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0))) < s_thr[a]);
+    for (int m0 = 0; m0 < P3_PPT; m0 += PU) {
+      uint32_t cc[PU];
+      int a[PU], u[PU], l[PU], thr[PU];
+      bool full[PU], tight[PU];
+#pragma unroll
+      for (int i = 0; i < PU; i++) {
+        const int r = (m0 + i) * P3_NT + tid;
+        cc[i] = s_col[r];
+        const uint32_t bn = s_u.bnd[r];
+        a[i] = (int)(cc[i] >> 24);
+        u[i] = (int)(bn & 0xffffu);
+        l[i] = (int)(bn >> 16);
       }
-      if (__builtin_amdgcn_ballot_w64(full)) need |= 1u << m;
+      bool any_tight = false;
+#pragma unroll
+      for (int i = 0; i < PU; i++) {
+        full[i] = a[i] == 0xff;  // not assigned yet: scored
+        tight[i] = false;
+        if (a[i] < 0xfe) {
+          u[i] = min(65535, u[i] + s_move[a[i]]);
+          l[i] = max(0, l[i] - (a[i] == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+          thr[i] = max(l[i], s_half[a[i]]);
+          tight[i] = u[i] > thr[i];
+          full[i] = false;
+          any_tight |= tight[i];
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(any_tight)) {
+#pragma unroll
+        for (int i = 0; i < PU; i++)
+          if (tight[i]) {
+            // the distance to the own centroid, in the scoring's arithmetic, as the new ub (single-precision root, as in the scoring)
+            const double t0 = __dsub_rn((double)(int)(cc[i] & 0xff), s_cent[a[i]][0]), t1 = __dsub_rn((double)(int)((cc[i] >> 8) & 0xff), s_cent[a[i]][1]),
+                         t2 = __dsub_rn((double)(int)((cc[i] >> 16) & 0xff), s_cent[a[i]][2]);
+            const double sd = __fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0)));
+            u[i] = min(65535, (int)(__fsqrt_rn((float)sd) * (float)P3_UNIT) + 2);
+            full[i] = u[i] > thr[i];
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < PU; i++) {
+        const int r = (m0 + i) * P3_NT + tid;
+        if (a[i] < 0xfe) s_u.bnd[r] = (uint32_t)u[i] | ((uint32_t)l[i] << 16);
+        const unsigned long long fb = __builtin_amdgcn_ballot_w64(full[i]);
+        if (full[i]) mylist[nlist + __popcll(fb & ((1ull << lane) - 1ull))] = (uint16_t)r;
+        nlist += __popcll(fb);
+#if TM_KM3_STAMPS
+        if (bx == 0 && lane == 0) atomicAdd(&st->stamps[7], (u64)__popcll(fb));
+#endif
+      }
     }
+    P3_STAMP(1);  // bounds of the 16 passes
     int changed = 0;
-    // P3_G points at a time against one centroid after the other: a centroid read from LDS (a broadcast) serves P3_G points.
+    // G listed points per lane at a time against one centroid after the other: a centroid read from LDS (a broadcast) serves G points.
     // Per (point, centroid): sum over dimensions in order of (p - c)^2, one IEEE subtraction and one fused multiply-add each;
     // ties -> lowest centroid.
-    while (need) {
-      int mi[P3_G];
+    auto score = [&](auto gtag, const int e0) {
+      constexpr int G = decltype(gtag)::value;
+      double px[G][3], bd[G], bd2[G];
+      int bc[G], rr[G];
+      uint32_t cc[G];
 #pragma unroll
-      for (int g = 0; g < P3_G; g++) {  // the next P3_G passes that need scoring (a short last group repeats its last pass: harmless)
-        mi[g] = need ? __builtin_ctz(need) : (g ? mi[g - 1] : 0);
-        need &= need - 1;
-      }
-      double px[P3_G][3], bd[P3_G];
-      int bc[P3_G];
-      uint32_t cc[P3_G];
-#pragma unroll
-      for (int m = 0; m < P3_G; m++) {
-        cc[m] = s_col[mi[m] * P3_NT + tid];
+      for (int m = 0; m < G; m++) {
+        const int e = e0 + m * 64 + lane;
+        rr[m] = e < nlist ? (int)mylist[e] : -1;
+        cc[m] = s_col[rr[m] < 0 ? tid : rr[m]];
         px[m][0] = (double)(int)(cc[m] & 0xff); px[m][1] = (double)(int)((cc[m] >> 8) & 0xff); px[m][2] = (double)(int)((cc[m] >> 16) & 0xff);
-        bd[m] = 0.0;
+        bd[m] = 0.0; bd2[m] = 1.0e300;
         bc[m] = -1;
       }
 #pragma unroll 1
       for (int c = 0; c < kk; c++) {
         const double c0 = s_cent[c][0], c1 = s_cent[c][1], c2 = s_cent[c][2];
 #pragma unroll
-        for (int m = 0; m < P3_G; m++) {
+        for (int m = 0; m < G; m++) {
           const double t0 = __dsub_rn(px[m][0], c0), t1 = __dsub_rn(px[m][1], c1), t2 = __dsub_rn(px[m][2], c2);
           const double sd = __fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0)));
-          if (bc[m] < 0 || sd < bd[m]) { bd[m] = sd; bc[m] = c; }
+          if (bc[m] < 0 || sd < bd[m]) { bd2[m] = bc[m] < 0 ? bd2[m] : bd[m]; bd[m] = sd; bc[m] = c; }
+          else if (sd < bd2[m]) bd2[m] = sd;
         }
       }
 #pragma unroll
-      for (int m = 0; m < P3_G; m++) {
-        const int r = mi[m] * P3_NT + tid;
-        if (cc[m] == 0xffffffffu || (m > 0 && mi[m] == mi[m - 1])) continue;
-        const int old = s_asg[r];
+      for (int m = 0; m < G; m++) {
+        const int r = rr[m];
+        if (r < 0) continue;
+        // single-precision roots: their error (2e-7 relative, 0.011 units at most) is far inside the margins of a whole unit
+        s_u.bnd[r] = (uint32_t)min(65535, (int)(__fsqrt_rn((float)bd[m]) * (float)P3_UNIT) + 2) |
+                     ((uint32_t)(bd2[m] > 1.0e12 ? 65535 : max(0, (int)(__fsqrt_rn((float)bd2[m]) * (float)P3_UNIT) - 1)) << 16);
+        const int old = (int)(cc[m] >> 24);
         if (old == bc[m]) continue;
         // only a point that changes cluster touches the carried sums
         const long long wi = w ? (long long)w[sg.begin + base + r] : 1;
         const int pi[3] = {(int)(cc[m] & 0xff), (int)((cc[m] >> 8) & 0xff), (int)((cc[m] >> 16) & 0xff)};
-        u64 *acc = &s_u.acc[tid & (P3_NCOPY - 1)][bc[m]][0];
+        u64 *acc = &s_acc[tid & (P3_NCOPY - 1)][bc[m]][0];
         atomicAdd(&acc[3], (u64)wi);
 #pragma unroll
         for (int j = 0; j < 3; j++) atomicAdd(&acc[j], (u64)(wi * pi[j]));
         if (old != 0xff) {
-          u64 *oacc = &s_u.acc[tid & (P3_NCOPY - 1)][old][0];
+          u64 *oacc = &s_acc[tid & (P3_NCOPY - 1)][old][0];
           atomicAdd(&oacc[3], (u64)0 - (u64)wi);
 #pragma unroll
           for (int j = 0; j < 3; j++) atomicAdd(&oacc[j], (u64)0 - (u64)(wi * pi[j]));
         }
-        s_asg[r] = (uint8_t)bc[m];
+        s_col[r] = (cc[m] & 0xffffffu) | ((uint32_t)bc[m] << 24);
         changed++;
       }
+    };
+    {  // 256 listed points per step while there are many, then 128, then 64: a short list costs one short step
+      int e0 = 0;
+      for (; nlist - e0 > 128; e0 += 256) score(std::integral_constant<int, 4>{}, e0);
+      if (nlist - e0 > 64) { score(std::integral_constant<int, 2>{}, e0); e0 += 128; }
+      if (nlist - e0 > 0) score(std::integral_constant<int, 1>{}, e0);
     }
+    P3_STAMP(2);  // full scoring of the listed points
     for (int o = 32; o > 0; o >>= 1) changed += __shfl_xor(changed, o);
     if ((tid & 63) == 0 && changed) atomicAdd(&s_chg, changed);
     __syncthreads();
+    P3_STAMP(3);  // waiting for the workgroup's other waves
     for (int e = tid; e < kk * 4; e += P3_NT) {
       u64 v = 0;
 #pragma unroll
-      for (int cp = 0; cp < P3_NCOPY; cp++) v += s_u.acc[cp][e >> 2][e & 3];
+      for (int cp = 0; cp < P3_NCOPY; cp++) v += s_acc[cp][e >> 2][e & 3];
       if (v == 0) continue;
       if ((e & 3) == 3) atomicAdd(&st->cnts[e >> 2], v); else atomicAdd(&st->sums[e >> 2][e & 3], v);
     }
     if (tid == 0 && s_chg) atomicAdd(&st->changed[it % 3], (unsigned)s_chg);
+    P3_STAMP(4);  // flush
     if (!p3_barrier(&st->bar, epoch, nbx, &st->timeout)) return;
+    P3_STAMP(5);  // barrier of the segment's workgroups
+    // (the three loads leave together: one round trip instead of three)
+    const int uc = min(tid / 3, P3_MAXK - 1), uj = tid - (tid / 3) * 3;
     const unsigned tot = __hip_atomic_load(&st->changed[it % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 cn = __hip_atomic_load(&st->cnts[uc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 sm = __hip_atomic_load(&st->sums[uc][uj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bx == 0 && tid == 0) __hip_atomic_store(&st->changed[(it + 2) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // last read two barriers ago
     if (tot == 0) break;
     // new centroids: exact integer sum / weight, one IEEE division; an empty cluster keeps its centroid
     if (tid < kk * 3) {
-      const int c = tid / 3, j = tid - c * 3;
-      const u64 cn = __hip_atomic_load(&st->cnts[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (cn > 0) s_cent[c][j] = __ddiv_rn((double)(long long)__hip_atomic_load(&st->sums[c][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (double)(long long)cn);
+      const int c = uc, j = uj;
+      const double old = s_cent[c][j];
+      double nw = old;
+      if (cn > 0) nw = __ddiv_rn((double)(long long)sm, (double)(long long)cn);
+      s_cent[c][j] = nw;
+      const double dd = nw - old;
+      s_dsq[c][j] = dd * dd;
     }
+    if (tid < P3_MAXK) s_half[tid] = 0x7fffffff;
+    __syncthreads();
+    // what the bounds need (identical in every workgroup of the segment): how far each centroid moved, rounded up (a centroid that did
+    // not move costs nothing), and half its distance to the nearest other one, rounded down
+    if (tid < kk) {
+      const double m2 = s_dsq[tid][0] + s_dsq[tid][1] + s_dsq[tid][2];
+      s_move[tid] = m2 == 0.0 ? 0 : (int)(sqrt(m2) * (double)P3_UNIT) + 2;
+    }
+    for (int pr = tid; pr < kk * kk; pr += P3_NT) {
+      const int ca = pr / kk, cb2 = pr - ca * kk;
+      if (ca >= cb2) continue;
+      const double t0 = s_cent[ca][0] - s_cent[cb2][0], t1 = s_cent[ca][1] - s_cent[cb2][1], t2 = s_cent[ca][2] - s_cent[cb2][2];
+      const int h = max(0, (int)(0.5 * sqrt(t0 * t0 + t1 * t1 + t2 * t2) * (double)P3_UNIT) - 1);
+      atomicMin(&s_half[ca], h);
+      atomicMin(&s_half[cb2], h);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int m1 = 0, m2 = 0, am = 0;
+      for (int c = 0; c < kk; c++) {
+        const int v = s_move[c];
+        if (v > m1) { m2 = m1; m1 = v; am = c; } else if (v > m2) m2 = v;
+      }
+      s_move[P3_MAXK] = m1; s_move[P3_MAXK + 1] = m2; s_move[P3_MAXK + 2] = am;
+    }
+    P3_STAMP(6);  // counts + sums read back, new centroids
     it++;
     if (it >= max_iter) break;
   }
   __syncthreads();
   for (int r = tid; r < P3_ROWS; r += P3_NT)
-    if (base + r < sg.count) assign[sg.begin + base + r] = (int32_t)s_asg[r];
+    if (base + r < sg.count) assign[sg.begin + base + r] = (int32_t)(s_col[r] >> 24);
   if (bx == 0) {
     for (int e = tid; e < kk * 3; e += P3_NT) cent[((int64_t)seg * k + e / 3) * 3 + e % 3] = s_cent[e / 3][e % 3];
     if (tid == 0) { segs[seg].kk = kk; segs[seg].iters = it; }
@@ -1108,6 +1209,14 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
     TM_CHECK(hstate[i].timeout == 0, TM_E_HIP, "k-means: the workgroups of a segment did not all become resident (barrier gave up)");
     if (host_kk) (*host_kk)[which[i]] = hs[i].kk;
     iters = std::max(iters, hs[i].iters);
+#if TM_KM3_STAMPS
+    fprintf(stderr, "[tm_km3 stamps] segment %zu: %d workgroups, %d iterations; per iteration (s_memtime ticks): zero+thresholds %.0f, own test %.0f, scoring %.0f, "
+            "workgroup sync %.0f, flush %.0f, barrier %.0f, read-back %.0f\n", i, hs[i].blk_count, hs[i].iters, (double)hstate[i].stamps[0] / std::max(1, hs[i].iters),
+            (double)hstate[i].stamps[1] / std::max(1, hs[i].iters), (double)hstate[i].stamps[2] / std::max(1, hs[i].iters), (double)hstate[i].stamps[3] / std::max(1, hs[i].iters),
+            (double)hstate[i].stamps[4] / std::max(1, hs[i].iters), (double)hstate[i].stamps[5] / std::max(1, hs[i].iters), (double)hstate[i].stamps[6] / std::max(1, hs[i].iters));
+    fprintf(stderr, "[tm_km3 stamps]   workgroup 0: %.1f points per iteration fail the own-centroid test, %.1f are scored (whole passes)\n",
+            (double)(hstate[i].stamps[7] >> 32) / std::max(1, hs[i].iters), (double)(hstate[i].stamps[7] & 0xffffffffu) / std::max(1, hs[i].iters));
+#endif
   }
   if (host_iters) *host_iters = iters;
   // centroids back in the caller's [nseg][k][3] layout (device)
