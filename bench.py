@@ -55,6 +55,20 @@ def _host_threads(visible):
     return max(1, min(visible, 16))
 
 
+def _collective_counts(enc, nsteps):
+    """calls and bytes of this rank's collectives per step (what the library asked the host's callback for)"""
+    coll = getattr(enc, "_collective", None)
+    if coll is None:
+        return None
+    names = {0: "all_reduce_sum_i32", 1: "all_reduce_max_i32", 2: "all_reduce_sum_i64", 3: "all_gather"}
+    out = {names[k]: v / float(nsteps) for k, v in coll.calls.items()}
+    out["bytes"] = coll.bytes / float(nsteps)
+    if coll.log is not None:
+        per = len(coll.log) // nsteps
+        out["last_step_calls"] = coll.log[-per:]
+    return out
+
+
 def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, scaled to frames/s.  Three legs:
     1 thread with the brute-force search; every host core (one oracle call per thread: ctypes drops the GIL) with the brute force;
@@ -273,6 +287,7 @@ def main():
                    "distinct_database_rows": int(ks["db_rows"]), "final_tiles_after_reindex": int(c["tiles"]),
                    "input": "RGB frames resident in HBM when the timed region starts (with_h2d: in page-locked host memory)",
                    "parallelism": distributed.describe(world)},
+        "collectives_per_step": _collective_counts(enc, args.steps + args.warmup) if world > 1 else None,
         "tiles_matched_per_sec": q_total / (st["reconstruct"] * 1e-3) if st["reconstruct"] > 0 else None,
         "stage_ms": {n: round(v, 3) for n, v in st.items()},
         "nominal_pairs": float(q_total) * float(T),

@@ -154,6 +154,13 @@ TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* 
 enum { TM_COLL_ALLREDUCE_SUM_I32 = 0, TM_COLL_ALLREDUCE_MAX_I32 = 1, TM_COLL_ALLREDUCE_SUM_I64 = 2, TM_COLL_ALLGATHER_BYTES = 3 };
 typedef int (*tm_collective_cb)(void *user, int kind, void *dev_buf, void *dev_recv, int64_t count);
 TM_API int tm_set_collective(tm_encoder *, int rank, int world, tm_collective_cb cb, void *user);
+/* The HIP stream (hipStream_t) every step of this encoder is queued on, and the callback's contract with it.  Mode 0 (default): the
+ * library drains the stream before each callback and the callback returns with the result in place (any communicator, any stream).
+ * Mode 1, stream-ordered: the callback ENQUEUES the collective on that stream (RCCL: ncclAllReduce(..., stream), or a
+ * torch.distributed call made with the stream current) and returns at once; the library neither drains before nor waits after --
+ * the ~80 collectives of a step (one per Lloyd iteration among them) then cost no host round trip each. */
+TM_API void *tm_get_stream(tm_encoder *);
+TM_API int tm_set_collective_mode(tm_encoder *, int stream_ordered);
 /* Dither (DoDither :1873-1907, one independent DitherTile per global tile): this process dithers tiles
  * [T * rank / world, T * (rank + 1) / world) only (T = global tiles after Reduce) and zeroes the rest; the host merges
  * TM_ARRAY_TILE_PALPX with an all-reduce(SUM) before Reconstruct.  (0, 1) = every tile (default). */

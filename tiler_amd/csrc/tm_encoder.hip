@@ -139,6 +139,7 @@ struct tm_encoder {
   // one process per GPU (tm_set_collective): the steps shard their work over `world` processes and merge through the host's collectives
   tm_collective_cb coll_cb = nullptr;
   void *coll_user = nullptr;
+  bool coll_stream_ordered = false;  // the callback enqueues on e->stream (tm_set_collective_mode): no drain before, no wait after
   Collectives co;
   bool load_sharded = false;     // Load only filled the frame tiles of this process's frames (and of the frame before them)
   int load_first = 0, load_count = 0;
@@ -245,7 +246,7 @@ static int need(tm_encoder *e, int step_bit, const char *what) {
 }
 
 static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t count) {
-  TM_HIP(hipStreamSynchronize(e->stream));  // everything queued so far is done before the host's collective touches the buffers
+  if (!e->coll_stream_ordered) TM_HIP(hipStreamSynchronize(e->stream));  // everything queued so far is done before the host's collective touches the buffers
   const int rc = e->coll_cb(e->coll_user, kind, buf, recv, count);
   TM_CHECK(rc == 0, TM_E_HIP, "the host's collective callback failed (kind %d, code %d)", kind, rc);
   return TM_OK;
@@ -1429,6 +1430,14 @@ int tm_set_query_shard(tm_encoder *e, int first_frame, int frame_count) {
   if (first_frame != e->shard_first || frame_count != e->shard_count) e->qf_valid = false;  // prefetched for the old range (freed with the next Load / Reconstruct)
   e->shard_first = first_frame;
   e->shard_count = frame_count;
+  return TM_OK;
+}
+
+void *tm_get_stream(tm_encoder *e) { return e ? (void *)e->stream : nullptr; }
+
+int tm_set_collective_mode(tm_encoder *e, int stream_ordered) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  e->coll_stream_ordered = stream_ordered != 0;
   return TM_OK;
 }
 

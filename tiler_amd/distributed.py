@@ -21,7 +21,9 @@ search of Reduce needs every frame's prediction error), PredictMotion shards by 
 the unit that chains (1496).  The same code runs under gloo on CPU tensors in tests/test_distributed_cpu.py (there with an
 oracle-backed stand-in for the encoder).
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -66,7 +68,20 @@ class Collective:
         self.rank, self.world, self.group = rank, world, group
         self.calls = {KIND_SUM_I32: 0, KIND_MAX_I32: 0, KIND_SUM_I64: 0, KIND_ALLGATHER: 0}
         self.bytes = 0
+        self.log = [] if os.environ.get("TM_COLL_DEBUG") else None  # (kind, bytes) of every call the library made
         self._cb = _CB(self._from_library)  # kept alive with the object
+        self._stream = None  # the encoder's stream as a torch stream, when the collectives are queued on it (bind_stream)
+
+    def bind_stream(self, stream_ptr):
+        """Called by TilingEncoder.SetCollective with the library's HIP stream.  With RCCL underneath (backend nccl) every collective
+        is issued with that stream current: torch orders the RCCL kernel after what the library queued and the library's next
+        kernel after the RCCL kernel, and nobody blocks the host.  Returns whether that mode is on (gloo stages through the host
+        and keeps the blocking contract; TM_COLL_BLOCKING=1 forces it)."""
+        self._stream = None
+        if os.environ.get("TM_COLL_BLOCKING") == "1" or not stream_ptr or dist.get_backend(self.group) != "nccl":
+            return False
+        self._stream = torch.cuda.ExternalStream(int(stream_ptr))
+        return True
 
     # ---- tensor level (also used by the CPU stand-in of the tests)
     def allreduce_sum(self, t):
@@ -117,19 +132,23 @@ class Collective:
         return torch.as_tensor(_V(), device="cuda")
 
     def _from_library(self, user, kind, buf, recv, count):
+        if self.log is not None:
+            self.log.append((kind, int(count) * (self.world if kind == KIND_ALLGATHER else (8 if kind == KIND_SUM_I64 else 4))))
         try:
-            if kind == KIND_SUM_I32:
-                self.allreduce_sum(self._view(buf, count, "<i4"))
-            elif kind == KIND_MAX_I32:
-                self.allreduce_max(self._view(buf, count, "<i4"))
-            elif kind == KIND_SUM_I64:
-                self.allreduce_sum(self._view(buf, count, "<i8"))
-            elif kind == KIND_ALLGATHER:
-                self.allgather(self._view(buf, count, "|u1"), self._view(recv, count * self.world, "|u1"))
-            else:
-                return -1
-            # the library's stream is not torch's: the result must be in place before the library's next kernel reads it
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext():
+                if kind == KIND_SUM_I32:
+                    self.allreduce_sum(self._view(buf, count, "<i4"))
+                elif kind == KIND_MAX_I32:
+                    self.allreduce_max(self._view(buf, count, "<i4"))
+                elif kind == KIND_SUM_I64:
+                    self.allreduce_sum(self._view(buf, count, "<i8"))
+                elif kind == KIND_ALLGATHER:
+                    self.allgather(self._view(buf, count, "|u1"), self._view(recv, count * self.world, "|u1"))
+                else:
+                    return -1
+                if self._stream is None:
+                    # blocking contract: torch's stream is not the library's, the result must be in place before the library's next kernel reads it
+                    torch.cuda.current_stream().synchronize()
             return 0
         except Exception as exc:  # noqa: BLE001  (must not unwind through the C frame)
             import traceback

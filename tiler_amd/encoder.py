@@ -72,6 +72,8 @@ _ENC_SIGS = {
     "tm_set_query_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_set_dither_shard": (c_int, [c_void_p, c_int, c_int]),
     "tm_set_collective": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "tm_get_stream": (c_void_p, [c_void_p]),
+    "tm_set_collective_mode": (c_int, [c_void_p, c_int]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
     "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
@@ -237,6 +239,9 @@ class TilingEncoder:
         self._coll_ref = coll  # the ctypes callback must outlive the encoder's use of it
         cb = ctypes.cast(coll.callback, c_void_p) if (coll is not None and world > 1) else None
         check(self._L.tm_set_collective(c_void_p(self._h), int(rank), int(world), cb, None))
+        # a communicator that can queue its work on the encoder's own stream (RCCL through torch.distributed) is used stream-ordered
+        ordered = bool(coll is not None and world > 1 and getattr(coll, "bind_stream", None) and coll.bind_stream(self._L.tm_get_stream(c_void_p(self._h))))
+        check(self._L.tm_set_collective_mode(c_void_p(self._h), 1 if ordered else 0))
 
     def SetDitherShard(self, rank, world):
         """Dither only tiles [T * rank / world, T * (rank + 1) / world); the others stay 0 in DeviceArray(7) for an all-reduce(SUM)"""
