@@ -947,29 +947,9 @@ static inline int64_t sqdist_i(const int32_t *a, const int32_t *b, int d) {
   return s;
 }
 
-int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int max_iter, int32_t *assign,
-                   double *cent, int *iters_out) {
-  if (iters_out) *iters_out = 0;
-  if (n <= 0 || k <= 0) return 0;
-  /* farthest-first ("maximin") init from point 0, ties -> lowest index (cf. InitFarthestFirst, kmodes.pas:694) */
-  int64_t *mind = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
-  for (int64_t i = 0; i < n; i++) mind[i] = INT64_MAX;
-  int kk = 0;
-  int64_t cur = 0;
-  while (kk < k) {
-    for (int j = 0; j < d; j++) cent[(size_t)kk * d + j] = (double)pts[cur * d + j];
-    kk++;
-    int64_t best = 0, bi = -1;
-    for (int64_t i = 0; i < n; i++) {
-      int64_t dd = sqdist_i(pts + i * d, pts + cur * d, d);
-      if (dd < mind[i]) mind[i] = dd;
-      if (mind[i] > best) { best = mind[i]; bi = i; }
-    }
-    if (bi < 0) break; /* no distinct point left */
-    cur = bi;
-  }
-  free(mind);
-  /* Lloyd: double distances accumulated in dimension order with a fused multiply-add, ties -> lowest centroid; exact integer weighted sums */
+/* Lloyd from kk given centroids: double distances accumulated in dimension order with a fused multiply-add, ties -> lowest centroid;
+ * exact integer weighted sums; stops when no assignment changes */
+static int kmeans_lloyd(const int32_t *pts, const uint32_t *w, int64_t n, int d, int kk, int max_iter, int32_t *assign, double *cent, int *iters_out) {
   int64_t *sum = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk * d);
   int64_t *cnt = (int64_t *)malloc(sizeof(int64_t) * (size_t)kk);
   for (int64_t i = 0; i < n; i++) assign[i] = -1;
@@ -1002,6 +982,77 @@ int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int 
   if (iters_out) *iters_out = it;
   free(sum); free(cnt);
   return kk;
+}
+
+int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int max_iter, int32_t *assign,
+                   double *cent, int *iters_out) {
+  if (iters_out) *iters_out = 0;
+  if (n <= 0 || k <= 0) return 0;
+  /* farthest-first ("maximin") init from point 0, ties -> lowest index (cf. InitFarthestFirst, kmodes.pas:694) */
+  int64_t *mind = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  for (int64_t i = 0; i < n; i++) mind[i] = INT64_MAX;
+  int kk = 0;
+  int64_t cur = 0;
+  while (kk < k) {
+    for (int j = 0; j < d; j++) cent[(size_t)kk * d + j] = (double)pts[cur * d + j];
+    kk++;
+    int64_t best = 0, bi = -1;
+    for (int64_t i = 0; i < n; i++) {
+      int64_t dd = sqdist_i(pts + i * d, pts + cur * d, d);
+      if (dd < mind[i]) mind[i] = dd;
+      if (mind[i] > best) { best = mind[i]; bi = i; }
+    }
+    if (bi < 0) break; /* no distinct point left */
+    cur = bi;
+  }
+  free(mind);
+  return kmeans_lloyd(pts, w, n, d, kk, max_iter, assign, cent, iters_out);
+}
+
+/* The build's seeding for the tile -> palette clustering: k-means++-style D^2 sampling made deterministic.
+ * The generator is a 64-bit LCG (Knuth's MMIX constants) started at TMO_PP_SEED; pick t draws r = floor(x_t * total / 2^64) over
+ * the exact integer masses q_i = weight_i * (squared distance of point i to its nearest centre so far) (q_i = weight_i for the first
+ * pick), 128-bit sums, and takes the first point whose running sum exceeds r.  A pick with total mass 0 (no point apart from the
+ * centres) ends the seeding with fewer centres.  seeds_out (may be NULL) receives the picked point indices. */
+uint64_t tmo_pp_next(uint64_t *state) { *state = *state * 6364136223846793005ull + 1442695040888963407ull; return *state; }
+int tmo_kmeans_pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int64_t *seeds_out) {
+  if (n <= 0 || k <= 0) return 0;
+  typedef unsigned __int128 u128;
+  int64_t *mind = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+  uint64_t rng = TMO_PP_SEED;
+  int kk = 0;
+  while (kk < k) {
+    u128 total = 0;
+    for (int64_t i = 0; i < n; i++) total += (u128)(w ? w[i] : 1) * (u128)(kk == 0 ? 1 : (uint64_t)mind[i]);
+    if (total == 0) break;
+    const uint64_t x = tmo_pp_next(&rng);
+    const u128 r = (u128)x * (uint64_t)(total >> 64) + (((u128)x * (uint64_t)total) >> 64); /* floor(x * total / 2^64) < total */
+    u128 run = 0;
+    int64_t pick = -1;
+    for (int64_t i = 0; i < n; i++) {
+      run += (u128)(w ? w[i] : 1) * (u128)(kk == 0 ? 1 : (uint64_t)mind[i]);
+      if (run > r) { pick = i; break; }
+    }
+    if (seeds_out) seeds_out[kk] = pick;
+    for (int64_t i = 0; i < n; i++) {
+      int64_t dd = sqdist_i(pts + i * d, pts + pick * d, d);
+      if (kk == 0 || dd < mind[i]) mind[i] = dd;
+    }
+    kk++;
+  }
+  free(mind);
+  return kk;
+}
+
+int tmo_kmeans_pp_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int max_iter, int32_t *assign, double *cent, int *iters_out) {
+  if (iters_out) *iters_out = 0;
+  if (n <= 0 || k <= 0) return 0;
+  int64_t *seeds = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
+  const int kk = tmo_kmeans_pp_seeds(pts, w, n, d, k, seeds);
+  for (int c = 0; c < kk; c++)
+    for (int j = 0; j < d; j++) cent[(size_t)c * d + j] = (double)pts[seeds[c] * d + j];
+  free(seeds);
+  return kmeans_lloyd(pts, w, n, d, kk, max_iter, assign, cent, iters_out);
 }
 
 static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return (x > y) - (x < y); }
@@ -1065,7 +1116,7 @@ void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, in
   /* DoPalettization, tilingencoder.pas:4105-4245, with BICO+ANN+yakmo replaced by the build's k-means on all tiles */
   double *cent = (double *)malloc(sizeof(double) * (size_t)pal_count * 192);
   int32_t *assign = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
-  tmo_kmeans_i32(feat, use, n, 192, pal_count, max_iter, assign, cent, NULL);
+  tmo_kmeans_pp_i32(feat, use, n, 192, pal_count, max_iter, assign, cent, NULL);
   int64_t *cnt = (int64_t *)calloc((size_t)pal_count, sizeof(int64_t));
   for (int64_t i = 0; i < n; i++) cnt[assign[i]]++; /* Inc(FPalettes[..].UseCount) per tile, 4229-4230 */
   int *ord = (int *)malloc(sizeof(int) * (size_t)pal_count), *lut = (int *)malloc(sizeof(int) * (size_t)pal_count);

@@ -141,6 +141,11 @@ int tmo_kmeans_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int 
  * writes pal_size colours (unused = TMO_NULL_COLOR) ordered by (Val,Sat,Hue). tilingencoder.pas:4434-4564 */
 void tmo_quantize_palette(const uint32_t *pixels, int64_t npx, int pal_size, int max_iter, int32_t *palette_out);
 /* tile->palette assignment + ranking by use count (tilingencoder.pas:4221-4244) */
+/* the build's deterministic D^2 seeding (tile -> palette clustering) and the k-means run from it */
+#define TMO_PP_SEED 0x42381337ull
+uint64_t tmo_pp_next(uint64_t *state);
+int tmo_kmeans_pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int64_t *seeds_out);
+int tmo_kmeans_pp_i32(const int32_t *pts, const uint32_t *w, int64_t n, int d, int k, int max_iter, int32_t *assign, double *cent, int *iters_out);
 void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, int pal_count, int max_iter, int32_t *pal_idx_out);
 
 /* ---- A11 OptimizePalettes (tilingencoder.pas:4309-4432) with Powell/Brent (powell.pas); in place, returns sweeps ---- */

@@ -38,6 +38,8 @@ class Oracle:
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.tmo_quantize_palette.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.tmo_palettize_tiles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.tmo_kmeans_pp_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.tmo_kmeans_pp_seeds.restype = ctypes.c_int
 
     # ---- colour
     def rgb_to_lab(self, r, g, b, det=False):
@@ -260,6 +262,14 @@ class Oracle:
         out = np.zeros(pal_size, np.int32)
         self.L.tmo_quantize_palette(_p(pixels), pixels.size, pal_size, max_iter, _p(out))
         return out
+
+    def kmeans_pp_seeds(self, pts, weights, k):
+        """the build's deterministic D^2 seeding: indices of the picked points (fewer than k when no distinct point is left)"""
+        pts = np.ascontiguousarray(pts, np.int32)
+        w = np.ascontiguousarray(weights, np.uint32) if weights is not None else None
+        seeds = np.full(k, -1, np.int64)
+        kk = self.L.tmo_kmeans_pp_seeds(_p(pts), _p(w), pts.shape[0], pts.shape[1], k, _p(seeds))
+        return seeds[:kk]
 
     def palettize(self, feat, use, pal_count, max_iter=300):
         feat = np.ascontiguousarray(feat, np.int32)

@@ -169,3 +169,35 @@ def test_kmodes_restatement_properties(oracle):
     assert len(set(zip(truth.tolist(), labels.tolist()))) == 3
     again = oracle.kmodes(rows, 3, 0, 256, -1)
     assert np.array_equal(again[0], labels) and again[2] == cost and iters >= 1
+
+
+def test_kmeans_pp_seeding_follows_its_stated_rule(oracle):
+    """tmo_kmeans_pp_seeds against an independent big-integer restatement of the rule in DESIGN.md section 6: 64-bit LCG (MMIX
+    constants) from 0x42381337, r = floor(x * total / 2^64) over the masses weight * nearest squared distance (weight alone for the
+    first pick), first point whose running sum exceeds r; a zero total ends the seeding."""
+    rng = np.random.default_rng(5)
+    for n, d, k, wmax in ((1, 4, 3, 1), (7, 3, 4, 5), (300, 192, 16, 4_000_000), (50, 8, 60, 2 ** 32 - 1)):
+        pts = rng.integers(-40000, 40000, size=(n, d)).astype(np.int32)
+        pts[n // 2:] = pts[: n - n // 2]  # duplicates: fewer distinct points than k in the last case
+        w = rng.integers(1, wmax + 1, size=n, dtype=np.uint64).astype(np.uint32)
+        got = oracle.kmeans_pp_seeds(pts, w, k)
+        state, seeds, mind = 0x42381337, [], None
+        P = pts.astype(object)
+        for _ in range(k):
+            mass = [int(w[i]) * (1 if mind is None else mind[i]) for i in range(n)]
+            total = sum(mass)
+            if total == 0:
+                break
+            state = (state * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+            r = (state * total) >> 64
+            run, pick = 0, None
+            for i in range(n):
+                run += mass[i]
+                if run > r:
+                    pick = i
+                    break
+            seeds.append(pick)
+            dist = [int(sum((int(a) - int(b)) ** 2 for a, b in zip(P[i], P[pick]))) for i in range(n)]
+            mind = dist if mind is None else [min(a, b) for a, b in zip(mind, dist)]
+        assert list(got) == seeds
+        assert len(set(seeds)) == len(seeds)

@@ -58,6 +58,7 @@ __device__ __forceinline__ int find_seg(const Seg *__restrict__ segs, int &bx, i
 // ---- farthest-first ------------------------------------------------------------------------------------------
 // best key: larger mindist wins, then lower index.  mindist can reach 2^38 (D=192), indices 2^31: two words.
 struct BestKey { long long dist; long long negidx; };
+struct FfCandOut { long long *dist, *gidx; int32_t *row; };  // where a process writes its candidate (FfCand's fields)
 __device__ __forceinline__ bool better(const BestKey &a, const BestKey &b) {
   return a.dist > b.dist || (a.dist == b.dist && a.negidx > b.negidx);
 }
@@ -690,12 +691,8 @@ __global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict
     double s[KCH];
 #pragma unroll
     for (int c = 0; c < KCH; c++) s[c] = 0.0;
-    int4 cur0 = src[0], cur1 = src[1];
-#pragma unroll 1
-    for (int ch = 0; ch < D / A_DCH; ch++) {
-      int4 nx0 = cur0, nx1 = cur1;
-      if (ch + 1 < D / A_DCH) { nx0 = src[(ch + 1) * chunk_stride]; nx1 = src[(ch + 1) * chunk_stride + 1]; }
-      const int v[A_DCH] = {cur0.x, cur0.y, cur0.z, cur0.w, cur1.x, cur1.y, cur1.z, cur1.w};
+    auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
+      const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
       for (int j = 0; j < A_DCH; j++) {
         const double pj = (double)v[j];
@@ -708,7 +705,19 @@ __global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict
           s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
         }
       }
-      cur0 = nx0; cur1 = nx1;
+    };
+    // two chunks per step, the next two in flight (a lone wave per SIMD has nothing else to cover the memory round trips with)
+    int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
+#pragma unroll 1
+    for (int ch = 0; ch < D / A_DCH; ch += 2) {
+      int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (ch + 2 < D / A_DCH) {
+        na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
+        nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
+      }
+      score_chunk(a0, a1, ch);
+      score_chunk(b0, b1, ch + 1);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
 #pragma unroll
     for (int c = 0; c < KCH; c++)
@@ -1337,23 +1346,18 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   // D = 192, one segment, centroids that fit LDS: after H_WARM plain iterations the assignment step only touches the points whose
   // bounds do not prove their assignment (k_h_bounds, then k_assign192 over the list); the arithmetic, hence the result, is unchanged
   static const int h_warm = getenv("TM_KM_WARM") ? atoi(getenv("TM_KM_WARM")) : 5;
+  const int h_kt = (k + KCH - 1) / KCH * KCH;  // row pitch of the transposed centroids (hcent_t)
   const bool skipping = d == 192 && nseg == 1 && k <= H_MAXK && !getenv("TM_KM_NOSKIP");
   DevBuf hub, hlb, hcent_t, hmove, hhalf, hneed, hcnt;
-  static const int h_nt = getenv("TM_KM_HNT") ? atoi(getenv("TM_KM_HNT")) : 256;  // points per workgroup of the list kernel
-  const size_t h_lds = (size_t)192 * KCH * 8 + (size_t)k * 193 * 8 + (size_t)256 * 3 * 4 + 16;
-  const int h_kt = (k + KCH - 1) / KCH * KCH;  // row pitch of the transposed centroids (hcent_t)
+  const size_t l_lds = (size_t)192 * KCH * 8 + (size_t)k * 193 * 8 + (size_t)256 * 3 * 4 + 16;  // k_assign192_list
   if (skipping) {
     TM_TRY(hub.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hlb.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hcent_t.alloc((size_t)h_kt * 192 * 8));
-    TM_TRY(hmove.alloc((size_t)(k + 3) * 8)); TM_TRY(hhalf.alloc((size_t)k * 8)); TM_TRY(hneed.alloc((size_t)std::max<int64_t>(n, 1) * 4)); TM_TRY(hcnt.alloc(4));
-    TM_HIP(hipMemsetAsync(hcnt.p, 0, 4, stream));
+    TM_TRY(hmove.alloc((size_t)(k + 3) * 8)); TM_TRY(hhalf.alloc((size_t)k * 8)); TM_TRY(hneed.alloc((size_t)std::max<int64_t>(n, 1) * 4)); TM_TRY(hcnt.alloc(8));
+    TM_HIP(hipMemsetAsync(hcnt.p, 0, 8, stream));
     TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
     if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
     if ((size_t)k * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, k * 192 * 8);
-    if (h_lds > 48 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h_lds);
-    }
+    if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
   int it = 0, issued = 0;
   const int poll_every = 16;  // launches after convergence return at once (quiet flag), so polling late costs little
@@ -1361,27 +1365,16 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     const int batch = std::min(poll_every, max_iter - issued);
     for (int b = 0; b < batch; b++, issued++) {
       if (skipping) {
+        const int gb = (int)((n + H_SLICE - 1) / H_SLICE);
         if (issued < h_warm) {
           const bool last_plain = issued == h_warm - 1;
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
         } else {
-          const int gb = (int)((n + H_SLICE - 1) / H_SLICE);
           hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)k * 192 * 8, stream, pts, n, ds, cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
-          if (h_nt == 64) hipLaunchKernelGGL(k_assign192_list<64>, dim3((unsigned)((n + 63) / 64)), dim3(64), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
-                                             cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
-          else if (h_nt == 128) hipLaunchKernelGGL(k_assign192_list<128>, dim3((unsigned)((n + 127) / 128)), dim3(128), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
-                                                   cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
-          else hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), h_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
-                                  cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
-        }
-        if (getenv("TM_KM_DEBUG") && issued >= h_warm) {
-          unsigned c = 0; Seg hsd; std::vector<double> mv((size_t)k + 1);
-          (void)hipMemcpyAsync(&c, hcnt.p, 4, hipMemcpyDeviceToHost, stream);
-          (void)hipMemcpyAsync(&hsd, dsegs.p, sizeof(Seg), hipMemcpyDeviceToHost, stream);
-          (void)hipStreamSynchronize(stream);
-          fprintf(stderr, "[tm_km] iteration %d: %u of %lld points through the full computation, %d moved\n", issued, c, (long long)n, hsd.changed);
+          hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                             cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
         }
         hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
                            hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>());
@@ -1436,6 +1429,182 @@ int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, in
   return TM_OK;
 }
 
+// ---- the build's seeding of the tile -> palette clustering: D^2 sampling, deterministic ---------------------------------------
+// k-means++-style seeding measured 0.1-0.7 dB (mean 0.5) above farthest-first on the bench clip with as many or fewer final tiles
+// (profiles/r02_seeding_experiment*.json); the build makes it reproducible: a 64-bit LCG (Knuth's MMIX constants) from PP_SEED, pick t draws
+// r = floor(x_t * total / 2^64) over the exact integer masses q_i = weight_i * (squared distance of point i to its nearest centre so
+// far) (q_i = weight_i for the first pick) in 128-bit sums, and takes the first point whose running sum exceeds r; a total of 0 (no
+// point apart from the centres) ends the seeding.  The oracle states the same rule (tmo_kmeans_pp_seeds).
+// Per pick: k_pp_mass (distances to the newest centre folded into the running minimum, masses, one 128-bit sum per 1024 points) and
+// k_pp_pick (the block holding r, then the point inside it).
+typedef unsigned __int128 u128;
+constexpr u64 PP_SEED = 0x42381337ull, PP_MUL = 6364136223846793005ull, PP_INC = 1442695040888963407ull;
+constexpr int PP_BLOCK = 1024;  // points per workgroup of k_pp_mass = per partial sum
+struct PpState { u64 rng; int kk, done; long long pick; u64 tot_lo, tot_hi; };
+struct PpSum { u64 lo, hi; };
+__device__ __forceinline__ u128 pp_mass(const uint32_t *w, const long long *mind, int64_t i, int first) {
+  return (u128)(w ? w[i] : 1u) * (u128)(first ? 1ull : (u64)mind[i]);
+}
+__device__ __forceinline__ u128 pp_draw(u64 x, u128 total) {  // floor(x * total / 2^64) < total
+  return (u128)x * (u64)(total >> 64) + (((u128)x * (u64)total) >> 64);
+}
+__global__ __launch_bounds__(256) void k_pp_mass(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, const int32_t *__restrict__ cur_row,
+                                                 const PpState *__restrict__ st, int first, long long *__restrict__ mind, PpSum *__restrict__ bsum) {
+  __shared__ int32_t s_c[192];
+  __shared__ PpSum s_part[4];
+  const int tid = threadIdx.x;
+  const bool update = !first && !st->done;
+  if (update)
+    for (int j = tid; j < 192; j += 256) s_c[j] = cur_row[j];
+  __syncthreads();
+  u128 mine = 0;
+  for (int m = 0; m < PP_BLOCK / 256; m++) {
+    const int64_t i = (int64_t)blockIdx.x * PP_BLOCK + m * 256 + tid;
+    if (i >= n) break;
+    if (update) {
+      const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
+      long long dd = 0;
+      for (int j = 0; j < 48; j++) {
+        const int4 v = p[j];
+        const long long t0 = (long long)v.x - s_c[4 * j], t1 = (long long)v.y - s_c[4 * j + 1];
+        const long long t2 = (long long)v.z - s_c[4 * j + 2], t3 = (long long)v.w - s_c[4 * j + 3];
+        dd += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+      }
+      if (dd < mind[i]) mind[i] = dd;
+    }
+    mine += pp_mass(w, mind, i, first);
+  }
+  u64 lo = (u64)mine, hi = (u64)(mine >> 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    const u128 other = ((u128)__shfl_xor(hi, o) << 64) | __shfl_xor(lo, o);
+    const u128 sum = (((u128)hi << 64) | lo) + other;
+    lo = (u64)sum; hi = (u64)(sum >> 64);
+  }
+  if ((tid & 63) == 0) s_part[tid >> 6] = PpSum{lo, hi};
+  __syncthreads();
+  if (tid == 0) {
+    u128 t = 0;
+    for (int wv = 0; wv < 4; wv++) t += ((u128)s_part[wv].hi << 64) | s_part[wv].lo;
+    bsum[blockIdx.x] = PpSum{(u64)t, (u64)(t >> 64)};
+  }
+}
+// One workgroup.  mode 0: the whole pick (single process): total, draw, block, point -> st->pick, cur_row, cent, seeds.
+// mode 1 (several processes): only this process's total -> st->tot_*.  mode 2: the draw against the totals of all processes (rank
+// order = global point order); the owner of r finds the point, everybody else reports no candidate.
+__global__ __launch_bounds__(256) void k_pp_pick(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, const long long *__restrict__ mind,
+                                                 const PpSum *__restrict__ bsum, int nb, int first, int k, PpState *__restrict__ st, int mode,
+                                                 const PpSum *__restrict__ totals, int rank, int world, long long global_begin,
+                                                 int32_t *__restrict__ cur_row, double *__restrict__ cent, long long *__restrict__ seeds, FfCandOut cand) {
+  __shared__ PpSum s_q[PP_BLOCK / 256][256], s_part[256];
+  __shared__ long long s_pick;
+  __shared__ u64 s_r[2];
+  const int tid = threadIdx.x;
+  if (st->done || st->kk >= k) {
+    if (mode == 2 && cand.dist && tid == 0) { *cand.dist = -1; *cand.gidx = 0x7fffffffffffffffll; }
+    return;
+  }
+  // the blocks' sums: thread t adds its share (consecutive blocks), thread 0 walks the 256 partial sums
+  const int per = (nb + 255) / 256;
+  {
+    u128 part = 0;
+    for (int b = tid * per; b < min(nb, (tid + 1) * per); b++) part += ((u128)bsum[b].hi << 64) | bsum[b].lo;
+    s_q[0][tid] = PpSum{(u64)part, (u64)(part >> 64)};
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s_pick = -1;
+    u128 local = 0;
+    for (int t = 0; t < 256; t++) local += ((u128)s_q[0][t].hi << 64) | s_q[0][t].lo;
+    if (mode == 1) { st->tot_lo = (u64)local; st->tot_hi = (u64)(local >> 64); }
+    else {
+      u128 total = local, before = 0;
+      if (mode == 2) {
+        total = 0;
+        for (int r = 0; r < world; r++) {
+          const u128 t = ((u128)totals[r].hi << 64) | totals[r].lo;
+          if (r < rank) before += t;
+          total += t;
+        }
+      }
+      if (total == 0) { st->done = 1; s_pick = -2; }
+      else {
+        const u64 x = st->rng * PP_MUL + PP_INC;
+        st->rng = x;
+        const u128 r = pp_draw(x, total);
+        if (r >= before && r < before + local) {  // the point is one of ours: which share of blocks, which block
+          u128 run = before;
+          int t = 0;
+          for (; t < 255; t++) {
+            const u128 v = ((u128)s_q[0][t].hi << 64) | s_q[0][t].lo;
+            if (run + v > r) break;
+            run += v;
+          }
+          int b = t * per;
+          for (; b < nb - 1; b++) {
+            const u128 v = ((u128)bsum[b].hi << 64) | bsum[b].lo;
+            if (run + v > r) break;
+            run += v;
+          }
+          s_pick = b;  // block index for now
+          const u128 rest = r - run;
+          s_r[0] = (u64)rest; s_r[1] = (u64)(rest >> 64);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (mode == 1) return;
+  const long long blk = s_pick;
+  if (blk == -2) {
+    if (mode == 2 && cand.dist && tid == 0) { *cand.dist = -1; *cand.gidx = 0x7fffffffffffffffll; }
+    return;
+  }
+  if (blk >= 0) {  // masses of the block's points in index order; thread t sums four of them, thread 0 walks the 256 sums, then four masses
+    for (int m = 0; m < PP_BLOCK / 256; m++) {
+      const int64_t i = blk * PP_BLOCK + m * 256 + tid;
+      const u128 q = i < n ? pp_mass(w, mind, i, first) : (u128)0;
+      s_q[m][tid] = PpSum{(u64)q, (u64)(q >> 64)};
+    }
+    __syncthreads();
+    {  // thread t: the sum of entries 4t .. 4t+3 (index order), into s_part
+      u128 part = 0;
+      for (int e = tid * (PP_BLOCK / 256); e < (tid + 1) * (PP_BLOCK / 256); e++) part += ((u128)s_q[e >> 8][e & 255].hi << 64) | s_q[e >> 8][e & 255].lo;
+      s_part[tid] = PpSum{(u64)part, (u64)(part >> 64)};
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const u128 rest = ((u128)s_r[1] << 64) | s_r[0];
+      u128 run = 0;
+      int t = 0;
+      for (; t < 255; t++) {
+        const u128 v = ((u128)s_part[t].hi << 64) | s_part[t].lo;
+        if (run + v > rest) break;
+        run += v;
+      }
+      long long pick = -1;
+      for (int e = t * (PP_BLOCK / 256); e < PP_BLOCK && pick < 0; e++) {
+        const PpSum q = s_q[e >> 8][e & 255];
+        run += ((u128)q.hi << 64) | q.lo;
+        if (run > rest) pick = blk * PP_BLOCK + e;
+      }
+      s_pick = pick;
+    }
+    __syncthreads();
+  }
+  const long long pick = blk >= 0 ? s_pick : -1;
+  if (mode == 0) {
+    if (pick >= 0) {
+      const int kk = st->kk;
+      for (int j = tid; j < 192; j += 256) { const int32_t v = pts[pick * 192 + j]; cur_row[j] = v; cent[(int64_t)kk * 192 + j] = (double)v; }
+      __syncthreads();
+      if (tid == 0) { seeds[kk] = pick; st->pick = pick; st->kk = kk + 1; }
+    }
+  } else {  // this process's candidate for the all-gather: the row of the picked point, or none
+    if (tid == 0) { *cand.dist = pick >= 0 ? 1 : -1; *cand.gidx = pick >= 0 ? global_begin + pick : 0x7fffffffffffffffll; }
+    if (tid < 192) cand.row[tid] = pick >= 0 ? pts[pick * 192 + tid] : 0;
+  }
+}
+
 // ---- DoPalettization -------------------------------------------------------------------------------------------
 __global__ void k_count_assign(const int32_t *__restrict__ assign, int64_t n, int k, u64 *__restrict__ cnt) {
   extern __shared__ unsigned int s_cnt[];  // per-workgroup histogram when k fits (a handful of hot global counters would serialise)
@@ -1458,6 +1627,30 @@ __global__ void k_apply_lut(const int32_t *__restrict__ assign, int64_t n, const
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = lut[assign[i]];
 }
 
+// the k seed points of one process's whole point set (indices, -1 beyond the centres found)
+static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std::vector<int64_t> *out, hipStream_t stream) {
+  DevBuf mind, bsum, state, cur_row, cent, seeds;
+  const int nb = (int)((n + PP_BLOCK - 1) / PP_BLOCK);
+  TM_TRY(mind.alloc((size_t)n * 8)); TM_TRY(bsum.alloc(sizeof(PpSum) * (size_t)nb)); TM_TRY(state.alloc(sizeof(PpState)));
+  TM_TRY(cur_row.alloc(192 * 4)); TM_TRY(cent.alloc((size_t)k * 192 * 8)); TM_TRY(seeds.alloc((size_t)k * 8));
+  TM_HIP(hipMemsetAsync(mind.p, 0x7f, (size_t)n * 8, stream));
+  TM_HIP(hipMemsetAsync(seeds.p, 0xff, (size_t)k * 8, stream));
+  PpState h0;
+  memset(&h0, 0, sizeof(h0));
+  h0.rng = PP_SEED;
+  TM_HIP(hipMemcpyAsync(state.p, &h0, sizeof(h0), hipMemcpyHostToDevice, stream));
+  for (int c = 0; c < k; c++) {
+    hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(256), 0, stream, pts, w, n, cur_row.as<int32_t>(), state.as<PpState>(), c == 0 ? 1 : 0, mind.as<long long>(), bsum.as<PpSum>());
+    hipLaunchKernelGGL(k_pp_pick, dim3(1), dim3(256), 0, stream, pts, w, n, mind.as<long long>(), bsum.as<PpSum>(), nb, c == 0 ? 1 : 0, k, state.as<PpState>(), 0,
+                       (const PpSum *)nullptr, 0, 1, 0ll, cur_row.as<int32_t>(), cent.as<double>(), seeds.as<long long>(), FfCandOut{nullptr, nullptr, nullptr});
+  }
+  TM_HIP(hipGetLastError());
+  out->assign((size_t)k, -1);
+  TM_HIP(hipMemcpyAsync(out->data(), seeds.p, (size_t)k * 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  return TM_OK;
+}
+
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream) {
   TM_TRY(require_device());
   TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536 (tilingencoder.pas:2959)", npal);
@@ -1468,7 +1661,13 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   TM_TRY(cnt.alloc((size_t)npal * 8));
   TM_TRY(lut.alloc((size_t)npal * 4));
   int kk = 0, iters = 0;
-  TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
+  if (getenv("TM_KM_FARTHEST_FIRST")) {  // the first rounds' seeding, kept for A/B runs (the oracle's tmo_kmeans_i32)
+    TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
+  } else {
+    std::vector<int64_t> seeds;
+    TM_TRY(pp_seeds((const int32_t *)feat, (const uint32_t *)use, n, npal, &seeds, stream));
+    TM_TRY(run_kmeans_seeded(feat, use, n, 192, npal, seeds.data(), max_iter, assign.p, cent.p, &kk, &iters, stream));
+  }
   // palettes ranked by number of tiles, descending (tilingencoder.pas:4229-4234); ties keep the initial order
   TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)npal * 8, stream));
   hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 512)), dim3(256), npal <= 8192 ? (size_t)npal * 4 : 0, stream,
@@ -1617,12 +1816,43 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
   TM_HIP(hipMemsetAsync(assign.p, 0xff, (size_t)n1 * 4, stream));
   TM_HIP(hipMemsetAsync(state.p, 0, sizeof(FfState), stream));
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
-  // farthest-first: point 0 of the whole set, then k - 1 picks, each settled among one candidate per process
+  // D^2 seeding over all processes (k_pp_mass / k_pp_pick): every process keeps the same generator state; per pick the processes'
+  // total masses are all-gathered (rank order = global point order), the owner of the draw finds the point, and the candidates
+  // (one real, the others empty) are all-gathered like the farthest-first ones were
   FfState hst{0, 0};
+  DevBuf ppstate, bsum, totals, mytot, ppseeds;
+  const int nb = (int)std::max<int64_t>(1, (n + PP_BLOCK - 1) / PP_BLOCK);
+  TM_TRY(ppstate.alloc(sizeof(PpState))); TM_TRY(bsum.alloc(sizeof(PpSum) * (size_t)nb)); TM_TRY(totals.alloc(sizeof(PpSum) * (size_t)co.world));
+  TM_TRY(mytot.alloc(sizeof(PpSum))); TM_TRY(ppseeds.alloc((size_t)k * 8));
+  {
+    PpState h0;
+    memset(&h0, 0, sizeof(h0));
+    h0.rng = PP_SEED;
+    TM_HIP(hipMemcpyAsync(ppstate.p, &h0, sizeof(h0), hipMemcpyHostToDevice, stream));
+    TM_HIP(hipMemsetAsync(bsum.p, 0, sizeof(PpSum) * (size_t)nb, stream));
+    TM_HIP(hipStreamSynchronize(stream));  // h0 is on the stack
+  }
+  FfCand *cd = cand.as<FfCand>();
+  const bool ff = getenv("TM_KM_FARTHEST_FIRST") != nullptr;
   for (int c = 0; c < k; c++) {
-    if (c > 0)
-      hipLaunchKernelGGL(k_ffd_update, dim3(nblk), dim3(256), 0, stream, pts, n, cur_row.as<int32_t>(), mind.as<long long>(), partial.as<BestKey>());
-    hipLaunchKernelGGL(k_ffd_cand, dim3(1), dim3(256), 0, stream, partial.as<BestKey>(), nblk, pts, n, (long long)global_begin, c == 0 ? 1 : 0, cand.as<FfCand>());
+    if (ff) {
+      if (c > 0)
+        hipLaunchKernelGGL(k_ffd_update, dim3(nblk), dim3(256), 0, stream, pts, n, cur_row.as<int32_t>(), mind.as<long long>(), partial.as<BestKey>());
+      hipLaunchKernelGGL(k_ffd_cand, dim3(1), dim3(256), 0, stream, partial.as<BestKey>(), nblk, pts, n, (long long)global_begin, c == 0 ? 1 : 0, cand.as<FfCand>());
+    } else {
+      const int first = c == 0 ? 1 : 0;
+      if (n > 0)
+        hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(256), 0, stream, pts, w, n, cur_row.as<int32_t>(), ppstate.as<PpState>(), first, mind.as<long long>(), bsum.as<PpSum>());
+      hipLaunchKernelGGL(k_pp_pick, dim3(1), dim3(256), 0, stream, pts, w, n, mind.as<long long>(), bsum.as<PpSum>(), n > 0 ? nb : 0, first, k, ppstate.as<PpState>(), 1,
+                         (const PpSum *)nullptr, co.rank, co.world, (long long)global_begin, cur_row.as<int32_t>(), cent.as<double>(), ppseeds.as<long long>(),
+                         FfCandOut{nullptr, nullptr, nullptr});
+      TM_HIP(hipGetLastError());
+      // tot_lo, tot_hi sit side by side in PpState: 16 bytes per process
+      TM_TRY(co.allgather(reinterpret_cast<uint8_t *>(ppstate.p) + offsetof(PpState, tot_lo), totals.p, (int64_t)sizeof(PpSum)));
+      hipLaunchKernelGGL(k_pp_pick, dim3(1), dim3(256), 0, stream, pts, w, n, mind.as<long long>(), bsum.as<PpSum>(), n > 0 ? nb : 0, first, k, ppstate.as<PpState>(), 2,
+                         totals.as<PpSum>(), co.rank, co.world, (long long)global_begin, cur_row.as<int32_t>(), cent.as<double>(), ppseeds.as<long long>(),
+                         FfCandOut{&cd->dist, &cd->gidx, cd->row});
+    }
     TM_HIP(hipGetLastError());
     TM_TRY(co.allgather(cand.p, cands.p, (int64_t)sizeof(FfCand)));
     hipLaunchKernelGGL(k_ffd_pick, dim3(1), dim3(256), 0, stream, cands.as<FfCand>(), co.world, k, state.as<FfState>(), cur_row.as<int32_t>(), cent.as<double>());

@@ -61,6 +61,14 @@ def describe(world):
             "query frames); Reindex and the host search of OptimizePalettes replicated") % world
 
 
+def _backend(group):
+    """'nccl' / 'gloo' / '' (an in-process stand-in for torch.distributed has no notion of one)"""
+    try:
+        return str(dist.get_backend(group))
+    except (AttributeError, RuntimeError, ValueError):
+        return ""
+
+
 class Collective:
     """The collectives the library asks for, over a torch.distributed group (NCCL = RCCL on ROCm, or gloo on CPU tensors)."""
 
@@ -78,7 +86,7 @@ class Collective:
         kernel after the RCCL kernel, and nobody blocks the host.  Returns whether that mode is on (gloo stages through the host
         and keeps the blocking contract; TM_COLL_BLOCKING=1 forces it)."""
         self._stream = None
-        if os.environ.get("TM_COLL_BLOCKING") == "1" or not stream_ptr or dist.get_backend(self.group) != "nccl":
+        if os.environ.get("TM_COLL_BLOCKING") == "1" or not stream_ptr or _backend(self.group) != "nccl":
             return False
         self._stream = torch.cuda.ExternalStream(int(stream_ptr))
         return True
@@ -104,7 +112,7 @@ class Collective:
         self.bytes += recv.numel() * recv.element_size()
         # as bytes: what travels is opaque to the collective (and gloo has no 16-bit integer types)
         rb, sb = recv.reshape(-1).view(torch.uint8), send.contiguous().reshape(-1).view(torch.uint8)
-        if sb.is_cuda and dist.get_backend(self.group) == "gloo":  # gloo gathers host tensors only (rehearsals of the GPU path without RCCL)
+        if sb.is_cuda and _backend(self.group) == "gloo":  # gloo gathers host tensors only (rehearsals of the GPU path without RCCL)
             host = torch.empty(rb.shape, dtype=torch.uint8)
             dist.all_gather_into_tensor(host, sb.cpu(), group=self.group)
             rb.copy_(host)

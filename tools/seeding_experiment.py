@@ -141,6 +141,12 @@ def main():
     gtiles, gflags, guse = tiles[sel].contiguous(), flags[sel].contiguous(), use[:T].contiguous()
     out = {"clip": f"{W}x{H} x {F} synthetic (tiler_amd.synth), {P} palettes x {S} colours", "global_tiles_T": int(T), "runs": []}
     out["runs"].append(run("farthest-first", tiles, flags, gtiles, gflags, guse, None))
+    only = os.environ.get("TM_SEEDING_ONLY")  # "tiles": just the mixed policy the build could adopt, over more seeds
+    if only == "tiles":
+        for seed in range(1, 11):
+            out["runs"].append(run("mixed tiles:k-means++ colours:farthest-first (seed %d)" % seed, tiles, flags, gtiles, gflags, guse, np.random.Generator(np.random.PCG64(seed))))
+        print(json.dumps(out, indent=1))
+        return
     for seed in (1, 2, 3):
         r = run("k-means++ (D^2 sampling, PCG64 seed %d)" % seed, tiles, flags, gtiles, gflags, guse, np.random.Generator(np.random.PCG64(seed)))
         out["runs"].append(r)
