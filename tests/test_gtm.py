@@ -269,14 +269,42 @@ def test_reader_decodes_committed_reference_stream(oracle):
 
 
 def test_lz_compress_recompresses_reference_stream(L, oracle):
-    """our encoder on real command bytes: round trip, and within 1.5x of the reference's own optimal-parse size"""
+    """our encoder on real command bytes: round trip, and within 3 % of the size the reference's own coder (the Pascal port of the LZMA
+    SDK, optimal parsing) made of the same bytes -- VERDICT r01 item 10; the priced parse of round 2 lands 1.2 % BELOW it"""
     pins = _pins()["football_cif"]
     blob = open(os.path.join(GOLDEN, "football_cif_kf1.lzma"), "rb").read()
     raw, _, _ = gtm_reader.lzma_decode(oracle, blob, pins["kf"][1]["raw"] + 16)
     ours = compress(L, raw)
     back, consumed, _ = gtm_reader.lzma_decode(oracle, ours, len(raw) + 16)
     assert back == raw and consumed == len(ours)
-    assert len(ours) < 1.5 * len(blob), (len(ours), len(blob))
+    assert len(ours) <= 1.03 * len(blob), (len(ours), len(blob))
+
+
+def test_lz_compress_parser_fuzz(L, oracle):
+    """the optimal parser against structured inputs that reach its corners: records with one changing field (literal-then-repeat), matches
+    longer than its nice length and than the format's 273, runs crossing its 4096-position window, alternating repeat distances, inputs
+    of every small size; every stream must come back exactly, with exact consumption, through the oracle's decoder"""
+    rng = np.random.default_rng(7)
+    cases = []
+    rec = rng.integers(0, 256, 24, dtype=np.uint8)
+    recs = np.tile(rec, (4000, 1))
+    recs[:, 5] = rng.integers(0, 4, 4000)
+    recs[::17, 11] = rng.integers(0, 256, recs[::17].shape[0])
+    cases.append(recs.tobytes())
+    a, b = rng.integers(0, 256, 700, dtype=np.uint8).tobytes(), rng.integers(0, 256, 900, dtype=np.uint8).tobytes()
+    cases.append((a + b) * 3 + a * 2 + b + a[:300] + b[:129] + a[:128] + b[:127] + a[:274] + b[:273] + a[:272])
+    cases.append(b"".join(bytes([i & 255]) * int(rng.integers(1, 9000)) for i in range(40)))
+    words = rng.integers(0, 40, 30000).astype("<u2")
+    cases.append(words.tobytes())
+    cases.append(bytes(rng.integers(0, 3, 20000, dtype=np.uint8)))
+    for n in range(0, 40):
+        cases.append(bytes(rng.integers(0, 4, n, dtype=np.uint8)))
+    for n in (4095, 4096, 4097, 8191, 8193):
+        cases.append((b"ab" * n)[:n] + bytes(rng.integers(0, 256, 50, dtype=np.uint8)))
+    for data in cases:
+        ours = compress(L, data)
+        back, consumed, _ = gtm_reader.lzma_decode(oracle, ours + b"next stream", len(data) + 16)
+        assert back == data and consumed == len(ours), (len(data), len(ours), consumed)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/docs/demo"), reason="the reference tree is not here")

@@ -5,12 +5,15 @@
 // / pb 2, 4 MiB dictionary, eight 0xFF size bytes, end marker) of 16-bit commands (data << 4 | cmd; 53-86, 5200-5206):
 // ExtendedCommand(settings) + SetDimensions + TileSet(tiles with UseCount > 1) + LoadPalette x P in the first
 // keyframe, then per frame tile-map items / SkipBlocks (5392-5437) and FrameEnd.
-// The LZMA encoder is our own (hash-chain greedy parse: literals, matches, rep0 matches); any valid LZMA stream with
-// these properties decodes in the reference's decoders/htmljs/lzma.js -- byte equality with the Pascal LZMA SDK port's
-// optimal parser is not a goal, only the properties and the decoded command stream are.
+// The LZMA encoder is our own (LzmaOptEncoder below: priced optimal parsing; the greedy parser of round 1 is kept beside it for A/B
+// runs); any valid LZMA stream with these properties decodes in the reference's decoders/htmljs/lzma.js -- byte equality with the
+// Pascal LZMA SDK port's output is not a goal, the properties, the decoded command stream and the stream SIZE are (1.2 % below the
+// reference's on its own demo stream, tests/test_gtm.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "tm_common.h"
@@ -195,12 +198,478 @@ class LzmaEncoder {  // lc/lp/pb as LZCompress sets them: SetLcLpPb(8,0,2), end 
   size_t rep_[4] = {0, 0, 0, 0};
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// The shipped coder: same bitstream, priced optimal parsing.  LZMA/ULZMAEncoder.pas (the Pascal port of the LZMA SDK the reference
+// links) chooses its literals / matches / repeated matches by dynamic programming over bit prices; the greedy parser above left 12 %
+// on the table on the reference's own command streams.  This one restates that scheme in its own structure:
+//  * match finder: exact 2-byte table, 3-byte and 4-byte hashes with a chain on the latter; per position the list of (length, nearest
+//    distance) pairs of strictly increasing length;
+//  * prices in 1/16 bit from the live probabilities (bit prices tabulated per 16 probability steps); length and distance price tables
+//    refreshed every 64 lengths / 128 matches, literal and choice prices read directly;
+//  * a window of up to 4096 positions: every node keeps the cheapest way to reach it with the state and the four repeat distances that
+//    way implies; from a node: literal, one-byte repeat, the four repeats at every length, every match length at its nearest distance,
+//    and literal-then-repeat0 (the pattern of a command stream: one field changes, the rest repeats).  A match or repeat of at least
+//    kNice bytes is taken at once.
+// Decoder-side semantics are untouched: lzma.js and the oracle's decoder read these streams like the greedy ones.
+class LzmaOptEncoder {
+ public:
+  static constexpr int kLc = 8, kLp = 0, kPb = 2, kNice = 128, kOpts = 4096, kDepth = 96;
+  static constexpr uint32_t kDict = 1u << 22, kInf = 1u << 30;
+
+  explicit LzmaOptEncoder(std::vector<uint8_t> &out) : rc_(out), lit_((size_t)0x300 << (kLc + kLp), 1024), opt_(kOpts) {
+    for (auto &r : is_match_) for (auto &p : r) p = 1024;
+    for (auto &r : is_rep0_long_) for (auto &p : r) p = 1024;
+    for (auto &p : is_rep_) p = 1024;
+    for (auto &p : is_rep_g0_) p = 1024;
+    for (auto &p : is_rep_g1_) p = 1024;
+    for (auto &p : is_rep_g2_) p = 1024;
+    for (auto &r : pos_slot_) for (auto &p : r) p = 1024;
+    for (auto &p : pos_special_) p = 1024;
+    for (auto &p : pos_align_) p = 1024;
+    for (int i = 0; i < 128; i++) {  // price of a bit whose probability is (i * 16 + 8) / 2048, in 1/16 bit
+      const double pr = (i * 16 + 8) / 2048.0;
+      bit_price_[i] = (uint32_t)std::lround(-std::log2(pr) * 16.0);
+    }
+  }
+
+  void encode(const uint8_t *src, size_t n) {
+    src_ = src; n_ = n;
+    head2_.assign(1 << 16, -1); head3_.assign(1 << 16, -1); head4_.assign(1 << 20, -1); chain_.assign(n ? n : 1, -1);
+    fill_len_prices(len_, len_prices_); fill_len_prices(rep_len_, rep_len_prices_);
+    fill_dist_prices(); fill_align_prices();
+    len_counter_ = rep_len_counter_ = 64; match_counter_ = 0; align_counter_ = 0;
+    mf_pos_ = 0;
+    size_t pos = 0;
+    while (pos < n) {
+      const int nsteps = optimum(pos);
+      for (int i = 0; i < nsteps; i++) {
+        const Step &st = steps_[i];
+        const uint32_t pos_state = (uint32_t)pos & ((1u << kPb) - 1);
+        if (st.back == kLit) emit_literal(pos, pos_state);
+        else if (st.back < 4) emit_rep(st.back, st.len, pos_state);
+        else emit_match(st.back - 4, st.len, pos_state);
+        pos += st.len;
+      }
+    }
+    emit_match(0xFFFFFFFFu, 2, (uint32_t)pos & ((1u << kPb) - 1));  // end marker
+    rc_.flush();
+  }
+
+ private:
+  static constexpr uint32_t kLit = 0xFFFFFFFFu;
+  struct Step { uint32_t back, len; };  // back: kLit, 0..3 = repeat (len 1: the one-byte repeat0), 4 + distance = match
+  struct Opt {
+    uint32_t price, pos_prev, back_prev;
+    bool lit_first;  // the way here is literal-then-repeat0: a literal at pos_prev, then repeat0 of len - 1
+    uint32_t state, reps[4];
+  };
+
+  // ---- prices
+  uint32_t price(uint16_t prob, int bit) const { return bit_price_[(bit ? 2048 - prob : prob) >> 4]; }
+  uint32_t tree_price(const uint16_t *probs, int nbits, uint32_t sym) const {
+    uint32_t m = 1, pr = 0;
+    for (int i = nbits - 1; i >= 0; i--) { const int b = (sym >> i) & 1; pr += price(probs[m], b); m = (m << 1) | b; }
+    return pr;
+  }
+  uint32_t rtree_price(const uint16_t *probs, int nbits, uint32_t sym) const {
+    uint32_t m = 1, pr = 0;
+    for (int i = 0; i < nbits; i++) { const int b = sym & 1; pr += price(probs[m], b); m = (m << 1) | b; sym >>= 1; }
+    return pr;
+  }
+  uint32_t literal_price(size_t pos, uint32_t state, uint32_t rep0) const {
+    const uint8_t prev_byte = pos ? src_[pos - 1] : 0;
+    const uint16_t *probs = &lit_[(size_t)0x300 * prev_byte];
+    const uint32_t cur = src_[pos];
+    if (state < 7) return tree_price(probs, 8, cur);
+    uint32_t match_byte = src_[pos - rep0 - 1], offs = 0x100, symbol = cur | 0x100, pr = 0;
+    do {
+      match_byte <<= 1;
+      pr += price(probs[offs + (match_byte & offs) + (symbol >> 8)], (symbol >> 7) & 1);
+      symbol <<= 1;
+      offs &= ~(match_byte ^ symbol);
+    } while (symbol < 0x10000);
+    return pr;
+  }
+  void fill_len_prices(const LenCoder &lc, uint32_t (*tab)[272]) {
+    for (int ps = 0; ps < (1 << kPb); ps++) {
+      const uint32_t a0 = price(lc.choice, 0), a1 = price(lc.choice, 1), b0 = a1 + price(lc.choice2, 0), b1 = a1 + price(lc.choice2, 1);
+      for (int l = 0; l < 8; l++) tab[ps][l] = a0 + tree_price(lc.low[ps], 3, l);
+      for (int l = 8; l < 16; l++) tab[ps][l] = b0 + tree_price(lc.mid[ps], 3, l - 8);
+      for (int l = 16; l < 272; l++) tab[ps][l] = b1 + tree_price(lc.high, 8, l - 16);
+    }
+  }
+  static uint32_t pos_slot_of(uint32_t dist) {
+    if (dist < 4) return dist;
+    const int n = 31 - __builtin_clz(dist);
+    return (uint32_t)(2 * n) + ((dist >> (n - 1)) & 1);
+  }
+  void fill_dist_prices() {
+    for (int ls = 0; ls < 4; ls++) {
+      for (uint32_t slot = 0; slot < 64; slot++) {
+        uint32_t pr = tree_price(pos_slot_[ls], 6, slot);
+        if (slot >= 14) pr += (uint32_t)(((slot >> 1) - 1) - 4) * 16;  // direct bits
+        slot_prices_[ls][slot] = pr;
+      }
+      for (uint32_t d = 0; d < 128; d++) {
+        const uint32_t slot = pos_slot_of(d);
+        uint32_t pr = slot_prices_[ls][slot];
+        if (slot >= 4) {
+          const int footer = (int)(slot >> 1) - 1;
+          const uint32_t base = (2u | (slot & 1)) << footer;
+          pr += rtree_price(pos_special_ + ((int)base - (int)slot - 1), footer, d - base);
+        }
+        dist_prices_[ls][d] = pr;
+      }
+    }
+    match_counter_ = 0;
+  }
+  void fill_align_prices() {
+    for (uint32_t i = 0; i < 16; i++) align_prices_[i] = rtree_price(pos_align_, 4, i);
+    align_counter_ = 0;
+  }
+  uint32_t dist_len_price(uint32_t dist, uint32_t len, uint32_t pos_state) const {
+    const uint32_t ls = std::min<uint32_t>(len - 2, 3);
+    const uint32_t pr = dist < 128 ? dist_prices_[ls][dist] : slot_prices_[ls][pos_slot_of(dist)] + align_prices_[dist & 15];
+    return pr + len_prices_[pos_state][len - 2];
+  }
+  uint32_t pure_rep_price(uint32_t k, uint32_t state, uint32_t pos_state) const {
+    if (k == 0) return price(is_rep_g0_[state], 0) + price(is_rep0_long_[state][pos_state], 1);
+    uint32_t pr = price(is_rep_g0_[state], 1);
+    if (k == 1) return pr + price(is_rep_g1_[state], 0);
+    return pr + price(is_rep_g1_[state], 1) + price(is_rep_g2_[state], (int)k - 2);
+  }
+  static uint32_t st_lit(uint32_t s) { return s < 4 ? 0 : (s < 10 ? s - 3 : s - 6); }
+  static uint32_t st_match(uint32_t s) { return s < 7 ? 7 : 10; }
+  static uint32_t st_rep(uint32_t s) { return s < 7 ? 8 : 11; }
+  static uint32_t st_shortrep(uint32_t s) { return s < 7 ? 9 : 11; }
+
+  // ---- match finder
+  static uint32_t h3(const uint8_t *p) { return (uint32_t)((p[0] | (p[1] << 8) | (p[2] << 16)) * 2654435761u) >> 16; }
+  static uint32_t h4(const uint8_t *p) { return (uint32_t)((p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24)) * 2654435761u) >> 12; }
+  void mf_insert(size_t i) {
+    if (i + 2 <= n_) head2_[src_[i] | (src_[i + 1] << 8)] = (int32_t)i;
+    if (i + 3 <= n_) head3_[h3(src_ + i)] = (int32_t)i;
+    if (i + 4 <= n_) { const uint32_t h = h4(src_ + i); chain_[i] = head4_[h]; head4_[h] = (int32_t)i; }
+  }
+  size_t match_len(size_t a, size_t b, size_t from, size_t max_len) const {  // a > b
+    size_t l = from;
+    while (l < max_len && src_[a + l] == src_[b + l]) l++;
+    return l;
+  }
+  // (length, distance - 1) pairs at position i, lengths strictly increasing; inserts i.  Positions must come in order.
+  int mf_find(size_t i, uint32_t *lens, uint32_t *dists) {
+    if (mf_pos_ == i + 1 && last_i_ == i) {  // asked again for the position a parse ended on: the lists it got then
+      for (int q = 0; q < last_np_; q++) { lens[q] = last_lens_[q]; dists[q] = last_dists_[q]; }
+      return last_np_;
+    }
+    while (mf_pos_ < i) mf_insert(mf_pos_++);
+    const size_t max_len = std::min<size_t>(273, n_ - i);
+    int np = 0;
+    size_t best = 1;
+    if (max_len >= 2) {
+      const int32_t c2 = head2_[src_[i] | (src_[i + 1] << 8)];
+      if (c2 >= 0 && i - (size_t)c2 <= kDict) {
+        best = match_len(i, (size_t)c2, 2, max_len);
+        lens[np] = (uint32_t)best; dists[np++] = (uint32_t)(i - (size_t)c2 - 1);
+      }
+      if (max_len >= 3 && best < max_len) {
+        const int32_t c3 = head3_[h3(src_ + i)];
+        if (c3 >= 0 && c3 != c2 && i - (size_t)c3 <= kDict && src_[c3] == src_[i] && src_[c3 + 1] == src_[i + 1] && src_[c3 + 2] == src_[i + 2]) {
+          const size_t l = match_len(i, (size_t)c3, 3, max_len);
+          if (l > best) { best = l; lens[np] = (uint32_t)l; dists[np++] = (uint32_t)(i - (size_t)c3 - 1); }
+        }
+      }
+      if (max_len >= 4 && best < max_len) {
+        int32_t c = head4_[h4(src_ + i)];
+        for (int depth = 0; c >= 0 && depth < kDepth; depth++, c = chain_[c]) {
+          const size_t dist = i - (size_t)c;
+          if (dist > kDict) break;
+          if (src_[c + best] != src_[i + best] || src_[c] != src_[i]) continue;
+          const size_t l = match_len(i, (size_t)c, 0, max_len);
+          if (l > best) {
+            best = l; lens[np] = (uint32_t)l; dists[np++] = (uint32_t)(dist - 1);
+            if (l == max_len) break;
+          }
+        }
+      }
+    }
+    mf_insert(i);
+    mf_pos_ = i + 1;
+    last_i_ = i; last_np_ = np;
+    for (int q = 0; q < np; q++) { last_lens_[q] = lens[q]; last_dists_[q] = dists[q]; }
+    return np;
+  }
+
+  // ---- the parse of one stretch starting at pos: fills steps_, returns their number
+  int optimum(size_t pos) {
+    const size_t avail0 = std::min<size_t>(273, n_ - pos);
+    uint32_t mlens[280], mdists[280];
+    int np = mf_find(pos, mlens, mdists);
+    auto single = [&](uint32_t back, uint32_t len) { steps_[0] = Step{back, len}; return 1; };
+    if (avail0 < 2) return single(kLit, 1);
+    uint32_t rep_lens[4], best_rep = 0;
+    for (int k = 0; k < 4; k++) {
+      rep_lens[k] = pos > reps_[k] ? (uint32_t)match_len(pos, pos - reps_[k] - 1, 0, avail0) : 0;
+      if (rep_lens[k] > rep_lens[best_rep]) best_rep = (uint32_t)k;
+    }
+    if (rep_lens[best_rep] >= (uint32_t)kNice) return single(best_rep, rep_lens[best_rep]);
+    const uint32_t main_len = np ? mlens[np - 1] : 0;
+    if (main_len >= (uint32_t)kNice) return single(mdists[np - 1] + 4, main_len);
+    const uint8_t cur_byte = src_[pos];
+    const bool has_rep0 = pos > reps_[0];
+    const uint8_t match_byte = has_rep0 ? src_[pos - reps_[0] - 1] : (uint8_t)~cur_byte;
+    if (main_len < 2 && cur_byte != match_byte && rep_lens[best_rep] < 2) return single(kLit, 1);
+
+    Opt *o = opt_.data();
+    o[0].state = state_; for (int k = 0; k < 4; k++) o[0].reps[k] = (uint32_t)reps_[k];
+    o[0].price = 0;
+    uint32_t pos_state = (uint32_t)pos & 3;
+    o[1].price = price(is_match_[state_][pos_state], 0) + literal_price(pos, state_, (uint32_t)reps_[0]);
+    o[1].pos_prev = 0; o[1].back_prev = kLit; o[1].lit_first = false;
+    const uint32_t match_price = price(is_match_[state_][pos_state], 1), rep_match_price = match_price + price(is_rep_[state_], 1);
+    if (match_byte == cur_byte) {
+      const uint32_t sp = rep_match_price + price(is_rep_g0_[state_], 0) + price(is_rep0_long_[state_][pos_state], 0);
+      if (sp < o[1].price) { o[1].price = sp; o[1].back_prev = 0; }
+    }
+    uint32_t len_end = std::max(main_len, rep_lens[best_rep]);
+    if (len_end < 2) return single(o[1].back_prev, 1);
+    for (uint32_t l = 2; l <= len_end; l++) o[l].price = kInf;
+    for (uint32_t k = 0; k < 4; k++) {
+      if (rep_lens[k] < 2) continue;
+      const uint32_t base = rep_match_price + pure_rep_price(k, state_, pos_state);
+      for (uint32_t l = 2; l <= rep_lens[k]; l++) {
+        const uint32_t pr = base + rep_len_prices_[pos_state][l - 2];
+        if (pr < o[l].price) { o[l].price = pr; o[l].pos_prev = 0; o[l].back_prev = k; o[l].lit_first = false; }
+      }
+    }
+    {
+      const uint32_t normal = match_price + price(is_rep_[state_], 0);
+      int pi = 0;
+      for (uint32_t l = rep_lens[0] >= 2 ? rep_lens[0] + 1 : 2; l <= main_len; l++) {
+        while (mlens[pi] < l) pi++;
+        const uint32_t pr = normal + dist_len_price(mdists[pi], l, pos_state);
+        if (pr < o[l].price) { o[l].price = pr; o[l].pos_prev = 0; o[l].back_prev = mdists[pi] + 4; o[l].lit_first = false; }
+      }
+    }
+    uint32_t cur = 0;
+    for (;;) {
+      cur++;
+      if (cur == len_end) return backward(cur);
+      np = mf_find(pos + cur, mlens, mdists);
+      const uint32_t new_len0 = np ? mlens[np - 1] : 0;
+      if (new_len0 >= (uint32_t)kNice) return backward(cur);  // the long match is taken by the next call
+      // the state and the repeat distances the cheapest way to this node implies
+      Opt &nd = o[cur];
+      {
+        uint32_t pp = nd.pos_prev;
+        uint32_t st = o[pp].state;
+        uint32_t rp[4] = {o[pp].reps[0], o[pp].reps[1], o[pp].reps[2], o[pp].reps[3]};
+        if (nd.lit_first) {  // literal at pp, then repeat0 up to here
+          st = st_rep(st_lit(st));
+        } else if (nd.back_prev == kLit) {
+          st = st_lit(st);
+        } else if (nd.back_prev < 4) {
+          if (cur - pp == 1) st = st_shortrep(st);  // only repeat0 of one byte gets here with length 1
+          else {
+            st = st_rep(st);
+            const uint32_t k = nd.back_prev, d = rp[k];
+            for (uint32_t j = k; j > 0; j--) rp[j] = rp[j - 1];
+            rp[0] = d;
+          }
+        } else {
+          st = st_match(st);
+          rp[3] = rp[2]; rp[2] = rp[1]; rp[1] = rp[0]; rp[0] = nd.back_prev - 4;
+        }
+        nd.state = st;
+        for (int k = 0; k < 4; k++) nd.reps[k] = rp[k];
+      }
+      const size_t p = pos + cur;
+      pos_state = (uint32_t)p & 3;
+      const uint32_t st = nd.state, cp = nd.price;
+      const uint8_t cb = src_[p];
+      const bool hr0 = p > nd.reps[0];
+      const uint8_t mb = hr0 ? src_[p - nd.reps[0] - 1] : (uint8_t)~cb;
+      const uint32_t lit_pr = cp + price(is_match_[st][pos_state], 0) + literal_price(p, st, nd.reps[0]);
+      bool next_is_lit = false;
+      if (lit_pr < o[cur + 1].price) {
+        o[cur + 1].price = lit_pr; o[cur + 1].pos_prev = cur; o[cur + 1].back_prev = kLit; o[cur + 1].lit_first = false;
+        next_is_lit = true;
+      }
+      const uint32_t mp = cp + price(is_match_[st][pos_state], 1), rmp = mp + price(is_rep_[st], 1);
+      if (mb == cb && !(o[cur + 1].pos_prev < cur && o[cur + 1].back_prev == 0 && !o[cur + 1].lit_first)) {
+        const uint32_t sp = rmp + price(is_rep_g0_[st], 0) + price(is_rep0_long_[st][pos_state], 0);
+        if (sp <= o[cur + 1].price) {
+          o[cur + 1].price = sp; o[cur + 1].pos_prev = cur; o[cur + 1].back_prev = 0; o[cur + 1].lit_first = false;
+          next_is_lit = false;
+        }
+      }
+      const size_t avail_full = std::min<size_t>(273, n_ - p);
+      size_t avail = std::min<size_t>(avail_full, (size_t)kOpts - 1 - cur);
+      if (avail < 2) continue;
+      if (avail > (size_t)kNice) avail = kNice;
+      auto reach = [&](uint32_t to) { while (len_end < to) o[++len_end].price = kInf; };
+      // literal, then repeat0 (one changed byte inside a repeating record)
+      if (next_is_lit && hr0 && mb != cb && avail_full >= 3) {
+        const size_t lim = std::min<size_t>(avail_full - 1, kNice);
+        const size_t l2 = match_len(p + 1, p - nd.reps[0], 0, lim);  // (p + 1) against (p + 1 - rep0 - 1)
+        if (l2 >= 2 && cur + 1 + l2 < (size_t)kOpts) {
+          const uint32_t st2 = st_lit(st), ps2 = (uint32_t)(p + 1) & 3;
+          const uint32_t pr = lit_pr + price(is_match_[st2][ps2], 1) + price(is_rep_[st2], 1) + pure_rep_price(0, st2, ps2) + rep_len_prices_[ps2][l2 - 2];
+          const uint32_t to = cur + 1 + (uint32_t)l2;
+          reach(to);
+          if (pr < o[to].price) { o[to].price = pr; o[to].pos_prev = cur; o[to].back_prev = 0; o[to].lit_first = true; }
+        }
+      }
+      uint32_t start_len = 2;
+      for (uint32_t k = 0; k < 4; k++) {
+        if (p <= nd.reps[k]) continue;
+        const size_t lk = match_len(p, p - nd.reps[k] - 1, 0, avail);
+        if (lk < 2) continue;
+        reach(cur + (uint32_t)lk);
+        const uint32_t base = rmp + pure_rep_price(k, st, pos_state);
+        for (uint32_t l = (uint32_t)lk; l >= 2; l--) {
+          const uint32_t pr = base + rep_len_prices_[pos_state][l - 2];
+          Opt &t = o[cur + l];
+          if (pr < t.price) { t.price = pr; t.pos_prev = cur; t.back_prev = k; t.lit_first = false; }
+        }
+        if (k == 0) start_len = (uint32_t)lk + 1;
+      }
+      uint32_t new_len = new_len0;
+      if (new_len > avail) { new_len = (uint32_t)avail; }
+      if (new_len >= start_len) {
+        const uint32_t normal = mp + price(is_rep_[st], 0);
+        reach(cur + new_len);
+        int pi = 0;
+        for (uint32_t l = start_len; l <= new_len; l++) {
+          while (pi < np - 1 && mlens[pi] < l) pi++;
+          const uint32_t pr = normal + dist_len_price(mdists[pi], l, pos_state);
+          Opt &t = o[cur + l];
+          if (pr < t.price) { t.price = pr; t.pos_prev = cur; t.back_prev = mdists[pi] + 4; t.lit_first = false; }
+        }
+      }
+    }
+  }
+  int backward(uint32_t cur) {
+    int nrev = 0;
+    const Opt *o = opt_.data();
+    while (cur > 0) {
+      const Opt &nd = o[cur];
+      if (nd.lit_first) {
+        rev_[nrev++] = Step{0, cur - nd.pos_prev - 1};  // repeat0
+        rev_[nrev++] = Step{kLit, 1};
+      } else {
+        rev_[nrev++] = Step{nd.back_prev, cur - nd.pos_prev};
+      }
+      cur = nd.pos_prev;
+    }
+    for (int i = 0; i < nrev; i++) steps_[i] = rev_[nrev - 1 - i];
+    return nrev;
+  }
+
+  // ---- emission (the model moves here, and only here)
+  void tree(uint16_t *probs, int nbits, uint32_t sym) {
+    uint32_t m = 1;
+    for (int i = nbits - 1; i >= 0; i--) { const int b = (sym >> i) & 1; rc_.bit(probs[m], b); m = (m << 1) | b; }
+  }
+  void rtree(uint16_t *probs, int nbits, uint32_t sym) {
+    uint32_t m = 1;
+    for (int i = 0; i < nbits; i++) { const int b = sym & 1; rc_.bit(probs[m], b); m = (m << 1) | b; sym >>= 1; }
+  }
+  void emit_len(LenCoder &lc, uint32_t len, uint32_t pos_state, uint32_t (*tab)[272], int &counter) {
+    len -= 2;
+    if (len < 8) { rc_.bit(lc.choice, 0); tree(lc.low[pos_state], 3, len); }
+    else if (len < 16) { rc_.bit(lc.choice, 1); rc_.bit(lc.choice2, 0); tree(lc.mid[pos_state], 3, len - 8); }
+    else { rc_.bit(lc.choice, 1); rc_.bit(lc.choice2, 1); tree(lc.high, 8, len - 16); }
+    if (--counter <= 0) { fill_len_prices(lc, tab); counter = 64; }
+  }
+  void emit_literal(size_t pos, uint32_t pos_state) {
+    rc_.bit(is_match_[state_][pos_state], 0);
+    const uint8_t prev_byte = pos ? src_[pos - 1] : 0;
+    uint16_t *probs = &lit_[(size_t)0x300 * prev_byte];
+    const uint32_t cur = src_[pos];
+    if (state_ < 7) {
+      tree(probs, 8, cur);
+    } else {
+      uint32_t match_byte = src_[pos - reps_[0] - 1], offs = 0x100, symbol = cur | 0x100;
+      do {
+        match_byte <<= 1;
+        rc_.bit(probs[offs + (match_byte & offs) + (symbol >> 8)], (symbol >> 7) & 1);
+        symbol <<= 1;
+        offs &= ~(match_byte ^ symbol);
+      } while (symbol < 0x10000);
+    }
+    state_ = st_lit(state_);
+  }
+  void emit_rep(uint32_t k, uint32_t len, uint32_t pos_state) {
+    rc_.bit(is_match_[state_][pos_state], 1);
+    rc_.bit(is_rep_[state_], 1);
+    if (k == 0) {
+      rc_.bit(is_rep_g0_[state_], 0);
+      rc_.bit(is_rep0_long_[state_][pos_state], len == 1 ? 0 : 1);
+      if (len == 1) { state_ = st_shortrep(state_); return; }
+    } else {
+      rc_.bit(is_rep_g0_[state_], 1);
+      if (k == 1) rc_.bit(is_rep_g1_[state_], 0);
+      else { rc_.bit(is_rep_g1_[state_], 1); rc_.bit(is_rep_g2_[state_], (int)k - 2); }
+      const size_t d = reps_[k];
+      for (uint32_t j = k; j > 0; j--) reps_[j] = reps_[j - 1];
+      reps_[0] = d;
+    }
+    emit_len(rep_len_, len, pos_state, rep_len_prices_, rep_len_counter_);
+    state_ = st_rep(state_);
+  }
+  void emit_match(uint32_t dist, uint32_t len, uint32_t pos_state) {
+    rc_.bit(is_match_[state_][pos_state], 1);
+    rc_.bit(is_rep_[state_], 0);
+    emit_len(len_, len, pos_state, len_prices_, len_counter_);
+    state_ = st_match(state_);
+    const uint32_t slot = pos_slot_of(dist);
+    tree(pos_slot_[std::min<uint32_t>(len - 2, 3)], 6, slot);
+    if (slot >= 4) {
+      const int footer = (int)(slot >> 1) - 1;
+      const uint32_t base = (2u | (slot & 1)) << footer, reduced = dist - base;
+      if (slot < 14) rtree(pos_special_ + ((int)base - (int)slot - 1), footer, reduced);
+      else {
+        rc_.direct(reduced >> 4, footer - 4);
+        rtree(pos_align_, 4, reduced & 15);
+        if (++align_counter_ >= 16) fill_align_prices();
+      }
+    }
+    reps_[3] = reps_[2]; reps_[2] = reps_[1]; reps_[1] = reps_[0]; reps_[0] = dist;
+    if (++match_counter_ >= 128) fill_dist_prices();
+  }
+
+  RangeEncoder rc_;
+  std::vector<uint16_t> lit_;
+  uint16_t is_match_[12][16], is_rep0_long_[12][16], is_rep_[12], is_rep_g0_[12], is_rep_g1_[12], is_rep_g2_[12];
+  uint16_t pos_slot_[4][64], pos_special_[128], pos_align_[16];
+  LenCoder len_, rep_len_;
+  uint32_t state_ = 0;
+  size_t reps_[4] = {0, 0, 0, 0};
+  const uint8_t *src_ = nullptr;
+  size_t n_ = 0, mf_pos_ = 0;
+  std::vector<int32_t> head2_, head3_, head4_, chain_;
+  std::vector<Opt> opt_;
+  Step steps_[kOpts + 8], rev_[kOpts + 8];
+  uint32_t bit_price_[128];
+  uint32_t len_prices_[4][272], rep_len_prices_[4][272], slot_prices_[4][64], dist_prices_[4][128], align_prices_[16];
+  int len_counter_ = 64, rep_len_counter_ = 64, match_counter_ = 0, align_counter_ = 0;
+  size_t last_i_ = (size_t)-1;
+  int last_np_ = 0;
+  uint32_t last_lens_[280], last_dists_[280];
+};
+
 void lz_compress_impl(const std::vector<uint8_t> &raw, std::vector<uint8_t> &dst) {  // LZCompress, extern.pas:420-439
   dst.push_back((uint8_t)((LzmaEncoder::kPb * 5 + LzmaEncoder::kLp) * 9 + LzmaEncoder::kLc));  // 0x62
   for (int i = 0; i < 4; i++) dst.push_back((uint8_t)(LzmaEncoder::kDict >> (8 * i)));
   for (int i = 0; i < 8; i++) dst.push_back(0xFF);
-  LzmaEncoder enc(dst);
-  enc.encode(raw.data(), raw.size());
+  if (getenv("TM_LZMA_GREEDY")) {  // round 1's parser, kept for A/B runs
+    LzmaEncoder enc(dst);
+    enc.encode(raw.data(), raw.size());
+  } else {
+    auto enc = std::make_unique<LzmaOptEncoder>(dst);  // (its parse window lives in the object: not on the stack)
+    enc->encode(raw.data(), raw.size());
+  }
 }
 
 struct Stream {
