@@ -545,6 +545,33 @@ def test_motion_search_quirks_and_ties(oracle):
     assert np.all(e[1] == 0) and np.all(e[2] == 0)  # all candidates equal: the tile's own position wins
 
 
+@pytest.mark.parametrize("tm_w,tm_h,radius,amp", [(19, 7, 32, 9000), (8, 4, 5, 16383), (33, 9, 17, 3000), (9, 13, 32, 10922), (12, 5, 32, 16384), (10, 6, 32, 12000)])
+def test_motion_search_matrix_path(oracle, monkeypatch, tm_w, tm_h, radius, amp):
+    """The matrix-core search (k_mo_search_mfma) against the oracle AND against the VALU kernel on the same data, on tile grids that are
+    not multiples of its 4 x 8 groups, with coefficients up to the bounds under which it runs (+-16383 in the plain blocks, +-10922 in
+    blocks 5 and 6: sums then wrap mod 2^32 like paddd) and just beyond them (the frame falls back to the VALU kernel on the device);
+    repeated windows make equal candidates, which the raster-order rule settles"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(tm_w * 1000 + tm_h * 10 + radius)
+    nwin = (tm_w * 8 - 7) * (tm_h * 8 - 7)
+    win = rng.integers(-amp, amp + 1, (nwin, 192)).astype(np.int16)
+    cur = rng.integers(-amp, amp + 1, (tm_w * tm_h, 192)).astype(np.int16)
+    q = min(amp, 10922) if amp != 12000 else 12000  # blocks 5 / 6 of both halves (amp 12000: beyond their bound -> fallback)
+    for hf in (0, 96):
+        win[:, hf + 40:hf + 56] = rng.integers(-q, q + 1, (nwin, 16))
+        cur[:, hf + 40:hf + 56] = rng.integers(-q, q + 1, (tm_w * tm_h, 16))
+    win[::11] = win[5]
+    cur[3] = win[5]
+    e = oracle.motion_search(cur, tm_w, tm_h, win, radius)
+    g = stages.motion_search(_dev(cur), tm_w, tm_h, _dev(win), radius)
+    torch.cuda.synchronize()
+    assert np.array_equal(_host_u32(g[0]), e[0]) and np.array_equal(g[1].cpu().numpy(), e[1]) and np.array_equal(g[2].cpu().numpy(), e[2])
+    monkeypatch.setenv("TM_MOTION_VALU", "1")
+    v = stages.motion_search(_dev(cur), tm_w, tm_h, _dev(win), radius)
+    torch.cuda.synchronize()
+    assert np.array_equal(_host_u32(v[0]), e[0]) and np.array_equal(v[1].cpu().numpy(), e[1]) and np.array_equal(v[2].cpu().numpy(), e[2])
+
+
 # ---- (f)#3 FrameTilingExtendedPaletteUsage -------------------------------------------------------------------------
 @pytest.mark.parametrize("nt,k", [(700, 64), (40, 64), (300, 5)])
 def test_knn_topk(oracle, nt, k):

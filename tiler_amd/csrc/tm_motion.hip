@@ -10,6 +10,7 @@
 // states the same thing in scalar C.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "tm_common.h"
 #include "tm_internal.h"
@@ -45,7 +46,8 @@ constexpr int MS_GROUPS = 32;   // 8 lanes per candidate, 256 threads
 // well for the double subtraction, lane 2 adds the re-squared pair sums of block 7.
 __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict__ cur, int tm_w, int tm_h,
                                                        const int16_t *__restrict__ win, int r, uint32_t *__restrict__ best_err,
-                                                       int8_t *__restrict__ out_px, int8_t *__restrict__ out_py) {
+                                                       int8_t *__restrict__ out_px, int8_t *__restrict__ out_py, const int *__restrict__ only_if = nullptr) {
+  if (only_if && !*only_if) return;  // the matrix-core search (k_mo_search_mfma) took this frame
   __shared__ uint32_t s_err[MS_TB * MS_TB][MS_GROUPS];
   __shared__ int s_pos[MS_TB * MS_TB][MS_GROUPS];
   const int tid = threadIdx.x, j8 = tid & 7, grp = tid >> 3;
@@ -147,6 +149,259 @@ __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The search on the matrix cores.  Of the 24 blocks of CompareEuclideanDCTPtr_asm 20 are plain squared differences (blocks 0-4 and 7-11
+// of each half; block 7 of the first half ALSO feeds the re-squared pair sums); whenever no psubsw can saturate there -- every
+// coefficient of those blocks within +-16383, checked on the data of every frame -- their sum is |a|^2 + |b|^2 - 2 a.b with everything
+// mod 2^32, exactly what paddd's wrap-around gives.  a.b over the 160 plain coefficients goes through v_mfma_i32_32x32x32_i8 with both
+// sides split into two int8 digits (one accumulator shifted between the HH, mixed and LL products, as in the KNN scan).  Block 6 of
+// both halves, (a6 -sat b5) -sat b6, joins them as a6 . (b5 + b6) whenever neither subtraction can saturate (those three blocks
+// within +-10922 on both sides; checked as well).  What stays on the VALU, psubsw arithmetic untouched, is the re-squaring of block
+// 7's pair sums: 8 coefficient operations per (tile, window) pair instead of 192.
+//  * k_mo_pack_win: the window features of a frame in MFMA fragment order: per block of 32 consecutive window positions of a row
+//    [12 chunks][64 lanes][16 B] digits (low digits of the 160 plain coefficients + the 16 of b5 + b6, then high), 32 norms, block 7 raw.
+//  * k_mo_search_mfma: a workgroup = 4 x 8 tiles (a 32 x 64 pixel region) as the B operand (tile = lane: a tile's running minimum never
+//    leaves its lane, its quirk coefficients sit in registers); its four waves share the (window row, block of 32) items of the union of
+//    the tiles' windows; per item 20 MFMAs, then per window row of the accumulator the quirk terms of the lanes whose tile can use it.
+// Candidates are compared by (error, raster position), which is "first strict minimum in raster order" whatever order they are seen in.
+// A frame whose data could saturate raises a flag on the device: this kernel then leaves at once and k_motion_search runs instead.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int MM_CH = 6;                                             // 32-wide chunks of the 160 plain coefficients + 16 of block 6 + 16 of padding
+constexpr int MM_DIG = 2 * MM_CH * 1024, MM_NORM = MM_DIG, MM_QUIRK = MM_DIG + 128;
+constexpr int MM_BLK_BYTES = MM_QUIRK + 32 * 16;                     // 12928
+constexpr int MM_LIMIT6 = 10922;                                     // |coefficient| bound of blocks 5 and 6 under which a6 - b5 - b6 cannot saturate
+constexpr int MM_TR = 4, MM_TC = 8;                                  // tiles of a workgroup: 4 rows x 8 columns
+constexpr int MM_LIMIT = 16383;                                      // |coefficient| bound under which no plain difference saturates
+
+__device__ __forceinline__ int mm_plain_col(int pb) {  // first coefficient of plain block pb (0..19): blocks 0-4, 7-11 of each half
+  const int hf = pb / 10, bi = pb - hf * 10;
+  return hf * 96 + (bi < 5 ? bi : bi + 2) * 8;
+}
+// matrix block mb (8 coefficients; 0..19 plain, 20 / 21 = block 6 of the first / second half, 22 / 23 padding) of a TILE's row: its
+// first coefficient, or -1 for padding
+__device__ __forceinline__ int mm_tile_col(int mb) { return mb < 20 ? mm_plain_col(mb) : mb == 20 ? 48 : mb == 21 ? 96 + 48 : -1; }
+
+__global__ __launch_bounds__(256) void k_mo_pack_win(const int16_t *__restrict__ win, int ww, int wh, int nbx, const int16_t *__restrict__ cur, int ntiles,
+                                                     uint8_t *__restrict__ out, int *__restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the 32 windows' rows as they lie in memory (pitch 400 B)
+  bool bad = false;
+  // the tile side's range check (its digits are made inside the search kernel)
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)ntiles * 24; i += (int64_t)gridDim.x * 256) {
+    const int blk = (int)(i % 24) % 12;
+    if (blk == 5) continue;  // never enters on the tile side
+    const int lim = blk == 6 ? MM_LIMIT6 : MM_LIMIT;
+    const uint4 v = reinterpret_cast<const uint4 *>(cur)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int lo = (int16_t)(w[k] & 0xffff), hi = (int16_t)(w[k] >> 16);
+      bad |= lo > lim || lo < -lim || hi > lim || hi < -lim;
+    }
+  }
+  const int64_t nblocks = (int64_t)wh * nbx;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int wy = (int)(blk / nbx), bx = (int)(blk - (int64_t)wy * nbx);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 24; i += 256) {
+      const int r = i / 24, v = i - r * 24, wx = bx * 32 + r;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (wx < ww) x = *reinterpret_cast<const uint4 *>(win + ((int64_t)wy * ww + wx) * 192 + v * 8);
+      *reinterpret_cast<uint4 *>(&s_raw[r][v * 8]) = x;
+    }
+    __syncthreads();
+    uint8_t *obase = out + blk * (int64_t)MM_BLK_BYTES;
+    for (int piece = threadIdx.x; piece < 2 * MM_CH * 64; piece += 256) {
+      const int kc = piece >> 6, ln = piece & 63, half = ln >> 5, r = ln & 31, c = kc % MM_CH;
+      const bool high = kc >= MM_CH;
+      uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int h8 = 0; h8 < 2; h8++) {  // two blocks of eight coefficients, 16 bytes each in LDS
+        const int mb = 4 * c + 2 * half + h8;
+        uint32_t x[4] = {0, 0, 0, 0};
+        int lim = MM_LIMIT;
+        if (mb < 20) {
+          const uint4 t4 = *reinterpret_cast<const uint4 *>(&s_raw[r][mm_plain_col(mb)]);
+          x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
+        } else if (mb < 22) {  // b5 + b6 of a half: the tile's a6 meets their sum
+          const uint4 t5 = *reinterpret_cast<const uint4 *>(&s_raw[r][(mb - 20) * 96 + 40]), t6 = *reinterpret_cast<const uint4 *>(&s_raw[r][(mb - 20) * 96 + 48]);
+          const uint32_t a5[4] = {t5.x, t5.y, t5.z, t5.w}, a6[4] = {t6.x, t6.y, t6.z, t6.w};
+          lim = 2 * MM_LIMIT6;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+              const int v5 = (int16_t)(a5[k] >> (16 * e)), v6 = (int16_t)(a6[k] >> (16 * e));
+              bad |= v5 > MM_LIMIT6 || v5 < -MM_LIMIT6 || v6 > MM_LIMIT6 || v6 < -MM_LIMIT6;
+              x[k] |= (uint32_t)((v5 + v6) & 0xffff) << (16 * e);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const int v = (int16_t)(x[k] >> (16 * e));
+            bad |= v > lim || v < -lim;
+            const int lo = ((v + 128) & 255) - 128;
+            const int digit = high ? (v - lo) >> 8 : lo;
+            const int b = h8 * 8 + k * 2 + e;
+            w[b >> 2] |= (uint32_t)(digit & 255) << ((b & 3) * 8);
+          }
+        }
+      }
+      *reinterpret_cast<uint4 *>(obase + piece * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    {  // |b|^2 over the 176 matrix coefficients: 8 threads per window, one coefficient of every block each
+      const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+      uint32_t sq = 0;
+#pragma unroll
+      for (int pb = 0; pb < 20; pb++) { const int v = s_raw[r][mm_plain_col(pb) + j]; sq += (uint32_t)(v * v); }
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) { const int v = s_raw[r][hf * 96 + 40 + j] + s_raw[r][hf * 96 + 48 + j]; sq += (uint32_t)(v * v); }
+      sq += (uint32_t)__shfl_xor((int)sq, 1); sq += (uint32_t)__shfl_xor((int)sq, 2); sq += (uint32_t)__shfl_xor((int)sq, 4);
+      if (j == 0) reinterpret_cast<uint32_t *>(obase + MM_NORM)[r] = sq;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 32) {  // block 7 of the first half, raw: its pair sums are re-squared on the VALU
+      const int r = threadIdx.x - 64;
+      *reinterpret_cast<uint4 *>(obase + MM_QUIRK + r * 16) = *reinterpret_cast<const uint4 *>(&s_raw[r][56]);
+    }
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void k_mo_search_mfma(const int16_t *__restrict__ cur, int tm_w, int tm_h, int ngroups, const uint8_t *__restrict__ packed, int nbx,
+                                                        int r, const int *__restrict__ flag, uint32_t *__restrict__ best_err,
+                                                        int8_t *__restrict__ out_px, int8_t *__restrict__ out_py) {
+  if (*flag) return;  // a coefficient beyond +-16383 somewhere in this frame: k_motion_search takes it
+  __shared__ __attribute__((aligned(16))) uint32_t s_q[4][32][4];  // per wave: block 7 (first half) of the item's 32 windows
+  __shared__ uint32_t s_err[8][32];
+  __shared__ int s_pos[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, t = lane & 31;
+  const int gw = (tm_w + MM_TC - 1) / MM_TC;
+  // workgroups are dealt to the XCDs round robin: workgroup b works on group (b % 8) * ceil(n / 8) + b / 8, so that the groups running
+  // on one XCD are neighbours in the picture and find each other's window blocks in that XCD's L2 (placement is a matter of speed only)
+  const int per_xcd = gridDim.x >> 3;  // (the grid is 8 x ceil(groups / 8) workgroups; the ones past the last group have nothing to do)
+  const int gsel = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (gsel >= ngroups) return;
+  const int gy = gsel / gw, gx = gsel - gy * gw;
+  const int sw = tm_w * 8, sh = tm_h * 8, ww = sw - 7;
+  const int sy = gy * MM_TR + (t >> 3), sx = gx * MM_TC + (t & 7);
+  const bool tvalid = sy < tm_h && sx < tm_w;
+  const int dy = sy * 8, dx = sx * 8;
+  const int16_t *arow = cur + ((int64_t)(tvalid ? sy : 0) * tm_w + (tvalid ? sx : 0)) * 192;
+  // B operand: the tile's digits in fragment order (lane = half * 32 + tile holds positions half * 16 .. + 15 of every chunk)
+  v4i Bf[2 * MM_CH];
+  uint32_t na = 0;
+#pragma unroll
+  for (int c = 0; c < MM_CH; c++) {
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++) {
+      const int tcol = mm_tile_col(4 * c + 2 * half + h8);
+      const uint4 x = tcol >= 0 ? *reinterpret_cast<const uint4 *>(arow + tcol) : make_uint4(0, 0, 0, 0);
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const int v = tvalid ? (int)(int16_t)(w[k] >> (16 * e)) : 0;
+          const int l8 = ((v + 128) & 255) - 128, h8v = (v - l8) >> 8;
+          const int b = h8 * 8 + k * 2 + e;
+          lo[b >> 2] |= (uint32_t)(l8 & 255) << ((b & 3) * 8);
+          hi[b >> 2] |= (uint32_t)(h8v & 255) << ((b & 3) * 8);
+          na += (uint32_t)(v * v);
+        }
+      }
+    }
+    Bf[c] = v4i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3]};
+    Bf[MM_CH + c] = v4i{(int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  }
+  na += (uint32_t)__shfl_xor((int)na, 32);  // both halves of the tile's 176 coefficients
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const uint4 a7h1 = tvalid ? *reinterpret_cast<const uint4 *>(arow + 56) : zero4;
+  // the tile's window (1218-1221) as start + unsigned extent; an absent tile gets an empty one
+  const int y0 = max(0, dy - r - 1), y1 = min(sh - 8, dy + r), x0 = max(0, dx - r - 1), x1 = min(sw - 8, dx + r);
+  const unsigned wy0 = (unsigned)y0, wyr = tvalid ? (unsigned)(y1 - y0) : 0u, wx0 = tvalid ? (unsigned)x0 : 0x40000000u, wxr = (unsigned)(x1 - x0);
+  // union of the group's windows, in (row, block of 32) items
+  const int ly = min(gy * MM_TR + MM_TR - 1, tm_h - 1) * 8, lx = min(gx * MM_TC + MM_TC - 1, tm_w - 1) * 8;
+  const int uy0 = max(0, gy * MM_TR * 8 - r - 1), uy1 = min(sh - 8, ly + r);
+  const int ux0 = max(0, gx * MM_TC * 8 - r - 1), ux1 = min(sw - 8, lx + r);
+  const int bx0 = ux0 >> 5, nbu = (ux1 >> 5) - bx0 + 1, nitems = (uy1 - uy0 + 1) * nbu;
+  uint32_t best = 0xffffffffu;
+  int bpos = 0x7fffffff;
+  for (int it = wave; it < nitems; it += 4) {
+    const int row = it / nbu, wy = uy0 + row, bx = bx0 + (it - row * nbu);
+    const uint8_t *base = packed + ((int64_t)wy * nbx + bx) * MM_BLK_BYTES;
+    v4i Af[2 * MM_CH];
+#pragma unroll
+    for (int kc = 0; kc < 2 * MM_CH; kc++) Af[kc] = *reinterpret_cast<const v4i *>(base + (kc * 64 + lane) * 16);
+    uint32_t nbr[16];  // |b|^2 of accumulator row q: window (q & 3) + 8 * (q >> 2) + 4 * half of the block
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+      const v4i x = *reinterpret_cast<const v4i *>(base + MM_NORM + (q4 * 8 + half * 4) * 4);
+      nbr[q4 * 4] = (uint32_t)x[0]; nbr[q4 * 4 + 1] = (uint32_t)x[1]; nbr[q4 * 4 + 2] = (uint32_t)x[2]; nbr[q4 * 4 + 3] = (uint32_t)x[3];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the previous item's block 7 are over
+    if (lane < 32) reinterpret_cast<uint4 *>(&s_q[wave][0][0])[lane] = *reinterpret_cast<const uint4 *>(base + MM_QUIRK + lane * 16);
+    v16i acc;
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = 0;
+#pragma unroll
+    for (int c = 0; c < MM_CH; c++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[MM_CH + c], Bf[MM_CH + c], acc, 0, 0, 0);  // b_H . a_H
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = (int)((unsigned)acc[q] << 8);
+#pragma unroll
+    for (int c = 0; c < MM_CH; c++) {
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[c], Bf[MM_CH + c], acc, 0, 0, 0);  // b_L . a_H
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[MM_CH + c], Bf[c], acc, 0, 0, 0);  // b_H . a_L
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = (int)((unsigned)acc[q] << 8);
+#pragma unroll
+    for (int c = 0; c < MM_CH; c++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[c], Bf[c], acc, 0, 0, 0);  // b_L . a_L
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // block 7 of the item's windows is in LDS (written by this wave's own lanes)
+    const bool rowin = (unsigned)wy - wy0 <= wyr;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int m = (q & 3) + 8 * (q >> 2) + 4 * half, wx = bx * 32 + m;
+      const bool in = rowin && (unsigned)wx - wx0 <= wxr;
+      if (!__builtin_amdgcn_ballot_w64(in)) continue;  // no tile of the group can use this window
+      const uint4 b7h1 = *reinterpret_cast<const uint4 *>(&s_q[wave][m][0]);
+      uint32_t e = na + nbr[q] - 2u * (uint32_t)acc[q];  // the 20 plain blocks and both block 6 terms
+      const uint32_t p0 = sq2(sat_sub2(a7h1.x, b7h1.x)), p1 = sq2(sat_sub2(a7h1.y, b7h1.y)), p2 = sq2(sat_sub2(a7h1.z, b7h1.z)),
+                     p3 = sq2(sat_sub2(a7h1.w, b7h1.w));
+      e = sq2acc(p3, sq2acc(p2, sq2acc(p1, sq2acc(p0, e))));  // the pair sums re-squared as int16 pairs (their plain sum is in the matrix part)
+      uint32_t err;  // + manhattan penalty (1236)
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(wx), "v"(dx), "v"(e));
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(wy), "v"(dy), "v"(err));
+      const int pos = wy * ww + wx;
+      const bool take = in && (err < best || (err == best && pos < bpos));
+      best = take ? err : best;
+      bpos = take ? pos : bpos;
+    }
+  }
+  s_err[wave * 2 + half][t] = best;
+  s_pos[wave * 2 + half][t] = bpos;
+  __syncthreads();
+  if (tid < 32) {
+    const int ty = gy * MM_TR + (tid >> 3), tx = gx * MM_TC + (tid & 7);
+    if (ty < tm_h && tx < tm_w) {
+      uint32_t be = 0xffffffffu;
+      int bp = 0x7fffffff;
+      for (int g = 0; g < 8; g++) {
+        const uint32_t e = s_err[g][tid];
+        const int p = s_pos[g][tid];
+        if (e < be || (e == be && p < bp)) { be = e; bp = p; }
+      }
+      const int64_t i = (int64_t)ty * tm_w + tx;
+      best_err[i] = be;
+      const int oy = bp / ww, ox = bp - oy * ww;
+      out_px[i] = (int8_t)(ox - tx * 8);
+      out_py[i] = (int8_t)(oy - ty * 8);
+    }
+  }
+}
 // front buffer of PredictMotion (1255-1260): the frame's tiles, un-mirrored, laid out as a tm_w*8 x tm_h*8 image
 __global__ void k_tiles_to_screen(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags, int tm_w, int tm_h,
                                   uint32_t *__restrict__ screen) {
@@ -240,8 +495,26 @@ int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, i
                          hipStream_t stream) {
   TM_CHECK(tm_w > 0 && tm_h > 0 && radius >= 1 && radius <= 128, TM_E_INVAL, "motion search: bad arguments");
   const int bw = (tm_w + MS_TB - 1) / MS_TB, bh = (tm_h + MS_TB - 1) / MS_TB;
-  hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
+  if (getenv("TM_MOTION_VALU")) {  // the VALU kernel alone (A/B runs)
+    hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
+                       (uint32_t *)best_err, (int8_t *)px, (int8_t *)py, (const int *)nullptr);
+    TM_HIP(hipGetLastError());
+    return TM_OK;
+  }
+  // matrix-core path: pack the windows, search; a frame whose coefficients could saturate a plain difference falls to the VALU kernel
+  // (decided on the device: both kernels are queued, one of them leaves at once)
+  const int ww = tm_w * 8 - 7, wh = tm_h * 8 - 7, nbx = (ww + 31) / 32;
+  DevBuf packed, flag;  // (released at return: the pool hands memory back out in stream order, and everything here is on `stream`)
+  TM_TRY(packed.alloc((size_t)wh * nbx * MM_BLK_BYTES));
+  TM_TRY(flag.alloc(sizeof(int)));
+  TM_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), stream));
+  hipLaunchKernelGGL(k_mo_pack_win, dim3(std::min(wh * nbx, 8192)), dim3(256), 0, stream, (const int16_t *)win, ww, wh, nbx, (const int16_t *)cur, tm_w * tm_h,
+                     packed.as<uint8_t>(), flag.as<int>());
+  const int gw = (tm_w + MM_TC - 1) / MM_TC, gh = (tm_h + MM_TR - 1) / MM_TR;
+  hipLaunchKernelGGL(k_mo_search_mfma, dim3(8 * ((gw * gh + 7) / 8)), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, gw * gh, packed.as<uint8_t>(), nbx, radius - 1, flag.as<int>(),
                      (uint32_t *)best_err, (int8_t *)px, (int8_t *)py);
+  hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
+                     (uint32_t *)best_err, (int8_t *)px, (int8_t *)py, flag.as<int>());
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
