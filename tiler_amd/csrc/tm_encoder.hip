@@ -152,6 +152,12 @@ struct tm_encoder {
   DevBuf qf_pre;
   int qf_f0 = -1, qf_nf = 0, qf_epu = -1;
   bool qf_valid = false;
+  // Reduce's exact grouping of the frame tiles (motion prediction off, one process): group of every tile-map item and the first item of
+  // every group.  Items of one group have the same pixels, hence the same features and the same nearest database row: Reconstruct
+  // searches once per GROUP (3.2 of 4.3 million on the bench clip) and hands the answer to the group's items.
+  DevBuf q_group, q_rep;
+  int64_t q_groups = 0;
+  bool qf_distinct = false;  // the prefetched features are the groups' (not a frame range's)
   void drop_prefetch() {  // never frees under a running kernel
     if (stream2) (void)hipStreamSynchronize(stream2);
     qf_valid = false;
@@ -307,6 +313,7 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
 
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
   e->drop_prefetch();  // features of the previous frame tiles
+  e->q_groups = 0;
   e->load_sharded = false;
   TM_CHECK(e->nframes > 0 && e->width > 0, TM_E_INVAL, "tm_set_video has not been called");
   TM_CHECK(e->frames != nullptr || e->frames_host != nullptr, TM_E_INVAL, "no frames: call tm_push_frame_rgb32 / tm_set_frames_device / tm_set_frames_host first");
@@ -514,6 +521,8 @@ static int step_reduce(tm_encoder *e) {
   TM_TRY(need(e, TM_STEP_LOAD, "Load"));
   TM_TRY(need_frame_tiles(e, "Reduce"));
   e->gtiles_have_rgb = true;
+  e->q_groups = 0;
+  e->drop_prefetch();
   if (e->has_pm) return step_reduce_motion(e);
   if (e->load_sharded) {
     // One process per GPU: exact dedup of this process's own frame tiles first, then of the union of every process's distinct
@@ -582,6 +591,11 @@ static int step_reduce(tm_encoder *e) {
   hipLaunchKernelGGL(k_clip_index, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, (int32_t)e->t);
   TM_HIP(hipGetLastError());
   TM_HIP(hipStreamSynchronize(e->stream));
+  if (!getenv("TM_NO_QUERY_GROUPS")) {  // kept for Reconstruct: one search per distinct frame tile
+    e->q_group = std::move(remap);
+    e->q_rep = std::move(order);
+    e->q_groups = nu;
+  }
   e->has_pal_px = e->reconstructed = false;
   progress(e, TM_STEP_REDUCE, 2, 2);
   return TM_OK;
@@ -593,6 +607,11 @@ static int recon_chunk_frames(const tm_encoder *e, int sn, bool epu) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::max(sn, 1), budget / (per * 384)));
 }
 
+// may Reconstruct search once per distinct frame tile?  (the k = 1 search of the whole clip in one process, rows within one chunk)
+static bool query_groups_usable(const tm_encoder *e, int sf, int sn, bool epu) {
+  return e->q_groups > 0 && !epu && !e->dist() && sf == 0 && sn == e->nframes && e->q_groups * 384 <= ((int64_t)8 << 30);
+}
+
 static int prefetch_query_features(tm_encoder *e) {
   if (getenv("TM_NO_PREFETCH")) return TM_OK;
   const int sf = std::max(0, std::min(e->shard_first, e->nframes));
@@ -602,17 +621,22 @@ static int prefetch_query_features(tm_encoder *e) {
   const int nf = std::min(recon_chunk_frames(e, sn, epu), sn);
   const int64_t per = e->tm_size();
   e->drop_prefetch();
+  const bool distinct = query_groups_usable(e, sf, sn, epu);
   if (!e->stream2) {  // lowest priority: the small dependent kernels of PreparePalettes must not queue behind this one's workgroups
     int lo = 0, hi = 0;
     TM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     TM_HIP(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo));
   }
   if (!e->ev_qf) TM_HIP(hipEventCreateWithFlags(&e->ev_qf, hipEventDisableTiming));
-  TM_TRY(e->qf_pre.alloc((size_t)nf * per * 384));
+  TM_TRY(e->qf_pre.alloc((size_t)(distinct ? e->q_groups : (int64_t)nf * per) * 384));
   TM_HIP(hipStreamSynchronize(e->stream));  // the pool handed out memory that work on the main stream may just have released
-  TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + (int64_t)sf * per * 256, (int64_t)nf * per, nullptr, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2));
+  if (distinct)
+    TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, e->q_groups, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2));
+  else
+    TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + (int64_t)sf * per * 256, (int64_t)nf * per, nullptr, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2));
   TM_HIP(hipEventRecord(e->ev_qf, e->stream2));
   e->qf_f0 = sf; e->qf_nf = nf; e->qf_epu = epu ? 1 : 0;
+  e->qf_distinct = distinct;
   e->qf_valid = true;
   return TM_OK;
 }
@@ -620,7 +644,7 @@ static int prefetch_query_features(tm_encoder *e) {
 // the chunk [f0, f0 + nf) of query features: the prefetched buffer when it is that chunk (the main stream then waits for it), else computed now
 static int query_features(tm_encoder *e, int f0, int nf, bool epu, DevBuf &qf, void **out) {
   const int64_t per = e->tm_size();
-  if (e->qf_valid && e->qf_f0 == f0 && e->qf_nf == nf && e->qf_epu == (epu ? 1 : 0)) {
+  if (e->qf_valid && !e->qf_distinct && e->qf_f0 == f0 && e->qf_nf == nf && e->qf_epu == (epu ? 1 : 0)) {
     TM_HIP(hipStreamWaitEvent(e->stream, e->ev_qf, 0));
     *out = e->qf_pre.p;
     return TM_OK;
@@ -809,9 +833,34 @@ static int step_reconstruct(tm_encoder *e) {
   tm_knn_index_impl *ix = nullptr;
   TM_TRY(knn_index_create(udb.p, nu, e->stream, &ix));
   progress(e, TM_STEP_RECONSTRUCT, 1, 2);
+  int rc = TM_OK;
+  if (query_groups_usable(e, sf, sn, false)) {
+    // one query per DISTINCT frame tile (Reduce's groups); the items of a group take its answer
+    const int64_t ng = e->q_groups;
+    DevBuf gt, ge;
+    TM_TRY(gt.alloc((size_t)ng * 4)); TM_TRY(ge.alloc((size_t)ng * 4));
+    void *qfp = nullptr;
+    if (e->qf_valid && e->qf_distinct) {
+      TM_HIP(hipStreamWaitEvent(e->stream, e->ev_qf, 0));
+      qfp = e->qf_pre.p;
+    } else {
+      TM_TRY(qf.alloc((size_t)ng * 384));
+      qfp = qf.p;
+      TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, ng, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
+    }
+    rc = knn_index_search(ix, qfp, ng, gt.p, ge.p, e->stream);
+    if (rc == TM_OK) {
+      double ms = 0; int kb = 0; int64_t pairs = 0;
+      knn_index_stats(ix, &ms, &kb, &pairs);
+      e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
+      hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, gt.as<int32_t>(), e->tm_tile.as<int32_t>());
+      hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, ge.as<int32_t>(), e->tm_err.as<int32_t>());
+      TM_HIP(hipGetLastError());
+      TM_HIP(hipStreamSynchronize(e->stream));  // gt / ge die with this scope
+    }
+  } else {
   // query features in frame chunks (bounded scratch for long / 4K clips: streaming through HBM)
   const int chunk_frames = recon_chunk_frames(e, sn, false);
-  int rc = TM_OK;
   for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
     const int nf = std::min(chunk_frames, sf + sn - f0);
     const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
@@ -823,6 +872,7 @@ static int step_reconstruct(tm_encoder *e) {
       knn_index_stats(ix, &ms, &kb, &pairs);
       e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
     }
+  }
   }
   knn_index_destroy(ix);
   TM_TRY(rc);

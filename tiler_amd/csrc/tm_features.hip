@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         const int64_t wy = t / ww, wx = t - wy * ww;
         col = tiles[(wy + y) * pal_size + wx + x];  // CopyRGBPixels(ABackBuffer, x, AIndex), 879-887
       } else {
-        col = tiles[t * 64 + src];
+        col = tiles[(pal_idx ? (int64_t)pal_idx[t] : t) * 64 + src];  // (SRC 0 with a row list: row t of the output is tile pal_idx[t])
       }
       float yy, uu, vv;
       if (use_lab && SRC != 3 && SRC != 4)
@@ -314,6 +314,19 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+// the same for a list of rows: output row i = features of tile rows[i] (Reconstruct's queries are the DISTINCT frame tiles)
+int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
+                     (const int32_t *)rows, nullptr, 0, (const uint8_t *)nullptr, n, mode_weighted(mode) ? 1 : 0, use_lab,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
   TM_HIP(hipGetLastError());
   return TM_OK;

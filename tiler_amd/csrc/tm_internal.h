@@ -13,6 +13,7 @@ int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w,
                 void *lab_means, hipStream_t stream);
 int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream);
 int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out, hipStream_t stream);
+int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream);
 int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
