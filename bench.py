@@ -284,7 +284,8 @@ def main():
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
                                f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else ""),
                    "frames": F, "tiles_per_frame": per, "query_tiles": q_total, "global_tiles_T": T,
-                   "distinct_database_rows": int(ks["db_rows"]), "final_tiles_after_reindex": int(c["tiles"]),
+                   "distinct_database_rows": int(ks["db_rows"]), "knn_queries": int(ks.get("queries", q_total)),
+                   "final_tiles_after_reindex": int(c["tiles"]),
                    "input": "RGB frames resident in HBM when the timed region starts (with_h2d: in page-locked host memory)",
                    "parallelism": distributed.describe(world)},
         "collectives_per_step": _collective_counts(enc, args.steps + args.warmup) if world > 1 else None,
@@ -373,7 +374,7 @@ def main():
                                  "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
                                  "mfma_pipe_frac_of_measured_peak": (dense * (2 * kd["k_bytes"] / 384.0) / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
                                  "launch_ms": kd["kernel_ms"] / max(kd["launches"], 1), "pairs_per_launch": kd["pairs"] / max(kd["launches"], 1),
-                                 "pairs_expected": float(q_total) * float(kd["db_rows"]),
+                                 "pairs_expected": float(kd.get("queries", q_total)) * float(kd["db_rows"]),
                                  "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated; parity-tested in tests/test_gpu_parity.py::test_knn_dense_mode*"}
     psnr = enc.PSNR() if hasattr(enc, "PSNR") else None
     if psnr:

@@ -174,6 +174,7 @@ struct tm_encoder {
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
   int64_t knn_db_rows = 0;  // distinct database rows actually searched
+  int64_t knn_queries = 0;  // queries of the last Reconstruct's k = 1 searches (distinct frame tiles when Reduce's groups are used)
   int steps_done = 0;  // bit per step
 
   int64_t tm_size() const { return (int64_t)tm_w * tm_h; }
@@ -768,7 +769,7 @@ static int step_reconstruct(tm_encoder *e) {
     TM_HIP(hipMemsetAsync(e->tm_err.p, 0, (size_t)e->q * 4, e->stream));
     TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
   }
-  e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0;
+  e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0; e->knn_queries = 0;
   const bool epu = e->s.FrameTilingExtendedPaletteUsage;
   if (epu) {
     // FrameTilingExtendedPaletteUsage (1559-1610): the 64 nearest rows of the whole database (duplicates included, as
@@ -849,6 +850,7 @@ static int step_reconstruct(tm_encoder *e) {
       TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, ng, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
     }
     rc = knn_index_search(ix, qfp, ng, gt.p, ge.p, e->stream);
+    e->knn_queries += ng;
     if (rc == TM_OK) {
       double ms = 0; int kb = 0; int64_t pairs = 0;
       knn_index_stats(ix, &ms, &kb, &pairs);
@@ -867,6 +869,7 @@ static int step_reconstruct(tm_encoder *e) {
     void *qfp = nullptr;
     rc = query_features(e, f0, nf, false, qf, &qfp);
     if (rc == TM_OK) rc = knn_index_search(ix, qfp, n, e->tm_tile.as<int32_t>() + off, e->tm_err.as<uint32_t>() + off, e->stream);
+    e->knn_queries += n;
     if (rc == TM_OK) {
       double ms = 0; int kb = 0; int64_t pairs = 0;
       knn_index_stats(ix, &ms, &kb, &pairs);
@@ -1540,6 +1543,8 @@ int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx :
   TM_HIP(hipStreamSynchronize(e->stream));
   return TM_OK;
 }
+
+int64_t tm_get_knn_queries(tm_encoder *e) { return e ? e->knn_queries : 0; }
 
 int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows) {
   if (e && db_rows) *db_rows = e->knn_db_rows;

@@ -288,4 +288,7 @@ class TilingEncoder:
         ms, pairs, launches, kb, rows = c_double(), c_int64(), c_int(), c_int(), c_int64()
         check(self._L.tm_get_knn_stats(c_void_p(self._h), ctypes.byref(ms), ctypes.byref(pairs), ctypes.byref(launches), ctypes.byref(kb),
                                        ctypes.byref(rows)))
-        return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value, db_rows=rows.value)
+        self._L.tm_get_knn_queries.restype = c_int64
+        self._L.tm_get_knn_queries.argtypes = [c_void_p]
+        return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value, db_rows=rows.value,
+                    queries=int(self._L.tm_get_knn_queries(c_void_p(self._h))))
