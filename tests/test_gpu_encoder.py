@@ -201,6 +201,24 @@ def test_extended_palette_usage_scan_matches_brute_force():
     assert moved.any()
 
 
+@pytest.mark.parametrize("epu", [False, True])
+def test_distinct_query_groups_equal_per_item_queries(monkeypatch, epu):
+    """Reconstruct searches once per DISTINCT frame tile (Reduce's exact groups) and expands the answers; with TM_NO_QUERY_GROUPS it
+    searches every item: same tile maps and tiles, fewer queries"""
+    from tiler_amd import synth
+    frames = synth.video(12, 320, 176, cut=6)
+    outs = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("TM_NO_QUERY_GROUPS", "1")
+        enc = _run_encoder(frames, PaletteCount=8, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0, FrameTilingExtendedPaletteUsage=epu)
+        outs.append((np.stack([enc.TileMap(f) for f in range(12)]), enc.Tiles()[1], enc.KnnStats()["queries"]))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[1][2] == 12 * 40 * 22
+    assert 0 < outs[0][2] < outs[1][2]
+
+
 @pytest.mark.parametrize("radius", [0, 8])
 def test_reload_gtm_round_trip(oracle, tmp_path, radius):
     """Save -> ReloadGTM into a fresh encoder (LoadStream, tilingencoder.pas:4880): palettes, tile pixels, tile maps and key

@@ -174,7 +174,7 @@ struct tm_encoder {
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
   int64_t knn_db_rows = 0;  // distinct database rows actually searched
-  int64_t knn_queries = 0;  // queries of the last Reconstruct's k = 1 searches (distinct frame tiles when Reduce's groups are used)
+  int64_t knn_queries = 0;  // queries of the last Reconstruct's searches (distinct frame tiles when Reduce's groups are used)
   int steps_done = 0;  // bit per step
 
   int64_t tm_size() const { return (int64_t)tm_w * tm_h; }
@@ -610,7 +610,8 @@ static int recon_chunk_frames(const tm_encoder *e, int sn, bool epu) {
 
 // may Reconstruct search once per distinct frame tile?  (the k = 1 search of the whole clip in one process, rows within one chunk)
 static bool query_groups_usable(const tm_encoder *e, int sf, int sn, bool epu) {
-  return e->q_groups > 0 && !epu && !e->dist() && sf == 0 && sn == e->nframes && e->q_groups * 384 <= ((int64_t)8 << 30);
+  // (the extended-palette search keeps 64 candidates per query: 512 more bytes a row)
+  return e->q_groups > 0 && !e->dist() && sf == 0 && sn == e->nframes && e->q_groups * (epu ? 384 + 512 : 384) <= ((int64_t)8 << 30);
 }
 
 static int prefetch_query_features(tm_encoder *e) {
@@ -787,8 +788,9 @@ static int step_reconstruct(tm_encoder *e) {
     }
     progress(e, TM_STEP_RECONSTRUCT, 1, 2);
     const int chunk_frames = recon_chunk_frames(e, sn, true);
-    TM_TRY(idx64.alloc((size_t)chunk_frames * per * 64 * 4));
-    TM_TRY(err64.alloc((size_t)chunk_frames * per * 64 * 4));
+    const bool groups = query_groups_usable(e, sf, sn, true);
+    TM_TRY(idx64.alloc((size_t)(groups ? e->q_groups : chunk_frames * per) * 64 * 4));
+    TM_TRY(err64.alloc((size_t)(groups ? e->q_groups : chunk_frames * per) * 64 * 4));
     // the scan runs over the DISTINCT rows; every result is expanded to all its duplicates (they count, as
     // ann_kdtree_short_search_multi sees them) from member lists
     DevBuf d_remap, d_order, d_use, ddb, g_off, g_members;
@@ -804,11 +806,41 @@ static int step_reconstruct(tm_encoder *e) {
     tm_knn_index_impl *ix = nullptr;
     TM_TRY(knn_index_create(ddb.p, nd, e->stream, &ix));
     int rc = TM_OK;
+    if (groups) {
+      // one query per DISTINCT frame tile (Reduce's groups): the 64 candidates and the re-rank are functions of the query's features alone
+      const int64_t ng = e->q_groups;
+      DevBuf gt, gp, ge;
+      TM_TRY(gt.alloc((size_t)ng * 4)); TM_TRY(gp.alloc((size_t)ng * 4)); TM_TRY(ge.alloc((size_t)ng * 4));
+      void *qfp = nullptr;
+      if (e->qf_valid && e->qf_distinct) {
+        TM_HIP(hipStreamWaitEvent(e->stream, e->ev_qf, 0));
+        qfp = e->qf_pre.p;
+      } else {
+        TM_TRY(qf.alloc((size_t)ng * 384));
+        qfp = qf.p;
+        TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, ng, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
+      }
+      e->knn_queries += ng;
+      rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qfp, ng, db.p, e->t, 64, idx64.p, err64.p, e->stream)
+                                   : knn_index_search_topk(ix, qfp, ng, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
+      if (rc == TM_OK)
+        rc = use_table ? launch_epu_rerank(qfp, ng, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, gt.as<int32_t>(), gp.as<int32_t>(), ge.as<uint32_t>(), e->stream)
+                       : launch_epu_rerank_ondemand(qfp, ng, idx64.p, 64, e->gpal_idx.p, e->t, e->gpal_px.p, e->palettes_dev.p, npal, e->s.PaletteSize,
+                                                    gt.as<int32_t>(), gp.as<int32_t>(), ge.as<uint32_t>(), e->stream);
+      if (rc == TM_OK) {
+        hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, gt.as<int32_t>(), e->tm_tile.as<int32_t>());
+        hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, gp.as<int32_t>(), e->tm_pal.as<int32_t>());
+        hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, ge.as<int32_t>(), e->tm_err.as<int32_t>());
+        TM_HIP(hipGetLastError());
+        TM_HIP(hipStreamSynchronize(e->stream));  // gt / gp / ge die with this scope
+      }
+    } else
     for (int f0 = sf; rc == TM_OK && f0 < sf + sn; f0 += chunk_frames) {
       const int nf = std::min(chunk_frames, sf + sn - f0);
       const int64_t n = (int64_t)nf * per, off = (int64_t)f0 * per;
       void *qfp = nullptr;
       rc = query_features(e, f0, nf, true, qf, &qfp);
+      e->knn_queries += n;
       if (rc == TM_OK)
         rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qfp, n, db.p, e->t, 64, idx64.p, err64.p, e->stream)  // debugging aid: VALU brute force over all rows
                                      : knn_index_search_topk(ix, qfp, n, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
