@@ -316,6 +316,30 @@ def test_dither_palette_sizes(tiles_flags, oracle, pal_size):
     assert np.array_equal(got, exp)
 
 
+def test_dither_thomas_knoll_at_the_error_bound(oracle):
+    """palettes that cannot reach the pixels (dark colours for white tiles, bright ones for black tiles, one channel only): the fed-back
+    error grows by up to 255 a step, to the bound the counting kernel's int32 comparison is sized for (|t| <= 1700 per channel)"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(3)
+    tiles = np.empty((96, 64), np.int32)
+    tiles[:24] = 0xFFFFFF
+    tiles[24:48] = 0
+    tiles[48:72] = rng.choice(np.array([0, 0xFFFFFF, 0xFF, 0xFF00, 0xFF0000, 0xFFFF], np.int32), size=(24, 64))
+    tiles[72:] = rng.integers(0, 1 << 24, size=(24, 64), dtype=np.int32)
+    flags = rng.integers(0, 4, size=96, dtype=np.uint8)
+    palettes = np.empty((6, 16), np.int32)
+    palettes[0] = np.arange(16) * 0x010101  # 16 greys 0..15
+    palettes[1] = 0xFFFFFF - np.arange(16) * 0x010101  # 16 greys 240..255
+    palettes[2] = np.arange(16)  # reds 0..15 only
+    palettes[3] = (255 - np.arange(16)) << 16  # blues 240..255 only
+    palettes[4] = [0, 0xFFFFFF] + [-65281] * 14  # two colours
+    palettes[5] = [0x000001] + [-65281] * 15  # one colour
+    pal_idx = (np.arange(96) % 6).astype(np.int32)
+    exp = oracle.dither(tiles, flags, pal_idx, palettes, True)
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("path", ["hash", "hash-collisions", "plain"])
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
 def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):

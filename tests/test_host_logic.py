@@ -137,3 +137,18 @@ def test_solve_tile_count_follows_golden_section(oracle):
                 mx = x
         x, probes = oracle.solve_tile_count(mins, target)
         assert probes == n and abs(x - last) < 1e-12
+
+
+def test_dither_kernel_arithmetic_shortcuts():
+    """the counting Thomas-Knoll kernel (tm_dither.hip) replaces two integer divisions by float arithmetic; both are exact over
+    the whole range the kernel can meet, checked value by value here"""
+    import numpy as np
+    e = np.arange(-16400, 16401, dtype=np.int64)  # fed-back error, |e| <= 64 * 255
+    ref = np.sign(e) * ((np.abs(e) * 9) // 100)  # Pascal div truncates toward zero (tilingencoder.pas:2589)
+    got = np.trunc(e.astype(np.float32) * np.float32(0.09)).astype(np.int64)
+    assert np.array_equal(ref, got)
+    a = np.arange(0, 1 << 22, dtype=np.int64)  # |luma difference| before the div 1000 of ColorCompare (2323-2337)
+    got = np.trunc(a.astype(np.float32) * np.float32(0.001) + np.float32(0.0005))  # numpy rounds the product, the kernel fuses: see below
+    fused = np.trunc((a.astype(np.float64) * np.float64(np.float32(0.001)) + np.float64(np.float32(0.0005))).astype(np.float32))
+    assert np.array_equal(fused.astype(np.int64), a // 1000)
+    assert np.array_equal(got.astype(np.int64), a // 1000)

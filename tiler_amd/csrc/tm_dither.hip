@@ -17,10 +17,11 @@
 namespace tmx {
 
 __device__ __forceinline__ int div_trunc_1000(int v) { return v / 1000; }  // Pascal div: toward zero, like C
-// full-rate 24-bit multiplies (32-bit v_mul_lo_u32 is quarter rate); callers guarantee |operands| < 2^23
-typedef short s16x2 __attribute__((ext_vector_type(2)));
+// full-rate 24-bit multiplies (32-bit v_mul_lo_u32 is quarter rate); callers guarantee |operands| < 2^23.  Inline assembly because the
+// compiler re-associates __mul24(a, b) + c chains into separate multiplies and three-operand adds (and 32-bit multiplies for squares)
 __device__ __forceinline__ int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int mad24(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int mad24s(int a, int b, int c) { int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); return r; }  // b wave-uniform
 
 // QuickSort(List[0], 0, last, 1, PlanCompareLuma) of extern.pas:370-418 on one lane's list, iterative form: explicit
 // stack for the "recurse left, loop right" shape; the pivot VALUE is constant during a partition pass because the
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
 // ---------------------------------------------------------------------------------------------------------------
 // Fast Thomas-Knoll path for the common palette shape: 1..16 live colours whose lumas are pairwise distinct.
 //  * The plan is wave-uniform, so it lives in SGPRs (16 x r,g,b,luma) and the 16-way search is fully unrolled; the
-//    argmin is one v_min_u32 per entry on (penalty << 4 | index): penalties stay below 2^28 (|t - p| <= 1723 per
-//    channel because |e| <= 64*255), and the lowest index wins equal penalties exactly like the reference's strict
-//    `<` scan in plan order (2597-2605).
+//    argmin is one v_min_i32 per entry on (16 penalty + index) - 208 |t|^2: the lowest index wins equal penalties exactly like
+//    the reference's strict `<` scan in plan order (2597-2605), and the term common to all entries never has to be computed:
+//    13 |t - p|^2 - 13 |t|^2 = 13 |p|^2 - 26 t.p is three multiply-adds with per-entry constants.  Range: the error entering
+//    step k is at most 63*255 in magnitude, so t is in [-1445, 1700] per channel, 208 |t|^2 <= 1.81e9, and
+//    208 (|p|^2 - 2 t.p) + 512 ld^2 + 15 <= 5.0e8 + 1.48e9: every value compared fits int32.
 //  * With distinct lumas the unstable QuickSort of the 64 picks (2611) has only one possible outcome -- picks ordered
 //    by luma, equal picks being the same byte -- so the lane does not sort: it counts its picks per luma rank and
 //    reads position cDitheringMap[..] of the sorted list off the running totals.
@@ -164,9 +167,11 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
   __shared__ int s_luma[16];
   __shared__ uint8_t s_remap[16];  // plan index -> palette slot
   __shared__ uint8_t s_by_rank[16];  // luma rank -> plan index
+  __shared__ uint4 s_inc[16];        // plan index -> 1 in byte (luma rank) of 128 bits
   const int lane = threadIdx.x;
   const int map_value = dither_map[lane];
-  int prg[16], pb[16], pl[16];  // prg: red | green << 16 (two int16), for the packed subtraction
+  int pr[16], pg[16], pb[16], pk[16];  // -416 r, -416 g, -416 b (wave-uniform: scalar registers), 208 (r^2 + g^2 + b^2) + i
+  float pl[16];                         // luma
   int cached_pal = -1;
   for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
     const int pi = pal_idx[t];
@@ -192,15 +197,19 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
         for (int i = 0; i < cnt; i++) rk += (s_luma[i] < my) ? 1 : 0;
         s_plan[lane].w = rk;
         s_by_rank[rk] = (uint8_t)lane;
+        const uint32_t one = 1u << ((rk & 3) * 8);
+        s_inc[lane] = make_uint4((rk >> 2) == 0 ? one : 0u, (rk >> 2) == 1 ? one : 0u, (rk >> 2) == 2 ? one : 0u, (rk >> 2) == 3 ? one : 0u);
       }
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 16; i++) {  // entries past the live count repeat entry 0: same penalty, higher index, never chosen
         const int j = i < cnt ? i : 0;
         const int4 p = s_plan[j];
-        prg[i] = __builtin_amdgcn_readfirstlane(p.x | (p.y << 16));
-        pb[i] = __builtin_amdgcn_readfirstlane(p.z);
-        pl[i] = __builtin_amdgcn_readfirstlane(s_luma[j]);
+        pr[i] = __builtin_amdgcn_readfirstlane(-416 * p.x);
+        pg[i] = __builtin_amdgcn_readfirstlane(-416 * p.y);
+        pb[i] = __builtin_amdgcn_readfirstlane(-416 * p.z);
+        pk[i] = 208 * (p.x * p.x + p.y * p.y + p.z * p.z) + i;
+        pl[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s_luma[j])));
       }
       cached_pal = pi;
     }
@@ -210,40 +219,35 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
     const uint32_t c = tiles[t * 64 + src];
     const int s0 = c & 0xff, s1 = (c >> 8) & 0xff, s2 = (c >> 16) & 0xff;
     int e0 = 0, e1 = 0, e2 = 0;
-    unsigned long long bins_lo = 0, bins_hi = 0;  // 8 bits per luma rank: how many of the 64 picks have that rank
+    uint32_t bins0 = 0, bins1 = 0, bins2 = 0, bins3 = 0;  // 8 bits per luma rank: how many of the 64 picks have that rank (at most 64: no carry)
     for (int k = 0; k < 64; k++) {
-      const int t0 = s0 + (e0 * 9) / 100, t1 = s1 + (e1 * 9) / 100, t2 = s2 + (e2 * 9) / 100;
-      const int lt = t0 * 299 + t1 * 587 + t2 * 114;
-      const s16x2 t01 = __builtin_bit_cast(s16x2, (uint32_t)(t0 & 0xffff) | ((uint32_t)t1 << 16));
-      uint32_t best = 0xffffffffu;
-      const uint32_t ltb = (uint32_t)(lt + (1 << 21));  // |lt| <= 1 723 000: biased so that v_sad_u32 gives |lt - luma|
+      // (e * 9) div 100 = trunc(float(e) * 0.09f) for |e| <= 16 400 (every value checked, tests/test_host_logic.py): three full-rate
+      // instructions instead of a quarter-rate v_mul_hi and its fix-ups
+      const int t0 = s0 + (int)((float)e0 * 0.09f), t1 = s1 + (int)((float)e1 * 0.09f), t2 = s2 + (int)((float)e2 * 0.09f);
+      const int lt = mad24(t2, 114, mad24(t1, 587, mul24(t0, 299)));
+      const float ltf = (float)lt;  // |lt| < 2^21: exact, and so is its difference with a luma
+      int best = INT_MAX;
 #pragma unroll
       for (int i = 0; i < 16; i++) {
-        // all factors fit 24 bits (|t - p| <= 1723, sum of squares <= 8.9e6, |luma difference| / 1000 <= 1978): full-rate
-        // v_mad_i32_i24 instead of quarter-rate 32-bit multiplies
-        // red and green differences as one packed int16 subtraction, their squares and the blue one summed by one dot2 (|t - p| <= 1723)
-        const s16x2 drg = t01 - __builtin_bit_cast(s16x2, prg[i]);
-        const int db = t2 - pb[i];
-        const int ssd = __builtin_amdgcn_sdot2(drg, drg, mul24(db, db), false);
+        // 16 * 13 (|p|^2 - 2 t.p) + i: all factors fit 24 bits (|t| <= 1700, 416 p <= 106 080): full-rate v_mad_i32_i24 instead of
+        // quarter-rate 32-bit multiplies
+        const int x = mad24s(t2, pb[i], mad24s(t1, pg[i], mad24s(t0, pr[i], pk[i])));
         // |(lt - luma) div 1000| = floor(|lt - luma| / 1000): exact as trunc(fma(a, 0.001f, 0.0005f)) for a < 2^22 (both ends
-        // of every thousand checked in exact arithmetic, monotone in between); only its square is used
-        uint32_t a;
-        asm("v_sad_u32 %0, %1, %2, 0" : "=v"(a) : "v"(ltb), "s"((uint32_t)(pl[i] + (1 << 21))));
-        const int ld = (int)__builtin_fmaf((float)a, 0.001f, 0.0005f);
-        // (13 ssd + 32 ld^2) << 4 | i as two multiply-adds: 208 ssd + i, then + 512 ld^2 (ssd < 2^24, ld^2 < 2^22: 24-bit factors)
-        best = min(best, (uint32_t)mad24(mul24(ld, ld), 512, mad24(ssd, 208, i)));
+        // of every thousand checked in exact arithmetic, monotone in between); only its square is used (|.| is a source modifier)
+        const int ld = (int)__builtin_fmaf(__builtin_fabsf(ltf - pl[i]), 0.001f, 0.0005f);
+        best = min(best, mad24(mul24(ld, ld), 512, x));  // + 16 * 32 ld^2 (ld^2 < 2^22)
       }
       const int4 p = s_plan[best & 15u];
       e0 += s0 - p.x; e1 += s1 - p.y; e2 += s2 - p.z;
-      const unsigned long long one = 1ull << ((p.w & 7) * 8);
-      bins_lo += p.w < 8 ? one : 0ull;
-      bins_hi += p.w < 8 ? 0ull : one;
+      const uint4 inc = s_inc[best & 15];
+      bins0 += inc.x; bins1 += inc.y; bins2 += inc.z; bins3 += inc.w;
     }
     int acc = 0, pick_rank = 0;
     bool found = false;
 #pragma unroll
     for (int r = 0; r < 16; r++) {  // position map_value of the luma-sorted list
-      acc += (int)(((r < 8 ? bins_lo : bins_hi) >> ((r & 7) * 8)) & 0xff);
+      const uint32_t w = (r >> 2) == 0 ? bins0 : (r >> 2) == 1 ? bins1 : (r >> 2) == 2 ? bins2 : bins3;
+      acc += (int)((w >> ((r & 3) * 8)) & 0xff);
       if (!found && acc > map_value) { pick_rank = r; found = true; }
     }
     out[t * 64 + src] = s_remap[s_by_rank[pick_rank]];  // re-mirror (2721-2722)
