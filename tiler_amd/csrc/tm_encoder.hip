@@ -148,6 +148,7 @@ struct tm_encoder {
   // Launched when PreparePalettes hands over to the host (OptimizePalettes' 2-5 ms search, then Dither's start), the one stretch where
   // the GPU idles; launched earlier they only trade time with the k-means kernels (measured: +3.8 ms there for -3.7 ms here).
   hipStream_t stream2 = nullptr;
+  hipStream_t stream_km = nullptr;  // TM_CU_SPLIT experiment: the tile k-means on its own compute units, stream2 on the others
   hipEvent_t ev_qf = nullptr;
   DevBuf qf_pre;
   int qf_f0 = -1, qf_nf = 0, qf_epu = -1;
@@ -167,6 +168,7 @@ struct tm_encoder {
     drop_prefetch();
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
+    if (stream_km) (void)hipStreamDestroy(stream_km);
     for (hipEvent_t ev : copy_events) (void)hipEventDestroy(ev);
     if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
   }
@@ -624,6 +626,13 @@ static int prefetch_query_features(tm_encoder *e) {
   const int64_t per = e->tm_size();
   e->drop_prefetch();
   const bool distinct = query_groups_usable(e, sf, sn, epu);
+  const int split = getenv("TM_CU_SPLIT") ? atoi(getenv("TM_CU_SPLIT")) : 0;
+  if (!e->stream2 && split > 0) {
+    uint32_t a[8] = {0}, b[8] = {0};
+    for (int i = 0; i < 256; i++) (i < split ? a : b)[i >> 5] |= 1u << (i & 31);
+    TM_HIP(hipExtStreamCreateWithCUMask(&e->stream_km, 8, a));
+    TM_HIP(hipExtStreamCreateWithCUMask(&e->stream2, 8, b));
+  }
   if (!e->stream2) {  // lowest priority: the small dependent kernels of PreparePalettes must not queue behind this one's workgroups
     int lo = 0, hi = 0;
     TM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -699,6 +708,12 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
   TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
   lap("cluster features");
+  if (getenv("TM_CU_SPLIT")) {
+    TM_HIP(hipStreamSynchronize(e->stream));
+    TM_TRY(prefetch_query_features(e));
+    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream_km));
+    TM_HIP(hipStreamSynchronize(e->stream_km));
+  } else
   TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
@@ -709,6 +724,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
+  if (!getenv("TM_CU_SPLIT"))
   TM_TRY(prefetch_query_features(e));  // the GPU has nothing to do while the host searches: Reconstruct's query features run now
   lap("prefetch launch");
   // OptimizePalettes (4309-4432): slot permutation by Powell on the host (P x PaletteSize colours)

@@ -762,6 +762,130 @@ __global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict
   }
 }
 
+// The same, a point spread over 4 lanes (each lane scores 4 of the 16 centroids of a pass): the thread-per-point shape leaves a lone wave per
+// SIMD with 6 144 dependent-ish double-precision operations and its workgroup's four waves queueing for 24 KB of LDS reads per point; here
+// the chain is a quarter as long and the list covers four times as many compute units.  Every accumulator still sums its 192 terms in
+// order, so the distances are the same doubles; the lanes' (best, second best) merge by (distance, centroid index), which is what the
+// in-order scan with its strict `<` computes.
+__global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
+                                                         const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
+                                                         int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
+                                                         double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
+                                                         const unsigned *__restrict__ need_cnt) {
+  if (*quiet >= 0) return;
+  constexpr int D = 192, NP = 64, CPL = KCH / 4;  // points per workgroup, centroids per lane and pass
+  const unsigned cnt = need ? *need_cnt : (unsigned)n_total, row0 = blockIdx.x * (unsigned)NP;  // no list: every point (the plain iterations)
+  if (row0 >= cnt) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ int s_nmoved;
+  const int kk = segs[0].kk, tid = threadIdx.x, slot = tid >> 2, sub = tid & 3;
+  double *s_c = reinterpret_cast<double *>(s_raw);                    // [D][KCH]
+  u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);       // [kk][D + 1]
+  int32_t *s_moved = reinterpret_cast<int32_t *>(s_delta + kk * (D + 1));  // [NP][3]: slot, old, new
+  const bool active = row0 + slot < cnt;
+  const int64_t gi = need ? need[active ? row0 + slot : row0] : (int64_t)(active ? row0 + slot : row0);
+  for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
+  if (tid == 0) s_nmoved = 0;
+  double bd = 1.0e300, bd2 = 1.0e300;
+  int bc = 0x7fffffff;
+  const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
+  const int64_t chunk_stride = n_total * (A_DCH / 4);  // int4 units between chunks
+#pragma unroll 1
+  for (int c0 = 0; c0 < kk; c0 += KCH) {
+    __syncthreads();
+    for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + c0 + (e % KCH)];
+    __syncthreads();
+    double s[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) s[c] = 0.0;
+    auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
+      const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int j = 0; j < A_DCH; j++) {
+        const double pj = (double)v[j];
+        const double *cj = s_c + (ch * A_DCH + j) * KCH + sub * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; c += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
+          const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
+          s[c] = __fma_rn(t0, t0, s[c]);
+          s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
+        }
+      }
+    };
+    int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
+#pragma unroll 1
+    for (int ch = 0; ch < D / A_DCH; ch += 2) {
+      int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (ch + 2 < D / A_DCH) {
+        na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
+        nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
+      }
+      score_chunk(a0, a1, ch);
+      score_chunk(b0, b1, ch + 1);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int ci = c0 + sub * CPL + c;
+      if (ci < kk) {  // this lane's centroids come in ascending order: strict `<` keeps the lowest index among equals
+        if (s[c] < bd) { bd2 = bd; bd = s[c]; bc = ci; }
+        else if (s[c] < bd2) bd2 = s[c];
+      }
+    }
+  }
+  // the four lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
+#pragma unroll
+  for (int o = 1; o < 4; o <<= 1) {
+    const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
+    const int oc = __shfl_xor(bc, o);
+    const bool take = od < bd || (od == bd && oc < bc);
+    const double loser = take ? bd : od;
+    bd2 = fmin(fmin(bd2, od2), loser);
+    if (take) { bd = od; bc = oc; }
+  }
+  if (active && sub == 0) {
+    ub[gi] = sqrt(bd) * (1.0 + 1e-12);
+    lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
+    const int old = assign[gi];
+    if (old != bc) {
+      assign[gi] = bc;
+      const int m = atomicAdd(&s_nmoved, 1);
+      s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
+    }
+  }
+  __syncthreads();
+  const int nmoved = s_nmoved;
+  if (nmoved == 0) return;
+  if (tid == 0) atomicAdd(&segs[0].changed, nmoved);
+#pragma unroll 2
+  for (int e = tid >> 6; e < nmoved; e += 4) {  // a wave per moved row between the carried sums (coalesced read, three dimensions per lane)
+    const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+    const int64_t mi = need ? need[row0 + s_moved[e * 3]] : (int64_t)(row0 + s_moved[e * 3]);
+    const long long wi = w ? (long long)w[mi] : 1;
+#pragma unroll
+    for (int j = tid & 63; j <= D; j += 64) {
+      const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
+      atomicAdd(&s_delta[nw * (D + 1) + j], v);
+      if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < kk * (D + 1); e += 256) {
+    const u64 v = s_delta[e];
+    if (v == 0) continue;
+    const int c = e / (D + 1), j = e - c * (D + 1);
+    if (j == D) atomicAdd(&cnts[c], v);
+    else atomicAdd(&sums[(int64_t)c * D + j], v);
+  }
+}
+
+// the seeds' centroids into the transposed copy the list kernels read (k_h_update keeps it current afterwards)
+__global__ void k_cent_transpose(const Seg *__restrict__ segs, const double *__restrict__ cent, double *__restrict__ cent_t, int kt) {
+  const int kk = segs[0].kk;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kk * 192; e += gridDim.x * blockDim.x) { const int c = e / 192, j = e - c * 192; cent_t[(int64_t)j * kt + c] = cent[e]; }
+}
+
 // k_update_all for one segment, plus what the bounds need: how far every centroid moved (rounded up) and half its distance to the
 // nearest other centroid (rounded down)
 __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k, u64 *__restrict__ sums, u64 *__restrict__ cnts, double *__restrict__ cent,
@@ -1355,9 +1479,11 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     TM_TRY(hmove.alloc((size_t)(k + 3) * 8)); TM_TRY(hhalf.alloc((size_t)k * 8)); TM_TRY(hneed.alloc((size_t)std::max<int64_t>(n, 1) * 4)); TM_TRY(hcnt.alloc(8));
     TM_HIP(hipMemsetAsync(hcnt.p, 0, 8, stream));
     TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
+    hipLaunchKernelGGL(k_cent_transpose, dim3(12), dim3(256), 0, stream, ds, cent, hcent_t.as<double>(), h_kt);
     if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
     if ((size_t)k * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, k * 192 * 8);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
+    if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
   int it = 0, issued = 0;
   const int poll_every = 16;  // launches after convergence return at once (quiet flag), so polling late costs little
@@ -1368,11 +1494,21 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         const int gb = (int)((n + H_SLICE - 1) / H_SLICE);
         if (issued < h_warm) {
           const bool last_plain = issued == h_warm - 1;
+          static const bool warm_list = getenv("TM_KM_WARM_LIST4") != nullptr;  // A/B aid: the plain iterations through the list kernel, every point listed (measured 0.17 ms per iteration slower: every point moves at first, and the moved rows are its serial part)
+          if (warm_list)
+            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)((n + 63) / 64)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                               cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), (const int32_t *)nullptr, (const unsigned *)nullptr);
+          else
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
         } else {
           hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)k * 192 * 8, stream, pts, n, ds, cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
+          static const bool list1 = getenv("TM_KM_LIST1") != nullptr;  // A/B aid: a thread per point
+          if (!list1)
+            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)((n + 63) / 64)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+                               cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
+          else
           hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
                              cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
         }
@@ -1435,11 +1571,11 @@ int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, in
 // r = floor(x_t * total / 2^64) over the exact integer masses q_i = weight_i * (squared distance of point i to its nearest centre so
 // far) (q_i = weight_i for the first pick) in 128-bit sums, and takes the first point whose running sum exceeds r; a total of 0 (no
 // point apart from the centres) ends the seeding.  The oracle states the same rule (tmo_kmeans_pp_seeds).
-// Per pick: k_pp_mass (distances to the newest centre folded into the running minimum, masses, one 128-bit sum per 1024 points) and
+// Per pick: k_pp_mass (distances to the newest centre folded into the running minimum, masses, one 128-bit sum per 512 points) and
 // k_pp_pick (the block holding r, then the point inside it).
 typedef unsigned __int128 u128;
 constexpr u64 PP_SEED = 0x42381337ull, PP_MUL = 6364136223846793005ull, PP_INC = 1442695040888963407ull;
-constexpr int PP_BLOCK = 1024;  // points per workgroup of k_pp_mass = per partial sum
+constexpr int PP_BLOCK = 512;   // points per workgroup of k_pp_mass = per partial sum
 struct PpState { u64 rng; int kk, done; long long pick; u64 tot_lo, tot_hi; };
 struct PpSum { u64 lo, hi; };
 __device__ __forceinline__ u128 pp_mass(const uint32_t *w, const long long *mind, int64_t i, int first) {
@@ -1448,31 +1584,45 @@ __device__ __forceinline__ u128 pp_mass(const uint32_t *w, const long long *mind
 __device__ __forceinline__ u128 pp_draw(u64 x, u128 total) {  // floor(x * total / 2^64) < total
   return (u128)x * (u64)(total >> 64) + (((u128)x * (u64)total) >> 64);
 }
-__global__ __launch_bounds__(256) void k_pp_mass(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, const int32_t *__restrict__ cur_row,
-                                                 const PpState *__restrict__ st, int first, long long *__restrict__ mind, PpSum *__restrict__ bsum) {
-  __shared__ int32_t s_c[192];
-  __shared__ PpSum s_part[4];
-  const int tid = threadIdx.x;
+// A point over 16 lanes (three 16-byte pieces each: a wave's load covers four whole rows); the squared distance is a sum of integers
+// mod 2^64, so the lanes' partial sums add up to the value the in-order loop gives.  A thread per point, each striding through its own
+// 768-byte row, measured 74 us per launch at 64 k points (192 us with smaller workgroups: every line fetched eight times over).
+constexpr int PP_NT = PP_BLOCK;  // (1024 / 1024 and 256 / 256 measured 0.3 and 0.1 ms per clip slower)
+__global__ __launch_bounds__(PP_NT) void k_pp_mass(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, const int32_t *__restrict__ cur_row,
+                                                   const PpState *__restrict__ st, int first, long long *__restrict__ mind, PpSum *__restrict__ bsum) {
+  __shared__ PpSum s_part[PP_NT / 64];
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
   const bool update = !first && !st->done;
-  if (update)
-    for (int j = tid; j < 192; j += 256) s_c[j] = cur_row[j];
-  __syncthreads();
   u128 mine = 0;
-  for (int m = 0; m < PP_BLOCK / 256; m++) {
-    const int64_t i = (int64_t)blockIdx.x * PP_BLOCK + m * 256 + tid;
-    if (i >= n) break;
-    if (update) {
-      const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
-      long long dd = 0;
-      for (int j = 0; j < 48; j++) {
-        const int4 v = p[j];
-        const long long t0 = (long long)v.x - s_c[4 * j], t1 = (long long)v.y - s_c[4 * j + 1];
-        const long long t2 = (long long)v.z - s_c[4 * j + 2], t3 = (long long)v.w - s_c[4 * j + 3];
-        dd += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+  if (update) {
+    int4 c[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) c[q] = reinterpret_cast<const int4 *>(cur_row)[l + 16 * q];
+#pragma unroll 4
+    for (int m = 0; m < PP_BLOCK / (PP_NT / 16); m++) {
+      const int64_t i = (int64_t)blockIdx.x * PP_BLOCK + m * (PP_NT / 16) + grp;
+      const bool valid = i < n;
+      const int4 *p = reinterpret_cast<const int4 *>(pts + (valid ? i : 0) * 192);
+      u64 dd = 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int4 v = p[l + 16 * q];
+        const long long t0 = (long long)v.x - c[q].x, t1 = (long long)v.y - c[q].y, t2 = (long long)v.z - c[q].z, t3 = (long long)v.w - c[q].w;
+        dd += (u64)(t0 * t0) + (u64)(t1 * t1) + (u64)(t2 * t2) + (u64)(t3 * t3);
       }
-      if (dd < mind[i]) mind[i] = dd;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) dd += __shfl_xor(dd, o);
+      if (valid && l == 0) {
+        long long md = mind[i];
+        if ((long long)dd < md) { md = (long long)dd; mind[i] = md; }
+        mine += (u128)(w ? w[i] : 1u) * (u128)(u64)md;
+      }
     }
-    mine += pp_mass(w, mind, i, first);
+  } else {
+    for (int m = 0; m < PP_BLOCK / PP_NT; m++) {
+      const int64_t i = (int64_t)blockIdx.x * PP_BLOCK + m * PP_NT + tid;
+      if (i < n) mine += pp_mass(w, mind, i, first);
+    }
   }
   u64 lo = (u64)mine, hi = (u64)(mine >> 64);
   for (int o = 32; o > 0; o >>= 1) {
@@ -1484,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_pp_mass(const int32_t *__restrict__ pts
   __syncthreads();
   if (tid == 0) {
     u128 t = 0;
-    for (int wv = 0; wv < 4; wv++) t += ((u128)s_part[wv].hi << 64) | s_part[wv].lo;
+    for (int wv = 0; wv < PP_NT / 64; wv++) t += ((u128)s_part[wv].hi << 64) | s_part[wv].lo;
     bsum[blockIdx.x] = PpSum{(u64)t, (u64)(t >> 64)};
   }
 }
@@ -1559,14 +1709,14 @@ __global__ __launch_bounds__(256) void k_pp_pick(const int32_t *__restrict__ pts
     if (mode == 2 && cand.dist && tid == 0) { *cand.dist = -1; *cand.gidx = 0x7fffffffffffffffll; }
     return;
   }
-  if (blk >= 0) {  // masses of the block's points in index order; thread t sums four of them, thread 0 walks the 256 sums, then four masses
+  if (blk >= 0) {  // masses of the block's points in index order; thread t sums PP_BLOCK / 256 of them, thread 0 walks the 256 sums, then those few masses
     for (int m = 0; m < PP_BLOCK / 256; m++) {
       const int64_t i = blk * PP_BLOCK + m * 256 + tid;
       const u128 q = i < n ? pp_mass(w, mind, i, first) : (u128)0;
       s_q[m][tid] = PpSum{(u64)q, (u64)(q >> 64)};
     }
     __syncthreads();
-    {  // thread t: the sum of entries 4t .. 4t+3 (index order), into s_part
+    {  // thread t: the sum of its PP_BLOCK / 256 consecutive entries (index order), into s_part
       u128 part = 0;
       for (int e = tid * (PP_BLOCK / 256); e < (tid + 1) * (PP_BLOCK / 256); e++) part += ((u128)s_q[e >> 8][e & 255].hi << 64) | s_q[e >> 8][e & 255].lo;
       s_part[tid] = PpSum{(u64)part, (u64)(part >> 64)};
@@ -1640,7 +1790,7 @@ static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std
   h0.rng = PP_SEED;
   TM_HIP(hipMemcpyAsync(state.p, &h0, sizeof(h0), hipMemcpyHostToDevice, stream));
   for (int c = 0; c < k; c++) {
-    hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(256), 0, stream, pts, w, n, cur_row.as<int32_t>(), state.as<PpState>(), c == 0 ? 1 : 0, mind.as<long long>(), bsum.as<PpSum>());
+    hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(PP_NT), 0, stream, pts, w, n, cur_row.as<int32_t>(), state.as<PpState>(), c == 0 ? 1 : 0, mind.as<long long>(), bsum.as<PpSum>());
     hipLaunchKernelGGL(k_pp_pick, dim3(1), dim3(256), 0, stream, pts, w, n, mind.as<long long>(), bsum.as<PpSum>(), nb, c == 0 ? 1 : 0, k, state.as<PpState>(), 0,
                        (const PpSum *)nullptr, 0, 1, 0ll, cur_row.as<int32_t>(), cent.as<double>(), seeds.as<long long>(), FfCandOut{nullptr, nullptr, nullptr});
   }
@@ -1842,7 +1992,7 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
     } else {
       const int first = c == 0 ? 1 : 0;
       if (n > 0)
-        hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(256), 0, stream, pts, w, n, cur_row.as<int32_t>(), ppstate.as<PpState>(), first, mind.as<long long>(), bsum.as<PpSum>());
+        hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(PP_NT), 0, stream, pts, w, n, cur_row.as<int32_t>(), ppstate.as<PpState>(), first, mind.as<long long>(), bsum.as<PpSum>());
       hipLaunchKernelGGL(k_pp_pick, dim3(1), dim3(256), 0, stream, pts, w, n, mind.as<long long>(), bsum.as<PpSum>(), n > 0 ? nb : 0, first, k, ppstate.as<PpState>(), 1,
                          (const PpSum *)nullptr, co.rank, co.world, (long long)global_begin, cur_row.as<int32_t>(), cent.as<double>(), ppseeds.as<long long>(),
                          FfCandOut{nullptr, nullptr, nullptr});
