@@ -340,6 +340,39 @@ def test_dither_thomas_knoll_at_the_error_bound(oracle):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("flavour", ["few-colours", "smooth", "no-duplicates"])
+def test_dither_thomas_knoll_distinct_pairs_path(oracle, flavour):
+    """enough tiles for launch_dither to plan every distinct (palette, colour) pair once and look the pixels up (tm_dither.hip, k_dd_*):
+    few colours (almost everything is a duplicate), smooth gradients (neighbouring B values share bitmap words), and random pixels (no
+    duplicates: the call falls back to the per-pixel kernel).  Palettes: full, short, one with a luma tie (literal-sort kernel, not
+    part of the pairs path), a one-colour palette and one that no tile uses"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(17)
+    n = 3000
+    if flavour == "few-colours":
+        pool = rng.integers(0, 1 << 24, size=40, dtype=np.int32)
+        tiles = pool[rng.integers(0, 40, size=(n, 64))]
+    elif flavour == "smooth":
+        base = rng.integers(0, 200, size=(n, 1, 3))
+        ramp = (np.arange(64) // 8 + np.arange(64) % 8).reshape(1, 64, 1) * rng.integers(0, 4, size=(n, 1, 3))
+        px = np.clip(base + ramp, 0, 255).astype(np.int64)
+        tiles = (px[..., 0] | (px[..., 1] << 8) | (px[..., 2] << 16)).astype(np.int32)
+    else:
+        tiles = rng.integers(0, 1 << 24, size=(n, 64), dtype=np.int32)
+    tiles = tiles | np.int32(rng.integers(0, 128)) << 24  # the top byte is not colour
+    flags = rng.integers(0, 4, size=n, dtype=np.uint8)
+    palettes = rng.integers(0, 1 << 24, size=(6, 16), dtype=np.int32)
+    palettes[1, 6:] = -65281
+    r, g, b = 100, 120, 60  # equal lumas, different colours: 299*15 - 587*9 + 114*7 = 0
+    palettes[2, 0] = (b << 16) | (g << 8) | r
+    palettes[2, 1] = ((b + 7) << 16) | ((g - 9) << 8) | (r + 15)
+    palettes[3, 1:] = -65281
+    pal_idx = rng.choice(np.array([0, 1, 2, 3, 5], np.int32), size=n)
+    exp = oracle.dither(tiles, flags, pal_idx, palettes, True)
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("path", ["hash", "hash-collisions", "plain"])
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
 def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):

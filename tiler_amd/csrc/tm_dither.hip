@@ -11,6 +11,11 @@
 #include <climits>
 #include <cstdlib>
 
+#include <vector>
+
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
 #include "tm_common.h"
 #include "tm_internal.h"
 
@@ -143,6 +148,19 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
 //    by luma, equal picks being the same byte -- so the lane does not sort: it counts its picks per luma rank and
 //    reads position cDitheringMap[..] of the sorted list off the running totals.
 // Palettes with a luma tie between different colours, or more than 16 live colours, take k_dither_tk (literal sort).
+// position map_value of a pixel's 64 picks in luma order, from the counts per luma rank (8 bits each)
+__device__ __forceinline__ int rank_at(const uint4 bins, int map_value) {
+  int acc = 0, pick_rank = 0;
+  bool found = false;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const uint32_t w = (r >> 2) == 0 ? bins.x : (r >> 2) == 1 ? bins.y : (r >> 2) == 2 ? bins.z : bins.w;
+    acc += (int)((w >> ((r & 3) * 8)) & 0xff);
+    if (!found && acc > map_value) { pick_rank = r; found = true; }
+  }
+  return pick_rank;
+}
+
 __global__ void k_palette_class(const int32_t *__restrict__ palettes, int npal, int pal_size, uint8_t *__restrict__ cls) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npal) return;
@@ -159,10 +177,22 @@ __global__ void k_palette_class(const int32_t *__restrict__ palettes, int npal, 
   cls[p] = fast ? 1 : 0;
 }
 
+// UNIQ: the same plan for a list of distinct (palette, colour) pairs instead of tiles -- a pixel's 64 picks depend on its colour and its
+// palette only, the position in the tile just selects one of them -- in chunks of 64 colours of one palette; the counts per luma
+// rank (16 bytes) go to dd.bins, the palette's rank -> slot table to dd.rs, and k_dd_lookup finishes every pixel (see launch_dither).
+struct DdArgs {
+  const uint32_t *ucol;         // [nu] distinct colours, grouped by palette
+  const int32_t *chunk_pal;     // [nchunks]
+  const uint32_t *chunk_begin;  // [nchunks] first colour of the chunk
+  const uint32_t *chunk_end;    // [nchunks] end of the chunk's palette segment
+  uint4 *bins;                  // [nu]
+  uint8_t *rs;                  // [npal][16]
+};
+template <bool UNIQ>
 __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags,
                                                        const int32_t *__restrict__ pal_idx, int64_t n, const int32_t *__restrict__ palettes,
                                                        int npal, int pal_size, const uint8_t *__restrict__ cls,
-                                                       const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out) {
+                                                       const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out, DdArgs dd) {
   __shared__ int4 s_plan[16];      // r, g, b, luma rank
   __shared__ int s_luma[16];
   __shared__ uint8_t s_remap[16];  // plan index -> palette slot
@@ -173,8 +203,8 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
   int pr[16], pg[16], pb[16], pk[16];  // -416 r, -416 g, -416 b (wave-uniform: scalar registers), 208 (r^2 + g^2 + b^2) + i
   float pl[16];                         // luma
   int cached_pal = -1;
-  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
-    const int pi = pal_idx[t];
+  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {  // n: tiles, or chunks of distinct colours
+    const int pi = UNIQ ? dd.chunk_pal[t] : pal_idx[t];
     if (pi < 0 || pi >= npal || !cls[pi]) continue;  // wave-uniform
     if (pi != cached_pal) {  // PreparePlan (2268-2301): drop cDitheringNullColor entries, keep order
       __syncthreads();
@@ -211,12 +241,23 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
         pk[i] = 208 * (p.x * p.x + p.y * p.y + p.z * p.z) + i;
         pl[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)s_luma[j])));
       }
+      if (UNIQ && lane < 16) dd.rs[pi * 16 + lane] = lane < cnt ? s_remap[s_by_rank[lane]] : 0;  // (every chunk of the palette writes the same bytes)
       cached_pal = pi;
     }
-    const int f = flags ? flags[t] : 0;
-    const int y = lane >> 3, x = lane & 7;
-    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // un-mirror (2696-2697)
-    const uint32_t c = tiles[t * 64 + src];
+    int src = 0;
+    uint32_t c = 0;
+    uint32_t u = 0;
+    bool valid = true;
+    if (UNIQ) {
+      u = dd.chunk_begin[t] + lane;
+      valid = u < dd.chunk_end[t];
+      c = valid ? dd.ucol[u] : 0u;
+    } else {
+      const int f = flags ? flags[t] : 0;
+      const int y = lane >> 3, x = lane & 7;
+      src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // un-mirror (2696-2697)
+      c = tiles[t * 64 + src];
+    }
     const int s0 = c & 0xff, s1 = (c >> 8) & 0xff, s2 = (c >> 16) & 0xff;
     int e0 = 0, e1 = 0, e2 = 0;
     uint32_t bins0 = 0, bins1 = 0, bins2 = 0, bins3 = 0;  // 8 bits per luma rank: how many of the 64 picks have that rank (at most 64: no carry)
@@ -242,15 +283,83 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
       const uint4 inc = s_inc[best & 15];
       bins0 += inc.x; bins1 += inc.y; bins2 += inc.z; bins3 += inc.w;
     }
-    int acc = 0, pick_rank = 0;
-    bool found = false;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {  // position map_value of the luma-sorted list
-      const uint32_t w = (r >> 2) == 0 ? bins0 : (r >> 2) == 1 ? bins1 : (r >> 2) == 2 ? bins2 : bins3;
-      acc += (int)((w >> ((r & 3) * 8)) & 0xff);
-      if (!found && acc > map_value) { pick_rank = r; found = true; }
+    if (UNIQ) {
+      if (valid) dd.bins[u] = make_uint4(bins0, bins1, bins2, bins3);
+      continue;
     }
-    out[t * 64 + src] = s_remap[s_by_rank[pick_rank]];  // re-mirror (2721-2722)
+    out[t * 64 + src] = s_remap[s_by_rank[rank_at(make_uint4(bins0, bins1, bins2, bins3), map_value)]];  // re-mirror (2721-2722)
+  }
+}
+
+// ---- duplicate pixels ---------------------------------------------------------------------------------------------------------
+// Video tiles repeat colours: on the bench clip 20.5 M pixels of the global tiles hold 2.3 M distinct (palette, colour) pairs.  The
+// distinct pairs are found without sorting: a bitmap over (palette, G, R) x B, one bit per pair seen (k_dd_mark), a popcount per
+// (palette, G, R) entry and an exclusive scan give every pair its index = scan[entry] + (set bits below B) -- pairs grouped by palette,
+// (G, R, B) ascending inside --, k_dd_expand lists the pairs, k_dither_tk_fast<true> plans each once, k_dd_lookup gives every pixel
+// its pair's counts and reads the position cDitheringMap[..] names off them.  Only palettes of the counting kernel's class take part.
+constexpr int DD_MAX_PAL = 256;  // 2.25 MB of table per palette
+__global__ void k_dd_mark(const uint32_t *__restrict__ tiles, const int32_t *__restrict__ pal_idx, int64_t n, int npal, const uint8_t *__restrict__ cls,
+                          uint32_t *__restrict__ bits) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * 64; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pi = pal_idx[i >> 6];
+    if (pi < 0 || pi >= npal || !cls[pi]) continue;
+    const uint32_t c = tiles[i];
+    const uint32_t e = ((uint32_t)pi << 16) | (c & 0xff00u) | (c & 0xffu), b = (c >> 16) & 0xff;  // entry = palette, G, R
+    const uint32_t m = 1u << (b & 31);
+    uint32_t *w = bits + (size_t)e * 8 + (b >> 5);
+    if (!(*w & m)) atomicOr(w, m);  // (a stale read only repeats the atomic)
+  }
+}
+__global__ void k_dd_count(const uint32_t *__restrict__ bits, int64_t nent, uint32_t *__restrict__ cnt) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= nent; e += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t c = 0;
+    if (e < nent) {
+      const uint4 a = reinterpret_cast<const uint4 *>(bits)[e * 2], b = reinterpret_cast<const uint4 *>(bits)[e * 2 + 1];
+      c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+    }
+    cnt[e] = c;  // one element more than entries: its scan value is the number of pairs
+  }
+}
+__global__ void k_dd_seg(const uint32_t *__restrict__ off, int npal, uint32_t *__restrict__ seg) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p <= npal) seg[p] = off[(size_t)p << 16];
+}
+__global__ void k_dd_expand(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ off, int64_t nent, uint32_t *__restrict__ ucol) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nent; e += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t o = off[e];
+    if (off[e + 1] == o) continue;
+    const uint32_t gr = (uint32_t)(e & 0xffff);  // G << 8 | R: a pixel's low 16 bits
+    for (int j = 0; j < 8; j++) {
+      uint32_t w = bits[e * 8 + j];
+      while (w) {
+        const int b = __ffs(w) - 1;
+        w &= w - 1;
+        ucol[o++] = gr | ((uint32_t)(j * 32 + b) << 16);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_dd_lookup(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags, const int32_t *__restrict__ pal_idx,
+                                                   int64_t n, int npal, const uint8_t *__restrict__ cls, const uint32_t *__restrict__ bits,
+                                                   const uint32_t *__restrict__ off, const uint4 *__restrict__ bins, const uint8_t *__restrict__ rs,
+                                                   const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int map_value = dither_map[lane];
+  for (int64_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += (int64_t)gridDim.x * 4) {
+    const int pi = pal_idx[t];
+    if (pi < 0 || pi >= npal || !cls[pi]) continue;
+    const int f = flags ? flags[t] : 0;
+    const int y = lane >> 3, x = lane & 7;
+    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // un-mirror (2696-2697)
+    const uint32_t c = tiles[t * 64 + src];
+    const size_t e = ((size_t)pi << 16) | (c & 0xffffu);
+    const int b = (c >> 16) & 0xff, bw = b >> 5;
+    const uint4 w0 = reinterpret_cast<const uint4 *>(bits)[e * 2], w1 = reinterpret_cast<const uint4 *>(bits)[e * 2 + 1];
+    const uint32_t ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    uint32_t u = off[e];
+#pragma unroll
+    for (int j = 0; j < 8; j++) u += __popc(j < bw ? ws[j] : j == bw ? ws[j] & ((1u << (b & 31)) - 1u) : 0u);
+    out[t * 64 + src] = rs[pi * 16 + rank_at(bins[u], map_value)];  // re-mirror (2721-2722)
   }
 }
 
@@ -351,9 +460,52 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
     if (!literal_only) {
       TM_TRY(cls.alloc((size_t)npal));
       hipLaunchKernelGGL(k_palette_class, dim3((npal + 63) / 64), dim3(64), 0, stream, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>());
-      hipLaunchKernelGGL(k_dither_tk_fast, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
-                         (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map,
-                         (uint8_t *)out_pal_px);
+      // distinct (palette, colour) pairs first: worth it when at most half of the pixels are distinct
+      static const bool no_dedup = getenv("TM_DITHER_NO_DEDUP") != nullptr;
+      bool dedup = !no_dedup && npal <= DD_MAX_PAL && n >= 1024;
+      DevBuf bits, cnt, off, seg, scan_tmp;
+      const int64_t nent = (int64_t)npal << 16;
+      std::vector<uint32_t> hseg((size_t)npal + 1, 0);
+      if (dedup) {
+        TM_TRY(bits.alloc((size_t)nent * 32)); TM_TRY(cnt.alloc((size_t)(nent + 1) * 4)); TM_TRY(off.alloc((size_t)(nent + 1) * 4)); TM_TRY(seg.alloc((size_t)(npal + 1) * 4));
+        TM_HIP(hipMemsetAsync(bits.p, 0, (size_t)nent * 32, stream));
+        hipLaunchKernelGGL(k_dd_mark, dim3((unsigned)std::min<int64_t>((n * 64 + 255) / 256, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)tiles, (const int32_t *)pal_idx, n, npal,
+                           cls.as<uint8_t>(), bits.as<uint32_t>());
+        hipLaunchKernelGGL(k_dd_count, dim3((unsigned)std::min<int64_t>((nent + 256) / 256, 256 * 16)), dim3(256), 0, stream, bits.as<uint32_t>(), nent, cnt.as<uint32_t>());
+        size_t tb = 0;
+        TM_HIP(rocprim::exclusive_scan(nullptr, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)(nent + 1), rocprim::plus<uint32_t>(), stream));
+        TM_TRY(scan_tmp.alloc(tb));
+        TM_HIP(rocprim::exclusive_scan(scan_tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)(nent + 1), rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_dd_seg, dim3((npal + 1 + 63) / 64), dim3(64), 0, stream, off.as<uint32_t>(), npal, seg.as<uint32_t>());
+        TM_HIP(hipMemcpyAsync(hseg.data(), seg.p, hseg.size() * 4, hipMemcpyDeviceToHost, stream));
+        TM_HIP(hipStreamSynchronize(stream));
+        dedup = (int64_t)hseg[npal] * 2 <= n * 64;
+      }
+      if (dedup && hseg[npal] > 0) {
+        const uint32_t nu = hseg[npal];
+        std::vector<int32_t> cpal;
+        std::vector<uint32_t> cbeg, cend;
+        for (int p = 0; p < npal; p++)
+          for (uint32_t a = hseg[p]; a < hseg[p + 1]; a += 64) { cpal.push_back(p); cbeg.push_back(a); cend.push_back(hseg[p + 1]); }
+        const int64_t nch = (int64_t)cpal.size();
+        DevBuf ucol, ubins, rs, dpal, dbeg, dend;
+        TM_TRY(ucol.alloc((size_t)nu * 4)); TM_TRY(ubins.alloc((size_t)nu * 16)); TM_TRY(rs.alloc((size_t)npal * 16));
+        TM_TRY(dpal.alloc((size_t)nch * 4)); TM_TRY(dbeg.alloc((size_t)nch * 4)); TM_TRY(dend.alloc((size_t)nch * 4));
+        TM_HIP(hipMemcpyAsync(dpal.p, cpal.data(), (size_t)nch * 4, hipMemcpyHostToDevice, stream));
+        TM_HIP(hipMemcpyAsync(dbeg.p, cbeg.data(), (size_t)nch * 4, hipMemcpyHostToDevice, stream));
+        TM_HIP(hipMemcpyAsync(dend.p, cend.data(), (size_t)nch * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_dd_expand, dim3((unsigned)std::min<int64_t>((nent + 255) / 256, 256 * 16)), dim3(256), 0, stream, bits.as<uint32_t>(), off.as<uint32_t>(), nent, ucol.as<uint32_t>());
+        const DdArgs dd{ucol.as<uint32_t>(), dpal.as<int32_t>(), dbeg.as<uint32_t>(), dend.as<uint32_t>(), ubins.as<uint4>(), rs.as<uint8_t>()};
+        hipLaunchKernelGGL(k_dither_tk_fast<true>, dim3((unsigned)std::min<int64_t>(nch, 256 * 40)), dim3(64), 0, stream, (const uint32_t *)nullptr, (const uint8_t *)nullptr,
+                           (const int32_t *)nullptr, nch, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map, (uint8_t *)nullptr, dd);
+        hipLaunchKernelGGL(k_dd_lookup, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags, (const int32_t *)pal_idx, n,
+                           npal, cls.as<uint8_t>(), bits.as<uint32_t>(), off.as<uint32_t>(), ubins.as<uint4>(), rs.as<uint8_t>(), tab->dither_map, (uint8_t *)out_pal_px);
+        TM_HIP(hipGetLastError());
+        TM_HIP(hipStreamSynchronize(stream));  // the chunk tables and the scratch die with this scope
+      } else if (!dedup)
+        hipLaunchKernelGGL(k_dither_tk_fast<false>, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
+                           (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map,
+                           (uint8_t *)out_pal_px, DdArgs{});
     }
     hipLaunchKernelGGL(k_dither_tk, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
                        (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, literal_only ? nullptr : cls.as<uint8_t>(),

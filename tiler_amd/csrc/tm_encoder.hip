@@ -708,11 +708,12 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
   TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
   lap("cluster features");
-  if (getenv("TM_CU_SPLIT")) {
+  if (getenv("TM_CU_SPLIT")) {  // experiment: the query features on a quarter of the compute units while the tile k-means has the rest
     TM_HIP(hipStreamSynchronize(e->stream));
     TM_TRY(prefetch_query_features(e));
-    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream_km));
-    TM_HIP(hipStreamSynchronize(e->stream_km));
+    hipStream_t km = e->stream_km ? e->stream_km : e->stream;
+    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, km));
+    TM_HIP(hipStreamSynchronize(km));
   } else
   TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
   lap("tile -> palette (192-D)");
