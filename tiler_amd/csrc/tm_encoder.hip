@@ -38,9 +38,24 @@ __global__ void k_tilemap_from_subset(const int32_t *__restrict__ keep, const in
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     tm_tile[i] = keep[i] ? sub_remap[pos[i]] : -1;
 }
-__global__ void k_histogram(const int32_t *__restrict__ idx, int64_t n, uint32_t *__restrict__ hist) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    if (idx[i] >= 0) atomicAdd(&hist[idx[i]], 1u);
+// use counts.  Neighbouring items often name the same tile (flat areas: one tile can own a tenth of the clip, and its counter then
+// serialises every atomic of the launch), so a wave adds a RUN of equal indices with one atomic: heads of runs by comparing with the lane
+// before, run lengths off the ballot of heads.
+__global__ __launch_bounds__(256) void k_histogram(const int32_t *__restrict__ idx, int64_t n, uint32_t *__restrict__ hist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < n; i0 += stride) {  // (workgroup-uniform bound: every lane reaches the ballot)
+    const int64_t i = i0 + threadIdx.x;
+    const int v = i < n ? idx[i] : -1;
+    const int prev = __shfl_up(v, 1);
+    const bool head = lane == 0 || v != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && v >= 0) {
+      const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+      const int len = rest ? __ffsll((long long)rest) : 64 - lane;
+      atomicAdd(&hist[v], (uint32_t)len);
+    }
+  }
 }
 __global__ void k_lookup(const int32_t *__restrict__ idx, int64_t n, const int32_t *__restrict__ table, int32_t *__restrict__ out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
