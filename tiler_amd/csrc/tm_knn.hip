@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   int *__restrict__ err_flag) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ int s_v[32][193];
+  __shared__ uint32_t s_norm[32];
   __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
   const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch, with_box);
@@ -105,10 +106,13 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
     }
     __syncthreads();
     // centred, permuted values of the 32 rows
-    for (int i = threadIdx.x; i < 32 * 192; i += 256) {
-      const int r = i / 192, p = i - r * 192;
-      const int v = (int)s_raw[r][s_p[p]] - (int)s_c[p];
-      s_v[r][p] = negate ? -v : v;
+    if (threadIdx.x < 192) {  // a thread per (permuted) column: no index arithmetic in the loop; the fourth wave's lanes beyond 192 sit it out
+      const int p = threadIdx.x, sp = s_p[p], c = s_c[p];
+#pragma unroll 8
+      for (int r = 0; r < 32; r++) {
+        const int v = (int)s_raw[r][sp] - c;
+        s_v[r][p] = negate ? -v : v;
+      }
     }
     __syncthreads();
     uint8_t *obase = out + tile * (int64_t)tile_bytes;
@@ -136,10 +140,18 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       }
       *reinterpret_cast<uint4 *>(obase + piece * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    {  // |v-c|^2 of every row (the kernel drops the query side's parity bit): eight lanes per row, integer sums (32 threads walking 192
+       // values each were the longest leg of a tile)
+      const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
+      uint32_t sq = 0;
+#pragma unroll 8
+      for (int p = part; p < 192; p += 8) { const int v = s_v[r][p]; sq += (uint32_t)(v * v); }
+      sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+      if (part == 0) { s_norm[r] = sq; reinterpret_cast<uint32_t *>(obase + kch * 1024)[r] = sq; }
+    }
+    if (with_box) __syncthreads();
     if (threadIdx.x < 32) {
-      uint32_t s = 0;
-      for (int p = 0; p < 192; p++) { const int v = s_v[threadIdx.x][p]; s += (uint32_t)(v * v); }
-      reinterpret_cast<uint32_t *>(obase + kch * 1024)[threadIdx.x] = s;  // |v-c|^2 (the kernel drops the query side's parity bit)
+      const uint32_t s = with_box ? s_norm[threadIdx.x] : 0u;
       if (with_box) {  // radial box dimension: |v-c| over the columns that are not box columns, rounded outwards, min/max over the rows
         int64_t row = std::min<int64_t>(tile * 32 + threadIdx.x, n - 1);
         if (rowperm) row = rowperm[row];
@@ -217,38 +229,53 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
   float cen[24];
 #pragma unroll
   for (int e = 0; e < 24; e++) cen[e] = (float)centre[j8 * 24 + e];
-  float boxc[KNN_NC];
+  float keep[24];  // 0 for the box columns, which do not count: a factor instead of a second, dependent round of loads
 #pragma unroll
-  for (int d = 0; d < KNN_NC; d++) boxc[d] = (float)centre[cs.col[d]];
+  for (int e = 0; e < 24; e++) {
+    keep[e] = 1.0f;
+#pragma unroll
+    for (int d = 0; d < KNN_NC; d++) if (cs.col[d] == j8 * 24 + e) keep[e] = 0.0f;
+  }
   unsigned int lmin = 0x7f800000u, lmax = 0u;
-  for (int64_t base = (int64_t)blockIdx.x * 32; base < n; base += (int64_t)gridDim.x * 32) {
-    const int64_t i = base + (threadIdx.x >> 3);
-    float sq = 0.0f;
-    if (i < n) {
+  constexpr int RG = 4;  // row groups of 32 per workgroup pass: 12 loads of 16 bytes in flight per lane
+  for (int64_t base = (int64_t)blockIdx.x * (32 * RG); base < n; base += (int64_t)gridDim.x * (32 * RG)) {
+    v4i x[RG][3];
+#pragma unroll
+    for (int g = 0; g < RG; g++) {
+      const int64_t i = min(base + g * 32 + (threadIdx.x >> 3), n - 1);
       const v4i *rp = reinterpret_cast<const v4i *>(feat + i * 192) + j8 * 3;
 #pragma unroll
-      for (int v = 0; v < 3; v++) {
-        const v4i x = rp[v];
+      for (int v = 0; v < 3; v++) x[g][v] = rp[v];
+    }
+#pragma unroll
+    for (int g = 0; g < RG; g++) {
+      const int64_t i = base + g * 32 + (threadIdx.x >> 3);
+      float sq = 0.0f;
+#pragma unroll
+      for (int v = 0; v < 3; v++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const float c0 = (float)(int16_t)(x[j] & 0xffff) - cen[v * 8 + 2 * j], c1 = (float)(x[j] >> 16) - cen[v * 8 + 2 * j + 1];
-          sq = fmaf(c0, c0, fmaf(c1, c1, sq));
+          const float c0 = (float)(int16_t)(x[g][v][j] & 0xffff) - cen[v * 8 + 2 * j], c1 = (float)(x[g][v][j] >> 16) - cen[v * 8 + 2 * j + 1];
+          sq = fmaf(c0 * keep[v * 8 + 2 * j], c0, fmaf(c1 * keep[v * 8 + 2 * j + 1], c1, sq));
         }
+      sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
+      if (i < n && j8 == 0) {
+        const float lr = sqrtf(fmaxf(sq, 0.0f));
+        out[i] = lr;
+        lmin = min(lmin, __float_as_uint(lr));
+        lmax = max(lmax, __float_as_uint(lr));
       }
-      if (j8 == 0)
-#pragma unroll
-        for (int d = 0; d < KNN_NC; d++) { const float c = (float)feat[i * 192 + cs.col[d]] - boxc[d]; sq -= c * c; }
-    }
-    sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
-    if (i < n && j8 == 0) {
-      const float lr = sqrtf(fmaxf(sq, 0.0f));
-      out[i] = lr;
-      lmin = min(lmin, __float_as_uint(lr));
-      lmax = max(lmax, __float_as_uint(lr));
     }
   }
   for (int o = 32; o > 0; o >>= 1) { lmin = min(lmin, (unsigned)__shfl_xor((int)lmin, o)); lmax = max(lmax, (unsigned)__shfl_xor((int)lmax, o)); }
-  if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lmin); atomicMax(&range[1], lmax); }
+  // one pair of atomics per workgroup: the two words are the same for the whole launch, and their atomics queue up one behind the other
+  __shared__ unsigned int s_rng[2][4];
+  if ((threadIdx.x & 63) == 0) { s_rng[0][threadIdx.x >> 6] = lmin; s_rng[1][threadIdx.x >> 6] = lmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&range[0], min(min(s_rng[0][0], s_rng[0][1]), min(s_rng[0][2], s_rng[0][3])));
+    atomicMax(&range[1], max(max(s_rng[1][0], s_rng[1][1]), max(s_rng[1][2], s_rng[1][3])));
+  }
 }
 
 // Morton key, value = row index: the three widest columns at 8 bits each over the union range, plus 8 bits of the radial coordinate
@@ -321,6 +348,7 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
                                                   const uint32_t *__restrict__ tie_list, const unsigned int *__restrict__ tie_count,
                                                   int *__restrict__ out_idx, const uint32_t *__restrict__ out_err) {
   __shared__ unsigned int s_min;
+  __shared__ int s_nt, s_tlist[2048];
   for (unsigned int k = blockIdx.x; k < *tie_count; k += gridDim.x) {
     const uint32_t p = tie_list[k];
     const int64_t q = qperm[p];
@@ -329,9 +357,19 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
     int qv[KNN_NC];  // the tie rescan prunes with the column boxes only
 #pragma unroll
     for (int d = 0; d < KNN_NC; d++) qv[d] = qrow[bx.col[d]];
-    if (threadIdx.x == 0) s_min = 0xffffffffu;
+    if (threadIdx.x == 0) { s_min = 0xffffffffu; s_nt = 0; }
     __syncthreads();
     unsigned int mine = 0xffffffffu;
+    auto rows = [&](int64_t t, int r0, int r1) {
+      for (int r = r0; r < r1; r++) {
+        const int64_t sr = t * 32 + r;
+        if (sr >= nt) break;
+        const uint32_t orow = tperm[sr];
+        if (orow < mine && ssd_rows(qrow, db + (int64_t)orow * 192) == best) mine = orow;
+      }
+    };
+    // the tiles whose box admits the minimum go on a list; their rows are then spread over the threads (a thread walking the 32 rows of
+    // its own tile was the whole cost of a tie: a handful of tiles survive, each on another thread, the rest of the workgroup waiting)
     for (int64_t t = threadIdx.x; t < n_ttiles; t += 256) {
       long long lb = 0;
 #pragma unroll
@@ -340,13 +378,13 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
         lb += g * g;
       }
       if (lb > (long long)best) continue;
-      for (int r = 0; r < 32; r++) {
-        const int64_t sr = t * 32 + r;
-        if (sr >= nt) break;
-        const uint32_t orow = tperm[sr];
-        if (orow < mine && ssd_rows(qrow, db + (int64_t)orow * 192) == best) mine = orow;
-      }
+      const int slot = atomicAdd(&s_nt, 1);
+      if (slot < 2048) s_tlist[slot] = (int)t;
+      else rows(t, 0, 32);  // list full: this thread takes the tile's rows itself
     }
+    __syncthreads();
+    const int total = min(s_nt, 2048) * 32;
+    for (int e = threadIdx.x; e < total; e += 256) rows(s_tlist[e >> 5], e & 31, (e & 31) + 1);
     if (mine != 0xffffffffu) atomicMin(&s_min, mine);
     __syncthreads();
     if (threadIdx.x == 0 && s_min != 0xffffffffu) out_idx[q] = (int)s_min;
@@ -480,7 +518,7 @@ static int upload_plan(tm_knn_index_impl *ix, hipStream_t stream) {
 static int row_radial(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &radial, hipStream_t stream) {
   TM_TRY(radial.alloc((size_t)std::max<int64_t>(n, 1) * 4));
   if (n <= 0) return TM_OK;
-  hipLaunchKernelGGL(k_row_radial, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 8192)), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve,
+  hipLaunchKernelGGL(k_row_radial, dim3((unsigned)std::min<int64_t>((n + 127) / 128, 2048)), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve,
                      ix->plan_dev.as<int16_t>(), radial.as<float>(), ix->rrange.as<unsigned int>());
   TM_HIP(hipGetLastError());
   return TM_OK;
