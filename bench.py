@@ -349,10 +349,17 @@ def main():
         sr["dedup"] = {"bound": "hbm", "kernel": "run_dedup (hash, radix sorts, compare, merge sort of distinct rows)", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": b, "note": "one 256 B key read + one 4 B index written per tile; blocking call (host reads the distinct count)"}
         del tiles, flags
-        ops = T * 64.0 * 64.0 * 16.0 * 12.0  # 64 pixels x 64 error-feedback steps x PaletteSize colours per tile, 12 int32 operations per compare
-        sr["dither"] = {"bound": "int32 valu", "kernel": "k_dither_tk_fast", "achieved": ops / st["dither"] / 1e9, "peak": INT32_VALU_PEAK_TOPS, "unit": "Tops/s",
-                        "frac": ops / st["dither"] / 1e9 / INT32_VALU_PEAK_TOPS, "ms": st["dither"], "hbm_gb_s": T * 320 / st["dither"] / 1e6,
-                        "note": "64 x 64 x PaletteSize colour compares per tile at 12 int32 operations each (DESIGN.md section 5); HBM traffic is negligible"}
+        # 64 error-feedback steps x PaletteSize colours per planned pixel, 9 int32 / fp32 operations per compare; the stage plans every DISTINCT
+        # (palette, colour) pair once (tm_get_dither_pairs) and the pixels look their pair up, so the executed work is the pairs', not the pixels'
+        pairs = enc.DitherPairs() if hasattr(enc, "DitherPairs") else 0
+        planned = pairs if pairs > 0 else T * 64
+        ops = planned * 64.0 * 16.0 * 9.0
+        sr["dither"] = {"bound": "int32 valu", "kernel": "k_dither_tk_fast<true> + k_dd_mark / k_dd_lookup" if pairs > 0 else "k_dither_tk_fast<false>",
+                        "achieved": ops / st["dither"] / 1e9, "peak": INT32_VALU_PEAK_TOPS, "unit": "Tops/s",
+                        "frac": ops / st["dither"] / 1e9 / INT32_VALU_PEAK_TOPS, "ms": st["dither"], "pixels": T * 64, "distinct_pairs": pairs, "executed_ops": ops,
+                        "nominal_ops": T * 64 * 64.0 * 16.0 * 9.0, "hbm_gb_s": T * 320 / st["dither"] / 1e6,
+                        "note": "executed = planned pixels x 64 steps x PaletteSize compares x 9 operations (DESIGN.md section 5); `ms` is the stage's wall time, "
+                                "most of which is now Reconstruct's query-feature kernel running beside it on the second stream"}
         it = enc.KmeansIters() if hasattr(enc, "KmeansIters") else None
         if it:
             b = 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * T * it["tile_iters"]

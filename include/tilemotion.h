@@ -170,9 +170,12 @@ TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */
 TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows);
-/* queries of the last Reconstruct's k = 1 searches: the DISTINCT frame tiles when Reduce's exact groups can be used (one process, motion
- * prediction and extended palette usage off), every tile-map item otherwise */
+/* queries of the last Reconstruct's searches: the DISTINCT frame tiles when Reduce's exact groups can be used (one process, motion
+ * prediction off), every tile-map item otherwise */
 TM_API int64_t tm_get_knn_queries(tm_encoder *);
+/* the last Dither: the distinct (palette, colour) pairs it planned once each (pixels look their pair up), 0 when every pixel was planned on
+ * its own (few duplicates, the Yliluoma ditherer, more than 256 palettes) */
+TM_API int64_t tm_get_dither_pairs(tm_encoder *);
 
 /* ======================================================================================= stage seam
  * All pointers are DEVICE pointers unless named host_*.  `stream` is a hipStream_t (NULL = default stream).

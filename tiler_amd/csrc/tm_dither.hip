@@ -77,9 +77,16 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
   const int lane = threadIdx.x;
   const int map_value = dither_map[lane];  // cDitheringMap[((y and 7) shl 3) or (x and 7)], natural orientation
   int cached_pal = -1, cnt = 0;
-  for (int64_t t = blockIdx.x; t < n; t += gridDim.x) {
+  // 64 tiles looked at per pass (a lane each), the ones that are this kernel's taken one by one: with the counting kernel's class being the
+  // rule, a wave that reads one palette index per pass spends the launch waiting for 300 000 dependent loads
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < n; base += (int64_t)gridDim.x * 64) {
+   const int64_t tl = base + lane;
+   const int pl = tl < n ? pal_idx[tl] : 0;
+   unsigned long long todo = __ballot(tl < n && !(cls && pl >= 0 && pl < npal && cls[pl]));
+   while (todo) {
+    const int64_t t = base + (__ffsll((long long)todo) - 1);
+    todo &= todo - 1;
     const int pi = pal_idx[t];
-    if (cls && pi >= 0 && pi < npal && cls[pi]) continue;  // the fast kernel's tile
     if (pi != cached_pal) {  // PreparePlan: drop cDitheringNullColor entries, keep order
       __syncthreads();
       int col = TM_NULL_COLOR;
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(64) void k_dither_tk(const uint32_t *__restrict__ t
     lane_quicksort(s_list, s_stack, lane, 63);
     const int pick = s_list[map_value][lane] & 0xff;
     out[t * 64 + src] = s_remap[pick];  // re-mirror (2721-2722): natural (y,x) lives at canonical position src
+   }
   }
 }
 
@@ -310,6 +318,16 @@ __global__ void k_dd_mark(const uint32_t *__restrict__ tiles, const int32_t *__r
     if (!(*w & m)) atomicOr(w, m);  // (a stale read only repeats the atomic)
   }
 }
+// the same table from a list of distinct pixel keys (palette << 24 | G << 16 | R << 8 | B: QuantizeUsingYakmo's, tm_kmeans.hip)
+__global__ void k_dd_mark_keys(const unsigned long long *__restrict__ keys, int64_t nk, int npal, const uint8_t *__restrict__ cls, uint32_t *__restrict__ bits) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = keys[i];
+    const long long pi = (long long)(k >> 24);
+    if (pi >= npal || !cls[pi]) continue;
+    const uint32_t e = ((uint32_t)pi << 16) | (uint32_t)((k >> 8) & 0xffff), b = (uint32_t)(k & 0xff);
+    atomicOr(bits + (size_t)e * 8 + (b >> 5), 1u << (b & 31));
+  }
+}
 __global__ void k_dd_count(const uint32_t *__restrict__ bits, int64_t nent, uint32_t *__restrict__ cnt) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e <= nent; e += (int64_t)gridDim.x * blockDim.x) {
     uint32_t c = 0;
@@ -342,7 +360,7 @@ __global__ void k_dd_expand(const uint32_t *__restrict__ bits, const uint32_t *_
 __global__ __launch_bounds__(256) void k_dd_lookup(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ flags, const int32_t *__restrict__ pal_idx,
                                                    int64_t n, int npal, const uint8_t *__restrict__ cls, const uint32_t *__restrict__ bits,
                                                    const uint32_t *__restrict__ off, const uint4 *__restrict__ bins, const uint8_t *__restrict__ rs,
-                                                   const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out) {
+                                                   const uint8_t *__restrict__ dither_map, uint8_t *__restrict__ out, int *__restrict__ missing) {
   const int lane = threadIdx.x & 63;
   const int map_value = dither_map[lane];
   for (int64_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += (int64_t)gridDim.x * 4) {
@@ -359,6 +377,10 @@ __global__ __launch_bounds__(256) void k_dd_lookup(const uint32_t *__restrict__ 
     uint32_t u = off[e];
 #pragma unroll
     for (int j = 0; j < 8; j++) u += __popc(j < bw ? ws[j] : j == bw ? ws[j] & ((1u << (b & 31)) - 1u) : 0u);
+    bool present = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j == bw) present = (ws[j] >> (b & 31)) & 1u;
+    if (!present) { *missing = 1; continue; }  // a caller's key list that does not cover these tiles: the call fails
     out[t * 64 + src] = rs[pi * 16 + rank_at(bins[u], map_value)];  // re-mirror (2721-2722)
   }
 }
@@ -447,7 +469,8 @@ __global__ __launch_bounds__(64) void k_dither_yliluoma(const uint32_t *__restri
 }
 
 int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,
-                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream) {
+                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream, int64_t *pairs_planned, const void *pair_keys, int64_t n_pair_keys) {
+  if (pairs_planned) *pairs_planned = 0;
   const DeviceTables *tab;
   TM_TRY(get_tables(&tab));
   TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
@@ -463,14 +486,19 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
       // distinct (palette, colour) pairs first: worth it when at most half of the pixels are distinct
       static const bool no_dedup = getenv("TM_DITHER_NO_DEDUP") != nullptr;
       bool dedup = !no_dedup && npal <= DD_MAX_PAL && n >= 1024;
-      DevBuf bits, cnt, off, seg, scan_tmp;
+      DevBuf bits, cnt, off, seg, scan_tmp, missing;
+
       const int64_t nent = (int64_t)npal << 16;
       std::vector<uint32_t> hseg((size_t)npal + 1, 0);
       if (dedup) {
         TM_TRY(bits.alloc((size_t)nent * 32)); TM_TRY(cnt.alloc((size_t)(nent + 1) * 4)); TM_TRY(off.alloc((size_t)(nent + 1) * 4)); TM_TRY(seg.alloc((size_t)(npal + 1) * 4));
         TM_HIP(hipMemsetAsync(bits.p, 0, (size_t)nent * 32, stream));
-        hipLaunchKernelGGL(k_dd_mark, dim3((unsigned)std::min<int64_t>((n * 64 + 255) / 256, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)tiles, (const int32_t *)pal_idx, n, npal,
-                           cls.as<uint8_t>(), bits.as<uint32_t>());
+        if (pair_keys && n_pair_keys > 0)
+          hipLaunchKernelGGL(k_dd_mark_keys, dim3((unsigned)std::min<int64_t>((n_pair_keys + 255) / 256, 256 * 16)), dim3(256), 0, stream, (const unsigned long long *)pair_keys, n_pair_keys, npal,
+                             cls.as<uint8_t>(), bits.as<uint32_t>());
+        else
+          hipLaunchKernelGGL(k_dd_mark, dim3((unsigned)std::min<int64_t>((n * 64 + 255) / 256, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)tiles, (const int32_t *)pal_idx, n, npal,
+                             cls.as<uint8_t>(), bits.as<uint32_t>());
         hipLaunchKernelGGL(k_dd_count, dim3((unsigned)std::min<int64_t>((nent + 256) / 256, 256 * 16)), dim3(256), 0, stream, bits.as<uint32_t>(), nent, cnt.as<uint32_t>());
         size_t tb = 0;
         TM_HIP(rocprim::exclusive_scan(nullptr, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)(nent + 1), rocprim::plus<uint32_t>(), stream));
@@ -480,16 +508,19 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
         TM_HIP(hipMemcpyAsync(hseg.data(), seg.p, hseg.size() * 4, hipMemcpyDeviceToHost, stream));
         TM_HIP(hipStreamSynchronize(stream));
         dedup = (int64_t)hseg[npal] * 2 <= n * 64;
+
       }
       if (dedup && hseg[npal] > 0) {
         const uint32_t nu = hseg[npal];
+        if (pairs_planned) *pairs_planned = nu;
         std::vector<int32_t> cpal;
         std::vector<uint32_t> cbeg, cend;
         for (int p = 0; p < npal; p++)
           for (uint32_t a = hseg[p]; a < hseg[p + 1]; a += 64) { cpal.push_back(p); cbeg.push_back(a); cend.push_back(hseg[p + 1]); }
         const int64_t nch = (int64_t)cpal.size();
         DevBuf ucol, ubins, rs, dpal, dbeg, dend;
-        TM_TRY(ucol.alloc((size_t)nu * 4)); TM_TRY(ubins.alloc((size_t)nu * 16)); TM_TRY(rs.alloc((size_t)npal * 16));
+        TM_TRY(ucol.alloc((size_t)nu * 4)); TM_TRY(ubins.alloc((size_t)nu * 16)); TM_TRY(rs.alloc((size_t)npal * 16)); TM_TRY(missing.alloc(4));
+        TM_HIP(hipMemsetAsync(missing.p, 0, 4, stream));
         TM_TRY(dpal.alloc((size_t)nch * 4)); TM_TRY(dbeg.alloc((size_t)nch * 4)); TM_TRY(dend.alloc((size_t)nch * 4));
         TM_HIP(hipMemcpyAsync(dpal.p, cpal.data(), (size_t)nch * 4, hipMemcpyHostToDevice, stream));
         TM_HIP(hipMemcpyAsync(dbeg.p, cbeg.data(), (size_t)nch * 4, hipMemcpyHostToDevice, stream));
@@ -499,9 +530,13 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
         hipLaunchKernelGGL(k_dither_tk_fast<true>, dim3((unsigned)std::min<int64_t>(nch, 256 * 40)), dim3(64), 0, stream, (const uint32_t *)nullptr, (const uint8_t *)nullptr,
                            (const int32_t *)nullptr, nch, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map, (uint8_t *)nullptr, dd);
         hipLaunchKernelGGL(k_dd_lookup, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags, (const int32_t *)pal_idx, n,
-                           npal, cls.as<uint8_t>(), bits.as<uint32_t>(), off.as<uint32_t>(), ubins.as<uint4>(), rs.as<uint8_t>(), tab->dither_map, (uint8_t *)out_pal_px);
+                           npal, cls.as<uint8_t>(), bits.as<uint32_t>(), off.as<uint32_t>(), ubins.as<uint4>(), rs.as<uint8_t>(), tab->dither_map, (uint8_t *)out_pal_px,
+                           missing.as<int>());
         TM_HIP(hipGetLastError());
-        TM_HIP(hipStreamSynchronize(stream));  // the chunk tables and the scratch die with this scope
+        int hmiss = 0;
+        TM_HIP(hipMemcpyAsync(&hmiss, missing.p, 4, hipMemcpyDeviceToHost, stream));
+        TM_HIP(hipStreamSynchronize(stream));  // (the chunk tables and the scratch die with this scope)
+        TM_CHECK(!hmiss, TM_E_INVAL, "dither: the list of distinct pixel keys does not cover these tiles");
       } else if (!dedup)
         hipLaunchKernelGGL(k_dither_tk_fast<false>, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,
                            (const int32_t *)pal_idx, n, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>(), tab->dither_map,

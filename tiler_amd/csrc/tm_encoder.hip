@@ -150,6 +150,9 @@ struct tm_encoder {
   std::vector<uint8_t> h_fflags;
   double stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int shard_first = 0, shard_count = -1;  // query frames this process matches in Reconstruct (multi-GPU: one shard per rank)
+  DevBuf pair_keys;          // the distinct pixel keys PreparePalettes' quantisation sorted out, for Dither (valid while pair_keys_n > 0:
+  int64_t pair_keys_n = 0;   // every step that rewrites the global tiles zeroes it)
+  int64_t dither_pairs = 0;  // distinct (palette, colour) pairs the last Dither planned (0: every pixel on its own)
   int dither_rank = 0, dither_world = 1;  // tiles this process dithers: [t * rank / world, t * (rank + 1) / world)
   // one process per GPU (tm_set_collective): the steps shard their work over `world` processes and merge through the host's collectives
   tm_collective_cb coll_cb = nullptr;
@@ -510,6 +513,7 @@ static int step_reduce_motion(tm_encoder *e) {
   int64_t nu = 0;
   TM_TRY(run_dedup(sub.p, nkeep, 256, nullptr, sremap.p, sorder.p, suse.p, &nu, e->stream));
   e->t = nu;
+  e->pair_keys_n = 0;
   TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
   TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
   TM_TRY(e->guse.alloc((size_t)e->t * 4));
@@ -571,7 +575,8 @@ static int step_reduce(tm_encoder *e) {
     progress(e, TM_STEP_REDUCE, 1, 2);
     const int64_t target = e->s.GlobalTilingTileCount > 0 ? e->s.GlobalTilingTileCount : nu;
     e->t = std::min<int64_t>(nu, target);
-    TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
+    e->pair_keys_n = 0;
+  TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
     TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
     TM_TRY(e->guse.alloc((size_t)e->t * 4));
     hipLaunchKernelGGL(k_gather_rows16, dim3(gridn(e->t * 16)), dim3(256), 0, e->stream, utiles.as<uint4>(), gorder.as<int32_t>(), e->t, 16, e->gtiles.as<uint4>());
@@ -597,6 +602,7 @@ static int step_reduce(tm_encoder *e) {
   progress(e, TM_STEP_REDUCE, 1, 2);
   int64_t target = e->s.GlobalTilingTileCount > 0 ? e->s.GlobalTilingTileCount : nu;
   e->t = std::min<int64_t>(nu, target);
+  e->pair_keys_n = 0;
   TM_TRY(e->gtiles.alloc((size_t)e->t * 256));
   TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(e->t, 1)));
   TM_TRY(e->guse.alloc((size_t)e->t * 4));
@@ -694,6 +700,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     t_last = now;
   };
   DevBuf feat;
+  e->pair_keys_n = 0;
   TM_TRY(e->gpal_idx.alloc((size_t)e->t * 4));
   TM_TRY(e->palettes_dev.alloc((size_t)e->s.PaletteCount * e->s.PaletteSize * 4));
   if (e->dist()) {
@@ -733,7 +740,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
-  TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream));
+  TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream, &e->pair_keys, &e->pair_keys_n));
   lap("palette colours (3-D)");
   }
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
@@ -758,10 +765,12 @@ static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
   TM_TRY(e->gpal_px.alloc((size_t)e->t * 64));
   const int64_t t0 = e->t * e->dither_rank / e->dither_world, t1 = e->t * (e->dither_rank + 1) / e->dither_world;
   if (e->dither_world > 1) TM_HIP(hipMemsetAsync(e->gpal_px.p, 0, (size_t)e->t * 64, e->stream));  // other shards' tiles: 0, merged with SUM
+  e->dither_pairs = 0;
   if (t1 > t0)
     TM_TRY(launch_dither(e->gtiles.as<uint8_t>() + t0 * 256, e->gflags.as<uint8_t>() + t0, e->gpal_idx.as<uint8_t>() + t0 * 4, t1 - t0, e->palettes_dev.p,
                          e->s.PaletteCount, e->s.PaletteSize, e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors,
-                         e->gpal_px.as<uint8_t>() + t0 * 64, e->stream));
+                         e->gpal_px.as<uint8_t>() + t0 * 64, e->stream, &e->dither_pairs, e->pair_keys_n > 0 && !getenv("TM_DITHER_OWN_KEYS") ? e->pair_keys.p : nullptr,
+                         e->pair_keys_n));
   if (e->dist() && e->dither_world > 1) TM_TRY(e->co.allreduce_sum_i32(e->gpal_px.p, e->t * 16));  // 64 bytes per tile = 16 words; other shares hold 0
   TM_HIP(hipStreamSynchronize(e->stream));
   e->has_pal_px = true;
@@ -1030,6 +1039,7 @@ static int step_reindex(tm_encoder *e) {  // Reindex, tilingencoder.pas:1993-203
   hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, remap.as<int32_t>(), ntm.as<int32_t>());
   TM_HIP(hipGetLastError());
   TM_HIP(hipStreamSynchronize(e->stream));
+  e->pair_keys_n = 0;
   e->gtiles = std::move(ntiles); e->gflags = std::move(nflags); e->gpal_idx = std::move(npal_idx); e->gpal_px = std::move(npal_px);
   e->tm_tile = std::move(ntm);
   e->guse = std::move(use);
@@ -1609,6 +1619,7 @@ int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx :
 }
 
 int64_t tm_get_knn_queries(tm_encoder *e) { return e ? e->knn_queries : 0; }
+int64_t tm_get_dither_pairs(tm_encoder *e) { return e ? e->dither_pairs : 0; }
 
 int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows) {
   if (e && db_rows) *db_rows = e->knn_db_rows;
@@ -1640,6 +1651,7 @@ int tm_reload_gtm(tm_encoder *e, const char *path) {  // ReloadGTM, tilingencode
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize, 0);
   TM_TRY(e->palettes_dev.alloc(e->palettes_host.size() * 4));
   TM_HIP(hipMemcpy(e->palettes_dev.p, e->palettes_host.data(), e->palettes_host.size() * 4, hipMemcpyHostToDevice));
+  e->pair_keys_n = 0;
   TM_TRY(e->gtiles.alloc((size_t)std::max<int64_t>(T, 1) * 256)); TM_TRY(e->gpal_px.alloc((size_t)std::max<int64_t>(T, 1) * 64));
   TM_TRY(e->gflags.alloc((size_t)std::max<int64_t>(T, 1))); TM_TRY(e->guse.alloc((size_t)std::max<int64_t>(T, 1) * 4));
   TM_TRY(e->gpal_idx.alloc((size_t)std::max<int64_t>(T, 1) * 4));

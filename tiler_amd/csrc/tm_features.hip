@@ -221,54 +221,81 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
 // PearsonCorrelation (tilingencoder.pas:2201-2228) of consecutive frames' Lab tile means: one thread per frame, the
 // reference's exact sequence (Math.mean sums in double; everything else sequential Single), so the sums are bit
 // identical to a CPU restatement and 300 frames run side by side.  Output: num, sum dx^2, sum dy^2 per frame.
+constexpr int PC = 2048;  // values per staged chunk
 __global__ __launch_bounds__(64) void k_pearson_frames(const float *__restrict__ lab, int nframes, int per, float *__restrict__ correl) {
-  // one wave per frame: all lanes stream x,y chunks into LDS (coalesced), lanes 0..2 run the sequential chains
-  __shared__ float s_x[1024], s_y[1024];
+  // one wave per frame.  Only the ADDITIONS of the reference's sums are a chain; everything that feeds them is element-wise, so all
+  // 64 lanes prepare a chunk in LDS (the doubles of the mean's terms, then the three products, each rounded exactly as the sequential
+  // code rounds it) and lanes 0..2 only add, reading 16 bytes at a time
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[2 * PC * 8];
   __shared__ double s_sum[2];
+  double (*s_d)[PC] = reinterpret_cast<double (*)[PC]>(s_raw);  // [2][PC], first pass
+  float (*s_p)[PC] = reinterpret_cast<float (*)[PC]>(s_raw);    // [3][PC], second pass
   const int f = blockIdx.x, lane = threadIdx.x;
   if (f == 0) { if (lane < 3) correl[lane] = 0.0f; return; }
   const float *x = lab + (int64_t)(f - 1) * per, *y = lab + (int64_t)f * per;
   double acc = 0.0;
-  for (int c0 = 0; c0 < per; c0 += 1024) {
-    const int n = min(1024, per - c0);
+  for (int c0 = 0; c0 < per; c0 += PC) {
+    const int n = min(PC, per - c0);
     __syncthreads();
-    for (int i = lane; i < n; i += 64) { s_x[i] = x[c0 + i]; s_y[i] = y[c0 + i]; }
+    {  // all of a chunk's loads in flight at once: a lone wave has nothing else to cover their latency with
+      float xv[PC / 64], yv[PC / 64];
+#pragma unroll
+      for (int u = 0; u < PC / 64; u++) { const int i = u * 64 + lane; xv[u] = i < n ? x[c0 + i] : 0.0f; yv[u] = i < n ? y[c0 + i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < PC / 64; u++) { const int i = u * 64 + lane; if (i < n) { s_d[0][i] = (double)xv[u]; s_d[1][i] = (double)yv[u]; } }
+    }
     __syncthreads();
     if (lane < 2) {
-      const float *src = lane == 0 ? s_x : s_y;
+      const double *src = s_d[lane];
       int i = 0;
-      for (; i + 16 <= n; i += 16) {  // batch the LDS reads; the additions stay one sequential chain
-        float v[16];
+#pragma unroll 1
+      for (; i + 32 <= n; i += 32) {  // sixteen reads issued before the first addition: their latency is paid once per 32 terms
+        double2 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = src[i + u];
+        for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const double2 *>(src + i + 2 * u);
 #pragma unroll
-        for (int u = 0; u < 16; u++) acc = __dadd_rn(acc, (double)v[u]);
+        for (int u = 0; u < 16; u++) { acc = __dadd_rn(acc, v[u].x); acc = __dadd_rn(acc, v[u].y); }
       }
-      for (; i < n; i++) acc = __dadd_rn(acc, (double)src[i]);
+      for (; i < n; i++) acc = __dadd_rn(acc, src[i]);
     }
   }
   if (lane < 2) s_sum[lane] = acc;
   __syncthreads();
   const float mx = (float)__ddiv_rn(s_sum[0], (double)per), my = (float)__ddiv_rn(s_sum[1], (double)per);
-  float chain = 0.0f;  // lane 0: num, lane 1: denx, lane 2: deny
-  for (int c0 = 0; c0 < per; c0 += 1024) {
-    const int n = min(1024, per - c0);
+  float chain = 0.0f;  // lane 0: num = sum dx*dy, lane 1: denx = sum dx*dx, lane 2: deny = sum dy*dy
+  for (int c0 = 0; c0 < per; c0 += PC) {
+    const int n = min(PC, per - c0);
     __syncthreads();
-    for (int i = lane; i < n; i += 64) { s_x[i] = x[c0 + i]; s_y[i] = y[c0 + i]; }
+    {
+      float xv[PC / 64], yv[PC / 64];
+#pragma unroll
+      for (int u = 0; u < PC / 64; u++) { const int i = u * 64 + lane; xv[u] = i < n ? x[c0 + i] : 0.0f; yv[u] = i < n ? y[c0 + i] : 0.0f; }
+#pragma unroll
+      for (int u = 0; u < PC / 64; u++) {
+        const int i = u * 64 + lane;
+        if (i < n) {
+          const float dx = __fsub_rn(xv[u], mx), dy = __fsub_rn(yv[u], my);
+          s_p[0][i] = __fmul_rn(dx, dy);
+          s_p[1][i] = __fmul_rn(dx, dx);
+          s_p[2][i] = __fmul_rn(dy, dy);
+        }
+      }
+    }
     __syncthreads();
     if (lane < 3) {
-      // lane 0: sum dx*dy, lane 1: sum dx*dx, lane 2: sum dy*dy
-      const float *pa = lane == 2 ? s_y : s_x, *pb = lane == 1 ? s_x : s_y;
-      const float ma = lane == 2 ? my : mx, mb = lane == 1 ? mx : my;
+      const float *src = s_p[lane];
       int i = 0;
-      for (; i + 16 <= n; i += 16) {
-        float va[16], vb[16];
+#pragma unroll 1
+      for (; i + 64 <= n; i += 64) {
+        float4 v[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) { va[u] = pa[i + u]; vb[u] = pb[i + u]; }
+        for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const float4 *>(src + i + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 16; u++) chain = __fadd_rn(chain, __fmul_rn(__fsub_rn(va[u], ma), __fsub_rn(vb[u], mb)));
+        for (int u = 0; u < 16; u++) {
+          chain = __fadd_rn(chain, v[u].x); chain = __fadd_rn(chain, v[u].y); chain = __fadd_rn(chain, v[u].z); chain = __fadd_rn(chain, v[u].w);
+        }
       }
-      for (; i < n; i++) chain = __fadd_rn(chain, __fmul_rn(__fsub_rn(pa[i], ma), __fsub_rn(pb[i], mb)));
+      for (; i < n; i++) chain = __fadd_rn(chain, src[i]);
     }
   }
   // the three raw sums go back to the host, which finishes with IEEE sqrt/divide (device __fsqrt_rn is a bare

@@ -42,7 +42,10 @@ int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq
 
 // tm_dither.hip
 int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int64_t n, const void *palettes, int npal, int pal_size,
-                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream);
+                  int use_tk, int y2_mixed, void *out_pal_px, hipStream_t stream, int64_t *pairs_planned = nullptr,
+                  const void *pair_keys = nullptr, int64_t n_pair_keys = 0);
+// pair_keys (optional): the distinct pixel keys palette << 24 | G << 16 | R << 8 | B of exactly these tiles (or a superset), as run_quantize_palettes
+// leaves them -- saves Dither its own pass over the pixels
 
 // tm_dedup.hip
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
@@ -84,12 +87,14 @@ int run_kmeans(const void *pts, const void *weights, int64_t n, int d, int k, in
 // the same Lloyd iterations from the caller's own initial centres (k point indices, -1 = none) instead of the farthest-first picks
 int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, int k, const int64_t *host_init_idx, int max_iter, void *assign, void *centroids,
                       int *host_k, int *host_iters, hipStream_t stream);
+// keep_keys / keep_n (optional): the sorted distinct pixel keys palette << 24 | G << 16 | R << 8 | B the quantisation found, for Dither
+struct DevBuf;
 int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
-                          hipStream_t stream);
+                          hipStream_t stream, DevBuf *keep_keys = nullptr, int64_t *keep_n = nullptr);
 // the same for the palettes p with p % pal_world == pal_rank only (independent tasks, one thread per palette in the reference:
 // tilingencoder.pas:1864); the other palettes' rows come back as zeros, so that an all-reduce(SUM) assembles the set
 int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
-                               int pal_rank, int pal_world, hipStream_t stream);
+                               int pal_rank, int pal_world, hipStream_t stream, DevBuf *keep_keys = nullptr, int64_t *keep_n = nullptr);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
 
 // tm_kmodes.hip: A17, TKModes.ComputeKModes (kmodes.pas:923-1094); host pointers

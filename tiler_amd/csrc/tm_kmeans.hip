@@ -2121,13 +2121,14 @@ static void rgb_to_hsv_bytes(int rr, int gg, int bb, int &h, int &s, int &v) {  
 }
 
 int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
-                          hipStream_t stream) {
-  return run_quantize_palettes_part(tiles, pal_idx, n, npal, pal_size, max_iter, out_palettes, 0, 1, stream);
+                          hipStream_t stream, DevBuf *keep_keys, int64_t *keep_n) {
+  return run_quantize_palettes_part(tiles, pal_idx, n, npal, pal_size, max_iter, out_palettes, 0, 1, stream, keep_keys, keep_n);
 }
 
 int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
-                               int pal_rank, int pal_world, hipStream_t stream) {
+                               int pal_rank, int pal_world, hipStream_t stream, DevBuf *keep_keys, int64_t *keep_n) {
   TM_TRY(require_device());
+  if (keep_n) *keep_n = 0;
   TM_CHECK(pal_world >= 1 && pal_rank >= 0 && pal_rank < pal_world, TM_E_INVAL, "quantize: bad palette share %d of %d", pal_rank, pal_world);
   TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536", npal);
   TM_CHECK(pal_size >= 2 && pal_size <= 64, TM_E_INVAL, "PaletteSize %d outside 2..64 (tilingencoder.pas:2965)", pal_size);
@@ -2210,6 +2211,7 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
       });
       for (size_t i = 0; i < items.size(); i++) hpal[(size_t)p * pal_size + i] = (items[i].b << 16) | (items[i].g << 8) | items[i].r;
     }
+    if (keep_keys && keep_n) { *keep_keys = std::move(ukeys); *keep_n = (int64_t)nu; }
   }
   if (pal_world > 1)
     for (int p = 0; p < npal; p++)

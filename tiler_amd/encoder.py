@@ -284,6 +284,12 @@ class TilingEncoder:
     def SyncTileMap(self):
         check(self._L.tm_sync_tilemap(c_void_p(self._h)))
 
+    def DitherPairs(self):
+        """distinct (palette, colour) pairs the last Dither planned once each; 0 = every pixel planned on its own"""
+        self._L.tm_get_dither_pairs.restype = c_int64
+        self._L.tm_get_dither_pairs.argtypes = [c_void_p]
+        return int(self._L.tm_get_dither_pairs(c_void_p(self._h)))
+
     def KnnStats(self):
         ms, pairs, launches, kb, rows = c_double(), c_int64(), c_int(), c_int(), c_int64()
         check(self._L.tm_get_knn_stats(c_void_p(self._h), ctypes.byref(ms), ctypes.byref(pairs), ctypes.byref(launches), ctypes.byref(kb),
