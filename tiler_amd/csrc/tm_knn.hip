@@ -93,16 +93,38 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
   __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
   const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch, with_box);
+  // the 32 rows of a tile come in as 16-byte vectors (three per thread) and are permuted out of LDS (the column permutation would otherwise
+  // turn the read into 6 144 two-byte loads per tile); the NEXT tile's vectors are fetched while this one is worked on, and the row
+  // numbers (curve order) of the one after: a workgroup walks its tiles one after the other, and two dependent round trips to memory per
+  // tile were most of the kernel
+  int pr[3], pv[3];
+#pragma unroll
+  for (int u = 0; u < 3; u++) { const int i = threadIdx.x + u * 256; pr[u] = i / 24; pv[u] = i - pr[u] * 24; }
+  auto row_of = [&](int64_t tile, int r) -> int64_t {
+    int64_t row = std::min<int64_t>(tile * 32 + r, n - 1);
+    return rowperm ? (int64_t)rowperm[row] : row;  // rows are packed in curve order
+  };
+  int64_t nrow[3];   // rows of the tile after next
+  uint4 nvec[3];     // vectors of the next tile
+  {
+    const int64_t t0 = blockIdx.x, t1 = (int64_t)blockIdx.x + gridDim.x;
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      nvec[u] = t0 < ntiles ? *reinterpret_cast<const uint4 *>(feat + row_of(t0, pr[u]) * 192 + pv[u] * 8) : make_uint4(0, 0, 0, 0);
+      nrow[u] = t1 < ntiles ? row_of(t1, pr[u]) : 0;
+    }
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
-    // the 32 rows come in as 16-byte vectors (three per thread) and are permuted out of LDS: the column permutation would otherwise
-    // turn the read into 6 144 two-byte loads per tile
-    for (int i = threadIdx.x; i < 32 * 24; i += 256) {
-      const int r = i / 24, v = i - r * 24;
-      int64_t row = tile * 32 + r;
-      if (row >= n) row = n - 1;
-      if (rowperm) row = rowperm[row];  // rows are packed in curve order
-      *reinterpret_cast<uint4 *>(&s_raw[r][v * 8]) = *reinterpret_cast<const uint4 *>(feat + row * 192 + v * 8);
+#pragma unroll
+    for (int u = 0; u < 3; u++) *reinterpret_cast<uint4 *>(&s_raw[pr[u]][pv[u] * 8]) = nvec[u];
+    {
+      const int64_t t1 = tile + gridDim.x, t2 = tile + 2 * (int64_t)gridDim.x;
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        if (t1 < ntiles) nvec[u] = *reinterpret_cast<const uint4 *>(feat + nrow[u] * 192 + pv[u] * 8);
+        if (t2 < ntiles) nrow[u] = row_of(t2, pr[u]);
+      }
     }
     __syncthreads();
     // centred, permuted values of the 32 rows
