@@ -2141,9 +2141,11 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
     hipLaunchKernelGGL(k_pixel_keys, dim3((int)std::min<int64_t>((npx + 255) / 256, 4096)), dim3(256), 0, stream, (const uint32_t *)tiles,
                        (const int32_t *)pal_idx, n, keys.as<u64>());
     size_t tb = 0;
-    TM_HIP(rocprim::radix_sort_keys(nullptr, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, 41, stream));
+    int key_bits = 25;  // 24 bits of colour + the palette number's: every 8 bits less is a pass over all pixels less
+    while (key_bits < 41 && (1ll << (key_bits - 24)) < npal) key_bits++;
+    TM_HIP(rocprim::radix_sort_keys(nullptr, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, key_bits, stream));
     TM_TRY(tmp.alloc(tb));
-    TM_HIP(rocprim::radix_sort_keys(tmp.p, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, 41, stream));
+    TM_HIP(rocprim::radix_sort_keys(tmp.p, tb, keys.as<u64>(), keys2.as<u64>(), (size_t)npx, 0, key_bits, stream));
     size_t tb2 = 0;
     TM_HIP(rocprim::run_length_encode(nullptr, tb2, keys2.as<u64>(), (unsigned int)npx, ukeys.as<u64>(), ucnt.as<uint32_t>(),
                                       nruns.as<unsigned int>(), stream));
