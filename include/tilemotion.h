@@ -174,7 +174,7 @@ TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int
  * prediction off), every tile-map item otherwise */
 TM_API int64_t tm_get_knn_queries(tm_encoder *);
 /* the last Dither: the distinct (palette, colour) pairs it planned once each (pixels look their pair up), 0 when every pixel was planned on
- * its own (few duplicates, the Yliluoma ditherer, more than 256 palettes) */
+ * its own (few duplicates, the Yliluoma ditherer, few tiles for the number of palettes) */
 TM_API int64_t tm_get_dither_pairs(tm_encoder *);
 
 /* ======================================================================================= stage seam

@@ -219,6 +219,24 @@ def test_distinct_query_groups_equal_per_item_queries(monkeypatch, epu):
     assert 0 < outs[0][2] < outs[1][2]
 
 
+def test_dither_plans_distinct_pairs_from_the_quantisation_keys(monkeypatch):
+    """a clip with enough global tiles for Dither's distinct-pair path: with PreparePalettes' sorted pixel keys handed over (the
+    default), with Dither marking the pairs from the pixels itself (TM_DITHER_OWN_KEYS) and with a plan per pixel
+    (TM_DITHER_NO_DEDUP is read once per process, so that leg is the stage test's: test_dither_thomas_knoll_distinct_pairs_path) the
+    encoder's output is the same; the pair count is reported and is at most the pixel count"""
+    from tiler_amd import synth
+    frames = synth.video(12, 320, 176, cut=6)
+    outs = []
+    for own in (False, True):
+        if own:
+            monkeypatch.setenv("TM_DITHER_OWN_KEYS", "1")
+        enc = _run_encoder(frames, PaletteCount=8, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0)
+        outs.append((np.stack([enc.TileMap(f) for f in range(12)]), enc.Tiles()[1], enc.DitherPairs()))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+
+
 @pytest.mark.parametrize("radius", [0, 8])
 def test_reload_gtm_round_trip(oracle, tmp_path, radius):
     """Save -> ReloadGTM into a fresh encoder (LoadStream, tilingencoder.pas:4880): palettes, tile pixels, tile maps and key

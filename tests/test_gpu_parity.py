@@ -373,6 +373,25 @@ def test_dither_thomas_knoll_distinct_pairs_path(oracle, flavour):
     assert np.array_equal(got, exp)
 
 
+def test_dither_distinct_pairs_with_many_palettes(monkeypatch):
+    """300 palettes over 80 000 tiles (the table of the distinct-pairs path: 19.7 M entries, 630 MB): the same bytes as a plan per pixel
+    (TM_DITHER_NO_DEDUP), which the other dither tests hold against the oracle"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(23)
+    n, npal = 80000, 300
+    pool = rng.integers(0, 1 << 24, size=5000, dtype=np.int32)
+    tiles = pool[rng.integers(0, 5000, size=(n, 64))]
+    flags = rng.integers(0, 4, size=n, dtype=np.uint8)
+    palettes = rng.integers(0, 1 << 24, size=(npal, 16), dtype=np.int32)
+    palettes[7, 9:] = -65281
+    pal_idx = rng.integers(0, npal, size=n, dtype=np.int32)
+    args = (_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True)
+    got = stages.dither(*args).cpu().numpy()
+    monkeypatch.setenv("TM_DITHER_NO_DEDUP", "1")
+    ref = stages.dither(*args).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("path", ["hash", "hash-collisions", "plain"])
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
 def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):

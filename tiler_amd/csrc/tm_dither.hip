@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64) void k_dither_tk_fast(const uint32_t *__restric
 // (palette, G, R) entry and an exclusive scan give every pair its index = scan[entry] + (set bits below B) -- pairs grouped by palette,
 // (G, R, B) ascending inside --, k_dd_expand lists the pairs, k_dither_tk_fast<true> plans each once, k_dd_lookup gives every pixel
 // its pair's counts and reads the position cDitheringMap[..] names off them.  Only palettes of the counting kernel's class take part.
-constexpr int DD_MAX_PAL = 256;  // 2.25 MB of table per palette
+constexpr int DD_MAX_PAL = 4096;  // 2.25 MB of table per palette, and no more table entries than four times the pixels (the table is cleared, counted and scanned per call)
 __global__ void k_dd_mark(const uint32_t *__restrict__ tiles, const int32_t *__restrict__ pal_idx, int64_t n, int npal, const uint8_t *__restrict__ cls,
                           uint32_t *__restrict__ bits) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * 64; i += (int64_t)gridDim.x * blockDim.x) {
@@ -484,11 +484,10 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
       TM_TRY(cls.alloc((size_t)npal));
       hipLaunchKernelGGL(k_palette_class, dim3((npal + 63) / 64), dim3(64), 0, stream, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>());
       // distinct (palette, colour) pairs first: worth it when at most half of the pixels are distinct
-      static const bool no_dedup = getenv("TM_DITHER_NO_DEDUP") != nullptr;
-      bool dedup = !no_dedup && npal <= DD_MAX_PAL && n >= 1024;
-      DevBuf bits, cnt, off, seg, scan_tmp, missing;
-
+      const bool no_dedup = getenv("TM_DITHER_NO_DEDUP") != nullptr;
       const int64_t nent = (int64_t)npal << 16;
+      bool dedup = !no_dedup && npal <= DD_MAX_PAL && n >= 1024 && nent <= n * 256;
+      DevBuf bits, cnt, off, seg, scan_tmp, missing;
       std::vector<uint32_t> hseg((size_t)npal + 1, 0);
       if (dedup) {
         TM_TRY(bits.alloc((size_t)nent * 32)); TM_TRY(cnt.alloc((size_t)(nent + 1) * 4)); TM_TRY(off.alloc((size_t)(nent + 1) * 4)); TM_TRY(seg.alloc((size_t)(npal + 1) * 4));
