@@ -21,19 +21,25 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ tiles, uint8_t *__restrict__ flags,
                                                     float *__restrict__ lab_means) {
   __shared__ float s_lab[4][LT_BATCH * LT_TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the tile arithmetic below stays on the scalar unit)
   const int64_t tiles_per_frame = (int64_t)tm_w * tm_h;
   const int64_t total = tiles_per_frame * nframes;
   const int64_t nbatch = (total + 4 * LT_BATCH - 1) / (4 * LT_BATCH);
   float *lab = s_lab[wave];  // a wave only touches its own part: no workgroup barrier
   for (int64_t it = blockIdx.x; it < nbatch; it += gridDim.x) {
     const int64_t base = (it * 4 + wave) * LT_BATCH;
-    for (int j = 0; j < LT_BATCH; j++) {
+    // frame, tile row and tile column of the batch's first tile by division, of the others by stepping
+    int64_t f = base / tiles_per_frame;
+    int sy, sx;
+    {
+      const int ti = (int)(base - f * tiles_per_frame);
+      sy = ti / tm_w;
+      sx = ti - sy * tm_w;
+    }
+    for (int j = 0; j < LT_BATCH; j++, sx++) {
       const int64_t t = base + j;
       if (t >= total) break;
-      const int64_t f = t / tiles_per_frame;
-      const int ti = (int)(t - f * tiles_per_frame);
-      const int sy = ti / tm_w, sx = ti - sy * tm_w;
+      if (sx == tm_w) { sx = 0; if (++sy == tm_h) { sy = 0; f++; } }
       const int y = lane >> 3, x = lane & 7;
       const int jj = sy * 8 + y, ii = sx * 8 + x;
       uint32_t px = 0;
