@@ -373,6 +373,28 @@ def test_dither_thomas_knoll_distinct_pairs_path(oracle, flavour):
     assert np.array_equal(got, exp)
 
 
+def test_dither_distinct_pairs_with_palette_indices_out_of_range(oracle):
+    """tiles that name no palette (-1, or one past the last) inside a call large enough for the distinct-pairs path: they come back as zeros,
+    as from the per-pixel kernels, and do not disturb their neighbours"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(29)
+    n = 2048
+    pool = rng.integers(0, 1 << 24, size=300, dtype=np.int32)
+    tiles = pool[rng.integers(0, 300, size=(n, 64))]
+    flags = rng.integers(0, 4, size=n, dtype=np.uint8)
+    palettes = rng.integers(0, 1 << 24, size=(4, 16), dtype=np.int32)
+    pal_idx = rng.integers(0, 4, size=n, dtype=np.int32)
+    bad = rng.choice(n, size=40, replace=False)
+    pal_idx[bad[:20]] = -1
+    pal_idx[bad[20:]] = 4
+    got = stages.dither(_dev(tiles), _dev(flags), _dev(pal_idx), _dev(palettes), True).cpu().numpy()
+    good = np.ones(n, bool)
+    good[bad] = False
+    exp = oracle.dither(tiles[good], flags[good], pal_idx[good], palettes, True)
+    assert np.array_equal(got[good], exp)
+    assert not got[bad].any()
+
+
 def test_dither_distinct_pairs_with_many_palettes(monkeypatch):
     """300 palettes over 80 000 tiles (the table of the distinct-pairs path: 19.7 M entries, 630 MB): the same bytes as a plan per pixel
     (TM_DITHER_NO_DEDUP), which the other dither tests hold against the oracle"""
