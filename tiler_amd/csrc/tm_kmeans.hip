@@ -918,13 +918,14 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
     if (lane == 0) { const double mv = sqrt(sd) * (1.0 + 1e-9); cmove[c] = mv; s_move[c] = mv; }
   }
   __syncthreads();
-  for (int pr = wave; pr < kk * kk; pr += 16) {  // pairwise distances: the smallest per centroid (non-negative doubles order like their bit patterns)
+  for (int pr = tid >> 4; pr < kk * kk; pr += 64) {  // pairwise distances, 16 lanes per pair: the smallest per centroid (non-negative doubles order like their bit patterns)
     const int a = pr / kk, b = pr - a * kk;
-    if (a >= b) continue;
+    if (a >= b) continue;  // (uniform in a group of 16 lanes, and the exchanges below stay inside one)
     double sd = 0.0;
-    for (int j = lane; j < 192; j += 64) { const double t = s_new[a * 193 + j] - s_new[b * 193 + j]; sd += t * t; }
-    sd = wave_sum(sd);
-    if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < 12; u++) { const int j = (tid & 15) + 16 * u; const double t = s_new[a * 193 + j] - s_new[b * 193 + j]; sd += t * t; }
+    for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+    if ((tid & 15) == 0) {
       atomicMin(&s_min[a], (unsigned long long)__double_as_longlong(sd));
       atomicMin(&s_min[b], (unsigned long long)__double_as_longlong(sd));
     }
