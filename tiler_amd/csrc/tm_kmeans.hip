@@ -601,18 +601,20 @@ static void launch_assign192(int ppt, dim3 grid, size_t lds, hipStream_t stream,
 constexpr int H_MAXK = 64;       // centroids kept in LDS by the skipping kernels
 constexpr double H_ETA = 1e-9;   // margin of the skip test
 constexpr int H_SLICE = 1024;    // points per workgroup of k_h_bounds
-__global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pts, int64_t n, const Seg *__restrict__ segs, const double *__restrict__ cent,
-                                                  const int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb,
+__global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pts, int64_t n, const Seg *__restrict__ segs,
+                                                  const double *__restrict__ cent_t /* [192][kt]: k_h_update's transposed copy */, int kt, const int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb,
                                                   const double *__restrict__ cmove /* [k] displacement of each centroid, then the largest, the second largest, whose */,
                                                   const double *__restrict__ shalf /* [k] half the distance to the nearest other centroid */, int k,
                                                   int32_t *__restrict__ need, unsigned *__restrict__ need_cnt, const int *__restrict__ quiet) {
   if (*quiet >= 0) return;
-  extern __shared__ double s_c[];  // [192][kk]: lanes of a wave read different centroids of one dimension -> different banks
-  __shared__ int s_list[H_SLICE];
-  __shared__ int s_nlist;
-  const int kk = segs[0].kk, tid = threadIdx.x;
-  for (int e = tid; e < kk * 192; e += 256) { const int c = e / 192, j = e - c * 192; s_c[j * kk + c] = cent[e]; }
-  if (tid == 0) s_nlist = 0;
+  extern __shared__ double s_c[];  // [192][kt]: lanes of a wave read different centroids of one dimension -> different banks
+  __shared__ int s_list[H_SLICE], s_need[H_SLICE];
+  __shared__ int s_nlist, s_nneed;
+  __shared__ unsigned s_base;
+  const int tid = threadIdx.x, kk = kt;  // (the recheck's pitch; columns past the live centroids are zeros nobody reads)
+
+  for (int e = tid; e < kt * 192; e += 256) s_c[e] = cent_t[e];  // a straight copy (transposing here cost 32-way bank conflicts and a division per element)
+  if (tid == 0) { s_nlist = 0; s_nneed = 0; }
   __syncthreads();
   const double dmax = cmove[k], dmax2 = cmove[k + 1];
   const int amax = (int)cmove[k + 2];
@@ -650,8 +652,16 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
     }
     const double u = sqrt(sd) * (1.0 + 1e-12);
     ub[i] = u;
-    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], lb[i]) * (1.0 - H_ETA))) need[atomicAdd(need_cnt, 1u)] = (int32_t)i;
+    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], lb[i]) * (1.0 - H_ETA))) s_need[atomicAdd(&s_nneed, 1)] = s_list[t];
   }
+  // the workgroup's share of the global list with ONE atomic on its counter (a counter every listed point of the launch adds to
+  // serialises them: ~6 ns each, and the early iterations list tens of thousands)
+  __syncthreads();
+  const int nneed = s_nneed;
+  if (nneed == 0) return;
+  if (tid == 0) s_base = atomicAdd(need_cnt, (unsigned)nneed);
+  __syncthreads();
+  for (int t = tid; t < nneed; t += 256) need[s_base + t] = (int32_t)(i0 + s_need[t]);
 }
 
 // The listed points through the full computation: k_assign192's arithmetic (sum over dimensions in order of (p - c)^2, one IEEE subtraction
@@ -1482,7 +1492,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
     hipLaunchKernelGGL(k_cent_transpose, dim3(12), dim3(256), 0, stream, ds, cent, hcent_t.as<double>(), h_kt);
     if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
-    if ((size_t)k * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, k * 192 * 8);
+    if ((size_t)h_kt * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, h_kt * 192 * 8);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
@@ -1503,7 +1513,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
         } else {
-          hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)k * 192 * 8, stream, pts, n, ds, cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
+          hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)h_kt * 192 * 8, stream, pts, n, ds, hcent_t.as<double>(), h_kt, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
           static const bool list1 = getenv("TM_KM_LIST1") != nullptr;  // A/B aid: a thread per point
           if (!list1)
