@@ -783,104 +783,119 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
                                                          double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
                                                          const unsigned *__restrict__ need_cnt) {
   if (*quiet >= 0) return;
-  constexpr int D = 192, NP = 64, CPL = KCH / 4;  // points per workgroup, centroids per lane and pass
-  const unsigned cnt = need ? *need_cnt : (unsigned)n_total, row0 = blockIdx.x * (unsigned)NP;  // no list: every point (the plain iterations)
-  if (row0 >= cnt) return;
+  constexpr int D = 192, NP = 64, CPL = KCH / 4;  // points per pass of a workgroup, centroids per lane and pass
+  const unsigned cnt = need ? *need_cnt : (unsigned)n_total;  // no list: every point (the plain iterations)
+  if (blockIdx.x * (unsigned)NP >= cnt) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ int s_nmoved;
   const int kk = segs[0].kk, tid = threadIdx.x, slot = tid >> 2, sub = tid & 3;
   double *s_c = reinterpret_cast<double *>(s_raw);                    // [D][KCH]
   u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);       // [kk][D + 1]
   int32_t *s_moved = reinterpret_cast<int32_t *>(s_delta + kk * (D + 1));  // [NP][3]: slot, old, new
-  const bool active = row0 + slot < cnt;
-  const int64_t gi = need ? need[active ? row0 + slot : row0] : (int64_t)(active ? row0 + slot : row0);
   for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
   if (tid == 0) s_nmoved = 0;
-  double bd = 1.0e300, bd2 = 1.0e300;
-  int bc = 0x7fffffff;
-  const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
+  // a fixed grid walks the list (a workgroup per 64 listed points was 5 000 workgroups launched to find that 4 950 have nothing to do,
+  // each staging the centroids first); with at most KCH centroids they are staged once per workgroup
+  const bool single = kk <= KCH;
+  if (single)
+    for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + (e % KCH)];
+  __syncthreads();
   const int64_t chunk_stride = n_total * (A_DCH / 4);  // int4 units between chunks
+  int total_moved = 0;
 #pragma unroll 1
-  for (int c0 = 0; c0 < kk; c0 += KCH) {
-    __syncthreads();
-    for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + c0 + (e % KCH)];
-    __syncthreads();
-    double s[CPL];
+  for (unsigned row0 = blockIdx.x * (unsigned)NP; row0 < cnt; row0 += gridDim.x * (unsigned)NP) {
+    const bool active = row0 + slot < cnt;
+    const int64_t gi = need ? need[active ? row0 + slot : row0] : (int64_t)(active ? row0 + slot : row0);
+    double bd = 1.0e300, bd2 = 1.0e300;
+    int bc = 0x7fffffff;
+    const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
+#pragma unroll 1
+    for (int c0 = 0; c0 < kk; c0 += KCH) {
+      if (!single) {
+        __syncthreads();
+        for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + c0 + (e % KCH)];
+        __syncthreads();
+      }
+      double s[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; c++) s[c] = 0.0;
-    auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
-      const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      for (int c = 0; c < CPL; c++) s[c] = 0.0;
+      auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
+        const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-      for (int j = 0; j < A_DCH; j++) {
-        const double pj = (double)v[j];
-        const double *cj = s_c + (ch * A_DCH + j) * KCH + sub * CPL;
+        for (int j = 0; j < A_DCH; j++) {
+          const double pj = (double)v[j];
+          const double *cj = s_c + (ch * A_DCH + j) * KCH + sub * CPL;
 #pragma unroll
-        for (int c = 0; c < CPL; c += 2) {
-          const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
-          const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
-          s[c] = __fma_rn(t0, t0, s[c]);
-          s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
+          for (int c = 0; c < CPL; c += 2) {
+            const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
+            const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
+            s[c] = __fma_rn(t0, t0, s[c]);
+            s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
+          }
+        }
+      };
+      int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
+#pragma unroll 1
+      for (int ch = 0; ch < D / A_DCH; ch += 2) {
+        int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (ch + 2 < D / A_DCH) {
+          na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
+          nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
+        }
+        score_chunk(a0, a1, ch);
+        score_chunk(b0, b1, ch + 1);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        const int ci = c0 + sub * CPL + c;
+        if (ci < kk) {  // this lane's centroids come in ascending order: strict `<` keeps the lowest index among equals
+          if (s[c] < bd) { bd2 = bd; bd = s[c]; bc = ci; }
+          else if (s[c] < bd2) bd2 = s[c];
         }
       }
-    };
-    int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
-#pragma unroll 1
-    for (int ch = 0; ch < D / A_DCH; ch += 2) {
-      int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-      if (ch + 2 < D / A_DCH) {
-        na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
-        nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
-      }
-      score_chunk(a0, a1, ch);
-      score_chunk(b0, b1, ch + 1);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+    // the four lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
 #pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int ci = c0 + sub * CPL + c;
-      if (ci < kk) {  // this lane's centroids come in ascending order: strict `<` keeps the lowest index among equals
-        if (s[c] < bd) { bd2 = bd; bd = s[c]; bc = ci; }
-        else if (s[c] < bd2) bd2 = s[c];
+    for (int o = 1; o < 4; o <<= 1) {
+      const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
+      const int oc = __shfl_xor(bc, o);
+      const bool take = od < bd || (od == bd && oc < bc);
+      const double loser = take ? bd : od;
+      bd2 = fmin(fmin(bd2, od2), loser);
+      if (take) { bd = od; bc = oc; }
+    }
+    if (active && sub == 0) {
+      ub[gi] = sqrt(bd) * (1.0 + 1e-12);
+      lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
+      const int old = assign[gi];
+      if (old != bc) {
+        assign[gi] = bc;
+        const int m = atomicAdd(&s_nmoved, 1);
+        s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
       }
     }
-  }
-  // the four lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
-#pragma unroll
-  for (int o = 1; o < 4; o <<= 1) {
-    const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
-    const int oc = __shfl_xor(bc, o);
-    const bool take = od < bd || (od == bd && oc < bc);
-    const double loser = take ? bd : od;
-    bd2 = fmin(fmin(bd2, od2), loser);
-    if (take) { bd = od; bc = oc; }
-  }
-  if (active && sub == 0) {
-    ub[gi] = sqrt(bd) * (1.0 + 1e-12);
-    lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
-    const int old = assign[gi];
-    if (old != bc) {
-      assign[gi] = bc;
-      const int m = atomicAdd(&s_nmoved, 1);
-      s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
-    }
-  }
-  __syncthreads();
-  const int nmoved = s_nmoved;
-  if (nmoved == 0) return;
-  if (tid == 0) atomicAdd(&segs[0].changed, nmoved);
+    __syncthreads();
+    const int nmoved = s_nmoved;
+    total_moved += nmoved;
 #pragma unroll 2
-  for (int e = tid >> 6; e < nmoved; e += 4) {  // a wave per moved row between the carried sums (coalesced read, three dimensions per lane)
-    const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
-    const int64_t mi = need ? need[row0 + s_moved[e * 3]] : (int64_t)(row0 + s_moved[e * 3]);
-    const long long wi = w ? (long long)w[mi] : 1;
+    for (int e = tid >> 6; e < nmoved; e += 4) {  // a wave per moved row between the carried sums (coalesced read, three dimensions per lane)
+      const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+      const int64_t mi = need ? need[row0 + s_moved[e * 3]] : (int64_t)(row0 + s_moved[e * 3]);
+      const long long wi = w ? (long long)w[mi] : 1;
 #pragma unroll
-    for (int j = tid & 63; j <= D; j += 64) {
-      const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
-      atomicAdd(&s_delta[nw * (D + 1) + j], v);
-      if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
+      for (int j = tid & 63; j <= D; j += 64) {
+        const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
+        atomicAdd(&s_delta[nw * (D + 1) + j], v);
+        if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
+      }
     }
+    __syncthreads();  // the moved list has been read
+    if (tid == 0) s_nmoved = 0;
+    __syncthreads();
   }
-  __syncthreads();
+  if (total_moved == 0) return;
+  if (tid == 0) atomicAdd(&segs[0].changed, total_moved);
   for (int e = tid; e < kk * (D + 1); e += 256) {
     const u64 v = s_delta[e];
     if (v == 0) continue;
@@ -1517,7 +1532,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
           static const bool list1 = getenv("TM_KM_LIST1") != nullptr;  // A/B aid: a thread per point
           if (!list1)
-            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)((n + 63) / 64)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)std::min<int64_t>((n + 63) / 64, 768)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
                                cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
           else
           hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
