@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   const int16_t *__restrict__ centre, const int16_t *__restrict__ perm,
                                                   const uint32_t *__restrict__ rowperm, int with_box, CurveSpec cs,
                                                   int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
-                                                  int *__restrict__ err_flag) {
+                                                  int *__restrict__ err_flag, int *__restrict__ qmeta /* query side of the second scan shape: [ntiles][16] */) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ int s_v[32][193];
   __shared__ uint32_t s_norm[32];
+  __shared__ long long s_bsq[32];  // query side: squared distance of each row from the centres over the box columns
   __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
   const int kch = 6 + hch, tile_bytes = knn_tile_bytes(hch, with_box);
@@ -128,6 +129,27 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
     }
     __syncthreads();
     // centred, permuted values of the 32 rows
+    if (qmeta && threadIdx.x >= 192 && threadIdx.x < 224) {
+      // the sub-tile's bounding box over the box columns, as the first scan shape computes it in its prologue: the rows are in LDS here (a
+      // kernel of its own gathered six scattered columns of every row again, 0.33 ms for 3.2 M rows), and these lanes have nothing else to do
+      const int r = threadIdx.x - 192;
+      int lo[KNN_NC], hi[KNN_NC];
+      long long boxsq = 0;
+#pragma unroll
+      for (int d = 0; d < KNN_NC; d++) {
+        const int v = s_raw[r][cs.col[d]];
+        lo[d] = hi[d] = v;
+        const long long c = v - (int)centre[cs.col[d]];
+        boxsq += c * c;
+      }
+      s_bsq[r] = boxsq;
+      for (int o = 16; o > 0; o >>= 1)  // the six dimensions' exchanges of a step are independent: they overlap
+#pragma unroll
+        for (int d = 0; d < KNN_NC; d++) { lo[d] = min(lo[d], __shfl_xor(lo[d], o)); hi[d] = max(hi[d], __shfl_xor(hi[d], o)); }
+      if (r == 0)
+#pragma unroll
+        for (int d = 0; d < KNN_NC; d++) { qmeta[tile * 16 + d] = lo[d]; qmeta[tile * 16 + 8 + d] = hi[d]; }
+    }
     if (threadIdx.x < 192) {  // a thread per (permuted) column: no index arithmetic in the loop; the fourth wave's lanes beyond 192 sit it out
       const int p = threadIdx.x, sp = s_p[p], c = s_c[p];
 #pragma unroll 8
@@ -171,7 +193,15 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
       if (part == 0) { s_norm[r] = sq; reinterpret_cast<uint32_t *>(obase + kch * 1024)[r] = sq; }
     }
-    if (with_box) __syncthreads();
+    if (with_box || qmeta) __syncthreads();
+    if (qmeta && threadIdx.x < 32) {  // the radial dimension of the sub-tile's box (the columns' part was done beside the centring phase)
+      const int r = threadIdx.x;
+      const long long n2 = (long long)(s_norm[r] & ~1u), boxsq = s_bsq[r];
+      int lo = max(0, (int)floor(sqrt((double)max(0ll, n2 - boxsq))) - 1);
+      int hi = (int)ceil(sqrt((double)max(0ll, n2 + 1 - boxsq))) + 1;
+      for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+      if (r == 0) { qmeta[tile * 16 + KNN_NC] = lo; qmeta[tile * 16 + 8 + KNN_NC] = hi; }
+    }
     if (threadIdx.x < 32) {
       const uint32_t s = with_box ? s_norm[threadIdx.x] : 0u;
       if (with_box) {  // radial box dimension: |v-c| over the columns that are not box columns, rounded outwards, min/max over the rows
@@ -567,10 +597,11 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
   const int64_t ntiles = (n + 31) / 32;
   TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch, with_box)));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
+  if (negate) TM_TRY(ix->qmeta.alloc((size_t)std::max<int64_t>(ntiles, 1) * 16 * 4));
   int grid = (int)std::min<int64_t>(ntiles, 4096);
   hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate,
                      ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, perm.as<uint32_t>(), with_box, ix->curve,
-                     ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>());
+                     ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>(), negate ? ix->qmeta.as<int>() : nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -771,42 +802,14 @@ static void launch_mfma(int ht, int hq, const KnnLaunch &a) {
   }
 }
 
-// per query sub-tile: bounding box over the box columns + the radial dimension (as the first scan shape computes it in its
-// prologue), and the database tile the sub-tile's first query falls into on the curve
-__global__ __launch_bounds__(256) void k_knn_qmeta(const int16_t *__restrict__ queries, const uint32_t *__restrict__ qperm,
-                                                   const uint32_t *__restrict__ qkey, int64_t nq, int64_t n_qtiles,
-                                                   const uint8_t *__restrict__ qpack, int q_bytes, KnnBoxes bx, int64_t n_ttiles,
-                                                   int *__restrict__ qmeta) {
-  const int lane32 = threadIdx.x & 31;
-  for (int64_t st = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); st < n_qtiles; st += (int64_t)gridDim.x * 8) {
-    const int64_t p = min(st * 32 + lane32, nq - 1);
-    const int16_t *row = queries + (int64_t)qperm[p] * 192;
-    const unsigned norm = reinterpret_cast<const unsigned *>(qpack + st * (int64_t)q_bytes + q_bytes - 128)[lane32] & ~1u;
-    long long boxsq = 0;
-    int *out = qmeta + st * 16;
-#pragma unroll
-    for (int d = 0; d < KNN_ND; d++) {
-      int lo, hi;
-      if (d < KNN_NC) {
-        lo = hi = row[bx.col[d]];
-        const long long c = lo - bx.cen[d];
-        boxsq += c * c;
-      } else {
-        const long long n2 = (long long)norm;
-        lo = max(0, (int)floor(sqrt((double)max(0ll, n2 - boxsq))) - 1);
-        hi = (int)ceil(sqrt((double)max(0ll, n2 + 1 - boxsq))) + 1;
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
-      if (lane32 == 0) { out[d] = lo; out[8 + d] = hi; }
-    }
-    if (lane32 == 0) {  // last tile whose first key <= the sub-tile's first key
-      const uint32_t k0 = qkey[st * 32];
-      int64_t lo = 0, hi = n_ttiles;
-      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (bx.tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
-      out[7] = (int)max((int64_t)0, lo - 1);
-      out[15] = 0;
-    }
+// per query sub-tile: the database tile its first query falls into on the curve (the sub-tile's box is written by k_knn_pack)
+__global__ __launch_bounds__(256) void k_knn_qmeta(const uint32_t *__restrict__ qkey, int64_t n_qtiles, KnnBoxes bx, int64_t n_ttiles, int *__restrict__ qmeta) {
+  for (int64_t st = (int64_t)blockIdx.x * 256 + threadIdx.x; st < n_qtiles; st += (int64_t)gridDim.x * 256) {
+    const uint32_t k0 = qkey[st * 32];  // last tile whose first key <= the sub-tile's first key
+    int64_t lo = 0, hi = n_ttiles;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (bx.tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
+    qmeta[st * 16 + 7] = (int)max((int64_t)0, lo - 1);
+    qmeta[st * 16 + 15] = 0;
   }
 }
 
@@ -976,9 +979,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   unsigned long long *stats = reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16);
   if (!v1) {
-    TM_TRY(ix->qmeta.alloc((size_t)nqt * 16 * 4));
-    hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 7) / 8, 8192)), dim3(256), 0, stream, (const int16_t *)queries,
-                       ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), nq, nqt, ix->qpack.as<uint8_t>(), knn_tile_bytes(ix->plan.hq, 0), bx, ntt,
+    hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 255) / 256, 4096)), dim3(256), 0, stream, ix->qkey.as<uint32_t>(), nqt, bx, ntt,
                        ix->qmeta.as<int>());
     TM_HIP(hipGetLastError());
   }
