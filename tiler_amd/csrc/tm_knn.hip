@@ -274,7 +274,8 @@ __device__ __forceinline__ uint32_t spread8(uint32_t v) {  // 8 bits -> every fo
 // R of every row, R = |v - c| over the columns that are not box columns (the radial box dimension of tm_knn_kernel.h),
 // and its range over the rows (floats >= 0: their bit patterns order like the values).  8 lanes per row, 48 bytes each.
 __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const int16_t *__restrict__ centre,
-                                                    float *__restrict__ out, unsigned int *__restrict__ range /* [0] min, [1] max */) {
+                                                    float *__restrict__ out, unsigned int *__restrict__ range /* [0] min, [1] max */,
+                                                    uint2 *__restrict__ ccol /* [n]: the row's three curve columns, for k_curve_keys */) {
   // this R only places the row on the curve (the box dimension gets its exact, outward-rounded values in k_knn_pack and in the scan's
   // prologue), so single precision is enough: the lane's 24 centres live in registers and every element is one subtract and one fma
   const int j8 = threadIdx.x & 7;
@@ -292,12 +293,16 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
   constexpr int RG = 4;  // row groups of 32 per workgroup pass: 12 loads of 16 bytes in flight per lane
   for (int64_t base = (int64_t)blockIdx.x * (32 * RG); base < n; base += (int64_t)gridDim.x * (32 * RG)) {
     v4i x[RG][3];
+    int16_t cc[RG][3];  // lane 0 of a row: its three curve columns (the lines are the ones the row's own loads fetch)
 #pragma unroll
     for (int g = 0; g < RG; g++) {
       const int64_t i = min(base + g * 32 + (threadIdx.x >> 3), n - 1);
       const v4i *rp = reinterpret_cast<const v4i *>(feat + i * 192) + j8 * 3;
 #pragma unroll
       for (int v = 0; v < 3; v++) x[g][v] = rp[v];
+      if (j8 == 0)
+#pragma unroll
+        for (int d = 0; d < 3; d++) cc[g][d] = feat[i * 192 + cs.col[d]];
     }
 #pragma unroll
     for (int g = 0; g < RG; g++) {
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
       if (i < n && j8 == 0) {
         const float lr = sqrtf(fmaxf(sq, 0.0f));
         out[i] = lr;
+        ccol[i] = make_uint2((uint32_t)(uint16_t)cc[g][0] | ((uint32_t)(uint16_t)cc[g][1] << 16), (uint32_t)(uint16_t)cc[g][2]);
         lmin = min(lmin, __float_as_uint(lr));
         lmax = max(lmax, __float_as_uint(lr));
       }
@@ -333,14 +339,16 @@ __global__ __launch_bounds__(256) void k_row_radial(const int16_t *__restrict__ 
 // Morton key, value = row index: the three widest columns at 8 bits each over the union range, plus 8 bits of the radial coordinate
 // over ITS range, so that the rows of a tile are alike in texture energy as well as in mean colour -- which is what the radial
 // box dimension needs in order to prune (30 % fewer evaluated pairs on the bench clip than a 3 x 10-bit curve of the columns alone).
-__global__ void k_curve_keys(const int16_t *__restrict__ feat, int64_t n, CurveSpec cs, const float *__restrict__ radial,
+__global__ void k_curve_keys(const uint2 *__restrict__ ccol /* k_row_radial's copy of the three curve columns */, int64_t n, CurveSpec cs, const float *__restrict__ radial,
                              uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     // per-dimension bit counts, interleaved from the top: a dimension with more bits splits first
     uint32_t q[4];
+    const uint2 c3 = ccol[i];
+    const int cv[3] = {(int)(int16_t)(c3.x & 0xffff), (int)(int16_t)(c3.x >> 16), (int)(int16_t)(c3.y & 0xffff)};
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-      const float v = d < 3 ? (float)feat[i * 192 + cs.col[d]] : (cs.rlog ? log2f(radial[i] + 1.0f) : radial[i]);
+      const float v = d < 3 ? (float)cv[d] : (cs.rlog ? log2f(radial[i] + 1.0f) : radial[i]);
       q[d] = (uint32_t)min((float)((1u << cs.bits[d]) - 1u), max(0.0f, (v - cs.off[d]) * cs.scale[d]));
     }
     uint32_t k = 0;
@@ -542,6 +550,7 @@ struct tm_knn_index_impl {
   DevBuf rrange, tradial, qradial;                  // radial coordinate of the rows (curve key) and its range
   CurveSpec curve;
   DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
+  DevBuf tccol, qccol;                              // the rows' three curve columns (k_row_radial -> k_curve_keys)
   DevBuf qmeta;                                     // per query sub-tile: box + home tile (second scan shape)
   int64_t last_blocks = 0, last_loads = 0, last_listed = 0;
   int64_t last_visited = 0, last_ties = 0;
@@ -567,20 +576,21 @@ static int upload_plan(tm_knn_index_impl *ix, hipStream_t stream) {
 
 // rows sorted along the Morton curve: perm (row order) and the sorted keys
 // log2(R + 1) per row into `radial` and the running range into ix->rrange (two uint32, reset by the caller)
-static int row_radial(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &radial, hipStream_t stream) {
+static int row_radial(tm_knn_index_impl *ix, const void *feat, int64_t n, DevBuf &radial, DevBuf &ccol, hipStream_t stream) {
   TM_TRY(radial.alloc((size_t)std::max<int64_t>(n, 1) * 4));
+  TM_TRY(ccol.alloc((size_t)std::max<int64_t>(n, 1) * 8));
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_row_radial, dim3((unsigned)std::min<int64_t>((n + 127) / 128, 2048)), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve,
-                     ix->plan_dev.as<int16_t>(), radial.as<float>(), ix->rrange.as<unsigned int>());
+                     ix->plan_dev.as<int16_t>(), radial.as<float>(), ix->rrange.as<unsigned int>(), ccol.as<uint2>());
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
 
-static int sort_by_curve(tm_knn_index_impl *ix, const void *feat, int64_t n, const DevBuf &radial, DevBuf &perm, DevBuf &keys_sorted, hipStream_t stream) {
+static int sort_by_curve(tm_knn_index_impl *ix, const DevBuf &ccol, int64_t n, const DevBuf &radial, DevBuf &perm, DevBuf &keys_sorted, hipStream_t stream) {
   TM_TRY(ix->skey.alloc((size_t)n * 4)); TM_TRY(ix->sidx.alloc((size_t)n * 4));
   TM_TRY(perm.alloc((size_t)n * 4)); TM_TRY(keys_sorted.alloc((size_t)n * 4));
   const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_curve_keys, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ix->curve, radial.as<float>(),
+  hipLaunchKernelGGL(k_curve_keys, dim3(grid), dim3(256), 0, stream, ccol.as<uint2>(), n, ix->curve, radial.as<float>(),
                      ix->skey.as<uint32_t>(), ix->sidx.as<uint32_t>());
   size_t tb = 0;
   TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, ix->skey.as<uint32_t>(), keys_sorted.as<uint32_t>(), ix->sidx.as<uint32_t>(),
@@ -890,8 +900,8 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
       TM_TRY(ix->rrange.alloc(8));
       const unsigned int init[2] = {0x7f800000u, 0u};
       TM_HIP(hipMemcpyAsync(ix->rrange.p, init, 8, hipMemcpyHostToDevice, stream));
-      TM_TRY(row_radial(ix, ix->db, ix->nt, ix->tradial, stream));
-      TM_TRY(row_radial(ix, queries, nq, ix->qradial, stream));
+      TM_TRY(row_radial(ix, ix->db, ix->nt, ix->tradial, ix->tccol, stream));
+      TM_TRY(row_radial(ix, queries, nq, ix->qradial, ix->qccol, stream));
       unsigned int rr[2];
       TM_HIP(hipMemcpyAsync(rr, ix->rrange.p, 8, hipMemcpyDeviceToHost, stream));
       TM_HIP(hipStreamSynchronize(stream));
@@ -929,7 +939,8 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
                 cs.bits[0], cs.bits[1], cs.bits[2], cs.bits[3], cs.rlog ? "own ranges, log radial" : "isotropic cells");
       fresh_radial = true;
     }
-    TM_TRY(sort_by_curve(ix, ix->db, ix->nt, ix->tradial, ix->tperm, ix->skey2, stream));
+    TM_TRY(sort_by_curve(ix, ix->tccol, ix->nt, ix->tradial, ix->tperm, ix->skey2, stream));
+    ix->tccol.release();
     ix->tradial.release();
     TM_TRY(ix->tkey.alloc((size_t)ntt * 4));
     TM_HIP(hipMemcpy2DAsync(ix->tkey.p, 4, ix->skey2.p, 128, 4, (size_t)ntt, hipMemcpyDeviceToDevice, stream));  // key of each tile's first row
@@ -945,8 +956,8 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
     }
     ix->packed = true;
   }
-  if (!fresh_radial) TM_TRY(row_radial(ix, queries, nq, ix->qradial, stream));  // a later batch on a built index (its range result is not used)
-  TM_TRY(sort_by_curve(ix, queries, nq, ix->qradial, ix->qperm, ix->qkey, stream));
+  if (!fresh_radial) TM_TRY(row_radial(ix, queries, nq, ix->qradial, ix->qccol, stream));  // a later batch on a built index (its range result is not used)
+  TM_TRY(sort_by_curve(ix, ix->qccol, nq, ix->qradial, ix->qperm, ix->qkey, stream));
   TM_TRY(run_pack(ix, queries, nq, 1, ix->plan.hq, ix->qperm, 0, ix->qpack, stream));
   return TM_OK;
 }
