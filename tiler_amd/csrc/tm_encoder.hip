@@ -169,6 +169,7 @@ struct tm_encoder {
   hipStream_t stream_km = nullptr;  // TM_CU_SPLIT experiment: the tile k-means on its own compute units, stream2 on the others
   hipEvent_t ev_qf = nullptr;
   DevBuf qf_pre;
+  DevBuf qf_colmm;  // the prefetched distinct rows' column ranges (the feature kernel keeps them; Reconstruct's search reads them)
   int qf_f0 = -1, qf_nf = 0, qf_epu = -1;
   bool qf_valid = false;
   // Reduce's exact grouping of the frame tiles (motion prediction off, one process): group of every tile-map item and the first item of
@@ -662,8 +663,12 @@ static int prefetch_query_features(tm_encoder *e) {
   if (!e->ev_qf) TM_HIP(hipEventCreateWithFlags(&e->ev_qf, hipEventDisableTiming));
   TM_TRY(e->qf_pre.alloc((size_t)(distinct ? e->q_groups : (int64_t)nf * per) * 384));
   TM_HIP(hipStreamSynchronize(e->stream));  // the pool handed out memory that work on the main stream may just have released
-  if (distinct)
-    TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, e->q_groups, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2));
+  if (distinct) {
+    TM_TRY(e->qf_colmm.alloc(384 * 4));
+    TM_HIP(hipMemsetAsync(e->qf_colmm.p, 0x7f, 192 * 4, e->stream2));                           // 0x7f7f7f7f: above any int16
+    TM_HIP(hipMemsetAsync(e->qf_colmm.as<uint8_t>() + 192 * 4, 0x80, 192 * 4, e->stream2));     // 0x80808080: below any int16
+    TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, e->q_groups, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2, e->qf_colmm.p));
+  }
   else
     TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + (int64_t)sf * per * 256, (int64_t)nf * per, nullptr, TM_PVS_WEIGHTED_DCT, 0, e->qf_pre.p, e->stream2));
   TM_HIP(hipEventRecord(e->ev_qf, e->stream2));
@@ -914,15 +919,17 @@ static int step_reconstruct(tm_encoder *e) {
     DevBuf gt, ge;
     TM_TRY(gt.alloc((size_t)ng * 4)); TM_TRY(ge.alloc((size_t)ng * 4));
     void *qfp = nullptr;
+    const void *qmm = nullptr;
     if (e->qf_valid && e->qf_distinct) {
       TM_HIP(hipStreamWaitEvent(e->stream, e->ev_qf, 0));
       qfp = e->qf_pre.p;
+      if (!getenv("TM_KNN_OWN_COLSTATS")) qmm = e->qf_colmm.p;
     } else {
       TM_TRY(qf.alloc((size_t)ng * 384));
       qfp = qf.p;
       TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, ng, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
     }
-    rc = knn_index_search(ix, qfp, ng, gt.p, ge.p, e->stream);
+    rc = knn_index_search(ix, qfp, ng, gt.p, ge.p, e->stream, qmm);
     e->knn_queries += ng;
     if (rc == TM_OK) {
       double ms = 0; int kb = 0; int64_t pairs = 0;

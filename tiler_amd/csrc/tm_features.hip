@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
                                                       int pal_size, const uint8_t *__restrict__ mirror_flags, int64_t n,
                                                       int weighted, int use_lab, const float *__restrict__ lut,
                                                       const double *__restrict__ weights, const uint8_t *__restrict__ snake,
-                                                      const float *__restrict__ srgb_lut, int16_t *__restrict__ out) {
+                                                      const float *__restrict__ srgb_lut, int16_t *__restrict__ out,
+                                                      int *__restrict__ colmm /* null, or [384]: running min / max of the 192 output columns (atomics) */) {
   __shared__ __attribute__((aligned(16))) float s_cpn[2][4][192];
+  int mmn[3] = {INT_MAX, INT_MAX, INT_MAX}, mmx[3] = {INT_MIN, INT_MIN, INT_MIN};  // of this lane's three output columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float l[64];
 #pragma unroll
@@ -164,8 +166,24 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         }
         double z = __dadd_rn(acc0, acc1);
         if (weighted) z = __dmul_rn(z, w[c]);
-        out[t * 192 + c * 64 + zz] = (int16_t)__double2ll_rn(z);  // Round(): half to even (3126)
+        const int16_t o = (int16_t)__double2ll_rn(z);  // Round(): half to even (3126)
+        out[t * 192 + c * 64 + zz] = o;
+        mmn[c] = min(mmn[c], (int)o);
+        mmx[c] = max(mmx[c], (int)o);
       }
+    }
+  }
+  if (colmm) {  // the search's digit plan wants the columns' ranges: kept here, a pass over all rows saved there (the four waves of a workgroup
+                // hold the same columns: one atomic pair per column and workgroup)
+    __shared__ int s_mm[4][384];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) { s_mm[wave][c * 64 + zz] = mmn[c]; s_mm[wave][192 + c * 64 + zz] = mmx[c]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 192; i += 256) {
+      const int a = min(min(s_mm[0][i], s_mm[1][i]), min(s_mm[2][i], s_mm[3][i]));
+      const int b = max(max(s_mm[0][192 + i], s_mm[1][192 + i]), max(s_mm[2][192 + i], s_mm[3][192 + i]));
+      if (a != INT_MAX) { atomicMin(&colmm[i], a); atomicMax(&colmm[192 + i], b); }
     }
   }
 }
@@ -347,20 +365,20 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
 
 // the same for a list of rows: output row i = features of tile rows[i] (Reconstruct's queries are the DISTINCT frame tiles)
-int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream) {
+int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream, void *colmm) {
   const DeviceTables *tab;
   TM_TRY(get_tables(&tab));
   TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      (const int32_t *)rows, nullptr, 0, (const uint8_t *)nullptr, n, mode_weighted(mode) ? 1 : 0, use_lab,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)colmm);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -374,7 +392,7 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<1>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
                      (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -384,7 +402,7 @@ int launch_features_pairs(const void *pal_px, const void *pairs, int64_t n, cons
   TM_TRY(get_tables(&tab));
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<4>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)pairs, (const uint8_t *)pal_px, nullptr,
-                     (const int32_t *)palettes, pal_size, nullptr, n, 1, 0, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out);
+                     (const int32_t *)palettes, pal_size, nullptr, n, 1, 0, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -397,7 +415,7 @@ int launch_features_table(const void *pal_px, int64_t ntiles, const void *palett
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<3>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px, nullptr,
                      (const int32_t *)palettes, pal_size, nullptr, n, 1, npal, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights,
-                     tab->snake, tab->srgb_lut, (int16_t *)out);
+                     tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -409,7 +427,7 @@ int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stre
   const int64_t n = (int64_t)(w - 7) * (h - 7);
   hipLaunchKernelGGL(k_features_i16<2>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)fb, nullptr, nullptr, nullptr, w,
                      nullptr, n, 1, 0, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights, tab->snake, tab->srgb_lut,
-                     (int16_t *)out);
+                     (int16_t *)out, (int *)nullptr);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

@@ -13,7 +13,8 @@ int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w,
                 void *lab_means, hipStream_t stream);
 int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream);
 int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out, hipStream_t stream);
-int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream);
+// colmm (optional): [384] ints on the device, mn[192] preset to INT_MAX and mx[192] to INT_MIN: the kernel folds the output columns' ranges in
+int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int mode, int use_lab, void *out, hipStream_t stream, void *colmm = nullptr);
 int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
@@ -33,7 +34,8 @@ int launch_epu_rerank(const void *queries, int64_t nq, const void *knn_idx, int 
 struct tm_knn_index_impl;
 int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_index_impl **out);
 void knn_index_destroy(tm_knn_index_impl *ix);
-int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream);
+// query_colmm (optional): the queries' column ranges as launch_features_rgb_rows leaves them (device, [384]) -- saves the search its own pass
+int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream, const void *query_colmm = nullptr);
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs);
 // grp_off / grp_members (optional): the index was built over DISTINCT rows; results are expanded to the original rows (member lists
 // as build_groups makes them), full_db = all rows, for the brute-force fallback

@@ -855,9 +855,16 @@ void knn_index_destroy(tm_knn_index_impl *ix) { delete ix; }
 
 // everything a search needs before the scan: digit plan (database repacked if the batch widens it), both sides sorted along
 // the curve and packed in MFMA fragment order
-static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream) {
+static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, hipStream_t stream, const void *query_colmm = nullptr) {
   ColStats qs;
   bool fresh_radial = false;  // the queries' radial coordinates were computed while the index was being built
+  if (query_colmm) {  // the producer of the queries kept their column ranges
+    int res[384];
+    TM_HIP(hipMemcpyAsync(res, query_colmm, sizeof(res), hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    memcpy(qs.mn, res, sizeof(int) * 192);
+    memcpy(qs.mx, res + 192, sizeof(int) * 192);
+  } else
   TM_TRY(col_stats(queries, nq, &qs, ix->scratch, stream));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   TM_HIP(hipMemsetAsync(ix->err_flag.p, 0, sizeof(int), stream));  // both pack passes below report into it
@@ -962,7 +969,7 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
   return TM_OK;
 }
 
-int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream) {
+int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream, const void *query_colmm) {
   TM_CHECK(ix != nullptr, TM_E_INVAL, "knn: null index");
   TM_CHECK(nq >= 0, TM_E_INVAL, "knn: negative query count");
   if (nq == 0) return TM_OK;
@@ -971,7 +978,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     TM_HIP(hipMemsetAsync(out_err, 0xff, (size_t)nq * 4, stream));
     return TM_OK;
   }
-  TM_TRY(prepare_search(ix, queries, nq, stream));
+  TM_TRY(prepare_search(ix, queries, nq, stream, query_colmm));
   const int64_t nqt = (nq + 31) / 32, ntt = (ix->nt + 31) / 32;
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
