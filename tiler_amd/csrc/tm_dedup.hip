@@ -128,11 +128,30 @@ __global__ void k_merge_runs(const uint32_t *__restrict__ sorted, const uint32_t
                              const uint32_t *__restrict__ head_excl, const uint32_t *__restrict__ head, int64_t n,
                              const uint32_t *__restrict__ use_in, uint32_t *__restrict__ rep, uint32_t *__restrict__ use_rep,
                              uint32_t *__restrict__ uniq) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t row = sorted[i], r = sorted[headpos_scanned[i]];
-    rep[row] = r;
-    atomicAdd(&use_rep[r], use_in ? use_in[row] : 1u);
-    if (head[i]) uniq[head_excl[i]] = r;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x; i0 < n; i0 += stride) {  // (workgroup-uniform bound: every lane reaches the ballot)
+    const int64_t i = i0 + threadIdx.x;
+    const bool in = i < n;
+    const uint32_t hp = in ? headpos_scanned[i] : 0xffffffffu;
+    const uint32_t row = in ? sorted[i] : 0u, r = in ? sorted[hp] : 0u;
+    if (in) {
+      rep[row] = r;
+      if (head[i]) uniq[head_excl[i]] = r;
+    }
+    if (use_in) {
+      if (in) atomicAdd(&use_rep[r], use_in[row]);
+    } else {
+      // rows of a run are neighbours here: the part of a run inside a wave adds its length with one atomic (a flat tile's run is a tenth of
+      // the clip, and its counter would take every one of those atomics in turn)
+      const uint32_t prev = (uint32_t)__shfl_up((int)hp, 1);
+      const bool first = lane == 0 || hp != prev;
+      const unsigned long long firsts = __ballot(first);
+      if (first && in) {
+        const unsigned long long rest = lane == 63 ? 0ull : firsts >> (lane + 1);
+        atomicAdd(&use_rep[r], (uint32_t)(rest ? __ffsll((long long)rest) : 64 - lane));
+      }
+    }
   }
 }
 
