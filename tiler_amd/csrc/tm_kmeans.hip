@@ -1002,12 +1002,14 @@ struct Seg3State {      // zeroed before the launch
   u64 cnts[P3_MAXK];
   u64 pick[P3_MAXK];
   unsigned bar, changed[3], timeout, pad[3];
+  alignas(128) unsigned rel;  // the barrier's release word, in a line of its own: the waiting workgroups poll IT, so their loads do not queue up with the arrivals' atomics on `bar`
+  unsigned pad2[31];
 #if TM_KM3_STAMPS
   u64 stamps[8];  // diagnostic build: s_memtime spans of workgroup 0's phases, summed over the iterations
 #endif
 };
 
-__device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsigned nblk, unsigned *timeout) {
+__device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned *rel, unsigned &epoch, unsigned nblk, unsigned *timeout) {
   // every thread of the workgroup calls it; false: the spin gave up (a workgroup of the segment is not resident), the caller leaves
   __shared__ int s_ok;
   __syncthreads();
@@ -1016,9 +1018,11 @@ __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned &epoch, unsig
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epoch++;
     const unsigned target = epoch * nblk;
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the last to arrive publishes the epoch; everybody else polls that word (arrivals are counted on `bar`, which nobody reads in a loop)
+    if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == target)
+      __hip_atomic_store(rel, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
-    for (unsigned spins = 1; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+    for (unsigned spins = 1; __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
       __builtin_amdgcn_s_sleep(1);
       if ((spins & 255u) == 0 && (spins > (1u << 24) || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  // (a second round trip: rarely)
         __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1100,7 +1104,7 @@ __global__ __launch_bounds__(P3_NT, 3) void k_kmeans3_persistent(const int32_t *
       for (int wv = 1; wv < P3_NT / 64; wv++) best = s_red[wv] > best ? s_red[wv] : best;
       if (best >> 32) atomicMax(&st->pick[c], best);
     }
-    if (!p3_barrier(&st->bar, epoch, nbx, &st->timeout)) return;
+    if (!p3_barrier(&st->bar, &st->rel, epoch, nbx, &st->timeout)) return;
     const u64 win = __hip_atomic_load(&st->pick[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((win >> 32) == 0) break;  // no distinct point left
     const int32_t *pc = pts + (sg.begin + (int64_t)(0xffffffffu - (uint32_t)win)) * 3;
@@ -1261,7 +1265,7 @@ __global__ __launch_bounds__(P3_NT, 3) void k_kmeans3_persistent(const int32_t *
     }
     if (tid == 0 && s_chg) atomicAdd(&st->changed[it % 3], (unsigned)s_chg);
     P3_STAMP(4);  // flush
-    if (!p3_barrier(&st->bar, epoch, nbx, &st->timeout)) return;
+    if (!p3_barrier(&st->bar, &st->rel, epoch, nbx, &st->timeout)) return;
     P3_STAMP(5);  // barrier of the segment's workgroups
     // (the three loads leave together: one round trip instead of three)
     const int uc = min(tid / 3, P3_MAXK - 1), uj = tid - (tid / 3) * 3;
