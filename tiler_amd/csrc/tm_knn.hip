@@ -735,13 +735,11 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
   // bitonic sort of the keys (one wave): (SSD, index of the row / of the distinct row's first occurrence) ascending
   for (int ks = 2; ks <= n2; ks <<= 1)
     for (int j = ks >> 1; j > 0; j >>= 1) {
-      for (int i = lane; i < n2; i += 64) {
-        const int o = i ^ j;
-        if (o > i) {
-          const unsigned long long a = s_key[i], b = s_key[o];
-          const bool up = (i & ks) == 0;
-          if ((a > b) == up) { s_key[i] = b; s_key[o] = a; }
-        }
+      for (int t = lane; t < (n2 >> 1); t += 64) {  // a lane per compare-exchange: the lower element of pair t (every lane works, not every other one)
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), o = i | j;
+        const unsigned long long a = s_key[i], b = s_key[o];
+        const bool up = (i & ks) == 0;
+        if ((a > b) == up) { s_key[i] = b; s_key[o] = a; }
       }
       __syncthreads();
     }
