@@ -38,6 +38,7 @@ struct KnnPlan {
   int16_t centre[192];    // per source column
   int16_t perm[192];      // packed position -> source column (columns with high digits first, nested sets)
   int nbig_t = 192, nbig_q = 192;
+  int tscale = 1;         // database digits are those of tscale * (t - c): 2 lets the scan's chain deliver 2 X without a final doubling
 };
 
 __host__ __device__ inline int knn_tile_bytes(int hch, int with_box) { return (6 + hch) * 1024 + 128 + (with_box ? 64 : 0); }
@@ -82,7 +83,8 @@ struct CurveSpec {
 // Pack n rows into MFMA fragment order: per 32-row tile [kc][64 lanes][16 B] (lane = half*32 + row) followed by
 // 32 u32 norms.  negate=1 (query side): digits of (c - v) and norm >> 1; negate=0 (database): digits of (v - c).
 // Rows >= n replicate row n-1 (ties resolve to the lower, real index).  err_flag is set if a digit overflows int8.
-__global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ feat, int64_t n, int64_t ntiles, int hch, int negate,
+// scale (database side, KnnPlan::tscale): the digits are those of scale * (v - c); the norms stay those of v - c.
+__global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ feat, int64_t n, int64_t ntiles, int hch, int negate, int scale,
                                                   const int16_t *__restrict__ centre, const int16_t *__restrict__ perm,
                                                   const uint32_t *__restrict__ rowperm, int with_box, CurveSpec cs,
                                                   int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
@@ -169,13 +171,13 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
         const int kpos = kc * 32 + half * 16 + b;  // byte position along K
         int digit;
         if (kpos < 192) {
-          const int v = s_v[r][kpos];
+          const int v = s_v[r][kpos] * scale;
           digit = ((v + 128) & 255) - 128;  // low digit in [-128,127]
           if (kpos >= hch * 32) {           // column without a high digit: must fit
             if (v != digit) bad = true;
           }
         } else {
-          const int v = s_v[r][kpos - 192];
+          const int v = s_v[r][kpos - 192] * scale;
           const int lo = ((v + 128) & 255) - 128;
           digit = (v - lo) >> 8;
           if (digit < -128 || digit > 127) bad = true;
@@ -482,8 +484,9 @@ static void merge_stats(ColStats &a, const ColStats &b) {
 
 // Per-side digit plan.  For every column pick the centre (midpoint of the query range, of the union or of the database)
 // that needs the fewest int8 products, then nest the smaller big-set into the larger one so both are prefixes.
-static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
+static int make_plan_scaled(const ColStats &ts, const ColStats &qs, KnnPlan *plan, int tscale) {
   bool tb[192], qb[192];
+  plan->tscale = tscale;
   for (int c = 0; c < 192; c++) {
     int tlo = ts.mn[c], thi = ts.mx[c], qlo = qs.mn[c], qhi = qs.mx[c];
     if (tlo > thi) { tlo = qlo; thi = qhi; }
@@ -497,7 +500,7 @@ static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
     bool bt = true, bq = true;
     for (int k = 0; k < 3; k++) {
       const int cc = cand[k];
-      const bool t2 = (thi - cc > 127) || (cc - tlo > 127), q2 = (qhi - cc > 127) || (cc - qlo > 127);
+      const bool t2 = (tscale * (thi - cc) > 127) || (tscale * (cc - tlo) > 127), q2 = (qhi - cc > 127) || (cc - qlo > 127);
       const int cost = 1 + (t2 ? 1 : 0) + (q2 ? 1 : 0) + (t2 && q2 ? 1 : 0);
       if (cost < best_cost) { best_cost = cost; best_c = cc; bt = t2; bq = q2; }
     }
@@ -524,11 +527,11 @@ static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
 }
 
 // does `plan` represent every value of one side's statistics exactly?  (both signs are checked: queries are negated)
-static bool plan_covers(const KnnPlan &plan, const ColStats &st, int hch) {
+static bool plan_covers(const KnnPlan &plan, const ColStats &st, int hch, int scale = 1) {
   for (int p = 0; p < 192; p++) {
     const int c = plan.perm[p];
     if (st.mn[c] > st.mx[c]) continue;
-    const int lo = st.mn[c] - plan.centre[c], hi = st.mx[c] - plan.centre[c];
+    const int lo = scale * (st.mn[c] - plan.centre[c]), hi = scale * (st.mx[c] - plan.centre[c]);
     if (p >= hch * 32) {
       if (lo < -127 || hi > 127) return false;
     } else {
@@ -536,6 +539,22 @@ static bool plan_covers(const KnnPlan &plan, const ColStats &st, int hch) {
     }
   }
   return true;
+}
+
+// The database digits doubled whenever the doubled values still fit two digits and cost no more products than the plain plan
+// (TM_KNN_TSCALE=1 keeps the plain plan for A/B runs): the scan's block epilogue is 16 vector instructions shorter with them.
+static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
+  const char *e = getenv("TM_KNN_TSCALE");
+  if (!(e && atoi(e) == 1)) {
+    KnnPlan p2, p1;
+    make_plan_scaled(ts, qs, &p2, 2);
+    make_plan_scaled(ts, qs, &p1, 1);
+    auto cost = [](const KnnPlan &p) { return p.ht + p.hq + std::min(p.ht, p.hq); };
+    if (plan_covers(p2, ts, p2.ht, 2) && plan_covers(p2, qs, p2.hq) && (cost(p2) <= cost(p1) || (e && atoi(e) == 2))) { *plan = p2; return TM_OK; }
+    *plan = p1;
+    return TM_OK;
+  }
+  return make_plan_scaled(ts, qs, plan, 1);
 }
 
 struct tm_knn_index_impl {
@@ -604,12 +623,13 @@ static int sort_by_curve(tm_knn_index_impl *ix, const DevBuf &ccol, int64_t n, c
 
 static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int negate, int hch, const DevBuf &perm, int with_box,
                     DevBuf &out, hipStream_t stream) {
+  const int scale = negate ? 1 : ix->plan.tscale;
   const int64_t ntiles = (n + 31) / 32;
   TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch, with_box)));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   if (negate) TM_TRY(ix->qmeta.alloc((size_t)std::max<int64_t>(ntiles, 1) * 16 * 4));
   int grid = (int)std::min<int64_t>(ntiles, 4096);
-  hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate,
+  hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate, scale,
                      ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, perm.as<uint32_t>(), with_box, ix->curve,
                      ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>(), negate ? ix->qmeta.as<int>() : nullptr);
   TM_HIP(hipGetLastError());
@@ -879,11 +899,11 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
   }
   if (!ix->packed || !plan_covers(ix->plan, qs, ix->plan.hq)) {
     TM_TRY(make_plan(ix->tstats, qs, &ix->plan));
-    TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
+    TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht, ix->plan.tscale) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
              "knn: feature range exceeds the exact two-digit int8 split");
     if (getenv("TM_KNN_DEBUG"))
-      fprintf(stderr, "[tm_knn] nq=%lld nt=%lld big columns: database %d, queries %d -> HT=%d HQ=%d K=%d bytes\n", (long long)nq,
-              (long long)ix->nt, ix->plan.nbig_t, ix->plan.nbig_q, ix->plan.ht, ix->plan.hq,
+      fprintf(stderr, "[tm_knn] nq=%lld nt=%lld big columns: database %d (digits x%d), queries %d -> HT=%d HQ=%d K=%d bytes\n", (long long)nq,
+              (long long)ix->nt, ix->plan.nbig_t, ix->plan.tscale, ix->plan.nbig_q, ix->plan.ht, ix->plan.hq,
               192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq)));
     TM_TRY(upload_plan(ix, stream));
     {  // curve + box columns: the KNN_ND widest columns of the union; the first three drive the Morton order
@@ -1006,7 +1026,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
     a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
     a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
-    a.prune = prune; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
+    a.prune = prune; a.tdouble = ix->plan.tscale == 2; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
     a.n_groups = (nqt + ns - 1) / ns;
     {
       static int ncu = 0;  // one persistent workgroup per CU
@@ -1017,14 +1037,17 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
         TM_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = std::max(1, prop.multiProcessorCount);
       }
-      a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)ncu * (16 / K2_NW));
+      a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)ncu * K2_WGS);
     }
     a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
     launch_scan2(ix->plan.ht, ix->plan.hq, a, stream);
   } else
-  launch_mfma(ix->plan.ht, ix->plan.hq,
-              KnnLaunch{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
-                        ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt, stats, stream});
+  {
+    KnnLaunch l{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
+                ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt, stats, stream};
+    l.tshift = ix->plan.tscale == 2 ? 0 : 1;
+    launch_mfma(ix->plan.ht, ix->plan.hq, l);
+  }
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
@@ -1038,9 +1061,9 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     TM_HIP(hipGetLastError());
   }
   int flag = 0;
-  unsigned long long cnt[16] = {0};
+  unsigned long long cnt[32] = {0};
   TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 128, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 256, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   float ms = 0;
@@ -1063,6 +1086,13 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     static const char *names2[10] = {"prologue", "list building", "consume seeds", "consume lists", "end-of-list wait (seeds)", "end-of-list wait (lists)",
                                      "  of consume: pop next", "  of consume: pop + tile landed", "results", "total"};
     for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn2 stamps] %-32s %6.2f %% of wave time\n", names2[i], 100.0 * (double)cnt[6 + i] / (double)cnt[15]);
+    {  // inside the consume loop (cnt[20..27] = stats[18..25])
+      const double blocks = (double)std::max<unsigned long long>(1, cnt[2]), steps = (double)std::max<unsigned long long>(1, cnt[25] + cnt[26]);
+      fprintf(stderr, "[tm_knn2 stamps] per block: wave time %.0f cycles; per step (%llu single, %llu pairs): top %.0f, chain %.0f, epilogue %.0f cycles; "
+                      "update branch in %.1f %% of blocks, refresh in %.2f %%; tile load issue %.0f cycles per tile\n",
+              (double)cnt[15] / blocks, cnt[25], cnt[26], (double)cnt[20] / steps, (double)cnt[21] / steps, (double)cnt[22] / steps,
+              100.0 * (double)cnt[23] / blocks, 100.0 * (double)cnt[24] / blocks, (double)cnt[27] / (double)std::max<unsigned long long>(1, cnt[3]));
+    }
   }
 #endif
 #if TM_KNN_STAMPS
@@ -1145,6 +1175,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
+  a.tshift = ix->plan.tscale == 2 ? 0 : 1;
   {  // few queries left: their few workgroups would each stage most of the database one after the other -- share the tile list
     const int64_t wgs = (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW);
     a.split = wgs >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(wgs, 1)));

@@ -26,9 +26,13 @@ namespace tmx {
 #ifndef TM_KNN2_WAVES
 #define TM_KNN2_WAVES 16  // 16: one workgroup per CU; 8: two (half the LDS each, fewer sub-tiles per group)
 #endif
+#ifndef TM_KNN2_WGS
+#define TM_KNN2_WGS (16 / TM_KNN2_WAVES)  // workgroups per CU (they split its LDS)
+#endif
 constexpr int K2_NW = TM_KNN2_WAVES;
 constexpr int K2_NT = K2_NW * 64;
-constexpr int K2_LDS = 163840 / (16 / K2_NW);
+constexpr int K2_WGS = TM_KNN2_WGS;
+constexpr int K2_LDS = 163840 / K2_WGS;
 constexpr int K2_LCAP = K2_NT;        // list entries: one chunk of tile slots always fits
 #ifndef TM_KNN2_BREAK
 #define TM_KNN2_BREAK (K2_LCAP / 2)
@@ -37,13 +41,32 @@ constexpr int K2_LCAP = K2_NT;        // list entries: one chunk of tile slots a
 #define TM_KNN2_SEEDS 8
 #endif
 constexpr int K2_SEEDS = TM_KNN2_SEEDS;  // tiles around the group's position on the curve, visited first by every sub-tile
-constexpr int K2_XCD_RUN = 32 * (16 / K2_NW);  // workgroups that run together on one XCD
+constexpr int K2_XCD_RUN = 32 * K2_WGS;  // workgroups that run together on one XCD
+#ifndef TM_KNN2_FAST_ISQRT
+#define TM_KNN2_FAST_ISQRT 1
+#endif
+#ifndef TM_KNN2_QNT
+#define TM_KNN2_QNT 0  // 2: the group's query operands are fetched with the non-temporal hint (read once per group: they need not displace tiles in L2)
+#endif
+#ifndef TM_KNN2_PAIR
+#define TM_KNN2_PAIR 0  // 1: two blocks (sub-tiles) of a tile in flight per wave
+#endif
+#ifndef TM_KNN2_REFRESH
+#define TM_KNN2_REFRESH 1  // when a sub-tile's bound is made anew: 0 on every improvement, 1 when the improved query may have held the maximum, 2 = 1 + every eighth block
+#endif
 #ifndef TM_KNN2_STAMPS
 #define TM_KNN2_STAMPS 0  // diagnostic build: s_memtime spans of the phases, summed over all waves into stats[4..]
 #endif
 #if TM_KNN2_STAMPS
 #define K2_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#define K2_FS(i, expr) do { fs[i] += (expr); } while (0)
+#define K2_NOW() __builtin_amdgcn_s_memtime()
+// the time after which a vector result is there: an instruction that reads it, issued in order before the clock is read
+#define K2_AFTER(v) do { const int d_ = __builtin_amdgcn_readfirstlane(v); asm volatile("" :: "s"(d_)); } while (0)
 #else
+#define K2_FS(i, expr) do { } while (0)
+#define K2_NOW() 0ull
+#define K2_AFTER(v) do { } while (0)
 #define K2_STAMP(i) do { } while (0)
 #endif
 
@@ -60,6 +83,7 @@ struct Knn2Args {
   const uint8_t *qpack; int64_t n_qtiles, nq;
   const int *qmeta;   // [n_qtiles][16]: box lo[7], home tile, box hi[7], pad
   int prune;
+  int tdouble;        // the database pack holds the digits of 2 (t - c)
   int *best_key, *best_tile;
   unsigned long long *stats;  // [0] (tile, sub-tile) blocks evaluated, [1] tiles read, [2] exact (query, row) pairs, [3] list entries
   int64_t n_groups;
@@ -67,27 +91,111 @@ struct Knn2Args {
   unsigned *tickets;  // [8] zeroed before the launch: next run-slot of each XCD's share of the groups
 };
 
-__device__ __forceinline__ unsigned k2_wave_umax(unsigned x) {
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
-  return max(max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
-             max((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
+__device__ __forceinline__ unsigned k2_wave_umax(unsigned x) {  // max over lanes 0..31 (every lane of a row of 16 ends with its row's)
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true));
+  return max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16));
 }
 
 // a fresh look at an LDS word other waves update (relaxed workgroup-scope load: a plain ds_read_b32 the compiler may not cache)
 __device__ __forceinline__ unsigned k2_peek(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// largest r with r * r <= x (x < 2^31)
+// largest r with r * r <= x (x < 2^31): the hardware's approximate root (within one unit of the last place, i.e. well within one of
+// the integer root here) set right by one step either way -- the correctly rounded sqrtf costs a dozen instructions more per test
 __device__ __forceinline__ unsigned k2_isqrt(unsigned x) {
+#if TM_KNN2_FAST_ISQRT
+  unsigned r = (unsigned)__builtin_amdgcn_sqrtf((float)x);
+  r += ((r + 1u) * (r + 1u) <= x) ? 1u : 0u;
+  r -= (r * r > x) ? 1u : 0u;
+  return r;
+#else
   unsigned r = (unsigned)sqrtf((float)x);
   r -= (r * r > x) ? 1u : 0u;
   r -= (r * r > x) ? 1u : 0u;
   return r;
+#endif
 }
 
-template <int HT, int HQ>
+// One block's chain: X over the digit products on one accumulator shifted between the phases (tm_knn_kernel.h); with TD the rows' own
+// term rides in on the second shift.  `q` = the sub-tile's B operands in LDS at this lane's 16 bytes.
+template <int HT, int HQ, bool TD>
+__device__ __forceinline__ v16i k2_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q) {
+  constexpr int HM = HT < HQ ? HT : HQ;
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0;
+  if (TD && HT + HQ == 0) acc = ntr;  // a single phase: the rows' term is the chain's starting value
+  if (HM > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HM; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+  }
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HQ; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
+#pragma unroll
+    for (int kc = 0; kc < HT; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+  }
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);              // T_L . Q_L
+  return acc;
+}
+
+// Two blocks of one tile at once: the phases of the two chains alternate, so that one chain's shifts (and the wait for the results they
+// read) run under the other chain's products -- a wave on its own keeps the matrix pipe fed through both chains instead of leaving it to
+// the other waves of its SIMD between the phases.
+template <int HT, int HQ, bool TD>
+__device__ __forceinline__ void k2_chain2(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *qa, const uint8_t *qb, v16i &A, v16i &B) {
+  constexpr int HM = HT < HQ ? HT : HQ;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { A[r] = 0; B[r] = 0; }
+  if (TD && HT + HQ == 0) { A = ntr; B = ntr; }
+  if (HM > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HM; kc++) A = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qa + (6 + kc) * 1024), A, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < HM; kc++) B = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), B, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) A[r] = (int)((unsigned)A[r] << 8);
+  }
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HQ; kc++) A = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qa + (6 + kc) * 1024), A, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < HT; kc++) A = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qa + kc * 1024), A, 0, 0, 0);
+    if (HM > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) B[r] = (int)((unsigned)B[r] << 8);
+    }
+#pragma unroll
+    for (int kc = 0; kc < HQ; kc++) B = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), B, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < HT; kc++) B = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), B, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) A[r] = (int)(((unsigned)A[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+  }
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++) A = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qa + kc * 1024), A, 0, 0, 0);
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) B[r] = (int)(((unsigned)B[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+  }
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++) B = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), B, 0, 0, 0);
+}
+
+// TD: the database digits are those of 2 (t - c) (KnnPlan::tscale = 2), so the chain yields 2 X at once and the rows' own term
+// |t-c|^2 rides in on the second digit shift (one v_lshl_add_u32 per register instead of a shift there and a shift-add at the end)
+template <int HT, int HQ, bool TD>
 __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   constexpr int KT = 6 + HT, KQ = 6 + HQ, HM = HT < HQ ? HT : HQ, ND = KNN_ND;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
@@ -112,6 +220,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
 #if TM_KNN2_STAMPS
   unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  unsigned long long fs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // inside the consume loop: [0] block top, [1] chain(s), [2] epilogue(s), [3] blocks that enter the update branch, [4] refreshes, [5] single blocks, [6] pairs, [7] tile load issue
   const unsigned long long st_begin = st_last;
 #endif
   // Persistent workgroups (one per CU): a workgroup draws query groups until none is left, so that no CU waits for a 16-wave
@@ -146,7 +255,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
     const int64_t st = min(st0 + s, a.n_qtiles - 1);
     const uint8_t *src = a.qpack + st * (int64_t)Q_BYTES + kc * 1024 + lane * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(lds + piece * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)(lds + piece * 1024), 16, 0, TM_KNN2_QNT);
   }
   for (int i = tid; i < NS * 32; i += NT) {
     const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
@@ -325,17 +434,19 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
       bool have = next_entry(tile, lbv, mask);
       while (have) {
         // the tile's MFMA A operands and norms, straight into registers
+        const unsigned long long fl0 = K2_NOW();
         const uint8_t *tb = a.tpack + (int64_t)tile * T_BYTES;
         v4i T[KT];
 #pragma unroll
         for (int kc = 0; kc < KT; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
-        int ntr[16];  // |t-c|^2 of accumulator row r: (r&3) + 8*(r>>2) + 4*half
+        v16i ntr;  // |t-c|^2 of accumulator row r: (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
         for (int q4 = 0; q4 < 4; q4++) {
           const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
           ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
         }
         nloads++;
+        K2_FS(7, K2_NOW() - fl0);
         // the entry after this one is chosen while the loads fly
         int ntile = 0, nlb = 0;
         unsigned nmask = 0;
@@ -349,73 +460,112 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
         st_acc[7] += __builtin_amdgcn_s_memtime() - tp0;  // ... until the tile has landed
 #endif
         const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
+        // a block's epilogue: the row minimum of each query against its running best
+        auto epilogue = [&](const int s, const v16i &acc) {
+          // d'' = 2 X + |t-c|^2 + 2 (|q-c|^2 >> 1) = SSD - parity (X: the chain over undoubled digits; with TD the chain holds 2 X + |t-c|^2
+          // already); the row minimum is taken without the query's own term
+          int t[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
+          const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
+                             min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
+          const int qi = s * 32 + (lane & 31);
+          const unsigned key_hi = (unsigned)tm + (unsigned)s_qn[qi] + 1u;  // d'' + 1 >= 0
+          const unsigned cur_hi = k2_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1);
+          bool refresh = false;
+          K2_FS(3, __builtin_amdgcn_ballot_w64(key_hi <= cur_hi) ? 1 : 0);
+          if (key_hi <= cur_hi) {
+            // which row (the first one reaching the minimum), and is it alone: a compare, a select and an add-with-carry per register
+            int ridx = 0;
+            unsigned cnt = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; r--) {
+              const bool e = t[r] == tm;
+              ridx = e ? r : ridx;
+              cnt += e ? 1u : 0u;
+            }
+            const int row = (ridx & 3) + ((ridx & 12) << 1) + 4 * half;
+            const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
+            const unsigned sm_now = k2_peek(&s_smax[s]);  // (its latency rides with the atomic's)
+            const unsigned long long pre = atomicMin(&s_best[qi], key);
+            const unsigned pre_hi = (unsigned)(pre >> 32);
+            if (pre_hi == key_hi || cnt > 1) atomicMin(&s_tie[qi], key_hi);  // the value was reached a second time
+            // The sub-tile's largest best can only have moved if this query held it: its old best is then no smaller than what the
+            // published bound was made from ((bound - 3)^2; a bound of 0xFFFE stands for "some query has no best yet").  A refresh
+            // skipped by a race only leaves the bound loose (and is made good at the end of the list).
+            const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
+#if TM_KNN2_REFRESH == 0
+            refresh = key_hi < pre_hi;
+#elif TM_KNN2_REFRESH == 1
+            refresh = key_hi < pre_hi && pre_hi >= thr;
+#else
+            refresh = key_hi < pre_hi && (pre_hi >= thr || (nblocks & 7) == 0);
+#endif
+          }
+          if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
+            K2_FS(4, 1);
+            const unsigned h = k2_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1);
+            const unsigned mx = k2_wave_umax(h);  // = largest d'' + 1 = the SSD bound the box test compares with
+            if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], min(0xFFFEu, (unsigned)__builtin_amdgcn_sqrtf((float)mx) + 3u));
+          }
+          nblocks++;
+          npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+        };
         while (mask) {
+          const unsigned long long f0 = K2_NOW();
+#if TM_KNN2_PAIR
+          {  // the sub-tiles' bests may have tightened since the entry was popped: one fresh look at all of them
+            const int sm = lane < NS ? (int)k2_peek(&s_smax[lane]) : -1;
+            mask &= (unsigned)__builtin_amdgcn_ballot_w64(lbv <= sm);
+            if (!mask) break;
+          }
+          const int sa = __builtin_ctz(mask);
+          mask &= mask - 1;
+          if (mask) {  // two blocks of the tile at once
+            const int sb = __builtin_ctz(mask);
+            mask &= mask - 1;
+            v16i accA, accB;
+            const unsigned long long f1 = K2_NOW();
+            k2_chain2<HT, HQ, TD>(T, ntr, lds + sa * (KQ * 1024) + lane * 16, lds + sb * (KQ * 1024) + lane * 16, accA, accB);
+            K2_AFTER(accB[0]);
+            const unsigned long long f2 = K2_NOW();
+            epilogue(sa, accA);
+            epilogue(sb, accB);
+            K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(6, 1);
+          } else {
+            const unsigned long long f1 = K2_NOW();
+            const v16i acc = k2_chain<HT, HQ, TD>(T, ntr, lds + sa * (KQ * 1024) + lane * 16);
+            K2_AFTER(acc[0]);
+            const unsigned long long f2 = K2_NOW();
+            epilogue(sa, acc);
+            K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(5, 1);
+          }
+#else
           const int s = __builtin_ctz(mask);
           mask &= mask - 1;
           // the sub-tile's best may have tightened since the entry was popped
           const int lbs = __builtin_amdgcn_readlane(lbv, s);
           const int sms = __builtin_amdgcn_readfirstlane((int)k2_peek(&s_smax[s]));
-          if (lbs > sms) continue;
-          const uint8_t *qb = lds + s * (KQ * 1024) + lane * 16;
-          v16i acc;
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[r] = 0;
-          if (HM > 0) {
-#pragma unroll
-            for (int kc = 0; kc < HM; kc++)
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
-          }
-          if (HT + HQ > 0) {
-#pragma unroll
-            for (int kc = 0; kc < HQ; kc++)
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
-#pragma unroll
-            for (int kc = 0; kc < HT; kc++)
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
-          }
-#pragma unroll
-          for (int kc = 0; kc < 6; kc++)
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(qb + kc * 1024), acc, 0, 0, 0);              // T_L . Q_L
-          // d'' = 2 acc + |t-c|^2 + 2 (|q-c|^2 >> 1) = SSD - parity; the row minimum is taken without the query's own term
-          int t[16];
-          int tm = INT_MAX;
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            t[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
-            tm = min(tm, t[r]);
-          }
-          const int qi = s * 32 + (lane & 31);
-          const unsigned key_hi = (unsigned)tm + (unsigned)s_qn[qi] + 1u;  // d'' + 1 >= 0
-          const unsigned cur_hi = k2_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1);
-          bool improved = false;
-          if (key_hi <= cur_hi) {
-            int row = 0, cnt = 0;
-#pragma unroll
-            for (int r = 15; r >= 0; r--)
-              if (t[r] == tm) { row = (r & 3) + 8 * (r >> 2) + 4 * half; cnt++; }
-            const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
-            const unsigned long long pre = atomicMin(&s_best[qi], key);
-            const unsigned pre_hi = (unsigned)(pre >> 32);
-            if (pre_hi == key_hi || cnt > 1) atomicMin(&s_tie[qi], key_hi);  // the value was reached a second time
-            improved = key_hi < pre_hi;
-          }
-          if (__builtin_amdgcn_ballot_w64(improved)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
-            const unsigned h = k2_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1);
-            const unsigned mx = k2_wave_umax(h);  // = largest d'' + 1 = the SSD bound the box test compares with
-            if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], min(0xFFFEu, (unsigned)sqrtf((float)mx) + 2u));
-          }
-          nblocks++;
-          npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+          if (lbs > sms) { K2_FS(0, K2_NOW() - f0); continue; }
+          const unsigned long long f1 = K2_NOW();
+          const v16i acc = k2_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16);
+          K2_AFTER(acc[0]);
+          const unsigned long long f2 = K2_NOW();
+          epilogue(s, acc);
+          K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(5, 1);
+#endif
         }
         tile = ntile; lbv = nlb; mask = nmask; have = nhave;
       }
     }
     K2_STAMP(round < 0 ? 2 : 3);  // consuming: seeds / lists
     __syncthreads();
+#if TM_KNN2_REFRESH != 0
+    for (int s = wave; s < nvalid; s += NW) {  // every sub-tile's bound made anew from its bests: what the races of the refresh rule above left loose ends here
+      const unsigned mx = k2_wave_umax(k2_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1));
+      if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], min(0xFFFEu, (unsigned)__builtin_amdgcn_sqrtf((float)mx) + 3u));
+    }
+#endif
     K2_STAMP(round < 0 ? 4 : 5);  // waiting for the other waves at the end of a list
     if (round >= 0 && (prune ? (run_batch >= n_run_batches && run_k >= run_alive) : chunk >= n_chunks)) break;
     round++;
@@ -436,6 +586,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
   K2_STAMP(8);  // results
   if (a.stats && lane == 0) {
     for (int i = 0; i < 9; i++) atomicAdd(a.stats + 4 + i, st_acc[i]);
+    for (int i = 0; i < 8; i++) atomicAdd(a.stats + 18 + i, fs[i]);  // (bytes 160.. of the counters: behind the group tickets)
     atomicAdd(a.stats + 13, __builtin_amdgcn_s_memtime() - st_begin);
   }
 #endif
@@ -451,8 +602,13 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
 template <int HT> void knn2_launch_ht(int hq, const Knn2Args &a, hipStream_t stream);
 int knn2_sub_tiles(int hq);  // NS of the queries' digit plan
 
+#define TM_KNN2_LAUNCH(HT, HQ)                                                                          \
+  do {                                                                                                 \
+    if (a.tdouble) hipLaunchKernelGGL((k_knn_scan2<HT, HQ, true>), grid, block, 0, stream, a);         \
+    else hipLaunchKernelGGL((k_knn_scan2<HT, HQ, false>), grid, block, 0, stream, a);                  \
+  } while (0)
 #define TM_KNN2_CASE(HT, HQ) \
-  case HQ: hipLaunchKernelGGL((k_knn_scan2<HT, HQ>), grid, block, 0, stream, a); break;
+  case HQ: TM_KNN2_LAUNCH(HT, HQ); break;
 
 #define TM_KNN2_DEFINE_HT(HT)                                                                         \
   template <> void knn2_launch_ht<HT>(int hq, const Knn2Args &a, hipStream_t stream) {               \
@@ -460,7 +616,7 @@ int knn2_sub_tiles(int hq);  // NS of the queries' digit plan
     switch (hq) {                                                                                     \
       TM_KNN2_CASE(HT, 0) TM_KNN2_CASE(HT, 1) TM_KNN2_CASE(HT, 2) TM_KNN2_CASE(HT, 3)                 \
       TM_KNN2_CASE(HT, 4) TM_KNN2_CASE(HT, 5)                                                         \
-      default: hipLaunchKernelGGL((k_knn_scan2<HT, 6>), grid, block, 0, stream, a);                   \
+      default: TM_KNN2_LAUNCH(HT, 6);                                                                 \
     }                                                                                                 \
   }
 

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
                                                           const uint32_t *__restrict__ qkey, int64_t nq, int prune,
                                                           int *__restrict__ best_key, int *__restrict__ best_tile,
                                                           unsigned long long *__restrict__ visited, int *__restrict__ tau,
-                                                          uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap, int cand_k) {
+                                                          uint2 *__restrict__ cand, int *__restrict__ cand_cnt, int cand_cap, int cand_k,
+                                                          int tshift /* 1; 0 when the database digits are those of 2 (t - c) */) {
   // TOPK: collection mode for the k-nearest search (ann_kdtree_short_search_multi, tilingencoder.pas:1563): every
   // query has a fixed threshold (an upper bound of its k-th smallest SSD); pruning uses it instead of a running best, and
   // every row with d'' <= tau is appended to the query's candidate list (d'', sorted row).  The threshold also walks down a
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(KNN_NW * 64, TM_KNN_OCC) void k_knn_mfma(const uint
       int tm = INT_MAX;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        t[r] = (int)(((unsigned)acc[r] << 1) + (unsigned)nt[r]);
+        t[r] = (int)(((unsigned)acc[r] << tshift) + (unsigned)nt[r]);
         tm = min(tm, t[r]);
       }
       const int m = (int)((unsigned)tm + (unsigned)nq2[s]);
@@ -608,6 +609,7 @@ struct KnnLaunch {
   int *best_key, *best_tile; unsigned long long *visited; hipStream_t stream;
   int *tau = nullptr; uint2 *cand = nullptr; int *cand_cnt = nullptr; int cand_cap = 0, cand_k = 0;  // collection mode (k nearest)
   int split = 1;  // collection mode: workgroups per query group (they share its tile list)
+  int tshift = 1; // 0: the database pack holds the digits of 2 (t - c) (KnnPlan::tscale = 2)
 };
 
 // one per HT, defined in tm_knn_k<HT>.hip
@@ -617,7 +619,7 @@ template <int HT> void knn_launch_ht(int hq, const KnnLaunch &a);
 #define TM_KNN_LAUNCH(HT, HQ, TOPK)                                                                                        \
   hipLaunchKernelGGL((k_knn_mfma<HT, HQ, TOPK>), grid, block, 0, a.stream, a.tpack, a.n_ttiles, a.bx, a.qpack, a.n_qtiles,     \
                      a.queries, a.qperm, a.qkey, a.nq, a.prune, a.best_key, a.best_tile, a.visited, a.tau, a.cand, a.cand_cnt, \
-                     a.cand_cap, a.cand_k)
+                     a.cand_cap, a.cand_k, a.tshift)
 #define TM_KNN_CASE(HT, HQ)                                                   \
   case HQ:                                                                    \
     if (a.tau) TM_KNN_LAUNCH(HT, HQ, true); else TM_KNN_LAUNCH(HT, HQ, false); \
