@@ -69,7 +69,7 @@ def _collective_counts(enc, nsteps):
     return out
 
 
-def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0):
+def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0, threads=None):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, scaled to frames/s.  Three legs:
     1 thread with the brute-force search; every host core (one oracle call per thread: ctypes drops the GIL) with the brute force;
     every host core with the exact kd-tree (bucket 32) the reference searches with.  `value` is the fastest of them."""
@@ -82,7 +82,7 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     from tiler_amd import synth
     o = Oracle(so)
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = _host_threads(visible)
+    cores = threads or _host_threads(visible)
     tm_w, tm_h = (width - 1) // 8 + 1, (height - 1) // 8 + 1
     per = tm_w * tm_h
     fr = synth.video(2, width, height)
@@ -155,6 +155,8 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     best = max(allb, allk)
     return {
         "value": best, "unit": "frames/s", "cores": cores, "kind": "port", "host_cpus_visible": visible,
+        "cores_rule": "threads of the all-cores legs = TM_BENCH_THREADS if set, else the cgroup CPU quota of this process, else min(CPUs in the affinity mask, 16): "
+                      "a one-GPU box of the pool shows every CPU of its 8-GPU host in the mask but owns a 16-CPU share of it",
         "sample": (f"oracle (C restatement, gcc -O3) timed on: 1 frame load+Lab+mirrors, {per // 4} query feature vectors, 512 global tiles "
                    f"(cluster features + Thomas-Knoll dither + database features), exact dedup of {n_s} tiles (scaled n log n, one thread as "
                    f"TFPList.Sort), KNN of {nqn} queries x {t_distinct} distinct rows; scaled linearly to {per} tiles/frame and {t_global} "
@@ -181,7 +183,9 @@ def main():
     ap.add_argument("--no-motion-extra", action="store_true", help="skip the untimed extra pass with MotionPredictRadius=32")
     ap.add_argument("--no-defaults-extra", action="store_true",
                     help="skip the untimed extra passes with the extended palette usage on (alone, and with motion prediction)")
-    ap.add_argument("--no-h2d-extra", action="store_true", help="skip the second timed region with the clip in host memory")
+    ap.add_argument("--no-h2d-extra", action="store_true", help="skip the timed regions with the clip in host memory")
+    ap.add_argument("--no-frozen-extra", action="store_true",
+                    help="skip the extra pass on SURVEY.md 8(d)'s literal generator (no frozen tile columns, hence no exact inter-frame duplicates)")
     ap.add_argument("--no-dense-extra", action="store_true",
                     help="skip the dense diagnostic launch of the KNN kernel (under rocprofv3 --stats it would share the kernel's row with the pruned launches)")
     args = ap.parse_args()
@@ -282,9 +286,15 @@ def main():
         "dtype": "i8",
         "data": "synthetic",
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
-                               f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else ""),
+                               f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else "")
+                               + "; generator = SURVEY.md 8(d) plus ONE addition: the +f drift is frozen on every third tile column (tiler_amd/synth.py), which makes "
+                               + "%.1f %% of the frame tiles exact duplicates of another frame tile -- Reconstruct searches once per DISTINCT frame tile "
+                                 "(knn_queries of query_tiles); `without_frozen_columns` is the same step on the literal generator" % (100.0 * (1.0 - float(ks.get("queries", q_total)) / q_total)),
                    "frames": F, "tiles_per_frame": per, "query_tiles": q_total, "global_tiles_T": T,
                    "distinct_database_rows": int(ks["db_rows"]), "knn_queries": int(ks.get("queries", q_total)),
+                   "duplicate_frame_tiles_fraction": 1.0 - float(ks.get("queries", q_total)) / q_total,
+                   "value_is": "device-resident: RGB frames in HBM when the timed region starts; the H2D-inclusive figures of SURVEY.md 8(d) are `with_h2d` "
+                               "(upload inside Load) and `with_h2d_overlapped` (upload of the next clip beside this clip's steps)",
                    "final_tiles_after_reindex": int(c["tiles"]),
                    "input": "RGB frames resident in HBM when the timed region starts (with_h2d: in page-locked host memory)",
                    "parallelism": distributed.describe(world)},
@@ -301,15 +311,38 @@ def main():
                              "the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }
     if world == 1 and not args.no_h2d_extra:
-        # the same K steps with the clip in host memory: every Load moves 4*W*H*F bytes across PCIe (chunks beside its own kernel)
+        # the same K steps with the clip in host memory: every step is handed the clip anew (tm_set_frames_host lends it until that
+        # step's Load has returned) and its Load moves 4*W*H*F bytes across PCIe, chunks beside its own kernel
+        def timed_host(nsteps, overlapped):
+            if overlapped:
+                enc.PrefetchFramesHost(host_frames)  # the first timed step's clip: its upload belongs to the step before it
+            barrier()
+            t0 = time.perf_counter()
+            sm = np.zeros(8)
+            for _ in range(nsteps):
+                enc.SetFramesHost(host_frames)
+                if overlapped:
+                    enc.PrefetchFramesHost(host_frames)  # the NEXT clip starts crossing PCIe now, beside this clip's steps
+                step()
+                sm += enc.StageMs()
+            barrier()
+            return time.perf_counter() - t0, sm
         enc.SetFramesHost(host_frames)
         step()
-        dth, _, sth = timed(args.steps)
-        enc.SetFramesDevice(frames)
+        dth, sth = timed_host(args.steps, False)
         out["with_h2d"] = {"value": F * args.steps / dth, "unit": "frames/s", "ms_per_step": dth / args.steps * 1e3,
                            "h2d_bytes_per_step": 4 * W * H * F, "load_ms": float(sth[0]) / args.steps,
                            "pcie_gb_s_in_load": 4.0 * W * H * F / (float(sth[0]) / args.steps * 1e-3) / 1e9 if sth[0] > 0 else None,
-                           "note": "tm_set_frames_host: pinned host memory -> HBM inside Load (SURVEY.md 8d's H2D-included reading); never `value`"}
+                           "note": "tm_set_frames_host before every step: pinned host memory -> HBM inside Load (SURVEY.md 8d's H2D-included reading of one "
+                                   "clip on its own); never `value`"}
+        dto, sto = timed_host(args.steps, True)
+        out["with_h2d_overlapped"] = {"value": F * args.steps / dto, "unit": "frames/s", "ms_per_step": dto / args.steps * 1e3,
+                                      "h2d_bytes_per_step": 4 * W * H * F, "load_ms": float(sto[0]) / args.steps,
+                                      "note": "clips back to back: tm_prefetch_frames_host moves clip n+1 into a second device buffer on the copy stream while "
+                                              "clip n's steps run, and its Load adopts the copies -- every timed step still moves one whole clip across PCIe "
+                                              "(the one issued in the last step is drained inside the timed region); never `value`"}
+        torch.cuda.synchronize()
+        enc.SetFramesDevice(frames)
     if world == 1 and rank == 0:
         # the peaks measured on this very device: a bare loop of the kernel's MFMA instruction and an HBM stream triad
         tops, gbs = ctypes.c_double(), ctypes.c_double()
@@ -360,12 +393,20 @@ def main():
                         "nominal_ops": T * 64 * 64.0 * 16.0 * 9.0, "hbm_gb_s": T * 320 / st["dither"] / 1e6,
                         "note": "executed = planned pixels x 64 steps x PaletteSize compares x 9 operations (DESIGN.md section 5); `ms` is the stage's wall time, "
                                 "most of which is now Reconstruct's query-feature kernel running beside it on the second stream"}
-        it = enc.KmeansIters() if hasattr(enc, "KmeansIters") else None
-        if it:
-            b = 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * T * it["tile_iters"]
-            sr["kmeans"] = {"bound": "hbm", "kernel": "palettize (192-D) + quantize (3-D) Lloyd iterations", "achieved": b / st["prepare_palettes"] / 1e6, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": b / st["prepare_palettes"] / 1e6 / HBM_PEAK_GBS, "ms": st["prepare_palettes"], "algorithmic_bytes": b, **it,
-                            "note": "3 B per colour point and 768 B per tile point per iteration; the stage is bound by dependent launches, not bytes"}
+        it = enc.KmeansIters()
+        if it["tile_iters"] > 0:
+            # "HBM, points re-read each iteration" -- 3 B per pixel and iteration for the colours (the stage clusters the
+            # DISTINCT colours of a palette with their counts, which is the same arithmetic on fewer points: both figures are given),
+            # 768 B per tile and iteration for the 192-D clustering (its int32 features)
+            b_nominal = 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * it["tile_points"] * it["tile_iters"]
+            b_exec = 12.0 * it["pixel_colour_iters"] + 768.0 * it["tile_points"] * it["tile_iters"]
+            sr["kmeans"] = {"bound": "hbm", "kernel": "k_assign192 / k_h_bounds / k_assign192_list4 / k_h_update (192-D), k_kmeans3_persistent (colours)",
+                            "achieved": b_nominal / st["prepare_palettes"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": b_nominal / st["prepare_palettes"] / 1e6 / HBM_PEAK_GBS, "ms": st["prepare_palettes"], "algorithmic_bytes": b_nominal,
+                            "executed_point_bytes": b_exec, **it,
+                            "note": "nominal = 3 B x pixels x iterations of the slowest palette + 768 B x tiles x iterations; the colours are clustered as "
+                                    "distinct (colour, count) points held in LDS and the tiles' iterations skip what provably cannot change, so the stage is "
+                                    "bound by its ~%d dependent iterations, not by these bytes" % (it["tile_iters"] + it["pixel_iters"])}
         sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms")}
         out["stage_rooflines"] = sr
     if world == 1 and not args.no_dense_extra:
@@ -418,8 +459,42 @@ def main():
         r = extra("with_motion_and_extended_palette_usage", MotionPredictRadius=32, FrameTilingExtendedPaletteUsage=True)
         r["note"] = ("the reference's default code paths (motion prediction radius 32 + extended palette usage) at the benchmark's %d palettes; "
                      "the reference's default PaletteCount is 1024 (tilingencoder.pas:3826)" % args.palettes)
+    if world == 1 and args.motion_radius == 0 and not args.no_frozen_extra:
+        # SURVEY.md 8(d)'s literal generator: no frozen tile columns, so no frame tile repeats exactly and every one of them is a KNN query
+        rng2 = np.random.Generator(np.random.PCG64(synth.SEED))
+        for f in range(F):
+            hv[f] = synth.frame(f, W, H, rng2, freeze=False).view(np.int32)
+        frames.copy_(host_frames)
+        torch.cuda.synchronize()
+        enc.SetFramesDevice(frames)
+        enc.Run()  # untimed: pool growth for the larger query side
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nrep = max(1, min(args.steps, 3))
+        sm = np.zeros(8)
+        for _ in range(nrep):
+            enc.Run()
+            sm += enc.StageMs()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / nrep
+        k2 = enc.KnnStats()
+        out["without_frozen_columns"] = {"value": F / dt1, "unit": "frames/s", "ms_per_step": dt1 * 1e3, "steps": nrep,
+                                         "stage_ms": {n: round(float(v) / nrep, 3) for n, v in zip(STAGES, sm)},
+                                         "knn_queries": int(k2.get("queries", q_total)), "distinct_database_rows": int(k2["db_rows"]),
+                                         "knn_launch_ms": k2["kernel_ms"] / max(k2["launches"], 1), "knn_pairs_per_launch": k2["pairs"] / max(k2["launches"], 1),
+                                         "final_tiles_after_reindex": int(enc.counts()["tiles"]),
+                                         "note": "the headline step on SURVEY.md 8(d)'s generator as written (tiler_amd.synth.frame(freeze=False)): device-resident like "
+                                                 "`value`, not part of it"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, T, int(ks["db_rows"]))
+        visible = out["cpu_baseline"]["host_cpus_visible"]
+        t32 = min(visible, 32)
+        if t32 != out["cpu_baseline"]["cores"] and not os.environ.get("TM_BENCH_THREADS"):
+            # the reference's demo streams were encoded with MaxThreadCount=32 (their embedded settings): the same legs with that many
+            # threads, whatever share of the host this process owns
+            c32 = cpu_baseline(W, H, F, args.palettes, T, int(ks["db_rows"]), threads=t32)
+            out["cpu_baseline"]["with_32_threads"] = {"value": c32["value"], "cores": c32["cores"], "legs": c32["legs"],
+                                                      "note": "min(visible CPUs, 32) threads, as the reference's demo settings (MaxThreadCount=32)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     enc.close()

@@ -90,9 +90,17 @@ TM_API int tm_push_frame_rgb32(tm_encoder *, int index, const uint32_t *pixels, 
 /* Same, but the frames already sit in device memory as [frame_count][height][width] uint32 (bench path). */
 TM_API int tm_set_frames_device(tm_encoder *, const void *dev_frames);
 /* Same, with the whole clip in HOST memory as [frame_count][height][width] uint32 (the batch form of the frame callback for a
- * host that holds the decoded clip; borrowed until the next Load has run).  Load then moves it across PCIe in chunks, each
- * chunk's copy running beside the Load kernel of the chunk before; page-locked memory makes the copies asynchronous. */
+ * host that holds the decoded clip).  The next Load moves it across PCIe in chunks, each chunk's copy running beside the Load
+ * kernel of the chunk before; page-locked memory makes the copies asynchronous.  The clip is BORROWED until that Load has
+ * returned; from then on the encoder reads its own device copy (a later Run(esLoad) without new frames reads that copy), and
+ * the host may free or reuse the memory. */
 TM_API int tm_set_frames_host(tm_encoder *, const uint32_t *host_frames);
+/* Start moving the clip the NEXT Load will read while the current clip's steps still run (a second device buffer, the copy
+ * stream): call it before tm_run of the current clip, then tm_set_frames_host with the same pointer before the next one -- that
+ * Load adopts the copies instead of issuing its own, so back-to-back clips pay PCIe beside the compute, not before it.
+ * Borrowed until the adopting Load has returned.  At most one clip can wait beside the one in flight (TM_E_INVAL otherwise);
+ * with both buffers taken the clip of the LAST Load gives way, after which a Load without new frames fails ("no frames"). */
+TM_API int tm_prefetch_frames_host(tm_encoder *, const uint32_t *host_frames);
 TM_API int tm_run(tm_encoder *, int step);          /* Run(AStep), :5529-5554; blocking */
 /* read-back views (copy-out) */
 TM_API int tm_get_counts(tm_encoder *, int64_t *tiles, int *frames, int *palettes, int *tm_w, int *tm_h, int *keyframes);
@@ -161,6 +169,17 @@ TM_API int tm_set_collective(tm_encoder *, int rank, int world, tm_collective_cb
  * the ~80 collectives of a step (one per Lloyd iteration among them) then cost no host round trip each. */
 TM_API void *tm_get_stream(tm_encoder *);
 TM_API int tm_set_collective_mode(tm_encoder *, int stream_ordered);
+/* The native form of the above -- what a FreePascal host needs for N GPUs and nothing else: RCCL is linked into the library, one
+ * process per GPU.  One process obtains an id (tm_comm_unique_id = ncclGetUniqueId), hands its 128 bytes to the others by any
+ * means (a file, an environment variable, a pipe), and every process calls tm_comm_init(enc, id, rank, world) on an encoder whose
+ * device has been chosen (tm_set_device).  From then on Run(step) shards and merges as described for tm_set_collective, with the
+ * four collective kinds issued as ncclAllReduce / ncclAllGather on the encoder's own stream: no callback, no host round trip.
+ * tm_comm_init is collective (ncclCommInitRank: it returns once all `world` processes have called it).  Sits where the
+ * reference's Run (tilingencoder.pas:5529-5554) sits: the host's code above it does not change with the number of GPUs. */
+#define TM_COMM_ID_BYTES 128
+TM_API int tm_comm_unique_id(uint8_t id[TM_COMM_ID_BYTES]);
+TM_API int tm_comm_init(tm_encoder *, const uint8_t id[TM_COMM_ID_BYTES], int rank, int world);
+TM_API int tm_comm_destroy(tm_encoder *);
 /* Dither (DoDither :1873-1907, one independent DitherTile per global tile): this process dithers tiles
  * [T * rank / world, T * (rank + 1) / world) only (T = global tiles after Reduce) and zeroes the rest; the host merges
  * TM_ARRAY_TILE_PALPX with an all-reduce(SUM) before Reconstruct.  (0, 1) = every tile (default). */
@@ -176,6 +195,12 @@ TM_API int64_t tm_get_knn_queries(tm_encoder *);
 /* the last Dither: the distinct (palette, colour) pairs it planned once each (pixels look their pair up), 0 when every pixel was planned on
  * its own (few duplicates, the Yliluoma ditherer, few tiles for the number of palettes) */
 TM_API int64_t tm_get_dither_pairs(tm_encoder *);
+/* What the last PreparePalettes ran through (single process): Lloyd iterations and points of the tile -> palette clustering
+ * (DoPalettization, tilingencoder.pas:4105-4245; yakmo's cap is cYakmoMaxIterations = 300) and, for the colour quantisation
+ * (QuantizeUsingYakmo, :4434-4532), the iterations of the slowest palette, the distinct colours clustered, the pixels they stand for and
+ * the sum over the palettes of (distinct colours x iterations). */
+TM_API int tm_get_kmeans_iters(tm_encoder *, int *tile_iters, int64_t *tile_points, int *pixel_iters, int64_t *pixel_colours, int64_t *pixels,
+                               int64_t *pixel_colour_iters);
 
 /* ======================================================================================= stage seam
  * All pointers are DEVICE pointers unless named host_*.  `stream` is a hipStream_t (NULL = default stream).

@@ -489,3 +489,78 @@ def test_y4m_and_png_export_show_what_the_player_shows(oracle, tmp_path, radius)
     for f in range(6):
         assert np.array_equal(got[f], to_yuv(np.asarray(src[f], np.uint32)))
     enc.close()
+
+
+def _state(enc, nframes):
+    hdr, pal, rgb = enc.Tiles()
+    maps = [enc.TileMap(f) for f in range(nframes)]
+    return dict(use=hdr["UseCount"].copy(), pal=pal.copy(), rgb=rgb.copy(), palettes=enc.Palettes().copy(), keyframes=np.array(enc.KeyFrames()),
+                correl=enc.FrameCorrelations().view(np.uint32).copy(), tile=np.concatenate([m["TileIdx"] for m in maps]),
+                flags=np.concatenate([m["Flags"] for m in maps]), mpal=np.concatenate([m["PalIdx"] for m in maps]))
+
+
+def _same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_frames_from_host_memory_equal_frames_on_the_device(pinned):
+    """tm_set_frames_host: a clip of several 48 MB chunks -- 200 frames of 320x200 go as 187 + 13 -- read
+    from page-locked and from pageable host memory gives what the same clip resident in HBM gives; the host clip is lent only until
+    the Load that reads it has returned (it is overwritten afterwards and Load re-run on the encoder's own copy); and a clip moved
+    by tm_prefetch_frames_host beside the previous clip's steps is adopted by its Load."""
+    from tiler_amd import synth
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep
+    nf, h, w = 200, 200, 320
+    clip_a = synth.video(nf, w, h, cut=50)
+    clip_b = synth.video(nf, w, h, seed=7, cut=70)
+
+    def host(arr):
+        t = torch.from_numpy(arr.view(np.int32).copy())
+        return t.pin_memory() if pinned else t
+
+    def fresh():
+        enc = TilingEncoder()
+        enc.LoadDefaultSettings()
+        enc.PaletteCount = 4
+        enc.MotionPredictRadius = 0
+        enc.FrameTilingExtendedPaletteUsage = False
+        enc.SetVideo(w, h, 24.0, nf)
+        return enc
+
+    ref = {}
+    for name, clip in (("a", clip_a), ("b", clip_b)):
+        enc = fresh()
+        dev = torch.from_numpy(clip.view(np.int32)).cuda()
+        enc.SetFramesDevice(dev)
+        enc.Run()
+        ref[name] = _state(enc, nf)
+        enc.close()
+    assert not _same(ref["a"], ref["b"])
+
+    enc = fresh()
+    ha, hb = host(clip_a), host(clip_b)
+    enc.SetFramesHost(ha)
+    enc.Run()
+    assert _same(_state(enc, nf), ref["a"])
+    ha.zero_()                       # the loan ended with that Load: the memory is the host's again
+    enc.Run()                        # Load again, without new frames: the encoder's own device copy
+    assert _same(_state(enc, nf), ref["a"])
+    ha.copy_(torch.from_numpy(clip_a.view(np.int32)))
+    # clips back to back: b crosses PCIe while a's steps run, then a again while b's run
+    enc.PrefetchFramesHost(ha)
+    enc.SetFramesHost(ha)
+    enc.PrefetchFramesHost(hb)
+    enc.Run()
+    assert _same(_state(enc, nf), ref["a"])
+    enc.SetFramesHost(hb)
+    enc.PrefetchFramesHost(ha)
+    enc.Run()
+    assert _same(_state(enc, nf), ref["b"])
+    with pytest.raises(Exception):   # two clips already wait beside the one in flight?  No: one waits (a) -- a second prefetch takes the
+        enc.PrefetchFramesHost(hb)   # last Load's buffer, a third has nowhere to go
+        enc.PrefetchFramesHost(hb)
+    enc.SetFramesHost(ha)
+    enc.Run()
+    assert _same(_state(enc, nf), ref["a"])
+    enc.close()

@@ -17,5 +17,5 @@ for src in "$HERE"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtilemotion.so" "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtilemotion.so" "${objs[@]}" -L/opt/rocm/lib -lrccl
 echo "built $OUT/libtilemotion.so"

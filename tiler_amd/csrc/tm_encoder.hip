@@ -12,6 +12,8 @@
 #include <map>
 #include <sstream>
 
+#include <rccl/rccl.h>
+
 #include "tm_common.h"
 #include "tm_internal.h"
 
@@ -132,7 +134,18 @@ struct tm_encoder {
   const void *frames = nullptr;  // [nframes][height][width] RGB32
   const void *frames_host = nullptr;  // the same in HOST memory (tm_set_frames_host): Load copies it over in chunks beside its own kernel
   hipStream_t copy_stream = nullptr;
-  std::vector<hipEvent_t> copy_events;
+  // Clips that come from host memory land in one of two device buffers: the one the last Load read, and the one a prefetch
+  // (tm_prefetch_frames_host) is filling for the next Load while this clip's later steps run.
+  struct HostClip {
+    DevBuf buf;
+    const void *host = nullptr;       // the host clip it holds (or is being filled with)
+    std::vector<hipEvent_t> events;   // one per chunk, recorded on the copy stream
+    int chunk = 0, nchunks = 0;
+    bool pending = false;             // filled (or being filled) by a prefetch that no Load has adopted yet
+    uint64_t seq = 0;                 // order of the prefetches
+  } hclip[2];
+  int hclip_cur = -1;                 // the buffer `frames` points into, if any
+  uint64_t hclip_seq = 0;
   DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
   DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
   DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, error behind PSNR (KNN or motion)
@@ -161,7 +174,10 @@ struct tm_encoder {
   Collectives co;
   bool load_sharded = false;     // Load only filled the frame tiles of this process's frames (and of the frame before them)
   int load_first = 0, load_count = 0;
-  bool dist() const { return coll_cb != nullptr && co.world > 1; }
+  // the native communicator (tm_comm_init): RCCL linked into the library, the collectives queued on the encoder's stream
+  ncclComm_t comm = nullptr;
+  bool force_dist = false;  // a one-rank communicator walks the sharded paths too (TM_COMM_FORCE_DIST=1: tests on a one-GPU box)
+  bool dist() const { return (coll_cb != nullptr || comm != nullptr) && (co.world > 1 || force_dist); }
   // Query features of Reconstruct's first chunk, computed AHEAD on a second (non-blocking) stream: they depend on the frame tiles only.
   // Launched when PreparePalettes hands over to the host (OptimizePalettes' 2-5 ms search, then Dither's start), the one stretch where
   // the GPU idles; launched earlier they only trade time with the k-means kernels (measured: +3.8 ms there for -3.7 ms here).
@@ -185,15 +201,19 @@ struct tm_encoder {
   }
   ~tm_encoder() {
     drop_prefetch();
+    if (comm) { (void)hipStreamSynchronize(stream); (void)ncclCommDestroy(comm); }
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream_km) (void)hipStreamDestroy(stream_km);
-    for (hipEvent_t ev : copy_events) (void)hipEventDestroy(ev);
-    if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+    for (HostClip &c : hclip)
+      for (hipEvent_t ev : c.events) (void)hipEventDestroy(ev);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
   }
   double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
+  KmeansRunStats km_stats;  // of the last PreparePalettes (single process: the sharded path runs its own loops)
   int64_t knn_db_rows = 0;  // distinct database rows actually searched
   int64_t knn_queries = 0;  // queries of the last Reconstruct's searches (distinct frame tiles when Reduce's groups are used)
   int steps_done = 0;  // bit per step
@@ -279,6 +299,24 @@ static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t coun
   TM_CHECK(rc == 0, TM_E_HIP, "the host's collective callback failed (kind %d, code %d)", kind, rc);
   return TM_OK;
 }
+#define TM_NCCL(call)                                                                                         \
+  do {                                                                                                        \
+    const ncclResult_t r_ = (call);                                                                           \
+    if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, ncclGetErrorString(r_)); return TM_E_HIP; }  \
+  } while (0)
+
+// the four collective kinds on the encoder's stream through the library's own communicator: nothing drains the stream before and
+// nothing waits after -- the RCCL kernel is ordered between what the step queued before and what it queues next
+static void bind_native_collectives(tm_encoder *e) {
+  e->co.allreduce_sum_i32 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclSum, e->comm, e->stream)); return (int)TM_OK; };
+  e->co.allreduce_max_i32 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclMax, e->comm, e->stream)); return (int)TM_OK; };
+  e->co.allreduce_sum_i64 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream)); return (int)TM_OK; };
+  e->co.allgather = [e](const void *snd, void *rcv, int64_t bytes) -> int {
+    TM_NCCL(ncclAllGather(snd, rcv, (size_t)bytes, ncclInt8, e->comm, e->stream));
+    return (int)TM_OK;
+  };
+}
+
 static void bind_collectives(tm_encoder *e) {
   e->co.allreduce_sum_i32 = [e](void *b, int64_t n) { return coll_run(e, TM_COLL_ALLREDUCE_SUM_I32, b, nullptr, n); };
   e->co.allreduce_max_i32 = [e](void *b, int64_t n) { return coll_run(e, TM_COLL_ALLREDUCE_MAX_I32, b, nullptr, n); };
@@ -333,6 +371,30 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
   return TM_OK;
 }
 
+// the chunked upload of a host clip into device buffer `slot`, queued on the copy stream with one event per chunk
+static int queue_host_clip(tm_encoder *e, int slot, const void *host) {
+  tm_encoder::HostClip &hc = e->hclip[slot];
+  const size_t fbytes = (size_t)e->width * e->height * 4;
+  TM_TRY(hc.buf.alloc(fbytes * e->nframes));
+  if (!e->copy_stream) TM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  hc.chunk = (int)std::max<size_t>(1, ((size_t)48 << 20) / fbytes);
+  hc.nchunks = (e->nframes + hc.chunk - 1) / hc.chunk;
+  while ((int)hc.events.size() < hc.nchunks) {
+    hipEvent_t ev;
+    TM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hc.events.push_back(ev);
+  }
+  for (int c = 0; c < hc.nchunks; c++) {
+    const int f0 = c * hc.chunk, nf = std::min(hc.chunk, e->nframes - f0);
+    TM_HIP(hipMemcpyAsync(hc.buf.as<uint8_t>() + fbytes * f0, (const uint8_t *)host + fbytes * f0, fbytes * nf, hipMemcpyHostToDevice, e->copy_stream));
+    TM_HIP(hipEventRecord(hc.events[c], e->copy_stream));
+  }
+  hc.host = host;
+  hc.pending = true;
+  hc.seq = ++e->hclip_seq;
+  return TM_OK;
+}
+
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
   e->drop_prefetch();  // features of the previous frame tiles
   e->q_groups = 0;
@@ -346,28 +408,35 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   TM_TRY(e->flab.alloc((size_t)e->q * 12));
   if (e->frames_host) {
     // The clip sits in host memory: chunks of frames cross PCIe on a copy stream while the Load kernel works on the chunk before
-    // (pinned memory makes the copies asynchronous; pageable memory still works, serialised by the runtime).
+    // (pinned memory makes the copies asynchronous; pageable memory still works, serialised by the runtime).  A clip that
+    // tm_prefetch_frames_host already queued is adopted instead: its copies ran beside the previous clip's steps.
     const size_t fbytes = (size_t)e->width * e->height * 4;
     const int64_t per = e->tm_size();
-    TM_TRY(e->frames_owned.alloc(fbytes * e->nframes));
-    e->frames = e->frames_owned.p;
-    if (!e->copy_stream) TM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-    const int chunk = (int)std::max<size_t>(1, ((size_t)48 << 20) / fbytes);
-    const int nchunks = (e->nframes + chunk - 1) / chunk;
-    while ((int)e->copy_events.size() < nchunks) {
-      hipEvent_t ev;
-      TM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      e->copy_events.push_back(ev);
+    int slot = -1;
+    for (int i = 0; i < 2; i++)
+      if (e->hclip[i].pending && e->hclip[i].host == e->frames_host && (slot < 0 || e->hclip[i].seq < e->hclip[slot].seq)) slot = i;
+    if (slot < 0) {
+      // no prefetch of this clip: any buffer that holds no waiting clip will do (the last Load's own included: its clip is being
+      // replaced); with two other clips waiting the older one is dropped (the copy stream orders the new copies behind its own)
+      for (int i = 0; i < 2; i++)
+        if (!e->hclip[i].pending && (slot < 0 || i != e->hclip_cur)) slot = i;
+      if (slot < 0) slot = e->hclip[0].seq < e->hclip[1].seq ? 0 : 1;
+      TM_HIP(hipStreamSynchronize(e->stream));       // the destination may have been handed out by the pool a moment ago
+      TM_TRY(queue_host_clip(e, slot, e->frames_host));
     }
-    TM_HIP(hipStreamSynchronize(e->stream));  // the destination may have been handed out by the pool a moment ago
-    for (int c = 0; c < nchunks; c++) {
-      const int f0 = c * chunk, nf = std::min(chunk, e->nframes - f0);
-      TM_HIP(hipMemcpyAsync(e->frames_owned.as<uint8_t>() + fbytes * f0, (const uint8_t *)e->frames_host + fbytes * f0, fbytes * nf, hipMemcpyHostToDevice, e->copy_stream));
-      TM_HIP(hipEventRecord(e->copy_events[c], e->copy_stream));
-      TM_HIP(hipStreamWaitEvent(e->stream, e->copy_events[c], 0));
-      TM_TRY(launch_load(e->frames_owned.as<uint8_t>() + fbytes * f0, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + (int64_t)f0 * per * 256,
+    tm_encoder::HostClip &hc = e->hclip[slot];
+    for (int c = 0; c < hc.nchunks; c++) {
+      const int f0 = c * hc.chunk, nf = std::min(hc.chunk, e->nframes - f0);
+      TM_HIP(hipStreamWaitEvent(e->stream, hc.events[c], 0));
+      TM_TRY(launch_load(hc.buf.as<uint8_t>() + fbytes * f0, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + (int64_t)f0 * per * 256,
                          e->fflags.as<uint8_t>() + (int64_t)f0 * per, e->flab.as<uint8_t>() + (int64_t)f0 * per * 12, e->stream));
     }
+    // From here on the encoder reads its own device copy: the host clip is no longer borrowed once this Load has returned (it
+    // synchronises below), and a later Run(esLoad) without new frames reads the copy again.
+    hc.pending = false;
+    e->hclip_cur = slot;
+    e->frames = hc.buf.p;
+    e->frames_host = nullptr;
   } else if (e->dist() && e->s.MotionPredictRadius <= 0) {
     // One process per GPU, motion prediction off: every process loads its own frames (frames are independent, 1293-1411) plus the
     // one before them, whose Lab means the first correlation needs.  The mirror flags (read back with every tile map) and the
@@ -746,6 +815,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
   TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream, &e->pair_keys, &e->pair_keys_n));
+  e->km_stats = kmeans_run_stats();
   lap("palette colours (3-D)");
   }
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
@@ -1382,6 +1452,9 @@ int tm_set_video(tm_encoder *e, int width, int height, double fps, int frame_cou
   e->frames = nullptr;
   e->frames_host = nullptr;
   e->frames_owned.release();
+  if (e->copy_stream) TM_HIP(hipStreamSynchronize(e->copy_stream));  // a prefetch of the old geometry may still be running
+  for (tm_encoder::HostClip &c : e->hclip) { c.buf.release(); c.pending = false; c.host = nullptr; }
+  e->hclip_cur = -1;
   e->steps_done = 0;
   if (e->auto_tile_count) recompute_auto_tile_count(e);
   return TM_OK;
@@ -1394,6 +1467,7 @@ int tm_push_frame_rgb32(tm_encoder *e, int index, const uint32_t *pixels, int st
   TM_HIP(hipSetDevice(e->device));
   const size_t fbytes = (size_t)e->width * e->height * 4;
   e->frames_host = nullptr;
+  e->hclip_cur = -1;
   if (!e->frames_owned.p || e->frames != e->frames_owned.p) {
     TM_TRY(e->frames_owned.alloc(fbytes * e->nframes));
     TM_HIP(hipMemsetAsync(e->frames_owned.p, 0, fbytes * e->nframes, e->stream));
@@ -1411,6 +1485,7 @@ int tm_set_frames_device(tm_encoder *e, const void *dev_frames) {
   e->frames_owned.release();
   e->frames = dev_frames;
   e->frames_host = nullptr;
+  e->hclip_cur = -1;
   return TM_OK;
 }
 
@@ -1419,7 +1494,27 @@ int tm_set_frames_host(tm_encoder *e, const uint32_t *host_frames) {
   TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
   e->frames_host = host_frames;
   e->frames = nullptr;
+  e->hclip_cur = -1;
   return TM_OK;
+}
+
+int tm_prefetch_frames_host(tm_encoder *e, const uint32_t *host_frames) {
+  TM_CHECK(e && host_frames, TM_E_INVAL, "null argument");
+  TM_CHECK(e->nframes > 0, TM_E_INVAL, "tm_set_video has not been called");
+  TM_HIP(hipSetDevice(e->device));
+  // the buffer to fill: one that neither holds a clip waiting for its Load nor the clip the steps in flight may still read from --
+  // unless both are taken, in which case the clip of the last Load gives way (its steps have returned: tm_run blocks)
+  int slot = -1;
+  for (int i = 0; i < 2; i++)
+    if (!e->hclip[i].pending && i != e->hclip_cur) slot = i;
+  if (slot < 0 && e->hclip_cur >= 0 && !e->hclip[e->hclip_cur].pending) {
+    slot = e->hclip_cur;
+    e->hclip_cur = -1;
+    if (e->frames == e->hclip[slot].buf.p) e->frames = nullptr;  // a Load without new frames would read a clip being overwritten
+  }
+  TM_CHECK(slot >= 0, TM_E_INVAL, "tm_prefetch_frames_host: two clips are already waiting for their Load");
+  TM_HIP(hipStreamSynchronize(e->stream));  // nothing queued on the encoder's stream still reads (or the pool just handed out) that buffer
+  return queue_host_clip(e, slot, host_frames);
 }
 
 int tm_run(tm_encoder *e, int step) {
@@ -1575,9 +1670,55 @@ int tm_set_collective_mode(tm_encoder *e, int stream_ordered) {
   return TM_OK;
 }
 
+int tm_comm_unique_id(uint8_t id[TM_COMM_ID_BYTES]) {
+  TM_CHECK(id, TM_E_INVAL, "null argument");
+  static_assert(sizeof(ncclUniqueId) == TM_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId u;
+  TM_NCCL(ncclGetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return TM_OK;
+}
+
+int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, int world) {
+  TM_CHECK(e && id, TM_E_INVAL, "null argument");
+  TM_CHECK(world >= 1 && rank >= 0 && rank < world, TM_E_INVAL, "bad process %d of %d", rank, world);
+  TM_CHECK(e->comm == nullptr, TM_E_INVAL, "tm_comm_init: this encoder already has a communicator (tm_comm_destroy first)");
+  TM_HIP(hipSetDevice(e->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  TM_NCCL(ncclCommInitRank(&e->comm, world, u, rank));
+  e->coll_cb = nullptr;
+  e->coll_user = nullptr;
+  e->coll_stream_ordered = true;
+  e->co.rank = rank;
+  e->co.world = world;
+  const char *f = getenv("TM_COMM_FORCE_DIST");
+  e->force_dist = f && atoi(f) != 0;
+  bind_native_collectives(e);
+  e->dither_rank = rank;
+  e->dither_world = world;
+  e->qf_valid = false;
+  return TM_OK;
+}
+
+int tm_comm_destroy(tm_encoder *e) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (!e->comm) return TM_OK;
+  TM_HIP(hipStreamSynchronize(e->stream));
+  TM_NCCL(ncclCommDestroy(e->comm));
+  e->comm = nullptr;
+  e->force_dist = false;
+  e->co = Collectives();
+  e->dither_rank = 0;
+  e->dither_world = 1;
+  e->qf_valid = false;
+  return TM_OK;
+}
+
 int tm_set_collective(tm_encoder *e, int rank, int world, tm_collective_cb cb, void *user) {
   TM_CHECK(e, TM_E_INVAL, "null encoder");
   TM_CHECK(world >= 1 && rank >= 0 && rank < world && (cb != nullptr || world == 1), TM_E_INVAL, "bad process %d of %d", rank, world);
+  TM_CHECK(e->comm == nullptr, TM_E_INVAL, "tm_set_collective: the encoder has a native communicator (tm_comm_destroy first)");
   e->coll_cb = world > 1 ? cb : nullptr;
   e->coll_user = user;
   e->co.rank = rank;
@@ -1627,6 +1768,17 @@ int tm_sync_tilemap(tm_encoder *e) {  // after shards were merged: TMI^.PalIdx :
 
 int64_t tm_get_knn_queries(tm_encoder *e) { return e ? e->knn_queries : 0; }
 int64_t tm_get_dither_pairs(tm_encoder *e) { return e ? e->dither_pairs : 0; }
+
+int tm_get_kmeans_iters(tm_encoder *e, int *tile_iters, int64_t *tile_points, int *pixel_iters, int64_t *pixel_colours, int64_t *pixels, int64_t *pixel_colour_iters) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (tile_iters) *tile_iters = e->km_stats.tile_iters;
+  if (tile_points) *tile_points = e->km_stats.tile_points;
+  if (pixel_iters) *pixel_iters = e->km_stats.pixel_iters;
+  if (pixel_colours) *pixel_colours = e->km_stats.pixel_colours;
+  if (pixels) *pixels = e->km_stats.pixels;
+  if (pixel_colour_iters) *pixel_colour_iters = e->km_stats.pixel_colour_iters;
+  return TM_OK;
+}
 
 int tm_get_knn_stats(tm_encoder *e, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows) {
   if (e && db_rows) *db_rows = e->knn_db_rows;

@@ -1372,6 +1372,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
     TM_CHECK(hstate[i].timeout == 0, TM_E_HIP, "k-means: the workgroups of a segment did not all become resident (barrier gave up)");
     if (host_kk) (*host_kk)[which[i]] = hs[i].kk;
     iters = std::max(iters, hs[i].iters);
+    kmeans_run_stats().pixel_colour_iters += hs[i].count * (int64_t)hs[i].iters;
 #if TM_KM3_STAMPS
     fprintf(stderr, "[tm_km3 stamps] segment %zu: %d workgroups, %d iterations; per iteration (s_memtime ticks): zero+thresholds %.0f, own test %.0f, scoring %.0f, "
             "workgroup sync %.0f, flush %.0f, barrier %.0f, read-back %.0f\n", i, hs[i].blk_count, hs[i].iters, (double)hstate[i].stamps[0] / std::max(1, hs[i].iters),
@@ -1831,6 +1832,11 @@ static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std
   return TM_OK;
 }
 
+KmeansRunStats &kmeans_run_stats() {
+  static thread_local KmeansRunStats st;
+  return st;
+}
+
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream) {
   TM_TRY(require_device());
   TM_CHECK(npal >= 1 && npal <= 65536, TM_E_INVAL, "PaletteCount %d outside 1..65536 (tilingencoder.pas:2959)", npal);
@@ -1848,6 +1854,8 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
     TM_TRY(pp_seeds((const int32_t *)feat, (const uint32_t *)use, n, npal, &seeds, stream));
     TM_TRY(run_kmeans_seeded(feat, use, n, 192, npal, seeds.data(), max_iter, assign.p, cent.p, &kk, &iters, stream));
   }
+  kmeans_run_stats().tile_iters = iters;
+  kmeans_run_stats().tile_points = n;
   // palettes ranked by number of tiles, descending (tilingencoder.pas:4229-4234); ties keep the initial order
   TM_HIP(hipMemsetAsync(cnt.p, 0, (size_t)npal * 8, stream));
   hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 512)), dim3(256), npal <= 8192 ? (size_t)npal * 4 : 0, stream,
@@ -2209,8 +2217,12 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
     const auto t_km = std::chrono::steady_clock::now();
     if (dbg) (void)hipStreamSynchronize(stream);
     const auto t_km0 = std::chrono::steady_clock::now();
+    kmeans_run_stats().pixel_colour_iters = 0;
     TM_TRY(kmeans_batched(pts.as<int32_t>(), ucnt.as<uint32_t>(), 3, sb, sc, pal_size, max_iter, assign.as<int32_t>(), cent.as<double>(),
                           &kk, &iters, stream));
+    kmeans_run_stats().pixel_iters = iters;  // (pixel_colour_iters: summed by the persistent launch, reset before it below)
+    kmeans_run_stats().pixel_colours = (int64_t)nu;
+    kmeans_run_stats().pixels = n * 64;
     if (dbg) fprintf(stderr, "[tm_pp]   colour keys + sort + runs %7.3f ms, k-means of %u colours %7.3f ms (%d iterations)\n",
                      std::chrono::duration<double, std::milli>(t_km0 - t_km).count() , nu,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_km0).count(), iters);

@@ -197,7 +197,7 @@ __device__ __forceinline__ void k2_chain2(const v4i (&T)[6 + HT], const v16i &nt
 // |t-c|^2 rides in on the second digit shift (one v_lshl_add_u32 per register instead of a shift there and a shift-add at the end)
 template <int HT, int HQ, bool TD>
 __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
-  constexpr int KT = 6 + HT, KQ = 6 + HQ, HM = HT < HQ ? HT : HQ, ND = KNN_ND;
+  constexpr int KT = 6 + HT, KQ = 6 + HQ, ND = KNN_ND;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
   constexpr int NS = k2_ns(KQ), NSP = (NS + 1) & ~1, NW = K2_NW, NT = K2_NT, LCAP = K2_LCAP;
   // one LDS object, carved by hand (16-byte aligned pieces)
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
       bool have = next_entry(tile, lbv, mask);
       while (have) {
         // the tile's MFMA A operands and norms, straight into registers
-        const unsigned long long fl0 = K2_NOW();
+        [[maybe_unused]] const unsigned long long fl0 = K2_NOW();
         const uint8_t *tb = a.tpack + (int64_t)tile * T_BYTES;
         v4i T[KT];
 #pragma unroll
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
           npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
         };
         while (mask) {
-          const unsigned long long f0 = K2_NOW();
+          [[maybe_unused]] const unsigned long long f0 = K2_NOW();
 #if TM_KNN2_PAIR
           {  // the sub-tiles' bests may have tightened since the entry was popped: one fresh look at all of them
             const int sm = lane < NS ? (int)k2_peek(&s_smax[lane]) : -1;
@@ -525,18 +525,18 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
             const int sb = __builtin_ctz(mask);
             mask &= mask - 1;
             v16i accA, accB;
-            const unsigned long long f1 = K2_NOW();
+            [[maybe_unused]] const unsigned long long f1 = K2_NOW();
             k2_chain2<HT, HQ, TD>(T, ntr, lds + sa * (KQ * 1024) + lane * 16, lds + sb * (KQ * 1024) + lane * 16, accA, accB);
             K2_AFTER(accB[0]);
-            const unsigned long long f2 = K2_NOW();
+            [[maybe_unused]] const unsigned long long f2 = K2_NOW();
             epilogue(sa, accA);
             epilogue(sb, accB);
             K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(6, 1);
           } else {
-            const unsigned long long f1 = K2_NOW();
+            [[maybe_unused]] const unsigned long long f1 = K2_NOW();
             const v16i acc = k2_chain<HT, HQ, TD>(T, ntr, lds + sa * (KQ * 1024) + lane * 16);
             K2_AFTER(acc[0]);
-            const unsigned long long f2 = K2_NOW();
+            [[maybe_unused]] const unsigned long long f2 = K2_NOW();
             epilogue(sa, acc);
             K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(5, 1);
           }
@@ -547,10 +547,10 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
           const int lbs = __builtin_amdgcn_readlane(lbv, s);
           const int sms = __builtin_amdgcn_readfirstlane((int)k2_peek(&s_smax[s]));
           if (lbs > sms) { K2_FS(0, K2_NOW() - f0); continue; }
-          const unsigned long long f1 = K2_NOW();
+          [[maybe_unused]] const unsigned long long f1 = K2_NOW();
           const v16i acc = k2_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16);
           K2_AFTER(acc[0]);
-          const unsigned long long f2 = K2_NOW();
+          [[maybe_unused]] const unsigned long long f2 = K2_NOW();
           epilogue(s, acc);
           K2_FS(0, f1 - f0); K2_FS(1, f2 - f1); K2_FS(2, K2_NOW() - f2); K2_FS(5, 1);
 #endif

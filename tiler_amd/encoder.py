@@ -55,6 +55,7 @@ _ENC_SIGS = {
     "tm_push_frame_rgb32": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "tm_set_frames_device": (c_int, [c_void_p, c_void_p]),
     "tm_set_frames_host": (c_int, [c_void_p, c_void_p]),
+    "tm_prefetch_frames_host": (c_int, [c_void_p, c_void_p]),
     "tm_run": (c_int, [c_void_p, c_int]),
     "tm_get_counts": (c_int, [c_void_p, ctypes.POINTER(c_int64)] + [ctypes.POINTER(c_int)] * 5),
     "tm_get_tile": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -173,6 +174,13 @@ class TilingEncoder:
         ptr = frames.data_ptr() if hasattr(frames, "data_ptr") else frames.ctypes.data
         check(self._L.tm_set_frames_host(c_void_p(self._h), c_void_p(ptr)))
 
+    def PrefetchFramesHost(self, frames):
+        """queues the upload of the clip the NEXT Load will read (same argument forms as SetFramesHost) beside the current clip's steps;
+        call SetFramesHost with the same clip before the Run that is to adopt it.  Borrowed until that Load has returned."""
+        self._prefetch_ref = frames
+        ptr = frames.data_ptr() if hasattr(frames, "data_ptr") else frames.ctypes.data
+        check(self._L.tm_prefetch_frames_host(c_void_p(self._h), c_void_p(ptr)))
+
     def Run(self, step=TEncoderStep.esAll):
         check(self._L.tm_run(c_void_p(self._h), int(step)))
 
@@ -283,6 +291,16 @@ class TilingEncoder:
 
     def SyncTileMap(self):
         check(self._L.tm_sync_tilemap(c_void_p(self._h)))
+
+    def KmeansIters(self):
+        """iterations and points of the last PreparePalettes' two clusterings (tm_get_kmeans_iters)"""
+        ti, pi = c_int(), c_int()
+        tp, pc, px, pci = c_int64(), c_int64(), c_int64(), c_int64()
+        self._L.tm_get_kmeans_iters.restype = c_int
+        self._L.tm_get_kmeans_iters.argtypes = [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+                                                ctypes.POINTER(c_int64)]
+        check(self._L.tm_get_kmeans_iters(c_void_p(self._h), ctypes.byref(ti), ctypes.byref(tp), ctypes.byref(pi), ctypes.byref(pc), ctypes.byref(px), ctypes.byref(pci)))
+        return dict(tile_iters=ti.value, tile_points=tp.value, pixel_iters=pi.value, pixel_colours=pc.value, pixel_points=px.value, pixel_colour_iters=pci.value)
 
     def DitherPairs(self):
         """distinct (palette, colour) pairs the last Dither planned once each; 0 = every pixel planned on its own"""

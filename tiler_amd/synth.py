@@ -3,18 +3,22 @@
 frame f, pixel (x, y):  R = (x*255//W + 2f) mod 256, G = (y*255//H + f) mod 256, B = ((x+y)*255//(W+H) + 3f) mod 256;
 uniform noise in [-N, N] (N = 8) on a fraction rho (0.25) of the 8x8 tiles, chosen per frame; every `cut` frames the
 channels rotate (R,G,B) -> (G,B,R) so keyframe detection has scene cuts to find.  Frames are RGB32 (0xAARRGGBB, the
-AV_PIX_FMT_RGB32 layout TFFMPEGFrameCallback hands over, extern.pas:149).  Static tiles (exact duplicates between
-frames) come from freezing the `+f` drift on a third of the tile columns.
+AV_PIX_FMT_RGB32 layout TFFMPEGFrameCallback hands over, extern.pas:149).
+
+An addition to SURVEY.md 8(d)'s generator, on by default (`freeze=True`): the `+f` drift is frozen on every third tile column, so
+that a third of the picture is static between scene cuts and exact inter-frame duplicate tiles occur (a quarter of all frame tiles
+on the 720p clip: the static columns' tiles that carry no noise).  `freeze=False` is the literal generator of 8(d), in which
+every tile changes every frame; bench.py reports both.
 """
 import numpy as np
 
 SEED = 0x42381337  # echoes CRandomSeed, extern.pas:226
 
 
-def frame(f, width, height, rng, noise=8, rho=0.25, cut=100):
+def frame(f, width, height, rng, noise=8, rho=0.25, cut=100, freeze=True):
     y, x = np.mgrid[0:height, 0:width].astype(np.int64)
     tx = x >> 3
-    drift = np.where(tx % 3 == 0, 0, f)  # frozen columns of tiles: exact inter-frame duplicates
+    drift = np.where(tx % 3 == 0, 0, f) if freeze else f  # frozen columns of tiles: exact inter-frame duplicates
     r = (x * 255 // width + 2 * drift) % 256
     g = (y * 255 // height + drift) % 256
     b = ((x + y) * 255 // (width + height) + 3 * drift) % 256

@@ -17,6 +17,6 @@ for src in "$HERE"/*.hip; do
   esac
 done
 for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtilemotion_$NAME.so" "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtilemotion_$NAME.so" "${objs[@]}" -L/opt/rocm/lib -lrccl
 rm -rf "$OBJ"
 echo "built $OUT/libtilemotion_$NAME.so"
