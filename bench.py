@@ -56,14 +56,13 @@ def _host_threads(visible):
 
 
 def _collective_counts(enc, nsteps):
-    """calls and bytes of this rank's collectives per step (what the library asked the host's callback for)"""
+    """calls and bytes of this rank's collectives per step, counted by the library (tm_get_collective_stats) on whichever path carries
+    them: its own RCCL communicator (tm_comm_init) or the host's callback (tm_set_collective)"""
+    st = enc.CollectiveStats()
+    out = {k: v / float(nsteps) for k, v in st.items()}
+    out["path"] = "native RCCL inside libtilemotion (tm_comm_init)" if getattr(enc, "_native_comm", None) else "host callback (tm_set_collective) over torch.distributed"
     coll = getattr(enc, "_collective", None)
-    if coll is None:
-        return None
-    names = {0: "all_reduce_sum_i32", 1: "all_reduce_max_i32", 2: "all_reduce_sum_i64", 3: "all_gather"}
-    out = {names[k]: v / float(nsteps) for k, v in coll.calls.items()}
-    out["bytes"] = coll.bytes / float(nsteps)
-    if coll.log is not None:
+    if coll is not None and coll.log is not None:
         per = len(coll.log) // nsteps
         out["last_step_calls"] = coll.log[-per:]
     return out
@@ -231,6 +230,13 @@ def main():
     enc.MotionPredictRadius = args.motion_radius
     enc.SetVideo(W, H, 24.0, F)
     enc.SetFramesDevice(frames)
+
+    if world > 1 and not rehearse and os.environ.get("TM_BENCH_CALLBACK") != "1":
+        # the native path: RCCL linked into libtilemotion, one communicator per encoder, the collectives on the encoder's own stream.
+        # The 128-byte id travels over the process group torch.distributed already has (a Pascal host would use a file or a pipe).
+        box = [TilingEncoder.CommUniqueId() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        enc.CommInit(box[0], rank, world)
 
     def barrier():
         torch.cuda.synchronize()

@@ -75,6 +75,10 @@ TM_API int tm_set_device(tm_encoder *, int device); /* which HIP device this enc
 /* Settings: keys are the INI names of SaveSettings (:3745-3770); setters clamp like :2919-3047. */
 TM_API int tm_load_default_settings(tm_encoder *);  /* LoadDefaultSettings, :3817-3845 */
 TM_API int tm_load_settings_ini(tm_encoder *, const char *path); /* LoadSettings, :3777 */
+TM_API int tm_save_settings_ini(tm_encoder *, const char *path); /* SaveSettings, :3738-3775: the text a .gtm embeds (:5331-5335), CR LF line ends */
+/* LoadSettings followed by SaveSettings on text (host only, no device): `ini_text` through the setters' clamps, back as the INI text
+ * SaveSettings would write; *out_len = its length, `out` (may be NULL) receives up to cap - 1 bytes and a terminator. */
+TM_API int tm_settings_text_host(const char *ini_text, char *out, int64_t cap, int64_t *out_len);
 TM_API int tm_set_int(tm_encoder *, const char *key, int64_t v);
 TM_API int tm_set_float(tm_encoder *, const char *key, double v);
 TM_API int tm_set_bool(tm_encoder *, const char *key, int v);
@@ -180,6 +184,9 @@ TM_API int tm_set_collective_mode(tm_encoder *, int stream_ordered);
 TM_API int tm_comm_unique_id(uint8_t id[TM_COMM_ID_BYTES]);
 TM_API int tm_comm_init(tm_encoder *, const uint8_t id[TM_COMM_ID_BYTES], int rank, int world);
 TM_API int tm_comm_destroy(tm_encoder *);
+/* Collectives this process has issued since the last reset, by kind (index = TM_COLL_*), and the bytes it put through them
+ * (all-reduce: the buffer; all-gather: world x the piece) -- whichever of the two paths above carries them. */
+TM_API int tm_get_collective_stats(tm_encoder *, int64_t calls[4], int64_t *bytes, int reset);
 /* Dither (DoDither :1873-1907, one independent DitherTile per global tile): this process dithers tiles
  * [T * rank / world, T * (rank + 1) / world) only (T = global tiles after Reduce) and zeroes the rest; the host merges
  * TM_ARRAY_TILE_PALPX with an all-reduce(SUM) before Reconstruct.  (0, 1) = every tile (default). */

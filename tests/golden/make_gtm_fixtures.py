@@ -4,6 +4,8 @@ data).  Run here (needs /root/reference; node optional: when present the referen
 stream).  Usage: python tests/golden/make_gtm_fixtures.py"""
 import collections
 import hashlib
+
+import numpy as np
 import json
 import os
 import shutil
@@ -41,6 +43,25 @@ def pins_for(oracle, name):
                palettes=len(pl.palettes), settings_sha256=hashlib.sha256(pl.settings.encode("latin-1")).hexdigest(),
                settings_head=pl.settings[:40], item_histogram=dict(sorted(hist.items())),
                frame_sha256={str(f): hashlib.sha256(pl.frames[f].tobytes()).hexdigest() for f in (0, 1, MAX_FRAMES - 1)})
+    # What the stream says about the encoder steps behind it: walk ALL key frames without rendering
+    full = gtm_reader.Player(render=False)
+    for raw in raws:
+        full.feed(raw)
+    n_ts = sum(b - a + 1 for a, b in full.tileset_ranges)
+    ts = np.concatenate([full.tiles[a:b + 1] for a, b in full.tileset_ranges]).reshape(-1, 64)
+    intra = np.frombuffer(b"".join(it[1] for fr in full.items for it in fr if it[0] == "intra"), np.uint8).reshape(-1, 64)
+    both = np.concatenate([ts, intra])
+    refs = np.array([it[1] for fr in full.items for it in fr if it[0] in ("ss", "ls", "ll")], np.int64)
+    out["tiles"] = dict(
+        declared=int(full.tile_count), tileset=int(n_ts), tileset_ranges=[list(r) for r in full.tileset_ranges], intra=int(intra.shape[0]),
+        # MakeTilesUnique(False) (tilingencoder.pas:4702-4718, 1993-2038) keys tiles by their 64 palette-index bytes alone, whatever
+        # their palette: no two tiles of a finished stream may share them.  Counted here with numpy, re-counted with the oracle's dedup in the test.
+        distinct_index_tiles=int(np.unique(both, axis=0).shape[0]),
+        # DoTMI (5208-5268): a tile used once travels inside its one item (intra); everything addressed by index lives in the TileSet,
+        # which holds the tiles before the first UseCount = 1 one (5236, 5292-5316)
+        max_explicit_reference=int(refs.max()), explicit_references=int(refs.shape[0]),
+        never_visibly_referenced=int(full.tile_count - n_ts - intra.shape[0]))
+    out["settings_text"] = pl.settings
     if len(raws) > 1:  # command walk of the second keyframe alone (what tests can redo from football_cif_kf1.lzma)
         w = gtm_reader.Player(render=False)
         w.w, w.h, w.tile_count = pl.w, pl.h, pl.tile_count

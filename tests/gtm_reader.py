@@ -73,6 +73,7 @@ class Player:
         self.items = []       # per frame: list of tuples describing each command that fills tile-map positions
         self._cur_items = []
         self.kf_ends = []
+        self.tileset_ranges = []  # (first, last) of every TileSet command
 
     def _draw(self, idx, attrs):
         if not self.render:
@@ -114,6 +115,7 @@ class Player:
                 a = u32(); p += 4
                 b = u32(); p += 4
                 self.pal_size = arg
+                self.tileset_ranges.append((a, b))
                 n = b - a + 1
                 self.tiles[a:b + 1] = np.frombuffer(raw, np.uint8, n * 64, p).reshape(n, 8, 8); p += n * 64
             elif cmd == CMD_FRAME_END:
@@ -159,7 +161,7 @@ class Player:
                 self._draw_pred(ox, oy)
             elif cmd == CMD_INTRA:
                 pal = u16(); p += 2
-                if self.render:
+                if self.tiles is not None:
                     self.tiles[self.cur_intra] = np.frombuffer(raw, np.uint8, 64, p).reshape(8, 8)
                 p += 64
                 self._cur_items.append(("intra", bytes(raw[p - 64:p]), pal, arg & 3))

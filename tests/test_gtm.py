@@ -322,3 +322,88 @@ def test_reader_pins_match_reference_demo_files(oracle):
         if "lzma_js_agrees" not in got:
             want[name].pop("lzma_js_agrees", None)
         assert got == want[name]
+
+
+# ---- what the reference's demo streams say about the encoder steps behind them -----------------------------------
+# The two demo files are the only reference-produced artefacts there are.  Beyond the format (above) they hold invariants of
+# MakeTilesUnique(False) / Reindex (tilingencoder.pas:1993-2038, 4702-4718), of DoTMI's intra-versus-TileSet split (5208-5316) and the
+# text SaveSettings writes (3738-3775, embedded at 5331-5335).  The numbers in tests/golden/gtm_demo_pins.json were derived here from the
+# streams (tests/golden/make_gtm_fixtures.py); where the streams themselves are at hand they are walked again.
+# Not pinnable from these streams: ReindexTiles' order by use count (4626-4700) -- both streams hold predicted items in every key
+# frame (340 000 and 30 022+ of them), whose hidden tile references count towards UseCount (2030) but are not in the stream, so the
+# visible counts of the TileSet are not even monotone (12 880 and 8 183 ascents).
+
+
+@pytest.mark.parametrize("name", ["city_cif", "football_cif"])
+def test_demo_streams_hold_no_two_tiles_with_the_same_index_bytes(name):
+    """MakeTilesUnique(False): tiles are keyed by their 64 palette-index bytes alone, whatever their palette (CompareTilePalPixels,
+    4702-4718) -- so a finished stream's TileSet tiles and intra tiles are pairwise distinct in those bytes; and every tile addressed
+    by index lies in the TileSet (tiles used once travel inside their one item, 5236)."""
+    t = _pins()[name]["tiles"]
+    assert t["distinct_index_tiles"] == t["tileset"] + t["intra"]
+    assert t["max_explicit_reference"] < t["tileset"] and t["tileset_ranges"] == [[0, t["tileset"] - 1]]
+    assert t["tileset"] + t["intra"] + t["never_visibly_referenced"] == t["declared"]
+
+
+def test_oracle_dedup_merges_nothing_in_a_reference_keyframe(oracle):
+    """the same invariant through the oracle's own MakeTilesUnique(False) (tmo_dedup_u8, keyed as 4702-4718) on the committed key
+    frame of football_cif: its 8 188 intra tiles stay 8 188, and the order it returns is CompareByte's (ascending content)"""
+    blob = open(os.path.join(GOLDEN, "football_cif_kf1.lzma"), "rb").read()
+    pins = _pins()["football_cif"]
+    raw = gtm_reader.lzma_decode(oracle, blob, pins["kf"][1]["raw"])[0]
+    w = gtm_reader.Player(render=False)
+    w.w, w.h, w.tile_count = pins["tm_w"], pins["tm_h"], pins["tile_count"]
+    w.feed(raw)
+    intra = np.frombuffer(b"".join(it[1] for fr in w.items for it in fr if it[0] == "intra"), np.uint8).reshape(-1, 64)
+    assert intra.shape[0] == pins["kf1_walk"]["item_histogram"]["intra"]
+    nu, rep, order, use, remap = oracle.dedup(intra)
+    assert nu == intra.shape[0] and np.array_equal(np.sort(rep), np.arange(nu)) and np.all(use == 1)
+    srt = intra[order]
+    keys = [bytes(r) for r in srt]
+    assert keys == sorted(keys)  # all use counts equal: ReindexTiles' second key, content ascending (CompareTileUseCountRev, 584-599)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/docs/demo"), reason="the reference tree is not here")
+@pytest.mark.parametrize("name", ["city_cif", "football_cif"])
+def test_oracle_dedup_merges_nothing_in_the_demo_streams(oracle, name):
+    """all key frames of the stream itself: TileSet + every intra tile through the oracle's dedup -- nothing merges"""
+    data = open(os.path.join("/root/reference/docs/demo", name + ".gtm"), "rb").read()
+    hdr, raws = gtm_reader.unpack(oracle, data)
+    pl = gtm_reader.Player(render=False)
+    for raw in raws:
+        pl.feed(raw)
+    ts = np.concatenate([pl.tiles[a:b + 1] for a, b in pl.tileset_ranges]).reshape(-1, 64)
+    intra = np.frombuffer(b"".join(it[1] for fr in pl.items for it in fr if it[0] == "intra"), np.uint8).reshape(-1, 64)
+    both = np.ascontiguousarray(np.concatenate([ts, intra]))
+    t = _pins()[name]["tiles"]
+    assert (ts.shape[0], intra.shape[0]) == (t["tileset"], t["intra"])
+    nu = oracle.dedup(both)[0]
+    assert nu == both.shape[0] == t["distinct_index_tiles"]
+    refs = [it[1] for fr in pl.items for it in fr if it[0] in ("ss", "ls", "ll")]
+    assert max(refs) == t["max_explicit_reference"] < ts.shape[0]
+
+
+@pytest.mark.parametrize("name", ["city_cif", "football_cif"])
+def test_settings_text_matches_the_demo_streams_line_for_line(L, name):
+    """LoadSettings (3777-3815) of the text a demo stream embeds, then SaveSettings (3738-3775): every `Key=Value` line of a key this
+    snapshot still writes comes back byte for byte (WriteFloat's shortest form, WriteBool as 0/1, CR LF), the sections and the keys
+    come in the stream's order, and the text ends as the stream's does.  (The streams were written by an older build: they also hold
+    ShotTransDistHiThres, DitheringUseGamma, FrameTilingUseGamma and EncoderGammaValue, which this snapshot neither reads nor writes,
+    and lack GlobalTilingUseTargetPSNR / GlobalTilingTargetPSNR.)"""
+    src = _pins()[name]["settings_text"]
+    L.tm_settings_text_host.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
+    n = ctypes.c_int64()
+    buf = ctypes.create_string_buffer(4096)
+    assert L.tm_settings_text_host(src.encode("latin-1"), buf, 4096, ctypes.byref(n)) == 0, L.tm_last_error()
+    ours = buf.raw[:n.value].decode("latin-1")
+    assert ours.endswith("\r\n") and "\n" not in ours.replace("\r\n", "") and src.endswith("\r\n")
+    src_lines, our_lines = src.split("\r\n"), ours.split("\r\n")
+    dropped = {"ShotTransDistHiThres", "DitheringUseGamma", "FrameTilingUseGamma", "EncoderGammaValue"}
+    added = {"GlobalTilingUseTargetPSNR", "GlobalTilingTargetPSNR"}
+    key = lambda l: l.split("=", 1)[0]
+    assert [l for l in src_lines if key(l) not in dropped] == [l for l in our_lines if key(l) not in added]
+    assert {key(l) for l in src_lines} - {key(l) for l in our_lines} == dropped
+    assert {key(l) for l in our_lines} - {key(l) for l in src_lines} == added
+    # idempotent: the text is a fixed point of load + save
+    assert L.tm_settings_text_host(ours.encode("latin-1"), buf, 4096, ctypes.byref(n)) == 0
+    assert buf.raw[:n.value].decode("latin-1") == ours

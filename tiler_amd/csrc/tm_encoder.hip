@@ -175,6 +175,11 @@ struct tm_encoder {
   bool load_sharded = false;     // Load only filled the frame tiles of this process's frames (and of the frame before them)
   int load_first = 0, load_count = 0;
   // the native communicator (tm_comm_init): RCCL linked into the library, the collectives queued on the encoder's stream
+  int64_t coll_calls[4] = {0, 0, 0, 0}, coll_bytes = 0;  // per kind, and the bytes this process put through them (tm_get_collective_stats)
+  void coll_count(int kind, int64_t count) {
+    coll_calls[kind]++;
+    coll_bytes += kind == TM_COLL_ALLGATHER_BYTES ? count * co.world : count * (kind == TM_COLL_ALLREDUCE_SUM_I64 ? 8 : 4);
+  }
   ncclComm_t comm = nullptr;
   bool force_dist = false;  // a one-rank communicator walks the sharded paths too (TM_COMM_FORCE_DIST=1: tests on a one-GPU box)
   bool dist() const { return (coll_cb != nullptr || comm != nullptr) && (co.world > 1 || force_dist); }
@@ -295,6 +300,7 @@ static int need(tm_encoder *e, int step_bit, const char *what) {
 
 static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t count) {
   if (!e->coll_stream_ordered) TM_HIP(hipStreamSynchronize(e->stream));  // everything queued so far is done before the host's collective touches the buffers
+  e->coll_count(kind, count);
   const int rc = e->coll_cb(e->coll_user, kind, buf, recv, count);
   TM_CHECK(rc == 0, TM_E_HIP, "the host's collective callback failed (kind %d, code %d)", kind, rc);
   return TM_OK;
@@ -308,10 +314,23 @@ static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t coun
 // the four collective kinds on the encoder's stream through the library's own communicator: nothing drains the stream before and
 // nothing waits after -- the RCCL kernel is ordered between what the step queued before and what it queues next
 static void bind_native_collectives(tm_encoder *e) {
-  e->co.allreduce_sum_i32 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclSum, e->comm, e->stream)); return (int)TM_OK; };
-  e->co.allreduce_max_i32 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclMax, e->comm, e->stream)); return (int)TM_OK; };
-  e->co.allreduce_sum_i64 = [e](void *b, int64_t n) -> int { TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream)); return (int)TM_OK; };
+  e->co.allreduce_sum_i32 = [e](void *b, int64_t n) -> int {
+    e->coll_count(TM_COLL_ALLREDUCE_SUM_I32, n);
+    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclSum, e->comm, e->stream));
+    return (int)TM_OK;
+  };
+  e->co.allreduce_max_i32 = [e](void *b, int64_t n) -> int {
+    e->coll_count(TM_COLL_ALLREDUCE_MAX_I32, n);
+    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclMax, e->comm, e->stream));
+    return (int)TM_OK;
+  };
+  e->co.allreduce_sum_i64 = [e](void *b, int64_t n) -> int {
+    e->coll_count(TM_COLL_ALLREDUCE_SUM_I64, n);
+    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream));
+    return (int)TM_OK;
+  };
   e->co.allgather = [e](const void *snd, void *rcv, int64_t bytes) -> int {
+    e->coll_count(TM_COLL_ALLGATHER_BYTES, bytes);
     TM_NCCL(ncclAllGather(snd, rcv, (size_t)bytes, ncclInt8, e->comm, e->stream));
     return (int)TM_OK;
   };
@@ -1126,6 +1145,10 @@ static int step_reindex(tm_encoder *e) {  // Reindex, tilingencoder.pas:1993-203
 }
 
 static std::string settings_text(const Settings &s) {  // GetSettings -> SaveSettings, tilingencoder.pas:2255, 3738-3775 (TMemIniFile layout)
+  // Sections in the order of their first write, keys in write order inside a section (the ShotTrans* keys are written last but belong
+  // to [Load]), a blank line after every section but the last, WriteBool as 0/1, WriteFloat in the shortest form -- and the line
+  // ends of the Win64 build that is the reference (CR LF): the text of the reference's own demo streams, line for line, for every key
+  // this snapshot still writes (tests/test_gtm.py::test_settings_text_matches_the_demo_streams_line_for_line).
   char buf[2048];
   auto flt = [](double v) { char b[64]; snprintf(b, sizeof(b), "%.15g", v); return std::string(b); };
   snprintf(buf, sizeof(buf),
@@ -1139,7 +1162,9 @@ static std::string settings_text(const Settings &s) {  // GetSettings -> SaveSet
            s.MotionPredictRadius, (int)s.GlobalTilingUseTargetPSNR, flt(s.GlobalTilingTargetPSNR).c_str(),
            flt(s.GlobalTilingQualityBasedTileCount).c_str(), s.GlobalTilingTileCount, s.PaletteSize, s.PaletteCount, s.DitheringMode,
            (int)s.DitheringUseThomasKnoll, s.DitheringYliluoma2MixedColors, (int)s.FrameTilingExtendedPaletteUsage, s.MaxThreadCount);
-  return buf;
+  std::string out;
+  for (const char *c = buf; *c; c++) { if (*c == '\n') out += '\r'; out += *c; }
+  return out;
 }
 
 static int save_to(tm_encoder *e, const char *path) {  // Save, tilingencoder.pas:2040-2058 -> SaveStream, 5177
@@ -1384,10 +1409,7 @@ int tm_load_default_settings(tm_encoder *e) {
   return TM_OK;
 }
 
-int tm_load_settings_ini(tm_encoder *e, const char *path) {  // LoadSettings, tilingencoder.pas:3777-3815
-  TM_CHECK(e && path, TM_E_INVAL, "null argument");
-  std::ifstream in(path);
-  TM_CHECK(in.good(), TM_E_IO, "cannot open %s", path);
+static int load_settings_from(tm_encoder *e, std::istream &in) {  // LoadSettings, tilingencoder.pas:3777-3815
   tm_load_default_settings(e);
   std::map<std::string, std::string> kv;
   std::string line;
@@ -1413,6 +1435,43 @@ int tm_load_settings_ini(tm_encoder *e, const char *path) {  // LoadSettings, ti
   }
   if (kv.count("InputFileName")) e->s.InputFileName = kv["InputFileName"];
   if (kv.count("OutputFileName")) e->s.OutputFileName = kv["OutputFileName"];
+  return TM_OK;
+}
+
+int tm_load_settings_ini(tm_encoder *e, const char *path) {
+  TM_CHECK(e && path, TM_E_INVAL, "null argument");
+  std::ifstream in(path);
+  TM_CHECK(in.good(), TM_E_IO, "cannot open %s", path);
+  return load_settings_from(e, in);
+}
+
+int tm_save_settings_ini(tm_encoder *e, const char *path) {  // SaveSettings, tilingencoder.pas:3738-3775
+  TM_CHECK(e && path, TM_E_INVAL, "null argument");
+  std::ofstream out(path, std::ios::binary);
+  TM_CHECK(out.good(), TM_E_IO, "cannot create %s", path);
+  const std::string t = settings_text(e->s);
+  out.write(t.data(), (std::streamsize)t.size());
+  TM_CHECK(out.good(), TM_E_IO, "cannot write %s", path);
+  return TM_OK;
+}
+
+// LoadSettings then SaveSettings on text, no device and no encoder needed: what an INI text becomes once the setters have clamped it
+// (the embedded settings of a .gtm, tilingencoder.pas:5331-5335, are this text)
+int tm_settings_text_host(const char *ini_text, char *out, int64_t cap, int64_t *out_len) {
+  TM_CHECK(ini_text && out_len, TM_E_INVAL, "null argument");
+  tm_encoder *e = new tm_encoder();  // host state only: nothing here touches a device
+  std::istringstream in(ini_text);
+  const int rc = load_settings_from(e, in);
+  std::string t;
+  if (rc == TM_OK) t = settings_text(e->s);
+  delete e;
+  TM_TRY(rc);
+  *out_len = (int64_t)t.size();
+  if (out && cap > 0) {
+    const size_t n = std::min<size_t>(t.size(), (size_t)cap - 1);
+    memcpy(out, t.data(), n);
+    out[n] = 0;
+  }
   return TM_OK;
 }
 
@@ -1698,6 +1757,14 @@ int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, in
   e->dither_rank = rank;
   e->dither_world = world;
   e->qf_valid = false;
+  return TM_OK;
+}
+
+int tm_get_collective_stats(tm_encoder *e, int64_t calls[4], int64_t *bytes, int reset) {
+  TM_CHECK(e, TM_E_INVAL, "null encoder");
+  if (calls) memcpy(calls, e->coll_calls, sizeof(e->coll_calls));
+  if (bytes) *bytes = e->coll_bytes;
+  if (reset) { memset(e->coll_calls, 0, sizeof(e->coll_calls)); e->coll_bytes = 0; }
   return TM_OK;
 }
 

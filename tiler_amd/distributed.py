@@ -174,7 +174,10 @@ def run_all(enc, nframes, rank=0, world=1, group=None):
     setting (TilingEncoder or a stand-in)."""
     from .encoder import TEncoderStep as S
     coll = getattr(enc, "_collective", None)
-    if coll is None or coll.world != world or coll.rank != rank or coll.group is not group:
+    native = getattr(enc, "_native_comm", None)  # TilingEncoder.CommInit: the library's own RCCL communicator carries the merges
+    if native is not None:
+        assert native == (rank, world), "the encoder's native communicator is rank %d of %d" % native
+    elif coll is None or coll.world != world or coll.rank != rank or coll.group is not group:
         coll = Collective(rank, world, group)
         enc.SetCollective(rank, world, coll)  # world == 1: plain single-process run
         enc._collective = coll

@@ -174,6 +174,11 @@ class TilingEncoder:
         ptr = frames.data_ptr() if hasattr(frames, "data_ptr") else frames.ctypes.data
         check(self._L.tm_set_frames_host(c_void_p(self._h), c_void_p(ptr)))
 
+    def SaveSettings(self, path):
+        self._L.tm_save_settings_ini.restype = c_int
+        self._L.tm_save_settings_ini.argtypes = [c_void_p, c_char_p]
+        check(self._L.tm_save_settings_ini(c_void_p(self._h), str(path).encode()))
+
     def PrefetchFramesHost(self, frames):
         """queues the upload of the clip the NEXT Load will read (same argument forms as SetFramesHost) beside the current clip's steps;
         call SetFramesHost with the same clip before the Run that is to adopt it.  Borrowed until that Load has returned."""
@@ -241,6 +246,41 @@ class TilingEncoder:
     # -- multi-GPU plumbing (one process per GPU; collectives stay in the host, see tiler_amd/distributed.py)
     def SetQueryShard(self, first_frame, frame_count):
         check(self._L.tm_set_query_shard(c_void_p(self._h), first_frame, frame_count))
+
+    # -- the native multi-process path: RCCL inside the library (tm_comm_*)
+    @staticmethod
+    def CommUniqueId():
+        """128 bytes from ncclGetUniqueId: one process makes them, every process of the job passes them to CommInit"""
+        from ._lib import lib
+        buf = (ctypes.c_uint8 * 128)()
+        L = lib()
+        L.tm_comm_unique_id.restype = c_int
+        L.tm_comm_unique_id.argtypes = [c_void_p]
+        check(L.tm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def CommInit(self, comm_id, rank, world):
+        """collective: returns once all `world` processes have called it.  From then on Run(step) shards and merges by itself."""
+        assert len(comm_id) == 128
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(comm_id)
+        self._L.tm_comm_init.restype = c_int
+        self._L.tm_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+        check(self._L.tm_comm_init(c_void_p(self._h), buf, int(rank), int(world)))
+        self._native_comm = (int(rank), int(world))
+
+    def CommDestroy(self):
+        self._L.tm_comm_destroy.restype = c_int
+        self._L.tm_comm_destroy.argtypes = [c_void_p]
+        check(self._L.tm_comm_destroy(c_void_p(self._h)))
+        self._native_comm = None
+
+    def CollectiveStats(self, reset=False):
+        calls = (c_int64 * 4)()
+        nbytes = c_int64()
+        self._L.tm_get_collective_stats.restype = c_int
+        self._L.tm_get_collective_stats.argtypes = [c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int]
+        check(self._L.tm_get_collective_stats(c_void_p(self._h), calls, ctypes.byref(nbytes), 1 if reset else 0))
+        return dict(all_reduce_sum_i32=calls[0], all_reduce_max_i32=calls[1], all_reduce_sum_i64=calls[2], all_gather=calls[3], bytes=nbytes.value)
 
     def SetCollective(self, rank, world, coll):
         """one process per GPU: `coll` (tiler_amd.distributed.Collective) runs the collectives the steps ask for; world == 1 clears it"""
