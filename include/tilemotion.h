@@ -306,6 +306,13 @@ TM_API int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, 
 TM_API int tm_stage_kmodes(const uint8_t *host_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *host_labels,
                            uint8_t *host_centroids, uint64_t *host_cost, int *host_iters, void *stream);
 
+/* A17, the other half: dl3quant (dlquant/quantizer.c:437-455; imported at extern.pas:196, never called, DLL not shipped): Dennis Lee's
+ * DL3 quantiser -- histogram at lookup_bpc bits per channel (build_table3, :486-518), greedy merging of the pair of least error
+ * (reduce_table3, :583-648; calc_err, :520-541), the entries' rounded means as the palette (set_palette3, :650-664).  DEVICE pointers:
+ * npixels x (R, G, B) bytes in, [3][quant_to] planar bytes out (like userpal), *out_colors = colours left (<= quant_to).  Blocking.
+ * Parity unpinned (no reference output exists); checked against the oracle's restatement. */
+TM_API int tm_stage_dl3quant(const uint8_t *dev_rgb, int64_t npixels, int quant_to, int lookup_bpc, uint8_t *dev_palette, int *out_colors, void *stream);
+
 /* A11: OptimizePalettes (:4309-4432), host arithmetic on HOST memory (P x PaletteSize colours); in place. */
 TM_API int tm_optimize_palettes_host(int32_t *palettes, int pal_count, int pal_size, int *sweeps);
 
@@ -346,6 +353,10 @@ TM_API void bico_set_num_threads(int num_threads);
 TM_API void bico_set_rebuild_properties(tm_bico *, uint32_t interval, double initial, double grow);
 TM_API void bico_insert_line(tm_bico *, const double *line, double weight);
 TM_API int64_t bico_get_results(tm_bico *, double *centroids, double *weights);
+/* dlquant_dll.dll (extern.pas:196; quantizer.h:20-21): HOST pointers as the import has them -- width x height RGB bytes in, the palette
+ * planar into userpal[3][PALETTE_MAX = 65536]; returns 0 on success (1 on failure, message in tm_last_error).  = tm_stage_dl3quant
+ * with an upload and a read-back around it. */
+TM_API int dl3quant(unsigned char *inbuf, int width, int height, int quant_to, int lookup_bpc, unsigned char userpal[3][65536]);
 
 #ifdef __cplusplus
 }

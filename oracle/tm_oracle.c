@@ -1771,3 +1771,117 @@ int tmo_kmodes(const uint8_t *x, int64_t n, int k, int num_init, int nmod, int m
   free(starts); free(s.memb); free(s.members - 1); free(s.cent); free(s.freq); free(clust); free(bestm); free(dis); free(mind); free(used); free(bestc);
   return k;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * A17, the other half: DL3 quantisation (Dennis Lee), dlquant/quantizer.c.  Restated with the types of the Win64
+ * (LLP64) build the reference ships for: ulong = 32-bit unsigned (sums wrap at 2^32 as there), slong = 32-bit signed,
+ * err = float, sqrtf and the float products and sums in IEEE single, CScale = 1 (:23).  The progress callbacks
+ * (progress_init / _update / _end, dllmain.c) only report; the stop button never fires here.
+ */
+typedef struct {
+  uint32_t r, g, b, pixel_count; /* CUBE3, :61-67 */
+  float err;
+  int32_t cc;
+  uint8_t rr, gg, bb;
+} tmo_cube3;
+
+static void dl3_setrgb(tmo_cube3 *rec) { /* setrgb, :478-484 */
+  const int v = (int)rec->pixel_count, v2 = v >> 1;
+  rec->rr = (uint8_t)((rec->r + (uint32_t)v2) / (uint32_t)v);
+  rec->gg = (uint8_t)((rec->g + (uint32_t)v2) / (uint32_t)v);
+  rec->bb = (uint8_t)((rec->b + (uint32_t)v2) / (uint32_t)v);
+}
+
+static float dl3_calc_err(const tmo_cube3 *t, int c1, int c2) { /* calc_err, :520-541 */
+  const uint32_t P1 = t[c1].pixel_count, P2 = t[c2].pixel_count, P3 = P1 + P2;
+  const int R3 = (int)((t[c1].r + t[c2].r + (P3 >> 1)) / P3), G3 = (int)((t[c1].g + t[c2].g + (P3 >> 1)) / P3),
+            B3 = (int)((t[c1].b + t[c2].b + (P3 >> 1)) / P3);
+  const int R1 = t[c1].rr, G1 = t[c1].gg, B1 = t[c1].bb, R2 = t[c2].rr, G2 = t[c2].gg, B2 = t[c2].bb;
+  /* squares3[] holds floats of i*i (:472): the sums below are exact in single (< 2^24) */
+  float dist1 = (float)((R3 - R1) * (R3 - R1)) + (float)((G3 - G1) * (G3 - G1)) + (float)((B3 - B1) * (B3 - B1));
+  dist1 = sqrtf(dist1) * (float)P1;
+  float dist2 = (float)((R2 - R3) * (R2 - R3)) + (float)((G2 - G3) * (G2 - G3)) + (float)((B2 - B3) * (B2 - B3));
+  dist2 = sqrtf(dist2) * (float)P2;
+  return dist1 + dist2;
+}
+
+static void dl3_recount_next(tmo_cube3 *t, int tot, int i) { /* recount_next, :543-559: the first j > i of least error */
+  int c2 = 0;
+  float err = HUGE_VALF;
+  for (int j = i + 1; j < tot; j++) {
+    const float cur = dl3_calc_err(t, i, j);
+    if (cur < err) { err = cur; c2 = j; }
+  }
+  t[i].err = err;
+  t[i].cc = c2;
+}
+
+static void dl3_recount_dist(tmo_cube3 *t, int tot, int c1) { /* recount_dist, :561-581 */
+  dl3_recount_next(t, tot, c1);
+  for (int i = 0; i < c1; i++) {
+    if (t[i].cc == c1) dl3_recount_next(t, tot, i);
+    else {
+      const float cur = dl3_calc_err(t, i, c1);
+      if (cur < t[i].err) { t[i].err = cur; t[i].cc = c1; }
+    }
+  }
+}
+
+int tmo_dl3quant(const uint8_t *rgb, int64_t npixels, int quant_to, int lookup_bpc, uint8_t *pal_out) {
+  if (!rgb || !pal_out || npixels <= 0 || quant_to < 1 || lookup_bpc < 1 || lookup_bpc > 8) return -1;
+  const int64_t lookup_size = (int64_t)1 << (lookup_bpc * 3); /* :441 */
+  tmo_cube3 *t = (tmo_cube3 *)calloc((size_t)lookup_size, sizeof(tmo_cube3)); /* init_table, :457-470 */
+  if (!t) return -1;
+  /* build_table3, :486-518 */
+  const int mbpc = (1 << lookup_bpc) - 1;
+  for (int64_t i = 0; i < npixels; i++) {
+    const uint8_t *px = rgb + i * 3;
+    const int r = px[0] * mbpc / 255, g = px[1] * mbpc / 255, b = px[2] * mbpc / 255;
+    const int64_t index = (int64_t)b | ((int64_t)g << lookup_bpc) | ((int64_t)r << (lookup_bpc << 1));
+    t[index].r += px[0]; /* * CScale = 1 */
+    t[index].g += px[1];
+    t[index].b += px[2];
+    t[index].pixel_count++;
+  }
+  int tot = 0;
+  for (int64_t i = 0; i < lookup_size; i++)
+    if (t[i].pixel_count) {
+      dl3_setrgb(t + i);
+      t[tot++] = t[i];
+    }
+  /* reduce_table3, :583-648 */
+  int i;
+  for (i = 0; i < tot - 1; i++) dl3_recount_next(t, tot, i);
+  t[i].err = HUGE_VALF;
+  t[i].cc = tot;
+  while (tot > quant_to) {
+    int c1 = 0;
+    float err = HUGE_VALF;
+    for (i = 0; i < tot; i++)
+      if (t[i].err < err) { err = t[i].err; c1 = i; }
+    const int c2 = t[c1].cc;
+    t[c2].r += t[c1].r;
+    t[c2].g += t[c1].g;
+    t[c2].b += t[c1].b;
+    t[c2].pixel_count += t[c1].pixel_count;
+    dl3_setrgb(t + c2);
+    tot--;
+    t[c1] = t[tot];
+    t[tot - 1].err = HUGE_VALF;
+    t[tot - 1].cc = tot;
+    for (i = 0; i < c1; i++)
+      if (t[i].cc == tot) t[i].cc = c1;
+    for (i = c1 + 1; i < tot; i++)
+      if (t[i].cc == tot) dl3_recount_next(t, tot, i);
+    dl3_recount_dist(t, tot, c1);
+    if (c2 != tot) dl3_recount_dist(t, tot, c2);
+  }
+  /* set_palette3 (:650-664) + copy_pal: planar R, G, B */
+  for (i = 0; i < tot; i++) {
+    pal_out[i] = t[i].rr;
+    pal_out[quant_to + i] = t[i].gg;
+    pal_out[2 * quant_to + i] = t[i].bb;
+  }
+  free(t);
+  return tot;
+}

@@ -23,10 +23,6 @@
 
 #ifdef __cplusplus
 extern "C" {
-/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
-int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
-               uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
-
 #endif
 
 enum { TMO_TILE_W = 8, TMO_TILE_PX = 64, TMO_CPNS = 3, TMO_DCT = 192 };
@@ -167,15 +163,19 @@ void tmo_epu_rerank_batch(const int16_t *q, int64_t nq, const int32_t *knn_idx, 
  * props_out (may be NULL) = {props byte, dictionary size, header size field or -1}. ---- */
 int64_t tmo_lzma_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, size_t *consumed, int *props_out);
 
-#ifdef __cplusplus
-}
 /* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
 int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
                uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
 
+/* A17, the other half: dl3quant (dlquant/quantizer.c:437-455) = build_table3 (:486-518: histogram at lookup_bpc bits per channel, entries
+ * compacted in index order) + reduce_table3 (:583-648: greedy merging of the pair with the least calc_err, :520-541) + set_palette3
+ * (:650-664).  `rgb` = npixels x (R, G, B) bytes; pal_out = [3][quant_to] planar like userpal; returns the number of colours left
+ * (<= quant_to), or -1 on bad arguments.  LLP64 types as the Win64 build: ulong = uint32, slong = int32.  PARITY UNPINNED: the
+ * reference holds no output of it and its build cannot be made here (Windows.h progress callbacks). */
+int tmo_dl3quant(const uint8_t *rgb, int64_t npixels, int quant_to, int lookup_bpc, uint8_t *pal_out);
+
+#ifdef __cplusplus
+}
 #endif
-/* A17: TKModes.ComputeKModes (kmodes.pas:923-1094) on rows of 80 bytes; labels 0-based as the code returns them; returns the number of centroids */
-int tmo_kmodes(const uint8_t *rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *labels_out,
-               uint8_t *centroids_out, uint64_t *cost_out, int *iters_out);
 
 #endif

@@ -151,6 +151,14 @@ class Oracle:
         self.L.tmo_kmodes(_p(rows), ctypes.c_int64(rows.shape[0]), k, num_init, nmod, max_iter, _p(labels), _p(cent), ctypes.byref(cost), ctypes.byref(iters))
         return labels, cent, cost.value, iters.value
 
+    def dl3quant(self, rgb, quant_to, lookup_bpc):
+        """dl3quant (dlquant/quantizer.c:437-455): rgb uint8 [n][3] -> (palette uint8 [3][quant_to] planar, colours left)"""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        pal = np.zeros((3, quant_to), np.uint8)
+        self.L.tmo_dl3quant.restype = ctypes.c_int
+        n = self.L.tmo_dl3quant(_p(rgb), ctypes.c_int64(rgb.shape[0]), ctypes.c_int(quant_to), ctypes.c_int(lookup_bpc), _p(pal))
+        return pal, n
+
     def kdtree_build(self, db, bucket=32):
         """exact kd-tree over db (kept alive by the returned handle's reference to the array)"""
         db = np.ascontiguousarray(db, np.int16)

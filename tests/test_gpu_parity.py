@@ -807,6 +807,46 @@ def test_kmodes(oracle, case, num_init):
     assert np.array_equal(labels, exp_labels)
 
 
+def _dl3_image(case, rng):
+    if case == "photo":      # smooth gradients + noise: a few thousand occupied cells, sums far from wrapping
+        y, x = np.mgrid[0:240, 0:320]
+        img = np.stack([(x * 255 // 320 + rng.integers(-20, 21, x.shape)) % 256, (y * 255 // 240 + rng.integers(-20, 21, x.shape)) % 256,
+                        ((x + y) * 255 // 560 + rng.integers(-9, 10, x.shape)) % 256], axis=-1)
+        return img.reshape(-1, 3).astype(np.uint8)
+    if case == "uniform":    # every cell occupied, counts nearly equal: many near-ties in the error
+        return rng.integers(0, 256, size=(150000, 3)).astype(np.uint8)
+    if case == "flat":       # a handful of colours with equal counts: exact ties -> the first index must win everywhere
+        base = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128], [64, 64, 64], [192, 192, 192],
+                         [255, 255, 0], [0, 255, 255]], np.uint8)
+        return np.repeat(base, 1000, axis=0)
+    if case == "one":        # fewer colours than asked for: nothing to merge
+        return np.tile(np.array([[17, 99, 230]], np.uint8), (500, 1))
+    raise ValueError(case)
+
+
+@pytest.mark.parametrize("case,quant_to,bpc", [("photo", 16, 4), ("photo", 64, 5), ("uniform", 16, 3), ("uniform", 256, 4), ("flat", 4, 4), ("flat", 1, 2),
+                                               ("one", 16, 4), ("photo", 2, 1)])
+def test_dl3quant(oracle, case, quant_to, bpc):
+    """A17: dl3quant (dlquant/quantizer.c:437-455) -- the palette and the number of colours left equal the oracle's restatement of
+    build_table3 / reduce_table3 / set_palette3 (parity unpinned: the reference holds no output of it), on smooth, structureless,
+    exactly tied and degenerate inputs; through the stage seam and through the import's own signature (extern.pas:196)"""
+    import ctypes
+    from tiler_amd import stages, lib
+    rng = np.random.default_rng(quant_to * 7 + bpc)
+    img = _dl3_image(case, rng)
+    exp_pal, exp_n = oracle.dl3quant(img, quant_to, bpc)
+    pal, n = stages.dl3quant(torch.from_numpy(img).cuda(), quant_to, bpc)
+    assert n == exp_n and np.array_equal(pal.cpu().numpy(), exp_pal)
+    # the fine seam: host pointers, userpal[3][65536]
+    L = lib()
+    L.dl3quant.restype = ctypes.c_int
+    L.dl3quant.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    userpal = np.zeros((3, 65536), np.uint8)
+    h = 100 if img.shape[0] % 100 == 0 else 1
+    assert L.dl3quant(img.ctypes.data, img.shape[0] // h, h, quant_to, bpc, userpal.ctypes.data) == 0
+    assert np.array_equal(userpal[:, :exp_n], exp_pal[:, :exp_n])
+
+
 def test_fine_seam_ann_double():
     """ANN.dll's own entry points (extern.pas:178-180) as DoPalettization calls them (tilingencoder.pas:4128, 4183-4187): an array of row
     pointers to double[192] centroids, one double query per call, the squared distance back through *err.  Checked against numpy's

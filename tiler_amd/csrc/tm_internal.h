@@ -98,6 +98,8 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
 int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                                int pal_rank, int pal_world, hipStream_t stream, DevBuf *keep_keys = nullptr, int64_t *keep_n = nullptr);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
+// tm_dl3.hip: dl3quant on device pointers (blocking)
+int run_dl3quant(const void *dev_rgb, int64_t npixels, int quant_to, int lookup_bpc, void *dev_pal, int *out_colors, hipStream_t stream);
 // what the calling thread's last tile -> palette clustering and last colour quantisation ran through (tm_get_kmeans_iters)
 struct KmeansRunStats { int tile_iters = 0; int64_t tile_points = 0; int pixel_iters = 0; int64_t pixel_colours = 0, pixels = 0, pixel_colour_iters = 0; };
 KmeansRunStats &kmeans_run_stats();

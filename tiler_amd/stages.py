@@ -207,3 +207,18 @@ def kmodes(rows, num_clusters, num_init=0, num_modalities=256, max_iter=-1):
     check(lib().tm_stage_kmodes(rows.ctypes.data_as(ctypes.c_void_p), rows.shape[0], num_clusters, num_init, num_modalities, max_iter,
                                 labels.ctypes.data_as(ctypes.c_void_p), cent.ctypes.data_as(ctypes.c_void_p), ctypes.byref(cost), ctypes.byref(iters), _stream()))
     return labels, cent, cost.value, iters.value
+
+
+def dl3quant(rgb, quant_to, lookup_bpc):
+    """dl3quant (dlquant/quantizer.c:437-455): rgb = torch uint8 CUDA tensor [n][3] (R, G, B) -> (palette uint8 CUDA [3][quant_to] planar,
+    number of colours left)"""
+    import torch
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.ndim == 2 and rgb.shape[1] == 3
+    rgb = rgb.contiguous()
+    pal = torch.zeros((3, quant_to), dtype=torch.uint8, device=rgb.device)
+    n = ctypes.c_int()
+    L = lib()
+    L.tm_stage_dl3quant.restype = ctypes.c_int
+    L.tm_stage_dl3quant.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    check(L.tm_stage_dl3quant(ctypes.c_void_p(rgb.data_ptr()), rgb.shape[0], int(quant_to), int(lookup_bpc), ctypes.c_void_p(pal.data_ptr()), ctypes.byref(n), _stream()))
+    return pal, n.value
