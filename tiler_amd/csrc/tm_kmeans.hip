@@ -602,18 +602,15 @@ constexpr int H_MAXK = 64;       // centroids kept in LDS by the skipping kernel
 constexpr double H_ETA = 1e-9;   // margin of the skip test
 constexpr int H_SLICE = 1024;    // points per workgroup of k_h_bounds
 __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pts, int64_t n, const Seg *__restrict__ segs,
-                                                  const double *__restrict__ cent_t /* [192][kt]: k_h_update's transposed copy */, int kt, const int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb,
+                                                  const double *__restrict__ cent /* [k][192] */, const int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb,
                                                   const double *__restrict__ cmove /* [k] displacement of each centroid, then the largest, the second largest, whose */,
                                                   const double *__restrict__ shalf /* [k] half the distance to the nearest other centroid */, int k,
                                                   int32_t *__restrict__ need, unsigned *__restrict__ need_cnt, const int *__restrict__ quiet) {
   if (*quiet >= 0) return;
-  extern __shared__ double s_c[];  // [192][kt]: lanes of a wave read different centroids of one dimension -> different banks
   __shared__ int s_list[H_SLICE], s_need[H_SLICE];
   __shared__ int s_nlist, s_nneed;
   __shared__ unsigned s_base;
-  const int tid = threadIdx.x, kk = kt;  // (the recheck's pitch; columns past the live centroids are zeros nobody reads)
-
-  for (int e = tid; e < kt * 192; e += 256) s_c[e] = cent_t[e];  // a straight copy (transposing here cost 32-way bank conflicts and a division per element)
+  const int tid = threadIdx.x;
   if (tid == 0) { s_nlist = 0; s_nneed = 0; }
   __syncthreads();
   const double dmax = cmove[k], dmax2 = cmove[k + 1];
@@ -633,26 +630,34 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
     if (!(u * (1.0 + H_ETA) < fmax(shalf[a], l) * (1.0 - H_ETA))) s_list[atomicAdd(&s_nlist, 1)] = r * 256 + tid;
   }
   __syncthreads();
-  // pass 2, the listed ones (dense lanes): the distance to the own centroid in the arithmetic of the full computation; its square root
-  // bounds it from above.  Still unproven -> the global list
+  // pass 2, the listed ones: the distance to the own centroid tightens ub; 16 lanes per point (12 dimensions each, the row and the centroid's
+  // row read as they lie in memory -- a slice without listed points, most of them late in a clustering, reads no centroid at all).  The
+  // partial sums add in another order than the scoring's chain does: both stay within 2.2e-14 (relative) of the exact sum, far inside the
+  // factor 1 + 1e-12 that makes the root an upper bound of the distance AS SCORED.  Still unproven -> the global list
   const int nlist = s_nlist;
-  for (int t = tid; t < nlist; t += 256) {
-    const int64_t i = i0 + s_list[t];
+  if (nlist == 0) return;
+  const int l16 = tid & 15;
+  for (int t0 = 0; t0 < nlist; t0 += 16) {
+    const int t = t0 + (tid >> 4);
+    const bool act = t < nlist;
+    const int64_t i = i0 + s_list[act ? t : 0];
     const int a = assign[i];
-    const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
-    const double *c = s_c + a;
+    const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192 + l16 * 12);
+    const double2 *c = reinterpret_cast<const double2 *>(cent + (int64_t)a * 192 + l16 * 12);
+    const int4 v0 = p[0], v1 = p[1], v2 = p[2];
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+    const int pv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    const double cv[12] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y, c3.x, c3.y, c4.x, c4.y, c5.x, c5.y};
     double sd = 0.0;
-#pragma unroll 4
-    for (int j = 0; j < 48; j++) {
-      const int4 v = p[j];
-      double d0 = __dsub_rn((double)v.x, c[(4 * j) * kk]); sd = __fma_rn(d0, d0, sd);
-      d0 = __dsub_rn((double)v.y, c[(4 * j + 1) * kk]); sd = __fma_rn(d0, d0, sd);
-      d0 = __dsub_rn((double)v.z, c[(4 * j + 2) * kk]); sd = __fma_rn(d0, d0, sd);
-      d0 = __dsub_rn((double)v.w, c[(4 * j + 3) * kk]); sd = __fma_rn(d0, d0, sd);
+#pragma unroll
+    for (int j = 0; j < 12; j++) { const double d0 = __dsub_rn((double)pv[j], cv[j]); sd = __fma_rn(d0, d0, sd); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+    if (act && l16 == 0) {
+      const double u = sqrt(sd) * (1.0 + 1e-12);
+      ub[i] = u;
+      if (!(u * (1.0 + H_ETA) < fmax(shalf[a], lb[i]) * (1.0 - H_ETA))) s_need[atomicAdd(&s_nneed, 1)] = s_list[t];
     }
-    const double u = sqrt(sd) * (1.0 + 1e-12);
-    ub[i] = u;
-    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], lb[i]) * (1.0 - H_ETA))) s_need[atomicAdd(&s_nneed, 1)] = s_list[t];
   }
   // the workgroup's share of the global list with ONE atomic on its counter (a counter every listed point of the launch adds to
   // serialises them: ~6 ns each, and the early iterations list tens of thousands)
@@ -777,6 +782,17 @@ __global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict
 // the chain is a quarter as long and the list covers four times as many compute units.  Every accumulator still sums its 192 terms in
 // order, so the distances are the same doubles; the lanes' (best, second best) merge by (distance, centroid index), which is what the
 // in-order scan with its strict `<` computes.
+template <int N>
+__device__ __forceinline__ void pin_accumulators(double (&s)[N]) {  // an empty statement the optimiser must have the values ready for
+#pragma unroll
+  for (int c = 0; c < N; c++) asm volatile("" : "+v"(s[c]));
+}
+
+template <int Q>
+__device__ __forceinline__ int quad_bcast(int v) {  // lane Q of every group of four lanes, to its whole group
+  return __builtin_amdgcn_update_dpp(0, v, Q | (Q << 2) | (Q << 4) | (Q << 6), 0xf, 0xf, true);
+}
+
 __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
                                                          const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
                                                          int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
@@ -792,23 +808,34 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
   double *s_c = reinterpret_cast<double *>(s_raw);                    // [D][KCH]
   u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);       // [kk][D + 1]
   int32_t *s_moved = reinterpret_cast<int32_t *>(s_delta + kk * (D + 1));  // [NP][3]: slot, old, new
-  for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
-  if (tid == 0) s_nmoved = 0;
   // a fixed grid walks the list (a workgroup per 64 listed points was 5 000 workgroups launched to find that 4 950 have nothing to do,
   // each staging the centroids first); with at most KCH centroids they are staged once per workgroup
   const bool single = kk <= KCH;
+  // The four lanes of a point each fetch a quarter of its row (48 dimensions, 12 loads of 16 bytes, all of them in flight together: ONE
+  // round trip to memory per point -- the chunk-major copy the plain iterations stream cost a listed point twelve round trips, two chunks
+  // at a time, and a short list is all latency) and hand the values round inside their group of four with DPP broadcasts, in the order
+  // of the dimensions.  The first pass's rows are asked for before anything else.
+  auto fetch = [&](unsigned row0, int4 (&x)[12], int64_t &gi, bool &active) {
+    active = row0 + slot < cnt;
+    gi = need ? need[active ? row0 + slot : row0] : (int64_t)(active ? row0 + slot : row0);
+    const int4 *src = reinterpret_cast<const int4 *>(pts + gi * D + sub * 48);
+#pragma unroll
+    for (int u = 0; u < 12; u++) x[u] = src[u];
+  };
+  int4 x[12];
+  int64_t gi;
+  bool active;
+  fetch(blockIdx.x * (unsigned)NP, x, gi, active);
+  for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
+  if (tid == 0) s_nmoved = 0;
   if (single)
     for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + (e % KCH)];
   __syncthreads();
-  const int64_t chunk_stride = n_total * (A_DCH / 4);  // int4 units between chunks
   int total_moved = 0;
 #pragma unroll 1
   for (unsigned row0 = blockIdx.x * (unsigned)NP; row0 < cnt; row0 += gridDim.x * (unsigned)NP) {
-    const bool active = row0 + slot < cnt;
-    const int64_t gi = need ? need[active ? row0 + slot : row0] : (int64_t)(active ? row0 + slot : row0);
     double bd = 1.0e300, bd2 = 1.0e300;
     int bc = 0x7fffffff;
-    const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
 #pragma unroll 1
     for (int c0 = 0; c0 < kk; c0 += KCH) {
       if (!single) {
@@ -819,33 +846,34 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
       double s[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; c++) s[c] = 0.0;
-      auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
-        const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      auto term = [&](int v, int j) {  // dimension j of the point against this lane's CPL centroids
+        const double pj = (double)v;
+        const double *cj = s_c + j * KCH + sub * CPL;
 #pragma unroll
-        for (int j = 0; j < A_DCH; j++) {
-          const double pj = (double)v[j];
-          const double *cj = s_c + (ch * A_DCH + j) * KCH + sub * CPL;
-#pragma unroll
-          for (int c = 0; c < CPL; c += 2) {
-            const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
-            const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
-            s[c] = __fma_rn(t0, t0, s[c]);
-            s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
-          }
+        for (int c = 0; c < CPL; c += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
+          const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
+          s[c] = __fma_rn(t0, t0, s[c]);
+          s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
         }
       };
-      int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
-#pragma unroll 1
-      for (int ch = 0; ch < D / A_DCH; ch += 2) {
-        int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (ch + 2 < D / A_DCH) {
-          na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
-          nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
+      auto quarter = [&](auto qtag) {  // the 48 dimensions lane Q of the group holds
+        constexpr int Q = decltype(qtag)::value;
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+          term(quad_bcast<Q>(x[u].x), Q * 48 + u * 4);
+          term(quad_bcast<Q>(x[u].y), Q * 48 + u * 4 + 1);
+          term(quad_bcast<Q>(x[u].z), Q * 48 + u * 4 + 2);
+          term(quad_bcast<Q>(x[u].w), Q * 48 + u * 4 + 3);
+          // the accumulators pinned here: without it the optimiser sinks the whole unrolled chain of multiply-adds below its 384 centroid
+          // reads, which then all have to stay live (1 500 spilled registers, the kernel eight times slower)
+          pin_accumulators(s);
         }
-        score_chunk(a0, a1, ch);
-        score_chunk(b0, b1, ch + 1);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-      }
+      };
+      quarter(std::integral_constant<int, 0>{});
+      quarter(std::integral_constant<int, 1>{});
+      quarter(std::integral_constant<int, 2>{});
+      quarter(std::integral_constant<int, 3>{});
 #pragma unroll
       for (int c = 0; c < CPL; c++) {
         const int ci = c0 + sub * CPL + c;
@@ -854,6 +882,12 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
           else if (s[c] < bd2) bd2 = s[c];
         }
       }
+    }
+    const int64_t gi_cur = gi;
+    const bool active_cur = active;
+    {  // the next pass's rows, while this one's results are merged and written
+      const unsigned nrow0 = row0 + gridDim.x * (unsigned)NP;
+      if (nrow0 < cnt) fetch(nrow0, x, gi, active);
     }
     // the four lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
 #pragma unroll
@@ -865,12 +899,12 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
       bd2 = fmin(fmin(bd2, od2), loser);
       if (take) { bd = od; bc = oc; }
     }
-    if (active && sub == 0) {
-      ub[gi] = sqrt(bd) * (1.0 + 1e-12);
-      lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
-      const int old = assign[gi];
+    if (active_cur && sub == 0) {
+      ub[gi_cur] = sqrt(bd) * (1.0 + 1e-12);
+      lb[gi_cur] = sqrt(bd2) * (1.0 - 1e-12);
+      const int old = assign[gi_cur];
       if (old != bc) {
-        assign[gi] = bc;
+        assign[gi_cur] = bc;
         const int m = atomicAdd(&s_nmoved, 1);
         s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
       }
@@ -1512,7 +1546,6 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
     hipLaunchKernelGGL(k_cent_transpose, dim3(12), dim3(256), 0, stream, ds, cent, hcent_t.as<double>(), h_kt);
     if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
-    if ((size_t)h_kt * 192 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_bounds), hipFuncAttributeMaxDynamicSharedMemorySize, h_kt * 192 * 8);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
@@ -1533,7 +1566,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
         } else {
-          hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), (size_t)h_kt * 192 * 8, stream, pts, n, ds, hcent_t.as<double>(), h_kt, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
+          hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), 0, stream, pts, n, ds, (const double *)cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
           static const bool list1 = getenv("TM_KM_LIST1") != nullptr;  // A/B aid: a thread per point
           if (!list1)
