@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--no-defaults-extra", action="store_true",
                     help="skip the untimed extra passes with the extended palette usage on (alone, and with motion prediction)")
     ap.add_argument("--no-h2d-extra", action="store_true", help="skip the timed regions with the clip in host memory")
+    ap.add_argument("--no-kmodes-extra", action="store_true", help="skip the k-modes operator's roofline line (A17, config 5's shape)")
     ap.add_argument("--no-frozen-extra", action="store_true",
                     help="skip the extra pass on SURVEY.md 8(d)'s literal generator (no frozen tile columns, hence no exact inter-frame duplicates)")
     ap.add_argument("--no-dense-extra", action="store_true",
@@ -413,6 +414,34 @@ def main():
                             "note": "nominal = 3 B x pixels x iterations of the slowest palette + 768 B x tiles x iterations; the colours are clustered as "
                                     "distinct (colour, count) points held in LDS and the tiles' iterations skip what provably cannot change, so the stage is "
                                     "bound by its ~%d dependent iterations, not by these bytes" % (it["tile_iters"] + it["pixel_iters"])}
+        if not args.no_kmodes_extra:
+            # A17's operator at config 5's shape (4K x 600: T = 1 618 022 rows of 80 bytes, 64 clusters): SURVEY.md 8(d) prices it at 80 B per
+            # point and iteration against HBM; what bounds it is KModesIter's bin-serial rule (960 points, then the modes move)
+            gk = torch.Generator(device="cuda").manual_seed(5)
+            nk, kk_ = 1618022, 64
+            proto = torch.randint(0, 48, (40, 80), generator=gk, device="cuda", dtype=torch.uint8)
+            rows_k = proto[torch.randint(0, 40, (nk,), generator=gk, device="cuda")]
+            noise = torch.rand((nk, 80), generator=gk, device="cuda") < 0.2
+            rows_k = torch.where(noise, torch.randint(0, 48, (nk, 80), generator=gk, device="cuda", dtype=torch.uint8), rows_k).contiguous()
+            del noise
+            stages.kmodes_dev(rows_k, kk_, 0, 48, 1)  # warm-up: pool growth
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, _, cost1, _, pit1 = stages.kmodes_dev(rows_k, kk_, 0, 48, 1)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            _, _, cost5, _, pit5 = stages.kmodes_dev(rows_k, kk_, 0, 48, 5)
+            torch.cuda.synchronize()
+            d5 = time.perf_counter() - t1
+            per_iter = (d5 - d1) / max(1, (pit5 - pit1) // nk)
+            bk = 80.0 * nk
+            sr["kmodes"] = {"bound": "hbm", "kernel": "k_kmodes_argmin + k_kmodes_walk + k_kmodes_apply per bin of 960 points", "achieved": bk / per_iter / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": bk / per_iter / 1e9 / HBM_PEAK_GBS, "ms_per_iteration": per_iter * 1e3, "rows": nk, "clusters": kk_,
+                            "init_and_first_iteration_ms": d1 * 1e3, "algorithmic_bytes_per_iteration": bk,
+                            "note": "tm_stage_kmodes_dev (TKModes.ComputeKModes, kmodes.pas:923-1094) on device pointers, 80 B per point and iteration; "
+                                    "every bin of 960 points is three dependent launches (score, moves in order, histogram update), which is what the time is"}
+            del rows_k
         sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms")}
         out["stage_rooflines"] = sr
     if world == 1 and not args.no_dense_extra:

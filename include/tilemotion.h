@@ -301,10 +301,14 @@ TM_API int tm_stage_palettize(const void *feat_i32, const void *use, int64_t n, 
  * empty-cluster repair with the LCG of :88-92 seeded $42381337 (:933), stop on cost non-decrease with three graces (:1040-1049).
  * HOST pointers, like the Pascal arrays: rows [n][80] with values < num_modalities, labels int32 [n] (0-based, as the code returns
  * them), centroids [num_clusters][80].  num_init <= 0: one run from point -num_init; > 0: that many runs from spread starting points
- * (:952-964), the cheapest kept.  max_iter < 0: no limit (aMaxIter = -1).  The dissimilarity scans run on the GPU (v_sad_u8), the
- * serial bookkeeping on the calling thread. */
+ * (:952-964), the cheapest kept.  max_iter < 0: no limit (aMaxIter = -1).  An upload and a read-back round tm_stage_kmodes_dev. */
 TM_API int tm_stage_kmodes(const uint8_t *host_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *host_labels,
                            uint8_t *host_centroids, uint64_t *host_cost, int *host_iters, void *stream);
+
+/* The same on DEVICE pointers (rows [n][80], labels [n], centroids [num_clusters][80]); cost, the best run's iteration count and the
+ * points x iterations gone through (all runs) come back to the host.  Blocking. */
+TM_API int tm_stage_kmodes_dev(const uint8_t *dev_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *dev_labels,
+                               uint8_t *dev_centroids, uint64_t *host_cost, int *host_iters, int64_t *host_point_iters, void *stream);
 
 /* A17, the other half: dl3quant (dlquant/quantizer.c:437-455; imported at extern.pas:196, never called, DLL not shipped): Dennis Lee's
  * DL3 quantiser -- histogram at lookup_bpc bits per channel (build_table3, :486-518), greedy merging of the pair of least error

@@ -807,6 +807,26 @@ def test_kmodes(oracle, case, num_init):
     assert np.array_equal(labels, exp_labels)
 
 
+def test_kmodes_on_device_pointers_at_the_4k_clip_shape(oracle):
+    """config 5's shape: a million rows of 80 bytes, 64 clusters, on device pointers -- labels, modes and cost equal
+    the oracle's after a farthest-first initialisation from point 0 and three iterations of KModesIter (the oracle's CPU time bounds the
+    iteration count here, not the GPU's); the data have structure (prototypes + noise) so that early bins move most of their points,
+    modes change in almost every bin and the late ones settle"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(5)
+    n, k = 1_000_000, 64
+    proto = rng.integers(0, 48, size=(40, 80))
+    rows = proto[rng.integers(0, 40, size=n)].copy()
+    noise = rng.random(rows.shape) < 0.2
+    rows[noise] = rng.integers(0, 48, size=int(noise.sum()))
+    rows = rows.astype(np.uint8)
+    exp_labels, exp_cent, exp_cost, exp_iters = oracle.kmodes(rows, k, 0, 48, 3)
+    labels, cent, cost, iters, point_iters = stages.kmodes_dev(torch.from_numpy(rows).cuda(), k, 0, 48, 3)
+    assert cost == exp_cost and iters == exp_iters and point_iters == 3 * n
+    assert np.array_equal(cent.cpu().numpy(), exp_cent)
+    assert np.array_equal(labels.cpu().numpy(), exp_labels)
+
+
 def _dl3_image(case, rng):
     if case == "photo":      # smooth gradients + noise: a few thousand occupied cells, sums far from wrapping
         y, x = np.mgrid[0:240, 0:320]

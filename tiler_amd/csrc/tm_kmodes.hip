@@ -1,17 +1,19 @@
 // tm_kmodes.hip -- A17: TKModes.ComputeKModes (kmodes.pas:923-1094) for rows of cKModesFeatureCount = 80 bytes.
 //
 // Unreachable in the reference snapshot (nothing calls it) but named by the north star, so it is built as an operator of its
-// own: tm_stage_kmodes.  What is parallel in the algorithm runs on the GPU --
+// own: tm_stage_kmodes (host pointers, like the Pascal arrays) and tm_stage_kmodes_dev (device pointers).  Everything the clustering
+// keeps -- memberships, member counts, the k x 80 x num_modalities histograms of MovePointCat, the modes, the LCG's seed -- lives in HBM:
 //   * MatchingDissim (kmodes.pas:248-259) = sum |a - b| + 2048 x #(a != b) over the 80 bytes of a row: twenty v_sad_u8
 //     (four bytes each) plus a count of the non-zero bytes of a XOR b, the GPU form of the reference's psadbw / pcmpeqb / popcnt
 //     (kmodes.pas:314-450);
 //   * GetMinMatchingDissim for a range of points against the k modes (the LAST minimum wins, `dis <= best`);
-//   * the farthest-first initialisation's min-distance update and its pick (the LAST largest among unused points wins, 757-762)
-// -- and what is inherently serial stays on the host exactly as written: Huang's online mode update MovePointCat (774-803) one
-// moved point after the other, the empty-cluster repair with the LCG RandInt (88-92), the stopping rule with its three graces.
-// KModesIter (851-921) scores a bin of 960 points against the modes as they stand at the start of the bin; here all remaining
-// points are scored in one launch and the launch is repeated from the next bin on only after a bin that changed a mode, which is
-// the same thing (a score only depends on the modes).
+//   * the farthest-first initialisation's min-distance update and its pick (the LAST largest among unused points wins, 757-762);
+//   * KModesIter (851-921) bin by bin, as the reference walks it (a bin of 960 points is scored against the modes as they stand at its
+//     start, then its points move one after the other): k_kmodes_argmin over the bin, k_kmodes_walk (the moves in order, the
+//     empty-cluster repair with RandInt, 88-92), k_kmodes_apply (Huang's online mode update MovePointCat, 774-803, one wave per
+//     (cluster, attribute) pair: the pairs are independent, the moves inside a pair are applied in order).
+// What bounds it is that bin-serial rule, not bytes: three dependent launches per 960 points.  The host keeps the stopping rule with its
+// three graces (1040-1049) and reads sixteen bytes per iteration.
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -91,53 +93,275 @@ __global__ __launch_bounds__(256) void k_kmodes_ff(const uint32_t *__restrict__ 
   }
 }
 
-uint32_t rand_int(uint32_t range, uint32_t &seed) {  // kmodes.pas:88-92
+__host__ __device__ inline uint32_t rand_int(uint32_t range, uint32_t &seed) {  // kmodes.pas:88-92
   seed = (uint32_t)((int32_t)(seed * 0x08088405u) + 1);
   return (uint32_t)(((uint64_t)seed * (uint64_t)range) >> 32);
 }
 
-struct Modes {
-  const uint8_t *x; int64_t n; int k, nmod;
-  std::vector<int32_t> memb, freq;   // freq [k][80][nmod]
-  std::vector<int64_t> members;
-  std::vector<uint8_t> cent;
-  bool cent_changed = false;
-  static int max_index(const int32_t *arr, int n) {  // GetMaxValueIndex, kmodes.pas:155-167: first largest
-    int res = -1, best = INT_MIN;
-    for (int i = 0; i < n; i++) if (arr[i] > best) { best = arr[i]; res = i; }
-    return res;
+// ---- the clustering's state lives in HBM: memberships, member counts, the per-(cluster, attribute) histograms of
+// MovePointCat (k x 80 x num_modalities counters), the modes, the LCG's seed, the iteration's cost and move counters
+struct KmState {
+  int32_t *memb, *clust;      // [n]
+  unsigned *dis;              // [n]
+  int32_t *members;           // [k]
+  int32_t *freq;              // [k][80][nmod]
+  uint8_t *cent;              // [k][80]
+  uint32_t *seed;             // [1]
+  unsigned long long *cost;   // [1] of the running iteration
+  unsigned *moves;            // [1]
+  int3 *mlist;                // the bin's moves in order: (point, to, from), at most 2 x 960
+  unsigned *nmoves;           // [1]
+  int *bad;                   // [1] set when something that cannot happen did (no donor for a repair)
+};
+
+__global__ void k_kmodes_validate(const uint8_t *__restrict__ rows, int64_t nbytes, int nmod, int *__restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nbytes; i += (int64_t)gridDim.x * blockDim.x)
+    if (rows[i] >= nmod) atomicExch(bad, 1);
+}
+
+__global__ void k_kmodes_take_rows(const uint8_t *__restrict__ rows, const int64_t *__restrict__ which, int k, uint8_t *__restrict__ cent) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * KM_ATTRS; e += gridDim.x * blockDim.x) cent[e] = rows[which[e / KM_ATTRS] * KM_ATTRS + e % KM_ATTRS];
+}
+
+// initial membership = the first scores; member counts and histograms by integer atomics (order-free) -- kmodes.pas:978-996
+__global__ void k_kmodes_init_tables(const uint8_t *__restrict__ rows, int64_t n, int nmod, KmState st) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * KM_ATTRS; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / KM_ATTRS;
+    const int a = (int)(e - i * KM_ATTRS), c = st.clust[i];
+    if (a == 0) { st.memb[i] = c; atomicAdd(&st.members[c], 1); }
+    atomicAdd(&st.freq[((int64_t)c * KM_ATTRS + a) * nmod + rows[e]], 1);
   }
-  void move(int64_t ipoint, int to, int from) {  // MovePointCat, kmodes.pas:774-803
-    const uint8_t *p = x + ipoint * KM_ATTRS;
-    memb[(size_t)ipoint] = to;
-    members[(size_t)to]++;
-    members[(size_t)from]--;
-    for (int a = 0; a < KM_ATTRS; a++) {
-      const int cur = p[a];
-      int32_t *tc = &freq[((size_t)to * KM_ATTRS + a) * nmod], *fc = &freq[((size_t)from * KM_ATTRS + a) * nmod];
-      tc[cur]++;
-      uint8_t &tcent = cent[(size_t)to * KM_ATTRS + a];
-      if (tc[tcent] < tc[cur]) { tcent = (uint8_t)cur; cent_changed = true; }
-      fc[cur]--;
-      uint8_t &fcent = cent[(size_t)from * KM_ATTRS + a];
-      if (fcent == cur) {
-        const uint8_t nv = (uint8_t)max_index(fc, nmod);
-        if (nv != fcent) { fcent = nv; cent_changed = true; }
+}
+
+// the first largest counter of a histogram row held four entries per lane (entry = lane + 64 slot): GetMaxValueIndex, kmodes.pas:155-167
+__device__ __forceinline__ int km_first_largest(const int (&t)[4], int nmod, int lane) {
+  int bv = INT_MIN, bi = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int idx = lane + 64 * s;
+    if (idx < nmod && t[s] > bv) { bv = t[s]; bi = idx; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ov = __shfl_xor(bv, o), oi = __shfl_xor(bi, o);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  return bi;
+}
+
+// the modes after the initial assignment (997-1011): an empty cluster takes, attribute by attribute, the value of a row drawn with
+// RandInt -- clusters in order, attributes in order, one draw each: a single thread walks the LCG; the others' modes come from their histograms
+__global__ __launch_bounds__(64) void k_kmodes_init_modes(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, KmState st) {
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (lane == 0) {
+      uint32_t seed = *st.seed;
+      for (int c = 0; c < k; c++)
+        if (st.members[c] == 0)
+          for (int a = 0; a < KM_ATTRS; a++) st.cent[c * KM_ATTRS + a] = rows[(int64_t)rand_int((uint32_t)n, seed) * KM_ATTRS + a];
+      *st.seed = seed;
+    }
+    return;
+  }
+  for (int pr = blockIdx.x - 1; pr < k * KM_ATTRS; pr += gridDim.x - 1) {
+    const int c = pr / KM_ATTRS;
+    if (st.members[c] == 0) continue;
+    int t[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) t[sl] = lane + 64 * sl < nmod ? st.freq[(int64_t)pr * nmod + lane + 64 * sl] : 0;
+    const int m = km_first_largest(t, nmod, lane);
+    if (lane == 0) st.cent[pr] = (uint8_t)m;
+  }
+}
+
+// ---- one bin of KModesIter (851-921), three launches.
+// (1) the bin's points against the modes as they stand NOW (the reference scores a bin at its start): k_kmodes_argmin over [b0, b1).
+// (2) k_kmodes_walk, one workgroup: the bin's cost, then its points in order -- a point whose score names another cluster moves (memberships
+//     and member counts at once; the histograms follow in (3)); a move that empties a cluster is followed by the repair of 879-897: a
+//     member of the LAST largest cluster, the RandInt-th in index order, moves into the empty one (found by all threads together: each
+//     counts its stretch of the memberships).  The moves go on a list in the order they happen.
+constexpr int KM_BIN = 960, KM_WT = 1024;
+__global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, int64_t b1, int k, KmState st) {
+  extern __shared__ int s_members[];  // [k]
+  __shared__ int s_mb[KM_BIN], s_cl[KM_BIN];
+  __shared__ unsigned long long s_cost[KM_WT / 64];
+  __shared__ int s_cnt[KM_WT], s_wtot[KM_WT / 64];
+  __shared__ int s_state, s_from, s_to;   // 0 done, 1 a repair is wanted: cluster s_to is empty, donor s_from
+  __shared__ unsigned s_pick;
+  __shared__ long long s_found;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = (int)(b1 - b0);
+  for (int c = tid; c < k; c += KM_WT) s_members[c] = st.members[c];
+  unsigned long long cost = 0;
+  for (int j = tid; j < nb; j += KM_WT) { s_mb[j] = st.memb[b0 + j]; s_cl[j] = st.clust[b0 + j]; cost += st.dis[b0 + j]; }
+  for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
+  if (lane == 0) s_cost[wave] = cost;
+  __syncthreads();
+  unsigned nmv = 0, moves = 0;
+  uint32_t seed = *st.seed;
+  int chunk = 0;                 // wave 0's place in the bin: 64 points at a time
+  unsigned long long todo = 0;   // the chunk's points still to look at
+  bool fresh = true;
+  const int64_t per = (n + KM_WT - 1) / KM_WT;
+  for (;;) {
+    if (wave == 0) {  // (every lane of the wave runs the walk with the same values: the list is written by lane 0)
+      int state = 0;
+      while (chunk * 64 < nb) {
+        const int j0 = chunk * 64;
+        if (fresh) { todo = j0 + 64 <= nb ? ~0ull : ((1ull << (nb - j0)) - 1ull); fresh = false; }
+        const bool mine = j0 + lane < nb && ((todo >> lane) & 1ull) && s_mb[j0 + lane] != s_cl[j0 + lane];
+        const unsigned long long mv = __builtin_amdgcn_ballot_w64(mine);
+        if (!mv) { chunk++; fresh = true; continue; }
+        const int bit = __builtin_ctzll(mv), j = j0 + bit;
+        todo &= bit == 63 ? 0ull : (~0ull << (bit + 1));  // everything up to and including j has been looked at
+        const int to = s_cl[j], old = s_mb[j];
+        if (lane == 0) {
+          st.memb[b0 + j] = to;
+          s_mb[j] = to;
+          st.mlist[nmv] = make_int3((int)(b0 + j), to, old);
+          s_members[to]++;
+          s_members[old]--;
+        }
+        nmv++;
+        moves++;
+        const int left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_members[old], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (left == 0) {  // CountClusterMembers(old_clust) = 0: the donor is the LAST largest cluster (667), its RandInt(size)-th member
+          int from = 0, mc = 0;
+          for (int c0 = 0; c0 < k; c0 += 64) {
+            const int c = c0 + lane;
+            const int v = c < k ? __hip_atomic_load(&s_members[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : -1;
+            int bv = v, bc = c;
+            for (int o = 32; o > 0; o >>= 1) {
+              const int ov = __shfl_xor(bv, o), oc = __shfl_xor(bc, o);
+              if (ov > bv || (ov == bv && oc > bc)) { bv = ov; bc = oc; }
+            }
+            if (bv >= mc) { mc = bv; from = bc; }
+          }
+          const uint32_t pick = rand_int((uint32_t)mc, seed);
+          if (lane == 0) { s_from = from; s_to = old; s_pick = pick; }
+          state = 1;
+          break;
+        }
+      }
+      if (lane == 0) s_state = state;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the memberships written so far are what the search below reads
+    }
+    __syncthreads();
+    if (s_state == 0) break;
+    // ---- all threads: the s_pick-th point (in index order) whose membership is s_from
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int from = s_from;
+    const int64_t lo = std::min<int64_t>((int64_t)tid * per, n), hi = std::min<int64_t>(lo + per, n);
+    int cnt = 0;
+    for (int64_t i = lo; i < hi; i++) cnt += __hip_atomic_load(&st.memb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == from ? 1 : 0;
+    int inc = cnt;  // inclusive prefix inside the wave
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    s_cnt[tid] = inc - cnt;
+    if (lane == 63) s_wtot[wave] = inc;
+    if (tid == 0) s_found = -1;
+    __syncthreads();
+    int before = s_cnt[tid];
+    for (int w2 = 0; w2 < wave; w2++) before += s_wtot[w2];
+    const int pick = (int)s_pick;
+    if (pick >= before && pick < before + cnt) {
+      int seen = before;
+      for (int64_t i = lo; i < hi; i++)
+        if (__hip_atomic_load(&st.memb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == from) {
+          if (seen == pick) { s_found = i; break; }
+          seen++;
+        }
+    }
+    __syncthreads();
+    const long long r = s_found;
+    if (r < 0) { if (tid == 0) *st.bad = 2; break; }
+    if (wave == 0) {  // the repair's own move: r leaves s_from for the emptied cluster
+      const int to = s_to;
+      if (lane == 0) {
+        st.memb[r] = to;
+        st.mlist[nmv] = make_int3((int)r, to, from);
+        s_members[to]++;
+        s_members[from]--;
+        if (r >= b0 && r < b1) s_mb[r - b0] = to;  // a point of this very bin: looked at again with its new membership when its turn comes
+      }
+      nmv++;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int c = tid; c < k; c += KM_WT) st.members[c] = s_members[c];
+  if (tid == 0) {
+    unsigned long long c = 0;
+    for (int w2 = 0; w2 < KM_WT / 64; w2++) c += s_cost[w2];
+    *st.cost += c;
+    *st.moves += moves;
+    *st.nmoves = nmv;
+    *st.seed = seed;
+  }
+}
+
+// (3) MovePointCat's histogram side (774-803), one wave per (cluster, attribute): the wave holds the pair's row of counters (four per
+//     lane) and its mode, walks the bin's move list in order and applies the moves that enter or leave its cluster -- the counter of the
+//     point's value up and the mode following it when it is overtaken; the counter down and, when the mode itself lost a member, the first
+//     largest counter as the new mode.  Pairs are independent of each other, which is all the parallelism the online update has.
+__global__ __launch_bounds__(256) void k_kmodes_apply(const uint8_t *__restrict__ rows, int k, int nmod, KmState st) {
+  const unsigned nmv = *st.nmoves;
+  if (nmv == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pr >= k * KM_ATTRS) return;
+  const int c = pr / KM_ATTRS, a = pr - c * KM_ATTRS;
+  int t[4];
+  bool loaded = false;
+  int mode = 0;
+  for (unsigned e0 = 0; e0 < nmv; e0 += 64) {
+    const unsigned e = e0 + lane;
+    int3 mv = make_int3(0, -1, -1);
+    if (e < nmv) mv = st.mlist[e];
+    const bool in = mv.y == c, out = mv.z == c;
+    unsigned long long m = __builtin_amdgcn_ballot_w64(in || out);
+    if (!m) continue;
+    const int cur_l = (in || out) ? (int)rows[(int64_t)mv.x * KM_ATTRS + a] : 0;  // the matching moves' values, fetched together
+    if (!loaded) {
+#pragma unroll
+      for (int sl = 0; sl < 4; sl++) t[sl] = lane + 64 * sl < nmod ? st.freq[(int64_t)pr * nmod + lane + 64 * sl] : 0;
+      mode = st.cent[pr];
+      loaded = true;
+    }
+    while (m) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      const int cur = __builtin_amdgcn_readlane(cur_l, bit);
+      const bool enters = __builtin_amdgcn_readlane((int)in, bit) != 0;
+      const int own = cur & 63, sl = cur >> 6;
+      const int d = enters ? 1 : -1;
+      if (lane == own) { t[0] += sl == 0 ? d : 0; t[1] += sl == 1 ? d : 0; t[2] += sl == 2 ? d : 0; t[3] += sl == 3 ? d : 0; }
+      if (enters) {
+        const int msl = mode >> 6;
+        const int vm = __builtin_amdgcn_readlane(msl == 0 ? t[0] : msl == 1 ? t[1] : msl == 2 ? t[2] : t[3], mode & 63);
+        const int vc = __builtin_amdgcn_readlane(sl == 0 ? t[0] : sl == 1 ? t[1] : sl == 2 ? t[2] : t[3], own);
+        if (vm < vc) mode = cur;
+      } else if (mode == cur) {
+        mode = km_first_largest(t, nmod, lane);
       }
     }
   }
-};
+  if (loaded) {
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) if (lane + 64 * sl < nmod) st.freq[(int64_t)pr * nmod + lane + 64 * sl] = t[sl];
+    if (lane == 0) st.cent[pr] = (uint8_t)mode;
+  }
+}
 
 }  // namespace
 
-int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, int max_iter, int32_t *labels_out, uint8_t *cent_out, uint64_t *cost_out,
-               int *iters_out, hipStream_t stream) {
+// TKModes.ComputeKModes on DEVICE pointers: rows [n][80], labels [n], centroids [k][80]; the host keeps the stopping rule
+// (1040-1049) and the run bookkeeping, one small read-back per iteration.
+int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, int max_iter, int32_t *labels_out, uint8_t *cent_out, uint64_t *cost_out,
+                   int *iters_out, int64_t *point_iters_out, hipStream_t stream) {
   TM_TRY(require_device());
   TM_CHECK(rows && labels_out && cent_out, TM_E_INVAL, "kmodes: null argument");
   TM_CHECK(n >= 1 && n < (1ll << 31), TM_E_INVAL, "kmodes: %lld points", (long long)n);
   TM_CHECK(k >= 1 && k <= 4096, TM_E_INVAL, "kmodes: %d clusters outside 1..4096", k);
   TM_CHECK(nmod >= 1 && nmod <= 256, TM_E_INVAL, "kmodes: %d modalities outside 1..256", nmod);
-  for (int64_t i = 0; i < n * KM_ATTRS; i++) TM_CHECK(rows[i] < nmod, TM_E_INVAL, "kmodes: value %d at byte %lld is not below the %d modalities", rows[i], (long long)i, nmod);
   if (max_iter < 0) max_iter = INT_MAX;
   const int nruns = num_init <= 0 ? 1 : num_init;
   std::vector<int64_t> starts((size_t)nruns);
@@ -153,52 +377,63 @@ int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, in
     }
   }
   for (int64_t sp : starts) TM_CHECK(sp >= 0 && sp < n, TM_E_INVAL, "kmodes: starting point %lld outside the %lld points", (long long)sp, (long long)n);
-  DevBuf drows, dmodes, dclust, ddis, dused, dmind, dpartial;
+  DevBuf dclust, ddis, dmemb, dmembers, dfreq, dcent, dused, dmind, dpartial, dwhich, dscal, dmlist, dbestm, dbestc;
   const int nblk = (int)std::min<int64_t>((n + 255) / 256, 2048);
-  TM_TRY(drows.alloc((size_t)n * KM_ATTRS)); TM_TRY(dmodes.alloc((size_t)k * KM_ATTRS)); TM_TRY(dclust.alloc((size_t)n * 4)); TM_TRY(ddis.alloc((size_t)n * 4));
-  TM_TRY(dused.alloc((size_t)n)); TM_TRY(dmind.alloc((size_t)n * 4)); TM_TRY(dpartial.alloc((size_t)nblk * 8));
-  TM_HIP(hipMemcpyAsync(drows.p, rows, (size_t)n * KM_ATTRS, hipMemcpyHostToDevice, stream));
-  Modes s;
-  s.x = rows; s.n = n; s.k = k; s.nmod = nmod;
-  s.memb.assign((size_t)n, -1);
-  s.members.assign((size_t)k, 0);
-  s.cent.assign((size_t)k * KM_ATTRS, 0xff);
-  s.freq.assign((size_t)k * KM_ATTRS * nmod, 0);
-  std::vector<int32_t> clust((size_t)n), bestm((size_t)n);
-  std::vector<unsigned> dis((size_t)n);
-  std::vector<uint8_t> used((size_t)n), bestc((size_t)k * KM_ATTRS);
-  std::vector<u64> partial((size_t)nblk);
+  TM_TRY(dclust.alloc((size_t)n * 4)); TM_TRY(ddis.alloc((size_t)n * 4)); TM_TRY(dmemb.alloc((size_t)n * 4)); TM_TRY(dmembers.alloc((size_t)k * 4));
+  TM_TRY(dfreq.alloc((size_t)k * KM_ATTRS * nmod * 4)); TM_TRY(dcent.alloc((size_t)k * KM_ATTRS)); TM_TRY(dused.alloc((size_t)n)); TM_TRY(dmind.alloc((size_t)n * 4));
+  TM_TRY(dpartial.alloc((size_t)nblk * 8)); TM_TRY(dwhich.alloc((size_t)k * 8)); TM_TRY(dscal.alloc(64)); TM_TRY(dmlist.alloc((size_t)(2 * KM_BIN + 8) * sizeof(int3)));
+  TM_TRY(dbestm.alloc((size_t)n * 4)); TM_TRY(dbestc.alloc((size_t)k * KM_ATTRS));
+  // scalars: [0] seed (u32), [8] cost (u64), [16] moves (u32), [20] nmoves (u32), [24] bad (int)
+  KmState st;
+  st.memb = dmemb.as<int32_t>(); st.clust = dclust.as<int32_t>(); st.dis = ddis.as<unsigned>(); st.members = dmembers.as<int32_t>(); st.freq = dfreq.as<int32_t>();
+  st.cent = dcent.as<uint8_t>(); st.seed = dscal.as<uint32_t>(); st.cost = reinterpret_cast<unsigned long long *>(dscal.as<uint8_t>() + 8);
+  st.moves = reinterpret_cast<unsigned *>(dscal.as<uint8_t>() + 16); st.nmoves = reinterpret_cast<unsigned *>(dscal.as<uint8_t>() + 20);
+  st.bad = reinterpret_cast<int *>(dscal.as<uint8_t>() + 24); st.mlist = dmlist.as<int3>();
+  {
+    uint8_t init[64] = {0};
+    const uint32_t seed0 = 0x42381337u;  // 933
+    memcpy(init, &seed0, 4);
+    TM_HIP(hipMemcpyAsync(dscal.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    TM_HIP(hipStreamSynchronize(stream));  // init[] is on the stack
+  }
+  hipLaunchKernelGGL(k_kmodes_validate, dim3((unsigned)std::min<int64_t>((n * KM_ATTRS + 255) / 256, 4096)), dim3(256), 0, stream, rows, n * KM_ATTRS, nmod, st.bad);
   const size_t lds = (size_t)k * KM_ATTRS;
   TM_CHECK(lds <= 160 * 1024 - 1024, TM_E_INVAL, "kmodes: the modes of %d clusters do not fit LDS", k);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_kmodes_argmin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto score_from = [&](int64_t first) -> int {  // clust / dis of points [first, n) against the modes as they stand
-    TM_HIP(hipMemcpyAsync(dmodes.p, s.cent.data(), (size_t)k * KM_ATTRS, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_kmodes_argmin, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n - first + 255) / 256, 2048))), dim3(256), lds, stream,
-                       drows.as<uint32_t>(), first, n, dmodes.as<uint32_t>(), k, dclust.as<int32_t>(), ddis.as<unsigned>());
+  auto score = [&](int64_t first, int64_t last) -> int {  // clust / dis of points [first, last) against the modes as they stand
+    hipLaunchKernelGGL(k_kmodes_argmin, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((last - first + 255) / 256, 2048))), dim3(256), lds, stream,
+                       reinterpret_cast<const uint32_t *>(rows), first, last, dcent.as<uint32_t>(), k, dclust.as<int32_t>(), ddis.as<unsigned>());
     TM_HIP(hipGetLastError());
-    TM_HIP(hipMemcpyAsync(clust.data() + first, dclust.as<int32_t>() + first, (size_t)(n - first) * 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipMemcpyAsync(dis.data() + first, ddis.as<unsigned>() + first, (size_t)(n - first) * 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
-    s.cent_changed = false;
     return TM_OK;
   };
-  uint32_t seed = 0x42381337u;  // 933
+  struct Scal { uint32_t seed, pad; unsigned long long cost; unsigned moves, nmoves; int bad; };
+  auto read_scal = [&](Scal *h) -> int {
+    TM_HIP(hipMemcpyAsync(h, dscal.p, sizeof(Scal), hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    TM_CHECK(h->bad != 1, TM_E_INVAL, "kmodes: a value is not below the %d modalities", nmod);
+    TM_CHECK(h->bad == 0, TM_E_INVAL, "kmodes: empty-cluster repair found no donor");
+    return TM_OK;
+  };
+  {  // nothing below may index a histogram with a value that is not a modality
+    Scal h;
+    TM_TRY(read_scal(&h));
+  }
+  std::vector<u64> partial((size_t)nblk);
+  std::vector<int64_t> which((size_t)k);
   uint64_t all_best = ~0ull;
   int all_iters = 0;
+  int64_t point_iters = 0;
   for (int run = 0; run < nruns; run++) {
-    // ---- InitFarthestFirst (694-772)
-    std::fill(used.begin(), used.end(), 0);
-    std::fill(s.cent.begin(), s.cent.end(), 0xff);
+    // ---- InitFarthestFirst (694-772): the picks settle on the host from every block's candidate
     TM_HIP(hipMemsetAsync(dmind.p, 0xff, (size_t)n * 4, stream));
     TM_HIP(hipMemsetAsync(dused.p, 0, (size_t)n, stream));
     int64_t far = starts[(size_t)run];
     for (int c = 0; c < k; c++) {
-      memcpy(&s.cent[(size_t)c * KM_ATTRS], rows + far * KM_ATTRS, KM_ATTRS);
-      used[(size_t)far] = 1;
+      which[(size_t)c] = far;
       const uint8_t one = 1;
       TM_HIP(hipMemcpyAsync(dused.as<uint8_t>() + far, &one, 1, hipMemcpyHostToDevice, stream));
       if (c == k - 1) break;
-      hipLaunchKernelGGL(k_kmodes_ff, dim3(nblk), dim3(256), 0, stream, drows.as<uint32_t>(), n, far, dused.as<uint8_t>(), dmind.as<unsigned>(), dpartial.as<u64>());
+      hipLaunchKernelGGL(k_kmodes_ff, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(rows), n, far, dused.as<uint8_t>(), dmind.as<unsigned>(), dpartial.as<u64>());
       TM_HIP(hipGetLastError());
       TM_HIP(hipMemcpyAsync(partial.data(), dpartial.p, (size_t)nblk * 8, hipMemcpyDeviceToHost, stream));
       TM_HIP(hipStreamSynchronize(stream));
@@ -206,54 +441,35 @@ int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, in
       for (u64 v : partial) best = std::max(best, v);
       far = best ? (int64_t)(uint32_t)(best - 1) : starts[(size_t)run];  // no unused point left: ifarthest stays InitPoint (756)
     }
+    TM_HIP(hipMemcpyAsync(dwhich.p, which.data(), (size_t)k * 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_kmodes_take_rows, dim3((unsigned)((k * KM_ATTRS + 255) / 256)), dim3(256), 0, stream, rows, dwhich.as<int64_t>(), k, st.cent);
     // ---- initial assignment and modes (978-1011)
-    std::fill(s.freq.begin(), s.freq.end(), 0);
-    std::fill(s.members.begin(), s.members.end(), 0);
-    TM_TRY(score_from(0));
-    for (int64_t i = 0; i < n; i++) {
-      const int c = clust[(size_t)i];
-      s.memb[(size_t)i] = c;
-      s.members[(size_t)c]++;
-      for (int a = 0; a < KM_ATTRS; a++) s.freq[((size_t)c * KM_ATTRS + a) * nmod + rows[i * KM_ATTRS + a]]++;
-    }
-    for (int c = 0; c < k; c++) {
-      if (s.members[(size_t)c] == 0) {
-        for (int a = 0; a < KM_ATTRS; a++) s.cent[(size_t)c * KM_ATTRS + a] = rows[(int64_t)rand_int((uint32_t)n, seed) * KM_ATTRS + a];
-      } else {
-        for (int a = 0; a < KM_ATTRS; a++) s.cent[(size_t)c * KM_ATTRS + a] = (uint8_t)Modes::max_index(&s.freq[((size_t)c * KM_ATTRS + a) * nmod], nmod);
-      }
-    }
+    TM_HIP(hipMemsetAsync(dfreq.p, 0, (size_t)k * KM_ATTRS * nmod * 4, stream));
+    TM_HIP(hipMemsetAsync(dmembers.p, 0, (size_t)k * 4, stream));
+    TM_TRY(score(0, n));
+    hipLaunchKernelGGL(k_kmodes_init_tables, dim3((unsigned)std::min<int64_t>((n * KM_ATTRS + 255) / 256, 8192)), dim3(256), 0, stream, rows, n, nmod, st);
+    hipLaunchKernelGGL(k_kmodes_init_modes, dim3((unsigned)std::min(k * KM_ATTRS, 2048) + 1), dim3(64), 0, stream, rows, n, k, nmod, st);
+    TM_HIP(hipGetLastError());
+    TM_HIP(hipStreamSynchronize(stream));  // `which` and `one` are host memory the copies above read
     int itr = 0, worse = 0, bestitr = 0;
     bool converged = false;
     uint64_t prevcost = ~0ull, bestcost = ~0ull;
     while (itr < max_iter && !converged) {
       itr++;
-      // ---- KModesIter (851-921)
-      int moves = 0;
-      uint64_t cost = 0;
-      TM_TRY(score_from(0));
-      for (int64_t b0 = 0; b0 < n; b0 += 960) {
-        const int64_t b1 = std::min<int64_t>(b0 + 960, n);
-        if (s.cent_changed) TM_TRY(score_from(b0));  // a mode moved since the scores were taken: the bins from here on see the new modes
-        for (int64_t i = b0; i < b1; i++) {
-          cost += dis[(size_t)i];
-          if (s.memb[(size_t)i] != clust[(size_t)i]) {
-            moves++;
-            const int old = s.memb[(size_t)i];
-            s.move(i, clust[(size_t)i], old);
-            if (s.members[(size_t)old] == 0) {  // CountClusterMembers(old_clust) = 0: refill it from the largest cluster (the LAST largest, 667)
-              int from = 0;
-              int64_t mc = 0;
-              for (int c = 0; c < k; c++) if (s.members[(size_t)c] >= mc) { mc = s.members[(size_t)c]; from = c; }
-              const uint32_t pick = rand_int((uint32_t)mc, seed);
-              int64_t r = -1, cnt = 0;
-              for (int64_t j = 0; j < n; j++) if (s.memb[(size_t)j] == from) { if (cnt == (int64_t)pick) { r = j; break; } cnt++; }
-              TM_CHECK(r >= 0, TM_E_INVAL, "kmodes: empty-cluster repair found no donor");
-              s.move(r, old, from);
-            }
-          }
-        }
+      point_iters += n;
+      // ---- KModesIter (851-921): bins of 960 points, each scored against the modes as they stand when its turn comes
+      TM_HIP(hipMemsetAsync(dscal.as<uint8_t>() + 8, 0, 12, stream));  // cost, moves
+      for (int64_t b0 = 0; b0 < n; b0 += KM_BIN) {
+        const int64_t b1 = std::min<int64_t>(b0 + KM_BIN, n);
+        TM_TRY(score(b0, b1));
+        hipLaunchKernelGGL(k_kmodes_walk, dim3(1), dim3(KM_WT), (size_t)k * 4, stream, n, b0, b1, k, st);
+        hipLaunchKernelGGL(k_kmodes_apply, dim3((unsigned)((k * KM_ATTRS + 3) / 4)), dim3(256), 0, stream, rows, k, nmod, st);
       }
+      TM_HIP(hipGetLastError());
+      Scal h;
+      TM_TRY(read_scal(&h));
+      const uint64_t cost = h.cost;
+      const int moves = (int)h.moves;
       converged = cost >= prevcost;
       if (converged) {  // SameValue(cost, prevcost, prevcost div 1000), 1041
         const double a = (double)cost, b = (double)prevcost;
@@ -263,22 +479,49 @@ int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, in
         if (same) { worse++; if (worse < 3) converged = false; }
       }
       converged = converged || moves == 0;
-      if (cost < bestcost) { bestitr = itr; bestcost = cost; bestm = s.memb; bestc = s.cent; }
+      if (cost < bestcost) {
+        bestitr = itr; bestcost = cost;
+        TM_HIP(hipMemcpyAsync(dbestm.p, dmemb.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        TM_HIP(hipMemcpyAsync(dbestc.p, dcent.p, (size_t)k * KM_ATTRS, hipMemcpyDeviceToDevice, stream));
+      }
       prevcost = cost;
     }
     if (bestcost < all_best) {  // 1078-1085: the first run with the strictly smallest cost
       all_best = bestcost;
       all_iters = bestitr;
-      memcpy(labels_out, bestm.data(), (size_t)n * 4);
-      memcpy(cent_out, bestc.data(), (size_t)k * KM_ATTRS);
+      TM_HIP(hipMemcpyAsync(labels_out, dbestm.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+      TM_HIP(hipMemcpyAsync(cent_out, dbestc.p, (size_t)k * KM_ATTRS, hipMemcpyDeviceToDevice, stream));
     }
   }
+  TM_HIP(hipStreamSynchronize(stream));
   if (cost_out) *cost_out = all_best;
   if (iters_out) *iters_out = all_iters;
+  if (point_iters_out) *point_iters_out = point_iters;
+  return TM_OK;
+}
+
+// the Pascal arrays' form: HOST pointers, an upload and a read-back round the device run
+int run_kmodes(const uint8_t *rows, int64_t n, int k, int num_init, int nmod, int max_iter, int32_t *labels_out, uint8_t *cent_out, uint64_t *cost_out,
+               int *iters_out, hipStream_t stream) {
+  TM_TRY(require_device());
+  TM_CHECK(rows && labels_out && cent_out, TM_E_INVAL, "kmodes: null argument");
+  TM_CHECK(n >= 1 && k >= 1 && k <= 4096, TM_E_INVAL, "kmodes: %lld points, %d clusters", (long long)n, k);
+  DevBuf drows, dlab, dcen;
+  TM_TRY(drows.alloc((size_t)n * KM_ATTRS)); TM_TRY(dlab.alloc((size_t)n * 4)); TM_TRY(dcen.alloc((size_t)k * KM_ATTRS));
+  TM_HIP(hipMemcpyAsync(drows.p, rows, (size_t)n * KM_ATTRS, hipMemcpyHostToDevice, stream));
+  TM_TRY(run_kmodes_dev(drows.as<uint8_t>(), n, k, num_init, nmod, max_iter, dlab.as<int32_t>(), dcen.as<uint8_t>(), cost_out, iters_out, nullptr, stream));
+  TM_HIP(hipMemcpyAsync(labels_out, dlab.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipMemcpyAsync(cent_out, dcen.p, (size_t)k * KM_ATTRS, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
   return TM_OK;
 }
 
 }  // namespace tmx
+
+extern "C" int tm_stage_kmodes_dev(const uint8_t *dev_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *dev_labels,
+                                   uint8_t *dev_centroids, uint64_t *host_cost, int *host_iters, int64_t *host_point_iters, void *stream) {
+  return tmx::run_kmodes_dev(dev_rows, n, num_clusters, num_init, num_modalities, max_iter, dev_labels, dev_centroids, host_cost, host_iters, host_point_iters, (hipStream_t)stream);
+}
 
 extern "C" int tm_stage_kmodes(const uint8_t *host_rows, int64_t n, int num_clusters, int num_init, int num_modalities, int max_iter, int32_t *host_labels,
                                uint8_t *host_centroids, uint64_t *host_cost, int *host_iters, void *stream) {

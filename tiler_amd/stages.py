@@ -222,3 +222,21 @@ def dl3quant(rgb, quant_to, lookup_bpc):
     L.tm_stage_dl3quant.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
     check(L.tm_stage_dl3quant(ctypes.c_void_p(rgb.data_ptr()), rgb.shape[0], int(quant_to), int(lookup_bpc), ctypes.c_void_p(pal.data_ptr()), ctypes.byref(n), _stream()))
     return pal, n.value
+
+
+def kmodes_dev(rows, num_clusters, num_init=0, num_modalities=256, max_iter=-1):
+    """TKModes.ComputeKModes on device memory: rows torch uint8 CUDA [n][80] -> (labels int32 CUDA [n], centroids uint8 CUDA [k][80], cost,
+    iterations of the best run, points x iterations of all runs)"""
+    import torch
+    assert rows.is_cuda and rows.dtype == torch.uint8 and rows.ndim == 2 and rows.shape[1] == 80
+    rows = rows.contiguous()
+    labels = torch.zeros(rows.shape[0], dtype=torch.int32, device=rows.device)
+    cent = torch.zeros((num_clusters, 80), dtype=torch.uint8, device=rows.device)
+    cost, iters, pit = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int64()
+    L = lib()
+    L.tm_stage_kmodes_dev.restype = ctypes.c_int
+    L.tm_stage_kmodes_dev.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]
+    check(L.tm_stage_kmodes_dev(ctypes.c_void_p(rows.data_ptr()), rows.shape[0], num_clusters, num_init, num_modalities, max_iter, ctypes.c_void_p(labels.data_ptr()),
+                                ctypes.c_void_p(cent.data_ptr()), ctypes.byref(cost), ctypes.byref(iters), ctypes.byref(pit), _stream()))
+    return labels, cent, cost.value, iters.value, pit.value

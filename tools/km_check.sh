@@ -7,7 +7,7 @@ rc=$?
 tail -3 gpurun_out/km_tests.log
 [ $rc -ne 0 ] && { grep -n "Error\|error\|assert" gpurun_out/km_tests.log | tail -20; exit $rc; }
 for rep in 1 2; do
-TM_PP_DEBUG=1 timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra > gpurun_out/km_bench.json 2> gpurun_out/km_bench.err || { tail -5 gpurun_out/km_bench.err; exit 1; }
+TM_PP_DEBUG=1 timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra > gpurun_out/km_bench.json 2> gpurun_out/km_bench.err || { tail -5 gpurun_out/km_bench.err; exit 1; }
 python -c "
 import json
 j=json.loads(open('gpurun_out/km_bench.json').read().strip().splitlines()[-1])

@@ -9,7 +9,7 @@ tail -3 gpurun_out/knn_tests.log
 for rep in 1 2; do
 for v in base "$@"; do
   if [ $v = base ]; then unset TM_LIB_VARIANT; else export TM_LIB_VARIANT=$v; fi
-  TM_KNN_DEBUG=1 timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  TM_KNN_DEBUG=1 timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
   python -c "
 import json
 j=json.loads(open('gpurun_out/ab_$v.json').read().strip().splitlines()[-1])

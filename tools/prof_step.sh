@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra > $OUT.json 2> $OUT.err || { tail -5 $OUT.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra > $OUT.json 2> $OUT.err || { tail -5 $OUT.err; exit 1; }
 python3 - $OUT <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
