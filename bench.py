@@ -60,6 +60,9 @@ def _collective_counts(enc, nsteps):
     them: its own RCCL communicator (tm_comm_init) or the host's callback (tm_set_collective)"""
     st = enc.CollectiveStats()
     out = {k: v / float(nsteps) for k, v in st.items()}
+    by_step = getattr(enc, "_coll_bytes_by_step", None)
+    if by_step:
+        out["bytes_by_stage"] = {k: v / float(nsteps) for k, v in by_step.items() if v}
     out["path"] = "native RCCL inside libtilemotion (tm_comm_init)" if getattr(enc, "_native_comm", None) else "host callback (tm_set_collective) over torch.distributed"
     coll = getattr(enc, "_collective", None)
     if coll is not None and coll.log is not None:
@@ -208,10 +211,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("TM_BENCH_DIST_TIMEOUT", "600")))  # a rank that dies must not leave the others waiting for ever
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
 
     W, H, F = args.width, args.height, args.frames
     # synthetic clip, generated on the host into page-locked memory, then parked in HBM before any timing

@@ -412,6 +412,76 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["keys", "keys-colliding-hashes", "gather-all"])
+def test_sharded_reduce_moves_only_what_can_survive(monkeypatch, mode):
+    """Reduce over three processes on a clip whose static tile columns repeat across the shard borders and whose tile budget bites (1 500 of
+    ~7 000 distinct tiles): the processes exchange 16-byte keys, choose the tiles that can be among the first 1 500 of the merged order and
+    all-gather only those; the result is the single run's, also when every hash collides (TM_DEDUP_DEGRADE_HASH:
+    four hash values for all tiles -- everything is then a candidate) and on the old path that gathers every distinct tile; and the
+    key path moves a fraction of the bytes."""
+    import threading
+    from tiler_amd import synth, distributed
+    from tiler_amd.encoder import TilingEncoder, TEncoderStep
+    nf, w, h, world = 40, 160, 96, 3
+    frames = synth.video(nf, w, h, cut=17)
+    kw = dict(PaletteCount=3, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0, FrameTilingExtendedPaletteUsage=False, GlobalTilingTileCount=1500)
+    ref = _run_encoder(frames, **kw)
+    want = (np.stack([ref.TileMap(f) for f in range(nf)]), ref.Tiles())
+    ref.close()
+    if mode == "gather-all":
+        monkeypatch.setenv("TM_REDUCE_GATHER_ALL", "1")
+    if mode == "keys-colliding-hashes":
+        monkeypatch.setenv("TM_DEDUP_DEGRADE_HASH", "1")
+    fake = _FakeDist(world)
+    monkeypatch.setattr(distributed, "dist", fake)
+    out, nbytes, errs = [None] * world, [0] * world, []
+
+    def rank_main(r):
+        try:
+            fake.local.rank = r
+            torch.cuda.set_device(0)
+            enc = TilingEncoder()
+            enc.LoadDefaultSettings()
+            for k, v in kw.items():
+                setattr(enc, k, v)
+            enc.SetVideo(w, h, 24.0, nf)
+            for f in range(nf):
+                enc.PushFrame(f, frames[f])
+            coll = distributed.Collective(r, world)
+            enc.SetCollective(r, world, coll)
+            enc._collective = coll
+            first, count = distributed.frame_shard(nf, r, world)
+            enc.SetQueryShard(first, count)
+            enc.Run(TEncoderStep.esLoad)
+            enc.CollectiveStats(reset=True)
+            enc.Run(TEncoderStep.esReduce)
+            nbytes[r] = enc.CollectiveStats()["bytes"]
+            for st in (TEncoderStep.esPreparePalettes, TEncoderStep.esDither, TEncoderStep.esReconstruct, TEncoderStep.esReindex):
+                enc.Run(st)
+            out[r] = (np.stack([enc.TileMap(f) for f in range(nf)]), enc.Tiles())
+            enc.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            fake.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(out[r][0], want[0])
+        for a, b in zip(out[r][1], want[1]):
+            assert np.array_equal(a, b)
+    distinct = len(np.unique(np.concatenate([synth_tiles for synth_tiles in [frames.reshape(nf, h // 8, 8, w // 8, 8).transpose(0, 1, 3, 2, 4).reshape(-1, 64)]]), axis=0))
+    if mode == "keys":
+        assert distinct > 3 * 1500  # the budget bites
+        assert nbytes[0] < 0.5 * distinct * 264 * 1  # far below one copy of every distinct tile (the old path moves world x that)
+    if mode == "gather-all":
+        assert nbytes[0] >= distinct * 264
+
+
 @pytest.mark.parametrize("radius", [0, 8])
 def test_y4m_and_png_export_show_what_the_player_shows(oracle, tmp_path, radius):
     """GenerateY4M / GeneratePNGs (tilingencoder.pas:2126-2199, 2075-2124): the rendered output frames must be the pictures the reference's

@@ -340,6 +340,132 @@ int build_groups(const void *remap, int64_t n, const void *counts, int64_t ngrou
   return TM_OK;
 }
 
+// ---- Reduce over several processes: which distinct tiles have to travel ---------------------------------------------------------------
+// Every process has deduplicated its own frame tiles; the merged order (use count descending, content ascending) keeps the first `target`
+// tiles.  Instead of all-gathering every process's distinct tiles (857 MB on the 720p bench clip for 321 k survivors) the processes
+// exchange a 16-byte KEY per distinct tile -- a 64-bit content hash, the first dword of the content (its leading bytes in comparison
+// order) and the local use count -- and every process runs this selection on the gathered keys (identical input, identical result):
+//   * keys whose hash no other key shares are SINGLES: no other process holds that content, the local use count is the true one;
+//   * keys that share their hash form a group: duplicates of one tile across processes (or a hash collision -- the groups are never
+//     trusted to be equal content, they only decide what travels); the group's summed use bounds every member's true use from above;
+//   * the singles ordered by (use descending, leading dword ascending): the key at position `target` is the cut-off -- every single
+//     beyond it (strictly) has `target` tiles before it in the true order whatever the groups turn out to be, and so has every member
+//     of a group whose SUM stays below the cut-off's use count.  Everything else is a candidate.
+// The candidates' tiles (a superset of the true first `target`, whole groups always) are then all-gathered and deduplicated exactly,
+// full compares and all, as the union was before.
+struct ReduceKey { unsigned long long hash; uint32_t prefix, use; };
+
+namespace {
+__global__ __launch_bounds__(256) void k_reduce_keys(const uint32_t *__restrict__ rows, const int32_t *__restrict__ idx, const uint32_t *__restrict__ use, int64_t n,
+                                                     int dwords, int degrade /* test hook: force hash collisions */, ReduceKey *__restrict__ out) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {  // k_row_hash's terms, through an index
+    const int64_t r = r0 + (threadIdx.x >> 4);
+    const int64_t row = r < n ? (int64_t)idx[r] : 0;
+    unsigned long long h = 0;
+    if (r < n)
+      for (int v = sub; v < dwords / 4; v += 16) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(rows + row * dwords + v * 4);
+        unsigned long long a = ((unsigned long long)x.y << 32 | x.x) + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * v + 1);
+        unsigned long long b = ((unsigned long long)x.w << 32 | x.z) + 0xC2B2AE3D27D4EB4Full * (unsigned long long)(2 * v + 2);
+        a ^= a >> 32; a *= 0xD6E8FEB86659FD93ull; a ^= a >> 32;
+        b ^= b >> 29; b *= 0xBF58476D1CE4E5B9ull; b ^= b >> 32;
+        h += a * 0x94D049BB133111EBull + b;
+      }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if (r < n && sub == 0) out[r] = ReduceKey{degrade ? (h & 3) : h, rows[row * dwords], use[r]};
+  }
+}
+}  // namespace
+
+namespace {
+__global__ void k_rk_split(const ReduceKey *__restrict__ keys, int64_t n, unsigned long long *__restrict__ hash, uint32_t *__restrict__ idx) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { hash[i] = keys[i].hash; idx[i] = (uint32_t)i; }
+}
+__global__ void k_rk_heads(const unsigned long long *__restrict__ hs, int64_t n, uint32_t *__restrict__ head) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) head[j] = (j == 0 || hs[j] != hs[j - 1]) ? 1u : 0u;
+}
+// gid = inclusive scan of the heads - 1; every key adds itself to its group
+__global__ void k_rk_groups(const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ head_incl, const ReduceKey *__restrict__ keys, int64_t n,
+                            uint32_t *__restrict__ gid_of, unsigned long long *__restrict__ gsum, uint32_t *__restrict__ gsize) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = head_incl[j] - 1u, i = sorted_idx[j];
+    gid_of[i] = g;
+    atomicAdd(&gsum[g], (unsigned long long)keys[i].use);
+    atomicAdd(&gsize[g], 1u);
+  }
+}
+__global__ void k_rk_single_keys(const ReduceKey *__restrict__ keys, const uint32_t *__restrict__ gid_of, const uint32_t *__restrict__ gsize, int64_t n,
+                                 unsigned long long *__restrict__ skey, unsigned long long *__restrict__ nsingles) {
+  unsigned long long local = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool single = gsize[gid_of[i]] == 1;
+    skey[i] = single ? ((unsigned long long)(~keys[i].use) << 32) | keys[i].prefix : ~0ull;
+    local += single ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(nsingles, local);
+}
+__global__ void k_rk_select(const unsigned long long *__restrict__ skey, const uint32_t *__restrict__ gid_of, const unsigned long long *__restrict__ gsum, int64_t n,
+                            unsigned long long cutoff, unsigned long long min_use, uint32_t *__restrict__ in_s) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    in_s[i] = skey[i] != ~0ull ? (skey[i] <= cutoff ? 1u : 0u) : (gsum[gid_of[i]] >= min_use ? 1u : 0u);
+}
+}  // namespace
+
+int reduce_make_keys(const void *rows, const void *idx, const void *use, int64_t n, int row_bytes, void *keys_out, hipStream_t stream) {
+  if (n <= 0) return TM_OK;
+  hipLaunchKernelGGL(k_reduce_keys, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, (const int32_t *)idx,
+                     (const uint32_t *)use, n, row_bytes / 4, getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0, (ReduceKey *)keys_out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int reduce_select_candidates(const void *keys_v, int64_t n, int64_t target, void *in_s, hipStream_t stream) {
+  TM_CHECK(n > 0 && n < (int64_t)1 << 31, TM_E_INVAL, "reduce: key count out of range");
+  const ReduceKey *keys = (const ReduceKey *)keys_v;
+  DevBuf hash, hash2, idx, idx2, head, head_incl, gid_of, gsum, gsize, skey, skey2, tmp, cnt;
+  TM_TRY(hash.alloc(n * 8)); TM_TRY(hash2.alloc(n * 8)); TM_TRY(idx.alloc(n * 4)); TM_TRY(idx2.alloc(n * 4)); TM_TRY(head.alloc(n * 4)); TM_TRY(head_incl.alloc(n * 4));
+  TM_TRY(gid_of.alloc(n * 4)); TM_TRY(gsum.alloc(n * 8)); TM_TRY(gsize.alloc(n * 4)); TM_TRY(skey.alloc(n * 8)); TM_TRY(skey2.alloc(n * 8)); TM_TRY(cnt.alloc(8));
+  hipLaunchKernelGGL(k_rk_split, dim3(gridn(n)), dim3(256), 0, stream, keys, n, hash.as<unsigned long long>(), idx.as<uint32_t>());
+  size_t tb = 0;
+  TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, hash.as<unsigned long long>(), hash2.as<unsigned long long>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), (size_t)n, 0, 64, stream));
+  TM_TRY(tmp.alloc(tb));
+  TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, hash.as<unsigned long long>(), hash2.as<unsigned long long>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), (size_t)n, 0, 64, stream));
+  hipLaunchKernelGGL(k_rk_heads, dim3(gridn(n)), dim3(256), 0, stream, hash2.as<unsigned long long>(), n, head.as<uint32_t>());
+  size_t tb2 = 0;
+  TM_HIP(rocprim::inclusive_scan(nullptr, tb2, head.as<uint32_t>(), head_incl.as<uint32_t>(), (size_t)n, rocprim::plus<uint32_t>(), stream));
+  TM_TRY(tmp.alloc(tb2));
+  TM_HIP(rocprim::inclusive_scan(tmp.p, tb2, head.as<uint32_t>(), head_incl.as<uint32_t>(), (size_t)n, rocprim::plus<uint32_t>(), stream));
+  TM_HIP(hipMemsetAsync(gsum.p, 0, n * 8, stream));
+  TM_HIP(hipMemsetAsync(gsize.p, 0, n * 4, stream));
+  TM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
+  hipLaunchKernelGGL(k_rk_groups, dim3(gridn(n)), dim3(256), 0, stream, idx2.as<uint32_t>(), head_incl.as<uint32_t>(), keys, n, gid_of.as<uint32_t>(),
+                     gsum.as<unsigned long long>(), gsize.as<uint32_t>());
+  hipLaunchKernelGGL(k_rk_single_keys, dim3(gridn(n)), dim3(256), 0, stream, keys, gid_of.as<uint32_t>(), gsize.as<uint32_t>(), n, skey.as<unsigned long long>(),
+                     cnt.as<unsigned long long>());
+  unsigned long long nsingles = 0;
+  TM_HIP(hipMemcpyAsync(&nsingles, cnt.p, 8, hipMemcpyDeviceToHost, stream));
+  TM_HIP(hipStreamSynchronize(stream));
+  unsigned long long cutoff = ~0ull - 1ull, min_use = 0;  // fewer singles than the budget: everything travels
+  if (target > 0 && (unsigned long long)target <= nsingles) {
+    size_t tb3 = 0;
+    TM_HIP(rocprim::radix_sort_keys(nullptr, tb3, skey.as<unsigned long long>(), skey2.as<unsigned long long>(), (size_t)n, 0, 64, stream));
+    TM_TRY(tmp.alloc(tb3));
+    TM_HIP(rocprim::radix_sort_keys(tmp.p, tb3, skey.as<unsigned long long>(), skey2.as<unsigned long long>(), (size_t)n, 0, 64, stream));
+    TM_HIP(hipMemcpyAsync(&cutoff, skey2.as<unsigned long long>() + (target - 1), 8, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    min_use = (unsigned long long)(uint32_t)(~(uint32_t)(cutoff >> 32));
+  }
+  hipLaunchKernelGGL(k_rk_select, dim3(gridn(n)), dim3(256), 0, stream, skey.as<unsigned long long>(), gid_of.as<uint32_t>(), gsum.as<unsigned long long>(), n, cutoff, min_use,
+                     (uint32_t *)in_s);
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipStreamSynchronize(stream));  // the scratch DevBufs die with this frame
+  return TM_OK;
+}
+
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
               int64_t *host_n_unique, hipStream_t stream) {
   return run_dedup_ex(rows, n, row_bytes, use_in, remap, order, use_out, host_n_unique, 0, stream);

@@ -90,6 +90,17 @@ __global__ void k_compose_remap(const int32_t *__restrict__ local_remap, int64_t
     out[i] = g < limit ? g : -1;
   }
 }
+// a frame tile's global index through the candidates: its local distinct tile travelled (in_s) as candidate number cand_pos[.] of this
+// process, which the exact dedup of all candidates mapped to cand_remap[.]; anything else is beyond the tile budget
+__global__ void k_compose_remap_cand(const int32_t *__restrict__ local_remap, int64_t n, const uint32_t *__restrict__ in_s, const int32_t *__restrict__ cand_pos,
+                                     const int32_t *__restrict__ cand_remap, int32_t cand_off, int32_t limit, int32_t *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t l = local_remap[i];
+    int32_t g = -1;
+    if (in_s[l]) g = cand_remap[cand_off + cand_pos[l]];
+    out[i] = g >= 0 && g < limit ? g : -1;
+  }
+}
 static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
 
 static int equal_quality_tile_count(double tc) {  // EqualQualityTileCount, utils.pas:1038-1041 (TFloat argument)
@@ -645,13 +656,39 @@ static int step_reduce(tm_encoder *e) {
     int64_t lnu = 0;
     TM_TRY(lremap.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(lorder.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(luse.alloc((size_t)std::max<int64_t>(nloc, 1) * 4));
     if (nloc > 0) TM_TRY(run_dedup(e->ftiles.as<uint8_t>() + f0 * per * 256, nloc, 256, nullptr, lremap.p, lorder.p, luse.p, &lnu, e->stream));
-    TM_TRY(rec.alloc((size_t)std::max<int64_t>(lnu, 1) * 264));
-    if (lnu > 0)
-      hipLaunchKernelGGL(k_pack_unique, dim3(gridn(lnu * 66)), dim3(256), 0, e->stream, e->ftiles.as<uint32_t>() + f0 * per * 64, e->fflags.as<uint8_t>() + f0 * per,
-                         lorder.as<int32_t>(), luse.as<uint32_t>(), lnu, rec.as<uint32_t>());
+    // What travels: by default only the tiles that can be among the first GlobalTilingTileCount of the merged order, chosen on 16-byte
+    // keys every process exchanges first (tm_dedup.hip, "Reduce over several processes"); TM_REDUCE_GATHER_ALL=1: every distinct tile
+    // of every process, as the first two rounds did (857 MB on the bench clip).
+    const bool by_keys = !getenv("TM_REDUCE_GATHER_ALL");
+    const int64_t budget = e->s.GlobalTilingTileCount > 0 ? (int64_t)e->s.GlobalTilingTileCount : 0;  // 0: no budget, everything stays
+    DevBuf lkeys, allkeys, in_s, sel, spos, sidx, suse;
+    int64_t nsel = lnu, key_off = 0;
+    if (by_keys) {
+      TM_TRY(lkeys.alloc((size_t)std::max<int64_t>(lnu, 1) * 16));
+      TM_TRY(reduce_make_keys(e->ftiles.as<uint8_t>() + f0 * per * 256, lorder.p, luse.p, lnu, 256, lkeys.p, e->stream));
+      std::vector<int64_t> kcounts;
+      TM_TRY(gather_var(e, lkeys.p, lnu, 16, allkeys, &kcounts));
+      int64_t ntot = 0;
+      for (int r = 0; r < e->co.world; r++) { if (r < e->co.rank) key_off += kcounts[r]; ntot += kcounts[r]; }
+      TM_CHECK(ntot > 0 && ntot < (1ll << 31), TM_E_INVAL, "Reduce: %lld distinct tiles over all processes", (long long)ntot);
+      TM_TRY(in_s.alloc((size_t)ntot * 4));
+      TM_TRY(reduce_select_candidates(allkeys.p, ntot, budget, in_s.p, e->stream));
+      TM_TRY(sel.alloc((size_t)std::max<int64_t>(lnu, 1) * 4)); TM_TRY(spos.alloc((size_t)std::max<int64_t>(lnu, 1) * 4));
+      nsel = 0;
+      if (lnu > 0) TM_TRY(compact_kept(in_s.as<uint32_t>() + key_off, lnu, sel.p, spos.p, &nsel, e->stream));
+      TM_TRY(sidx.alloc((size_t)std::max<int64_t>(nsel, 1) * 4)); TM_TRY(suse.alloc((size_t)std::max<int64_t>(nsel, 1) * 4));
+      if (nsel > 0) {
+        hipLaunchKernelGGL(k_gather<int32_t>, dim3(gridn(nsel)), dim3(256), 0, e->stream, lorder.as<int32_t>(), sel.as<int32_t>(), nsel, sidx.as<int32_t>());
+        hipLaunchKernelGGL(k_gather<uint32_t>, dim3(gridn(nsel)), dim3(256), 0, e->stream, luse.as<uint32_t>(), sel.as<int32_t>(), nsel, suse.as<uint32_t>());
+      }
+    }
+    TM_TRY(rec.alloc((size_t)std::max<int64_t>(nsel, 1) * 264));
+    if (nsel > 0)
+      hipLaunchKernelGGL(k_pack_unique, dim3(gridn(nsel * 66)), dim3(256), 0, e->stream, e->ftiles.as<uint32_t>() + f0 * per * 64, e->fflags.as<uint8_t>() + f0 * per,
+                         by_keys ? sidx.as<int32_t>() : lorder.as<int32_t>(), by_keys ? suse.as<uint32_t>() : luse.as<uint32_t>(), nsel, rec.as<uint32_t>());
     TM_HIP(hipGetLastError());
     std::vector<int64_t> counts;
-    TM_TRY(gather_var(e, rec.p, lnu, 264, urec, &counts));
+    TM_TRY(gather_var(e, rec.p, nsel, 264, urec, &counts));
     int64_t nun = 0, my_off = 0;
     for (int r = 0; r < e->co.world; r++) { if (r < e->co.rank) my_off += counts[r]; nun += counts[r]; }
     TM_CHECK(nun > 0 && nun < (1ll << 31), TM_E_INVAL, "Reduce: %lld distinct tiles over all processes", (long long)nun);
@@ -673,7 +710,10 @@ static int step_reduce(tm_encoder *e) {
     TM_HIP(hipMemcpyAsync(e->guse.p, guse2.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
     // tile map of this process's frames (TransferTiles: TileIdx := the tile's index, 4079-4083); the other frames' items are their owners'
     TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
-    if (nloc > 0)
+    if (nloc > 0 && by_keys)
+      hipLaunchKernelGGL(k_compose_remap_cand, dim3(gridn(nloc)), dim3(256), 0, e->stream, lremap.as<int32_t>(), nloc, in_s.as<uint32_t>() + key_off, spos.as<int32_t>(),
+                         gremap.as<int32_t>(), (int32_t)my_off, (int32_t)e->t, e->tm_tile.as<int32_t>() + f0 * per);
+    else if (nloc > 0)
       hipLaunchKernelGGL(k_compose_remap, dim3(gridn(nloc)), dim3(256), 0, e->stream, lremap.as<int32_t>(), nloc, gremap.as<int32_t>(), (int32_t)my_off, (int32_t)e->t,
                          e->tm_tile.as<int32_t>() + f0 * per);
     TM_HIP(hipGetLastError());

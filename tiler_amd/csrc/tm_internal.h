@@ -98,6 +98,10 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
 int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                                int pal_rank, int pal_world, hipStream_t stream, DevBuf *keep_keys = nullptr, int64_t *keep_n = nullptr);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
+// tm_dedup.hip, Reduce over several processes (see there): a 16-byte key per distinct tile (rows[idx[r]], use[r]) and, on the gathered keys of
+// all processes, the tiles that can be among the first `target` of the merged order (in_s: uint32 flags)
+int reduce_make_keys(const void *rows, const void *idx, const void *use, int64_t n, int row_bytes, void *keys_out /* n x 16 bytes */, hipStream_t stream);
+int reduce_select_candidates(const void *keys, int64_t n, int64_t target, void *in_s, hipStream_t stream);
 // tm_dl3.hip: dl3quant on device pointers (blocking)
 int run_dl3quant(const void *dev_rgb, int64_t npixels, int quant_to, int lookup_bpc, void *dev_pal, int *out_colors, hipStream_t stream);
 // what the calling thread's last tile -> palette clustering and last colour quantisation ran through (tm_get_kmeans_iters)

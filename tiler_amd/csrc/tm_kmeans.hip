@@ -1053,8 +1053,10 @@ __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned *rel, unsigne
     epoch++;
     const unsigned target = epoch * nblk;
     // the last to arrive publishes the epoch; everybody else polls that word (arrivals are counted on `bar`, which nobody reads in a loop)
-    if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == target)
-      __hip_atomic_store(rel, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (acquire-release on the arrival, release on the publication: the other workgroups' writes are ordered before the waiters' acquire
+    // through the last arriver, as the memory model wants it -- not only because every cross-workgroup datum here is an agent-scope atomic)
+    if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == target)
+      __hip_atomic_store(rel, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     for (unsigned spins = 1; __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
       __builtin_amdgcn_s_sleep(1);
@@ -1379,7 +1381,12 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
     hs.push_back(g);
     which.push_back(s);
   }
-  if (nblk > 3 * cus) return TM_OK;  // all workgroups must be resident together (four fit a CU; three are asked for)
+  {  // all workgroups must be resident together: what the runtime says fits a CU (registers, LDS, the launch bound of three), not a guess
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kmeans3_persistent, P3_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    per_cu = std::min(per_cu, 3);
+    if (nblk > per_cu * cus) return TM_OK;
+  }
   if (host_kk) host_kk->assign(nseg, 0);
   if (host_iters) *host_iters = 0;
   *used = 1;
@@ -1392,6 +1399,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   TM_HIP(hipMemcpyAsync(dsegs.p, hs.data(), sizeof(Seg3) * hs.size(), hipMemcpyHostToDevice, stream));
   TM_HIP(hipMemsetAsync(dstate.p, 0, sizeof(Seg3State) * hs.size(), stream));
   TM_HIP(hipMemsetAsync(dcent.p, 0, sizeof(double) * hs.size() * k * 3, stream));
+  TM_CHECK(nblk >= 1 && k >= 1 && k <= P3_MAXK, TM_E_INVAL, "k-means: resident launch of %d workgroups for %d centres (at most %d)", nblk, k, P3_MAXK);
   hipLaunchKernelGGL(k_kmeans3_persistent, dim3(nblk), dim3(P3_NT), 0, stream, pts, w, dsegs.as<Seg3>(), dstate.as<Seg3State>(), k, max_iter, assign,
                      dcent.as<double>());
   TM_HIP(hipGetLastError());
@@ -1402,8 +1410,14 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   TM_HIP(hipMemcpyAsync(hcent.data(), dcent.p, hcent.size() * 8, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
   int iters = 0;
+  for (size_t i = 0; i < hs.size(); i++)
+    if (hstate[i].timeout != 0) {  // a workgroup of a segment never became resident (the barrier gave up): the launches-per-iteration path instead
+      fprintf(stderr, "[tm_kmeans] the resident pixel k-means gave up at its barrier (segment %zu); falling back to one launch per iteration\n", i);
+      *used = 0;
+      return TM_OK;
+    }
+  kmeans_run_stats().pixel_colour_iters = 0;
   for (size_t i = 0; i < hs.size(); i++) {
-    TM_CHECK(hstate[i].timeout == 0, TM_E_HIP, "k-means: the workgroups of a segment did not all become resident (barrier gave up)");
     if (host_kk) (*host_kk)[which[i]] = hs[i].kk;
     iters = std::max(iters, hs[i].iters);
     kmeans_run_stats().pixel_colour_iters += hs[i].count * (int64_t)hs[i].iters;

@@ -162,6 +162,13 @@ class Collective:
             import traceback
             traceback.print_exc()
             self.error = exc
+            if self.world > 1 and _backend(self.group) in ("nccl", "gloo") and os.environ.get("TM_COLL_KEEP_ALIVE") != "1":
+                # the other ranks are inside (or about to enter) this very collective and would wait for this rank until the group's
+                # timeout: leaving at once breaks their connections, which they report as errors of their own
+                import sys
+                sys.stderr.write("[tiler_amd.distributed] rank %d: collective failed, leaving the job\n" % self.rank)
+                sys.stderr.flush()
+                os._exit(70)
             return -2
 
     @property
@@ -184,13 +191,24 @@ def run_all(enc, nframes, rank=0, world=1, group=None):
     motion = int(enc.MotionPredictRadius) > 0
     first, count = frame_shard(nframes, rank, world)
     enc.SetQueryShard(first, count)
-    enc.Run(S.esLoad)
-    enc.Run(S.esPredictMotion)  # frames are independent (each is searched in the source pixels of its neighbour)
-    enc.Run(S.esReduce)
-    enc.Run(S.esPreparePalettes)
-    enc.Run(S.esDither)
+    stats = getattr(enc, "CollectiveStats", None) if world > 1 else None
+    by_step = getattr(enc, "_coll_bytes_by_step", None)
+    if stats is not None and by_step is None:
+        by_step = enc._coll_bytes_by_step = {}
+
+    def run(step):
+        before = stats()["bytes"] if stats is not None else 0
+        enc.Run(step)
+        if stats is not None:
+            by_step[step.name] = by_step.get(step.name, 0) + stats()["bytes"] - before
+
+    run(S.esLoad)
+    run(S.esPredictMotion)  # frames are independent (each is searched in the source pixels of its neighbour)
+    run(S.esReduce)
+    run(S.esPreparePalettes)
+    run(S.esDither)
     if motion:
         first, count = keyframe_shard(enc.KeyFrames(), nframes, rank, world)
         enc.SetQueryShard(first, count)
-    enc.Run(S.esReconstruct)
-    enc.Run(S.esReindex)
+    run(S.esReconstruct)
+    run(S.esReindex)
