@@ -157,6 +157,13 @@ struct tm_encoder {
   } hclip[2];
   int hclip_cur = -1;                 // the buffer `frames` points into, if any
   uint64_t hclip_seq = 0;
+  // Load's inter-frame correlation is a chain of additions per frame (0.86 ms at 720p x 300) that nothing before the key frames' first
+  // use waits for: it runs on a stream of its own beside Reduce, and its host tail (square roots, FindKeyFrames) is taken when somebody
+  // asks (load_tail): a later step, a getter, the next Load
+  hipStream_t stream_aux = nullptr;
+  hipEvent_t ev_tiles = nullptr;
+  DevBuf dcorrel;
+  bool load_tail_pending = false;
   DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
   DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
   DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, error behind PSNR (KNN or motion)
@@ -221,6 +228,8 @@ struct tm_encoder {
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream_km) (void)hipStreamDestroy(stream_km);
+    if (stream_aux) { (void)hipStreamSynchronize(stream_aux); (void)hipStreamDestroy(stream_aux); }
+    if (ev_tiles) (void)hipEventDestroy(ev_tiles);
     if (copy_stream) (void)hipStreamSynchronize(copy_stream);
     for (HostClip &c : hclip)
       for (hipEvent_t ev : c.events) (void)hipEventDestroy(ev);
@@ -401,6 +410,33 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
   return TM_OK;
 }
 
+// the host tail of Load -- PearsonCorrelation's last lines (2221-2227) and FindKeyFrames (3373-3411) -- once the sums are there
+static int load_tail(tm_encoder *e) {
+  if (!e->load_tail_pending) return TM_OK;
+  e->load_tail_pending = false;
+  std::vector<float> sums((size_t)e->nframes * 3);
+  hipStream_t st = e->stream_aux ? e->stream_aux : e->stream;
+  TM_HIP(hipMemcpyAsync(sums.data(), e->dcorrel.p, sums.size() * 4, hipMemcpyDeviceToHost, st));
+  TM_HIP(hipStreamSynchronize(st));
+  e->correl.assign(e->nframes, 0.0f);
+  for (int f = 1; f < e->nframes; f++) {  // tail of PearsonCorrelation (2221-2227) in host IEEE arithmetic
+    const float denx = std::sqrt(sums[f * 3 + 1]), deny = std::sqrt(sums[f * 3 + 2]);
+    const float den = denx * deny;
+    e->correl[f] = den != 0.0f ? sums[f * 3] / den : 1.0f;
+  }
+  // FindKeyFrames, automatic mode (3373-3411)
+  e->kf_start.clear();
+  int64_t last = INT32_MIN;
+  for (int f = 0; f < e->nframes; f++) {
+    bool kf = f == 0;
+    if (!kf && (double)e->correl[f] < e->s.ShotTransCorrelLoThres) kf = true;
+    if (!kf && (double)(f - last) >= e->s.ShotTransMaxSecondsPerKF * e->fps) kf = true;
+    if ((double)(f - last) < e->s.ShotTransMinSecondsPerKF * e->fps) kf = false;
+    if (kf) { e->kf_start.push_back(f); last = f; }
+  }
+  return TM_OK;
+}
+
 // the chunked upload of a host clip into device buffer `slot`, queued on the copy stream with one event per chunk
 static int queue_host_clip(tm_encoder *e, int slot, const void *host) {
   tm_encoder::HostClip &hc = e->hclip[slot];
@@ -426,6 +462,7 @@ static int queue_host_clip(tm_encoder *e, int slot, const void *host) {
 }
 
 static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (decode excluded: frames are pushed in)
+  TM_TRY(load_tail(e));  // (a correlation still running reads the Lab means this Load is about to replace)
   e->drop_prefetch();  // features of the previous frame tiles
   e->q_groups = 0;
   e->load_sharded = false;
@@ -487,8 +524,9 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   progress(e, TM_STEP_LOAD, 1, 3);
   // inter-frame correlation: one GPU thread per frame runs the reference's sequential Single sums (order matters)
   const int per = (int)e->tm_size() * 3;
-  DevBuf dcorrel;
+  DevBuf &dcorrel = e->dcorrel;
   TM_TRY(dcorrel.alloc((size_t)e->nframes * 12));
+  e->h_fflags.clear();  // fetched lazily by tm_get_tilemap
   if (e->load_sharded) {
     const int64_t f0 = e->load_first, f1 = f0 + e->load_count, lo = std::max<int64_t>(f0 - 1, 0);
     TM_HIP(hipMemsetAsync(dcorrel.p, 0, (size_t)e->nframes * 12, e->stream));
@@ -497,29 +535,31 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
     if (lo < f0) TM_HIP(hipMemsetAsync(dcorrel.as<uint8_t>() + lo * 12, 0, 12, e->stream));
     TM_TRY(e->co.allreduce_sum_i32(dcorrel.p, (int64_t)e->nframes * 3));  // owner holds the float, everyone else +0.0: exact
     TM_TRY(e->co.allreduce_sum_i32(e->fflags.p, (e->q + 3) / 4));
-  } else
-  TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
-  std::vector<float> sums((size_t)e->nframes * 3);
-  e->h_fflags.clear();  // fetched lazily by tm_get_tilemap
-  TM_HIP(hipMemcpyAsync(sums.data(), dcorrel.p, sums.size() * 4, hipMemcpyDeviceToHost, e->stream));
-  TM_HIP(hipStreamSynchronize(e->stream));
-  e->correl.assign(e->nframes, 0.0f);
-  for (int f = 1; f < e->nframes; f++) {  // tail of PearsonCorrelation (2221-2227) in host IEEE arithmetic
-    const float denx = std::sqrt(sums[f * 3 + 1]), deny = std::sqrt(sums[f * 3 + 2]);
-    const float den = denx * deny;
-    e->correl[f] = den != 0.0f ? sums[f * 3] / den : 1.0f;
+    TM_HIP(hipStreamSynchronize(e->stream));
+    hipStream_t keep = e->stream_aux;
+    e->stream_aux = nullptr;  // (the sums sit behind the encoder's own stream here)
+    e->load_tail_pending = true;
+    const int rc = load_tail(e);
+    e->stream_aux = keep;
+    TM_TRY(rc);
+  } else if (getenv("TM_LOAD_TAIL_NOW")) {  // A/B aid: the correlation on the encoder's stream, its tail before Load returns
+    TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
+    TM_HIP(hipStreamSynchronize(e->stream));
+    hipStream_t keep = e->stream_aux;
+    e->stream_aux = nullptr;
+    e->load_tail_pending = true;
+    const int rc = load_tail(e);
+    e->stream_aux = keep;
+    TM_TRY(rc);
+  } else {
+    if (!e->stream_aux) TM_HIP(hipStreamCreateWithFlags(&e->stream_aux, hipStreamNonBlocking));
+    if (!e->ev_tiles) TM_HIP(hipEventCreateWithFlags(&e->ev_tiles, hipEventDisableTiming));
+    TM_HIP(hipEventRecord(e->ev_tiles, e->stream));
+    TM_HIP(hipStreamWaitEvent(e->stream_aux, e->ev_tiles, 0));
+    TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream_aux));
+    e->load_tail_pending = true;
   }
   progress(e, TM_STEP_LOAD, 2, 3);
-  // FindKeyFrames, automatic mode (3373-3411)
-  e->kf_start.clear();
-  int64_t last = INT32_MIN;
-  for (int f = 0; f < e->nframes; f++) {
-    bool kf = f == 0;
-    if (!kf && (double)e->correl[f] < e->s.ShotTransCorrelLoThres) kf = true;
-    if (!kf && (double)(f - last) >= e->s.ShotTransMaxSecondsPerKF * e->fps) kf = true;
-    if ((double)(f - last) < e->s.ShotTransMinSecondsPerKF * e->fps) kf = false;
-    if (kf) { e->kf_start.push_back(f); last = f; }
-  }
   if (e->auto_tile_count || e->s.GlobalTilingTileCount <= 0) recompute_auto_tile_count(e);
   // tile map starts empty (InitFrames, 2661-2686)
   TM_TRY(e->tm_tile.alloc((size_t)e->q * 4));
@@ -530,6 +570,7 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
   TM_HIP(hipMemsetAsync(e->tm_err.p, 0xff, (size_t)e->q * 4, e->stream));
   e->t = 0;
   e->has_pal_px = e->reconstructed = e->has_pm = false;
+  TM_HIP(hipStreamSynchronize(e->stream));  // Run(esLoad) is blocking for everything but the correlation above (and the stage times stay the stages')
   progress(e, TM_STEP_LOAD, 3, 3);
   return TM_OK;
 }
@@ -585,6 +626,7 @@ static int step_predict_motion(tm_encoder *e) {
 }
 
 static int step_reduce_motion(tm_encoder *e) {
+  TM_TRY(load_tail(e));
   // Reduce with motion prediction (1909-1926): SolveTileCount searches the PSNR threshold above which a tile-map item
   // stays predicted (4014-4046); the items below it are transferred (4048-4103), made unique and ordered (4038, 1923).
   // The search runs on per-group maxima of the prediction error (a group = one distinct tile content): PSNR is a
@@ -918,6 +960,7 @@ static int step_reconstruct(tm_encoder *e) {
   // previous reconstructed frame, so all frames go in one batch; the motion branch (below) then walks the frames in order.
   TM_TRY(need(e, TM_STEP_DITHER, "Dither"));
   TM_TRY(need_frame_tiles(e, "Reconstruct"));
+  TM_TRY(load_tail(e));
   DevBuf db, qf;
   TM_TRY(db.alloc((size_t)e->t * 384));
   if (e->dist()) {  // PrepareReconstruct (4566-4613) per share of the global tiles, then the all-gather of the int16 rows (T x 384 bytes in all)
@@ -1210,6 +1253,7 @@ static std::string settings_text(const Settings &s) {  // GetSettings -> SaveSet
 static int save_to(tm_encoder *e, const char *path) {  // Save, tilingencoder.pas:2040-2058 -> SaveStream, 5177
   TM_TRY(need(e, TM_STEP_REINDEX, "Reindex"));
   TM_CHECK(path && *path, TM_E_INVAL, "Save: no output file name");
+  TM_TRY(load_tail(e));
   TM_HIP(hipSetDevice(e->device));
   GtmInput in;
   in.tm_w = e->tm_w; in.tm_h = e->tm_h; in.nframes = e->nframes; in.fps = e->fps;
@@ -1552,6 +1596,8 @@ int tm_set_video(tm_encoder *e, int width, int height, double fps, int frame_cou
   e->frames_host = nullptr;
   e->frames_owned.release();
   if (e->copy_stream) TM_HIP(hipStreamSynchronize(e->copy_stream));  // a prefetch of the old geometry may still be running
+  if (e->stream_aux) TM_HIP(hipStreamSynchronize(e->stream_aux));    // and so may the old clip's correlation
+  e->load_tail_pending = false;
   for (tm_encoder::HostClip &c : e->hclip) { c.buf.release(); c.pending = false; c.host = nullptr; }
   e->hclip_cur = -1;
   e->steps_done = 0;
@@ -1633,7 +1679,7 @@ int tm_get_counts(tm_encoder *e, int64_t *tiles, int *frames, int *palettes, int
   if (palettes) *palettes = e->palettes_host.empty() ? 0 : e->s.PaletteCount;
   if (tm_w) *tm_w = e->tm_w;
   if (tm_h) *tm_h = e->tm_h;
-  if (keyframes) *keyframes = (int)e->kf_start.size();
+  if (keyframes) { TM_TRY(load_tail(e)); *keyframes = (int)e->kf_start.size(); }
   return TM_OK;
 }
 
@@ -1715,18 +1761,21 @@ int tm_get_palette(tm_encoder *e, int i, int32_t *rgb) {
 
 int tm_get_keyframes(tm_encoder *e, int32_t *start_frames) {
   TM_CHECK(e && start_frames, TM_E_INVAL, "null argument");
+  TM_TRY(load_tail(e));
   memcpy(start_frames, e->kf_start.data(), e->kf_start.size() * 4);
   return TM_OK;
 }
 
 int tm_get_frame_correlations(tm_encoder *e, float *correl) {
   TM_CHECK(e && correl, TM_E_INVAL, "null argument");
+  TM_TRY(load_tail(e));
   memcpy(correl, e->correl.data(), e->correl.size() * 4);
   return TM_OK;
 }
 
 int tm_get_psnr(tm_encoder *e, double *per_keyframe, double *global_mean) {  // TKeyFrame.LogPSNR, tilingencoder.pas:1006-1028
   TM_CHECK(e, TM_E_INVAL, "null encoder");
+  TM_TRY(load_tail(e));
   TM_CHECK(e->reconstructed && e->tm_err.p && !e->kf_start.empty(), TM_E_INVAL, "PSNR: Reconstruct has not been run");
   TM_HIP(hipSetDevice(e->device));
   // ReconstructPSNRCml = sum of the items' PSNR (Single, 1619 / 1644) in a Double (1657); the reference adds in thread order, here
@@ -1911,6 +1960,7 @@ int tm_reload_gtm(tm_encoder *e, const char *path) {  // ReloadGTM, tilingencode
   const int64_t q = (int64_t)e->nframes * e->tm_size(), T = (int64_t)g.use.size();
   e->q = q; e->t = T; e->fps = g.fps;
   e->s.PaletteSize = g.pal_size; e->s.PaletteCount = std::max(1, g.pal_count);
+  TM_TRY(load_tail(e));  // (not after these lines: a pending tail would put Load's key frames over the stream's)
   e->kf_start = g.kf_start;
   e->correl.assign((size_t)e->nframes, 0.0f);
   e->palettes_host.assign(g.palettes.begin(), g.palettes.end());

@@ -1021,7 +1021,18 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
 #else
 #define P3_STAMP(i) do { } while (0)
 #endif
-constexpr int P3_PPT = 16, P3_NT = 256, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 4;
+#ifndef TM_KM3_NT
+#define TM_KM3_NT 256
+#endif
+#ifndef TM_KM3_PPT
+#define TM_KM3_PPT 16
+#endif
+constexpr int P3_PPT = TM_KM3_PPT, P3_NT = TM_KM3_NT, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 4;
+// workgroups a CU is asked to hold (LDS: ten bytes a point + 12 KB).  Measured (round 3): 1024 x 12 and 512 x 20 / 24 points per workgroup, one
+// per CU and a third as many participants at a palette's barrier, take 13.8-13.9 / 14.3 / 14.9 ms for PreparePalettes against 13.7 with 256 x 16
+constexpr int P3_WGS = (P3_ROWS * 10 + 12288) * 3 <= 160 * 1024 && P3_NT * 3 <= 1024 ? 3 : 1;
+static_assert(TM_KM3_NT != 256 || TM_KM3_PPT != 16 || P3_WGS == 3, "the shipped shape holds three workgroups per CU");
+static_assert(P3_PPT % 4 == 0 && P3_ROWS <= 65535 && P3_NT >= 192, "pixel k-means shape");
 constexpr int P3_UNIT = 128;  // the per-point distance bounds are 16-bit fixed point, 1/128 of a colour step (distances stay below 442)
 
 struct Seg3 {
@@ -1073,7 +1084,7 @@ __device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned *rel, unsigne
   return s_ok != 0;
 }
 
-__global__ __launch_bounds__(P3_NT, 3) void k_kmeans3_persistent(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg3 *__restrict__ segs,
+__global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, Seg3 *__restrict__ segs,
                                                              Seg3State *__restrict__ state, int k, int max_iter, int32_t *__restrict__ assign,
                                                              double *__restrict__ cent) {
   // the workgroup's points stay on chip for the whole clustering: packed colour and assignment in LDS (slot m * NT + tid: no bank
@@ -1384,7 +1395,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   {  // all workgroups must be resident together: what the runtime says fits a CU (registers, LDS, the launch bound of three), not a guess
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kmeans3_persistent, P3_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    per_cu = std::min(per_cu, 3);
+    per_cu = std::min(per_cu, P3_WGS);
     if (nblk > per_cu * cus) return TM_OK;
   }
   if (host_kk) host_kk->assign(nseg, 0);
