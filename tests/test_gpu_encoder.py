@@ -561,6 +561,32 @@ def test_y4m_and_png_export_show_what_the_player_shows(oracle, tmp_path, radius)
     enc.close()
 
 
+@pytest.mark.parametrize("tc,full", [(40, False), (151, False), (400, False), (151, True)])
+def test_tile_budget_without_motion_prediction_keeps_the_first_tiles_of_the_order(oracle, monkeypatch, tc, full):
+    """MotionPredictRadius = 0 with a GlobalTilingTileCount below the number of distinct tiles: Reduce keeps the first `tc` tiles of
+    ReindexTiles' order (use count descending, content ascending).  The library orders only the rows that can be among them (a histogram
+    of the use counts, one of the leading dword among the rows at the cut-off's count, a sort of those candidates: VERDICT r02 item 8);
+    the oracle sorts everything.  Budgets that cut inside the single-use tiles, inside the multiply used ones, and the full sort forced
+    (TM_DEDUP_FULL_ORDER) all give the oracle's tiles, palettes and tile maps."""
+    from tiler_amd import synth
+    from tests import oracle_pipeline
+    if full:
+        monkeypatch.setenv("TM_DEDUP_FULL_ORDER", "1")
+    frames = synth.video(9, 104, 56, cut=4)
+    exp = oracle_pipeline.run(oracle, frames, palette_count=2, min_s=0.1, motion_radius=0, tile_count=tc)
+    enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=0, FrameTilingExtendedPaletteUsage=False, GlobalTilingTileCount=tc)
+    assert enc.counts()["tiles"] == exp["final_T"]
+    hdr, pal, rgb = enc.Tiles()
+    assert np.array_equal(pal, exp["final_pal_px"]) and np.array_equal(hdr["UseCount"], exp["final_use"]) and np.array_equal(rgb, exp["final_rgb"])
+    assert np.array_equal(enc.Palettes(), exp["palettes"])
+    per = exp["per"]
+    for f in range(9):
+        tm = enc.TileMap(f)
+        sl = slice(f * per, (f + 1) * per)
+        assert np.array_equal(tm["TileIdx"], exp["final_tm_tile"][sl]) and np.array_equal(tm["PalIdx"], exp["tm_pal"][sl])
+    enc.close()
+
+
 def _state(enc, nframes):
     hdr, pal, rgb = enc.Tiles()
     maps = [enc.TileMap(f) for f in range(nframes)]

@@ -769,7 +769,8 @@ static int step_reduce(tm_encoder *e) {
   TM_TRY(order.alloc((size_t)e->q * 4));
   TM_TRY(use.alloc((size_t)e->q * 4));
   int64_t nu = 0;
-  TM_TRY(run_dedup(e->ftiles.p, e->q, 256, nullptr, remap.p, order.p, use.p, &nu, e->stream));
+  // (only the first GlobalTilingTileCount tiles of the order stay: the rows behind them are counted and numbered, not ordered)
+  TM_TRY(run_dedup(e->ftiles.p, e->q, 256, nullptr, remap.p, order.p, use.p, &nu, e->stream, e->s.GlobalTilingTileCount > 0 ? (int64_t)e->s.GlobalTilingTileCount : 0));
   progress(e, TM_STEP_REDUCE, 1, 2);
   int64_t target = e->s.GlobalTilingTileCount > 0 ? e->s.GlobalTilingTileCount : nu;
   e->t = std::min<int64_t>(nu, target);
@@ -911,8 +912,13 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     hipStream_t km = e->stream_km ? e->stream_km : e->stream;
     TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, km));
     TM_HIP(hipStreamSynchronize(km));
-  } else
-  TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
+  } else {
+    if (getenv("TM_QF_EARLY")) {  // experiment: Reconstruct's query features beside the clusterings, on a small grid (TM_QF_GRID)
+      TM_HIP(hipStreamSynchronize(e->stream));
+      TM_TRY(prefetch_query_features(e));
+    }
+    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
+  }
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
   TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream, &e->pair_keys, &e->pair_keys_n));
@@ -923,7 +929,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
   TM_HIP(hipStreamSynchronize(e->stream));
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
-  if (!getenv("TM_CU_SPLIT"))
+  if (!getenv("TM_CU_SPLIT") && !getenv("TM_QF_EARLY"))
   TM_TRY(prefetch_query_features(e));  // the GPU has nothing to do while the host searches: Reconstruct's query features run now
   lap("prefetch launch");
   // OptimizePalettes (4309-4432): slot permutation by Powell on the host (P x PaletteSize colours)

@@ -51,9 +51,9 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
 
 // tm_dedup.hip
 int run_dedup(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
-              int64_t *host_n_unique, hipStream_t stream);
+              int64_t *host_n_unique, hipStream_t stream, int64_t exact_first = 0);
 int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in, void *remap, void *order, void *use_out,
-                 int64_t *host_n_unique, int by_index, hipStream_t stream);
+                 int64_t *host_n_unique, int by_index, hipStream_t stream, int64_t exact_first = 0);
 
 int build_groups(const void *remap, int64_t n, const void *counts, int64_t ngroups, void *off, void *members, hipStream_t stream);
 int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t *host_count, hipStream_t stream);
