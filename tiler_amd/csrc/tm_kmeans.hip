@@ -1004,6 +1004,291 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
   }
 }
 
+// ---- the skipping iteration as ONE launch (at most KCH centroids) ---------------------------------------------------------------
+// k_h_bounds, k_assign192_list4 and k_h_update are three dependent launches per iteration, and the kernel trace puts 4.5 us of every launch
+// of such a chain in its turnaround alone (an empty launch takes that long): 13.5 of the 41 us an iteration takes in the steady state.
+// Here an iteration is one launch.  Every workgroup first derives what the bounds need from the sums the LAST launch left complete --
+// new centroids (exact integer sum / weight, one IEEE division), their displacements, half the distance to the nearest other centroid;
+// 3 072 divisions and 120 pairs, a few microseconds, done by all workgroups alike -- then moves the bounds of its own slice of points,
+// rechecks the loosened ones and scores the still unproven ones itself (the list never leaves the workgroup), and adds the moved
+// points' deltas to THIS iteration's delta buffer.  What crosses launches is double-buffered so that a workgroup that is late reading
+// never meets one that is early writing: sums S[it & 1] = S[(it - 1) & 1] + D[(it - 1) % 3] (workgroup 0 writes them), deltas D[it % 3]
+// (zeroed two launches ahead), the moved-points counter likewise, the centroids C[it & 1].  Same arithmetic as the three kernels, hence
+// the same assignments and centroids, bit for bit.
+struct HIter {
+  u64 *S[2];        // [kk][193]: 192 coordinate sums + the weight, as of the start of iteration it (written by workgroup 0)
+  u64 *D[3];        // deltas of iteration it
+  unsigned *chg;    // [3] points moved in iteration it
+  double *C[2];     // [k][192] centroids used in iteration it
+};
+__global__ __launch_bounds__(256, 2) void k_h_iter(const int32_t *__restrict__ pts, int64_t n, const uint32_t *__restrict__ w, const Seg *__restrict__ segs, HIter h, int it,
+                                                   int update_only, int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb, int *__restrict__ quiet) {
+  if (*quiet >= 0) return;
+  constexpr int D = 192, NP = 64, CPL = KCH / 4, PITCH = D + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  double *s_ct = reinterpret_cast<double *>(s_raw);                         // [D][KCH] transposed centroids (scoring)
+  double *s_rm = reinterpret_cast<double *>(s_raw + D * KCH * 8);           // [KCH][PITCH] row-major centroids (recheck, pairs), later ...
+  u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);              // ... [kk][PITCH] deltas of this workgroup's moved points
+  int *s_list = reinterpret_cast<int *>(s_raw + D * KCH * 8 + KCH * PITCH * 8);  // [H_SLICE]
+  int *s_need = s_list + H_SLICE;                                           // [H_SLICE]
+  int *s_moved = s_need + H_SLICE;                                          // [NP][3]
+  __shared__ double s_move[KCH + 3], s_half[KCH];
+  __shared__ unsigned long long s_min[KCH];
+  __shared__ int s_nlist, s_nneed, s_nmoved;
+  const int tid = threadIdx.x, kk = segs[0].kk, wave = tid >> 6, lane = tid & 63;
+  const int pp = (it - 1) & 1, pc = it & 1, dp = (it + 2) % 3, dc = it % 3, dn = (it + 1) % 3;
+#if TM_KMH_STAMPS
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define KH_STAMP(i) do { if (blockIdx.x == 1 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(reinterpret_cast<unsigned long long *>(h.chg + 4) + (i), t_ - st_last); st_last = t_; } } while (0)
+#else
+#define KH_STAMP(i) do { } while (0)
+#endif
+  const bool changed = __hip_atomic_load(&h.chg[dp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (!changed) {  // the assignment before this launch moved nothing: converged at it - 1 (every workgroup leaves; one says so)
+    if (blockIdx.x == 0 && tid == 0) *quiet = it - 1;
+    return;
+  }
+  // ---- phase 0: sums, centroids, displacements, half distances (every workgroup; workgroup 0 also publishes)
+  if (tid < KCH) s_min[tid] = 0x7ff0000000000000ull;
+  if (tid == 0) { s_nlist = 0; s_nneed = 0; s_nmoved = 0; }
+  for (int e = tid; e < KCH * PITCH; e += 256) s_rm[e] = 0.0;
+  for (int e = tid; e < D * KCH; e += 256) s_ct[e] = 0.0;
+  __syncthreads();
+  {  // a wave per centroid (four of them each), three dimensions per lane and centroid: ALL the loads first -- taken one centroid after the
+     // other this phase was twelve dependent round trips to L2, 35 us of a 63 us launch
+    u64 sm[4][3], dl[4][3], cn[4];
+    double od[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = min(wave + 4 * q, kk - 1);
+      cn[q] = h.S[pp][c * PITCH + D];
+      dl[q][0] = h.D[dp][c * PITCH + D];
+#pragma unroll
+      for (int u = 0; u < 3; u++) sm[q][u] = h.S[pp][c * PITCH + lane + 64 * u];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) cn[q] += dl[q][0];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = min(wave + 4 * q, kk - 1);
+#pragma unroll
+      for (int u = 0; u < 3; u++) { dl[q][u] = h.D[dp][c * PITCH + lane + 64 * u]; od[q][u] = h.C[pp][c * D + lane + 64 * u]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = wave + 4 * q;
+      if (c >= kk) break;  // (uniform in the wave)
+      double sd = 0.0;
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int j = lane + 64 * u;
+        const u64 sv = sm[q][u] + dl[q][u];
+        const double nw = cn[q] > 0 ? __ddiv_rn((double)(long long)sv, (double)(long long)cn[q]) : od[q][u];
+        if (blockIdx.x == 0) { h.S[pc][c * PITCH + j] = sv; h.C[pc][c * D + j] = nw; }
+        s_rm[c * PITCH + j] = nw;
+        s_ct[j * KCH + c] = nw;
+        const double t = nw - od[q][u];
+        sd += t * t;
+      }
+      if (blockIdx.x == 0 && lane == 0) h.S[pc][c * PITCH + D] = cn[q];
+      for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      if (lane == 0) s_move[c] = sqrt(sd) * (1.0 + 1e-9);
+    }
+  }
+  if (blockIdx.x == 0) {  // two launches ahead: the delta buffer and the counter of iteration it + 1
+    for (int e = tid; e < kk * PITCH; e += 256) h.D[dn][e] = 0;
+    if (tid == 0) h.chg[dn] = 0;
+  }
+  if (update_only) return;  // (the iteration cap was reached: the centroids of the last assignment are out)
+  __syncthreads();
+  KH_STAMP(0);  // sums, centroids, displacements
+  for (int pr = tid >> 4; pr < kk * kk; pr += 16) {  // pairwise distances, 16 lanes per pair
+    const int a = pr / kk, b = pr - a * kk;
+    if (a >= b) continue;
+    double sd = 0.0;
+#pragma unroll
+    for (int u = 0; u < 12; u++) { const int j = (tid & 15) + 16 * u; const double t = s_rm[a * PITCH + j] - s_rm[b * PITCH + j]; sd += t * t; }
+    for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+    if ((tid & 15) == 0) {
+      atomicMin(&s_min[a], (unsigned long long)__double_as_longlong(sd));
+      atomicMin(&s_min[b], (unsigned long long)__double_as_longlong(sd));
+    }
+  }
+  __syncthreads();
+  if (tid < kk) s_half[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
+  if (tid == 0) {
+    double mx = 0.0, mx2 = 0.0;
+    int amx = 0;
+    for (int c = 0; c < kk; c++) {
+      const double v = s_move[c];
+      if (v > mx) { mx2 = mx; mx = v; amx = c; } else if (v > mx2) mx2 = v;
+    }
+    s_move[KCH] = mx; s_move[KCH + 1] = mx2; s_move[KCH + 2] = (double)amx;
+  }
+  __syncthreads();
+  KH_STAMP(1);  // pairs, half distances
+  // ---- phase 1: the slice's bounds move with the centroids; the loosened ones are rechecked against their own centroid (k_h_bounds)
+  const double dmax = s_move[KCH], dmax2 = s_move[KCH + 1];
+  const int amax = (int)s_move[KCH + 2];
+  const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
+#pragma unroll
+  for (int r = 0; r < H_SLICE / 256; r++) {
+    const int64_t i = i0 + r * 256 + tid;
+    if (i >= n) break;
+    const int a = assign[i];
+    const double u = (ub[i] + s_move[a]) * (1.0 + 1e-15);
+    double l = lb[i] - (a == amax ? dmax2 : dmax);
+    l -= fabs(l) * 1e-15;
+    ub[i] = u;
+    lb[i] = l;
+    if (!(u * (1.0 + H_ETA) < fmax(s_half[a], l) * (1.0 - H_ETA))) s_list[atomicAdd(&s_nlist, 1)] = r * 256 + tid;
+  }
+  __syncthreads();
+  KH_STAMP(2);  // bounds of the slice
+  const int nlist = s_nlist;
+  {
+    const int l16 = tid & 15;
+    for (int t0 = 0; t0 < nlist; t0 += 16) {
+      const int t = t0 + (tid >> 4);
+      const bool act = t < nlist;
+      const int64_t i = i0 + s_list[act ? t : 0];
+      const int a = assign[i];
+      const int4 *p = reinterpret_cast<const int4 *>(pts + i * D + l16 * 12);
+      const int4 v0 = p[0], v1 = p[1], v2 = p[2];
+      const int pv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+      const double *c = s_rm + a * PITCH + l16 * 12;
+      double sd = 0.0;
+#pragma unroll
+      for (int j = 0; j < 12; j++) { const double d0 = __dsub_rn((double)pv[j], c[j]); sd = __fma_rn(d0, d0, sd); }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      if (act && l16 == 0) {
+        const double u = sqrt(sd) * (1.0 + 1e-12);
+        ub[i] = u;
+        if (!(u * (1.0 + H_ETA) < fmax(s_half[a], lb[i]) * (1.0 - H_ETA))) s_need[atomicAdd(&s_nneed, 1)] = s_list[t];
+      }
+    }
+  }
+  __syncthreads();  // (the row-major centroids are done with: their space holds the deltas from here on)
+  KH_STAMP(3);  // rechecks
+  const int cnt = s_nneed;
+  if (cnt == 0) return;
+  for (int e = tid; e < kk * PITCH; e += 256) s_delta[e] = 0;
+  __syncthreads();
+  // ---- phase 2: the unproven points through the full computation (k_assign192_list4: four lanes per point, a quarter row each)
+  const int slot = tid >> 2, sub = tid & 3;
+  int total_moved = 0;
+#pragma unroll 1
+  for (int row0 = 0; row0 < cnt; row0 += NP) {
+    const bool active = row0 + slot < cnt;
+    const int64_t gi = i0 + s_need[active ? row0 + slot : row0];
+    int4 x[12];
+    {
+      const int4 *src = reinterpret_cast<const int4 *>(pts + gi * D + sub * 48);
+#pragma unroll
+      for (int u = 0; u < 12; u++) x[u] = src[u];
+    }
+    double sc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) sc[c] = 0.0;
+    auto term = [&](int v, int j) {
+      const double pj = (double)v;
+      const double *cj = s_ct + j * KCH + sub * CPL;
+#pragma unroll
+      for (int c = 0; c < CPL; c += 2) {
+        const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
+        const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
+        sc[c] = __fma_rn(t0, t0, sc[c]);
+        sc[c + 1] = __fma_rn(t1, t1, sc[c + 1]);
+      }
+    };
+    auto quarter = [&](auto qtag) {
+      constexpr int Q = decltype(qtag)::value;
+#pragma unroll
+      for (int u = 0; u < 12; u++) {
+        term(quad_bcast<Q>(x[u].x), Q * 48 + u * 4);
+        term(quad_bcast<Q>(x[u].y), Q * 48 + u * 4 + 1);
+        term(quad_bcast<Q>(x[u].z), Q * 48 + u * 4 + 2);
+        term(quad_bcast<Q>(x[u].w), Q * 48 + u * 4 + 3);
+        pin_accumulators(sc);
+      }
+    };
+    quarter(std::integral_constant<int, 0>{});
+    quarter(std::integral_constant<int, 1>{});
+    quarter(std::integral_constant<int, 2>{});
+    quarter(std::integral_constant<int, 3>{});
+    double bd = 1.0e300, bd2 = 1.0e300;
+    int bc = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int ci = sub * CPL + c;
+      if (ci < kk) {
+        if (sc[c] < bd) { bd2 = bd; bd = sc[c]; bc = ci; }
+        else if (sc[c] < bd2) bd2 = sc[c];
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+      const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
+      const int oc = __shfl_xor(bc, o);
+      const bool take = od < bd || (od == bd && oc < bc);
+      const double loser = take ? bd : od;
+      bd2 = fmin(fmin(bd2, od2), loser);
+      if (take) { bd = od; bc = oc; }
+    }
+    if (active && sub == 0) {
+      ub[gi] = sqrt(bd) * (1.0 + 1e-12);
+      lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
+      const int old = assign[gi];
+      if (old != bc) {
+        assign[gi] = bc;
+        const int m = atomicAdd(&s_nmoved, 1);
+        s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
+      }
+    }
+    __syncthreads();
+    const int nmoved = s_nmoved;
+    total_moved += nmoved;
+#pragma unroll 2
+    for (int e = wave; e < nmoved; e += 4) {  // a wave per moved row between the carried sums
+      const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+      const int64_t mi = i0 + s_need[row0 + s_moved[e * 3]];
+      const long long wi = w ? (long long)w[mi] : 1;
+#pragma unroll
+      for (int j = lane; j <= D; j += 64) {
+        const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
+        atomicAdd(&s_delta[nw * PITCH + j], v);
+        if (old >= 0) atomicAdd(&s_delta[old * PITCH + j], (u64)0 - v);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_nmoved = 0;
+    __syncthreads();
+  }
+  KH_STAMP(4);  // scoring
+  if (total_moved == 0) return;
+  if (tid == 0) atomicAdd(&h.chg[dc], (unsigned)total_moved);
+  for (int e = tid; e < kk * PITCH; e += 256) {
+    const u64 v = s_delta[e];
+    if (v != 0) atomicAdd(&h.D[dc][e], v);
+  }
+  KH_STAMP(5);  // flush
+}
+
+// the sums and the counter the plain iterations carried, in the fused iteration's buffers: S[(first - 1) & 1] = (sums, weights), no
+// deltas pending, "something moved" (the first fused launch makes the centroid update the last plain iteration is owed)
+__global__ void k_h_iter_setup(const u64 *__restrict__ sums, const u64 *__restrict__ cnts, const double *__restrict__ cent, int kk_max, HIter h, int first,
+                               const Seg *__restrict__ segs) {
+  const int pp = (first - 1) & 1;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kk_max * 193; e += gridDim.x * blockDim.x) {
+    const int c = e / 193, j = e - c * 193;
+    h.S[pp][e] = j < 192 ? sums[c * 192 + j] : cnts[c];
+    h.D[0][e] = 0; h.D[1][e] = 0; h.D[2][e] = 0;
+    if (j < 192) h.C[pp][c * 192 + j] = cent[c * 192 + j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { h.chg[0] = 0; h.chg[1] = 0; h.chg[2] = 0; h.chg[(first + 2) % 3] = segs[0].changed ? 1u : 0u; }
+}
+
 // ---- D = 3, one launch for the whole clustering -----------------------------------------------------------------
 // The pixel k-means of QuantizeUsingYakmo (tilingencoder.pas:4434-4532) runs ~180 Lloyd iterations over a few hundred thousand
 // distinct colours per palette: a few microseconds of arithmetic per iteration, so as separate launches (two per iteration, two per
@@ -1020,6 +1305,9 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
 #define P3_STAMP(i) do { if (bx == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); st->stamps[i] += t_ - st_last; st_last = t_; } } while (0)
 #else
 #define P3_STAMP(i) do { } while (0)
+#endif
+#ifndef TM_KMH_STAMPS
+#define TM_KMH_STAMPS 0  // diagnostic build: s_memtime spans of k_h_iter's phases (workgroup 1), summed over the launches
 #endif
 #ifndef TM_KM3_NT
 #define TM_KM3_NT 256
@@ -1574,6 +1862,27 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
+  // TM_KM_FUSED=1: the skipping iterations as ONE launch each (k_h_iter) instead of three.  Built and measured in round 3: it saves two
+  // launch turnarounds (4.5 us each) and loses more than that -- 48-58 us per iteration against 41 (phase spans of one workgroup: sums and
+  // centroids 12 %, centroid pairs 19 %, bounds 3 %, rechecks 26 %, scoring its OWN unproven points 37 %: the three kernels spread the
+  // unproven points of a crowded slice over fresh workgroups, one launch leaves them to the slice's own) -- so the three kernels ship
+  const bool fused = skipping && k <= KCH && max_iter > h_warm && getenv("TM_KM_FUSED") != nullptr;
+  DevBuf fbuf;
+  HIter hit;
+  memset(&hit, 0, sizeof(hit));
+  const size_t f_lds = (size_t)192 * KCH * 8 + (size_t)KCH * 193 * 8 + (size_t)2 * H_SLICE * 4 + 64 * 3 * 4;
+  if (fused) {
+    const size_t sb = (size_t)k * 193 * 8, cb = (size_t)k * 192 * 8;
+    TM_TRY(fbuf.alloc(5 * sb + 2 * cb + 64));
+    uint8_t *b = fbuf.as<uint8_t>();
+    hit.S[0] = reinterpret_cast<u64 *>(b); hit.S[1] = reinterpret_cast<u64 *>(b + sb);
+    hit.D[0] = reinterpret_cast<u64 *>(b + 2 * sb); hit.D[1] = reinterpret_cast<u64 *>(b + 3 * sb); hit.D[2] = reinterpret_cast<u64 *>(b + 4 * sb);
+    hit.C[0] = reinterpret_cast<double *>(b + 5 * sb); hit.C[1] = reinterpret_cast<double *>(b + 5 * sb + cb);
+    hit.chg = reinterpret_cast<unsigned *>(b + 5 * sb + 2 * cb);
+    TM_HIP(hipMemsetAsync(fbuf.p, 0, 5 * sb + 2 * cb + 64, stream));
+    if (f_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_iter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_lds);
+  }
+  bool fused_started = false;
   int it = 0, issued = 0;
   const int poll_every = 16;  // launches after convergence return at once (quiet flag), so polling late costs little
   while (issued < max_iter) {
@@ -1590,6 +1899,14 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
           else
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
+          if (fused && last_plain) {  // the update this iteration is owed is the first fused launch's: hand over the carried sums
+            hipLaunchKernelGGL(k_h_iter_setup, dim3(16), dim3(256), 0, stream, sums.as<u64>(), cnts.as<u64>(), (const double *)cent, k, hit, h_warm, (const Seg *)ds);
+            fused_started = true;
+            continue;
+          }
+        } else if (fused) {
+          hipLaunchKernelGGL(k_h_iter, dim3(gb), dim3(256), f_lds, stream, pts, n, w, (const Seg *)ds, hit, issued, 0, assign, hub.as<double>(), hlb.as<double>(), quiet.as<int>());
+          continue;
         } else {
           hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), 0, stream, pts, n, ds, (const double *)cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
@@ -1624,6 +1941,30 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     it = issued;
   }
   TM_HIP(hipGetLastError());
+#if TM_KMH_STAMPS
+  if (fused_started) {
+    unsigned long long stv[6];
+    TM_HIP(hipMemcpy(stv, reinterpret_cast<const unsigned long long *>(hit.chg + 4), sizeof(stv), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[tm_kmh stamps] workgroup 1, ticks summed over the launches: sums+centroids %llu, pairs %llu, bounds %llu, rechecks %llu, scoring %llu, flush %llu\n", stv[0], stv[1],
+            stv[2], stv[3], stv[4], stv[5]);
+  }
+#endif
+  if (fused_started) {  // the final centroids sit in the fused iteration's buffers: those of the converged assignment, or one more update at the cap
+    int q = -1;
+    TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
+    TM_HIP(hipStreamSynchronize(stream));
+    int final_it = q;
+    if (q < 0) {
+      hipLaunchKernelGGL(k_h_iter, dim3(1), dim3(256), f_lds, stream, pts, n, w, (const Seg *)ds, hit, max_iter, 1, assign, hub.as<double>(), hlb.as<double>(), quiet.as<int>());
+      TM_HIP(hipGetLastError());
+      int q2 = -1;
+      TM_HIP(hipMemcpyAsync(&q2, quiet.p, 4, hipMemcpyDeviceToHost, stream));
+      TM_HIP(hipStreamSynchronize(stream));
+      final_it = q2 >= 0 ? q2 : max_iter;  // (the last assignment may itself have moved nothing: then its centroids stand)
+      if (q2 >= 0) it = q2;
+    }
+    if (final_it >= h_warm - 1) TM_HIP(hipMemcpyAsync(cent, hit.C[final_it & 1], (size_t)k * 192 * 8, hipMemcpyDeviceToDevice, stream));
+  }
   if (host_iters) *host_iters = it;
   TM_HIP(hipMemcpyAsync(hs.data(), dsegs.p, sizeof(Seg) * nseg, hipMemcpyDeviceToHost, stream));
   TM_HIP(hipStreamSynchronize(stream));
