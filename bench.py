@@ -27,17 +27,20 @@ STAGES = ["load", "predict_motion", "reduce", "prepare_palettes", "dither", "rec
 
 
 def _traffic_from_profiles(kernel_build):
-    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r02_pmc_knn_traffic.json), only when
-    they were taken on this build of the kernel; null otherwise -- the figure is never a constant of this file."""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_knn_traffic.json")
-    try:
-        with open(p) as f:
-            t = json.load(f)
-    except OSError:
-        return None, "no PMC pass committed for this build"
-    if t.get("kernel_build") != kernel_build:
-        return None, "profiles/r02_pmc_knn_traffic.json was taken on build %r, this is %r" % (t.get("kernel_build"), kernel_build)
-    return t["traffic_bytes"], "2 x FETCH_SIZE + WRITE_SIZE of one pruned launch, separate --pmc passes (%s)" % t.get("source", "profiles/")
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/r*_pmc_knn_traffic.json, newest round
+    first), only when they were taken on this build of the kernel; null otherwise -- the figure is never a constant of this file."""
+    import glob
+    seen = []
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_knn_traffic.json")), reverse=True):
+        try:
+            with open(p) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel_build") == kernel_build:
+            return t["traffic_bytes"], "2 x FETCH_SIZE + WRITE_SIZE of one pruned launch, separate --pmc passes (%s)" % t.get("source", "profiles/")
+        seen.append("%s: build %r" % (os.path.basename(p), t.get("kernel_build")))
+    return None, "no PMC pass committed for this build %r (%s)" % (kernel_build, "; ".join(seen) or "none in profiles/")
 
 
 def _host_threads(visible):

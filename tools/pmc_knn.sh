@@ -2,11 +2,11 @@
 # PMC passes over the KNN scan kernels of one bench step (pruned launch + the dense diagnostic launch), each counter set in its own
 # run (no tracing beside --pmc).  Run on the GPU box:  bash tools/pmc_knn.sh <tag>   -> gpurun_out/pmc_<tag>/*.csv + summary
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
-BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-h2d-extra"
+BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra"
 run() {  # name, counters...
   local name=$1; shift
   timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-include-regex "k_knn_scan2|k_knn_mfma" --output-format csv -d $OUT/$name -- $BENCH > $OUT/$name.json 2> $OUT/$name.err || { tail -5 $OUT/$name.err; return 1; }
@@ -15,4 +15,5 @@ run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
 run sq2 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS &&
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum &&
-python3 tools/pmc_summary.py $OUT > $OUT/summary.txt && cat $OUT/summary.txt
+python3 tools/pmc_summary.py $OUT > $OUT/summary.txt && cat $OUT/summary.txt &&
+python3 tools/pmc_traffic.py $OUT $TAG > $OUT/traffic.json && cat $OUT/traffic.json
