@@ -1853,6 +1853,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   DevBuf hub, hlb, hcent_t, hmove, hhalf, hneed, hcnt;
   const size_t l_lds = (size_t)192 * KCH * 8 + (size_t)k * 193 * 8 + (size_t)256 * 3 * 4 + 16;  // k_assign192_list
   if (skipping) {
+    // a dynamic-LDS request above the CU's 160 KB comes back from the launch as a bare "invalid argument" (round 2's scratch records hold one,
+    // from a k = 64 build of these kernels that kept more in LDS): refuse it here, by name
+    TM_CHECK(l_lds <= 160 * 1024 && (size_t)k * 193 * 8 <= 160 * 1024, TM_E_INVAL, "k-means: %d centroids need %zu bytes of LDS in the list kernel (the CU has 163840)", k, l_lds);
     TM_TRY(hub.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hlb.alloc((size_t)std::max<int64_t>(n, 1) * 8)); TM_TRY(hcent_t.alloc((size_t)h_kt * 192 * 8));
     TM_TRY(hmove.alloc((size_t)(k + 3) * 8)); TM_TRY(hhalf.alloc((size_t)k * 8)); TM_TRY(hneed.alloc((size_t)std::max<int64_t>(n, 1) * 4)); TM_TRY(hcnt.alloc(8));
     TM_HIP(hipMemsetAsync(hcnt.p, 0, 8, stream));
@@ -1872,6 +1875,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   memset(&hit, 0, sizeof(hit));
   const size_t f_lds = (size_t)192 * KCH * 8 + (size_t)KCH * 193 * 8 + (size_t)2 * H_SLICE * 4 + 64 * 3 * 4;
   if (fused) {
+    TM_CHECK(f_lds <= 160 * 1024, TM_E_INVAL, "k-means: the single-launch iteration needs %zu bytes of LDS (the CU has 163840)", f_lds);
     const size_t sb = (size_t)k * 193 * 8, cb = (size_t)k * 192 * 8;
     TM_TRY(fbuf.alloc(5 * sb + 2 * cb + 64));
     uint8_t *b = fbuf.as<uint8_t>();
