@@ -52,7 +52,7 @@ struct RowLess {
 };
 
 // 64-bit content hash: 16 lanes per row, one uint4 each per 256 bytes; position enters every term, the terms add up
-__global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade,
+__global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade, int shift,
                                                   unsigned long long *__restrict__ hash) {
   const int sub = threadIdx.x & 15;
   const int64_t stride = (int64_t)gridDim.x * 16;
@@ -70,18 +70,35 @@ __global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ r
       }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o);
-    if (row < n && sub == 0) hash[row] = degrade ? (h & 3) : h;  // degrade: test hook that forces collisions
+    if (row < n && sub == 0) hash[row] = degrade ? (h & 3) : (h >> shift);  // degrade: test hook that forces collisions; shift: only the top bits are kept (run_dedup_ex)
   }
 }
 
-// runs of equal hash: head flags as k_mark_heads writes them; a non-head row that differs from its predecessor is a collision
-__global__ void k_mark_heads_hash(const uint32_t *__restrict__ sorted, const unsigned long long *__restrict__ hsorted, int64_t n,
-                                  RowLess less, uint32_t *__restrict__ head, uint32_t *__restrict__ headpos, int *__restrict__ collision) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const bool h = (i == 0) || hsorted[i] != hsorted[i - 1];
-    if (!h && less.cmp(sorted[i - 1], sorted[i]) != 0) *collision = 1;
-    head[i] = h ? 1u : 0u;
-    headpos[i] = h ? (uint32_t)i : 0u;
+// runs of equal hash: head flags as k_mark_heads writes them; a non-head row that differs from its predecessor is a collision.  16 lanes per row: a uint4 each, so a 256-byte row is one coalesced read per side (a thread
+// walking both rows on its own took 0.43 ms for the bench clip's 1.08 M non-head rows)
+__global__ __launch_bounds__(256) void k_mark_heads_hash(const uint32_t *__restrict__ sorted, const unsigned long long *__restrict__ hsorted, int64_t n,
+                                                         RowLess less, uint32_t *__restrict__ head, uint32_t *__restrict__ headpos, int *__restrict__ collision) {
+  const int sub = threadIdx.x & 15, vecs = less.dwords / 4;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t i0 = blockIdx.x * (int64_t)16; i0 < n; i0 += stride) {
+    const int64_t i = i0 + (threadIdx.x >> 4);
+    bool h = true, diff = false;
+    if (i < n) {
+      h = (i == 0) || hsorted[i] != hsorted[i - 1];
+      if (!h) {
+        const uint4 *pa = reinterpret_cast<const uint4 *>(less.rows + (int64_t)sorted[i - 1] * less.dwords);
+        const uint4 *pb = reinterpret_cast<const uint4 *>(less.rows + (int64_t)sorted[i] * less.dwords);
+        for (int v = sub; v < vecs; v += 16) {
+          const uint4 x = pa[v], y = pb[v];
+          diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+        }
+      }
+      if (sub == 0) {
+        head[i] = h ? 1u : 0u;
+        headpos[i] = h ? (uint32_t)i : 0u;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(diff) && (threadIdx.x & 63) == 0) *collision = 1;
   }
 }
 
@@ -251,19 +268,36 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     DevBuf hkey, hkey2, flag;
     TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8)); TM_TRY(flag.alloc(4));
     TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    // The sort only has to bring equal rows together, so the hash keeps only as many of its top bits (whole 8-bit passes of the sort) as hold
+    // the chance of two different rows among n sharing them below 2^-12 -- 56 for Reindex's 321 k rows (the bench clip's 4.32 M frame tiles
+    // need all 64).  Rows that share them and differ are caught by the full compare like any collision (the plain path then: exact, slow).
+    // The kept bits are moved DOWN and sorted as bits [0, hbits): a range that ends at bit 64 without starting at 0 sends rocPRIM's
+    // merge-sort path (up to ~1 M keys) through a mask built with a shift by 64 -- it then orders by the wrong bits and its merge reads out
+    // of bounds (found the hard way: a memory access fault on the GPU box).
+    int hbits = 64;
+    const int degrade = getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0;
+    if (!degrade) {
+      int lg = 1;
+      while (((int64_t)1 << lg) < n) lg++;
+      hbits = std::min(64, (2 * lg + 11 + 7) / 8 * 8);
+      if (const char *hb = getenv("TM_DEDUP_HASH_BITS")) hbits = std::max(8, std::min(64, atoi(hb) / 8 * 8));  // A/B aid
+    }
     hipLaunchKernelGGL(k_row_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, n,
-                       row_bytes / 4, getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0, hkey.as<unsigned long long>());
+                       row_bytes / 4, degrade, 64 - hbits, hkey.as<unsigned long long>());
     size_t tbh = 0;
     TM_HIP(rocprim::radix_sort_pairs(nullptr, tbh, hkey.as<unsigned long long>(), hkey2.as<unsigned long long>(), idx.as<uint32_t>(),
-                                     sorted.as<uint32_t>(), (size_t)n, 0, 64, stream));
+                                     sorted.as<uint32_t>(), (size_t)n, 0, hbits, stream));
     TM_TRY(tmp.alloc(tbh));
     TM_HIP(rocprim::radix_sort_pairs(tmp.p, tbh, hkey.as<unsigned long long>(), hkey2.as<unsigned long long>(), idx.as<uint32_t>(),
-                                     sorted.as<uint32_t>(), (size_t)n, 0, 64, stream));
-    hipLaunchKernelGGL(k_mark_heads_hash, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), hkey2.as<unsigned long long>(), n, less,
-                       head.as<uint32_t>(), headpos.as<uint32_t>(), flag.as<int>());
+                                     sorted.as<uint32_t>(), (size_t)n, 0, hbits, stream));
+    hipLaunchKernelGGL(k_mark_heads_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, sorted.as<uint32_t>(),
+                       hkey2.as<unsigned long long>(), n, less, head.as<uint32_t>(), headpos.as<uint32_t>(), flag.as<int>());
     int collision = 0;
-    TM_HIP(hipMemcpyAsync(&collision, flag.p, 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&collision, flag.p, 4));
+      TM_TRY(hr_.wait());
+    }
     grouped = collision == 0;
   }
   if (!grouped) {
@@ -287,9 +321,12 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
                      use_rep.as<uint32_t>(), uniq.as<uint32_t>());
   // number of runs = head_excl[n-1] + head[n-1]
   uint32_t last_excl = 0, last_head = 0;
-  TM_HIP(hipMemcpyAsync(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(&last_head, head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4));
+    TM_TRY(hr_.get(&last_head, head.as<uint32_t>() + (n - 1), 4));
+    TM_TRY(hr_.wait());
+  }
   const int64_t nu = (int64_t)last_excl + last_head;
   bool ranked = false;  // ord2 already holds the final order
   unsigned long long live = 0;
@@ -304,8 +341,11 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     TM_HIP(hipMemsetAsync(h1.p, 0, 1024 * 4, stream));
     hipLaunchKernelGGL(k_po_use_hist, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), h1.as<uint32_t>());
     std::vector<uint32_t> hh1(1024), hh2(4096);
-    TM_HIP(hipMemcpyAsync(hh1.data(), h1.p, 1024 * 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(hh1.data(), h1.p, 1024 * 4));
+      TM_TRY(hr_.wait());
+    }
     int64_t above = 0;
     int ustar = -1;
     for (int u = 1023; u >= 1; u--) {
@@ -315,8 +355,11 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     if (ustar >= 1 && ustar < 1023) {  // (a cut inside the clamped bin -- 1023 uses and more -- takes the full sort below)
       TM_HIP(hipMemsetAsync(h2.p, 0, 4096 * 4, stream));
       hipLaunchKernelGGL(k_po_lead_hist, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, less, h2.as<uint32_t>());
-      TM_HIP(hipMemcpyAsync(hh2.data(), h2.p, 4096 * 4, hipMemcpyDeviceToHost, stream));
-      TM_HIP(hipStreamSynchronize(stream));
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(hh2.data(), h2.p, 4096 * 4));
+        TM_TRY(hr_.wait());
+      }
       int64_t ncand = above;
       int bstar = 4095;
       for (int b = 0; b < 4096; b++) {
@@ -367,8 +410,11 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   TM_TRY(tmp.alloc(tb4));
   TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb4, key.as<uint32_t>(), key2.as<uint32_t>(), uniq.as<uint32_t>(), ord2.as<uint32_t>(),
                                    (size_t)nu, 0, 32, stream));
-  TM_HIP(hipMemcpyAsync(&live, cnt.p, 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&live, cnt.p, 8));
+    TM_TRY(hr_.wait());
+  }
   }
   TM_HIP(hipMemsetAsync(pos.p, 0xff, n * 4, stream));
   hipLaunchKernelGGL(k_scatter_pos, dim3(gridn((int64_t)live)), dim3(256), 0, stream, ord2.as<uint32_t>(), (int64_t)live,
@@ -404,9 +450,12 @@ int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t 
   TM_HIP(hipGetLastError());
   uint32_t last_pos = 0;
   int32_t last_keep = 0;
-  TM_HIP(hipMemcpyAsync(&last_pos, (const uint32_t *)pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(&last_keep, (const int32_t *)keep + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&last_pos, (const uint32_t *)pos + (n - 1), 4));
+    TM_TRY(hr_.get(&last_keep, (const int32_t *)keep + (n - 1), 4));
+    TM_TRY(hr_.wait());
+  }
   *host_count = (int64_t)last_pos + (last_keep ? 1 : 0);
   return TM_OK;
 }
@@ -550,16 +599,22 @@ int reduce_select_candidates(const void *keys_v, int64_t n, int64_t target, void
   hipLaunchKernelGGL(k_rk_single_keys, dim3(gridn(n)), dim3(256), 0, stream, keys, gid_of.as<uint32_t>(), gsize.as<uint32_t>(), n, skey.as<unsigned long long>(),
                      cnt.as<unsigned long long>());
   unsigned long long nsingles = 0;
-  TM_HIP(hipMemcpyAsync(&nsingles, cnt.p, 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&nsingles, cnt.p, 8));
+    TM_TRY(hr_.wait());
+  }
   unsigned long long cutoff = ~0ull - 1ull, min_use = 0;  // fewer singles than the budget: everything travels
   if (target > 0 && (unsigned long long)target <= nsingles) {
     size_t tb3 = 0;
     TM_HIP(rocprim::radix_sort_keys(nullptr, tb3, skey.as<unsigned long long>(), skey2.as<unsigned long long>(), (size_t)n, 0, 64, stream));
     TM_TRY(tmp.alloc(tb3));
     TM_HIP(rocprim::radix_sort_keys(tmp.p, tb3, skey.as<unsigned long long>(), skey2.as<unsigned long long>(), (size_t)n, 0, 64, stream));
-    TM_HIP(hipMemcpyAsync(&cutoff, skey2.as<unsigned long long>() + (target - 1), 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&cutoff, skey2.as<unsigned long long>() + (target - 1), 8));
+      TM_TRY(hr_.wait());
+    }
     min_use = (unsigned long long)(uint32_t)(~(uint32_t)(cutoff >> 32));
   }
   hipLaunchKernelGGL(k_rk_select, dim3(gridn(n)), dim3(256), 0, stream, skey.as<unsigned long long>(), gid_of.as<uint32_t>(), gsum.as<unsigned long long>(), n, cutoff, min_use,

@@ -504,8 +504,11 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
         TM_TRY(scan_tmp.alloc(tb));
         TM_HIP(rocprim::exclusive_scan(scan_tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)(nent + 1), rocprim::plus<uint32_t>(), stream));
         hipLaunchKernelGGL(k_dd_seg, dim3((npal + 1 + 63) / 64), dim3(64), 0, stream, off.as<uint32_t>(), npal, seg.as<uint32_t>());
-        TM_HIP(hipMemcpyAsync(hseg.data(), seg.p, hseg.size() * 4, hipMemcpyDeviceToHost, stream));
-        TM_HIP(hipStreamSynchronize(stream));
+        {
+          HostRead hr_(stream);
+          TM_TRY(hr_.get(hseg.data(), seg.p, hseg.size() * 4));
+          TM_TRY(hr_.wait());
+        }
         dedup = (int64_t)hseg[npal] * 2 <= n * 64;
 
       }
@@ -533,8 +536,11 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
                            missing.as<int>());
         TM_HIP(hipGetLastError());
         int hmiss = 0;
-        TM_HIP(hipMemcpyAsync(&hmiss, missing.p, 4, hipMemcpyDeviceToHost, stream));
-        TM_HIP(hipStreamSynchronize(stream));  // (the chunk tables and the scratch die with this scope)
+        {
+          HostRead hr_(stream);
+          TM_TRY(hr_.get(&hmiss, missing.p, 4));
+          TM_TRY(hr_.wait());  // (the chunk tables and the scratch die with this scope)
+        }
         TM_CHECK(!hmiss, TM_E_INVAL, "dither: the list of distinct pixel keys does not cover these tiles");
       } else if (!dedup)
         hipLaunchKernelGGL(k_dither_tk_fast<false>, dim3(grid), dim3(64), 0, stream, (const uint32_t *)tiles, (const uint8_t *)flags,

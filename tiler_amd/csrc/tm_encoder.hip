@@ -377,8 +377,11 @@ static int gather_var(tm_encoder *e, const void *send, int64_t count, int item, 
   TM_HIP(hipMemcpyAsync(dcnt.p, &count, 8, hipMemcpyHostToDevice, e->stream));
   TM_TRY(e->co.allgather(dcnt.p, dall.p, 8));
   counts->assign((size_t)W, 0);
-  TM_HIP(hipMemcpyAsync(counts->data(), dall.p, (size_t)W * 8, hipMemcpyDeviceToHost, e->stream));
-  TM_HIP(hipStreamSynchronize(e->stream));
+  {
+    HostRead hr_(e->stream);
+    TM_TRY(hr_.get(counts->data(), dall.p, (size_t)W * 8));
+    TM_TRY(hr_.wait());
+  }
   int64_t mx = 0, total = 0;
   for (int64_t c : *counts) { mx = std::max(mx, c); total += c; }
   TM_TRY(out.alloc((size_t)std::max<int64_t>(total, 1) * item));
@@ -416,8 +419,11 @@ static int load_tail(tm_encoder *e) {
   e->load_tail_pending = false;
   std::vector<float> sums((size_t)e->nframes * 3);
   hipStream_t st = e->stream_aux ? e->stream_aux : e->stream;
-  TM_HIP(hipMemcpyAsync(sums.data(), e->dcorrel.p, sums.size() * 4, hipMemcpyDeviceToHost, st));
-  TM_HIP(hipStreamSynchronize(st));
+  {
+    HostRead hr_(st);
+    TM_TRY(hr_.get(sums.data(), e->dcorrel.p, sums.size() * 4));
+    TM_TRY(hr_.wait());
+  }
   e->correl.assign(e->nframes, 0.0f);
   for (int f = 1; f < e->nframes; f++) {  // tail of PearsonCorrelation (2221-2227) in host IEEE arithmetic
     const float denx = std::sqrt(sums[f * 3 + 1]), deny = std::sqrt(sums[f * 3 + 2]);
@@ -926,8 +932,11 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   lap("palette colours (3-D)");
   }
   e->palettes_host.resize((size_t)e->s.PaletteCount * e->s.PaletteSize);
-  TM_HIP(hipMemcpyAsync(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4, hipMemcpyDeviceToHost, e->stream));
-  TM_HIP(hipStreamSynchronize(e->stream));
+  {
+    HostRead hr_(e->stream);
+    TM_TRY(hr_.get(e->palettes_host.data(), e->palettes_dev.p, e->palettes_host.size() * 4));
+    TM_TRY(hr_.wait());
+  }
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
   if (!getenv("TM_CU_SPLIT") && !getenv("TM_QF_EARLY"))
   TM_TRY(prefetch_query_features(e));  // the GPU has nothing to do while the host searches: Reconstruct's query features run now

@@ -283,8 +283,11 @@ int launch_epu_rerank_ondemand(const void *queries, int64_t nq, const void *knn_
     TM_TRY(tmp.alloc(tb));
     TM_HIP(rocprim::exclusive_scan(tmp.p, tb, cnt.as<unsigned long long>(), off.as<unsigned long long>(), 0ull, (size_t)(n + 1), rocprim::plus<unsigned long long>(), stream));
     unsigned long long m = 0;
-    TM_HIP(hipMemcpyAsync(&m, off.as<unsigned long long>() + n, 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&m, off.as<unsigned long long>() + n, 8));
+      TM_TRY(hr_.wait());
+    }
     if (m > 0) {
       TM_CHECK(m < (1ull << 32), TM_E_NOMEM, "epu: %llu pairs in one batch", m);
       TM_TRY(keys.alloc((size_t)m * 8)); TM_TRY(keys2.alloc((size_t)m * 8)); TM_TRY(pos.alloc((size_t)m * 4)); TM_TRY(pos2.alloc((size_t)m * 4));
@@ -300,8 +303,11 @@ int launch_epu_rerank_ondemand(const void *queries, int64_t nq, const void *knn_
       TM_TRY(tmp.alloc(tb));
       TM_HIP(rocprim::inclusive_scan(tmp.p, tb, head.as<uint32_t>(), rank.as<uint32_t>(), (size_t)m, rocprim::plus<uint32_t>(), stream));
       uint32_t nu = 0;
-      TM_HIP(hipMemcpyAsync(&nu, rank.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-      TM_HIP(hipStreamSynchronize(stream));
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(&nu, rank.as<uint32_t>() + (m - 1), 4));
+        TM_TRY(hr_.wait());
+      }
       TM_TRY(ukeys.alloc((size_t)nu * 8)); TM_TRY(feat.alloc((size_t)nu * 384));
       hipLaunchKernelGGL(k_epu_rows, dim3(g), dim3(256), 0, stream, keys2.as<unsigned long long>(), pos2.as<uint32_t>(), rank.as<uint32_t>(), (int64_t)m, row_of.as<uint32_t>(),
                          ukeys.as<unsigned long long>());

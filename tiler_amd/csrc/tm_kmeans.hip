@@ -1704,10 +1704,13 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   TM_HIP(hipGetLastError());
   std::vector<Seg3State> hstate(hs.size());
   std::vector<double> hcent(hs.size() * (size_t)k * 3);
-  TM_HIP(hipMemcpyAsync(hs.data(), dsegs.p, sizeof(Seg3) * hs.size(), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(hstate.data(), dstate.p, sizeof(Seg3State) * hs.size(), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(hcent.data(), dcent.p, hcent.size() * 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(hs.data(), dsegs.p, sizeof(Seg3) * hs.size()));
+    TM_TRY(hr_.get(hstate.data(), dstate.p, sizeof(Seg3State) * hs.size()));
+    TM_TRY(hr_.get(hcent.data(), dcent.p, hcent.size() * 8));
+    TM_TRY(hr_.wait());
+  }
   int iters = 0;
   for (size_t i = 0; i < hs.size(); i++)
     if (hstate[i].timeout != 0) {  // a workgroup of a segment never became resident (the barrier gave up): the launches-per-iteration path instead
@@ -1939,8 +1942,11 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, (d == 192 || fuse3) ? 1 : 0, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
     }
     int q = -1;
-    TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&q, quiet.p, 4));
+      TM_TRY(hr_.wait());
+    }
     if (q >= 0) { it = q; break; }
     it = issued;
   }
@@ -1955,23 +1961,32 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
 #endif
   if (fused_started) {  // the final centroids sit in the fused iteration's buffers: those of the converged assignment, or one more update at the cap
     int q = -1;
-    TM_HIP(hipMemcpyAsync(&q, quiet.p, 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&q, quiet.p, 4));
+      TM_TRY(hr_.wait());
+    }
     int final_it = q;
     if (q < 0) {
       hipLaunchKernelGGL(k_h_iter, dim3(1), dim3(256), f_lds, stream, pts, n, w, (const Seg *)ds, hit, max_iter, 1, assign, hub.as<double>(), hlb.as<double>(), quiet.as<int>());
       TM_HIP(hipGetLastError());
       int q2 = -1;
-      TM_HIP(hipMemcpyAsync(&q2, quiet.p, 4, hipMemcpyDeviceToHost, stream));
-      TM_HIP(hipStreamSynchronize(stream));
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(&q2, quiet.p, 4));
+        TM_TRY(hr_.wait());
+      }
       final_it = q2 >= 0 ? q2 : max_iter;  // (the last assignment may itself have moved nothing: then its centroids stand)
       if (q2 >= 0) it = q2;
     }
     if (final_it >= h_warm - 1) TM_HIP(hipMemcpyAsync(cent, hit.C[final_it & 1], (size_t)k * 192 * 8, hipMemcpyDeviceToDevice, stream));
   }
   if (host_iters) *host_iters = it;
-  TM_HIP(hipMemcpyAsync(hs.data(), dsegs.p, sizeof(Seg) * nseg, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(hs.data(), dsegs.p, sizeof(Seg) * nseg));
+    TM_TRY(hr_.wait());
+  }
   if (host_kk) {
     host_kk->resize(nseg);
     for (int s = 0; s < nseg; s++) (*host_kk)[s] = hs[s].kk;
@@ -2230,8 +2245,11 @@ static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std
   }
   TM_HIP(hipGetLastError());
   out->assign((size_t)k, -1);
-  TM_HIP(hipMemcpyAsync(out->data(), seeds.p, (size_t)k * 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(out->data(), seeds.p, (size_t)k * 8));
+    TM_TRY(hr_.wait());
+  }
   return TM_OK;
 }
 
@@ -2264,8 +2282,11 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   hipLaunchKernelGGL(k_count_assign, dim3((int)std::min<int64_t>((n + 255) / 256, 512)), dim3(256), npal <= 8192 ? (size_t)npal * 4 : 0, stream,
                      assign.as<int32_t>(), n, npal, cnt.as<u64>());
   std::vector<u64> hc(npal);
-  TM_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)npal * 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(hc.data(), cnt.p, (size_t)npal * 8));
+    TM_TRY(hr_.wait());
+  }
   std::vector<int> ord(npal), hl(npal);
   for (int i = 0; i < npal; i++) ord[i] = i;
   std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hc[a] > hc[b]; });
@@ -2449,13 +2470,19 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
     hipLaunchKernelGGL(k_ffd_pick, dim3(1), dim3(256), 0, stream, cands.as<FfCand>(), co.world, k, state.as<FfState>(), cur_row.as<int32_t>(), cent.as<double>());
     TM_HIP(hipGetLastError());
     if ((c & 3) == 3 || c == k - 1) {  // "no distinct point left" ends the picks early; looked at every few picks
-      TM_HIP(hipMemcpyAsync(&hst, state.p, sizeof(FfState), hipMemcpyDeviceToHost, stream));
-      TM_HIP(hipStreamSynchronize(stream));
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(&hst, state.p, sizeof(FfState)));
+        TM_TRY(hr_.wait());
+      }
       if (hst.done) break;
     }
   }
-  TM_HIP(hipMemcpyAsync(&hst, state.p, sizeof(FfState), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&hst, state.p, sizeof(FfState)));
+    TM_TRY(hr_.wait());
+  }
   hs.kk = hst.kk;
   hs.init_done = 1;
   TM_CHECK(hs.kk >= 1, TM_E_INVAL, "palettize: no point anywhere");
@@ -2485,8 +2512,11 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
     TM_TRY(co.allreduce_sum_i64(red.p, (int64_t)k * d + k + 1));
     hipLaunchKernelGGL(k_kmd_update, dim3(1), dim3(1024), 0, stream, red.as<u64>(), dsegs.as<Seg>(), k, cent.as<double>());
     u64 changed = 0;
-    TM_HIP(hipMemcpyAsync(&changed, red.as<u64>() + (size_t)k * d + k, 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&changed, red.as<u64>() + (size_t)k * d + k, 8));
+      TM_TRY(hr_.wait());
+    }
     if (changed == 0) break;
   }
   // palettes ranked by number of tiles over all processes, descending (tilingencoder.pas:4229-4234); ties keep the initial order
@@ -2499,8 +2529,11 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
   TM_HIP(hipGetLastError());
   TM_TRY(co.allreduce_sum_i64(cnt.p, npal));
   std::vector<u64> hc(npal);
-  TM_HIP(hipMemcpyAsync(hc.data(), cnt.p, (size_t)npal * 8, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(hc.data(), cnt.p, (size_t)npal * 8));
+    TM_TRY(hr_.wait());
+  }
   std::vector<int> ord(npal), hl(npal);
   for (int i = 0; i < npal; i++) ord[i] = i;
   std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hc[a] > hc[b]; });
@@ -2594,15 +2627,21 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
     TM_HIP(rocprim::run_length_encode(tmp.p, tb2, keys2.as<u64>(), (unsigned int)npx, ukeys.as<u64>(), ucnt.as<uint32_t>(),
                                       nruns.as<unsigned int>(), stream));
     unsigned int nu = 0;
-    TM_HIP(hipMemcpyAsync(&nu, nruns.p, 4, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&nu, nruns.p, 4));
+      TM_TRY(hr_.wait());
+    }
     // segment boundaries per palette: lower bound of each palette number in the sorted unique keys, found on the device
     DevBuf dlb;
     TM_TRY(dlb.alloc((size_t)(npal + 1) * 8));
     hipLaunchKernelGGL(k_palette_bounds, dim3((npal + 1 + 63) / 64), dim3(64), 0, stream, ukeys.as<u64>(), (int64_t)nu, npal, dlb.as<long long>());
     std::vector<long long> lb((size_t)npal + 1);
-    TM_HIP(hipMemcpyAsync(lb.data(), dlb.p, lb.size() * 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(lb.data(), dlb.p, lb.size() * 8));
+      TM_TRY(hr_.wait());
+    }
     std::vector<int64_t> sb(npal, 0), sc(npal, 0);
     {
       for (int p = 0; p < npal; p++) { sb[p] = lb[p]; sc[p] = p % pal_world == pal_rank ? lb[p + 1] - lb[p] : 0; }  // other processes' palettes: empty segments
@@ -2630,8 +2669,11 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
                      std::chrono::duration<double, std::milli>(t_km0 - t_km).count() , nu,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_km0).count(), iters);
     std::vector<double> hc((size_t)npal * pal_size * 3);
-    TM_HIP(hipMemcpyAsync(hc.data(), cent.p, hc.size() * 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(hc.data(), cent.p, hc.size() * 8));
+      TM_TRY(hr_.wait());
+    }
     // host tail (P x PaletteSize colours): Round, clamp, Posterize(.,255) = identity, sort by (Val, Sat, Hue)
     // -- tilingencoder.pas:4513-4558, utils.pas:526-534, 741-748
     struct Item { int v, s, h, r, g, b, idx; };

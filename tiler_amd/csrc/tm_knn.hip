@@ -471,8 +471,11 @@ static int col_stats(const void *feat, int64_t n, ColStats *out, DevBuf &scratch
     TM_HIP(hipGetLastError());
   }
   int res[384];
-  TM_HIP(hipMemcpyAsync(res, scratch.p, sizeof(res), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(res, scratch.p, sizeof(res)));
+    TM_TRY(hr_.wait());
+  }
   memcpy(out->mn, res, sizeof(int) * 192);
   memcpy(out->mx, res + 192, sizeof(int) * 192);
   return TM_OK;
@@ -878,8 +881,11 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
   bool fresh_radial = false;  // the queries' radial coordinates were computed while the index was being built
   if (query_colmm) {  // the producer of the queries kept their column ranges
     int res[384];
-    TM_HIP(hipMemcpyAsync(res, query_colmm, sizeof(res), hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(res, query_colmm, sizeof(res)));
+      TM_TRY(hr_.wait());
+    }
     memcpy(qs.mn, res, sizeof(int) * 192);
     memcpy(qs.mx, res + 192, sizeof(int) * 192);
   } else
@@ -928,8 +934,11 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
       TM_TRY(row_radial(ix, ix->db, ix->nt, ix->tradial, ix->tccol, stream));
       TM_TRY(row_radial(ix, queries, nq, ix->qradial, ix->qccol, stream));
       unsigned int rr[2];
-      TM_HIP(hipMemcpyAsync(rr, ix->rrange.p, 8, hipMemcpyDeviceToHost, stream));
-      TM_HIP(hipStreamSynchronize(stream));
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(rr, ix->rrange.p, 8));
+        TM_TRY(hr_.wait());
+      }
       float rlo, rhi;
       memcpy(&rlo, &rr[0], 4); memcpy(&rhi, &rr[1], 4);
       if (!(rhi > rlo)) { rlo = 0.0f; rhi = 1.0f; }
@@ -1062,9 +1071,12 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   }
   int flag = 0;
   unsigned long long cnt[32] = {0};
-  TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(cnt, ix->counters.p, 256, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
+    TM_TRY(hr_.get(cnt, ix->counters.p, 256));
+    TM_TRY(hr_.wait());
+  }
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   float ms = 0;
   TM_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
@@ -1188,9 +1200,12 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   TM_HIP(hipGetLastError());
   unsigned int novf = 0;
   int flag = 0;
-  TM_HIP(hipMemcpyAsync(&novf, counter.p, 4, hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipMemcpyAsync(&flag, ix->err_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-  TM_HIP(hipStreamSynchronize(stream));
+  {
+    HostRead hr_(stream);
+    TM_TRY(hr_.get(&novf, counter.p, 4));
+    TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
+    TM_TRY(hr_.wait());
+  }
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   if (getenv("TM_KNN_DEBUG"))
     fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,

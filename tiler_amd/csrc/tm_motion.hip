@@ -579,8 +579,11 @@ int solve_tile_count(const void *group, int64_t ngroups, const void *pm_err, con
     hipLaunchKernelGGL(k_count_groups, dim3(gridn(ngroups)), dim3(256), 0, stream, gmax.as<uint32_t>(), ngroups, ep, ek, hp ? 1 : 0, hk ? 1 : 0,
                        count.as<unsigned long long>());
     unsigned long long c = 0;
-    TM_HIP(hipMemcpyAsync(&c, count.p, 8, hipMemcpyDeviceToHost, stream));
-    TM_HIP(hipStreamSynchronize(stream));
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&c, count.p, 8));
+      TM_TRY(hr_.wait());
+    }
     const double y = (double)c;
     last = x; n++;
     if (std::fabs(y - target) <= 0.5) break;

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "tm_common.h"
@@ -17,6 +18,48 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 const char *get_error() { return g_err; }
+
+// ---- small read-backs through page-locked memory (HostRead, tm_common.h) ---------------------------------------------
+namespace {
+struct PinnedArea {
+  uint8_t *p = nullptr;
+  size_t used = 0;
+  int depth = 0;  // live HostRead objects of this thread: the area is handed out bump-wise and starts over when the last one goes
+  bool failed = false;
+  static constexpr size_t CAP = 64 * 1024;  // (never freed: a thread's 64 KB, and thread exit may come after the runtime has gone)
+};
+thread_local PinnedArea t_pin;
+}  // namespace
+
+HostRead::HostRead(hipStream_t s) : stream(s) { t_pin.depth++; }
+HostRead::~HostRead() {
+  if (--t_pin.depth == 0) t_pin.used = 0;
+}
+int HostRead::get(void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return TM_OK;
+  static const bool off_env = getenv("TM_NO_PINNED_READBACK") != nullptr;  // A/B aid
+  if (off_env) t_pin.failed = true;
+  if (!t_pin.p && !t_pin.failed) {
+    void *q = nullptr;
+    if (hipHostMalloc(&q, PinnedArea::CAP, hipHostMallocPortable) == hipSuccess) t_pin.p = (uint8_t *)q;
+    else { (void)hipGetLastError(); t_pin.failed = true; }  // no page-locked memory to be had: the plain copy is still correct
+  }
+  const size_t off = (t_pin.used + 15) & ~(size_t)15;
+  if (!t_pin.p || n >= 8 || off + bytes > PinnedArea::CAP) {  // straight to the destination (stream-ordered like the others)
+    TM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    return TM_OK;
+  }
+  TM_HIP(hipMemcpyAsync(t_pin.p + off, src, bytes, hipMemcpyDeviceToHost, stream));
+  t_pin.used = off + bytes;
+  items[n++] = Item{dst, off, bytes};
+  return TM_OK;
+}
+int HostRead::wait() {
+  TM_HIP(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; i++) memcpy(items[i].dst, t_pin.p + items[i].off, items[i].bytes);
+  n = 0;
+  return TM_OK;
+}
 
 // ---- device memory pool (see tm_common.h) --------------------------------------------------------------------------
 namespace {
