@@ -245,7 +245,16 @@ def main():
         # The 128-byte id travels over the process group torch.distributed already has (a Pascal host would use a file or a pipe).
         box = [TilingEncoder.CommUniqueId() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        enc.CommInit(box[0], rank, world)
+        ok = 1
+        try:
+            enc.CommInit(box[0], rank, world)
+        except Exception as ex:  # noqa: BLE001 -- a rank whose communicator does not come up must not leave the others inside theirs
+            ok = 0
+            print("[bench] rank %d: tm_comm_init failed (%s); every rank falls back to the host callback" % (rank, ex), file=sys.stderr)
+        agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0 and ok:
+            enc.CommDestroy()
 
     def barrier():
         torch.cuda.synchronize()
