@@ -219,6 +219,10 @@ TM_API int tm_get_kmeans_iters(tm_encoder *, int *tile_iters, int64_t *tile_poin
 TM_API int tm_stage_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h,
                          void *tiles, void *flags, void *lab_means, void *stream);
 
+/* RGBToLAB (utils.pas:374-410) of n colours 0x00RRGGBB -> float [n][3] (L, a, b): the colour conversion the load and feature kernels
+ * share, as an operator of its own (the whole 24-bit domain is checked against the oracle through it). */
+TM_API int tm_stage_rgb_to_lab(const void *rgb, int64_t n, void *out_lab, void *stream);
+
 /* A4+A5: ConvertToCpnPixels (:3049) + ComputeCpnPixelsPsyVisFeatures (:3103) -> int16 [n][192].
  * mirror_flags may be NULL (no un-mirroring). */
 TM_API int tm_stage_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab,

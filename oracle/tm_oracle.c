@@ -214,6 +214,11 @@ void tmo_lab_domain_check(int64_t *out) {
   }
 }
 
+/* RGBToLAB of n colours 0x00RRGGBB -> out[n][3], det = 1: through the deterministic root (for whole-domain checks of the device's form) */
+void tmo_rgb_to_lab_array(const uint32_t *rgb, int64_t n, int det, float *out) {
+  for (int64_t i = 0; i < n; i++) lab_core((int)((rgb[i] >> 16) & 255), (int)((rgb[i] >> 8) & 255), (int)(rgb[i] & 255), det, &out[i * 3], &out[i * 3 + 1], &out[i * 3 + 2]);
+}
+
 void tmo_rgb_to_lab(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 0, ol, oa, ob); }
 void tmo_rgb_to_lab_det(int r, int g, int b, float *ol, float *oa, float *ob) { lab_core(r, g, b, 1, ol, oa, ob); }
 

@@ -50,6 +50,7 @@ void tmo_rgb_to_lab_det(int r, int g, int b, float *ol, float *oa, float *ob);  
 int32_t tmo_lab_to_rgb(float l, float a, float b);
 void tmo_rgb_to_hsv(uint32_t col, uint8_t *h, uint8_t *s, uint8_t *v);
 double tmo_cbrt_det(double x);
+void tmo_rgb_to_lab_array(const uint32_t *rgb, int64_t n, int det, float *out); /* n colours 0x00RRGGBB -> [n][3] */
 void tmo_rgb_to_lab_fast(int r, int g, int b, float *ol, float *oa, float *ob);  /* the kernels' division-free form of _det */
 void tmo_lab_domain_check(int64_t *out);  /* all 2^24 colours: [0] det != libm pow, [1] fast != det */
 

@@ -47,6 +47,15 @@ class Oracle:
         (self.L.tmo_rgb_to_lab_det if det else self.L.tmo_rgb_to_lab)(r, g, b, ctypes.byref(l), ctypes.byref(a), ctypes.byref(bb))
         return l.value, a.value, bb.value
 
+    def rgb_to_lab_array(self, rgb, det=True):
+        """RGBToLAB of colours 0x00RRGGBB (uint32 [n]) -> float32 [n][3]"""
+        rgb = np.ascontiguousarray(rgb, np.uint32)
+        out = np.empty((rgb.shape[0], 3), np.float32)
+        self.L.tmo_rgb_to_lab_array.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+        self.L.tmo_rgb_to_lab_array.restype = None
+        self.L.tmo_rgb_to_lab_array(rgb.ctypes.data, rgb.shape[0], 1 if det else 0, out.ctypes.data)
+        return out
+
     def rgb_to_yuv(self, r, g, b):
         y, u, v = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
         self.L.tmo_rgb_to_yuv(r, g, b, ctypes.byref(y), ctypes.byref(u), ctypes.byref(v))

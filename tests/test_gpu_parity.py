@@ -444,6 +444,19 @@ def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):
     assert np.array_equal(g_remap.cpu().numpy().astype(np.int64), remap)
 
 
+def test_lab_of_every_colour(oracle):
+    """RGBToLAB (utils.pas:374-410) on the device over the WHOLE domain: all 2^24 colours through tm_stage_rgb_to_lab against the oracle's
+    deterministic form (which tests/test_oracle_pins.py proves equal to the reference's libm power() on the same domain).  The kernels
+    seed their cube root with the hardware's log2 / exp2, which no host restatement can follow bit for bit -- so the proof that only
+    the narrowed Singles matter, and that they are the oracle's, is this exhaustive comparison on the device itself."""
+    from tiler_amd import stages
+    rgb = torch.arange(1 << 24, dtype=torch.int32, device="cuda")
+    got = stages.rgb_to_lab(rgb).cpu().numpy()
+    want = oracle.rgb_to_lab_array(np.arange(1 << 24, dtype=np.uint32), det=True)
+    bad = np.flatnonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))
+    assert bad.size == 0, (bad.size, [hex(int(c)) for c in bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
 @pytest.mark.parametrize("n,d,k", [(500, 3, 16), (40, 3, 64), (300, 192, 8), (1, 3, 4), (2000, 192, 40)])
 def test_kmeans(oracle, n, d, k):
     from tiler_amd import stages

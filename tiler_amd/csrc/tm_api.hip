@@ -24,6 +24,11 @@ int tm_stage_load(const void *frames, int nframes, int img_w, int img_h, int tm_
   return launch_load(frames, nframes, img_w, img_h, tm_w, tm_h, tiles, flags, lab_means, (hipStream_t)stream);
 }
 
+int tm_stage_rgb_to_lab(const void *rgb, int64_t n, void *out_lab, void *stream) {
+  TM_TRY(require_device());
+  return launch_rgb_to_lab(rgb, n, out_lab, (hipStream_t)stream);
+}
+
 int tm_stage_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out_i16,
                           void *stream) {
   return launch_features_rgb(tiles, n, mirror_flags, mode, use_lab, out_i16, (hipStream_t)stream);

@@ -22,17 +22,21 @@ __device__ __forceinline__ void rgb_to_yuv(int r, int g, int b, float &y, float 
 }
 
 // The build's stand-in for power(x, 1/3) at utils.pas:403-405.  The oracle defines it as an integer-seeded Newton root in +,-,*,/
-// (tmo_cbrt_det); this is the same function on RGBToLAB's domain, computed without a division: x^(-1/3) by four Newton steps in multiplications and fma, the root as x a a with one
-// multiplicative correction.  oracle/tm_oracle.c restates this form (tmo_rgb_to_lab_fast) and proves it equal to the oracle's
-// deterministic root -- and to libm pow, the reference's power() (utils.pas:403) -- after narrowing to Single on every one of the
-// 2^24 colours (tests/test_oracle_pins.py), so RGBToLAB keeps its values; the 21 double divisions per pixel it replaces were 90 %
-// of k_load_tiles.
-__device__ __forceinline__ double cbrt_det(double x) {
-  unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  u = 0x553EF0FF289DD796ull - u / 3ull;
-  double a = __longlong_as_double((long long)u);
+// (tmo_cbrt_det) and proves that root equal to libm pow -- the reference's power() -- after narrowing to Single on every one of the 2^24
+// colours (tests/test_oracle_pins.py).  Only that Single leaves RGBToLAB, so any double within a few units in the last place of the true
+// root serves, as long as it narrows the same way on the whole domain.  Here: x^(-1/3) seeded by the hardware's log2 / exp2 (v_log_f32,
+// v_exp_f32: about 3e-7 off), one Newton step in multiplications and fma (2e-13), the root as x a a with one multiplicative correction
+// (the rounding of the last operations).  No division, no integer seed arithmetic: 12 double operations where the four-step form from
+// the exponent seed took 27 (they were 70 % of k_load_tiles' instructions).  Equality with the oracle on the whole domain is checked ON
+// THE DEVICE: tests/test_gpu_parity.py::test_lab_of_every_colour runs all 2^24 colours through tm_stage_rgb_to_lab.
+#ifndef TM_CBRT_NEWTON
+#define TM_CBRT_NEWTON 1
+#endif
+__device__ __forceinline__ double cbrt_det(float xf) {
+  const double x = (double)xf;
+  double a = (double)__builtin_amdgcn_exp2f(__fmul_rn(__builtin_amdgcn_logf(xf), -1.0f / 3));
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < TM_CBRT_NEWTON; i++) {
     const double e = __fma_rn(-x, __dmul_rn(__dmul_rn(a, a), a), 1.0);
     a = __fma_rn(__dmul_rn(a, e), 1.0 / 3, a);
   }
@@ -48,7 +52,7 @@ __device__ __forceinline__ double div_xyz(double n) {
 }
 
 __device__ __forceinline__ float lab_f(float t) {
-  if ((double)t > 0.008856) return (float)cbrt_det((double)t);
+  if ((double)t > 0.008856) return (float)cbrt_det(t);
   return (float)__dadd_rn(__dmul_rn(7.787, (double)t), 16.0 / 116);
 }
 

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
   const int64_t total = tiles_per_frame * nframes;
   const int64_t nbatch = (total + 4 * LT_BATCH - 1) / (4 * LT_BATCH);
   float *lab = s_lab[wave];  // a wave only touches its own part: no workgroup barrier
+  const int py = lane >> 3, pxl = lane & 7;
+  const unsigned lane_off = (unsigned)(py * img_w + pxl);
   for (int64_t it = blockIdx.x; it < nbatch; it += gridDim.x) {
     const int64_t base = (it * 4 + wave) * LT_BATCH;
     // frame, tile row and tile column of the batch's first tile by division, of the others by stepping
@@ -40,27 +42,32 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
       const int64_t t = base + j;
       if (t >= total) break;
       if (sx == tm_w) { sx = 0; if (++sy == tm_h) { sy = 0; f++; } }
-      const int y = lane >> 3, x = lane & 7;
-      const int jj = sy * 8 + y, ii = sx * 8 + x;
+      // the tile's first pixel on the scalar unit, the lane's pixel as a 32-bit offset from it (a 64-bit index per lane was a dozen vector instructions)
+      const uint32_t *fp = frames + ((f * img_h + (int64_t)sy * 8) * (int64_t)img_w + (int64_t)sx * 8);
       uint32_t px = 0;
-      if (jj < img_h && ii < img_w) px = swap_rb(frames[(f * img_h + jj) * (int64_t)img_w + ii]);
+      if (sy * 8 + py < img_h && sx * 8 + pxl < img_w) px = swap_rb(fp[lane_off]);
       float l, a, b;
       rgb_to_lab_det(px & 0xff, (px >> 8) & 0xff, (px >> 16) & 0xff, srgb_lut, l, a, b);
-      lab[j * LT_TILE + lane] = l;
-      lab[j * LT_TILE + LT_PLANE + lane] = a;
-      lab[j * LT_TILE + 2 * LT_PLANE + lane] = b;
-      // quadrant luma sums (GetTileZoneSum, 4842-4863): integer, order free -> sums of 4 pixels by DPP, the 16 of them through SGPRs
+      float *lt = lab + j * LT_TILE + lane;
+      lt[0] = l;
+      lt[LT_PLANE] = a;
+      lt[2 * LT_PLANE] = b;
+      // quadrant luma sums (GetTileZoneSum, 4842-4863): integer, order free.  Sums of 4 pixels by quad permutes; lanes 4g..4g+3 then hold
+      // group g = (pixel row g / 2, half g & 1).  A row of 16 lanes holds groups 4r..4r+3: row_shr:8 leaves (4r) + (4r+2) in its lanes 8..11
+      // and (4r+1) + (4r+3) in lanes 12..15 -- the left and right halves of pixel rows 2r and 2r+1 --, and the scalar unit adds two rows each
       int luma = (int)(px & 0xff) * 299 + (int)((px >> 8) & 0xff) * 587 + (int)((px >> 16) & 0xff) * 114;
-      luma += __builtin_amdgcn_update_dpp(0, luma, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
-      luma += __builtin_amdgcn_update_dpp(0, luma, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
-      int q[2][2] = {{0, 0}, {0, 0}};  // [bottom][right]
-#pragma unroll
-      for (int g = 0; g < 16; g++) q[g >> 3][g & 1] += __builtin_amdgcn_readlane(luma, g * 4);  // lanes 4g..4g+3: row g / 2, half g & 1
-      const bool hm = q[0][0] + q[1][0] < q[0][1] + q[1][1];  // q00+q10 < q01+q11
-      const bool vm = q[0][0] + q[0][1] < q[1][0] + q[1][1];  // q00+q01 < q10+q11
-      const int src = ((vm ? 7 - y : y) << 3) | (hm ? 7 - x : x);
+      luma += __builtin_amdgcn_update_dpp(0, luma, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      luma += __builtin_amdgcn_update_dpp(0, luma, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+      luma += __builtin_amdgcn_update_dpp(0, luma, 0x118, 0xf, 0xf, true);   // row_shr:8 (lanes 0..7 of a row add nothing)
+      const int q00 = __builtin_amdgcn_readlane(luma, 8) + __builtin_amdgcn_readlane(luma, 24);    // [bottom][right]
+      const int q01 = __builtin_amdgcn_readlane(luma, 12) + __builtin_amdgcn_readlane(luma, 28);
+      const int q10 = __builtin_amdgcn_readlane(luma, 40) + __builtin_amdgcn_readlane(luma, 56);
+      const int q11 = __builtin_amdgcn_readlane(luma, 44) + __builtin_amdgcn_readlane(luma, 60);
+      const bool hm = q00 + q10 < q01 + q11;
+      const bool vm = q00 + q01 < q10 + q11;
+      const int src = ((vm ? 7 - py : py) << 3) | (hm ? 7 - pxl : pxl);
       const uint32_t canon = __shfl(px, src);
-      tiles[t * 64 + lane] = canon;
+      (tiles + t * 64)[lane] = canon;
       if (lane == 0) flags[t] = (uint8_t)((hm ? 1 : 0) | (vm ? 2 : 0));
     }
     // Result[di+c] += lab, 64 Singles in raster order, then *= 1/64 (1349-1362): one lane per (tile, plane)
@@ -341,6 +348,25 @@ static int grid_for(int64_t work_items, int per_block) {
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+// RGBToLAB (utils.pas:374-410) of n colours 0x00RRGGBB -> [n][3] Singles: the colour math of the load and feature kernels on its own
+__global__ void k_rgb_to_lab(const uint32_t *__restrict__ rgb, int64_t n, const float *__restrict__ srgb_lut, float *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = rgb[i];
+    float l, a, b;
+    rgb_to_lab_det((c >> 16) & 0xff, (c >> 8) & 0xff, c & 0xff, srgb_lut, l, a, b);
+    out[i * 3] = l; out[i * 3 + 1] = a; out[i * 3 + 2] = b;
+  }
+}
+int launch_rgb_to_lab(const void *rgb, int64_t n, void *out, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(n >= 0 && (n == 0 || (rgb && out)), TM_E_INVAL, "tm_stage_rgb_to_lab: bad arguments");
+  if (n == 0) return TM_OK;
+  hipLaunchKernelGGL(k_rgb_to_lab, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, stream, (const uint32_t *)rgb, n, tab->srgb_lut, (float *)out);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
 }
 
 int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,

@@ -11,6 +11,7 @@ namespace tmx {
 // tm_features.hip
 int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
                 void *lab_means, hipStream_t stream);
+int launch_rgb_to_lab(const void *rgb, int64_t n, void *out, hipStream_t stream);
 int launch_pearson(const void *lab, int nframes, int per, void *correl, hipStream_t stream);
 int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out, hipStream_t stream);
 // colmm (optional): [384] ints on the device, mn[192] preset to INT_MAX and mx[192] to INT_MIN: the kernel folds the output columns' ranges in

@@ -30,6 +30,14 @@ def load(frames, tm_w, tm_h):
     return tiles, flags, lab
 
 
+def rgb_to_lab(rgb):
+    """RGBToLAB (utils.pas:374-410) of colours 0x00RRGGBB (int32 [n]) -> float32 [n][3]"""
+    assert rgb.is_cuda and rgb.dtype == torch.int32 and rgb.is_contiguous()
+    out = torch.empty((rgb.shape[0], 3), dtype=torch.float32, device=rgb.device)
+    check(lib().tm_stage_rgb_to_lab(_p(rgb), rgb.shape[0], _p(out), _stream()))
+    return out
+
+
 def features_rgb(tiles, mirror_flags=None, mode=1, use_lab=False):
     """ConvertToCpnPixels + ComputeCpnPixelsPsyVisFeatures (tilingencoder.pas:3049-3131) -> int16 [n][192]"""
     assert tiles.is_cuda and tiles.dtype == torch.int32 and tiles.is_contiguous()
