@@ -15,7 +15,10 @@ namespace tmx {
 // planes -- each sum is 64 Single additions in raster order (1349-1362), a dependent chain that would hold a whole wave per tile.
 // LoadFromImage (tilingencoder.pas:1293-1320) -> PrepareInterFrameData (1329-1367) -> mirror heuristics
 // (4865-4878) + H/V flip (1393-1411).
-constexpr int LT_BATCH = 16, LT_TILE = 195, LT_PLANE = 65;  // strides in floats: lane (tile, plane) of the summing phase reads bank 3 * tile + plane
+#ifndef TM_LT_BATCH
+#define TM_LT_BATCH 8  // tiles a wave converts before 3 x that many of its lanes add up the Lab planes (LDS: 780 bytes per tile and wave; measured: 4-6 1.80-1.85 ms, 8 1.78, 12 1.93, 16 2.19, 20 2.65 -- the waves a CU holds matter more than the lanes the sums use)
+#endif
+constexpr int LT_BATCH = TM_LT_BATCH, LT_TILE = 195, LT_PLANE = 65;  // strides in floats: lane (tile, plane) of the summing phase reads bank 3 * tile + plane
 __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__ frames, int nframes, int img_w, int img_h,
                                                     int tm_w, int tm_h, const float *__restrict__ srgb_lut,
                                                     uint32_t *__restrict__ tiles, uint8_t *__restrict__ flags,
