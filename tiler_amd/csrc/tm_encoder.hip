@@ -449,7 +449,8 @@ static int queue_host_clip(tm_encoder *e, int slot, const void *host) {
   const size_t fbytes = (size_t)e->width * e->height * 4;
   TM_TRY(hc.buf.alloc(fbytes * e->nframes));
   if (!e->copy_stream) TM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  hc.chunk = (int)std::max<size_t>(1, ((size_t)48 << 20) / fbytes);
+  static const size_t chunk_mb = getenv("TM_H2D_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("TM_H2D_CHUNK_MB"))) : 48;  // (A/B aid)
+  hc.chunk = (int)std::max<size_t>(1, (chunk_mb << 20) / fbytes);
   hc.nchunks = (e->nframes + hc.chunk - 1) / hc.chunk;
   while ((int)hc.events.size() < hc.nchunks) {
     hipEvent_t ev;
@@ -498,7 +499,16 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
       TM_TRY(queue_host_clip(e, slot, e->frames_host));
     }
     tm_encoder::HostClip &hc = e->hclip[slot];
-    for (int c = 0; c < hc.nchunks; c++) {
+    // chunks that have already arrived (a prefetched clip: all of them, as a rule) go through ONE launch; the rest follow chunk by chunk
+    int arrived = 0;
+    while (arrived < hc.nchunks && hipEventQuery(hc.events[arrived]) == hipSuccess) arrived++;
+    (void)hipGetLastError();  // (hipErrorNotReady of the first chunk still in flight is not an error)
+    if (arrived > 0) {
+      const int nf = std::min(arrived * hc.chunk, e->nframes);
+      TM_HIP(hipStreamWaitEvent(e->stream, hc.events[arrived - 1], 0));
+      TM_TRY(launch_load(hc.buf.p, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.p, e->fflags.p, e->flab.p, e->stream));
+    }
+    for (int c = arrived; c < hc.nchunks; c++) {
       const int f0 = c * hc.chunk, nf = std::min(hc.chunk, e->nframes - f0);
       TM_HIP(hipStreamWaitEvent(e->stream, hc.events[c], 0));
       TM_TRY(launch_load(hc.buf.as<uint8_t>() + fbytes * f0, nf, e->width, e->height, e->tm_w, e->tm_h, e->ftiles.as<uint8_t>() + (int64_t)f0 * per * 256,
