@@ -2020,6 +2020,8 @@ int run_kmeans_seeded(const void *pts, const void *weights, int64_t n, int d, in
 // r = floor(x_t * total / 2^64) over the exact integer masses q_i = weight_i * (squared distance of point i to its nearest centre so
 // far) (q_i = weight_i for the first pick) in 128-bit sums, and takes the first point whose running sum exceeds r; a total of 0 (no
 // point apart from the centres) ends the seeding.  The oracle states the same rule (tmo_kmeans_pp_seeds).
+// (Measured in round 3 and dropped: skipping the rows the triangle inequality rules out -- D(own centre, new centre)^2 >= 4 md, exact in
+// integers -- took 0.07 ms off the sixteen passes: the pass is not bound by the rows' bytes.)
 // Per pick: k_pp_mass (distances to the newest centre folded into the running minimum, masses, one 128-bit sum per 512 points) and
 // k_pp_pick (the block holding r, then the point inside it).
 typedef unsigned __int128 u128;
@@ -2087,14 +2089,53 @@ __global__ __launch_bounds__(PP_NT) void k_pp_mass(const int32_t *__restrict__ p
     bsum[blockIdx.x] = PpSum{(u64)t, (u64)(t >> 64)};
   }
 }
+// inclusive prefix (128-bit) of one value per thread over a workgroup of 256, in thread order: shuffles inside the waves, the four wave
+// totals through LDS; *total = the sum of all.  Every thread of the workgroup calls it.
+__device__ __forceinline__ u128 pp_scan256(u128 v, PpSum *s_w, u128 *total) {
+  u64 lo = (u64)v, hi = (u64)(v >> 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u64 olo = __shfl_up(lo, o), ohi = __shfl_up(hi, o);
+    if (lane >= o) {
+      const u128 s = (((u128)hi << 64) | lo) + (((u128)ohi << 64) | olo);
+      lo = (u64)s; hi = (u64)(s >> 64);
+    }
+  }
+  if (lane == 63) s_w[wave] = PpSum{lo, hi};
+  __syncthreads();
+  u128 before = 0, tot = 0;
+#pragma unroll
+  for (int wv = 0; wv < 4; wv++) {
+    const u128 t = ((u128)s_w[wv].hi << 64) | s_w[wv].lo;
+    if (wv < wave) before += t;
+    tot += t;
+  }
+  *total = tot;
+  __syncthreads();  // (s_w may be written again)
+  return before + (((u128)hi << 64) | lo);
+}
+// the first thread (in thread order) whose flag is set, 256 if none: a ballot per wave, the four answers through LDS
+__device__ __forceinline__ int pp_first256(bool flag, int *s_f) {
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(flag);
+  if ((threadIdx.x & 63) == 0) s_f[threadIdx.x >> 6] = b ? (int)(threadIdx.x & ~63u) + __builtin_ctzll(b) : 256;
+  __syncthreads();
+  const int f = min(min(s_f[0], s_f[1]), min(s_f[2], s_f[3]));
+  __syncthreads();
+  return f;
+}
+
 // One workgroup.  mode 0: the whole pick (single process): total, draw, block, point -> st->pick, cur_row, cent, seeds.
 // mode 1 (several processes): only this process's total -> st->tot_*.  mode 2: the draw against the totals of all processes (rank
 // order = global point order); the owner of r finds the point, everybody else reports no candidate.
+// "The first point whose running sum exceeds r" is found with prefix sums over the workgroup instead of one thread walking 2 x 256
+// partial sums (24 -> 9 us per pick: sixteen picks wait for it one after the other).
 __global__ __launch_bounds__(256) void k_pp_pick(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, const long long *__restrict__ mind,
                                                  const PpSum *__restrict__ bsum, int nb, int first, int k, PpState *__restrict__ st, int mode,
                                                  const PpSum *__restrict__ totals, int rank, int world, long long global_begin,
                                                  int32_t *__restrict__ cur_row, double *__restrict__ cent, long long *__restrict__ seeds, FfCandOut cand) {
-  __shared__ PpSum s_q[PP_BLOCK / 256][256], s_part[256];
+  __shared__ PpSum s_w[4];
+  __shared__ int s_f[4];
   __shared__ long long s_pick;
   __shared__ u64 s_r[2];
   const int tid = threadIdx.x;
@@ -2102,18 +2143,14 @@ __global__ __launch_bounds__(256) void k_pp_pick(const int32_t *__restrict__ pts
     if (mode == 2 && cand.dist && tid == 0) { *cand.dist = -1; *cand.gidx = 0x7fffffffffffffffll; }
     return;
   }
-  // the blocks' sums: thread t adds its share (consecutive blocks), thread 0 walks the 256 partial sums
+  // the blocks' sums: thread t adds its share (consecutive blocks); their prefix over the workgroup
   const int per = (nb + 255) / 256;
-  {
-    u128 part = 0;
-    for (int b = tid * per; b < min(nb, (tid + 1) * per); b++) part += ((u128)bsum[b].hi << 64) | bsum[b].lo;
-    s_q[0][tid] = PpSum{(u64)part, (u64)(part >> 64)};
-  }
-  __syncthreads();
+  u128 part = 0;
+  for (int b = tid * per; b < min(nb, (tid + 1) * per); b++) part += ((u128)bsum[b].hi << 64) | bsum[b].lo;
+  u128 local = 0;
+  const u128 incl = pp_scan256(part, s_w, &local);
   if (tid == 0) {
-    s_pick = -1;
-    u128 local = 0;
-    for (int t = 0; t < 256; t++) local += ((u128)s_q[0][t].hi << 64) | s_q[0][t].lo;
+    s_pick = -1;  // -1: the point is another process's, -2: nothing left to pick, -3: ours
     if (mode == 1) { st->tot_lo = (u64)local; st->tot_hi = (u64)(local >> 64); }
     else {
       u128 total = local, before = 0;
@@ -2130,67 +2167,65 @@ __global__ __launch_bounds__(256) void k_pp_pick(const int32_t *__restrict__ pts
         const u64 x = st->rng * PP_MUL + PP_INC;
         st->rng = x;
         const u128 r = pp_draw(x, total);
-        if (r >= before && r < before + local) {  // the point is one of ours: which share of blocks, which block
-          u128 run = before;
-          int t = 0;
-          for (; t < 255; t++) {
-            const u128 v = ((u128)s_q[0][t].hi << 64) | s_q[0][t].lo;
-            if (run + v > r) break;
-            run += v;
-          }
-          int b = t * per;
-          for (; b < nb - 1; b++) {
-            const u128 v = ((u128)bsum[b].hi << 64) | bsum[b].lo;
-            if (run + v > r) break;
-            run += v;
-          }
-          s_pick = b;  // block index for now
-          const u128 rest = r - run;
-          s_r[0] = (u64)rest; s_r[1] = (u64)(rest >> 64);
+        if (r >= before && r < before + local) {  // the point is one of ours
+          const u128 rl = r - before;
+          s_r[0] = (u64)rl; s_r[1] = (u64)(rl >> 64);
+          s_pick = -3;
         }
       }
     }
   }
   __syncthreads();
   if (mode == 1) return;
-  const long long blk = s_pick;
+  long long blk = s_pick;
   if (blk == -2) {
     if (mode == 2 && cand.dist && tid == 0) { *cand.dist = -1; *cand.gidx = 0x7fffffffffffffffll; }
     return;
   }
-  if (blk >= 0) {  // masses of the block's points in index order; thread t sums PP_BLOCK / 256 of them, thread 0 walks the 256 sums, then those few masses
-    for (int m = 0; m < PP_BLOCK / 256; m++) {
-      const int64_t i = blk * PP_BLOCK + m * 256 + tid;
-      const u128 q = i < n ? pp_mass(w, mind, i, first) : (u128)0;
-      s_q[m][tid] = PpSum{(u64)q, (u64)(q >> 64)};
-    }
-    __syncthreads();
-    {  // thread t: the sum of its PP_BLOCK / 256 consecutive entries (index order), into s_part
-      u128 part = 0;
-      for (int e = tid * (PP_BLOCK / 256); e < (tid + 1) * (PP_BLOCK / 256); e++) part += ((u128)s_q[e >> 8][e & 255].hi << 64) | s_q[e >> 8][e & 255].lo;
-      s_part[tid] = PpSum{(u64)part, (u64)(part >> 64)};
-    }
-    __syncthreads();
-    if (tid == 0) {
-      const u128 rest = ((u128)s_r[1] << 64) | s_r[0];
-      u128 run = 0;
-      int t = 0;
-      for (; t < 255; t++) {
-        const u128 v = ((u128)s_part[t].hi << 64) | s_part[t].lo;
-        if (run + v > rest) break;
+  if (blk == -3) {  // (uniform) which thread's share of blocks, which block of it, which point of the block
+    const u128 rl = ((u128)s_r[1] << 64) | s_r[0];
+    const int ts = pp_first256(incl > rl, s_f);  // rl < local: there is one
+    if (tid == ts) {
+      u128 run = incl - part;
+      int b = tid * per;
+      for (; b < min(nb, (tid + 1) * per) - 1; b++) {
+        const u128 v = ((u128)bsum[b].hi << 64) | bsum[b].lo;
+        if (run + v > rl) break;
         run += v;
       }
+      s_pick = b;
+      const u128 rest = rl - run;
+      s_r[0] = (u64)rest; s_r[1] = (u64)(rest >> 64);
+    }
+    __syncthreads();
+    blk = s_pick;
+    const u128 rest = ((u128)s_r[1] << 64) | s_r[0];
+    // masses of the block's points in index order: thread t holds PP_BLOCK / 256 consecutive ones
+    constexpr int E = PP_BLOCK / 256;
+    u128 q[E], qs = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int64_t i = blk * PP_BLOCK + tid * E + e;
+      q[e] = i < n ? pp_mass(w, mind, i, first) : (u128)0;
+      qs += q[e];
+    }
+    u128 unused;
+    const u128 qincl = pp_scan256(qs, s_w, &unused);
+    const int tq = pp_first256(qincl > rest, s_f);
+    if (tid == tq) {
+      u128 run = qincl - qs;
       long long pick = -1;
-      for (int e = t * (PP_BLOCK / 256); e < PP_BLOCK && pick < 0; e++) {
-        const PpSum q = s_q[e >> 8][e & 255];
-        run += ((u128)q.hi << 64) | q.lo;
-        if (run > rest) pick = blk * PP_BLOCK + e;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        run += q[e];
+        if (pick < 0 && run > rest) pick = blk * PP_BLOCK + tid * E + e;
       }
       s_pick = pick;
     }
+    if (tq >= 256 && tid == 0) s_pick = -1;  // (cannot happen: rest < the block's sum)
     __syncthreads();
   }
-  const long long pick = blk >= 0 ? s_pick : -1;
+  const long long pick = blk >= 0 ? s_pick : -1;  // (blk = -1: another process's)
   if (mode == 0) {
     if (pick >= 0) {
       const int kk = st->kk;
