@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
                                                               const double *__restrict__ lut, const double *__restrict__ weights,
                                                               const uint8_t *__restrict__ snake, const float *__restrict__ srgb_lut,
                                                               int32_t *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float s_cpn[2][4][192];
+  // the planes as DOUBLES: every lane multiplies the same 192 plane values by its own LUT row, so they are widened once, by the lane that
+  // made them, instead of 192 times in every lane (v_cvt_f64_f32 runs at half rate: 204 of them were a third of the kernel)
+  __shared__ __attribute__((aligned(16))) double s_cpn[2][4][192];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double l[64];
 #pragma unroll
@@ -226,23 +228,21 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
       const uint32_t col = tiles[t * 64 + lane];
       float yy, uu, vv;
       rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
-      s_cpn[buf][wave][lane] = yy;
-      s_cpn[buf][wave][64 + lane] = uu;
-      s_cpn[buf][wave][128 + lane] = vv;
+      s_cpn[buf][wave][lane] = (double)yy;
+      s_cpn[buf][wave][64 + lane] = (double)uu;
+      s_cpn[buf][wave][128 + lane] = (double)vv;
     }
     __syncthreads();
     if (valid) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const float *cp = &s_cpn[buf][wave][c * 64];
+        const double *cp = &s_cpn[buf][wave][c * 64];
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) {
-          const float4 cv = *reinterpret_cast<const float4 *>(cp + k);
-          r = __dadd_rn(r, __dmul_rn((double)cv.x, l[k]));
-          r = __dadd_rn(r, __dmul_rn((double)cv.y, l[k + 1]));
-          r = __dadd_rn(r, __dmul_rn((double)cv.z, l[k + 2]));
-          r = __dadd_rn(r, __dmul_rn((double)cv.w, l[k + 3]));
+        for (int k = 0; k < 64; k += 2) {
+          const double2 cv = *reinterpret_cast<const double2 *>(cp + k);
+          r = __dadd_rn(r, __dmul_rn(cv.x, l[k]));
+          r = __dadd_rn(r, __dmul_rn(cv.y, l[k + 1]));
         }
         if (weighted) r = __dmul_rn(r, w[c]);
         out[t * 192 + c * 64 + zz] = (int32_t)__double2ll_rn(r);
