@@ -1315,6 +1315,9 @@ __global__ void k_h_iter_setup(const u64 *__restrict__ sums, const u64 *__restri
 #ifndef TM_KM3_PPT
 #define TM_KM3_PPT 16
 #endif
+#ifndef TM_KM3_PU
+#define TM_KM3_PU 4  // points of a thread whose bounds are tested together (the dependent LDS round trips of a batch overlap)
+#endif
 constexpr int P3_PPT = TM_KM3_PPT, P3_NT = TM_KM3_NT, P3_ROWS = P3_PPT * P3_NT, P3_MAXK = 64, P3_NCOPY = 4;
 // workgroups a CU is asked to hold (LDS: ten bytes a point + 12 KB).  Measured (round 3): 1024 x 12 and 512 x 20 / 24 points per workgroup, one
 // per CU and a third as many participants at a palette's barrier, take 13.8-13.9 / 14.3 / 14.9 ms for PreparePalettes against 13.7 with 256 x 16
@@ -1471,58 +1474,63 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
     const int mv1 = s_move[P3_MAXK], mv2 = s_move[P3_MAXK + 1], amax = s_move[P3_MAXK + 2];
     int nlist = 0;  // uniform in the wave
     uint16_t *const mylist = s_list[wave];
-    constexpr int PU = 4;  // passes in flight: their LDS round trips overlap
+    // Pass A, every point: the bounds loosened by the centroids' displacements; the points whose bounds no longer prove their assignment (and
+    // the ones not assigned yet) go on the wave's list.  Pass B, the listed points only, 64 at a time: the real distance to the own centroid
+    // as the new ub; what still fails stays on the list (compacted in place, order kept) and is scored.  One in seven points is listed, one
+    // in fifteen scored: with the recheck inside pass A every wave ran its double-precision arithmetic for all of its points, because some
+    // lane of every batch needed it.
+    int ntight = 0;
+    constexpr int PU = TM_KM3_PU;  // points of a thread in flight: their LDS round trips overlap
 #pragma unroll 1
     for (int m0 = 0; m0 < P3_PPT; m0 += PU) {
-      uint32_t cc[PU];
-      int a[PU], u[PU], l[PU], thr[PU];
-      bool full[PU], tight[PU];
+      uint32_t cc[PU], bn[PU];
 #pragma unroll
       for (int i = 0; i < PU; i++) {
         const int r = (m0 + i) * P3_NT + tid;
         cc[i] = s_col[r];
-        const uint32_t bn = s_u.bnd[r];
-        a[i] = (int)(cc[i] >> 24);
-        u[i] = (int)(bn & 0xffffu);
-        l[i] = (int)(bn >> 16);
-      }
-      bool any_tight = false;
-#pragma unroll
-      for (int i = 0; i < PU; i++) {
-        full[i] = a[i] == 0xff;  // not assigned yet: scored
-        tight[i] = false;
-        if (a[i] < 0xfe) {
-          u[i] = min(65535, u[i] + s_move[a[i]]);
-          l[i] = max(0, l[i] - (a[i] == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
-          thr[i] = max(l[i], s_half[a[i]]);
-          tight[i] = u[i] > thr[i];
-          full[i] = false;
-          any_tight |= tight[i];
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(any_tight)) {
-#pragma unroll
-        for (int i = 0; i < PU; i++)
-          if (tight[i]) {
-            // the distance to the own centroid, in the scoring's arithmetic, as the new ub (single-precision root, as in the scoring)
-            const double t0 = __dsub_rn((double)(int)(cc[i] & 0xff), s_cent[a[i]][0]), t1 = __dsub_rn((double)(int)((cc[i] >> 8) & 0xff), s_cent[a[i]][1]),
-                         t2 = __dsub_rn((double)(int)((cc[i] >> 16) & 0xff), s_cent[a[i]][2]);
-            const double sd = __fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0)));
-            u[i] = min(65535, (int)(__fsqrt_rn((float)sd) * (float)P3_UNIT) + 2);
-            full[i] = u[i] > thr[i];
-          }
+        bn[i] = s_u.bnd[r];
       }
 #pragma unroll
       for (int i = 0; i < PU; i++) {
         const int r = (m0 + i) * P3_NT + tid;
-        if (a[i] < 0xfe) s_u.bnd[r] = (uint32_t)u[i] | ((uint32_t)l[i] << 16);
-        const unsigned long long fb = __builtin_amdgcn_ballot_w64(full[i]);
-        if (full[i]) mylist[nlist + __popcll(fb & ((1ull << lane) - 1ull))] = (uint16_t)r;
-        nlist += __popcll(fb);
+        const int a = (int)(cc[i] >> 24);
+        bool listed = a == 0xff;  // not assigned yet: scored
+        if (a < 0xfe) {
+          const int u = min(65535, (int)(bn[i] & 0xffffu) + s_move[a]);
+          const int l = max(0, (int)(bn[i] >> 16) - (a == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+          s_u.bnd[r] = (uint32_t)u | ((uint32_t)l << 16);
+          listed = u > max(l, s_half[a]);
+        }
+        const unsigned long long tb = __builtin_amdgcn_ballot_w64(listed);
+        if (listed) mylist[ntight + __popcll(tb & ((1ull << lane) - 1ull))] = (uint16_t)r;
+        ntight += __popcll(tb);
 #if TM_KM3_STAMPS
-        if (bx == 0 && lane == 0) atomicAdd(&st->stamps[7], (u64)__popcll(fb));
+        if (bx == 0 && lane == 0) atomicAdd(&st->stamps[7], (u64)__popcll(tb) << 32);
 #endif
       }
+    }
+#pragma unroll 1
+    for (int e0 = 0; e0 < ntight; e0 += 64) {
+      const bool valid = e0 + lane < ntight;
+      const int r = valid ? (int)mylist[e0 + lane] : tid;
+      const uint32_t cc = s_col[r], bn = s_u.bnd[r];
+      const int a = (int)(cc >> 24);
+      bool full = valid;
+      if (valid && a < 0xfe) {
+        // the distance to the own centroid, in the scoring's arithmetic, as the new ub (single-precision root, as in the scoring)
+        const double t0 = __dsub_rn((double)(int)(cc & 0xff), s_cent[a][0]), t1 = __dsub_rn((double)(int)((cc >> 8) & 0xff), s_cent[a][1]),
+                     t2 = __dsub_rn((double)(int)((cc >> 16) & 0xff), s_cent[a][2]);
+        const double sd = __fma_rn(t2, t2, __fma_rn(t1, t1, __fma_rn(t0, t0, 0.0)));
+        const int u = min(65535, (int)(__fsqrt_rn((float)sd) * (float)P3_UNIT) + 2), l = (int)(bn >> 16);
+        s_u.bnd[r] = (uint32_t)u | ((uint32_t)l << 16);
+        full = u > max(l, s_half[a]);
+      }
+      const unsigned long long fb = __builtin_amdgcn_ballot_w64(full);
+      if (full) mylist[nlist + __popcll(fb & ((1ull << lane) - 1ull))] = (uint16_t)r;  // (nlist <= e0: never over an entry still to be read)
+      nlist += __popcll(fb);
+#if TM_KM3_STAMPS
+      if (bx == 0 && lane == 0) atomicAdd(&st->stamps[7], (u64)__popcll(fb));
+#endif
     }
     P3_STAMP(1);  // bounds of the 16 passes
     int changed = 0;
