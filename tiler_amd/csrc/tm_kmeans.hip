@@ -1383,6 +1383,7 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
   __shared__ double s_cent[P3_MAXK][3];
   __shared__ double s_dsq[P3_MAXK][3];  // squared displacement of each centroid coordinate in the last update
   __shared__ int s_half[P3_MAXK];      // half the distance to the nearest other centroid, rounded down (P3_UNIT)
+  __shared__ int2 s_mh[P3_MAXK];       // (s_move, s_half) of a centroid side by side: the pass over all points fetches both with one read
   __shared__ int s_move[P3_MAXK + 3];  // displacement of each centroid in the last update, rounded up; then the largest, the second largest, whose
   __shared__ uint32_t s_col[P3_ROWS];   // colour | assignment << 24 (0xff: none yet, 0xfe: slot past the end of the segment)
   // farthest-first distances, then the points' bounds: ub >= the distance to the own centroid, lb <= the distance to every other one
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
   u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
   const int wave = tid >> 6, lane = tid & 63;
-  if (tid < P3_MAXK) { s_move[tid] = 0; s_half[tid] = 0; }
+  if (tid < P3_MAXK) { s_move[tid] = 0; s_half[tid] = 0; s_mh[tid] = make_int2(0, 0); }
   if (tid < 3) s_move[P3_MAXK + tid] = 0;
   for (;;) {
     __syncthreads();  // s_cent, s_move, s_half of this iteration are in place; the farthest-first pass is done with the union; the previous flush with s_acc
@@ -1496,10 +1497,11 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
         const int a = (int)(cc[i] >> 24);
         bool listed = a == 0xff;  // not assigned yet: scored
         if (a < 0xfe) {
-          const int u = min(65535, (int)(bn[i] & 0xffffu) + s_move[a]);
+          const int2 mh = s_mh[a];
+          const int u = min(65535, (int)(bn[i] & 0xffffu) + mh.x);
           const int l = max(0, (int)(bn[i] >> 16) - (a == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
           s_u.bnd[r] = (uint32_t)u | ((uint32_t)l << 16);
-          listed = u > max(l, s_half[a]);
+          listed = u > max(l, mh.y);
         }
         const unsigned long long tb = __builtin_amdgcn_ballot_w64(listed);
         if (listed) mylist[ntight + __popcll(tb & ((1ull << lane) - 1ull))] = (uint16_t)r;
@@ -1633,24 +1635,30 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
     // not move costs nothing), and half its distance to the nearest other one, rounded down
     if (tid < kk) {
       const double m2 = s_dsq[tid][0] + s_dsq[tid][1] + s_dsq[tid][2];
-      s_move[tid] = m2 == 0.0 ? 0 : (int)(sqrt(m2) * (double)P3_UNIT) + 2;
+      s_move[tid] = m2 == 0.0 ? 0 : (int)(__fsqrt_rn((float)m2) * (float)P3_UNIT) + 2;
     }
     for (int pr = tid; pr < kk * kk; pr += P3_NT) {
       const int ca = pr / kk, cb2 = pr - ca * kk;
       if (ca >= cb2) continue;
       const double t0 = s_cent[ca][0] - s_cent[cb2][0], t1 = s_cent[ca][1] - s_cent[cb2][1], t2 = s_cent[ca][2] - s_cent[cb2][2];
-      const int h = max(0, (int)(0.5 * sqrt(t0 * t0 + t1 * t1 + t2 * t2) * (double)P3_UNIT) - 1);
+      // (single-precision root, as everywhere the bounds are made: its error, 0.006 units at most, is far inside the whole unit of margin;
+      // the double-precision one is a few dozen instructions on every iteration's critical path)
+      const int h = max(0, (int)(0.5f * __fsqrt_rn((float)(t0 * t0 + t1 * t1 + t2 * t2)) * (float)P3_UNIT) - 1);
       atomicMin(&s_half[ca], h);
       atomicMin(&s_half[cb2], h);
     }
     __syncthreads();
-    if (tid == 0) {
-      int m1 = 0, m2 = 0, am = 0;
-      for (int c = 0; c < kk; c++) {
-        const int v = s_move[c];
-        if (v > m1) { m2 = m1; m1 = v; am = c; } else if (v > m2) m2 = v;
-      }
-      s_move[P3_MAXK] = m1; s_move[P3_MAXK + 1] = m2; s_move[P3_MAXK + 2] = am;
+    if (tid < kk) s_mh[tid] = make_int2(s_move[tid], s_half[tid]);  // (both final: the barrier above)
+    if (wave == 0) {  // the largest displacement, whose it is (the first, if several), and the largest among the others: over the lanes of one
+                      // wave (a thread walking the centroids read them one after the other: sixteen dependent LDS round trips per iteration)
+      static_assert(P3_MAXK <= 64, "one lane per centroid");
+      const int v = lane < kk ? s_move[lane] : 0;
+      int m1 = v;
+      for (int o = 32; o > 0; o >>= 1) m1 = max(m1, __shfl_xor(m1, o));
+      const int am = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v == m1 && (lane < kk || m1 == 0)));
+      int m2 = lane == am ? 0 : v;
+      for (int o = 32; o > 0; o >>= 1) m2 = max(m2, __shfl_xor(m2, o));
+      if (lane == 0) { s_move[P3_MAXK] = m1; s_move[P3_MAXK + 1] = m2; s_move[P3_MAXK + 2] = am; }
     }
     P3_STAMP(6);  // counts + sums read back, new centroids
     it++;
