@@ -991,16 +991,19 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
   }
   __syncthreads();
   if (tid < kk) shalf[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
-  if (tid == 0) {
-    double mx = 0.0, mx2 = 0.0;  // the largest displacement, the largest among the others, and whose the largest is
-    int amx = 0;
-    for (int c = 0; c < kk; c++) {
-      const double v = s_move[c];
-      if (v > mx) { mx2 = mx; mx = v; amx = c; } else if (v > mx2) mx2 = v;
+  if (wave == 0) {  // the largest displacement, the largest among the others, and whose the largest is (the first of several): over the lanes of a wave
+    static_assert(H_MAXK <= 64, "one lane per centroid");
+    const double v = lane < kk ? s_move[lane] : 0.0;
+    double mx = v;
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    const int amx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v == mx && (lane < kk || mx == 0.0)));
+    double mx2 = lane == amx ? 0.0 : v;
+    for (int o = 32; o > 0; o >>= 1) mx2 = fmax(mx2, __shfl_xor(mx2, o));
+    if (lane == 0) {
+      cmove[k] = mx; cmove[k + 1] = mx2; cmove[k + 2] = (double)amx;
+      if (!changed && *quiet_iter < 0) *quiet_iter = it;
+      segs[0].changed = 0;
     }
-    cmove[k] = mx; cmove[k + 1] = mx2; cmove[k + 2] = (double)amx;
-    if (!changed && *quiet_iter < 0) *quiet_iter = it;
-    segs[0].changed = 0;
   }
 }
 
