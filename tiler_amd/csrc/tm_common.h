@@ -99,6 +99,10 @@ struct HostRead {
   int n = 0;
 };
 
+// sixteen page-locked 32-bit words of the calling thread (nullptr if none are to be had): for flags a host loop polls behind events
+// without draining the stream
+int *pinned_words();
+
 // Constant tables of the reference (utils.pas:47-109) + LUTs of InitLuts (tilingencoder.pas:1683-1727),
 // uploaded once per device.
 struct DeviceTables {

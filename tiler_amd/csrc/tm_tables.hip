@@ -31,6 +31,18 @@ struct PinnedArea {
 thread_local PinnedArea t_pin;
 }  // namespace
 
+int *pinned_words() {
+  static thread_local int *w = nullptr;
+  static thread_local bool tried = false;
+  if (!w && !tried) {
+    tried = true;
+    void *q = nullptr;
+    if (hipHostMalloc(&q, 64, hipHostMallocPortable) == hipSuccess) w = (int *)q;
+    else (void)hipGetLastError();
+  }
+  return w;
+}
+
 HostRead::HostRead(hipStream_t s) : stream(s) { t_pin.depth++; }
 HostRead::~HostRead() {
   if (--t_pin.depth == 0) t_pin.used = 0;
