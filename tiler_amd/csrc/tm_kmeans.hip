@@ -1781,13 +1781,15 @@ __global__ void k_seed_centres(Seg *__restrict__ segs, int nseg, int k, const in
 
 static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const std::vector<int64_t> &seg_begin,
                           const std::vector<int64_t> &seg_count, int k, int max_iter, int32_t *assign, double *cent,
-                          std::vector<int> *host_kk, int *host_iters, hipStream_t stream, const int64_t *init_idx = nullptr) {
+                          std::vector<int> *host_kk, int *host_iters, hipStream_t stream, const int64_t *init_idx = nullptr,
+                          const long long *dev_init_idx = nullptr /* the same on the device (D2 seeding leaves them there) */) {
   TM_CHECK(d == 3 || d == 192, TM_E_INVAL, "kmeans: only d = 3 (pixels) or 192 (tile features) are built");
   TM_CHECK(k >= 1 && k <= 65536, TM_E_INVAL, "kmeans: k out of range");
   const int nseg = (int)seg_begin.size();
   if (host_iters) *host_iters = 0;
   if (nseg == 0) return TM_OK;
-  if (d == 3 && !init_idx) {  // the whole clustering in one launch when its workgroups fit the chip together
+  const bool seeded = init_idx != nullptr || dev_init_idx != nullptr;
+  if (d == 3 && !seeded) {  // the whole clustering in one launch when its workgroups fit the chip together
     int used = 0;
     TM_TRY(kmeans3_persistent(pts, w, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, &used));
     if (used) return TM_OK;
@@ -1818,7 +1820,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   TM_TRY(cnts.alloc((size_t)nseg * k * 8));
   TM_TRY(flag.alloc(4));
   TM_HIP(hipMemcpyAsync(dsegs.p, hs.data(), sizeof(Seg) * nseg, hipMemcpyHostToDevice, stream));
-  TM_HIP(hipMemsetAsync(mind.p, 0x7f, std::max<int64_t>(n, 1) * 8, stream));  // 0x7f7f... ~ 9.2e18 > any distance
+  if (!seeded) TM_HIP(hipMemsetAsync(mind.p, 0x7f, std::max<int64_t>(n, 1) * 8, stream));  // 0x7f7f... ~ 9.2e18 > any distance (the farthest-first picks' running minima)
   TM_HIP(hipMemsetAsync(sums.p, 0, (size_t)nseg * k * d * 8, stream));
   TM_HIP(hipMemsetAsync(cnts.p, 0, (size_t)nseg * k * 8, stream));
   TM_HIP(hipMemsetAsync(assign, 0xff, std::max<int64_t>(n, 1) * 4, stream));
@@ -1826,13 +1828,15 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   Seg *ds = dsegs.as<Seg>();
   const int sg_grid = (nseg + 63) / 64;
   DevBuf didx;
-  if (init_idx) {
+  if (dev_init_idx) {
+    hipLaunchKernelGGL(k_seed_centres, dim3(nseg), dim3(64), 0, stream, ds, nseg, k, pts, d, dev_init_idx, cent);
+  } else if (init_idx) {
     TM_TRY(didx.alloc((size_t)nseg * k * 8));
     TM_HIP(hipMemcpyAsync(didx.p, init_idx, (size_t)nseg * k * 8, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_seed_centres, dim3(nseg), dim3(64), 0, stream, ds, nseg, k, pts, d, didx.as<long long>(), cent);
   } else
   hipLaunchKernelGGL(k_ff_first, dim3(sg_grid), dim3(64), 0, stream, ds, nseg, k, pts, d, cent);
-  for (int c = 1; c < k && !init_idx; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
+  for (int c = 1; c < k && !seeded; c++) {  // k-1 further picks (segments with no distinct point left latch init_done)
     if (d == 3)
       hipLaunchKernelGGL(k_ff_update<3>, dim3(nblk), dim3(256), 0, stream, pts, ds, k, mind.as<long long>(), partial.as<BestKey>());
     else
@@ -2312,7 +2316,8 @@ __global__ void k_apply_lut(const int32_t *__restrict__ assign, int64_t n, const
 }
 
 // the k seed points of one process's whole point set (indices, -1 beyond the centres found)
-static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std::vector<int64_t> *out, hipStream_t stream) {
+// out (host) and / or dev_out (the device buffer itself: k indices, -1 beyond the centres found); nothing is read back unless `out` is asked for
+static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std::vector<int64_t> *out, hipStream_t stream, DevBuf *dev_out = nullptr) {
   DevBuf mind, bsum, state, cur_row, cent, seeds;
   const int nb = (int)((n + PP_BLOCK - 1) / PP_BLOCK);
   TM_TRY(mind.alloc((size_t)n * 8)); TM_TRY(bsum.alloc(sizeof(PpSum) * (size_t)nb)); TM_TRY(state.alloc(sizeof(PpState)));
@@ -2329,12 +2334,13 @@ static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std
                        (const PpSum *)nullptr, 0, 1, 0ll, cur_row.as<int32_t>(), cent.as<double>(), seeds.as<long long>(), FfCandOut{nullptr, nullptr, nullptr});
   }
   TM_HIP(hipGetLastError());
-  out->assign((size_t)k, -1);
-  {
+  if (out) {
+    out->assign((size_t)k, -1);
     HostRead hr_(stream);
     TM_TRY(hr_.get(out->data(), seeds.p, (size_t)k * 8));
     TM_TRY(hr_.wait());
   }
+  if (dev_out) *dev_out = std::move(seeds);  // (the other buffers go back to the pool: what is queued on this stream after them is ordered behind their last use)
   return TM_OK;
 }
 
@@ -2356,9 +2362,13 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   if (getenv("TM_KM_FARTHEST_FIRST")) {  // the first rounds' seeding, kept for A/B runs (the oracle's tmo_kmeans_i32)
     TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
   } else {
-    std::vector<int64_t> seeds;
-    TM_TRY(pp_seeds((const int32_t *)feat, (const uint32_t *)use, n, npal, &seeds, stream));
-    TM_TRY(run_kmeans_seeded(feat, use, n, 192, npal, seeds.data(), max_iter, assign.p, cent.p, &kk, &iters, stream));
+    DevBuf dseeds;  // the seeds never leave the device: no read-back, no drain of the stream, no upload between the seeding and the iterations
+    TM_TRY(pp_seeds((const int32_t *)feat, (const uint32_t *)use, n, npal, nullptr, stream, &dseeds));
+    std::vector<int64_t> b{0}, c{n};
+    std::vector<int> kks;
+    TM_TRY(kmeans_batched((const int32_t *)feat, (const uint32_t *)use, 192, b, c, npal, max_iter, assign.as<int32_t>(), cent.as<double>(), &kks, &iters, stream, nullptr,
+                          dseeds.as<long long>()));
+    kk = kks[0];
   }
   kmeans_run_stats().tile_iters = iters;
   kmeans_run_stats().tile_points = n;
