@@ -1546,11 +1546,14 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
       constexpr int G = decltype(gtag)::value;
       double px[G][3], bd[G], bd2[G];
       int bc[G], rr[G];
-      uint32_t cc[G];
+      uint32_t cc[G], wv[G];
 #pragma unroll
       for (int m = 0; m < G; m++) {
         const int e = e0 + m * 64 + lane;
         rr[m] = e < nlist ? (int)mylist[e] : -1;
+        // the weight is only needed if the point moves, but it comes from memory: asked for now, it arrives under the distance arithmetic
+        // instead of behind it (a round trip to L2 or HBM at the end of every scoring step of every iteration)
+        wv[m] = (w && rr[m] >= 0) ? w[sg.begin + base + rr[m]] : 1u;
         cc[m] = s_col[rr[m] < 0 ? tid : rr[m]];
         px[m][0] = (double)(int)(cc[m] & 0xff); px[m][1] = (double)(int)((cc[m] >> 8) & 0xff); px[m][2] = (double)(int)((cc[m] >> 16) & 0xff);
         bd[m] = 0.0; bd2[m] = 1.0e300;
@@ -1577,7 +1580,7 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
         const int old = (int)(cc[m] >> 24);
         if (old == bc[m]) continue;
         // only a point that changes cluster touches the carried sums
-        const long long wi = w ? (long long)w[sg.begin + base + r] : 1;
+        const long long wi = (long long)wv[m];
         const int pi[3] = {(int)(cc[m] & 0xff), (int)((cc[m] >> 8) & 0xff), (int)((cc[m] >> 16) & 0xff)};
         u64 *acc = &s_acc[tid & (P3_NCOPY - 1)][bc[m]][0];
         atomicAdd(&acc[3], (u64)wi);
