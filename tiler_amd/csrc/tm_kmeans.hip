@@ -1494,18 +1494,20 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
         cc[i] = s_col[r];
         bn[i] = s_u.bnd[r];
       }
+      // (no branch around a point's table look-up: the compiler then waits for every look-up on its own, one LDS round trip after the
+      // other; fetched for all the points of the batch at once -- entry 62 / 63 for the slots without a centroid, never used -- they overlap)
+      int2 mh[PU];
+#pragma unroll
+      for (int i = 0; i < PU; i++) mh[i] = s_mh[(cc[i] >> 24) & (P3_MAXK - 1)];
 #pragma unroll
       for (int i = 0; i < PU; i++) {
         const int r = (m0 + i) * P3_NT + tid;
         const int a = (int)(cc[i] >> 24);
-        bool listed = a == 0xff;  // not assigned yet: scored
-        if (a < 0xfe) {
-          const int2 mh = s_mh[a];
-          const int u = min(65535, (int)(bn[i] & 0xffffu) + mh.x);
-          const int l = max(0, (int)(bn[i] >> 16) - (a == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
-          s_u.bnd[r] = (uint32_t)u | ((uint32_t)l << 16);
-          listed = u > max(l, mh.y);
-        }
+        const bool has = a < 0xfe;
+        const int u = min(65535, (int)(bn[i] & 0xffffu) + mh[i].x);
+        const int l = max(0, (int)(bn[i] >> 16) - (a == amax ? mv2 : mv1));  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+        s_u.bnd[r] = has ? ((uint32_t)u | ((uint32_t)l << 16)) : bn[i];
+        const bool listed = has ? u > max(l, mh[i].y) : a == 0xff;  // (not assigned yet: scored)
         const unsigned long long tb = __builtin_amdgcn_ballot_w64(listed);
         if (listed) mylist[ntight + __popcll(tb & ((1ull << lane) - 1ull))] = (uint16_t)r;
         ntight += __popcll(tb);
