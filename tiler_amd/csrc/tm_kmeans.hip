@@ -616,18 +616,48 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
   const double dmax = cmove[k], dmax2 = cmove[k + 1];
   const int amax = (int)cmove[k + 2];
   const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
-  // pass 1, every point of the slice: move the bounds with the centroids; the points whose loosened bounds no longer prove them -> LDS list
+  // pass 1, every point of the slice: move the bounds with the centroids; the points whose loosened bounds no longer prove them -> LDS list.
+  // The four points of a thread go through it side by side -- their loads first, then the table look-ups that depend on them, then the
+  // arithmetic, one list append per wave: with a loop that could leave early and an LDS atomic per listed point the compiler kept the
+  // points apart, and every point paid its two dependent round trips to memory on its own (this launch is ~20 % of an iteration)
+  {
+    constexpr int R = H_SLICE / 256;
+    int a[R];
+    double u[R], l[R], mv[R], sh[R];
+    bool valid[R], listed[R];
 #pragma unroll
-  for (int r = 0; r < H_SLICE / 256; r++) {
-    const int64_t i = i0 + r * 256 + tid;
-    if (i >= n) break;
-    const int a = assign[i];
-    const double u = (ub[i] + cmove[a]) * (1.0 + 1e-15);
-    double l = lb[i] - (a == amax ? dmax2 : dmax);  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
-    l -= fabs(l) * 1e-15;
-    ub[i] = u;
-    lb[i] = l;
-    if (!(u * (1.0 + H_ETA) < fmax(shalf[a], l) * (1.0 - H_ETA))) s_list[atomicAdd(&s_nlist, 1)] = r * 256 + tid;
+    for (int r = 0; r < R; r++) {
+      const int64_t i = i0 + r * 256 + tid;
+      valid[r] = i < n;
+      const int64_t ii = valid[r] ? i : i0;  // (the slice's first point exists)
+      a[r] = assign[ii]; u[r] = ub[ii]; l[r] = lb[ii];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) { mv[r] = cmove[a[r]]; sh[r] = shalf[a[r]]; }
+    int cnt = 0;
+    unsigned long long bal[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int64_t i = i0 + r * 256 + tid;
+      const double un = (u[r] + mv[r]) * (1.0 + 1e-15);
+      double ln = l[r] - (a[r] == amax ? dmax2 : dmax);  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+      ln -= fabs(ln) * 1e-15;
+      if (valid[r]) { ub[i] = un; lb[i] = ln; }
+      listed[r] = valid[r] && !(un * (1.0 + H_ETA) < fmax(sh[r], ln) * (1.0 - H_ETA));
+      bal[r] = __builtin_amdgcn_ballot_w64(listed[r]);
+      cnt += __popcll(bal[r]);
+    }
+    if (cnt) {  // (uniform in the wave)
+      const int lane = tid & 63;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_nlist, cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (listed[r]) s_list[base + __popcll(bal[r] & ((1ull << lane) - 1ull))] = r * 256 + tid;
+        base += __popcll(bal[r]);
+      }
+    }
   }
   __syncthreads();
   // pass 2, the listed ones: the distance to the own centroid tightens ub; 16 lanes per point (12 dimensions each, the row and the centroid's
