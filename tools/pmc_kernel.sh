@@ -7,7 +7,7 @@ CNT=${@:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_A
 OUT=gpurun_out/pmck_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
-timeout -k 10 600 rocprofv3 --pmc $CNT --kernel-include-regex "$RE" --output-format csv -d $OUT/p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-include-regex "$RE" --output-format csv -d $OUT/p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-frozen-extra --no-kmodes-extra > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 python3 - $OUT <<'PY'
 import csv, glob, sys
 from collections import OrderedDict
