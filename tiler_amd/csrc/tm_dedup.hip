@@ -21,6 +21,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
+#include <cmath>
 
 #include "tm_common.h"
 #include "tm_internal.h"
@@ -269,17 +270,15 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8)); TM_TRY(flag.alloc(4));
     TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
     // The sort only has to bring equal rows together, so the hash keeps only as many of its top bits (whole 8-bit passes of the sort) as hold
-    // the chance of two different rows among n sharing them below 2^-12 -- 56 for Reindex's 321 k rows (the bench clip's 4.32 M frame tiles
-    // need all 64).  Rows that share them and differ are caught by the full compare like any collision (the plain path then: exact, slow).
+    // the chance of two different rows among n sharing them below 2^-12 -- 48 for Reindex's 321 k rows, 56 for the bench clip's 4.32 M frame tiles
+    // (seven passes instead of eight).  Rows that share them and differ are caught by the full compare like any collision (the plain path then: exact, slow).
     // The kept bits are moved DOWN and sorted as bits [0, hbits): a range that ends at bit 64 without starting at 0 sends rocPRIM's
     // merge-sort path (up to ~1 M keys) through a mask built with a shift by 64 -- it then orders by the wrong bits and its merge reads out
     // of bounds (found the hard way: a memory access fault on the GPU box).
     int hbits = 64;
     const int degrade = getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0;
     if (!degrade) {
-      int lg = 1;
-      while (((int64_t)1 << lg) < n) lg++;
-      hbits = std::min(64, (2 * lg + 11 + 7) / 8 * 8);
+      hbits = std::min(64, ((int)std::ceil(2.0 * std::log2((double)std::max<int64_t>(n, 2)) + 11.0) + 7) / 8 * 8);  // n^2 / 2^(bits + 1) <= 2^-12
       if (const char *hb = getenv("TM_DEDUP_HASH_BITS")) hbits = std::max(8, std::min(64, atoi(hb) / 8 * 8));  // A/B aid
     }
     hipLaunchKernelGGL(k_row_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, n,
