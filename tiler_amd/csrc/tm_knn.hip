@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
                                                   int *__restrict__ err_flag, int *__restrict__ qmeta /* query side of the second scan shape: [ntiles][16] */) {
   __shared__ int16_t s_c[192], s_p[192];
-  __shared__ int s_v[32][193];
+  __shared__ __attribute__((aligned(16))) int s_v[32][196];  // (pitch 196: a row's 16-value groups are 16-byte aligned, and sixteen rows' groups cover the 64 banks once)
   __shared__ uint32_t s_norm[32];
   __shared__ long long s_bsq[32];  // query side: squared distance of each row from the centres over the box columns
   __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
@@ -165,20 +165,23 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
     bool bad = false;
     for (int piece = threadIdx.x; piece < kch * 64; piece += 256) {
       const int kc = piece >> 6, ln = piece & 63, half = ln >> 5, r = ln & 31;
+      // the piece's sixteen values as four 16-byte LDS reads (sixteen 4-byte ones were most of this loop's instructions)
+      const int kpos0 = kc * 32 + half * 16;  // byte position along K of the piece's first value
+      const bool high = kpos0 >= 192;         // (uniform in the piece: 192 is a multiple of 16)
+      const int4 *src = reinterpret_cast<const int4 *>(&s_v[r][high ? kpos0 - 192 : kpos0]);
+      const int4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      const int vals[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      const bool must_fit = !high && kpos0 >= hch * 32;  // columns without a high digit (hch * 32 is a multiple of 16 too)
       uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int b = 0; b < 16; b++) {
-        const int kpos = kc * 32 + half * 16 + b;  // byte position along K
+        const int v = vals[b] * scale;
+        const int lo = ((v + 128) & 255) - 128;  // low digit in [-128,127]
         int digit;
-        if (kpos < 192) {
-          const int v = s_v[r][kpos] * scale;
-          digit = ((v + 128) & 255) - 128;  // low digit in [-128,127]
-          if (kpos >= hch * 32) {           // column without a high digit: must fit
-            if (v != digit) bad = true;
-          }
+        if (!high) {
+          digit = lo;
+          if (must_fit && v != lo) bad = true;
         } else {
-          const int v = s_v[r][kpos - 192] * scale;
-          const int lo = ((v + 128) & 255) - 128;
           digit = (v - lo) >> 8;
           if (digit < -128 || digit > 127) bad = true;
         }
