@@ -265,10 +265,21 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   TM_TRY(key.alloc(n * 4)); TM_TRY(key2.alloc(n * 4)); TM_TRY(ord2.alloc(n * 4)); TM_TRY(pos.alloc(n * 4)); TM_TRY(cnt.alloc(16));
   hipLaunchKernelGGL(k_iota, dim3(gridn(n)), dim3(256), 0, stream, idx.as<uint32_t>(), n);
   bool grouped = false;  // true: `sorted` is in hash order (runs of equal rows, lowest index first), not yet in content order
+  DevBuf hflag;  // set by the full compares of the hash groups: two different rows shared a hash
+  TM_TRY(hflag.alloc(4));
+  TM_HIP(hipMemsetAsync(hflag.p, 0, 4, stream));
+  auto plain_heads = [&]() -> int {  // the plain path: a stable merge sort of all row indices with a comparator that reads the rows
+    size_t tb = 0;
+    TM_HIP(rocprim::merge_sort(nullptr, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+    TM_TRY(tmp.alloc(tb));
+    TM_HIP(rocprim::merge_sort(tmp.p, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
+    hipLaunchKernelGGL(k_mark_heads, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), n, less, head.as<uint32_t>(),
+                       headpos.as<uint32_t>());
+    return TM_OK;
+  };
   if (!getenv("TM_DEDUP_PLAIN")) {
-    DevBuf hkey, hkey2, flag;
-    TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8)); TM_TRY(flag.alloc(4));
-    TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    DevBuf hkey, hkey2;
+    TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8));
     // The sort only has to bring equal rows together, so the hash keeps only as many of its top bits (whole 8-bit passes of the sort) as hold
     // the chance of two different rows among n sharing them below 2^-12 -- 48 for Reindex's 321 k rows, 56 for the bench clip's 4.32 M frame tiles
     // (seven passes instead of eight).  Rows that share them and differ are caught by the full compare like any collision (the plain path then: exact, slow).
@@ -290,41 +301,35 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     TM_HIP(rocprim::radix_sort_pairs(tmp.p, tbh, hkey.as<unsigned long long>(), hkey2.as<unsigned long long>(), idx.as<uint32_t>(),
                                      sorted.as<uint32_t>(), (size_t)n, 0, hbits, stream));
     hipLaunchKernelGGL(k_mark_heads_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, sorted.as<uint32_t>(),
-                       hkey2.as<unsigned long long>(), n, less, head.as<uint32_t>(), headpos.as<uint32_t>(), flag.as<int>());
+                       hkey2.as<unsigned long long>(), n, less, head.as<uint32_t>(), headpos.as<uint32_t>(), hflag.as<int>());
+    grouped = true;  // until the flag says otherwise: it is read with the distinct count below, one round trip for both
+  }
+  if (!grouped) TM_TRY(plain_heads());
+  uint32_t last_excl = 0, last_head = 0;
+  for (;;) {
+    size_t tb2 = 0;
+    TM_HIP(rocprim::inclusive_scan(nullptr, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
+    size_t tb3 = 0;
+    TM_HIP(rocprim::exclusive_scan(nullptr, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    TM_TRY(tmp.alloc(std::max(tb2, tb3)));
+    TM_HIP(rocprim::inclusive_scan(tmp.p, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
+    TM_HIP(rocprim::exclusive_scan(tmp.p, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    TM_HIP(hipMemsetAsync(use_rep.p, 0, n * 4, stream));
+    hipLaunchKernelGGL(k_merge_runs, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), hps.as<uint32_t>(),
+                       head_excl.as<uint32_t>(), head.as<uint32_t>(), n, (const uint32_t *)use_in, rep.as<uint32_t>(),
+                       use_rep.as<uint32_t>(), uniq.as<uint32_t>());
+    // number of runs = head_excl[n-1] + head[n-1]
     int collision = 0;
     {
       HostRead hr_(stream);
-      TM_TRY(hr_.get(&collision, flag.p, 4));
+      TM_TRY(hr_.get(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4));
+      TM_TRY(hr_.get(&last_head, head.as<uint32_t>() + (n - 1), 4));
+      TM_TRY(hr_.get(&collision, hflag.p, 4));
       TM_TRY(hr_.wait());
     }
-    grouped = collision == 0;
-  }
-  if (!grouped) {
-    size_t tb = 0;
-    TM_HIP(rocprim::merge_sort(nullptr, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
-    TM_TRY(tmp.alloc(tb));
-    TM_HIP(rocprim::merge_sort(tmp.p, tb, idx.as<uint32_t>(), sorted.as<uint32_t>(), (size_t)n, less, stream));
-    hipLaunchKernelGGL(k_mark_heads, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), n, less, head.as<uint32_t>(),
-                       headpos.as<uint32_t>());
-  }
-  size_t tb2 = 0;
-  TM_HIP(rocprim::inclusive_scan(nullptr, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
-  size_t tb3 = 0;
-  TM_HIP(rocprim::exclusive_scan(nullptr, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-  TM_TRY(tmp.alloc(std::max(tb2, tb3)));
-  TM_HIP(rocprim::inclusive_scan(tmp.p, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
-  TM_HIP(rocprim::exclusive_scan(tmp.p, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-  TM_HIP(hipMemsetAsync(use_rep.p, 0, n * 4, stream));
-  hipLaunchKernelGGL(k_merge_runs, dim3(gridn(n)), dim3(256), 0, stream, sorted.as<uint32_t>(), hps.as<uint32_t>(),
-                     head_excl.as<uint32_t>(), head.as<uint32_t>(), n, (const uint32_t *)use_in, rep.as<uint32_t>(),
-                     use_rep.as<uint32_t>(), uniq.as<uint32_t>());
-  // number of runs = head_excl[n-1] + head[n-1]
-  uint32_t last_excl = 0, last_head = 0;
-  {
-    HostRead hr_(stream);
-    TM_TRY(hr_.get(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4));
-    TM_TRY(hr_.get(&last_head, head.as<uint32_t>() + (n - 1), 4));
-    TM_TRY(hr_.wait());
+    if (!(grouped && collision)) break;
+    grouped = false;  // a collision among the hashes (about once in 2^12 calls by the choice of bits above): the same again over the plain order
+    TM_TRY(plain_heads());
   }
   const int64_t nu = (int64_t)last_excl + last_head;
   bool ranked = false;  // ord2 already holds the final order
