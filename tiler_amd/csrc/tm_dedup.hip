@@ -204,7 +204,17 @@ __global__ void k_merge_runs(const uint32_t *__restrict__ sorted, const uint32_t
       if (head[i]) uniq[head_excl[i]] = r;
     }
     if (use_in) {
-      if (in) atomicAdd(&use_rep[r], use_in[row]);
+      // the same with counts to add up: a segmented sum over the lanes of a run (the hp of a run's rows are equal and the runs are
+      // neighbours), one atomic per run and wave
+      uint32_t v = in ? use_in[row] : 0u;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ov = (uint32_t)__shfl_down((int)v, o);
+        const uint32_t ohp = (uint32_t)__shfl_down((int)hp, o);
+        if (lane + o < 64 && ohp == hp) v += ov;
+      }
+      const uint32_t prev = (uint32_t)__shfl_up((int)hp, 1);
+      if (in && (lane == 0 || hp != prev) && v) atomicAdd(&use_rep[r], v);
     } else {
       // rows of a run are neighbours here: the part of a run inside a wave adds its length with one atomic (a flat tile's run is a tenth of
       // the clip, and its counter would take every one of those atomics in turn)
