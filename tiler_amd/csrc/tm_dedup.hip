@@ -130,12 +130,28 @@ __global__ void k_prefix_rows(const PrefixKey *__restrict__ keys, int64_t nu, ui
 // ---- only the first `exact_first` positions of the final order matter (Reduce keeps that many tiles): which distinct rows can be there --
 // use counts of the distinct rows, clamped to 1023: a histogram per workgroup in LDS (most rows are used once: one global counter would take
 // every row's atomic in turn), flushed with one atomic per occupied bin
-__global__ __launch_bounds__(256) void k_po_use_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t *__restrict__ hist) {
+// (the flush goes to the histogram copy of the XCD the workgroup runs on -- hist8: [8][bins], folded by k_po_fold --: every workgroup
+// holds single-use rows, and 4 096 workgroups of eight XCDs adding to hist[1] passed that one word round for most of the kernel's 70 us)
+__device__ __forceinline__ unsigned po_xcc() {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  return xcc & 7u;
+}
+__global__ void k_po_fold(const uint32_t *__restrict__ hist8, int bins, uint32_t *__restrict__ hist) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < bins; e += gridDim.x * blockDim.x) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) s += hist8[x * bins + e];
+    hist[e] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_po_use_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t *__restrict__ hist8) {
   __shared__ uint32_t s_h[1024];
   for (int e = threadIdx.x; e < 1024; e += 256) s_h[e] = 0;
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&s_h[min(use_rep[uniq[i]], 1023u)], 1u);
   __syncthreads();
+  uint32_t *hist = hist8 + po_xcc() * 1024;
   for (int e = threadIdx.x; e < 1024; e += 256) if (s_h[e]) atomicAdd(&hist[e], s_h[e]);
 }
 __device__ __forceinline__ uint32_t po_lead(const RowLess &less, uint32_t row) {  // the row's leading dword in comparison order
@@ -144,7 +160,7 @@ __device__ __forceinline__ uint32_t po_lead(const RowLess &less, uint32_t row) {
 }
 // among the rows used exactly `use_star` times: a histogram of the leading dword's top 12 bits
 __global__ __launch_bounds__(256) void k_po_lead_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t use_star, RowLess less,
-                                                      uint32_t *__restrict__ hist) {
+                                                      uint32_t *__restrict__ hist8) {
   __shared__ uint32_t s_h[4096];
   for (int e = threadIdx.x; e < 4096; e += 256) s_h[e] = 0;
   __syncthreads();
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(256) void k_po_lead_hist(const uint32_t *__restrict
     if (use_rep[r] == use_star) atomicAdd(&s_h[po_lead(less, r) >> 20], 1u);
   }
   __syncthreads();
+  uint32_t *hist = hist8 + po_xcc() * 4096;
   for (int e = threadIdx.x; e < 4096; e += 256) if (s_h[e]) atomicAdd(&hist[e], s_h[e]);
 }
 // candidate = used more often than use_star, or exactly that often with a leading dword in the first buckets
@@ -350,10 +367,12 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     // the bucket that position falls into; rows used more often, or u* times with a leading dword up to that bucket, are the only ones
     // that can come before it.  They alone are sorted (the comparator reads the rows where the keys tie); the others follow as they come.
     // 3.24 M distinct rows for a budget of 321 k on the bench clip: a merge sort of a tenth of them instead of all.
-    DevBuf h1, h2, flag, fpos;
-    TM_TRY(h1.alloc(1024 * 4)); TM_TRY(h2.alloc(4096 * 4));
-    TM_HIP(hipMemsetAsync(h1.p, 0, 1024 * 4, stream));
-    hipLaunchKernelGGL(k_po_use_hist, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), h1.as<uint32_t>());
+    DevBuf h1, h2, h8, flag, fpos;
+    TM_TRY(h1.alloc(1024 * 4)); TM_TRY(h2.alloc(4096 * 4)); TM_TRY(h8.alloc(8 * 4096 * 4));
+    const int po_grid = std::min(gridn(nu), 1024);  // (every workgroup flushes its bins: fewer workgroups, fewer atomics on the popular ones)
+    TM_HIP(hipMemsetAsync(h8.p, 0, 8 * 1024 * 4, stream));
+    hipLaunchKernelGGL(k_po_use_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), h8.as<uint32_t>());
+    hipLaunchKernelGGL(k_po_fold, dim3(4), dim3(256), 0, stream, h8.as<uint32_t>(), 1024, h1.as<uint32_t>());
     std::vector<uint32_t> hh1(1024), hh2(4096);
     {
       HostRead hr_(stream);
@@ -367,8 +386,9 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
       above += hh1[(size_t)u];
     }
     if (ustar >= 1 && ustar < 1023) {  // (a cut inside the clamped bin -- 1023 uses and more -- takes the full sort below)
-      TM_HIP(hipMemsetAsync(h2.p, 0, 4096 * 4, stream));
-      hipLaunchKernelGGL(k_po_lead_hist, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, less, h2.as<uint32_t>());
+      TM_HIP(hipMemsetAsync(h8.p, 0, 8 * 4096 * 4, stream));
+      hipLaunchKernelGGL(k_po_lead_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, less, h8.as<uint32_t>());
+      hipLaunchKernelGGL(k_po_fold, dim3(16), dim3(256), 0, stream, h8.as<uint32_t>(), 4096, h2.as<uint32_t>());
       {
         HostRead hr_(stream);
         TM_TRY(hr_.get(hh2.data(), h2.p, 4096 * 4));
