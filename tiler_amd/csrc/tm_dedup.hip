@@ -233,15 +233,9 @@ __global__ void k_merge_runs(const uint32_t *__restrict__ sorted, const uint32_t
       const uint32_t prev = (uint32_t)__shfl_up((int)hp, 1);
       if (in && (lane == 0 || hp != prev) && v) atomicAdd(&use_rep[r], v);
     } else {
-      // rows of a run are neighbours here: the part of a run inside a wave adds its length with one atomic (a flat tile's run is a tenth of
-      // the clip, and its counter would take every one of those atomics in turn)
-      const uint32_t prev = (uint32_t)__shfl_up((int)hp, 1);
-      const bool first = lane == 0 || hp != prev;
-      const unsigned long long firsts = __ballot(first);
-      if (first && in) {
-        const unsigned long long rest = lane == 63 ? 0ull : firsts >> (lane + 1);
-        atomicAdd(&use_rep[r], (uint32_t)(rest ? __ffsll((long long)rest) : 64 - lane));
-      }
+      // rows of a run are neighbours here, and a run's last row knows where the run began: its length is a plain store (3.2 M atomics on
+      // words scattered over 17 MB, passed between the XCDs' L2s, were most of this kernel)
+      if (in && (i == n - 1 || head[i + 1])) use_rep[r] = (uint32_t)(i - hp + 1);
     }
   }
 }
