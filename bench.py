@@ -38,9 +38,13 @@ def _traffic_from_profiles(kernel_build):
         except (OSError, ValueError):
             continue
         if t.get("kernel_build") == kernel_build:
+            _traffic_from_profiles.extra = {k: t[k] for k in ("mfma_busy_frac", "mfma_busy_note", "tcc_hit_rate_pruned") if k in t}
             return t["traffic_bytes"], "2 x FETCH_SIZE + WRITE_SIZE of one pruned launch, separate --pmc passes (%s)" % t.get("source", "profiles/")
         seen.append("%s: build %r" % (os.path.basename(p), t.get("kernel_build")))
     return None, "no PMC pass committed for this build %r (%s)" % (kernel_build, "; ".join(seen) or "none in profiles/")
+
+
+_traffic_from_profiles.extra = {}
 
 
 def _host_threads(visible):
@@ -334,6 +338,8 @@ def main():
                      "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair (exact count: padding rows are not pairs); "
                              "the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
     }
+    if traffic is not None:  # what the committed PMC passes of this kernel build say beside the traffic: matrix pipe busy time, L2 hit rate
+        out["roofline"].update({"pmc_" + k: v for k, v in _traffic_from_profiles.extra.items()})
     if world == 1 and not args.no_h2d_extra:
         # the same K steps with the clip in host memory: every step is handed the clip anew (tm_set_frames_host lends it until that
         # step's Load has returned) and its Load moves 4*W*H*F bytes across PCIe, chunks beside its own kernel
