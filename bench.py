@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json headline metric on MI355X: encoded frames/sec (+ tiles-matched/sec) of the TileMotion
-per-frame tile pipeline on the 720p, 300-frame, 16-palette synthetic clip (configs[1]).
+per-frame tile pipeline on the 720p, 300-frame, 16-palette synthetic clip (configs[1]), generated exactly as SURVEY.md 8(d) writes it.
 
 A step = one TTilingEncoder.Run(esAll) pass (Load -> Reduce -> PreparePalettes -> Dither -> Reconstruct -> Reindex)
-over the whole clip.  `value` is measured with the RGB frames already resident in HBM; `with_h2d` repeats the same K steps with
-the clip in page-locked HOST memory, so that every step also moves it across PCIe (SURVEY.md 8d's "H2D included" reading).
+over the whole clip.  `value` is measured with the RGB frames already resident in HBM; `with_h2d_d2h` repeats the same K steps with
+the clip in page-locked HOST memory and the results read back (tile maps of every frame, tiles, palettes), so that every step also
+moves the clip across PCIe and its results back (SURVEY.md 8d's "H2D/D2H included" reading); `with_h2d_overlapped_d2h` does the same
+with the next clip's upload queued beside this clip's steps.
 N > 1: one process per GPU (torch.distributed, RCCL); the clip is ONE job split over the ranks (strong scaling), see
-tiler_amd/distributed.py.  Prints one JSON line.
+tiler_amd/distributed.py.  `python bench.py --gpus N` with no launcher around it starts the N ranks itself (torch.distributed.run as a
+child process, before this process touches a GPU) and relays rank 0's line.  Prints one JSON line.
 """
 import argparse
 import ctypes
@@ -78,6 +81,32 @@ def _collective_counts(enc, nsteps):
     return out
 
 
+def _spawn_ranks(n):
+    """`--gpus N` without a launcher: N fresh rank processes through torch.distributed.run, started from this process BEFORE it has
+    made any GPU call (never an exec: a process that has initialised the GPU must not be replaced).  Rank 0's JSON line is relayed on
+    stdout, everything else goes to stderr; the exit code is the launcher's (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver of this pool only does dmabuf IPC
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
 def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, seconds_budget=24.0, threads=None):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, scaled to frames/s.  Three legs:
     1 thread with the brute-force search; every host core (one oracle call per thread: ctypes drops the GIL) with the brute force;
@@ -94,7 +123,7 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     cores = threads or _host_threads(visible)
     tm_w, tm_h = (width - 1) // 8 + 1, (height - 1) // 8 + 1
     per = tm_w * tm_h
-    fr = synth.video(2, width, height)
+    fr = synth.video(2, width, height, freeze=False)
     rng = np.random.default_rng(0)
 
     def par(fn, parts, threads):
@@ -195,10 +224,14 @@ def main():
     ap.add_argument("--no-h2d-extra", action="store_true", help="skip the timed regions with the clip in host memory")
     ap.add_argument("--no-kmodes-extra", action="store_true", help="skip the k-modes operator's roofline line (A17, config 5's shape)")
     ap.add_argument("--no-frozen-extra", action="store_true",
-                    help="skip the extra pass on SURVEY.md 8(d)'s literal generator (no frozen tile columns, hence no exact inter-frame duplicates)")
+                    help="skip the extra pass on the clip with frozen tile columns (this repo's addition to the generator: exact inter-frame duplicates)")
+    ap.add_argument("--frozen-columns", action="store_true",
+                    help="time `value` on the clip with frozen tile columns instead of SURVEY.md 8(d)'s literal generator (A/B runs against earlier rounds)")
     ap.add_argument("--no-dense-extra", action="store_true",
                     help="skip the dense diagnostic launch of the KNN kernel (under rocprofv3 --stats it would share the kernel's row with the pruned launches)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -231,7 +264,7 @@ def main():
     rng = np.random.Generator(np.random.PCG64(synth.SEED))
     hv = host_frames.numpy()
     for f in range(F):
-        hv[f] = synth.frame(f, W, H, rng).view(np.int32)
+        hv[f] = synth.frame(f, W, H, rng, freeze=args.frozen_columns).view(np.int32)
     frames = host_frames.cuda()
     torch.cuda.synchronize()
 
@@ -244,21 +277,30 @@ def main():
     enc.SetVideo(W, H, 24.0, F)
     enc.SetFramesDevice(frames)
 
-    if world > 1 and not rehearse and os.environ.get("TM_BENCH_CALLBACK") != "1":
-        # the native path: RCCL linked into libtilemotion, one communicator per encoder, the collectives on the encoder's own stream.
-        # The 128-byte id travels over the process group torch.distributed already has (a Pascal host would use a file or a pipe).
+    if world > 1 and not rehearse and os.environ.get("TM_BENCH_NATIVE") == "1":
+        # Opt-in (the default is the host callback over torch.distributed's RCCL process group, the path every multi-process test has run):
+        # RCCL linked into libtilemotion, one communicator per encoder, the collectives on the encoder's own stream.  It has only ever run
+        # with one rank (tests/c/native_comm.c), so the ranks first agree that each of them is READY to enter the collective init (library
+        # exports tm_comm_*, device chosen, id received) -- a rank that fails before that never leaves the others inside it -- and
+        # tm_comm_init itself is non-blocking with a time limit (TM_COMM_TIMEOUT_S).
         box = [TilingEncoder.CommUniqueId() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        ok = 1
-        try:
-            enc.CommInit(box[0], rank, world)
-        except Exception as ex:  # noqa: BLE001 -- a rank whose communicator does not come up must not leave the others inside theirs
-            ok = 0
-            print("[bench] rank %d: tm_comm_init failed (%s); every rank falls back to the host callback" % (rank, ex), file=sys.stderr)
-        agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        ready = 1 if (box[0] is not None and hasattr(_lib_fn(), "tm_comm_init")) else 0
+        agreed = torch.tensor([ready], dtype=torch.int32, device="cuda")
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 0 and ok:
-            enc.CommDestroy()
+        if int(agreed.item()) == 1:
+            ok = 1
+            try:
+                enc.CommInit(box[0], rank, world)
+            except Exception as ex:  # noqa: BLE001
+                ok = 0
+                print("[bench] rank %d: tm_comm_init failed (%s); every rank falls back to the host callback" % (rank, ex), file=sys.stderr)
+            agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0 and ok:
+                enc.CommDestroy()
+        else:
+            print("[bench] rank %d: not every rank is ready for tm_comm_init; the host callback carries the collectives" % rank, file=sys.stderr)
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,18 +314,25 @@ def main():
     def timed(nsteps):
         barrier()
         t0 = time.perf_counter()
-        knn = dict(ms=0.0, pairs=0, launches=0)
-        stage_ms = np.zeros(8)
+        knn = dict(ms=0.0, pairs=0, launches=0, seed_ms=0.0, lists_ms=0.0, consume_ms=0.0, seed_pairs=0, consume_pairs=0)
+        stage_ms, stage_max, step_max, tl = np.zeros(8), np.zeros(8), 0.0, t0
         for _ in range(nsteps):
             step()
             ks = enc.KnnStats()
             knn["ms"] += ks["kernel_ms"]; knn["pairs"] += ks["pairs"]; knn["launches"] += ks["launches"]
-            stage_ms += enc.StageMs()
+            for k in ("seed_ms", "lists_ms", "consume_ms", "seed_pairs", "consume_pairs"):
+                knn[k] += ks[k]
+            sm = enc.StageMs()
+            stage_ms += sm
+            stage_max = np.maximum(stage_max, sm)
+            tn = time.perf_counter()  # (Run is blocking: the step's results are on the host side of the call when it returns)
+            step_max, tl = max(step_max, tn - tl), tn
         barrier()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        knn["stage_max"], knn["step_max_ms"] = stage_max, step_max * 1e3
         return float(t.item()), knn, stage_ms
 
     for _ in range(args.warmup):
@@ -292,9 +341,13 @@ def main():
 
     c = enc.counts()
     ks = enc.KnnStats()
-    per_launch_ms = knn["ms"] / max(knn["launches"], 1)
-    alg_ops_per_launch = 384.0 * knn["pairs"] / max(knn["launches"], 1)  # 2*192 integer ops per (query, tile) pair
+    # the dominant kernel = the scan's consume kernel (k_knn_consume); its seed and list kernels are reported beside it
+    nl = max(knn["launches"], 1)
+    per_launch_ms = knn["consume_ms"] / nl
+    alg_ops_per_launch = 384.0 * knn["consume_pairs"] / nl  # 2*192 integer ops per (query, tile) pair
     achieved = alg_ops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+    scan_ms = knn["ms"] / nl
+    achieved_scan = 384.0 * knn["pairs"] / nl / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
     per = c["tm_w"] * c["tm_h"]
     q_total = F * per
@@ -315,25 +368,33 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{W}x{H} {F}-frame synthetic noise+gradients, 8x8 tiles, {args.palettes} palettes x 16 colours, "
                                f"Thomas-Knoll dither, KNN k=1 (EPU off), MotionPredictRadius={args.motion_radius}" + (" (motion prediction excluded, SURVEY.md 8d)" if args.motion_radius == 0 else "")
-                               + "; generator = SURVEY.md 8(d) plus ONE addition: the +f drift is frozen on every third tile column (tiler_amd/synth.py), which makes "
-                               + "%.1f %% of the frame tiles exact duplicates of another frame tile -- Reconstruct searches once per DISTINCT frame tile "
-                                 "(knn_queries of query_tiles); `without_frozen_columns` is the same step on the literal generator" % (100.0 * (1.0 - float(ks.get("queries", q_total)) / q_total)),
+                               + ("; generator = SURVEY.md 8(d) as written (tiler_amd.synth.frame(freeze=False)): %.1f %% of the frame tiles are exact duplicates of another "
+                                  "frame tile; `with_frozen_columns` is the same step on the clip earlier rounds were quoted on" if not args.frozen_columns else
+                                  "; generator = SURVEY.md 8(d) plus ONE addition (--frozen-columns): the +f drift is frozen on every third tile column, which makes "
+                                  "%.1f %% of the frame tiles exact duplicates of another frame tile") % (100.0 * (1.0 - float(ks.get("queries", q_total)) / q_total)),
                    "frames": F, "tiles_per_frame": per, "query_tiles": q_total, "global_tiles_T": T,
                    "distinct_database_rows": int(ks["db_rows"]), "knn_queries": int(ks.get("queries", q_total)),
                    "duplicate_frame_tiles_fraction": 1.0 - float(ks.get("queries", q_total)) / q_total,
-                   "value_is": "device-resident: RGB frames in HBM when the timed region starts; the H2D-inclusive figures of SURVEY.md 8(d) are `with_h2d` "
-                               "(upload inside Load) and `with_h2d_overlapped` (upload of the next clip beside this clip's steps)",
+                   "value_is": "device-resident: RGB frames in HBM when the timed region starts; the transfer-inclusive figures of SURVEY.md 8(d) are "
+                               "`with_h2d_d2h` (upload inside Load, tile maps / tiles / palettes read back after the step) and `with_h2d_overlapped_d2h` "
+                               "(upload of the next clip beside this clip's steps), details under `transfers`",
                    "final_tiles_after_reindex": int(c["tiles"]),
-                   "input": "RGB frames resident in HBM when the timed region starts (with_h2d: in page-locked host memory)",
+                   "input": "RGB frames resident in HBM when the timed region starts (with_h2d_d2h: in page-locked host memory)",
                    "parallelism": distributed.describe(world)},
         "collectives_per_step": _collective_counts(enc, args.steps + args.warmup) if world > 1 else None,
         "tiles_matched_per_sec": q_total / (st["reconstruct"] * 1e-3) if st["reconstruct"] > 0 else None,
         "stage_ms": {n: round(v, 3) for n, v in st.items()},
+        "stage_ms_max": {n: round(float(v), 3) for n, v in zip(STAGES, knn["stage_max"])},
+        "step_ms_max": round(knn["step_max_ms"], 3),
         "nominal_pairs": float(q_total) * float(T),
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_DENSE_PEAK_TOPS,
-                     "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_knn_scan2", "kernel_build": kernel_build,
+                     "traffic": traffic, "traffic_note": traffic_note, "kernel": "k_knn_consume", "kernel_build": kernel_build,
                      "launch_ms": per_launch_ms, "k_bytes": ks["k_bytes"],
-                     "pairs_per_launch": knn["pairs"] / max(knn["launches"], 1),
+                     "pairs_per_launch": knn["consume_pairs"] / nl,
+                     "scan": {"kernels_ms": {"k_knn_seed": knn["seed_ms"] / nl, "k_knn_lists": knn["lists_ms"] / nl, "k_knn_consume": per_launch_ms},
+                              "ms": scan_ms, "pairs": knn["pairs"] / nl, "achieved": achieved_scan, "frac": achieved_scan / I8_DENSE_PEAK_TOPS,
+                              "note": "the whole search = three kernels back to back (seeds, tile lists, consume); `frac` here prices all evaluated pairs "
+                                      "against the three kernels' time, the roofline line above the dominant kernel alone"},
                      "mfma_pipe_frac": achieved * (2 * ks["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
                      "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair (exact count: padding rows are not pairs); "
                              "the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
@@ -341,38 +402,64 @@ def main():
     if traffic is not None:  # what the committed PMC passes of this kernel build say beside the traffic: matrix pipe busy time, L2 hit rate
         out["roofline"].update({"pmc_" + k: v for k, v in _traffic_from_profiles.extra.items()})
     if world == 1 and not args.no_h2d_extra:
-        # the same K steps with the clip in host memory: every step is handed the clip anew (tm_set_frames_host lends it until that
-        # step's Load has returned) and its Load moves 4*W*H*F bytes across PCIe, chunks beside its own kernel
+        # SURVEY.md 8(d)'s metric as it is defined, "H2D/D2H included": the same K steps with the clip in page-locked host memory -- every
+        # step is handed the clip anew (tm_set_frames_host lends it until that step's Load has returned) and its Load moves 4*W*H*F bytes
+        # across PCIe, chunks beside its own kernel -- and with what the reference's consumers read after Run (tilingencoder.pas:486-568:
+        # Frames[i].TileMap of every frame, Tiles, Palettes) copied back into page-locked host buffers inside the timed region.
+        tm_host = torch.empty(F * per * 18, dtype=torch.uint8, pin_memory=True)
+        cap_t = int(T)
+        hdr_host = torch.empty(cap_t * 20, dtype=torch.uint8, pin_memory=True)
+        pal_host = torch.empty(cap_t * 64, dtype=torch.uint8, pin_memory=True)
+        rgb_host = torch.empty(cap_t * 256, dtype=torch.uint8, pin_memory=True)
+        Lc = _lib_fn()
+
+        def read_back():
+            enc.TileMaps(0, F, out=tm_host)
+            nt_ = enc.counts()["tiles"]
+            _check(Lc.tm_get_tiles(ctypes.c_void_p(enc._h), 0, nt_, ctypes.c_void_p(hdr_host.data_ptr()), ctypes.c_void_p(pal_host.data_ptr()),
+                                   ctypes.c_void_p(rgb_host.data_ptr())))
+            enc.Palettes()
+            return F * per * 18 + nt_ * 340 + args.palettes * 16 * 4
+
         def timed_host(nsteps, overlapped):
             if overlapped:
                 enc.PrefetchFramesHost(host_frames)  # the first timed step's clip: its upload belongs to the step before it
             barrier()
             t0 = time.perf_counter()
-            sm = np.zeros(8)
+            sm, d2h_s, d2h_b = np.zeros(8), 0.0, 0
             for _ in range(nsteps):
                 enc.SetFramesHost(host_frames)
                 if overlapped:
                     enc.PrefetchFramesHost(host_frames)  # the NEXT clip starts crossing PCIe now, beside this clip's steps
                 step()
                 sm += enc.StageMs()
+                t1 = time.perf_counter()
+                d2h_b += read_back()
+                d2h_s += time.perf_counter() - t1
             barrier()
-            return time.perf_counter() - t0, sm
+            return time.perf_counter() - t0, sm, d2h_s, d2h_b
         enc.SetFramesHost(host_frames)
         step()
-        dth, sth = timed_host(args.steps, False)
-        out["with_h2d"] = {"value": F * args.steps / dth, "unit": "frames/s", "ms_per_step": dth / args.steps * 1e3,
-                           "h2d_bytes_per_step": 4 * W * H * F, "load_ms": float(sth[0]) / args.steps,
-                           "pcie_gb_s_in_load": 4.0 * W * H * F / (float(sth[0]) / args.steps * 1e-3) / 1e9 if sth[0] > 0 else None,
-                           "note": "tm_set_frames_host before every step: pinned host memory -> HBM inside Load (SURVEY.md 8d's H2D-included reading of one "
-                                   "clip on its own); never `value`"}
-        dto, sto = timed_host(args.steps, True)
-        out["with_h2d_overlapped"] = {"value": F * args.steps / dto, "unit": "frames/s", "ms_per_step": dto / args.steps * 1e3,
-                                      "h2d_bytes_per_step": 4 * W * H * F, "load_ms": float(sto[0]) / args.steps,
-                                      "note": "clips back to back: tm_prefetch_frames_host moves clip n+1 into a second device buffer on the copy stream while "
-                                              "clip n's steps run, and its Load adopts the copies -- every timed step still moves one whole clip across PCIe "
-                                              "(the one issued in the last step is drained inside the timed region); never `value`"}
+        read_back()
+        dth, sth, dh, db = timed_host(args.steps, False)
+        dto, sto, doh, dob = timed_host(args.steps, True)
+        out["with_h2d_d2h"] = F * args.steps / dth
+        out["with_h2d_overlapped_d2h"] = F * args.steps / dto
+        out["transfers"] = {
+            "unit": "frames/s", "h2d_bytes_per_step": 4 * W * H * F, "d2h_bytes_per_step": db // args.steps,
+            "with_h2d_d2h": {"value": F * args.steps / dth, "ms_per_step": dth / args.steps * 1e3, "load_ms": float(sth[0]) / args.steps,
+                             "d2h_ms": dh / args.steps * 1e3, "d2h_gb_s": db / dh / 1e9 if dh > 0 else None,
+                             "pcie_gb_s_in_load": 4.0 * W * H * F / (float(sth[0]) / args.steps * 1e-3) / 1e9 if sth[0] > 0 else None,
+                             "note": "tm_set_frames_host before every step: pinned host memory -> HBM inside Load; tm_get_tilemaps (all frames, one copy), "
+                                     "tm_get_tiles, tm_get_palette after it; one clip on its own; never `value`"},
+            "with_h2d_overlapped_d2h": {"value": F * args.steps / dto, "ms_per_step": dto / args.steps * 1e3, "load_ms": float(sto[0]) / args.steps,
+                                        "d2h_ms": doh / args.steps * 1e3,
+                                        "note": "clips back to back: tm_prefetch_frames_host moves clip n+1 into a second device buffer on the copy stream "
+                                                "while clip n's steps run, and its Load adopts the copies -- every timed step still moves one whole clip across "
+                                                "PCIe (the one issued in the last step is drained inside the timed region) and reads its results back; never `value`"}}
         torch.cuda.synchronize()
         enc.SetFramesDevice(frames)
+        del tm_host, hdr_host, pal_host, rgb_host
     if world == 1 and rank == 0:
         # the peaks measured on this very device: a bare loop of the kernel's MFMA instruction and an HBM stream triad
         tops, gbs = ctypes.c_double(), ctypes.c_double()
@@ -425,18 +512,14 @@ def main():
                                 "most of which is now Reconstruct's query-feature kernel running beside it on the second stream"}
         it = enc.KmeansIters()
         if it["tile_iters"] > 0:
-            # "HBM, points re-read each iteration" -- 3 B per pixel and iteration for the colours (the stage clusters the
-            # DISTINCT colours of a palette with their counts, which is the same arithmetic on fewer points: both figures are given),
-            # 768 B per tile and iteration for the 192-D clustering (its int32 features)
-            b_nominal = 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * it["tile_points"] * it["tile_iters"]
-            b_exec = 12.0 * it["pixel_colour_iters"] + 768.0 * it["tile_points"] * it["tile_iters"]
-            sr["kmeans"] = {"bound": "hbm", "kernel": "k_assign192 / k_h_bounds / k_assign192_list4 / k_h_update (192-D), k_kmeans3_persistent (colours)",
-                            "achieved": b_nominal / st["prepare_palettes"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": b_nominal / st["prepare_palettes"] / 1e6 / HBM_PEAK_GBS, "ms": st["prepare_palettes"], "algorithmic_bytes": b_nominal,
-                            "executed_point_bytes": b_exec, **it,
-                            "note": "nominal = 3 B x pixels x iterations of the slowest palette + 768 B x tiles x iterations; the colours are clustered as "
-                                    "distinct (colour, count) points held in LDS and the tiles' iterations skip what provably cannot change, so the stage is "
-                                    "bound by its ~%d dependent iterations, not by these bytes" % (it["tile_iters"] + it["pixel_iters"])}
+            n_it = it["tile_iters"] + it["pixel_iters"]
+            sr["kmeans"] = {"bound": "latency (dependent iterations)", "kernel": "k_assign192 / k_h_bounds / k_assign192_list4 / k_h_update (192-D), k_kmeans3_persistent (colours)",
+                            "ms": st["prepare_palettes"], "dependent_iterations": n_it, "us_per_iteration": st["prepare_palettes"] * 1e3 / max(n_it, 1), **it,
+                            "nominal_point_bytes": 3.0 * it["pixel_points"] * it["pixel_iters"] + 768.0 * it["tile_points"] * it["tile_iters"],
+                            "note": "SURVEY.md 8(d) prices k-means at 3 B per pixel and iteration (768 B per tile and iteration for the 192-D clustering); the "
+                                    "kernels never move those bytes -- the colours are clustered as distinct (colour, count) points held in LDS and the tiles' "
+                                    "iterations skip what provably cannot change -- so no HBM fraction is claimed: the stage is its dependent iterations "
+                                    "(tile clustering, then the slowest palette's colours) times the microseconds each takes"}
         if not args.no_kmodes_extra:
             # A17's operator at config 5's shape (4K x 600: T = 1 618 022 rows of 80 bytes, 64 clusters): SURVEY.md 8(d) prices it at 80 B per
             # point and iteration against HBM; what bounds it is KModesIter's bin-serial rule (960 points, then the modes move)
@@ -465,7 +548,7 @@ def main():
                             "note": "tm_stage_kmodes_dev (TKModes.ComputeKModes, kmodes.pas:923-1094) on device pointers, 80 B per point and iteration; "
                                     "every bin of 960 points is three dependent launches (score, moves in order, histogram update), which is what the time is"}
             del rows_k
-        sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms")}
+        sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms", "scan")}
         out["stage_rooflines"] = sr
     if world == 1 and not args.no_dense_extra:
         # diagnostic, outside the timed region: the same kernel with pruning off = a dense Q x T_distinct distance GEMM (BASELINE config 3)
@@ -475,7 +558,7 @@ def main():
             enc.Run(s_)
         del os.environ["TM_KNN_NOPRUNE"]
         kd = enc.KnnStats()
-        dense = 384.0 * kd["pairs"] / max(kd["launches"], 1) / (kd["kernel_ms"] / max(kd["launches"], 1) * 1e-3) / 1e12
+        dense = 384.0 * kd["pairs"] / max(kd["launches"], 1) / (kd["kernel_ms"] / max(kd["launches"], 1) * 1e-3) / 1e12  # (dense: the consume kernel is the whole search)
         out["roofline_dense"] = {"bound": "mfma", "achieved": dense, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": dense / I8_DENSE_PEAK_TOPS,
                                  "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
                                  "mfma_pipe_frac_of_measured_peak": (dense * (2 * kd["k_bytes"] / 384.0) / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
@@ -517,15 +600,16 @@ def main():
         r = extra("with_motion_and_extended_palette_usage", MotionPredictRadius=32, FrameTilingExtendedPaletteUsage=True)
         r["note"] = ("the reference's default code paths (motion prediction radius 32 + extended palette usage) at the benchmark's %d palettes; "
                      "the reference's default PaletteCount is 1024 (tilingencoder.pas:3826)" % args.palettes)
-    if world == 1 and args.motion_radius == 0 and not args.no_frozen_extra:
-        # SURVEY.md 8(d)'s literal generator: no frozen tile columns, so no frame tile repeats exactly and every one of them is a KNN query
+    if world == 1 and args.motion_radius == 0 and not args.no_frozen_extra and not args.frozen_columns:
+        # the clip rounds 1-3 were quoted on: the generator plus frozen tile columns (exact inter-frame duplicates, so Reconstruct searches
+        # once per DISTINCT frame tile: 3.24 M of 4.32 M)
         rng2 = np.random.Generator(np.random.PCG64(synth.SEED))
         for f in range(F):
-            hv[f] = synth.frame(f, W, H, rng2, freeze=False).view(np.int32)
+            hv[f] = synth.frame(f, W, H, rng2, freeze=True).view(np.int32)
         frames.copy_(host_frames)
         torch.cuda.synchronize()
         enc.SetFramesDevice(frames)
-        enc.Run()  # untimed: pool growth for the larger query side
+        enc.Run()  # untimed: pool sizes
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         nrep = max(1, min(args.steps, 3))
@@ -536,13 +620,15 @@ def main():
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t1) / nrep
         k2 = enc.KnnStats()
-        out["without_frozen_columns"] = {"value": F / dt1, "unit": "frames/s", "ms_per_step": dt1 * 1e3, "steps": nrep,
-                                         "stage_ms": {n: round(float(v) / nrep, 3) for n, v in zip(STAGES, sm)},
-                                         "knn_queries": int(k2.get("queries", q_total)), "distinct_database_rows": int(k2["db_rows"]),
-                                         "knn_launch_ms": k2["kernel_ms"] / max(k2["launches"], 1), "knn_pairs_per_launch": k2["pairs"] / max(k2["launches"], 1),
-                                         "final_tiles_after_reindex": int(enc.counts()["tiles"]),
-                                         "note": "the headline step on SURVEY.md 8(d)'s generator as written (tiler_amd.synth.frame(freeze=False)): device-resident like "
-                                                 "`value`, not part of it"}
+        out["with_frozen_columns"] = {"value": F / dt1, "unit": "frames/s", "ms_per_step": dt1 * 1e3, "steps": nrep,
+                                      "stage_ms": {n: round(float(v) / nrep, 3) for n, v in zip(STAGES, sm)},
+                                      "knn_queries": int(k2.get("queries", q_total)), "distinct_database_rows": int(k2["db_rows"]),
+                                      "knn_kernels_ms": {"k_knn_seed": k2["seed_ms"] / max(k2["launches"], 1), "k_knn_lists": k2["lists_ms"] / max(k2["launches"], 1),
+                                                         "k_knn_consume": k2["consume_ms"] / max(k2["launches"], 1)},
+                                      "knn_pairs_per_launch": k2["pairs"] / max(k2["launches"], 1),
+                                      "final_tiles_after_reindex": int(enc.counts()["tiles"]),
+                                      "note": "the headline step on the generator PLUS this repo's frozen tile columns (tiler_amd.synth.frame(freeze=True)), the clip "
+                                              "rounds 1-3 quoted `value` on: device-resident like `value`, not part of it"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, F, args.palettes, T, int(ks["db_rows"]))
         visible = out["cpu_baseline"]["host_cpus_visible"]

@@ -111,6 +111,10 @@ TM_API int tm_get_counts(tm_encoder *, int64_t *tiles, int *frames, int *palette
 TM_API int tm_get_tile(tm_encoder *, int64_t i, tm_tile_hdr *hdr, uint8_t pal_px[64], uint32_t rgb_px[64]);
 TM_API int tm_get_tiles(tm_encoder *, int64_t first, int64_t count, tm_tile_hdr *hdrs, uint8_t *pal_px, uint32_t *rgb_px);
 TM_API int tm_get_tilemap(tm_encoder *, int frame, tm_tilemap_item *items /* tm_w*tm_h */);
+/* Frames[first_frame .. first_frame+frame_count-1].TileMap in one call (tilingencoder.pas:178-184, 509-512): the packed 18-byte items are
+ * put together on the device and cross PCIe in one copy (at the link's rate when `items` is page-locked memory); the per-frame form above is
+ * this with frame_count = 1. */
+TM_API int tm_get_tilemaps(tm_encoder *, int first_frame, int frame_count, tm_tilemap_item *items /* frame_count*tm_w*tm_h */);
 TM_API int tm_get_palette(tm_encoder *, int i, int32_t *rgb /* PaletteSize */);
 TM_API int tm_get_keyframes(tm_encoder *, int32_t *start_frames /* keyframes */);
 TM_API int tm_get_frame_correlations(tm_encoder *, float *correl /* frames */);
@@ -196,6 +200,9 @@ TM_API int tm_sync_tilemap(tm_encoder *);
 /* device time (HIP events on the encoder's stream) of the KNN distance kernel over the last Reconstruct */
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */
 TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows);
+/* the same launches kernel by kernel (the scan is three kernels): device ms of k_knn_seed / k_knn_lists / k_knn_consume,
+ * and the (query, row) pairs the seed and the consume kernel evaluated; kernel_ms above is the sum of the three, pairs the sum of the two */
+TM_API int tm_get_knn_kernel_split(tm_encoder *, double ms[3], int64_t pairs[2]);
 /* queries of the last Reconstruct's searches: the DISTINCT frame tiles when Reduce's exact groups can be used (one process, motion
  * prediction off), every tile-map item otherwise */
 TM_API int64_t tm_get_knn_queries(tm_encoder *);

@@ -1,4 +1,5 @@
-"""bench.py --gpus 2 as the driver starts it (python -m torch.distributed.run, one process per rank), rehearsed on ONE device:
+"""bench.py --gpus 2 as the driver starts it (no launcher: bench.py spawns python -m torch.distributed.run itself, one process per rank),
+rehearsed on ONE device:
 TM_BENCH_REHEARSE=1 puts both ranks on the one GPU and the collectives over gloo (RCCL takes one rank per device), so everything of the
 multi-process path runs except RCCL itself -- the rendezvous, the sharding of every step (Load by frames, Reduce by keys, the k-means'
 data-parallel iterations, Dither, Reconstruct with the gathered database), the merges, rank 0's JSON line.  The ranks are FRESH child
@@ -20,6 +21,8 @@ def _bench(args, env=None, launcher=None):
     e = dict(os.environ)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     e.update(env or {})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):  # (a launcher around pytest must not look like one around bench.py)
+        e.pop(k, None)
     cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py")] + args
     p = subprocess.run(cmd, env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -28,10 +31,10 @@ def _bench(args, env=None, launcher=None):
 
 def test_two_ranks_on_one_device_equal_the_single_process():
     small = ["--width", "640", "--height", "360", "--frames", "120", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-motion-extra",
-             "--no-defaults-extra", "--no-dense-extra", "--no-h2d-extra", "--no-frozen-extra", "--no-kmodes-extra"]
+             "--no-defaults-extra", "--no-dense-extra", "--no-h2d-extra", "--no-frozen-extra", "--no-kmodes-extra", "--frozen-columns"]
     one = _bench(["--gpus", "1"] + small)
-    two = _bench(["--gpus", "2"] + small, env={"TM_BENCH_REHEARSE": "1"},
-                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533"])
+    # no launcher around it: `bench.py --gpus 2` starts its two ranks itself, as the driver's command form needs it to
+    two = _bench(["--gpus", "2"] + small, env={"TM_BENCH_REHEARSE": "1"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     for key in ("final_tiles_after_reindex", "global_tiles_T", "query_tiles", "distinct_database_rows"):
         assert two["config"][key] == one["config"][key], key

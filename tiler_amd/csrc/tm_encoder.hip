@@ -7,6 +7,7 @@
 // re-rank, OptimizePalettes, the .gtm writer and reader included); what stays outside the path is listed in DESIGN.md "Scope".
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <fstream>
 #include <map>
@@ -196,6 +197,7 @@ struct tm_encoder {
   hipEvent_t ev_tiles = nullptr;
   DevBuf dcorrel;
   bool load_tail_pending = false;
+  double kf_lo_thres = 0, kf_min_s = 0, kf_max_s = 0, kf_fps = 0;  // ShotTrans* and the frame rate at the time of that Load
   DevBuf ftiles, fflags, flab;   // frame tiles (canonical), mirror flags, Lab means
   DevBuf gtiles, gflags, guse, gpal_idx, gpal_px, palettes_dev;  // global tiles
   DevBuf tm_tile, tm_pal, tm_err;  // tile map, frame-major: TileIdx, PalIdx, error behind PSNR (KNN or motion)
@@ -256,7 +258,7 @@ struct tm_encoder {
   }
   ~tm_encoder() {
     drop_prefetch();
-    if (comm) { (void)hipStreamSynchronize(stream); (void)ncclCommDestroy(comm); }
+    if (comm) { (void)hipStreamSynchronize(stream); (void)ncclCommAbort(comm); }  // (abort = destroy without the collective handshake: no peer is waited for)
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream_km) (void)hipStreamDestroy(stream_km);
@@ -270,6 +272,8 @@ struct tm_encoder {
   double knn_ms = 0;   // device time of the distance kernel, summed over launches of the last Reconstruct
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
+  double knn_split_ms[3] = {0, 0, 0};  // seeds / lists / consume kernels of those launches
+  int64_t knn_split_pairs[2] = {0, 0};
   KmeansRunStats km_stats;  // of the last PreparePalettes (single process: the sharded path runs its own loops)
   int64_t knn_db_rows = 0;  // distinct database rows actually searched
   int64_t knn_queries = 0;  // queries of the last Reconstruct's searches (distinct frame tiles when Reduce's groups are used)
@@ -362,28 +366,49 @@ static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t coun
     const ncclResult_t r_ = (call);                                                                           \
     if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, ncclGetErrorString(r_)); return TM_E_HIP; }  \
   } while (0)
+// The library's communicator is non-blocking (tm_comm_init), so a call on it may answer ncclInProgress: the state is then polled until
+// it settles, for at most TM_COMM_TIMEOUT_S seconds (default 120).
+static ncclResult_t nccl_settle(ncclComm_t comm, ncclResult_t r) {
+  if (r != ncclInProgress) return r;
+  const char *ts = getenv("TM_COMM_TIMEOUT_S");
+  const double limit = ts ? std::max(1.0, atof(ts)) : 120.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t q = ncclCommGetAsyncError(comm, &st);
+    if (q != ncclSuccess) return q;
+    if (st != ncclInProgress) return st;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return ncclSystemError;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+#define TM_NCCLC(comm, call)                                                                                  \
+  do {                                                                                                        \
+    const ncclResult_t r_ = nccl_settle((comm), (call));                                                      \
+    if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, ncclGetErrorString(r_)); return TM_E_HIP; }  \
+  } while (0)
 
 // the four collective kinds on the encoder's stream through the library's own communicator: nothing drains the stream before and
 // nothing waits after -- the RCCL kernel is ordered between what the step queued before and what it queues next
 static void bind_native_collectives(tm_encoder *e) {
   e->co.allreduce_sum_i32 = [e](void *b, int64_t n) -> int {
     e->coll_count(TM_COLL_ALLREDUCE_SUM_I32, n);
-    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclSum, e->comm, e->stream));
+    TM_NCCLC(e->comm, ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclSum, e->comm, e->stream));
     return (int)TM_OK;
   };
   e->co.allreduce_max_i32 = [e](void *b, int64_t n) -> int {
     e->coll_count(TM_COLL_ALLREDUCE_MAX_I32, n);
-    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclMax, e->comm, e->stream));
+    TM_NCCLC(e->comm, ncclAllReduce(b, b, (size_t)n, ncclInt32, ncclMax, e->comm, e->stream));
     return (int)TM_OK;
   };
   e->co.allreduce_sum_i64 = [e](void *b, int64_t n) -> int {
     e->coll_count(TM_COLL_ALLREDUCE_SUM_I64, n);
-    TM_NCCL(ncclAllReduce(b, b, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream));
+    TM_NCCLC(e->comm, ncclAllReduce(b, b, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream));
     return (int)TM_OK;
   };
   e->co.allgather = [e](const void *snd, void *rcv, int64_t bytes) -> int {
     e->coll_count(TM_COLL_ALLGATHER_BYTES, bytes);
-    TM_NCCL(ncclAllGather(snd, rcv, (size_t)bytes, ncclInt8, e->comm, e->stream));
+    TM_NCCLC(e->comm, ncclAllGather(snd, rcv, (size_t)bytes, ncclInt8, e->comm, e->stream));
     return (int)TM_OK;
   };
 }
@@ -448,7 +473,6 @@ static int need_global_rgb(tm_encoder *e, const char *step) {
 // the host tail of Load -- PearsonCorrelation's last lines (2221-2227) and FindKeyFrames (3373-3411) -- once the sums are there
 static int load_tail(tm_encoder *e) {
   if (!e->load_tail_pending) return TM_OK;
-  e->load_tail_pending = false;
   std::vector<float> sums((size_t)e->nframes * 3);
   hipStream_t st = e->stream_aux ? e->stream_aux : e->stream;
   {
@@ -456,6 +480,7 @@ static int load_tail(tm_encoder *e) {
     TM_TRY(hr_.get(sums.data(), e->dcorrel.p, sums.size() * 4));
     TM_TRY(hr_.wait());
   }
+  e->load_tail_pending = false;  // only now: a failed read-back leaves the tail to the next caller instead of stale key frames
   e->correl.assign(e->nframes, 0.0f);
   for (int f = 1; f < e->nframes; f++) {  // tail of PearsonCorrelation (2221-2227) in host IEEE arithmetic
     const float denx = std::sqrt(sums[f * 3 + 1]), deny = std::sqrt(sums[f * 3 + 2]);
@@ -467,9 +492,10 @@ static int load_tail(tm_encoder *e) {
   int64_t last = INT32_MIN;
   for (int f = 0; f < e->nframes; f++) {
     bool kf = f == 0;
-    if (!kf && (double)e->correl[f] < e->s.ShotTransCorrelLoThres) kf = true;
-    if (!kf && (double)(f - last) >= e->s.ShotTransMaxSecondsPerKF * e->fps) kf = true;
-    if ((double)(f - last) < e->s.ShotTransMinSecondsPerKF * e->fps) kf = false;
+    // (the settings as they stood when Load ran: the reference finds its key frames inside Load, 1741-1840)
+    if (!kf && (double)e->correl[f] < e->kf_lo_thres) kf = true;
+    if (!kf && (double)(f - last) >= e->kf_max_s * e->kf_fps) kf = true;
+    if ((double)(f - last) < e->kf_min_s * e->kf_fps) kf = false;
     if (kf) { e->kf_start.push_back(f); last = f; }
   }
   return TM_OK;
@@ -587,6 +613,7 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
     hipStream_t keep = e->stream_aux;
     e->stream_aux = nullptr;  // (the sums sit behind the encoder's own stream here)
     e->load_tail_pending = true;
+    e->kf_lo_thres = e->s.ShotTransCorrelLoThres; e->kf_min_s = e->s.ShotTransMinSecondsPerKF; e->kf_max_s = e->s.ShotTransMaxSecondsPerKF; e->kf_fps = e->fps;
     const int rc = load_tail(e);
     e->stream_aux = keep;
     TM_TRY(rc);
@@ -596,6 +623,7 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
     hipStream_t keep = e->stream_aux;
     e->stream_aux = nullptr;
     e->load_tail_pending = true;
+    e->kf_lo_thres = e->s.ShotTransCorrelLoThres; e->kf_min_s = e->s.ShotTransMinSecondsPerKF; e->kf_max_s = e->s.ShotTransMaxSecondsPerKF; e->kf_fps = e->fps;
     const int rc = load_tail(e);
     e->stream_aux = keep;
     TM_TRY(rc);
@@ -606,6 +634,7 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
     TM_HIP(hipStreamWaitEvent(e->stream_aux, e->ev_tiles, 0));
     TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream_aux));
     e->load_tail_pending = true;
+    e->kf_lo_thres = e->s.ShotTransCorrelLoThres; e->kf_min_s = e->s.ShotTransMinSecondsPerKF; e->kf_max_s = e->s.ShotTransMaxSecondsPerKF; e->kf_fps = e->fps;
   }
   progress(e, TM_STEP_LOAD, 2, 3);
   if (e->auto_tile_count || e->s.GlobalTilingTileCount <= 0) recompute_auto_tile_count(e);
@@ -1046,6 +1075,8 @@ static int step_reconstruct(tm_encoder *e) {
     TM_HIP(hipMemsetAsync(e->tm_pal.p, 0xff, (size_t)e->q * 4, e->stream));
   }
   e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0; e->knn_queries = 0;
+  for (double &v : e->knn_split_ms) v = 0;
+  e->knn_split_pairs[0] = e->knn_split_pairs[1] = 0;
   const bool epu = e->s.FrameTilingExtendedPaletteUsage;
   if (epu) {
     // FrameTilingExtendedPaletteUsage (1559-1610): the 64 nearest rows of the whole database (duplicates included, as
@@ -1164,6 +1195,12 @@ static int step_reconstruct(tm_encoder *e) {
       double ms = 0; int kb = 0; int64_t pairs = 0;
       knn_index_stats(ix, &ms, &kb, &pairs);
       e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
+      {
+        double sm[3]; int64_t sp[2];
+        knn_index_kernel_split(ix, sm, sp);
+        for (int i_ = 0; i_ < 3; i_++) e->knn_split_ms[i_] += sm[i_];
+        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1];
+      }
       hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, gt.as<int32_t>(), e->tm_tile.as<int32_t>());
       hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, ge.as<int32_t>(), e->tm_err.as<int32_t>());
       TM_HIP(hipGetLastError());
@@ -1183,6 +1220,12 @@ static int step_reconstruct(tm_encoder *e) {
       double ms = 0; int kb = 0; int64_t pairs = 0;
       knn_index_stats(ix, &ms, &kb, &pairs);
       e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
+      {
+        double sm[3]; int64_t sp[2];
+        knn_index_kernel_split(ix, sm, sp);
+        for (int i_ = 0; i_ < 3; i_++) e->knn_split_ms[i_] += sm[i_];
+        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1];
+      }
     }
   }
   }
@@ -1783,40 +1826,57 @@ int tm_get_tile(tm_encoder *e, int64_t i, tm_tile_hdr *hdr, uint8_t pal_px[64], 
   return tm_get_tiles(e, i, 1, hdr, pal_px, rgb_px);
 }
 
-int tm_get_tilemap(tm_encoder *e, int frame, tm_tilemap_item *items) {
+// The tile maps as the reference's consumers read them (Frames[i].TileMap, tilingencoder.pas:178-184, 509-512): the packed 18-byte items are
+// put together on the device -- TMI^.PSNR := EuclideanToPSNR(knnErr | mpErr) (1619 / 1644; after PredictMotion alone: of its best error, 1250)
+// in double precision there, compared with a tolerance like every PSNR -- and cross PCIe in ONE copy.
+__global__ __launch_bounds__(256) void k_pack_tilemap(const int32_t *__restrict__ ti, const int32_t *__restrict__ pi, const uint32_t *__restrict__ er,
+                                                      const int8_t *__restrict__ px, const int8_t *__restrict__ py, const uint8_t *__restrict__ pr,
+                                                      const uint8_t *__restrict__ ff, int with_psnr, int64_t n, uint32_t *__restrict__ out) {
+  __shared__ uint32_t s_items[256 * 18 / 4 + 2];
+  const int64_t base = (int64_t)blockIdx.x * 256, i = base + threadIdx.x;
+  if (i < n) {
+    uint8_t *o = reinterpret_cast<uint8_t *>(s_items) + threadIdx.x * 18;
+    const int32_t t = ti[i], p = pi[i];
+    float ps = 0.0f;
+    if (with_psnr) {  // EuclideanToPSNR, utils.pas:1074-1078
+      const float r = (float)((double)er[i] * (1.0 / 192));
+      const float m = r > 0.5f ? r : 0.5f;
+      ps = (float)(10 * log10(255 * 255 / (double)m));
+    }
+    const uint8_t f = ff[i];
+    const uint32_t fl = (f & 1 ? 1u : 0u) | (f & 2 ? 2u : 0u) | ((pr && pr[i]) ? 4u : 0u);
+    memcpy(o, &t, 4); memcpy(o + 4, &p, 4);
+    o[8] = (uint8_t)(px ? px[i] : 0); o[9] = (uint8_t)(py ? py[i] : 0);
+    memcpy(o + 10, &ps, 4); memcpy(o + 14, &fl, 4);
+  }
+  __syncthreads();
+  const int64_t cnt = min((int64_t)256, n - base);
+  const int words = (int)((cnt * 18 + 3) / 4);  // 256 items = 1152 whole words; the last workgroup's tail word is padded inside the staging buffer
+  uint32_t *dst = out + base * 18 / 4;          // base * 18 is a multiple of 4
+  for (int w = threadIdx.x; w < words; w += 256) dst[w] = s_items[w];
+}
+
+int tm_get_tilemaps(tm_encoder *e, int first_frame, int frame_count, tm_tilemap_item *items) {
   TM_CHECK(e && items, TM_E_INVAL, "null argument");
-  TM_CHECK(frame >= 0 && frame < e->nframes && (e->steps_done & 1), TM_E_INVAL, "bad frame %d", frame);
+  TM_CHECK((e->steps_done & 1) && first_frame >= 0 && frame_count >= 0 && first_frame + frame_count <= e->nframes, TM_E_INVAL,
+           "frame range [%d,+%d) outside 0..%d (or no Load yet)", first_frame, frame_count, e->nframes);
+  if (frame_count == 0) return TM_OK;
   TM_HIP(hipSetDevice(e->device));
-  if (e->h_fflags.size() != (size_t)e->q) {
-    e->h_fflags.resize((size_t)e->q);
-    TM_HIP(hipMemcpy(e->h_fflags.data(), e->fflags.p, (size_t)e->q, hipMemcpyDeviceToHost));
-  }
-  const int64_t per = e->tm_size(), off = (int64_t)frame * per;
-  std::vector<int32_t> ti(per), pi(per);
-  std::vector<uint32_t> er(per);
-  TM_HIP(hipMemcpy(ti.data(), e->tm_tile.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
-  TM_HIP(hipMemcpy(pi.data(), e->tm_pal.as<int32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
-  TM_HIP(hipMemcpy(er.data(), e->tm_err.as<uint32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));
-  std::vector<int8_t> px(per, 0), py(per, 0);
-  std::vector<uint8_t> pr(per, 0);
-  if (e->has_pm) {
-    TM_HIP(hipMemcpy(px.data(), e->tm_px.as<int8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
-    TM_HIP(hipMemcpy(py.data(), e->tm_py.as<int8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
-    TM_HIP(hipMemcpy(pr.data(), e->tm_pred.as<uint8_t>() + off, (size_t)per, hipMemcpyDeviceToHost));
-    if (!e->reconstructed) TM_HIP(hipMemcpy(er.data(), e->pm_err.as<uint32_t>() + off, (size_t)per * 4, hipMemcpyDeviceToHost));  // 1250
-  }
-  for (int64_t i = 0; i < per; i++) {
-    items[i].TileIdx = ti[i];
-    items[i].PalIdx = pi[i];
-    items[i].PredictedX = px[i];
-    items[i].PredictedY = py[i];
-    // TMI^.PSNR := EuclideanToPSNR(knnErr | mpErr), 1619 / 1644; after PredictMotion alone: of its best error, 1250
-    items[i].PSNR = (e->reconstructed || e->has_pm) ? euclidean_to_psnr(er[i]) : 0.0f;
-    const uint8_t f = e->h_fflags[(size_t)(off + i)];
-    items[i].Flags = (f & 1 ? 1u : 0u) | (f & 2 ? 2u : 0u) | (pr[i] ? 4u : 0u);
-  }
+  const int64_t per = e->tm_size(), off = (int64_t)first_frame * per, n = per * frame_count;
+  DevBuf pack;
+  TM_TRY(pack.alloc((size_t)n * 18 + 8));
+  const bool pm = e->has_pm;
+  const uint32_t *er = (pm && !e->reconstructed) ? e->pm_err.as<uint32_t>() : e->tm_err.as<uint32_t>();
+  hipLaunchKernelGGL(k_pack_tilemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>() + off, e->tm_pal.as<int32_t>() + off,
+                     er + off, pm ? e->tm_px.as<int8_t>() + off : nullptr, pm ? e->tm_py.as<int8_t>() + off : nullptr,
+                     pm ? e->tm_pred.as<uint8_t>() + off : nullptr, e->fflags.as<uint8_t>() + off, (e->reconstructed || pm) ? 1 : 0, n, pack.as<uint32_t>());
+  TM_HIP(hipGetLastError());
+  TM_HIP(hipMemcpyAsync(items, pack.p, (size_t)n * 18, hipMemcpyDeviceToHost, e->stream));  // page-locked destination: one DMA at PCIe rate
+  TM_HIP(hipStreamSynchronize(e->stream));
   return TM_OK;
 }
+
+int tm_get_tilemap(tm_encoder *e, int frame, tm_tilemap_item *items) { return tm_get_tilemaps(e, frame, 1, items); }
 
 int tm_get_palette(tm_encoder *e, int i, int32_t *rgb) {
   TM_CHECK(e && rgb, TM_E_INVAL, "null argument");
@@ -1900,7 +1960,30 @@ int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, in
   TM_HIP(hipSetDevice(e->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
-  TM_NCCL(ncclCommInitRank(&e->comm, world, u, rank));
+  {
+    // Non-blocking: a rank that never arrives (it failed before this call) must end in an error here, not in a wait without end
+    // (TM_COMM_TIMEOUT_S seconds, default 120).  Later calls on the communicator go through TM_NCCL, which waits out ncclInProgress.
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclResult_t r = ncclCommInitRankConfig(&e->comm, world, u, rank, &cfg);
+    const char *ts = getenv("TM_COMM_TIMEOUT_S");
+    const double limit = ts ? std::max(1.0, atof(ts)) : 120.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (r == ncclInProgress || (r == ncclSuccess && e->comm)) {
+      ncclResult_t st = ncclSuccess;
+      const ncclResult_t q = ncclCommGetAsyncError(e->comm, &st);
+      if (q != ncclSuccess) { r = q; break; }
+      if (st != ncclInProgress) { r = st; break; }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) { r = ncclSystemError; set_error("tm_comm_init: not every one of the %d processes arrived within %.0f s", world, limit); break; }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (r != ncclSuccess) {
+      const std::string why = std::string(get_error());
+      if (e->comm) { (void)ncclCommAbort(e->comm); e->comm = nullptr; }
+      if (why.find("tm_comm_init: not every") == std::string::npos) set_error("ncclCommInitRankConfig failed: %s", ncclGetErrorString(r));
+      return TM_E_HIP;
+    }
+  }
   e->coll_cb = nullptr;
   e->coll_user = nullptr;
   e->coll_stream_ordered = true;
@@ -1927,8 +2010,10 @@ int tm_comm_destroy(tm_encoder *e) {
   TM_CHECK(e, TM_E_INVAL, "null encoder");
   if (!e->comm) return TM_OK;
   TM_HIP(hipStreamSynchronize(e->stream));
+  TM_NCCLC(e->comm, ncclCommFinalize(e->comm));  // (non-blocking communicator: flush what it still holds, then free it)
   TM_NCCL(ncclCommDestroy(e->comm));
   e->comm = nullptr;
+  e->coll_stream_ordered = false;  // a callback installed afterwards gets the default contract: stream drained before, result in place after
   e->force_dist = false;
   e->co = Collectives();
   e->dither_rank = 0;
@@ -1941,6 +2026,7 @@ int tm_set_collective(tm_encoder *e, int rank, int world, tm_collective_cb cb, v
   TM_CHECK(e, TM_E_INVAL, "null encoder");
   TM_CHECK(world >= 1 && rank >= 0 && rank < world && (cb != nullptr || world == 1), TM_E_INVAL, "bad process %d of %d", rank, world);
   TM_CHECK(e->comm == nullptr, TM_E_INVAL, "tm_set_collective: the encoder has a native communicator (tm_comm_destroy first)");
+  e->coll_stream_ordered = false;  // mode 0 until tm_set_collective_mode says otherwise
   e->coll_cb = world > 1 ? cb : nullptr;
   e->coll_user = user;
   e->co.rank = rank;
@@ -1999,6 +2085,13 @@ int tm_get_kmeans_iters(tm_encoder *e, int *tile_iters, int64_t *tile_points, in
   if (pixel_colours) *pixel_colours = e->km_stats.pixel_colours;
   if (pixels) *pixels = e->km_stats.pixels;
   if (pixel_colour_iters) *pixel_colour_iters = e->km_stats.pixel_colour_iters;
+  return TM_OK;
+}
+
+int tm_get_knn_kernel_split(tm_encoder *e, double ms[3], int64_t pairs[2]) {
+  TM_CHECK(e && ms && pairs, TM_E_INVAL, "null argument");
+  for (int i = 0; i < 3; i++) ms[i] = e->knn_split_ms[i];
+  pairs[0] = e->knn_split_pairs[0]; pairs[1] = e->knn_split_pairs[1];
   return TM_OK;
 }
 

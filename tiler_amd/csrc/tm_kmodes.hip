@@ -430,8 +430,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     int64_t far = starts[(size_t)run];
     for (int c = 0; c < k; c++) {
       which[(size_t)c] = far;
-      const uint8_t one = 1;
-      TM_HIP(hipMemcpyAsync(dused.as<uint8_t>() + far, &one, 1, hipMemcpyHostToDevice, stream));
+      TM_HIP(hipMemsetAsync(dused.as<uint8_t>() + far, 1, 1, stream));
       if (c == k - 1) break;
       hipLaunchKernelGGL(k_kmodes_ff, dim3(nblk), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(rows), n, far, dused.as<uint8_t>(), dmind.as<unsigned>(), dpartial.as<u64>());
       TM_HIP(hipGetLastError());
@@ -450,7 +449,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     hipLaunchKernelGGL(k_kmodes_init_tables, dim3((unsigned)std::min<int64_t>((n * KM_ATTRS + 255) / 256, 8192)), dim3(256), 0, stream, rows, n, nmod, st);
     hipLaunchKernelGGL(k_kmodes_init_modes, dim3((unsigned)std::min(k * KM_ATTRS, 2048) + 1), dim3(64), 0, stream, rows, n, k, nmod, st);
     TM_HIP(hipGetLastError());
-    TM_HIP(hipStreamSynchronize(stream));  // `which` and `one` are host memory the copies above read
+    TM_HIP(hipStreamSynchronize(stream));  // `which` is host memory the copy above reads
     int itr = 0, worse = 0, bestitr = 0;
     bool converged = false;
     uint64_t prevcost = ~0ull, bestcost = ~0ull;

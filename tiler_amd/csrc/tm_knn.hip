@@ -22,6 +22,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdlib>
@@ -30,6 +31,8 @@
 #include "tm_internal.h"
 #include "tm_knn_kernel.h"
 #include "tm_knn2_kernel.h"
+#define TM_KNN3_WITH_LISTS
+#include "tm_knn3_kernel.h"
 
 namespace tmx {
 
@@ -577,15 +580,22 @@ struct tm_knn_index_impl {
   DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
   DevBuf tccol, qccol;                              // the rows' three curve columns (k_row_radial -> k_curve_keys)
   DevBuf qmeta;                                     // per query sub-tile: box + home tile (second scan shape)
+  // third scan shape: what the seed kernel leaves for the other two (bests, tie values, bounds) and the groups' tile lists
+  DevBuf gbest, gtie, gsmax, segs, nsegs, arena_tile, arena_lb;
+  uint64_t arena_cap = 0, arena_want = 0;           // list entries the arena holds / the largest cursor a search has reported
+  hipEvent_t ev_seed = nullptr, ev_lists = nullptr;
+  double last_seed_ms = 0, last_lists_ms = 0, last_consume_ms = 0;
   int64_t last_blocks = 0, last_loads = 0, last_listed = 0;
   int64_t last_visited = 0, last_ties = 0;
   double last_ms = 0;
   int last_kbytes = 0;
-  int64_t last_pairs = 0;
+  int64_t last_pairs = 0, last_seed_pairs = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~tm_knn_index_impl() {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_seed) (void)hipEventDestroy(ev_seed);
+    if (ev_lists) (void)hipEventDestroy(ev_lists);
   }
 };
 
@@ -859,6 +869,75 @@ static void launch_scan2(int ht, int hq, const Knn2Args &a, hipStream_t stream) 
   }
 }
 
+#define TM_KNN3_BY_HT(FN)                                          \
+  switch (ht) {                                                      \
+    case 0: FN<0>(hq, a, stream); break;                             \
+    case 1: FN<1>(hq, a, stream); break;                             \
+    case 2: FN<2>(hq, a, stream); break;                             \
+    case 3: FN<3>(hq, a, stream); break;                             \
+    case 4: FN<4>(hq, a, stream); break;                             \
+    case 5: FN<5>(hq, a, stream); break;                             \
+    default: FN<6>(hq, a, stream); break;                            \
+  }
+static std::atomic<double> g_list_entries_per_group{640.0};
+static void launch_seed3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_seed_ht) }
+static void launch_consume3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_consume_ht) }
+
+static int device_cus() {  // compute units of the current device (persistent kernels launch one workgroup per CU)
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    ncu = std::max(1, prop.multiProcessorCount);
+  }
+  return ncu;
+}
+
+// The third scan shape (tm_knn3_kernel.h): seeds -> lists -> consume, all queued on `stream`; the host looks at nothing in between.  The
+// list arena is sized from experience (640 entries per group to begin with; the bench clip needs ~400); a search whose lists did not fit
+// is told so by the cursor it reads back with its other counters (knn_index_search) and runs again with the arena the cursor asks for.
+static int launch_scan3(tm_knn_index_impl *ix, int64_t nq, int64_t nqt, int64_t ntt, int prune, const KnnBoxes &bx, unsigned long long *stats, hipStream_t stream) {
+  const int ns = knn3_sub_tiles(ix->plan.hq), nsp = (ns + 1) & ~1;
+  Knn3Args a;
+  a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
+  a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
+  a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
+  a.ns = ns; a.mode = prune ? K3_MODE_LISTS : K3_MODE_DENSE; a.tdouble = ix->plan.tscale == 2;
+  a.n_groups = (nqt + ns - 1) / ns;
+  a.max_segs = (int)(ntt / (K3_LCAP - K3_LIST_NT) + 2);  // every segment but a list's last holds more than K3_LCAP - K3_LIST_NT entries
+  if (prune) {
+    TM_TRY(ix->gbest.alloc((size_t)nqt * 32 * 8)); TM_TRY(ix->gtie.alloc((size_t)nqt * 32 * 4)); TM_TRY(ix->gsmax.alloc((size_t)nqt * 4));
+    TM_TRY(ix->segs.alloc((size_t)a.n_groups * a.max_segs * 8)); TM_TRY(ix->nsegs.alloc((size_t)a.n_groups * 4));
+    // entries per group: what the process's searches have needed so far (+ 30 %), 640 to begin with -- an index lives for one Reconstruct,
+    // the experience is kept beside it
+    const uint64_t want = std::max<uint64_t>(ix->arena_want, std::max<uint64_t>(1u << 16, (uint64_t)((double)a.n_groups * g_list_entries_per_group.load())));
+    TM_CHECK(want < (1ull << 32), TM_E_UNSUPPORTED, "knn: %llu list entries exceed the arena's 32-bit offsets", (unsigned long long)want);
+    TM_TRY(ix->arena_tile.alloc((size_t)want * 4)); TM_TRY(ix->arena_lb.alloc((size_t)want * nsp * 2));  // (no-ops while they are large enough)
+    ix->arena_cap = want;
+  }
+  a.gbest = ix->gbest.as<unsigned long long>(); a.gtie = ix->gtie.as<unsigned>(); a.gsmax = ix->gsmax.as<unsigned>();
+  a.segs = ix->segs.as<uint2>(); a.nsegs = ix->nsegs.as<int>();
+  a.ltile = ix->arena_tile.as<unsigned>(); a.llb = ix->arena_lb.as<uint16_t>(); a.arena_cap = ix->arena_cap;
+  a.arena_cursor = stats + 18;  // (bytes 160.. of the counters: behind the group tickets)
+  a.best_key = ix->best_key.as<int>(); a.best_tile = ix->best_tile.as<int>(); a.stats = stats;
+  a.seed_stats = reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 256);
+  a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)device_cus() * K3_WGS);
+  a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
+  if (prune) {
+    launch_seed3(ix->plan.ht, ix->plan.hq, a, stream);
+    TM_HIP(hipEventRecord(ix->ev_seed, stream));
+    hipLaunchKernelGGL(k_knn_lists, dim3((unsigned)a.n_groups), dim3(K3_LIST_NT), 0, stream, a);
+    TM_HIP(hipEventRecord(ix->ev_lists, stream));
+  } else {
+    TM_HIP(hipEventRecord(ix->ev_seed, stream));
+    TM_HIP(hipEventRecord(ix->ev_lists, stream));
+  }
+  launch_consume3(ix->plan.ht, ix->plan.hq, a, stream);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
 int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_index_impl **out) {
   TM_TRY(require_device());
   TM_CHECK(nt >= 0, TM_E_INVAL, "knn: negative row count");
@@ -866,7 +945,8 @@ int knn_index_create(const void *db, int64_t nt, hipStream_t stream, tm_knn_inde
   ix->db = (const int16_t *)db;
   ix->nt = nt;
   int rc = col_stats(db, nt, &ix->tstats, ix->scratch, stream);
-  if (rc == TM_OK && (hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess)) {
+  if (rc == TM_OK && (hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess || hipEventCreate(&ix->ev_seed) != hipSuccess ||
+                      hipEventCreate(&ix->ev_lists) != hipSuccess)) {
     set_error("hipEventCreate failed");
     rc = TM_E_HIP;
   }
@@ -1013,10 +1093,11 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->best_key.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
-  TM_TRY(ix->counters.alloc(256));  // [4..15]: phase stamps of a diagnostic build; bytes 128..159: the second scan shape's group tickets
-  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256, stream));
+  TM_TRY(ix->counters.alloc(256 + 2048));  // [4..15]: phase stamps of a diagnostic build; bytes 128..159: the group tickets; bytes 256..: the seed kernel's striped counters
   const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
-  const bool v1 = getenv("TM_KNN_V1") != nullptr;  // the first scan shape (tm_knn_kernel.h), kept for A/B runs; the k-nearest scans still use it
+  // the scan's shape: 3 = seeds / lists / consume (tm_knn3_kernel.h); 2 = round 2-3's single kernel, 1 = round 1's, both kept for A/B runs
+  const int shape = getenv("TM_KNN_V1") ? 1 : getenv("TM_KNN_V2") ? 2 : 3;
+  const bool v1 = shape == 1;
   int *bt = ix->best_tile.as<int>();
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
@@ -1031,8 +1112,14 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
                        ix->qmeta.as<int>());
     TM_HIP(hipGetLastError());
   }
+  int flag = 0;
+  unsigned long long cnt[32 + 256] = {0};
+  for (int attempt = 0;; attempt++) {
+  TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256 + 2048, stream));
   TM_HIP(hipEventRecord(ix->ev0, stream));
-  if (!v1) {
+  if (shape == 3) {
+    TM_TRY(launch_scan3(ix, nq, nqt, ntt, prune, bx, stats, stream));
+  } else if (shape == 2) {
     const int ns = knn2_sub_tiles(ix->plan.hq);
     Knn2Args a;
     a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
@@ -1040,17 +1127,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
     a.prune = prune; a.tdouble = ix->plan.tscale == 2; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
     a.n_groups = (nqt + ns - 1) / ns;
-    {
-      static int ncu = 0;  // one persistent workgroup per CU
-      if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        TM_HIP(hipGetDevice(&dev));
-        TM_HIP(hipGetDeviceProperties(&prop, dev));
-        ncu = std::max(1, prop.multiProcessorCount);
-      }
-      a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)ncu * K2_WGS);
-    }
+    a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)device_cus() * K2_WGS);
     a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
     launch_scan2(ix->plan.ht, ix->plan.hq, a, stream);
   } else
@@ -1072,32 +1149,68 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
                        (const uint32_t *)out_err);
     TM_HIP(hipGetLastError());
   }
-  int flag = 0;
-  unsigned long long cnt[32] = {0};
   {
     HostRead hr_(stream);
     TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
-    TM_TRY(hr_.get(cnt, ix->counters.p, 256));
+    TM_TRY(hr_.get(cnt, ix->counters.p, 256 + 2048));
     TM_TRY(hr_.wait());
+  }
+  cnt[12] = cnt[13] = cnt[14] = 0;  // the seed kernel's blocks, tiles read, pairs: summed over its 64 striped slots
+  for (int i = 0; i < 64; i++) { cnt[12] += cnt[32 + i * 4]; cnt[13] += cnt[32 + i * 4 + 1]; cnt[14] += cnt[32 + i * 4 + 2]; }
+  if (shape == 3 && prune) {  // remember what the lists needed (never below the starting guess: a small search says little about the next)
+    const int ns_ = knn3_sub_tiles(ix->plan.hq);
+    const double per = 1.3 * (double)cnt[20] / (double)std::max<int64_t>(1, (nqt + ns_ - 1) / ns_);
+    double cur = g_list_entries_per_group.load();
+    while (per > cur && !g_list_entries_per_group.compare_exchange_weak(cur, per)) {}
+  }
+  if (shape == 3 && prune && cnt[20] > ix->arena_cap) {  // the tile lists did not fit the arena: the cursor says what they need
+    TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
+    if (getenv("TM_KNN_DEBUG")) fprintf(stderr, "[tm_knn] list arena: %llu entries needed, %llu held -- searching again\n", cnt[20], (unsigned long long)ix->arena_cap);
+    ix->arena_want = cnt[20] + cnt[20] / 4;
+    continue;
+  }
+  break;
   }
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   float ms = 0;
   TM_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
   ix->last_ms = ms;
+  if (shape == 3) {  // the three kernels on their own (ev0 | seeds | ev_seed | lists | ev_lists | consume | ev1)
+    float a_ = 0, b_ = 0, c_ = 0;
+    TM_HIP(hipEventElapsedTime(&a_, ix->ev0, ix->ev_seed));
+    TM_HIP(hipEventElapsedTime(&b_, ix->ev_seed, ix->ev_lists));
+    TM_HIP(hipEventElapsedTime(&c_, ix->ev_lists, ix->ev1));
+    ix->last_seed_ms = a_; ix->last_lists_ms = b_; ix->last_consume_ms = c_;
+  } else {
+    ix->last_seed_ms = ix->last_lists_ms = 0; ix->last_consume_ms = ms;
+  }
   ix->last_kbytes = 192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
   ix->last_visited = (int64_t)cnt[2];
   ix->last_ties = (int64_t)(cnt[0] & 0xffffffffull);
   // pairs actually evaluated: exact (real query, real row) pairs from the second scan shape; the first counts whole 32 x 32 blocks
-  ix->last_pairs = v1 ? ix->last_visited * 1024 : (int64_t)cnt[4];
-  ix->last_blocks = (int64_t)cnt[2]; ix->last_loads = (int64_t)cnt[3]; ix->last_listed = v1 ? 0 : (int64_t)cnt[5];
+  ix->last_pairs = v1 ? ix->last_visited * 1024 : (int64_t)(cnt[4] + cnt[14]);  // (cnt[12..14]: the third shape's seed kernel)
+  ix->last_seed_pairs = (int64_t)cnt[14];
+  ix->last_blocks = (int64_t)(cnt[2] + cnt[12]); ix->last_loads = (int64_t)(cnt[3] + cnt[13]); ix->last_listed = v1 ? 0 : (int64_t)cnt[5];
   if (getenv("TM_KNN_DEBUG")) {
-    const int64_t groups = v1 ? (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW) : (nqt + knn2_sub_tiles(ix->plan.hq) - 1) / knn2_sub_tiles(ix->plan.hq);
+    const int nsg = shape == 3 ? knn3_sub_tiles(ix->plan.hq) : knn2_sub_tiles(ix->plan.hq);
+    const int64_t groups = v1 ? (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW) : (nqt + nsg - 1) / nsg;
+    if (shape == 3) fprintf(stderr, "[tm_knn] v3: seeds %.3f ms, lists %.3f ms (%.1f entries per group, arena %.0f %% full), consume %.3f ms\n", ix->last_seed_ms, ix->last_lists_ms,
+                            (double)cnt[20] / (double)groups, 100.0 * (double)cnt[20] / (double)std::max<uint64_t>(1, ix->arena_cap), ix->last_consume_ms);
     fprintf(stderr, "[tm_knn] %s kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (%lld blocks; workgroups read %.3f%% of tiles, %.1f per group; %.1f list entries per group), %lld tie settlements\n",
-            v1 ? "v1" : "v2", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)cnt[2],
-            100.0 * (double)cnt[3] / ((double)groups * (double)ntt), (double)cnt[3] / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);
+            v1 ? "v1" : shape == 2 ? "v2" : "v3", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)ix->last_blocks,
+            100.0 * (double)ix->last_loads / ((double)groups * (double)ntt), (double)ix->last_loads / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);
   }
+#if TM_KNN3_STAMPS
+  if (shape == 3) {
+    static const char *names3[6] = {"prologue", "segment load", "consume", "end-of-segment wait", "results", "total"};
+    for (int i = 0; i < 6; i++) fprintf(stderr, "[tm_knn3 stamps] %-24s %6.2f %% of the consume kernel's wave time\n", names3[i], 100.0 * (double)cnt[6 + i] / (double)cnt[11]);
+    static const char *names_s[7] = {"set-up", "wait: first slice + tile", "wait: later slices", "blocks", "end barrier", "results", "total"};
+    for (int i = 0; i < 7; i++) fprintf(stderr, "[tm_knn3 stamps] seeds: %-24s %6.2f %% of wave time (%.0f clock ticks per wave)\n", names_s[i], 100.0 * (double)cnt[22 + i] / (double)cnt[28],
+                                        (double)cnt[22 + i] / (8.0 * (double)((nqt + knn3_sub_tiles(ix->plan.hq) - 1) / knn3_sub_tiles(ix->plan.hq))));
+  }
+#endif
 #if TM_KNN2_STAMPS
-  if (!v1) {
+  if (shape == 2) {
     static const char *names2[10] = {"prologue", "list building", "consume seeds", "consume lists", "end-of-list wait (seeds)", "end-of-list wait (lists)",
                                      "  of consume: pop next", "  of consume: pop + tile landed", "results", "total"};
     for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn2 stamps] %-32s %6.2f %% of wave time\n", names2[i], 100.0 * (double)cnt[6 + i] / (double)cnt[15]);
@@ -1246,6 +1359,11 @@ int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq
   return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
 }
 
+void knn_index_kernel_split(tm_knn_index_impl *ix, double ms[3], int64_t pairs[2]) {
+  ms[0] = ix->last_seed_ms; ms[1] = ix->last_lists_ms; ms[2] = ix->last_consume_ms;
+  pairs[0] = ix->last_seed_pairs; pairs[1] = ix->last_pairs - ix->last_seed_pairs;
+}
+
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs) {
   if (ms) *ms = ix->last_ms;
   if (kbytes) *kbytes = ix->last_kbytes;
@@ -1253,5 +1371,6 @@ void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pa
 }
 
 int knn2_sub_tiles(int hq) { return k2_ns(6 + std::min(std::max(hq, 0), 6)); }
+int knn3_sub_tiles(int hq) { return k3_ns(6 + std::min(std::max(hq, 0), 6)); }
 
 }  // namespace tmx

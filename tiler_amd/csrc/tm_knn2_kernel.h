@@ -54,6 +54,9 @@ constexpr int K2_XCD_RUN = 32 * K2_WGS;  // workgroups that run together on one 
 #ifndef TM_KNN2_REFRESH
 #define TM_KNN2_REFRESH 1  // when a sub-tile's bound is made anew: 0 on every improvement, 1 when the improved query may have held the maximum, 2 = 1 + every eighth block
 #endif
+#ifndef TM_KNN2_XCD_CONTIG
+#define TM_KNN2_XCD_CONTIG 0
+#endif
 #ifndef TM_KNN2_STAMPS
 #define TM_KNN2_STAMPS 0  // diagnostic build: s_memtime spans of the phases, summed over all waves into stats[4..]
 #endif
@@ -237,8 +240,14 @@ __global__ __launch_bounds__(K2_NT) void k_knn_scan2(const Knn2Args a) {
     for (int k = 0; k < 8 && gsel < 0; k++) {
       const unsigned x = (xcc + k) & 7u;
       const unsigned t = atomicAdd(&a.tickets[x], 1u);
+#if TM_KNN2_XCD_CONTIG
+      const int64_t per = (a.n_groups + 7) / 8;  // every XCD walks one contiguous eighth of the curve, group after group
+      const int64_t gg = (int64_t)x * per + t;
+      if ((int64_t)t < per && gg < a.n_groups) gsel = gg;
+#else
       const int64_t gg = ((int64_t)(t / K2_XCD_RUN) * 8 + x) * K2_XCD_RUN + (t % K2_XCD_RUN);
       if (gg < a.n_groups) gsel = gg;
+#endif
     }
     s_ctl[3] = (int)gsel;
   }

@@ -1,0 +1,674 @@
+// tm_knn3_kernel.h -- the nearest-neighbour scan of the KNN stage, third shape ("KNN"): three kernels instead of one.
+//
+// The second shape (tm_knn2_kernel.h, round 2-3) did everything in one persistent kernel: a workgroup loaded its 384 queries, scored the
+// tiles around its position on the curve, built tile lists with all 1024 threads, consumed them, built the next ... and its phase stamps
+// showed 21 % of the wave time in phases where the matrix pipe has nothing to do (list building 10.8 %, the wait for the slowest wave at
+// every list's end 6.8 %, prologue 3.7 %).  Here each phase is a kernel of its own, shaped for what it does:
+//   1. k_knn_seed    every query sub-tile against the K3_SEEDS database tiles around its group's position on the curve: bests (one 64-bit
+//                    word per query), tie values, and the sub-tile's bound sqrt(largest best) -- MFMA work with no list in sight, several
+//                    workgroups per CU.
+//   2. k_knn_lists   the tile list of every query group, judged against the seeds' bounds: runs of KNN_GROUP tiles first, then the tiles of
+//                    surviving runs; per entry the box lower bound of each (tile, sub-tile) pair as a 16-bit square root.  No MFMA, no query
+//                    operands: small workgroups, many per CU, whose global loads hide behind each other.  Lists go to an arena in HBM in
+//                    segments of <= K3_LCAP entries.
+//   3. k_knn_consume persistent workgroups (one per CU, 16 waves): a group's query operands and its seeds' bests into LDS, then one list
+//                    segment after the other: copied into LDS, consumed by the waves on their own exactly as in the second shape (pop an
+//                    entry, re-judge it against the sub-tiles' bounds AS THEY ARE NOW, tile into registers, one MFMA chain per sub-tile
+//                    that wants it).  An entry judged with the seeds' bound instead of a later, tighter one costs one pop, not a block.
+// Arithmetic, operands, boxes, curve and the exactness argument are those of the earlier shapes: a pair is skipped only when its lower
+// bound exceeds the sub-tile's largest best + 1 (both sides of the 16-bit compare rounded the safe way), the minimum VALUE is exact, a
+// second row reaching it raises the tie flag that k_knn_ties settles by original index.
+#pragma once
+#include "tm_knn_kernel.h"
+
+namespace tmx {
+
+#ifndef TM_KNN3_WAVES
+#define TM_KNN3_WAVES 16  // consume: 16 = one workgroup per CU; 8 = two (half the LDS each, fewer sub-tiles per group)
+#endif
+constexpr int K3_NW = TM_KNN3_WAVES;
+constexpr int K3_NT = K3_NW * 64;
+constexpr int K3_WGS = 16 / K3_NW;       // consume workgroups per CU (they split its LDS)
+constexpr int K3_LDS = 163840 / K3_WGS;
+constexpr int K3_LCAP = 1024;            // entries of a list segment (what the consume kernel holds in LDS at a time)
+#ifndef TM_KNN3_SEEDS
+#define TM_KNN3_SEEDS 8
+#endif
+constexpr int K3_SEEDS = TM_KNN3_SEEDS;  // tiles around the group's position on the curve, scored first by every sub-tile
+#ifndef TM_KNN3_XCD_CONTIG
+#define TM_KNN3_XCD_CONTIG 0             // 1: every XCD walks one contiguous eighth of the groups (measured: no change in L2 hits)
+#endif
+constexpr int K3_XCD_RUN = 32 * K3_WGS;  // groups dealt to one XCD at a time (neighbours on the curve)
+#ifndef TM_KNN3_REFRESH_EVERY
+#define TM_KNN3_REFRESH_EVERY 64         // consume: list entries between two full refreshes of the sub-tiles' bounds (a power of two; 0 = never)
+#endif
+#ifndef TM_KNN3_STAMPS
+#define TM_KNN3_STAMPS 0                 // diagnostic build: s_memtime spans of the consume kernel's phases, summed over all waves
+#endif
+#if TM_KNN3_STAMPS
+#define K3_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define K3_STAMP(i) do { } while (0)
+#endif
+constexpr int K3_LIST_NT = 256;          // threads of a list-building workgroup
+
+constexpr int k3_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 64 + 64 + K3_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
+constexpr int k3_ns(int kq) {
+  int ns = 16;
+  while (ns > 1 && k3_lds_bytes(ns, kq) > K3_LDS) ns--;
+  return ns;
+}
+
+enum { K3_MODE_LISTS = 0, K3_MODE_DENSE = 1 };
+
+struct Knn3Args {
+  const uint8_t *tpack; int64_t n_ttiles, nt_rows;
+  const int *box_lo, *box_hi, *grp_lo, *grp_hi;  // database tile boxes [KNN_ND][n_ttiles], boxes of runs of KNN_GROUP tiles
+  const uint8_t *qpack; int64_t n_qtiles, nq;
+  const int *qmeta;             // [n_qtiles][16]: box lo[7], home tile, box hi[7], pad
+  int ns;                       // sub-tiles per group (k3_ns of the queries' digit plan)
+  int mode;                     // consume: K3_MODE_LISTS / K3_MODE_DENSE (every tile, every sub-tile; no seeds, no lists)
+  int tdouble;                  // the database pack holds the digits of 2 (t - c)
+  // between the kernels (HBM)
+  unsigned long long *gbest;    // [n_qtiles * 32] (d'' + 1) << 32 | sorted row
+  unsigned *gtie;               // [n_qtiles * 32] smallest d'' + 1 seen twice
+  unsigned *gsmax;              // [n_qtiles] upper bound of sqrt(largest best + 1) of the sub-tile, 0xFFFE = some query has none
+  uint2 *segs;                  // [n_groups][max_segs] (first entry, entries) of each list segment
+  int *nsegs;                   // [n_groups]
+  int max_segs;
+  unsigned *ltile;              // arena [arena_cap] tile of each entry
+  uint16_t *llb;                // arena [arena_cap][nsp] lower bounds per sub-tile slot
+  unsigned long long arena_cap; // entries
+  unsigned long long *arena_cursor;  // entries handed out (keeps counting past the capacity: the host sizes the next arena from it)
+  int *best_key, *best_tile;
+  unsigned long long *stats;    // consume: [0] blocks evaluated, [1] tiles read, [2] exact (query, row) pairs, [3] list entries consumed
+  unsigned long long *seed_stats;  // [64][4] striped by workgroup: blocks, tiles read, pairs of the seed kernel
+  int64_t n_groups;
+  int grid_blocks;              // consume: persistent workgroups
+  unsigned *tickets;            // [8] zeroed before the consume launch: next run-slot of each XCD's share of the groups
+};
+
+__device__ __forceinline__ unsigned k3_wave_umax(unsigned x) {  // max over lanes 0..31 (every lane of a row of 16 ends with its row's)
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, true));
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, true));
+  return max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16));
+}
+
+// a fresh look at an LDS word other waves update (relaxed workgroup-scope load: a plain ds_read_b32 the compiler may not cache)
+__device__ __forceinline__ unsigned k3_peek(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// largest r with r * r <= x (x < 2^31): the hardware's approximate root (within one unit of the last place, i.e. well within one of
+// the integer root here) set right by one step either way
+__device__ __forceinline__ unsigned k3_isqrt(unsigned x) {
+  unsigned r = (unsigned)__builtin_amdgcn_sqrtf((float)x);
+  r += ((r + 1u) * (r + 1u) <= x) ? 1u : 0u;
+  r -= (r * r > x) ? 1u : 0u;
+  return r;
+}
+
+// the bound a sub-tile's tiles are judged against, from its largest best mx = d'' + 1 (an SSD bound): an upper bound of its square root
+__device__ __forceinline__ unsigned k3_bound_of(unsigned mx) { return mx == ~0u ? 0xFFFEu : min(0xFFFEu, (unsigned)__builtin_amdgcn_sqrtf((float)mx) + 3u); }
+
+// One block's chain: X over the digit products on one accumulator shifted between the phases; with TD (database digits of 2 (t - c)) the
+// rows' own term |t-c|^2 rides in on the second shift and the chain ends in 2 X + |t-c|^2.  `q` = the sub-tile's B operands in LDS at this
+// lane's 16 bytes (chunk stride 1024).
+template <int HT, int HQ, bool TD>
+__device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q) {
+  constexpr int HM = HT < HQ ? HT : HQ;
+  v16i acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0;
+  if (TD && HT + HQ == 0) acc = ntr;  // a single phase: the rows' term is the chain's starting value
+  if (HM > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HM; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+  }
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HQ; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
+#pragma unroll
+    for (int kc = 0; kc < HT; kc++)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+  }
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++)
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);              // T_L . Q_L
+  return acc;
+}
+
+// a tile's MFMA A operands and the rows' norms, straight into registers (global_load_dwordx4, 1 KB contiguous per instruction)
+template <int KT>
+__device__ __forceinline__ void k3_load_tile(const uint8_t *tb, int lane, int half, v4i (&T)[KT], v16i &ntr) {
+#pragma unroll
+  for (int kc = 0; kc < KT; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; q4++) {  // |t-c|^2 of accumulator row r: (r&3) + 8*(r>>2) + 4*half
+    const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
+    ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
+  }
+}
+
+// A block's epilogue: the row minimum of each query (lane & 31; the two half-waves hold 16 rows each) against its running best in LDS.
+// d'' = 2 X + |t-c|^2 + 2 (|q-c|^2 >> 1) = SSD - parity.  Returns true in lanes whose improvement may have lowered the sub-tile's largest
+// best (the caller refreshes the bound when any lane says so); `sm_now` = the sub-tile's published bound, or 0 to ask for a refresh on
+// every improvement.
+template <bool TD>
+__device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, int tile, int half, unsigned qn, unsigned long long *best, unsigned *tie,
+                                            unsigned sm_now) {
+  int t[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
+  const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
+                     min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
+  const unsigned key_hi = (unsigned)tm + qn + 1u;  // d'' + 1 >= 0
+  const unsigned cur_hi = k3_peek(reinterpret_cast<unsigned *>(best) + 1);
+  bool refresh = false;
+  if (key_hi <= cur_hi) {
+    // which row (the first one reaching the minimum), and is it alone: a compare, a select and an add-with-carry per register
+    int ridx = 0;
+    unsigned cnt = 0;
+#pragma unroll
+    for (int r = 15; r >= 0; r--) {
+      const bool e = t[r] == tm;
+      ridx = e ? r : ridx;
+      cnt += e ? 1u : 0u;
+    }
+    const int row = (ridx & 3) + ((ridx & 12) << 1) + 4 * half;
+    const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
+    const unsigned long long pre = atomicMin(best, key);
+    const unsigned pre_hi = (unsigned)(pre >> 32);
+    if (pre_hi == key_hi || cnt > 1) atomicMin(tie, key_hi);  // the value was reached a second time
+    // The sub-tile's largest best can only have moved if this query held it: its old best is then no smaller than what the published
+    // bound was made from ((bound - 3)^2; a bound of 0xFFFE stands for "some query has no best yet").  A refresh skipped by a race only
+    // leaves the bound loose (and is made good at the end of the segment).
+    const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
+    refresh = key_hi < pre_hi && pre_hi >= thr;
+  }
+  return refresh;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ 1. seeds
+// One workgroup (8 waves) per query group: wave w holds seed tile w in registers; the group's sub-tiles pass through LDS three at a time
+// (double buffered, LDS-DMA), every wave scoring each against its tile.  Bests meet in LDS (64-bit atomic minimum per query) and leave as
+// gbest / gtie / gsmax.  ~62 KB of LDS: two workgroups per CU, 100 registers per wave.
+constexpr int K3_SEED_SLICE = 3;
+template <int HT, int HQ, bool TD>
+__global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a) {
+  constexpr int KT = 6 + HT, KQ = 6 + HQ;
+  constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
+  constexpr int SL = K3_SEED_SLICE, NW = K3_SEEDS;
+  __shared__ __attribute__((aligned(16))) uint8_t s_q[2][SL * KQ * 1024];
+  __shared__ unsigned long long s_best[16 * 32];
+  __shared__ unsigned s_tie[16 * 32];
+  __shared__ int s_qn[16 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+  const int NS = a.ns;
+  const int64_t g = blockIdx.x, st0 = g * NS;
+  const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
+  const int home = a.qmeta[st0 * 16 + 7];
+  const int r0a = (int)max((int64_t)0, min((int64_t)home - (K3_SEEDS / 2 - 1), a.n_ttiles - K3_SEEDS));
+  const int n_seed = (int)min((int64_t)K3_SEEDS, a.n_ttiles - r0a);
+  auto stage = [&](int slice, int buf) {  // the slice's query operands, SL * KQ pieces of 1 KB over the waves
+    for (int piece = wave; piece < SL * KQ; piece += NW) {
+      const int s = piece / KQ, kc = piece - s * KQ;
+      const int64_t st = min(st0 + slice * SL + s, a.n_qtiles - 1);
+      const uint8_t *src = a.qpack + st * (int64_t)Q_BYTES + kc * 1024 + lane * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(&s_q[buf][piece * 1024]), 16, 0, 0);
+    }
+  };
+#if TM_KNN3_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = st_last;
+#endif
+  stage(0, 0);
+  for (int i = tid; i < NS * 32; i += NW * 64) {
+    const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
+    s_qn[i] = reinterpret_cast<const int *>(a.qpack + st * (int64_t)Q_BYTES + KQ * 1024)[i & 31] & ~1;
+    s_best[i] = ~0ull;
+    s_tie[i] = ~0u;
+  }
+  const bool active = wave < n_seed;
+  const int tile = r0a + (active ? wave : 0);
+  v4i T[KT];
+  v16i ntr;
+  k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
+  const int n_slices = (nvalid + SL - 1) / SL;
+  long long nblocks = 0, npairs = 0;
+  const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
+  K3_STAMP(0);  // set-up: addresses, the tile's loads issued
+  for (int sl = 0; sl < n_slices; sl++) {
+    __syncthreads();  // slice sl has landed (the barrier waits for the LDS-DMA pieces); buffer (sl + 1) & 1 is no longer read
+    K3_STAMP(sl == 0 ? 1 : 2);  // waiting for the first slice (and the tile) / for a later slice and the other waves
+    if (sl + 1 < n_slices) stage(sl + 1, (sl + 1) & 1);
+    if (active) {
+      for (int j = 0; j < SL && sl * SL + j < nvalid; j++) {
+        const int s = sl * SL + j;
+        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16);
+        const int qi = s * 32 + (lane & 31);
+        k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], 0u);
+        nblocks++;
+        npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+      }
+    }
+    K3_STAMP(3);  // the slice's blocks (behind the wait for the NEXT slice's pieces the compiler puts before the first LDS read)
+  }
+  __syncthreads();
+  K3_STAMP(4);
+  for (int i = tid; i < nvalid * 32; i += NW * 64) {
+    a.gbest[st0 * 32 + i] = s_best[i];
+    a.gtie[st0 * 32 + i] = s_tie[i];
+  }
+  for (int s = wave; s < nvalid; s += NW) {
+    const unsigned mx = k3_wave_umax((unsigned)(s_best[s * 32 + (lane & 31)] >> 32));
+    if (lane == 0) a.gsmax[st0 + s] = k3_bound_of(mx);
+  }
+#if TM_KNN3_STAMPS
+  K3_STAMP(5);  // results
+  if (a.stats && lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(a.stats + 20 + i, st_acc[i]);
+    atomicAdd(a.stats + 26, __builtin_amdgcn_s_memtime() - st_begin);
+  }
+#endif
+  // The seeds' own counters (blocks, tiles read, pairs), one set of atomics per WORKGROUP into one of 64 striped slots: 90 000 waves adding to
+  // three words of one cache line took their turns at the L2 and held every other request of the kernel up behind them (2.5 of its 3.3 ms).
+  if (a.seed_stats) {
+    __shared__ unsigned long long s_cnt[2];
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    if (lane == 0 && active) { atomicAdd(&s_cnt[0], (unsigned long long)nblocks); atomicAdd(&s_cnt[1], (unsigned long long)npairs); }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long *slot = a.seed_stats + (blockIdx.x & 63) * 4;
+      atomicAdd(slot, s_cnt[0]);
+      atomicAdd(slot + 1, (unsigned long long)n_seed);
+      atomicAdd(slot + 2, s_cnt[1]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ 2. lists
+// One workgroup (256 threads) per query group.  Runs of KNN_GROUP tiles are judged first, 16 of them at a time in outward order from the
+// home run (one thread per (run, sub-tile) pair); then only the tiles of surviving runs are tested, 128 threads per run, against the
+// sub-tiles that survived the run's box.  Entries collect in LDS in that order; a segment that is full (or the list's end) takes its place
+// in the arena with one atomic add and is copied out.  Past the arena's capacity nothing is written and the segment's count is 0: the
+// cursor keeps counting, the host sees the overflow with the scan's other counters and repeats the search with a larger arena.
+#ifdef TM_KNN3_WITH_LISTS  // (not a template: defined in one translation unit, tm_knn.hip)
+__global__ __launch_bounds__(K3_LIST_NT) void k_knn_lists(const Knn3Args a) {
+  constexpr int ND = KNN_ND, NT = K3_LIST_NT, LCAP = K3_LCAP;
+  constexpr int RB = NT / 16, RS = NT / KNN_GROUP;  // runs per batch, runs per tile-test step
+  static_assert(KNN_GROUP == 128 && RB <= 64 && RS >= 1, "run batches are compacted by one wave");
+  __shared__ int s_qbox[16 * 16];
+  __shared__ unsigned s_smax[16];
+  __shared__ unsigned s_rmask[RB], s_runs[RB];
+  __shared__ int s_ctl[4];  // [0] entries in the buffer, [1] surviving runs of the batch, [2] arena offset of the segment being flushed
+  __shared__ unsigned s_ltile[LCAP];
+  __shared__ unsigned s_llbw[LCAP * 8];  // [LCAP][nsp / 2] words
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int NS = a.ns, NSP = (NS + 1) & ~1, NSW = NSP / 2;
+  const int64_t g = blockIdx.x, st0 = g * NS, n_ttiles = a.n_ttiles;
+  const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
+  for (int i = tid; i < 16 * 16; i += NT) s_qbox[i] = (i >> 4) < nvalid ? a.qmeta[(st0 + (i >> 4)) * 16 + (i & 15)] : 0;
+  if (tid < 16) s_smax[tid] = tid < nvalid ? a.gsmax[st0 + tid] : 0u;
+  if (tid == 0) s_ctl[0] = 0;
+  __syncthreads();
+  const int home = s_qbox[7];
+  const int r0a = (int)max((int64_t)0, min((int64_t)home - (K3_SEEDS / 2 - 1), n_ttiles - K3_SEEDS));
+  const int r0b = (int)min((int64_t)r0a + K3_SEEDS, n_ttiles);
+  const int n_grp = (int)((n_ttiles + KNN_GROUP - 1) / KNN_GROUP), home_run = home / KNN_GROUP;
+  const int total_run_slots = 2 * max(home_run, n_grp - 1 - home_run) + 1, n_run_batches = (total_run_slots + RB - 1) / RB;
+  int nseg = 0;
+  auto flush = [&]() {  // the buffer's entries become a segment (every thread calls it; n is uniform)
+    const int n = s_ctl[0];
+    if (n > 0) {
+      if (tid == 0) {
+        const unsigned long long off = atomicAdd(a.arena_cursor, (unsigned long long)n);
+        const bool fits = off + (unsigned long long)n <= a.arena_cap;
+        s_ctl[2] = fits ? 1 : 0;
+        s_ctl[3] = (int)(unsigned)off;  // (arena_cap < 2^32 entries: checked on the host)
+        if (nseg < a.max_segs) a.segs[g * a.max_segs + nseg] = make_uint2((unsigned)off, fits ? (unsigned)n : 0u);
+      }
+      __syncthreads();
+      if (s_ctl[2]) {
+        const unsigned off = (unsigned)s_ctl[3];
+        for (int i = tid; i < n; i += NT) a.ltile[off + i] = s_ltile[i];
+        unsigned *dst = reinterpret_cast<unsigned *>(a.llb) + (size_t)off * NSW;
+        for (int i = tid; i < n * NSW; i += NT) dst[i] = s_llbw[(i / NSW) * 8 + (i % NSW)];
+      }
+      nseg++;
+      __syncthreads();
+      if (tid == 0) s_ctl[0] = 0;
+      __syncthreads();
+    }
+  };
+  for (int run_batch = 0; run_batch < n_run_batches; run_batch++) {
+    if (tid < RB) s_rmask[tid] = 0;
+    __syncthreads();
+    {
+      const int jr = run_batch * RB + (tid >> 4), s = tid & 15;
+      const int off = (jr + 1) >> 1, run = (jr & 1) ? home_run + off : home_run - off;
+      if (jr < total_run_slots && run >= 0 && run < n_grp && s < nvalid) {
+        unsigned lbq = 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+          const int tlo = a.grp_lo[d * n_grp + run], thi = a.grp_hi[d * n_grp + run];
+          const int gap = max(0, max(tlo - s_qbox[s * 16 + 8 + d], s_qbox[s * 16 + d] - thi)) >> 1;
+          lbq += (unsigned)(gap * gap);
+        }
+        if (2u * k3_isqrt(lbq) <= s_smax[s]) atomicOr(&s_rmask[tid >> 4], 1u << s);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // surviving runs of the batch, in outward order
+      const int jr = run_batch * RB + lane;
+      const int off = (jr + 1) >> 1, run = (jr & 1) ? home_run + off : home_run - off;
+      const unsigned m = lane < RB ? s_rmask[lane] : 0u;
+      const unsigned long long alive = __builtin_amdgcn_ballot_w64(m != 0);
+      if (m) s_runs[__popcll(alive & ((1ull << lane) - 1ull))] = ((unsigned)run << 16) | m;
+      if (lane == 0) s_ctl[1] = __popcll(alive);
+    }
+    __syncthreads();
+    const int run_alive = s_ctl[1];
+    for (int run_k = 0; run_k < run_alive; run_k += RS) {
+      if (s_ctl[0] + NT > LCAP) flush();  // (uniform: every thread reads the same count behind the last barrier)
+      // tile tests: RS surviving runs per step, thread = (run, tile of the run); the run's sub-tile mask is uniform in a wave
+      const int k = run_k + (tid >> 7);
+      const unsigned rm = k < run_alive ? s_runs[k] : 0u;
+      const unsigned rmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(rm & 0xFFFFu));
+      const int64_t tile = (int64_t)(rm >> 16) * KNN_GROUP + (tid & 127);
+      const bool valid = rmask != 0 && tile < n_ttiles && !(tile >= r0a && tile < r0b);
+      // 16-bit lower bounds of this lane's tile against the 16 sub-tile slots: a 256-bit shift register, one value pushed per slot (so
+      // the loop stays rolled: no run-time register index), slot s ends in bits 16 * (s & 1) of lbw[s >> 1]
+      unsigned lbw[8];
+#pragma unroll
+      for (int p = 0; p < 8; p++) lbw[p] = 0xFFFFFFFFu;
+      bool any = false;
+      if (rmask) {
+        int tlo[ND], thi[ND];
+        const int64_t tc = valid ? tile : 0;
+#pragma unroll
+        for (int d = 0; d < ND; d++) { tlo[d] = a.box_lo[(int64_t)d * n_ttiles + tc]; thi[d] = a.box_hi[(int64_t)d * n_ttiles + tc]; }
+#pragma unroll 1
+        for (int s = 0; s < 16; s++) {
+          unsigned v16 = 0xFFFFu;
+          if ((rmask >> s) & 1u) {  // uniform
+            const v4i q0 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16]), q1 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 4]),
+                      q2 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 8]), q3 = *reinterpret_cast<const v4i *>(&s_qbox[s * 16 + 12]);
+            const int qlo[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            const int qhi[8] = {q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+            unsigned lbq = 0;
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+              const int gap = max(0, max(tlo[d] - qhi[d], qlo[d] - thi[d])) >> 1;
+              lbq += (unsigned)(gap * gap);
+            }
+            const unsigned lb16 = min(0xFFFEu, 2u * k3_isqrt(lbq));
+            if (valid && lb16 <= s_smax[s]) { v16 = lb16; any = true; }
+          }
+#pragma unroll
+          for (int p = 0; p < 7; p++) lbw[p] = __builtin_amdgcn_alignbit(lbw[p + 1], lbw[p], 16);
+          lbw[7] = (lbw[7] >> 16) | (v16 << 16);
+        }
+      }
+      {  // ordered append: the waves take their places one after the other (wave w's tiles come before wave w + 1's)
+        const unsigned long long pb = __builtin_amdgcn_ballot_w64(any);
+        __shared__ int s_wcnt[NT / 64];
+        if (lane == 0) s_wcnt[tid >> 6] = __popcll(pb);
+        __syncthreads();
+        int base = s_ctl[0];
+        for (int w = 0; w < (tid >> 6); w++) base += s_wcnt[w];
+        const int idx = base + __popcll(pb & ((1ull << lane) - 1ull));
+        if (any) {
+          s_ltile[idx] = (unsigned)tile;
+#pragma unroll
+          for (int p = 0; p < 8; p++) s_llbw[idx * 8 + p] = lbw[p];
+        }
+        __syncthreads();
+        if (tid == 0) { int t = s_ctl[0]; for (int w = 0; w < NT / 64; w++) t += s_wcnt[w]; s_ctl[0] = t; }
+        __syncthreads();
+      }
+    }
+  }
+  flush();
+  if (tid == 0) a.nsegs[g] = min(nseg, a.max_segs);
+}
+
+#endif  // TM_KNN3_WITH_LISTS
+
+// ------------------------------------------------------------------------------------------------------------------ 3. consume
+template <int HT, int HQ, bool TD>
+__global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
+  constexpr int KT = 6 + HT, KQ = 6 + HQ;
+  constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
+  constexpr int NS = k3_ns(KQ), NSP = (NS + 1) & ~1, NW = K3_NW, NT = K3_NT, LCAP = K3_LCAP;
+  // one LDS object, carved by hand (16-byte aligned pieces)
+  constexpr int OFF_QN = NS * KQ * 1024, OFF_BEST = OFF_QN + NS * 128, OFF_TIE = OFF_BEST + NS * 256, OFF_QBOX = OFF_TIE + NS * 128,
+                OFF_SMAX = OFF_QBOX + NS * 64, OFF_CTL = OFF_SMAX + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
+                LDS_TOTAL = OFF_LLB + LCAP * NSP * 2;
+  static_assert(LDS_TOTAL == k3_lds_bytes(NS, KQ) && LDS_TOTAL <= K3_LDS, "LDS carve");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
+  int *const s_qn = reinterpret_cast<int *>(lds + OFF_QN);                                  // [NS][32] 2 * (|q-c|^2 >> 1)
+  unsigned long long *const s_best = reinterpret_cast<unsigned long long *>(lds + OFF_BEST);  // [NS][32] (d'' + 1) << 32 | sorted row
+  unsigned *const s_tie = reinterpret_cast<unsigned *>(lds + OFF_TIE);                      // [NS][32] smallest d'' + 1 seen twice
+  [[maybe_unused]] int *const s_qbox = reinterpret_cast<int *>(lds + OFF_QBOX);             // [NS][16] (kept in the carve: the dense mode's home)
+  unsigned *const s_smax = reinterpret_cast<unsigned *>(lds + OFF_SMAX);                    // [16] upper bound of sqrt(largest best + 1)
+  int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor, [3] group
+  unsigned *const s_ltile = reinterpret_cast<unsigned *>(lds + OFF_LTILE);                  // [LCAP]
+  uint16_t *const s_llb = reinterpret_cast<uint16_t *>(lds + OFF_LLB);                      // [LCAP][NSP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+#if TM_KNN3_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_begin = st_last;
+#endif
+  // Persistent workgroups (one per CU): a workgroup draws query groups until none is left.  Groups are dealt in runs of K3_XCD_RUN
+  // consecutive groups per XCD (the id is read from the hardware: placement is a matter of speed only); an XCD whose share is exhausted
+  // helps the next one.
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0;
+  const bool dense = a.mode == K3_MODE_DENSE;
+  for (;;) {
+  __syncthreads();  // the previous group's LDS is no longer read
+  if (tid == 0) {
+    int64_t gsel = -1;
+    for (int k = 0; k < 8 && gsel < 0; k++) {
+      const unsigned x = (xcc + k) & 7u;
+      const unsigned t = atomicAdd(&a.tickets[x], 1u);
+#if TM_KNN3_XCD_CONTIG
+      const int64_t per = (a.n_groups + 7) / 8;
+      const int64_t gg = (int64_t)x * per + t;
+      if ((int64_t)t < per && gg < a.n_groups) gsel = gg;
+#else
+      const int64_t gg = ((int64_t)(t / K3_XCD_RUN) * 8 + x) * K3_XCD_RUN + (t % K3_XCD_RUN);
+      if (gg < a.n_groups) gsel = gg;
+#endif
+    }
+    s_ctl[3] = (int)gsel;
+  }
+  __syncthreads();
+  const int64_t g = __builtin_amdgcn_readfirstlane(s_ctl[3]);
+  if (g < 0) break;
+  const int64_t st0 = g * NS;
+  const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
+  const int64_t n_ttiles = a.n_ttiles;
+
+  // ---- prologue: the group's query operands, norms, and what the seeds left
+  // (each phase outside the consume loop takes its thread index afresh, through an empty asm the compiler cannot see through: otherwise
+  // the addresses it derives from it are computed once, before the persistent loop, and live -- spilled -- across the consume loop)
+  int tp = threadIdx.x;
+  asm volatile("" : "+v"(tp));
+  for (int piece = wave; piece < NS * KQ; piece += NW) {
+    const int s = piece / KQ, kc = piece - s * KQ;
+    const int64_t st = min(st0 + s, a.n_qtiles - 1);
+    const uint8_t *src = a.qpack + st * (int64_t)Q_BYTES + kc * 1024 + lane * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)(lds + piece * 1024), 16, 0, 0);
+  }
+  for (int i = tp; i < NS * 32; i += NT) {
+    const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
+    const bool real = (i >> 5) < nvalid && !dense;
+    s_qn[i] = reinterpret_cast<const int *>(a.qpack + st * (int64_t)Q_BYTES + KQ * 1024)[i & 31] & ~1;
+    s_best[i] = real ? a.gbest[st0 * 32 + i] : ~0ull;
+    s_tie[i] = real ? a.gtie[st0 * 32 + i] : ~0u;
+  }
+  if (tp < 16) s_smax[tp] = (tp < nvalid && !dense) ? a.gsmax[st0 + tp] : 0xFFFEu;
+  const int nseg = dense ? (int)((n_ttiles + LCAP - 1) / LCAP) : a.nsegs[g];
+  __syncthreads();  // (waits for the LDS-DMA pieces too)
+  K3_STAMP(0);  // prologue
+
+  for (int seg = 0; seg < nseg; seg++) {
+    // ---------------------------------------------------------------- the next segment of the group's tile list, into LDS
+    int list_n;
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    if (dense) {  // every tile, every sub-tile
+      list_n = (int)min((int64_t)LCAP, n_ttiles - (int64_t)seg * LCAP);
+      for (int i = tl; i < list_n; i += NT) {
+        s_ltile[i] = (unsigned)(seg * LCAP + i);
+        for (int p = 0; p < NSP; p++) s_llb[i * NSP + p] = p < nvalid ? 0 : 0xFFFF;
+      }
+    } else {
+      const uint2 sg = a.segs[g * a.max_segs + seg];
+      list_n = (int)sg.y;
+      for (int i = tl; i < list_n; i += NT) s_ltile[i] = a.ltile[sg.x + i];
+      const unsigned *src = reinterpret_cast<const unsigned *>(a.llb) + (size_t)sg.x * (NSP / 2);
+#pragma unroll 1
+      for (int i = tl; i < list_n * (NSP / 2); i += NT) reinterpret_cast<unsigned *>(s_llb)[i] = src[i];
+    }
+    if (tl == 0) s_ctl[1] = 0;
+    __syncthreads();
+    K3_STAMP(1);  // segment load
+    // ---------------------------------------------------------------- consume: every wave on its own
+    {
+      nlisted += (wave == 0) ? list_n : 0;
+      auto next_entry = [&](int &tile_o, int &lb_o, unsigned &mask_o) -> bool {
+        for (;;) {
+          int j = 0;
+          if (lane == 0) j = atomicAdd(&s_ctl[1], 1);
+          j = __builtin_amdgcn_readfirstlane(j);
+          if (j >= list_n) return false;
+#if TM_KNN3_REFRESH_EVERY
+          if ((j & (TM_KNN3_REFRESH_EVERY - 1)) == TM_KNN3_REFRESH_EVERY - 1)
+            for (int s = 0; s < nvalid; s++) {  // every so many entries the popping wave makes every sub-tile's bound anew from its bests: what the
+                                                // races of the refresh rule left loose ends here (the second shape did this at every list's end)
+              const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1));
+              if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], k3_bound_of(mx));
+            }
+#endif
+          const int t = (int)s_ltile[j];
+          const int lb = lane < NSP ? (int)s_llb[j * NSP + lane] : 0xFFFF;
+          const int sm = lane < NS ? (int)k3_peek(&s_smax[lane]) : -1;
+          const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lb <= sm);
+          if (m) { tile_o = __builtin_amdgcn_readfirstlane(t); lb_o = lb; mask_o = m; return true; }
+        }
+      };
+      int tile = 0, lbv = 0;
+      unsigned mask = 0;
+      bool have = next_entry(tile, lbv, mask);
+      while (have) {
+        v4i T[KT];
+        v16i ntr;
+        k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
+        nloads++;
+        // the entry after this one is chosen while the loads fly
+        int ntile = 0, nlb = 0;
+        unsigned nmask = 0;
+        const bool nhave = next_entry(ntile, nlb, nmask);
+        const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
+        while (mask) {
+          const int s = __builtin_ctz(mask);
+          mask &= mask - 1;
+          // the sub-tile's best may have tightened since the entry was popped
+          const int lbs = __builtin_amdgcn_readlane(lbv, s);
+          const unsigned sm_now = (unsigned)__builtin_amdgcn_readfirstlane((int)k3_peek(&s_smax[s]));
+          if (lbs > (int)sm_now) continue;
+          const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16);
+          const int qi = s * 32 + (lane & 31);
+          const bool refresh = k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], sm_now);
+          if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
+            const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1));  // = largest d'' + 1
+            if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], k3_bound_of(mx));
+          }
+          nblocks++;
+          npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+        }
+        tile = ntile; lbv = nlb; mask = nmask; have = nhave;
+      }
+    }
+    K3_STAMP(2);  // consuming
+    __syncthreads();
+    if (seg + 1 < nseg)
+      for (int s = wave; s < nvalid; s += NW) {  // every sub-tile's bound made anew from its bests: what the races of the refresh rule left loose ends here
+        const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + (s * 32 + (lane & 31)) * 2 + 1));
+        if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], k3_bound_of(mx));
+      }
+    K3_STAMP(3);  // waiting for the other waves at the end of a segment
+  }
+
+  // ---- results, in the format k_knn_refine / k_knn_ties read
+  int tr = threadIdx.x;
+  asm volatile("" : "+v"(tr));
+  for (int i = tr; i < NS * 32; i += NT) {
+    const int64_t st = st0 + (i >> 5);
+    if (st >= a.n_qtiles) continue;
+    const unsigned long long k = s_best[i];
+    const unsigned hi = (unsigned)(k >> 32);
+    const int64_t q = st * 32 + (i & 31);
+    a.best_key[q] = (int)(hi - 1u);
+    a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
+  }
+  K3_STAMP(4);  // results
+  }  // next query group
+#if TM_KNN3_STAMPS
+  if (a.stats && lane == 0) {
+    for (int i = 0; i < 5; i++) atomicAdd(a.stats + 4 + i, st_acc[i]);
+    atomicAdd(a.stats + 9, __builtin_amdgcn_s_memtime() - st_begin);
+  }
+#endif
+  if (a.stats && lane == 0) {
+    atomicAdd(a.stats, (unsigned long long)nblocks);
+    atomicAdd(a.stats + 1, (unsigned long long)nloads);
+    atomicAdd(a.stats + 2, (unsigned long long)npairs);
+    if (wave == 0) atomicAdd(a.stats + 3, (unsigned long long)nlisted);
+  }
+}
+
+// one per HT, defined in tm_knn3_k<HT>.hip
+template <int HT> void knn3_launch_seed_ht(int hq, const Knn3Args &a, hipStream_t stream);
+template <int HT> void knn3_launch_consume_ht(int hq, const Knn3Args &a, hipStream_t stream);
+int knn3_sub_tiles(int hq);  // NS of the queries' digit plan
+
+#define TM_KNN3_LAUNCH(KERNEL, HT, HQ)                                                                  \
+  do {                                                                                                 \
+    if (a.tdouble) hipLaunchKernelGGL((KERNEL<HT, HQ, true>), grid, block, 0, stream, a);              \
+    else hipLaunchKernelGGL((KERNEL<HT, HQ, false>), grid, block, 0, stream, a);                       \
+  } while (0)
+#define TM_KNN3_CASE(KERNEL, HT, HQ) \
+  case HQ: TM_KNN3_LAUNCH(KERNEL, HT, HQ); break;
+#define TM_KNN3_SWITCH(KERNEL, HT)                                                                                            \
+  switch (hq) {                                                                                                               \
+    TM_KNN3_CASE(KERNEL, HT, 0) TM_KNN3_CASE(KERNEL, HT, 1) TM_KNN3_CASE(KERNEL, HT, 2) TM_KNN3_CASE(KERNEL, HT, 3)           \
+    TM_KNN3_CASE(KERNEL, HT, 4) TM_KNN3_CASE(KERNEL, HT, 5)                                                                   \
+    default: TM_KNN3_LAUNCH(KERNEL, HT, 6);                                                                                   \
+  }
+
+#define TM_KNN3_DEFINE_HT(HT)                                                                         \
+  template <> void knn3_launch_seed_ht<HT>(int hq, const Knn3Args &a, hipStream_t stream) {          \
+    const dim3 grid((unsigned)a.n_groups), block(K3_SEEDS * 64);                                      \
+    TM_KNN3_SWITCH(k_knn_seed, HT)                                                                    \
+  }                                                                                                   \
+  template <> void knn3_launch_consume_ht<HT>(int hq, const Knn3Args &a, hipStream_t stream) {       \
+    const dim3 grid((unsigned)a.grid_blocks), block(K3_NT);                                           \
+    TM_KNN3_SWITCH(k_knn_consume, HT)                                                                 \
+  }
+
+}  // namespace tmx

@@ -45,6 +45,9 @@ int *pinned_words() {
 
 HostRead::HostRead(hipStream_t s) : stream(s) { t_pin.depth++; }
 HostRead::~HostRead() {
+  // copies queued and never waited for (an error return between get() and wait()) may still be in flight into the thread's area: they
+  // must land before the area is handed out again
+  if (n > 0) (void)hipStreamSynchronize(stream);
   if (--t_pin.depth == 0) t_pin.used = 0;
 }
 int HostRead::get(void *dst, const void *src, size_t bytes) {

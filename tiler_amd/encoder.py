@@ -61,6 +61,7 @@ _ENC_SIGS = {
     "tm_get_tile": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "tm_get_tiles": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "tm_get_tilemap": (c_int, [c_void_p, c_int, c_void_p]),
+    "tm_get_tilemaps": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "tm_get_palette": (c_int, [c_void_p, c_int, c_void_p]),
     "tm_get_keyframes": (c_int, [c_void_p, c_void_p]),
     "tm_get_frame_correlations": (c_int, [c_void_p, c_void_p]),
@@ -77,6 +78,7 @@ _ENC_SIGS = {
     "tm_set_collective_mode": (c_int, [c_void_p, c_int]),
     "tm_get_device_array": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "tm_sync_tilemap": (c_int, [c_void_p]),
+    "tm_get_knn_kernel_split": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64)]),
     "tm_get_knn_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                          ctypes.POINTER(c_int64)]),
 }
@@ -211,6 +213,20 @@ class TilingEncoder:
         items = np.zeros(c["tm_w"] * c["tm_h"], TILEMAP_ITEM)
         check(self._L.tm_get_tilemap(c_void_p(self._h), frame, items.ctypes.data_as(c_void_p)))
         return items
+
+    def TileMaps(self, first=0, count=None, out=None):
+        """Frames[first .. first+count-1].TileMap in one read-back; `out` (optional) = a uint8 array / tensor of count*tm_w*tm_h*18 bytes to
+        fill (page-locked memory makes the copy one DMA)"""
+        c = self.counts()
+        count = c["frames"] - first if count is None else count
+        per = c["tm_w"] * c["tm_h"]
+        if out is None:
+            items = np.zeros(count * per, TILEMAP_ITEM)
+            check(self._L.tm_get_tilemaps(c_void_p(self._h), first, count, items.ctypes.data_as(c_void_p)))
+            return items.reshape(count, per)
+        ptr = out.data_ptr() if hasattr(out, "data_ptr") else out.ctypes.data
+        check(self._L.tm_get_tilemaps(c_void_p(self._h), first, count, c_void_p(ptr)))
+        return out
 
     def Palettes(self):
         c = self.counts()
@@ -354,5 +370,8 @@ class TilingEncoder:
                                        ctypes.byref(rows)))
         self._L.tm_get_knn_queries.restype = c_int64
         self._L.tm_get_knn_queries.argtypes = [c_void_p]
+        sm, sp = (c_double * 3)(), (c_int64 * 2)()
+        check(self._L.tm_get_knn_kernel_split(c_void_p(self._h), sm, sp))
         return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value, db_rows=rows.value,
-                    queries=int(self._L.tm_get_knn_queries(c_void_p(self._h))))
+                    queries=int(self._L.tm_get_knn_queries(c_void_p(self._h))),
+                    seed_ms=sm[0], lists_ms=sm[1], consume_ms=sm[2], seed_pairs=sp[0], consume_pairs=sp[1])

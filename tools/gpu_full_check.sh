@@ -11,5 +11,5 @@ python - <<'PY'
 import json
 j = json.loads(open("gpurun_out/bench_q.json").read().strip().splitlines()[-1])
 print("fps=%.0f ms=%.2f stages=%s knn_ms=%.2f frac=%.4f" % (j["value"], j["ms_per_step"], j["stage_ms"], j["roofline"]["launch_ms"], j["roofline"]["frac"]))
-print("h2d", j.get("with_h2d", {}).get("value"), "dense", j.get("roofline_dense", {}).get("mfma_pipe_frac"))
+print("h2d+d2h", j.get("with_h2d_d2h"), j.get("with_h2d_overlapped_d2h"), "scan", j["roofline"].get("scan", {}).get("kernels_ms"), "dense", j.get("roofline_dense", {}).get("mfma_pipe_frac"))
 PY

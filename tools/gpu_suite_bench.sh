@@ -11,7 +11,9 @@ python - <<'PY'
 import json
 j = json.loads(open("gpurun_out/bench_full.json").read().strip().splitlines()[-1])
 print("fps=%.0f ms=%.2f stages=%s knn_ms=%.2f frac=%.4f" % (j["value"], j["ms_per_step"], j["stage_ms"], j["roofline"]["launch_ms"], j["roofline"]["frac"]))
-for k in ("with_h2d", "with_h2d_overlapped", "without_frozen_columns", "with_motion_prediction", "with_extended_palette_usage", "with_motion_and_extended_palette_usage"):
+print("with_h2d_d2h", j.get("with_h2d_d2h"), "overlapped", j.get("with_h2d_overlapped_d2h"), j.get("transfers", {}).get("with_h2d_d2h"))
+print("scan", j["roofline"].get("scan"))
+for k in ("with_frozen_columns", "with_motion_prediction", "with_extended_palette_usage", "with_motion_and_extended_palette_usage"):
     if k in j: print(k, round(j[k]["value"]), j[k].get("ms_per_step", j[k].get("ms")))
 print("kmeans", j.get("stage_rooflines", {}).get("kmeans"))
 print("cpu", {k: v for k, v in j.get("cpu_baseline", {}).items() if k in ("value", "cores", "legs", "with_32_threads")})
