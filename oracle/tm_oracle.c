@@ -1359,6 +1359,36 @@ int tmo_optimize_palettes(int32_t *pals, int pal_count, int pal_size) { /* Optim
   return iteration;
 }
 
+/* Test hooks for A11's scalar pieces (tests/test_oracle_pins.py): Bracket and Brent of powell.pas on a handful of fixed scalar functions
+ * (+ - * / and fabs only, so that Python restates them bit for bit), with the function evaluations counted -- the fixture they are held to
+ * was recorded from scipy.optimize (tests/golden/make_powell_fixtures.py), the code powell.pas says it was taken from. */
+double tmo_test_scalar_fn(int id, double x) {
+  switch (id) {
+    case 0: return (x - 2.0) * (x - 2.0) + 1.0;
+    case 1: return x * x * x * x - 3.0 * x * x * x + 2.0;
+    case 2: return (x + 1.5) * (x + 1.5) * (x - 0.3) * (x - 0.3) + 0.1 * x;
+    case 3: return fabs(x - 0.7) + 0.01 * x * x;
+    case 4: return x * x / (1.0 + x * x) - 0.2 * x;
+    case 5: return -1.0 / (1.0 + (x - 3.0) * (x - 3.0));
+    case 6: return (x - 0.25) * (x - 0.25) * (x - 0.25) * (x - 0.25) + 0.5 * (x - 0.25) * (x - 0.25);
+    default: return 1e3 * (x + 40.0) * (x + 40.0) - 7.0;
+  }
+}
+typedef struct { int id; int calls; } test_fn_ctx;
+static double test_fn_counted(double x, void *c) { test_fn_ctx *t = (test_fn_ctx *)c; t->calls++; return tmo_test_scalar_fn(t->id, x); }
+int tmo_test_bracket(int fn, double xa, double xb, double out[4]) { /* xa, xb, xc as Bracket returns them (sorted ends), function evaluations */
+  test_fn_ctx c = {fn, 0};
+  bracket(test_fn_counted, &c, xa, xb, out);
+  out[3] = c.calls;
+  return 0;
+}
+int tmo_test_brent(int fn, double xtol, int maxiter, double out[3]) { /* xmin, f(xmin), function evaluations (Bracket's included) */
+  test_fn_ctx c = {fn, 0};
+  brent(test_fn_counted, &c, xtol, maxiter, &out[0], &out[1]);
+  out[2] = c.calls;
+  return 0;
+}
+
 /* =====================================================================================================================
  * (f)#2 checker: LZMA-alone decoder, restating decoders/htmljs/lzma.js (decodeHeader :395-450, decodeBody :477-576,
  * RangeDecoder :128-190, LenDecoder :252-264, Decoder2 :270-300).  Used by tests/ to read back what the product's

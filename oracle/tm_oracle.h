@@ -147,6 +147,11 @@ void tmo_palettize_tiles(const int32_t *feat, const uint32_t *use, int64_t n, in
 
 /* ---- A11 OptimizePalettes (tilingencoder.pas:4309-4432) with Powell/Brent (powell.pas); in place, returns sweeps ---- */
 int tmo_optimize_palettes(int32_t *palettes, int pal_count, int pal_size);
+/* test hooks: Bracket (powell.pas:56-147) and Brent (:149-266) on fixed scalar functions, evaluations counted; held to a fixture recorded
+ * from scipy.optimize (tests/golden/make_powell_fixtures.py) */
+double tmo_test_scalar_fn(int id, double x);
+int tmo_test_bracket(int fn, double xa, double xb, double out[4]);
+int tmo_test_brent(int fn, double xtol, int maxiter, double out[3]);
 
 /* ---- (f)#1 motion prediction (tilingencoder.pas:1154-1282, 1496-1532) and the Reduce threshold search (4014-4046) ---- */
 void tmo_window_dcts(const uint32_t *fb, int w, int h, int16_t *out /* [(h-7)*(w-7)][192] */);

@@ -232,3 +232,20 @@ def test_keyframe_shards_cover_the_clip():
             assert a + c == b
         assert all(c == 0 or a in kf for a, c in got)
     assert [frame_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form) must start two rank processes itself and hand their
+    outcome back: here, without a GPU, both ranks refuse loudly (libtilemotion has no CPU path), the launcher reports the failure and the
+    parent exits non-zero with no JSON line on stdout."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_gpu_rehearsal.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-2000:]  # one refusal per rank

@@ -201,3 +201,40 @@ def test_kmeans_pp_seeding_follows_its_stated_rule(oracle):
             mind = dist if mind is None else [min(a, b) for a, b in zip(mind, dist)]
         assert list(got) == seeds
         assert len(set(seeds)) == len(seeds)
+
+
+def test_powell_bracket_and_brent_against_scipy(oracle):
+    """A11's scalar pieces against the code powell.pas says it was taken from: the fixture (tests/golden/powell_scipy.json, made by
+    tests/golden/make_powell_fixtures.py) holds what scipy.optimize's own `bracket` and `Brent` compute on eight scalar functions, with
+    powell.pas' exact golden-ratio constants in place of scipy's rounded literals and scipy's tolerance made absolute.
+      * Bracket (powell.pas:56-147): the three points and the number of function evaluations, bit for bit, in every case.
+      * Brent (:149-266): one evaluation more than scipy (the re-evaluation of the bracket's middle point, :262) and identical iterates
+        wherever the fixture's run met none of the documented differences in the tolerance rule (`exact`); everywhere the minimiser
+        within 4 xtol of scipy's and the value no worse than scipy's up to the function's change over that distance."""
+    import ctypes
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "powell_scipy.json")))
+    L = oracle.L
+    L.tmo_test_scalar_fn.restype = ctypes.c_double
+    L.tmo_test_scalar_fn.argtypes = [ctypes.c_int, ctypes.c_double]
+    L.tmo_test_bracket.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    L.tmo_test_brent.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    assert len(fx["bracket"]) >= 24 and len(fx["brent"]) >= 20
+    for c in fx["bracket"]:
+        r = (ctypes.c_double * 4)()
+        L.tmo_test_bracket(c["fn"], c["xa"], c["xb"], r)
+        assert sorted([r[0], r[2]]) == c["ends"] and r[1] == c["mid"] and int(r[3]) == c["calls"], (c, list(r))
+    n_exact = 0
+    for c in fx["brent"]:
+        r = (ctypes.c_double * 3)()
+        L.tmo_test_brent(c["fn"], c["xtol"], 100, r)
+        x, fmin, calls = r[0], r[1], int(r[2])
+        assert fmin == L.tmo_test_scalar_fn(c["fn"], x)
+        if c["exact"]:
+            n_exact += 1
+            assert x == c["x"] and fmin == c["fx"] and calls == c["calls"] + 1, (c, list(r))
+        assert abs(x - c["x"]) <= 4 * c["xtol"], (c, list(r))
+        slack = max(abs(L.tmo_test_scalar_fn(c["fn"], c["x"] + s * 4 * c["xtol"]) - c["fx"]) for s in (-1.0, 1.0))
+        assert fmin <= c["fx"] + slack, (c, list(r))
+    assert n_exact >= 16

@@ -91,10 +91,12 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   const int16_t *__restrict__ centre, const int16_t *__restrict__ perm,
                                                   const uint32_t *__restrict__ rowperm, int with_box, CurveSpec cs,
                                                   int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
-                                                  int *__restrict__ err_flag, int *__restrict__ qmeta /* query side of the second scan shape: [ntiles][16] */) {
+                                                  int *__restrict__ err_flag, int *__restrict__ qmeta /* query side of the second scan shape: [ntiles][16] */,
+                                                  uint8_t *__restrict__ hmask /* database side: [ntiles] which high-digit chunks of the tile hold a non-zero digit */) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ __attribute__((aligned(16))) int s_v[32][196];  // (pitch 196: a row's 16-value groups are 16-byte aligned, and sixteen rows' groups cover the 64 banks once)
   __shared__ uint32_t s_norm[32];
+  __shared__ unsigned s_hm;  // bit kc: high-digit chunk kc of this tile is not all zero
   __shared__ long long s_bsq[32];  // query side: squared distance of each row from the centres over the box columns
   __shared__ __attribute__((aligned(16))) int16_t s_raw[32][200];  // the tile's rows as they lie in memory (pitch 400 B)
   for (int i = threadIdx.x; i < 192; i += 256) { s_p[i] = perm[i]; s_c[i] = centre[perm[i]]; }
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
   }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    if (threadIdx.x == 0) s_hm = 0;
 #pragma unroll
     for (int u = 0; u < 3; u++) *reinterpret_cast<uint4 *>(&s_raw[pr[u]][pv[u] * 8]) = nvec[u];
     {
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
         w[b >> 2] |= (uint32_t)(digit & 255) << ((b & 3) * 8);
       }
       *reinterpret_cast<uint4 *>(obase + piece * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+      if (high && (w[0] | w[1] | w[2] | w[3])) atomicOr(&s_hm, 1u << (kc - 6));
     }
     {  // |v-c|^2 of every row (the kernel drops the query side's parity bit): eight lanes per row, integer sums (32 threads walking 192
        // values each were the longest leg of a tile)
@@ -201,7 +205,11 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
       sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
       if (part == 0) { s_norm[r] = sq; reinterpret_cast<uint32_t *>(obase + kch * 1024)[r] = sq; }
     }
-    if (with_box || qmeta) __syncthreads();
+    __syncthreads();
+    if (threadIdx.x == 0) {  // (rows >= n replicate row n - 1: they add no digit the real rows do not have)
+      if (hmask) hmask[tile] = (uint8_t)s_hm;
+      if (qmeta) qmeta[tile * 16 + 15] = (int)s_hm;
+    }
     if (qmeta && threadIdx.x < 32) {  // the radial dimension of the sub-tile's box (the columns' part was done beside the centring phase)
       const int r = threadIdx.x;
       const long long n2 = (long long)(s_norm[r] & ~1u), boxsq = s_bsq[r];
@@ -524,10 +532,21 @@ static int make_plan_scaled(const ColStats &ts, const ColStats &qs, KnnPlan *pla
   const int costA = chunks(nu) + 2 * chunks(nq), costB = chunks(nu) + 2 * chunks(nt);
   const bool a = costA <= costB;
   const bool *inner = a ? qb : tb;
+  // Inside each class the widest columns come first: a 32-row tile whose values all stay within one digit on a chunk of 32 columns has
+  // an all-zero high-digit chunk there, and the scan skips the products with it (tm_knn3_kernel.h) -- with the wide columns (the DC terms,
+  // the lowest frequencies) packed into the first chunks, the later chunks are empty for most tiles.
+  int order[192];
+  for (int c = 0; c < 192; c++) order[c] = c;
+  auto halfrange = [&](int c) {
+    const int lo = std::min(ts.mn[c] <= ts.mx[c] ? ts.mn[c] : INT_MAX, qs.mn[c] <= qs.mx[c] ? qs.mn[c] : INT_MAX);
+    const int hi = std::max(ts.mn[c] <= ts.mx[c] ? ts.mx[c] : INT_MIN, qs.mn[c] <= qs.mx[c] ? qs.mx[c] : INT_MIN);
+    return hi >= lo ? std::max(hi - (int)plan->centre[c], (int)plan->centre[c] - lo) : 0;
+  };
+  std::stable_sort(order, order + 192, [&](int x, int y) { return halfrange(x) > halfrange(y); });
   int p = 0;
-  for (int c = 0; c < 192; c++) if (inner[c]) plan->perm[p++] = (int16_t)c;
-  for (int c = 0; c < 192; c++) if (!inner[c] && (tb[c] || qb[c])) plan->perm[p++] = (int16_t)c;
-  for (int c = 0; c < 192; c++) if (!tb[c] && !qb[c]) plan->perm[p++] = (int16_t)c;
+  for (int i = 0; i < 192; i++) { const int c = order[i]; if (inner[c]) plan->perm[p++] = (int16_t)c; }
+  for (int i = 0; i < 192; i++) { const int c = order[i]; if (!inner[c] && (tb[c] || qb[c])) plan->perm[p++] = (int16_t)c; }
+  for (int i = 0; i < 192; i++) { const int c = order[i]; if (!tb[c] && !qb[c]) plan->perm[p++] = (int16_t)c; }
   plan->ht = a ? chunks(nu) : chunks(nt);
   plan->hq = a ? chunks(nq) : chunks(nu);
   plan->nbig_t = nt;
@@ -582,6 +601,7 @@ struct tm_knn_index_impl {
   DevBuf qmeta;                                     // per query sub-tile: box + home tile (second scan shape)
   // third scan shape: what the seed kernel leaves for the other two (bests, tie values, bounds) and the groups' tile lists
   DevBuf gbest, gtie, gsmax, segs, nsegs, arena_tile, arena_lb;
+  DevBuf thmask;                                    // per database tile: which of its high-digit chunks are not all zero
   uint64_t arena_cap = 0, arena_want = 0;           // list entries the arena holds / the largest cursor a search has reported
   hipEvent_t ev_seed = nullptr, ev_lists = nullptr;
   double last_seed_ms = 0, last_lists_ms = 0, last_consume_ms = 0;
@@ -644,10 +664,12 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
   TM_TRY(out.alloc((size_t)ntiles * knn_tile_bytes(hch, with_box)));
   TM_TRY(ix->err_flag.alloc(sizeof(int)));
   if (negate) TM_TRY(ix->qmeta.alloc((size_t)std::max<int64_t>(ntiles, 1) * 16 * 4));
+  else TM_TRY(ix->thmask.alloc((size_t)std::max<int64_t>(ntiles, 1)));
   int grid = (int)std::min<int64_t>(ntiles, 4096);
   hipLaunchKernelGGL(k_knn_pack, dim3(grid), dim3(256), 0, stream, (const int16_t *)feat, n, ntiles, hch, negate, scale,
                      ix->plan_dev.as<int16_t>(), ix->plan_dev.as<int16_t>() + 192, perm.as<uint32_t>(), with_box, ix->curve,
-                     ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>(), negate ? ix->qmeta.as<int>() : nullptr);
+                     ix->box_lo.as<int>(), ix->box_hi.as<int>(), out.as<uint8_t>(), ix->err_flag.as<int>(), negate ? ix->qmeta.as<int>() : nullptr,
+                     negate ? nullptr : ix->thmask.as<uint8_t>());
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -853,7 +875,6 @@ __global__ __launch_bounds__(256) void k_knn_qmeta(const uint32_t *__restrict__ 
     int64_t lo = 0, hi = n_ttiles;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (bx.tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
     qmeta[st * 16 + 7] = (int)max((int64_t)0, lo - 1);
-    qmeta[st * 16 + 15] = 0;
   }
 }
 
@@ -903,6 +924,8 @@ static int launch_scan3(tm_knn_index_impl *ix, int64_t nq, int64_t nqt, int64_t 
   a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
   a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
   a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
+  a.thmask = ix->thmask.as<uint8_t>();
+  TM_CHECK(ntt < (1 << 24), TM_E_UNSUPPORTED, "knn: %lld database tiles exceed the list entries' 24-bit tile index", (long long)ntt);
   a.ns = ns; a.mode = prune ? K3_MODE_LISTS : K3_MODE_DENSE; a.tdouble = ix->plan.tscale == 2;
   a.n_groups = (nqt + ns - 1) / ns;
   a.max_segs = (int)(ntt / (K3_LCAP - K3_LIST_NT) + 2);  // every segment but a list's last holds more than K3_LCAP - K3_LIST_NT entries
@@ -1194,8 +1217,9 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   if (getenv("TM_KNN_DEBUG")) {
     const int nsg = shape == 3 ? knn3_sub_tiles(ix->plan.hq) : knn2_sub_tiles(ix->plan.hq);
     const int64_t groups = v1 ? (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW) : (nqt + nsg - 1) / nsg;
-    if (shape == 3) fprintf(stderr, "[tm_knn] v3: seeds %.3f ms, lists %.3f ms (%.1f entries per group, arena %.0f %% full), consume %.3f ms\n", ix->last_seed_ms, ix->last_lists_ms,
-                            (double)cnt[20] / (double)groups, 100.0 * (double)cnt[20] / (double)std::max<uint64_t>(1, ix->arena_cap), ix->last_consume_ms);
+    if (shape == 3) fprintf(stderr, "[tm_knn] v3: seeds %.3f ms, lists %.3f ms (%.1f entries per group, arena %.0f %% full), consume %.3f ms, %.2f of %d matrix instructions per block\n", ix->last_seed_ms, ix->last_lists_ms,
+                            (double)cnt[20] / (double)groups, 100.0 * (double)cnt[20] / (double)std::max<uint64_t>(1, ix->arena_cap), ix->last_consume_ms,
+                            (double)cnt[21] / (double)std::max<unsigned long long>(1, cnt[2]), 6 + ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
     fprintf(stderr, "[tm_knn] %s kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (%lld blocks; workgroups read %.3f%% of tiles, %.1f per group; %.1f list entries per group), %lld tie settlements\n",
             v1 ? "v1" : shape == 2 ? "v2" : "v3", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)ix->last_blocks,
             100.0 * (double)ix->last_loads / ((double)groups * (double)ntt), (double)ix->last_loads / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);

@@ -52,7 +52,7 @@ constexpr int K3_XCD_RUN = 32 * K3_WGS;  // groups dealt to one XCD at a time (n
 #endif
 constexpr int K3_LIST_NT = 256;          // threads of a list-building workgroup
 
-constexpr int k3_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 64 + 64 + K3_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
+constexpr int k3_lds_bytes(int ns, int kq) { return ns * (kq * 1024 + 576) + 64 + 64 + 64 + K3_LCAP * (4 + 2 * ((ns + 1) & ~1)); }
 constexpr int k3_ns(int kq) {
   int ns = 16;
   while (ns > 1 && k3_lds_bytes(ns, kq) > K3_LDS) ns--;
@@ -65,7 +65,8 @@ struct Knn3Args {
   const uint8_t *tpack; int64_t n_ttiles, nt_rows;
   const int *box_lo, *box_hi, *grp_lo, *grp_hi;  // database tile boxes [KNN_ND][n_ttiles], boxes of runs of KNN_GROUP tiles
   const uint8_t *qpack; int64_t n_qtiles, nq;
-  const int *qmeta;             // [n_qtiles][16]: box lo[7], home tile, box hi[7], pad
+  const int *qmeta;             // [n_qtiles][16]: box lo[7], home tile, box hi[7], mask of the sub-tile's non-zero high-digit chunks
+  const uint8_t *thmask;        // [n_ttiles] the same mask for every database tile
   int ns;                       // sub-tiles per group (k3_ns of the queries' digit plan)
   int mode;                     // consume: K3_MODE_LISTS / K3_MODE_DENSE (every tile, every sub-tile; no seeds, no lists)
   int tdouble;                  // the database pack holds the digits of 2 (t - c)
@@ -114,27 +115,35 @@ __device__ __forceinline__ unsigned k3_bound_of(unsigned mx) { return mx == ~0u 
 // One block's chain: X over the digit products on one accumulator shifted between the phases; with TD (database digits of 2 (t - c)) the
 // rows' own term |t-c|^2 rides in on the second shift and the chain ends in 2 X + |t-c|^2.  `q` = the sub-tile's B operands in LDS at this
 // lane's 16 bytes (chunk stride 1024).
+// `tm` / `qm` (wave-uniform): bit kc set = high-digit chunk kc of the tile / of the sub-tile holds a non-zero digit.  A product with an
+// all-zero chunk adds nothing and is skipped, its LDS read with it: the columns are packed widest first (make_plan_scaled), so a tile of
+// smooth content has its high digits in the first chunk or two only.
 template <int HT, int HQ, bool TD>
-__device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q) {
+__device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q, unsigned tm, unsigned qm) {
   constexpr int HM = HT < HQ ? HT : HQ;
   v16i acc;
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0;
   if (TD && HT + HQ == 0) acc = ntr;  // a single phase: the rows' term is the chain's starting value
   if (HM > 0) {
+    if (tm & qm) {
 #pragma unroll
-    for (int kc = 0; kc < HM; kc++)
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
+      for (int kc = 0; kc < HM; kc++)
+        if (((tm & qm) >> kc) & 1u)
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+      for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+    }
   }
   if (HT + HQ > 0) {
 #pragma unroll
     for (int kc = 0; kc < HQ; kc++)
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
+      if ((qm >> kc) & 1u)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
 #pragma unroll
     for (int kc = 0; kc < HT; kc++)
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
+      if ((tm >> kc) & 1u)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
   }
@@ -204,11 +213,12 @@ template <int HT, int HQ, bool TD>
 __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a) {
   constexpr int KT = 6 + HT, KQ = 6 + HQ;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
-  constexpr int SL = K3_SEED_SLICE, NW = K3_SEEDS;
+  constexpr int SL = (2 * K3_SEED_SLICE * KQ * 1024 + 10 * 1024 > 80 * 1024) ? K3_SEED_SLICE - 1 : K3_SEED_SLICE, NW = K3_SEEDS;  // two workgroups per CU
   __shared__ __attribute__((aligned(16))) uint8_t s_q[2][SL * KQ * 1024];
   __shared__ unsigned long long s_best[16 * 32];
   __shared__ unsigned s_tie[16 * 32];
   __shared__ int s_qn[16 * 32];
+  __shared__ unsigned s_qm[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
   const int NS = a.ns;
   const int64_t g = blockIdx.x, st0 = g * NS;
@@ -236,8 +246,10 @@ __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a)
     s_best[i] = ~0ull;
     s_tie[i] = ~0u;
   }
+  if (tid < 16) s_qm[tid] = tid < nvalid ? (unsigned)a.qmeta[(st0 + tid) * 16 + 15] : 0u;
   const bool active = wave < n_seed;
   const int tile = r0a + (active ? wave : 0);
+  const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)a.thmask[tile]);
   v4i T[KT];
   v16i ntr;
   k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a)
     if (active) {
       for (int j = 0; j < SL && sl * SL + j < nvalid; j++) {
         const int s = sl * SL + j;
-        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16);
+        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16, tm, (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[s]));
         const int qi = s * 32 + (lane & 31);
         k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], 0u);
         nblocks++;
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(K3_LIST_NT) void k_knn_lists(const Knn3Args a) {
         for (int w = 0; w < (tid >> 6); w++) base += s_wcnt[w];
         const int idx = base + __popcll(pb & ((1ull << lane) - 1ull));
         if (any) {
-          s_ltile[idx] = (unsigned)tile;
+          s_ltile[idx] = (unsigned)tile | ((unsigned)a.thmask[tile] << 24);  // the entry carries the tile's high-chunk mask: the consumer has it before the tile
 #pragma unroll
           for (int p = 0; p < 8; p++) s_llbw[idx * 8 + p] = lbw[p];
         }
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   constexpr int NS = k3_ns(KQ), NSP = (NS + 1) & ~1, NW = K3_NW, NT = K3_NT, LCAP = K3_LCAP;
   // one LDS object, carved by hand (16-byte aligned pieces)
   constexpr int OFF_QN = NS * KQ * 1024, OFF_BEST = OFF_QN + NS * 128, OFF_TIE = OFF_BEST + NS * 256, OFF_QBOX = OFF_TIE + NS * 128,
-                OFF_SMAX = OFF_QBOX + NS * 64, OFF_CTL = OFF_SMAX + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
+                OFF_SMAX = OFF_QBOX + NS * 64, OFF_QMASK = OFF_SMAX + 64, OFF_CTL = OFF_QMASK + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
                 LDS_TOTAL = OFF_LLB + LCAP * NSP * 2;
   static_assert(LDS_TOTAL == k3_lds_bytes(NS, KQ) && LDS_TOTAL <= K3_LDS, "LDS carve");
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   unsigned *const s_tie = reinterpret_cast<unsigned *>(lds + OFF_TIE);                      // [NS][32] smallest d'' + 1 seen twice
   [[maybe_unused]] int *const s_qbox = reinterpret_cast<int *>(lds + OFF_QBOX);             // [NS][16] (kept in the carve: the dense mode's home)
   unsigned *const s_smax = reinterpret_cast<unsigned *>(lds + OFF_SMAX);                    // [16] upper bound of sqrt(largest best + 1)
+  unsigned *const s_qmask = reinterpret_cast<unsigned *>(lds + OFF_QMASK);                  // [16] non-zero high-digit chunks of each sub-tile
   int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor, [3] group
   unsigned *const s_ltile = reinterpret_cast<unsigned *>(lds + OFF_LTILE);                  // [LCAP]
   uint16_t *const s_llb = reinterpret_cast<uint16_t *>(lds + OFF_LLB);                      // [LCAP][NSP]
@@ -474,7 +487,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   // helps the next one.
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0;
+  long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0, nmfma = 0;
   const bool dense = a.mode == K3_MODE_DENSE;
   for (;;) {
   __syncthreads();  // the previous group's LDS is no longer read
@@ -520,7 +533,10 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     s_best[i] = real ? a.gbest[st0 * 32 + i] : ~0ull;
     s_tie[i] = real ? a.gtie[st0 * 32 + i] : ~0u;
   }
-  if (tp < 16) s_smax[tp] = (tp < nvalid && !dense) ? a.gsmax[st0 + tp] : 0xFFFEu;
+  if (tp < 16) {
+    s_smax[tp] = (tp < nvalid && !dense) ? a.gsmax[st0 + tp] : 0xFFFEu;
+    s_qmask[tp] = tp < nvalid ? (unsigned)a.qmeta[(st0 + tp) * 16 + 15] : 0u;
+  }
   const int nseg = dense ? (int)((n_ttiles + LCAP - 1) / LCAP) : a.nsegs[g];
   __syncthreads();  // (waits for the LDS-DMA pieces too)
   K3_STAMP(0);  // prologue
@@ -533,7 +549,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     if (dense) {  // every tile, every sub-tile
       list_n = (int)min((int64_t)LCAP, n_ttiles - (int64_t)seg * LCAP);
       for (int i = tl; i < list_n; i += NT) {
-        s_ltile[i] = (unsigned)(seg * LCAP + i);
+        s_ltile[i] = (unsigned)(seg * LCAP + i) | ((unsigned)a.thmask[seg * LCAP + i] << 24);
         for (int p = 0; p < NSP; p++) s_llb[i * NSP + p] = p < nvalid ? 0 : 0xFFFF;
       }
     } else {
@@ -568,13 +584,15 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           const int lb = lane < NSP ? (int)s_llb[j * NSP + lane] : 0xFFFF;
           const int sm = lane < NS ? (int)k3_peek(&s_smax[lane]) : -1;
           const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lb <= sm);
-          if (m) { tile_o = __builtin_amdgcn_readfirstlane(t); lb_o = lb; mask_o = m; return true; }
+          if (m) { tile_o = __builtin_amdgcn_readfirstlane(t); lb_o = lb; mask_o = m; return true; }  // (tile_o: tile | high-chunk mask << 24)
         }
       };
-      int tile = 0, lbv = 0;
+      int tile_w = 0, lbv = 0;
       unsigned mask = 0;
-      bool have = next_entry(tile, lbv, mask);
+      bool have = next_entry(tile_w, lbv, mask);
       while (have) {
+        const int tile = tile_w & 0xFFFFFF;
+        const unsigned tm = (unsigned)tile_w >> 24;
         v4i T[KT];
         v16i ntr;
         k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
@@ -591,7 +609,9 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           const int lbs = __builtin_amdgcn_readlane(lbv, s);
           const unsigned sm_now = (unsigned)__builtin_amdgcn_readfirstlane((int)k3_peek(&s_smax[s]));
           if (lbs > (int)sm_now) continue;
-          const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16);
+          const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_qmask[s]);
+          const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16, tm, qm);
+          nmfma += 6 + __builtin_popcount(tm & qm) + __builtin_popcount(qm) + __builtin_popcount(tm);
           const int qi = s * 32 + (lane & 31);
           const bool refresh = k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], sm_now);
           if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           nblocks++;
           npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
         }
-        tile = ntile; lbv = nlb; mask = nmask; have = nhave;
+        tile_w = ntile; lbv = nlb; mask = nmask; have = nhave;
       }
     }
     K3_STAMP(2);  // consuming
@@ -639,6 +659,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     atomicAdd(a.stats + 1, (unsigned long long)nloads);
     atomicAdd(a.stats + 2, (unsigned long long)npairs);
     if (wave == 0) atomicAdd(a.stats + 3, (unsigned long long)nlisted);
+    atomicAdd(a.stats + 19, (unsigned long long)nmfma);  // matrix instructions issued (a full chain has 6 + HT + HQ + min(HT, HQ))
   }
 }
 
