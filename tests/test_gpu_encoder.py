@@ -412,13 +412,13 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["keys", "keys-colliding-hashes", "gather-all"])
+@pytest.mark.parametrize("mode", ["keys", "keys-colliding-hashes"])
 def test_sharded_reduce_moves_only_what_can_survive(monkeypatch, mode):
     """Reduce over three processes on a clip whose static tile columns repeat across the shard borders and whose tile budget bites (1 500 of
     ~7 000 distinct tiles): the processes exchange 16-byte keys, choose the tiles that can be among the first 1 500 of the merged order and
     all-gather only those; the result is the single run's, also when every hash collides (TM_DEDUP_DEGRADE_HASH:
-    four hash values for all tiles -- everything is then a candidate) and on the old path that gathers every distinct tile; and the
-    key path moves a fraction of the bytes."""
+    four hash values for all tiles -- everything is then a candidate); and the key path moves a fraction of the bytes a copy of every
+    distinct tile would (what rounds 1-2 gathered)."""
     import threading
     from tiler_amd import synth, distributed
     from tiler_amd.encoder import TilingEncoder, TEncoderStep
@@ -428,8 +428,6 @@ def test_sharded_reduce_moves_only_what_can_survive(monkeypatch, mode):
     ref = _run_encoder(frames, **kw)
     want = (np.stack([ref.TileMap(f) for f in range(nf)]), ref.Tiles())
     ref.close()
-    if mode == "gather-all":
-        monkeypatch.setenv("TM_REDUCE_GATHER_ALL", "1")
     if mode == "keys-colliding-hashes":
         monkeypatch.setenv("TM_DEDUP_DEGRADE_HASH", "1")
     fake = _FakeDist(world)
@@ -477,9 +475,7 @@ def test_sharded_reduce_moves_only_what_can_survive(monkeypatch, mode):
     distinct = len(np.unique(np.concatenate([synth_tiles for synth_tiles in [frames.reshape(nf, h // 8, 8, w // 8, 8).transpose(0, 1, 3, 2, 4).reshape(-1, 64)]]), axis=0))
     if mode == "keys":
         assert distinct > 3 * 1500  # the budget bites
-        assert nbytes[0] < 0.5 * distinct * 264 * 1  # far below one copy of every distinct tile (the old path moves world x that)
-    if mode == "gather-all":
-        assert nbytes[0] >= distinct * 264
+        assert nbytes[0] < 0.5 * distinct * 264 * 1  # far below one copy of every distinct tile (gathering them all moves world x that)
 
 
 @pytest.mark.parametrize("radius", [0, 8])

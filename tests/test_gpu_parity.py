@@ -476,20 +476,14 @@ def test_kmeans(oracle, n, d, k):
     assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64)), "centroids must match bit for bit"
 
 
-@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("k", [16, 40])
 @pytest.mark.parametrize("case", ["lattice-ties", "tight-clusters", "one-cluster-far"])
-def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k, fused, monkeypatch):
+def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k):
     """the iterations that skip points whose bounds prove their assignment (k_h_bounds, k_assign192_list4) against the oracle's plain Lloyd
     on data that stresses them: lattice points with many EXACTLY equal distances (ties go to the lowest centroid), clusters tighter than
     the margins of any sloppy bound, and one far cluster (large centroid displacements in the first iterations); 40 centroids take three
-    passes of 16 through the list kernel, whose four lanes per point each score four centroids of a pass; fused: the opt-in single
-    launch per iteration (TM_KM_FUSED, k_h_iter: k <= 16 only, slower than the three kernels and therefore not the default)"""
+    passes of 16 through the list kernel, whose four lanes per point each score four centroids of a pass"""
     from tiler_amd import stages
-    if fused:
-        if k > 16:
-            pytest.skip("the single-launch iteration holds 16 centroids")
-        monkeypatch.setenv("TM_KM_FUSED", "1")
     rng = np.random.default_rng(len(case))
     n, d = 6000, 192
     if case == "lattice-ties":

@@ -42,6 +42,18 @@ const char *get_error();
 // Fails loudly when no gfx950 device can run the kernels (there is no CPU path).
 int require_device();
 
+// The library's environment switches (the table in include/tilemotion.h documents them).  They are sampled at the API boundary -- tm_create,
+// tm_run, every tm_stage_* and fine-seam entry (knobs_reload, through require_device) -- into the calling thread's set; nothing inside a step
+// calls getenv.
+struct Knobs {
+  bool knn_debug = false, knn_noprune = false, topk_brute = false, no_query_groups = false, dither_own_keys = false, dither_no_dedup = false,
+       dither_literal = false, dedup_plain = false, dedup_degrade_hash = false, dedup_full_order = false, motion_valu = false, pp_debug = false,
+       comm_force_dist = false;
+  double epu_table_gib = 6.0, comm_timeout_s = 120.0;
+};
+const Knobs &knobs();
+void knobs_reload();
+
 // Device memory pool: hipMalloc / hipFree of the pipeline's multi-GB temporaries cost ~16 ms per 720p clip (and hipFree
 // synchronises the device), so freed blocks are kept per host thread and handed out again.  A thread drives its encoder on
 // one stream, so reuse is stream-ordered; blocks never migrate between threads.  pool_trim() returns everything to the

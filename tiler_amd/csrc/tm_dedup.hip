@@ -298,7 +298,7 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
                        headpos.as<uint32_t>());
     return TM_OK;
   };
-  if (!getenv("TM_DEDUP_PLAIN")) {
+  if (!knobs().dedup_plain) {
     DevBuf hkey, hkey2;
     TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8));
     // The sort only has to bring equal rows together, so the hash keeps only as many of its top bits (whole 8-bit passes of the sort) as hold
@@ -308,10 +308,9 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     // merge-sort path (up to ~1 M keys) through a mask built with a shift by 64 -- it then orders by the wrong bits and its merge reads out
     // of bounds (found the hard way: a memory access fault on the GPU box).
     int hbits = 64;
-    const int degrade = getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0;
+    const int degrade = knobs().dedup_degrade_hash ? 1 : 0;
     if (!degrade) {
       hbits = std::min(64, ((int)std::ceil(2.0 * std::log2((double)std::max<int64_t>(n, 2)) + 11.0) + 7) / 8 * 8);  // n^2 / 2^(bits + 1) <= 2^-12
-      if (const char *hb = getenv("TM_DEDUP_HASH_BITS")) hbits = std::max(8, std::min(64, atoi(hb) / 8 * 8));  // A/B aid
     }
     hipLaunchKernelGGL(k_row_hash, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, n,
                        row_bytes / 4, degrade, 64 - hbits, hkey.as<unsigned long long>());
@@ -355,7 +354,7 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   const int64_t nu = (int64_t)last_excl + last_head;
   bool ranked = false;  // ord2 already holds the final order
   unsigned long long live = 0;
-  if (grouped && !by_index && !use_in && exact_first > 0 && exact_first < nu && !getenv("TM_DEDUP_FULL_ORDER")) {
+  if (grouped && !by_index && !use_in && exact_first > 0 && exact_first < nu && !knobs().dedup_full_order) {
     // Only the first exact_first positions have to be right.  The order is use count descending, content ascending: a histogram of the use
     // counts finds the count u* of position exact_first, a histogram of the leading dword's top bits among the rows used u* times finds
     // the bucket that position falls into; rows used more often, or u* times with a leading dword up to that bucket, are the only ones
@@ -598,7 +597,7 @@ __global__ void k_rk_select(const unsigned long long *__restrict__ skey, const u
 int reduce_make_keys(const void *rows, const void *idx, const void *use, int64_t n, int row_bytes, void *keys_out, hipStream_t stream) {
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_reduce_keys, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32)), dim3(256), 0, stream, (const uint32_t *)rows, (const int32_t *)idx,
-                     (const uint32_t *)use, n, row_bytes / 4, getenv("TM_DEDUP_DEGRADE_HASH") ? 1 : 0, (ReduceKey *)keys_out);
+                     (const uint32_t *)use, n, row_bytes / 4, knobs().dedup_degrade_hash ? 1 : 0, (ReduceKey *)keys_out);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

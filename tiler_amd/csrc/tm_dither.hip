@@ -478,13 +478,13 @@ int launch_dither(const void *tiles, const void *flags, const void *pal_idx, int
   if (n <= 0) return TM_OK;
   int grid = (int)std::min<int64_t>(n, 256 * 40);
   if (use_tk) {
-    static const bool literal_only = getenv("TM_DITHER_LITERAL") != nullptr;  // debugging aid: every tile through the literal sort
+    const bool literal_only = knobs().dither_literal;  // debugging aid: every tile through the literal sort
     DevBuf cls;
     if (!literal_only) {
       TM_TRY(cls.alloc((size_t)npal));
       hipLaunchKernelGGL(k_palette_class, dim3((npal + 63) / 64), dim3(64), 0, stream, (const int32_t *)palettes, npal, pal_size, cls.as<uint8_t>());
       // distinct (palette, colour) pairs first: worth it when at most half of the pixels are distinct
-      const bool no_dedup = getenv("TM_DITHER_NO_DEDUP") != nullptr;
+      const bool no_dedup = knobs().dither_no_dedup;
       const int64_t nent = (int64_t)npal << 16;
       bool dedup = !no_dedup && npal <= DD_MAX_PAL && n >= 1024 && nent <= n * 256;
       DevBuf bits, cnt, off, seg, scan_tmp, missing;

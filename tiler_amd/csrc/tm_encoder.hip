@@ -116,13 +116,7 @@ __global__ void k_unpack_unique(const uint32_t *__restrict__ rec, int64_t n, uin
     if (v < 64) tiles[r * 64 + v] = rec[e]; else if (v == 64) use[r] = rec[e]; else flags[r] = (uint8_t)rec[e];
   }
 }
-__global__ void k_compose_remap(const int32_t *__restrict__ local_remap, int64_t n, const int32_t *__restrict__ union_remap, int32_t union_off, int32_t limit,
-                                int32_t *__restrict__ out) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t g = union_remap[union_off + local_remap[i]];
-    out[i] = g < limit ? g : -1;
-  }
-}
+
 // a frame tile's global index through the candidates: its local distinct tile travelled (in_s) as candidate number cand_pos[.] of this
 // process, which the exact dedup of all candidates mapped to cand_remap[.]; anything else is beyond the tile budget
 __global__ void k_compose_remap_cand(const int32_t *__restrict__ local_remap, int64_t n, const uint32_t *__restrict__ in_s, const int32_t *__restrict__ cand_pos,
@@ -239,7 +233,6 @@ struct tm_encoder {
   // Launched when PreparePalettes hands over to the host (OptimizePalettes' 2-5 ms search, then Dither's start), the one stretch where
   // the GPU idles; launched earlier they only trade time with the k-means kernels (measured: +3.8 ms there for -3.7 ms here).
   hipStream_t stream2 = nullptr;
-  hipStream_t stream_km = nullptr;  // TM_CU_SPLIT experiment: the tile k-means on its own compute units, stream2 on the others
   hipEvent_t ev_qf = nullptr;
   DevBuf qf_pre;
   DevBuf qf_colmm;  // the prefetched distinct rows' column ranges (the feature kernel keeps them; Reconstruct's search reads them)
@@ -261,7 +254,6 @@ struct tm_encoder {
     if (comm) { (void)hipStreamSynchronize(stream); (void)ncclCommAbort(comm); }  // (abort = destroy without the collective handshake: no peer is waited for)
     if (ev_qf) (void)hipEventDestroy(ev_qf);
     if (stream2) (void)hipStreamDestroy(stream2);
-    if (stream_km) (void)hipStreamDestroy(stream_km);
     if (stream_aux) { (void)hipStreamSynchronize(stream_aux); (void)hipStreamDestroy(stream_aux); }
     if (ev_tiles) (void)hipEventDestroy(ev_tiles);
     if (copy_stream) (void)hipStreamSynchronize(copy_stream);
@@ -370,8 +362,7 @@ static int coll_run(tm_encoder *e, int kind, void *buf, void *recv, int64_t coun
 // it settles, for at most TM_COMM_TIMEOUT_S seconds (default 120).
 static ncclResult_t nccl_settle(ncclComm_t comm, ncclResult_t r) {
   if (r != ncclInProgress) return r;
-  const char *ts = getenv("TM_COMM_TIMEOUT_S");
-  const double limit = ts ? std::max(1.0, atof(ts)) : 120.0;
+  const double limit = knobs().comm_timeout_s;
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     ncclResult_t st = ncclSuccess;
@@ -507,7 +498,7 @@ static int queue_host_clip(tm_encoder *e, int slot, const void *host) {
   const size_t fbytes = (size_t)e->width * e->height * 4;
   TM_TRY(hc.buf.alloc(fbytes * e->nframes));
   if (!e->copy_stream) TM_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  static const size_t chunk_mb = getenv("TM_H2D_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("TM_H2D_CHUNK_MB"))) : 48;  // (A/B aid)
+  constexpr size_t chunk_mb = 48;  // (4-48 MB measured alike)
   hc.chunk = (int)std::max<size_t>(1, (chunk_mb << 20) / fbytes);
   hc.nchunks = (e->nframes + hc.chunk - 1) / hc.chunk;
   while ((int)hc.events.size() < hc.nchunks) {
@@ -612,16 +603,6 @@ static int step_load(tm_encoder *e) {  // Load, tilingencoder.pas:1741-1841 (dec
     TM_HIP(hipStreamSynchronize(e->stream));
     hipStream_t keep = e->stream_aux;
     e->stream_aux = nullptr;  // (the sums sit behind the encoder's own stream here)
-    e->load_tail_pending = true;
-    e->kf_lo_thres = e->s.ShotTransCorrelLoThres; e->kf_min_s = e->s.ShotTransMinSecondsPerKF; e->kf_max_s = e->s.ShotTransMaxSecondsPerKF; e->kf_fps = e->fps;
-    const int rc = load_tail(e);
-    e->stream_aux = keep;
-    TM_TRY(rc);
-  } else if (getenv("TM_LOAD_TAIL_NOW")) {  // A/B aid: the correlation on the encoder's stream, its tail before Load returns
-    TM_TRY(launch_pearson(e->flab.p, e->nframes, per, dcorrel.p, e->stream));
-    TM_HIP(hipStreamSynchronize(e->stream));
-    hipStream_t keep = e->stream_aux;
-    e->stream_aux = nullptr;
     e->load_tail_pending = true;
     e->kf_lo_thres = e->s.ShotTransCorrelLoThres; e->kf_min_s = e->s.ShotTransMinSecondsPerKF; e->kf_max_s = e->s.ShotTransMaxSecondsPerKF; e->kf_fps = e->fps;
     const int rc = load_tail(e);
@@ -775,14 +756,13 @@ static int step_reduce(tm_encoder *e) {
     int64_t lnu = 0;
     TM_TRY(lremap.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(lorder.alloc((size_t)std::max<int64_t>(nloc, 1) * 4)); TM_TRY(luse.alloc((size_t)std::max<int64_t>(nloc, 1) * 4));
     if (nloc > 0) TM_TRY(run_dedup(e->ftiles.as<uint8_t>() + f0 * per * 256, nloc, 256, nullptr, lremap.p, lorder.p, luse.p, &lnu, e->stream));
-    // What travels: by default only the tiles that can be among the first GlobalTilingTileCount of the merged order, chosen on 16-byte
-    // keys every process exchanges first (tm_dedup.hip, "Reduce over several processes"); TM_REDUCE_GATHER_ALL=1: every distinct tile
-    // of every process, as the first two rounds did (857 MB on the bench clip).
-    const bool by_keys = !getenv("TM_REDUCE_GATHER_ALL");
+    // What travels: only the tiles that can be among the first GlobalTilingTileCount of the merged order, chosen on 16-byte keys every
+    // process exchanges first (tm_dedup.hip, "Reduce over several processes"; gathering every distinct tile of every process, as the
+    // first two rounds did, moved 857 MB on the bench clip).
     const int64_t budget = e->s.GlobalTilingTileCount > 0 ? (int64_t)e->s.GlobalTilingTileCount : 0;  // 0: no budget, everything stays
     DevBuf lkeys, allkeys, in_s, sel, spos, sidx, suse;
     int64_t nsel = lnu, key_off = 0;
-    if (by_keys) {
+    {
       TM_TRY(lkeys.alloc((size_t)std::max<int64_t>(lnu, 1) * 16));
       TM_TRY(reduce_make_keys(e->ftiles.as<uint8_t>() + f0 * per * 256, lorder.p, luse.p, lnu, 256, lkeys.p, e->stream));
       std::vector<int64_t> kcounts;
@@ -804,7 +784,7 @@ static int step_reduce(tm_encoder *e) {
     TM_TRY(rec.alloc((size_t)std::max<int64_t>(nsel, 1) * 264));
     if (nsel > 0)
       hipLaunchKernelGGL(k_pack_unique, dim3(gridn(nsel * 66)), dim3(256), 0, e->stream, e->ftiles.as<uint32_t>() + f0 * per * 64, e->fflags.as<uint8_t>() + f0 * per,
-                         by_keys ? sidx.as<int32_t>() : lorder.as<int32_t>(), by_keys ? suse.as<uint32_t>() : luse.as<uint32_t>(), nsel, rec.as<uint32_t>());
+                         sidx.as<int32_t>(), suse.as<uint32_t>(), nsel, rec.as<uint32_t>());
     TM_HIP(hipGetLastError());
     std::vector<int64_t> counts;
     TM_TRY(gather_var(e, rec.p, nsel, 264, urec, &counts));
@@ -829,12 +809,9 @@ static int step_reduce(tm_encoder *e) {
     TM_HIP(hipMemcpyAsync(e->guse.p, guse2.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
     // tile map of this process's frames (TransferTiles: TileIdx := the tile's index, 4079-4083); the other frames' items are their owners'
     TM_HIP(hipMemsetAsync(e->tm_tile.p, 0xff, (size_t)e->q * 4, e->stream));
-    if (nloc > 0 && by_keys)
+    if (nloc > 0)
       hipLaunchKernelGGL(k_compose_remap_cand, dim3(gridn(nloc)), dim3(256), 0, e->stream, lremap.as<int32_t>(), nloc, in_s.as<uint32_t>() + key_off, spos.as<int32_t>(),
                          gremap.as<int32_t>(), (int32_t)my_off, (int32_t)e->t, e->tm_tile.as<int32_t>() + f0 * per);
-    else if (nloc > 0)
-      hipLaunchKernelGGL(k_compose_remap, dim3(gridn(nloc)), dim3(256), 0, e->stream, lremap.as<int32_t>(), nloc, gremap.as<int32_t>(), (int32_t)my_off, (int32_t)e->t,
-                         e->tm_tile.as<int32_t>() + f0 * per);
     TM_HIP(hipGetLastError());
     TM_HIP(hipStreamSynchronize(e->stream));
     e->has_pal_px = e->reconstructed = false;
@@ -864,7 +841,7 @@ static int step_reduce(tm_encoder *e) {
   hipLaunchKernelGGL(k_clip_index, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, (int32_t)e->t);
   TM_HIP(hipGetLastError());
   TM_HIP(hipStreamSynchronize(e->stream));
-  if (!getenv("TM_NO_QUERY_GROUPS")) {  // kept for Reconstruct: one search per distinct frame tile
+  if (!knobs().no_query_groups) {  // kept for Reconstruct: one search per distinct frame tile
     e->q_group = std::move(remap);
     e->q_rep = std::move(order);
     e->q_groups = nu;
@@ -887,7 +864,6 @@ static bool query_groups_usable(const tm_encoder *e, int sf, int sn, bool epu) {
 }
 
 static int prefetch_query_features(tm_encoder *e) {
-  if (getenv("TM_NO_PREFETCH")) return TM_OK;
   const int sf = std::max(0, std::min(e->shard_first, e->nframes));
   const int sn = e->shard_count < 0 ? e->nframes - sf : std::max(0, std::min(e->shard_count, e->nframes - sf));
   if (sn <= 0) return TM_OK;
@@ -896,13 +872,6 @@ static int prefetch_query_features(tm_encoder *e) {
   const int64_t per = e->tm_size();
   e->drop_prefetch();
   const bool distinct = query_groups_usable(e, sf, sn, epu);
-  const int split = getenv("TM_CU_SPLIT") ? atoi(getenv("TM_CU_SPLIT")) : 0;
-  if (!e->stream2 && split > 0) {
-    uint32_t a[8] = {0}, b[8] = {0};
-    for (int i = 0; i < 256; i++) (i < split ? a : b)[i >> 5] |= 1u << (i & 31);
-    TM_HIP(hipExtStreamCreateWithCUMask(&e->stream_km, 8, a));
-    TM_HIP(hipExtStreamCreateWithCUMask(&e->stream2, 8, b));
-  }
   if (!e->stream2) {  // lowest priority: the small dependent kernels of PreparePalettes must not queue behind this one's workgroups
     int lo = 0, hi = 0;
     TM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -943,7 +912,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(need(e, TM_STEP_REDUCE, "Reduce"));
   TM_TRY(need_global_rgb(e, "PreparePalettes"));
   TM_CHECK(e->t > 0, TM_E_INVAL, "no global tiles");
-  const bool dbg = getenv("TM_PP_DEBUG") != nullptr;  // wall time of the sub-steps (adds stream synchronisations)
+  const bool dbg = knobs().pp_debug;  // wall time of the sub-steps (adds stream synchronisations)
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!dbg) return;
@@ -983,19 +952,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
   TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
   TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
   lap("cluster features");
-  if (getenv("TM_CU_SPLIT")) {  // experiment: the query features on a quarter of the compute units while the tile k-means has the rest
-    TM_HIP(hipStreamSynchronize(e->stream));
-    TM_TRY(prefetch_query_features(e));
-    hipStream_t km = e->stream_km ? e->stream_km : e->stream;
-    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, km));
-    TM_HIP(hipStreamSynchronize(km));
-  } else {
-    if (getenv("TM_QF_EARLY")) {  // experiment: Reconstruct's query features beside the clusterings, on a small grid (TM_QF_GRID)
-      TM_HIP(hipStreamSynchronize(e->stream));
-      TM_TRY(prefetch_query_features(e));
-    }
-    TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
-  }
+  TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
   lap("tile -> palette (192-D)");
   progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
   TM_TRY(run_quantize_palettes(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->stream, &e->pair_keys, &e->pair_keys_n));
@@ -1009,7 +966,6 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     TM_TRY(hr_.wait());
   }
   progress(e, TM_STEP_PREPARE_PALETTES, 2, 3);
-  if (!getenv("TM_CU_SPLIT") && !getenv("TM_QF_EARLY"))
   TM_TRY(prefetch_query_features(e));  // the GPU has nothing to do while the host searches: Reconstruct's query features run now
   lap("prefetch launch");
   // OptimizePalettes (4309-4432): slot permutation by Powell on the host (P x PaletteSize colours)
@@ -1031,7 +987,7 @@ static int step_dither(tm_encoder *e) {  // Dither, tilingencoder.pas:1873-1907
   if (t1 > t0)
     TM_TRY(launch_dither(e->gtiles.as<uint8_t>() + t0 * 256, e->gflags.as<uint8_t>() + t0, e->gpal_idx.as<uint8_t>() + t0 * 4, t1 - t0, e->palettes_dev.p,
                          e->s.PaletteCount, e->s.PaletteSize, e->s.DitheringUseThomasKnoll ? 1 : 0, e->s.DitheringYliluoma2MixedColors,
-                         e->gpal_px.as<uint8_t>() + t0 * 64, e->stream, &e->dither_pairs, e->pair_keys_n > 0 && !getenv("TM_DITHER_OWN_KEYS") ? e->pair_keys.p : nullptr,
+                         e->gpal_px.as<uint8_t>() + t0 * 64, e->stream, &e->dither_pairs, e->pair_keys_n > 0 && !knobs().dither_own_keys ? e->pair_keys.p : nullptr,
                          e->pair_keys_n));
   if (e->dist() && e->dither_world > 1) TM_TRY(e->co.allreduce_sum_i32(e->gpal_px.p, e->t * 16));  // 64 bytes per tile = 16 words; other shares hold 0
   TM_HIP(hipStreamSynchronize(e->stream));
@@ -1086,7 +1042,7 @@ static int step_reconstruct(tm_encoder *e) {
     const int npal = e->s.PaletteCount;
     // the table of every tile under every palette while it fits (T x P x 384 bytes: 2 GB at 16 palettes); with the reference's default
     // of 1024 palettes it would be tens of terabytes, and the re-rank builds just the rows its queries name instead
-    const double table_gib = getenv("TM_EPU_TABLE_GIB") ? atof(getenv("TM_EPU_TABLE_GIB")) : 6.0;
+    const double table_gib = knobs().epu_table_gib;
     const bool use_table = (double)e->t * npal * 384.0 <= table_gib * 1073741824.0;
     if (use_table) {
       TM_TRY(table.alloc((size_t)e->t * npal * 384));
@@ -1127,7 +1083,7 @@ static int step_reconstruct(tm_encoder *e) {
         TM_TRY(launch_features_rgb_rows(e->ftiles.p, e->q_rep.p, ng, TM_PVS_WEIGHTED_DCT, 0, qf.p, e->stream));
       }
       e->knn_queries += ng;
-      rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qfp, ng, db.p, e->t, 64, idx64.p, err64.p, e->stream)
+      rc = knobs().topk_brute ? launch_knn_topk(qfp, ng, db.p, e->t, 64, idx64.p, err64.p, e->stream)
                                    : knn_index_search_topk(ix, qfp, ng, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
       if (rc == TM_OK)
         rc = use_table ? launch_epu_rerank(qfp, ng, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, gt.as<int32_t>(), gp.as<int32_t>(), ge.as<uint32_t>(), e->stream)
@@ -1148,7 +1104,7 @@ static int step_reconstruct(tm_encoder *e) {
       rc = query_features(e, f0, nf, true, qf, &qfp);
       e->knn_queries += n;
       if (rc == TM_OK)
-        rc = getenv("TM_TOPK_BRUTE") ? launch_knn_topk(qfp, n, db.p, e->t, 64, idx64.p, err64.p, e->stream)  // debugging aid: VALU brute force over all rows
+        rc = knobs().topk_brute ? launch_knn_topk(qfp, n, db.p, e->t, 64, idx64.p, err64.p, e->stream)  // debugging aid: VALU brute force over all rows
                                      : knn_index_search_topk(ix, qfp, n, 64, idx64.p, err64.p, e->stream, g_off.p, g_members.p, db.p, e->t);
       if (rc == TM_OK)
         rc = use_table ? launch_epu_rerank(qfp, n, idx64.p, 64, e->gpal_idx.p, e->t, npal, table.p, e->tm_tile.as<int32_t>() + off,
@@ -1183,7 +1139,7 @@ static int step_reconstruct(tm_encoder *e) {
     if (e->qf_valid && e->qf_distinct) {
       TM_HIP(hipStreamWaitEvent(e->stream, e->ev_qf, 0));
       qfp = e->qf_pre.p;
-      if (!getenv("TM_KNN_OWN_COLSTATS")) qmm = e->qf_colmm.p;
+      qmm = e->qf_colmm.p;
     } else {
       TM_TRY(qf.alloc((size_t)ng * 384));
       qfp = qf.p;
@@ -1303,16 +1259,13 @@ static int step_reindex(tm_encoder *e) {  // Reindex, tilingencoder.pas:1993-203
   TM_TRY(use.alloc((size_t)e->t * 4));
   // UseCount recount from the tile maps (2018-2031); MakeTilesUnique(False) merges by palette-index content and
   // sums the counts of merged tiles -- same totals as counting after the merge remap
-  if (!getenv("TM_HIST_ONE")) {  // (TM_HIST_ONE=1: one histogram for all XCDs, for A/B)
+  {  // one histogram copy per XCD, folded afterwards ("Atomics across XCDs")
     DevBuf h8;
     TM_TRY(h8.alloc((size_t)e->t * 4 * 8));
     TM_HIP(hipMemsetAsync(h8.p, 0, (size_t)e->t * 4 * 8, e->stream));
     hipLaunchKernelGGL(k_histogram_xcd, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, h8.as<uint32_t>(), (int64_t)e->t);
     hipLaunchKernelGGL(k_hist_fold, dim3(gridn(e->t)), dim3(256), 0, e->stream, h8.as<uint32_t>(), (int64_t)e->t, hist.as<uint32_t>());
     // (h8 goes back to the pool with this scope; what takes it next is queued on this stream behind the fold)
-  } else {
-    TM_HIP(hipMemsetAsync(hist.p, 0, (size_t)e->t * 4, e->stream));
-    hipLaunchKernelGGL(k_histogram, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->tm_tile.as<int32_t>(), e->q, hist.as<uint32_t>());
   }
   int64_t nu = 0;
   TM_TRY(run_dedup(e->gpal_px.p, e->t, 64, hist.p, remap.p, order.p, use.p, &nu, e->stream));
@@ -1773,6 +1726,7 @@ int tm_prefetch_frames_host(tm_encoder *e, const uint32_t *host_frames) {
 
 int tm_run(tm_encoder *e, int step) {
   TM_CHECK(e, TM_E_INVAL, "null encoder");
+  knobs_reload();  // the environment switches are sampled here, once per Run; the steps read the sampled set
   if (step == TM_STEP_ALL) {  // Run(esAll): every step in order (5535-5553); Save only once an output name is set
     for (int s = TM_STEP_LOAD; s <= TM_STEP_REINDEX; s++) TM_TRY(run_step(e, s));
     if (!e->s.OutputFileName.empty()) TM_TRY(run_step(e, TM_STEP_SAVE));
@@ -1957,6 +1911,7 @@ int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, in
   TM_CHECK(e && id, TM_E_INVAL, "null argument");
   TM_CHECK(world >= 1 && rank >= 0 && rank < world, TM_E_INVAL, "bad process %d of %d", rank, world);
   TM_CHECK(e->comm == nullptr, TM_E_INVAL, "tm_comm_init: this encoder already has a communicator (tm_comm_destroy first)");
+  knobs_reload();
   TM_HIP(hipSetDevice(e->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
@@ -1966,8 +1921,7 @@ int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, in
     ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
     cfg.blocking = 0;
     ncclResult_t r = ncclCommInitRankConfig(&e->comm, world, u, rank, &cfg);
-    const char *ts = getenv("TM_COMM_TIMEOUT_S");
-    const double limit = ts ? std::max(1.0, atof(ts)) : 120.0;
+    const double limit = knobs().comm_timeout_s;
     const auto t0 = std::chrono::steady_clock::now();
     while (r == ncclInProgress || (r == ncclSuccess && e->comm)) {
       ncclResult_t st = ncclSuccess;
@@ -1989,8 +1943,7 @@ int tm_comm_init(tm_encoder *e, const uint8_t id[TM_COMM_ID_BYTES], int rank, in
   e->coll_stream_ordered = true;
   e->co.rank = rank;
   e->co.world = world;
-  const char *f = getenv("TM_COMM_FORCE_DIST");
-  e->force_dist = f && atoi(f) != 0;
+  e->force_dist = knobs().comm_force_dist;
   bind_native_collectives(e);
   e->dither_rank = rank;
   e->dither_world = world;

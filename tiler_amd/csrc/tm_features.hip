@@ -405,8 +405,7 @@ int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int
   TM_TRY(get_tables(&tab));
   TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   if (n <= 0) return TM_OK;
-  static const int cap = getenv("TM_QF_GRID") ? atoi(getenv("TM_QF_GRID")) : 0;  // experiment: a grid that leaves room beside it ("Second stream")
-  const int grid = cap > 0 ? std::min(cap, grid_for(n, 4)) : grid_for(n, 4);
+  const int grid = grid_for(n, 4);
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      (const int32_t *)rows, nullptr, 0, (const uint8_t *)nullptr, n, mode_weighted(mode) ? 1 : 0, use_lab,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)colmm);

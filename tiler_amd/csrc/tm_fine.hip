@@ -64,6 +64,7 @@ extern "C" {
 
 // ---- ANN.dll (extern.pas:178-180): double coordinates, any dimension
 tm_annd *ann_kdtree_create(double **rows, int n, int dd, int bs, int split) {
+  knobs_reload();
   (void)bs; (void)split;  // bucket size / split rule shape a kd-tree; the exact answer does not depend on them
   if (require_device() != TM_OK) return nullptr;
   if (dd < 1 || n < 0 || (n > 0 && !rows)) { set_error("ann_kdtree_create: bad arguments (n %d, dd %d)", n, dd); return nullptr; }
@@ -81,6 +82,7 @@ tm_annd *ann_kdtree_create(double **rows, int n, int dd, int bs, int split) {
 void ann_kdtree_destroy(tm_annd *a) { delete a; }
 
 int ann_kdtree_search_batch(tm_annd *a, const double *queries, int nq, int32_t *idxs, double *errs) {
+  knobs_reload();
   TM_CHECK(a && (nq == 0 || (queries && idxs)), TM_E_INVAL, "null argument");
   if (nq <= 0) return TM_OK;
   std::lock_guard<std::mutex> lk(a->mu);
@@ -95,6 +97,7 @@ int ann_kdtree_search_batch(tm_annd *a, const double *queries, int nq, int32_t *
 }
 
 int ann_kdtree_search(tm_annd *a, const double *q, double eps, double *err) {
+  knobs_reload();
   (void)eps;  // the reference passes 0.0 (exact, tilingencoder.pas:4128)
   int32_t idx = -1;
   double e = 0.0;
@@ -105,6 +108,7 @@ int ann_kdtree_search(tm_annd *a, const double *q, double eps, double *err) {
 
 // ---- ANN_short.dll (extern.pas:182-185): the same export names in ANN_short.dll, `_short` on the Pascal side
 tm_ann *ann_kdtree_short_create(int16_t **rows, int n, int dd, int bs, int split) {
+  knobs_reload();
   (void)bs; (void)split;  // bucket size / split rule shape a kd-tree; the exact answer does not depend on them
   if (require_device() != TM_OK) return nullptr;
   if (dd != 192 || n < 0 || (n > 0 && !rows)) { set_error("ann_kdtree_create: only dd = 192 (cTileDCTSize) is supported"); return nullptr; }
@@ -125,6 +129,7 @@ tm_ann *ann_kdtree_short_create(int16_t **rows, int n, int dd, int bs, int split
 void ann_kdtree_short_destroy(tm_ann *a) { delete a; }
 
 int ann_kdtree_short_search_batch(tm_ann *a, const int16_t *queries, int nq, int32_t *idxs, uint32_t *errs) {
+  knobs_reload();
   TM_CHECK(a && (nq == 0 || (queries && idxs)), TM_E_INVAL, "null argument");
   if (nq <= 0) return TM_OK;
   std::lock_guard<std::mutex> lk(a->mu);
@@ -138,6 +143,7 @@ int ann_kdtree_short_search_batch(tm_ann *a, const int16_t *queries, int nq, int
 }
 
 int ann_kdtree_short_search(tm_ann *a, const int16_t *q, uint32_t eps, uint32_t *err) {
+  knobs_reload();
   (void)eps;  // the reference always passes 0 (exact); a positive eps would only allow a worse answer
   int32_t idx = -1;
   uint32_t e = 0xffffffffu;
@@ -147,6 +153,7 @@ int ann_kdtree_short_search(tm_ann *a, const int16_t *q, uint32_t eps, uint32_t 
 }
 
 void ann_kdtree_short_search_multi(tm_ann *a, int32_t *idxs, uint32_t *errs, int cnt, const int16_t *q, uint32_t eps) {
+  knobs_reload();
   (void)eps;
   for (int i = 0; i < cnt; i++) { if (idxs) idxs[i] = -1; if (errs) errs[i] = 0xffffffffu; }
   if (!a || !q || !idxs || cnt <= 0 || a->n == 0) return;
@@ -201,6 +208,7 @@ static int kmeans_host(const std::vector<int32_t> &pts, const uint32_t *w, int n
 extern "C" {
 
 tm_yakmo *yakmo_create(uint32_t k, uint32_t restart_count, int max_iter, int init_type, int init_seed, int do_normalize, int is_verbose) {
+  knobs_reload();
   (void)restart_count; (void)init_type; (void)init_seed; (void)do_normalize; (void)is_verbose;
   if (k == 0 || k > 65536) { set_error("yakmo_create: k out of range"); return nullptr; }
   tm_yakmo *y = new tm_yakmo();
@@ -221,17 +229,20 @@ void yakmo_load_train_data(tm_yakmo *y, uint32_t row_count, uint32_t col_count, 
 }
 
 void yakmo_train_on_data(tm_yakmo *y, int32_t *point_to_cluster) {
+  knobs_reload();
   if (!y || y->rows <= 0) return;
   if (kmeans_host(y->pts, nullptr, y->rows, y->cols, std::min(y->k, y->rows), y->max_iter, point_to_cluster, y->cent, &y->live) != TM_OK)
     y->live = 0;
 }
 
 void yakmo_get_centroids(tm_yakmo *y, double **centroids) {
+  knobs_reload();
   if (!y || !centroids) return;
   for (int c = 0; c < y->live; c++) memcpy(centroids[c], &y->cent[(size_t)c * y->cols], sizeof(double) * (size_t)y->cols);
 }
 
 tm_bico *bico_create(int64_t dimension, int64_t npoints, int64_t k, int64_t nrandproj, int64_t coresetsize, int random_seed) {
+  knobs_reload();
   (void)nrandproj; (void)random_seed;
   if (dimension <= 0 || coresetsize <= 0) { set_error("bico_create: bad arguments"); return nullptr; }
   tm_bico *b = new tm_bico();
@@ -246,12 +257,14 @@ void bico_set_num_threads(int) {}
 void bico_set_rebuild_properties(tm_bico *, uint32_t, double, double) {}
 
 void bico_insert_line(tm_bico *b, const double *line, double weight) {
+  knobs_reload();
   if (!b || !line) return;
   for (int c = 0; c < b->dim; c++) b->pts.push_back((int32_t)llrint(line[c]));
   b->w.push_back((uint32_t)std::max<long long>(1, llrint(weight)));
 }
 
 int64_t bico_get_results(tm_bico *b, double *centroids, double *weights) {
+  knobs_reload();
   // the coreset of the inserted points = the build's k-means with coresetsize centres; weight = summed point weights
   if (!b || !centroids || !weights || b->w.empty()) return 0;
   const int n = (int)b->w.size(), k = (int)std::min<int64_t>(b->coreset, n);

@@ -66,142 +66,11 @@ struct LenCoder {
   }
 };
 
-class LzmaEncoder {  // lc/lp/pb as LZCompress sets them: SetLcLpPb(8,0,2), end marker on (extern.pas:429-430)
- public:
-  static constexpr int kLc = 8, kLp = 0, kPb = 2;
-  static constexpr uint32_t kDict = 1u << 22;
-
-  LzmaEncoder(std::vector<uint8_t> &out) : rc_(out), lit_((size_t)0x300 << (kLc + kLp), 1024) {
-    for (auto &r : is_match_) for (auto &p : r) p = 1024;
-    for (auto &r : is_rep0_long_) for (auto &p : r) p = 1024;
-    for (auto &p : is_rep_) p = 1024;
-    for (auto &p : is_rep_g0_) p = 1024;
-    for (auto &p : is_rep_g1_) p = 1024;
-    for (auto &p : is_rep_g2_) p = 1024;
-    for (auto &r : pos_slot_) for (auto &p : r) p = 1024;
-    for (auto &p : pos_special_) p = 1024;
-    for (auto &p : pos_align_) p = 1024;
-  }
-
-  void encode(const uint8_t *src, size_t n) {
-    std::vector<int32_t> head(1 << 16, -1), prev(n ? n : 1, -1);
-    auto hash3 = [&](size_t i) { return (uint32_t)((src[i] | (src[i + 1] << 8) | (src[i + 2] << 16)) * 2654435761u) >> 16; };
-    size_t pos = 0;
-    while (pos < n) {
-      const uint32_t pos_state = (uint32_t)pos & ((1u << kPb) - 1);
-      // candidates: rep0, then the hash chain
-      size_t best_len = 0, best_dist = 0, rep_len = 0;
-      const size_t max_len = std::min<size_t>(273, n - pos);
-      if (pos > rep_[0]) {
-        const uint8_t *a = src + pos, *b = src + pos - rep_[0] - 1;
-        while (rep_len < max_len && a[rep_len] == b[rep_len]) rep_len++;
-      }
-      if (pos + 3 <= n) {
-        const uint32_t h = hash3(pos);
-        int32_t cand = head[h];
-        for (int depth = 0; cand >= 0 && depth < 32; depth++, cand = prev[cand]) {
-          const size_t dist = pos - (size_t)cand;  // >= 1
-          if (dist > kDict) break;
-          const uint8_t *a = src + pos, *b = src + cand;
-          size_t l = 0;
-          while (l < max_len && a[l] == b[l]) l++;
-          if (l > best_len) { best_len = l; best_dist = dist - 1; if (l == max_len) break; }
-        }
-      }
-      size_t step;
-      if (rep_len >= 2 && rep_len + 1 >= best_len) {  // rep0 long match: cheapest way to say "same distance again"
-        rc_.bit(is_match_[state_][pos_state], 1);
-        rc_.bit(is_rep_[state_], 1);
-        rc_.bit(is_rep_g0_[state_], 0);
-        rc_.bit(is_rep0_long_[state_][pos_state], 1);
-        encode_len(rep_len_, (uint32_t)rep_len, pos_state);
-        state_ = state_ < 7 ? 8 : 11;
-        step = rep_len;
-      } else if (best_len >= 3 || (best_len == 2 && best_dist < 128)) {
-        encode_match((uint32_t)best_dist, (uint32_t)best_len, pos_state);
-        step = best_len;
-      } else {
-        encode_literal(src, pos, pos_state);
-        step = 1;
-      }
-      for (size_t k = 0; k < step; k++) {  // index every position we pass
-        const size_t i = pos + k;
-        if (i + 3 <= n) { const uint32_t h = hash3(i); prev[i] = head[h]; head[h] = (int32_t)i; }
-      }
-      pos += step;
-    }
-    // end marker: a match with distance 0xFFFFFFFF and the minimum length
-    encode_match(0xFFFFFFFFu, 2, (uint32_t)pos & ((1u << kPb) - 1));
-    rc_.flush();
-  }
-
- private:
-  void tree(uint16_t *probs, int nbits, uint32_t sym) {
-    uint32_t m = 1;
-    for (int i = nbits - 1; i >= 0; i--) { const int b = (sym >> i) & 1; rc_.bit(probs[m], b); m = (m << 1) | b; }
-  }
-  void rtree(uint16_t *probs, int nbits, uint32_t sym) {
-    uint32_t m = 1;
-    for (int i = 0; i < nbits; i++) { const int b = sym & 1; rc_.bit(probs[m], b); m = (m << 1) | b; sym >>= 1; }
-  }
-  void encode_len(LenCoder &lc, uint32_t len, uint32_t pos_state) {
-    len -= 2;
-    if (len < 8) { rc_.bit(lc.choice, 0); tree(lc.low[pos_state], 3, len); }
-    else if (len < 16) { rc_.bit(lc.choice, 1); rc_.bit(lc.choice2, 0); tree(lc.mid[pos_state], 3, len - 8); }
-    else { rc_.bit(lc.choice, 1); rc_.bit(lc.choice2, 1); tree(lc.high, 8, len - 16); }
-  }
-  void encode_literal(const uint8_t *src, size_t pos, uint32_t pos_state) {
-    rc_.bit(is_match_[state_][pos_state], 0);
-    const uint8_t prev_byte = pos ? src[pos - 1] : 0;
-    uint16_t *probs = &lit_[(size_t)0x300 * ((((uint32_t)pos & ((1u << kLp) - 1)) << kLc) + (prev_byte >> (8 - kLc)))];
-    const uint32_t cur = src[pos];
-    if (state_ < 7) {
-      tree(probs, 8, cur);
-    } else {  // after a match the literal is coded against the byte the last distance points at
-      uint32_t match_byte = src[pos - rep_[0] - 1], offs = 0x100, symbol = cur | 0x100;
-      do {
-        match_byte <<= 1;
-        rc_.bit(probs[offs + (match_byte & offs) + (symbol >> 8)], (symbol >> 7) & 1);
-        symbol <<= 1;
-        offs &= ~(match_byte ^ symbol);
-      } while (symbol < 0x10000);
-    }
-    state_ = state_ < 4 ? 0 : (state_ < 10 ? state_ - 3 : state_ - 6);
-  }
-  static uint32_t pos_slot_of(uint32_t dist) {
-    if (dist < 4) return dist;
-    const int n = 31 - __builtin_clz(dist);
-    return (uint32_t)(2 * n) + ((dist >> (n - 1)) & 1);
-  }
-  void encode_match(uint32_t dist, uint32_t len, uint32_t pos_state) {
-    rc_.bit(is_match_[state_][pos_state], 1);
-    rc_.bit(is_rep_[state_], 0);
-    encode_len(len_, len, pos_state);
-    state_ = state_ < 7 ? 7 : 10;
-    const uint32_t slot = pos_slot_of(dist);
-    tree(pos_slot_[std::min<uint32_t>(len - 2, 3)], 6, slot);
-    if (slot >= 4) {
-      const int footer = (int)(slot >> 1) - 1;
-      const uint32_t base = (2u | (slot & 1)) << footer, reduced = dist - base;
-      if (slot < 14) rtree(pos_special_ + ((int)base - (int)slot - 1), footer, reduced);  // index 0 is reached with m = 1
-      else { rc_.direct(reduced >> 4, footer - 4); rtree(pos_align_, 4, reduced & 15); }
-    }
-    rep_[3] = rep_[2]; rep_[2] = rep_[1]; rep_[1] = rep_[0]; rep_[0] = dist;
-  }
-
-  RangeEncoder rc_;
-  std::vector<uint16_t> lit_;
-  uint16_t is_match_[12][16], is_rep0_long_[12][16], is_rep_[12], is_rep_g0_[12], is_rep_g1_[12], is_rep_g2_[12];
-  uint16_t pos_slot_[4][64], pos_special_[128], pos_align_[16];
-  LenCoder len_, rep_len_;
-  uint32_t state_ = 0;
-  size_t rep_[4] = {0, 0, 0, 0};
-};
-
 // ---------------------------------------------------------------------------------------------------------------
-// The shipped coder: same bitstream, priced optimal parsing.  LZMA/ULZMAEncoder.pas (the Pascal port of the LZMA SDK the reference
-// links) chooses its literals / matches / repeated matches by dynamic programming over bit prices; the greedy parser above left 12 %
-// on the table on the reference's own command streams.  This one restates that scheme in its own structure:
+// The coder: LZMA-alone with lc/lp/pb as LZCompress sets them (SetLcLpPb(8,0,2), end marker on: extern.pas:429-430), priced optimal
+// parsing.  LZMA/ULZMAEncoder.pas (the Pascal port of the LZMA SDK the reference links) chooses its literals / matches / repeated matches by
+// dynamic programming over bit prices; round 1's greedy parser left 12 % on the table on the reference's own command streams.  This one
+// restates that scheme in its own structure:
 //  * match finder: exact 2-byte table, 3-byte and 4-byte hashes with a chain on the latter; per position the list of (length, nearest
 //    distance) pairs of strictly increasing length;
 //  * prices in 1/16 bit from the live probabilities (bit prices tabulated per 16 probability steps); length and distance price tables
@@ -210,7 +79,8 @@ class LzmaEncoder {  // lc/lp/pb as LZCompress sets them: SetLcLpPb(8,0,2), end 
 //    way implies; from a node: literal, one-byte repeat, the four repeats at every length, every match length at its nearest distance,
 //    and literal-then-repeat0 (the pattern of a command stream: one field changes, the rest repeats).  A match or repeat of at least
 //    kNice bytes is taken at once.
-// Decoder-side semantics are untouched: lzma.js and the oracle's decoder read these streams like the greedy ones.
+// Decoder-side semantics are the format's: lzma.js and the oracle's decoder read these streams.  (Round 1's greedy parser, 12.5 % larger on the
+// reference's own command stream, is gone.)
 class LzmaOptEncoder {
  public:
   static constexpr int kLc = 8, kLp = 0, kPb = 2, kNice = 128, kOpts = 4096, kDepth = 96;
@@ -660,16 +530,11 @@ class LzmaOptEncoder {
 };
 
 void lz_compress_impl(const std::vector<uint8_t> &raw, std::vector<uint8_t> &dst) {  // LZCompress, extern.pas:420-439
-  dst.push_back((uint8_t)((LzmaEncoder::kPb * 5 + LzmaEncoder::kLp) * 9 + LzmaEncoder::kLc));  // 0x62
-  for (int i = 0; i < 4; i++) dst.push_back((uint8_t)(LzmaEncoder::kDict >> (8 * i)));
+  dst.push_back((uint8_t)((LzmaOptEncoder::kPb * 5 + LzmaOptEncoder::kLp) * 9 + LzmaOptEncoder::kLc));  // 0x62
+  for (int i = 0; i < 4; i++) dst.push_back((uint8_t)(LzmaOptEncoder::kDict >> (8 * i)));
   for (int i = 0; i < 8; i++) dst.push_back(0xFF);
-  if (getenv("TM_LZMA_GREEDY")) {  // round 1's parser, kept for A/B runs
-    LzmaEncoder enc(dst);
-    enc.encode(raw.data(), raw.size());
-  } else {
-    auto enc = std::make_unique<LzmaOptEncoder>(dst);  // (its parse window lives in the object: not on the stack)
-    enc->encode(raw.data(), raw.size());
-  }
+  auto enc = std::make_unique<LzmaOptEncoder>(dst);  // (its parse window lives in the object: not on the stack)
+  enc->encode(raw.data(), raw.size());
 }
 
 struct Stream {

@@ -703,110 +703,7 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
 // and one fused multiply-add each, ties -> lowest centroid) and its carried sums, shaped for FEW points: one point per lane read straight
 // from the chunk-major copy (32 bytes per chunk, the next chunk in flight), the centroids broadcast from LDS (staged from the transposed
 // copy k_h_update leaves; reading them as scalar operands through the scalar cache instead measured 20 % slower: 24 KB of centroids do
-// not stay in it), workgroups of NT points so that a short list still spreads over the chip.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_assign192_list(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
-                                                       const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
-                                                       int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
-                                                       double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
-                                                       const unsigned *__restrict__ need_cnt) {
-  if (*quiet >= 0) return;
-  constexpr int D = 192;
-  const unsigned cnt = *need_cnt, row0 = blockIdx.x * (unsigned)NT;
-  if (row0 >= cnt) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ int s_nmoved;
-  const int kk = segs[0].kk, tid = threadIdx.x;
-  double *s_c = reinterpret_cast<double *>(s_raw);                    // [D][KCH]
-  u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);       // [kk][D + 1]
-  int32_t *s_moved = reinterpret_cast<int32_t *>(s_delta + kk * (D + 1));  // [NT][3]: point, old, new
-  const bool active = row0 + tid < cnt;
-  const int64_t gi = need[active ? row0 + tid : row0];
-  for (int e = tid; e < kk * (D + 1); e += NT) s_delta[e] = 0;
-  if (tid == 0) s_nmoved = 0;
-  double bd = 0.0, bd2 = 1.0e300;
-  int bc = -1;
-  const int4 *src = reinterpret_cast<const int4 *>(pts_chunked + gi * A_DCH);
-  const int64_t chunk_stride = n_total * (A_DCH / 4);  // int4 units between chunks
-#pragma unroll 1
-  for (int c0 = 0; c0 < kk; c0 += KCH) {
-    __syncthreads();
-    for (int e = tid; e < D * KCH; e += NT) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + c0 + (e % KCH)];
-    __syncthreads();
-    double s[KCH];
-#pragma unroll
-    for (int c = 0; c < KCH; c++) s[c] = 0.0;
-    auto score_chunk = [&](const int4 &x0, const int4 &x1, int ch) {
-      const int v[A_DCH] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-      for (int j = 0; j < A_DCH; j++) {
-        const double pj = (double)v[j];
-        const double *cj = s_c + (ch * A_DCH + j) * KCH;
-#pragma unroll
-        for (int c = 0; c < KCH; c += 2) {
-          const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
-          const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
-          s[c] = __fma_rn(t0, t0, s[c]);
-          s[c + 1] = __fma_rn(t1, t1, s[c + 1]);
-        }
-      }
-    };
-    // two chunks per step, the next two in flight (a lone wave per SIMD has nothing else to cover the memory round trips with)
-    int4 a0 = src[0], a1 = src[1], b0 = src[chunk_stride], b1 = src[chunk_stride + 1];
-#pragma unroll 1
-    for (int ch = 0; ch < D / A_DCH; ch += 2) {
-      int4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-      if (ch + 2 < D / A_DCH) {
-        na0 = src[(ch + 2) * chunk_stride]; na1 = src[(ch + 2) * chunk_stride + 1];
-        nb0 = src[(ch + 3) * chunk_stride]; nb1 = src[(ch + 3) * chunk_stride + 1];
-      }
-      score_chunk(a0, a1, ch);
-      score_chunk(b0, b1, ch + 1);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-#pragma unroll
-    for (int c = 0; c < KCH; c++)
-      if (c0 + c < kk) {
-        if (bc < 0 || s[c] < bd) { if (bc >= 0) bd2 = bd; bd = s[c]; bc = c0 + c; }
-        else if (s[c] < bd2) bd2 = s[c];
-      }
-  }
-  if (active) {
-    ub[gi] = sqrt(bd) * (1.0 + 1e-12);
-    lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
-    const int old = assign[gi];
-    if (old != bc) {
-      assign[gi] = bc;
-      const int slot = atomicAdd(&s_nmoved, 1);
-      s_moved[slot * 3] = tid; s_moved[slot * 3 + 1] = old; s_moved[slot * 3 + 2] = bc;
-    }
-  }
-  __syncthreads();
-  const int nmoved = s_nmoved;
-  if (nmoved == 0) return;
-  if (tid == 0) atomicAdd(&segs[0].changed, nmoved);
-#pragma unroll 2
-  for (int e = tid >> 6; e < nmoved; e += NT / 64) {  // a wave per moved row between the carried sums (coalesced read, three dimensions per lane)
-    const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
-    const int64_t mi = need[row0 + s_moved[e * 3]];
-    const long long wi = w ? (long long)w[mi] : 1;
-#pragma unroll
-    for (int j = tid & 63; j <= D; j += 64) {
-      const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
-      atomicAdd(&s_delta[nw * (D + 1) + j], v);
-      if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < kk * (D + 1); e += NT) {
-    const u64 v = s_delta[e];
-    if (v == 0) continue;
-    const int c = e / (D + 1), j = e - c * (D + 1);
-    if (j == D) atomicAdd(&cnts[c], v);
-    else atomicAdd(&sums[(int64_t)c * D + j], v);
-  }
-}
-
+// not stay in it).  (A thread-per-point form of it was the first list kernel; the four-lane form below replaced it.)
 // The same, a point spread over 4 lanes (each lane scores 4 of the 16 centroids of a pass): the thread-per-point shape leaves a lone wave per
 // SIMD with 6 144 dependent-ish double-precision operations and its workgroup's four waves queueing for 24 KB of LDS reads per point; here
 // the chain is a quarter as long and the list covers four times as many compute units.  Every accumulator still sums its 192 terms in
@@ -1037,291 +934,6 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
   }
 }
 
-// ---- the skipping iteration as ONE launch (at most KCH centroids) ---------------------------------------------------------------
-// k_h_bounds, k_assign192_list4 and k_h_update are three dependent launches per iteration, and the kernel trace puts 4.5 us of every launch
-// of such a chain in its turnaround alone (an empty launch takes that long): 13.5 of the 41 us an iteration takes in the steady state.
-// Here an iteration is one launch.  Every workgroup first derives what the bounds need from the sums the LAST launch left complete --
-// new centroids (exact integer sum / weight, one IEEE division), their displacements, half the distance to the nearest other centroid;
-// 3 072 divisions and 120 pairs, a few microseconds, done by all workgroups alike -- then moves the bounds of its own slice of points,
-// rechecks the loosened ones and scores the still unproven ones itself (the list never leaves the workgroup), and adds the moved
-// points' deltas to THIS iteration's delta buffer.  What crosses launches is double-buffered so that a workgroup that is late reading
-// never meets one that is early writing: sums S[it & 1] = S[(it - 1) & 1] + D[(it - 1) % 3] (workgroup 0 writes them), deltas D[it % 3]
-// (zeroed two launches ahead), the moved-points counter likewise, the centroids C[it & 1].  Same arithmetic as the three kernels, hence
-// the same assignments and centroids, bit for bit.
-struct HIter {
-  u64 *S[2];        // [kk][193]: 192 coordinate sums + the weight, as of the start of iteration it (written by workgroup 0)
-  u64 *D[3];        // deltas of iteration it
-  unsigned *chg;    // [3] points moved in iteration it
-  double *C[2];     // [k][192] centroids used in iteration it
-};
-__global__ __launch_bounds__(256, 2) void k_h_iter(const int32_t *__restrict__ pts, int64_t n, const uint32_t *__restrict__ w, const Seg *__restrict__ segs, HIter h, int it,
-                                                   int update_only, int32_t *__restrict__ assign, double *__restrict__ ub, double *__restrict__ lb, int *__restrict__ quiet) {
-  if (*quiet >= 0) return;
-  constexpr int D = 192, NP = 64, CPL = KCH / 4, PITCH = D + 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  double *s_ct = reinterpret_cast<double *>(s_raw);                         // [D][KCH] transposed centroids (scoring)
-  double *s_rm = reinterpret_cast<double *>(s_raw + D * KCH * 8);           // [KCH][PITCH] row-major centroids (recheck, pairs), later ...
-  u64 *s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);              // ... [kk][PITCH] deltas of this workgroup's moved points
-  int *s_list = reinterpret_cast<int *>(s_raw + D * KCH * 8 + KCH * PITCH * 8);  // [H_SLICE]
-  int *s_need = s_list + H_SLICE;                                           // [H_SLICE]
-  int *s_moved = s_need + H_SLICE;                                          // [NP][3]
-  __shared__ double s_move[KCH + 3], s_half[KCH];
-  __shared__ unsigned long long s_min[KCH];
-  __shared__ int s_nlist, s_nneed, s_nmoved;
-  const int tid = threadIdx.x, kk = segs[0].kk, wave = tid >> 6, lane = tid & 63;
-  const int pp = (it - 1) & 1, pc = it & 1, dp = (it + 2) % 3, dc = it % 3, dn = (it + 1) % 3;
-#if TM_KMH_STAMPS
-  unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#define KH_STAMP(i) do { if (blockIdx.x == 1 && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(reinterpret_cast<unsigned long long *>(h.chg + 4) + (i), t_ - st_last); st_last = t_; } } while (0)
-#else
-#define KH_STAMP(i) do { } while (0)
-#endif
-  const bool changed = __hip_atomic_load(&h.chg[dp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  if (!changed) {  // the assignment before this launch moved nothing: converged at it - 1 (every workgroup leaves; one says so)
-    if (blockIdx.x == 0 && tid == 0) *quiet = it - 1;
-    return;
-  }
-  // ---- phase 0: sums, centroids, displacements, half distances (every workgroup; workgroup 0 also publishes)
-  if (tid < KCH) s_min[tid] = 0x7ff0000000000000ull;
-  if (tid == 0) { s_nlist = 0; s_nneed = 0; s_nmoved = 0; }
-  for (int e = tid; e < KCH * PITCH; e += 256) s_rm[e] = 0.0;
-  for (int e = tid; e < D * KCH; e += 256) s_ct[e] = 0.0;
-  __syncthreads();
-  {  // a wave per centroid (four of them each), three dimensions per lane and centroid: ALL the loads first -- taken one centroid after the
-     // other this phase was twelve dependent round trips to L2, 35 us of a 63 us launch
-    u64 sm[4][3], dl[4][3], cn[4];
-    double od[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int c = min(wave + 4 * q, kk - 1);
-      cn[q] = h.S[pp][c * PITCH + D];
-      dl[q][0] = h.D[dp][c * PITCH + D];
-#pragma unroll
-      for (int u = 0; u < 3; u++) sm[q][u] = h.S[pp][c * PITCH + lane + 64 * u];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) cn[q] += dl[q][0];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int c = min(wave + 4 * q, kk - 1);
-#pragma unroll
-      for (int u = 0; u < 3; u++) { dl[q][u] = h.D[dp][c * PITCH + lane + 64 * u]; od[q][u] = h.C[pp][c * D + lane + 64 * u]; }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int c = wave + 4 * q;
-      if (c >= kk) break;  // (uniform in the wave)
-      double sd = 0.0;
-#pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int j = lane + 64 * u;
-        const u64 sv = sm[q][u] + dl[q][u];
-        const double nw = cn[q] > 0 ? __ddiv_rn((double)(long long)sv, (double)(long long)cn[q]) : od[q][u];
-        if (blockIdx.x == 0) { h.S[pc][c * PITCH + j] = sv; h.C[pc][c * D + j] = nw; }
-        s_rm[c * PITCH + j] = nw;
-        s_ct[j * KCH + c] = nw;
-        const double t = nw - od[q][u];
-        sd += t * t;
-      }
-      if (blockIdx.x == 0 && lane == 0) h.S[pc][c * PITCH + D] = cn[q];
-      for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
-      if (lane == 0) s_move[c] = sqrt(sd) * (1.0 + 1e-9);
-    }
-  }
-  if (blockIdx.x == 0) {  // two launches ahead: the delta buffer and the counter of iteration it + 1
-    for (int e = tid; e < kk * PITCH; e += 256) h.D[dn][e] = 0;
-    if (tid == 0) h.chg[dn] = 0;
-  }
-  if (update_only) return;  // (the iteration cap was reached: the centroids of the last assignment are out)
-  __syncthreads();
-  KH_STAMP(0);  // sums, centroids, displacements
-  for (int pr = tid >> 4; pr < kk * kk; pr += 16) {  // pairwise distances, 16 lanes per pair
-    const int a = pr / kk, b = pr - a * kk;
-    if (a >= b) continue;
-    double sd = 0.0;
-#pragma unroll
-    for (int u = 0; u < 12; u++) { const int j = (tid & 15) + 16 * u; const double t = s_rm[a * PITCH + j] - s_rm[b * PITCH + j]; sd += t * t; }
-    for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
-    if ((tid & 15) == 0) {
-      atomicMin(&s_min[a], (unsigned long long)__double_as_longlong(sd));
-      atomicMin(&s_min[b], (unsigned long long)__double_as_longlong(sd));
-    }
-  }
-  __syncthreads();
-  if (tid < kk) s_half[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
-  if (tid == 0) {
-    double mx = 0.0, mx2 = 0.0;
-    int amx = 0;
-    for (int c = 0; c < kk; c++) {
-      const double v = s_move[c];
-      if (v > mx) { mx2 = mx; mx = v; amx = c; } else if (v > mx2) mx2 = v;
-    }
-    s_move[KCH] = mx; s_move[KCH + 1] = mx2; s_move[KCH + 2] = (double)amx;
-  }
-  __syncthreads();
-  KH_STAMP(1);  // pairs, half distances
-  // ---- phase 1: the slice's bounds move with the centroids; the loosened ones are rechecked against their own centroid (k_h_bounds)
-  const double dmax = s_move[KCH], dmax2 = s_move[KCH + 1];
-  const int amax = (int)s_move[KCH + 2];
-  const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
-#pragma unroll
-  for (int r = 0; r < H_SLICE / 256; r++) {
-    const int64_t i = i0 + r * 256 + tid;
-    if (i >= n) break;
-    const int a = assign[i];
-    const double u = (ub[i] + s_move[a]) * (1.0 + 1e-15);
-    double l = lb[i] - (a == amax ? dmax2 : dmax);
-    l -= fabs(l) * 1e-15;
-    ub[i] = u;
-    lb[i] = l;
-    if (!(u * (1.0 + H_ETA) < fmax(s_half[a], l) * (1.0 - H_ETA))) s_list[atomicAdd(&s_nlist, 1)] = r * 256 + tid;
-  }
-  __syncthreads();
-  KH_STAMP(2);  // bounds of the slice
-  const int nlist = s_nlist;
-  {
-    const int l16 = tid & 15;
-    for (int t0 = 0; t0 < nlist; t0 += 16) {
-      const int t = t0 + (tid >> 4);
-      const bool act = t < nlist;
-      const int64_t i = i0 + s_list[act ? t : 0];
-      const int a = assign[i];
-      const int4 *p = reinterpret_cast<const int4 *>(pts + i * D + l16 * 12);
-      const int4 v0 = p[0], v1 = p[1], v2 = p[2];
-      const int pv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-      const double *c = s_rm + a * PITCH + l16 * 12;
-      double sd = 0.0;
-#pragma unroll
-      for (int j = 0; j < 12; j++) { const double d0 = __dsub_rn((double)pv[j], c[j]); sd = __fma_rn(d0, d0, sd); }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
-      if (act && l16 == 0) {
-        const double u = sqrt(sd) * (1.0 + 1e-12);
-        ub[i] = u;
-        if (!(u * (1.0 + H_ETA) < fmax(s_half[a], lb[i]) * (1.0 - H_ETA))) s_need[atomicAdd(&s_nneed, 1)] = s_list[t];
-      }
-    }
-  }
-  __syncthreads();  // (the row-major centroids are done with: their space holds the deltas from here on)
-  KH_STAMP(3);  // rechecks
-  const int cnt = s_nneed;
-  if (cnt == 0) return;
-  for (int e = tid; e < kk * PITCH; e += 256) s_delta[e] = 0;
-  __syncthreads();
-  // ---- phase 2: the unproven points through the full computation (k_assign192_list4: four lanes per point, a quarter row each)
-  const int slot = tid >> 2, sub = tid & 3;
-  int total_moved = 0;
-#pragma unroll 1
-  for (int row0 = 0; row0 < cnt; row0 += NP) {
-    const bool active = row0 + slot < cnt;
-    const int64_t gi = i0 + s_need[active ? row0 + slot : row0];
-    int4 x[12];
-    {
-      const int4 *src = reinterpret_cast<const int4 *>(pts + gi * D + sub * 48);
-#pragma unroll
-      for (int u = 0; u < 12; u++) x[u] = src[u];
-    }
-    double sc[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; c++) sc[c] = 0.0;
-    auto term = [&](int v, int j) {
-      const double pj = (double)v;
-      const double *cj = s_ct + j * KCH + sub * CPL;
-#pragma unroll
-      for (int c = 0; c < CPL; c += 2) {
-        const double2 cv = *reinterpret_cast<const double2 *>(cj + c);
-        const double t0 = __dsub_rn(pj, cv.x), t1 = __dsub_rn(pj, cv.y);
-        sc[c] = __fma_rn(t0, t0, sc[c]);
-        sc[c + 1] = __fma_rn(t1, t1, sc[c + 1]);
-      }
-    };
-    auto quarter = [&](auto qtag) {
-      constexpr int Q = decltype(qtag)::value;
-#pragma unroll
-      for (int u = 0; u < 12; u++) {
-        term(quad_bcast<Q>(x[u].x), Q * 48 + u * 4);
-        term(quad_bcast<Q>(x[u].y), Q * 48 + u * 4 + 1);
-        term(quad_bcast<Q>(x[u].z), Q * 48 + u * 4 + 2);
-        term(quad_bcast<Q>(x[u].w), Q * 48 + u * 4 + 3);
-        pin_accumulators(sc);
-      }
-    };
-    quarter(std::integral_constant<int, 0>{});
-    quarter(std::integral_constant<int, 1>{});
-    quarter(std::integral_constant<int, 2>{});
-    quarter(std::integral_constant<int, 3>{});
-    double bd = 1.0e300, bd2 = 1.0e300;
-    int bc = 0x7fffffff;
-#pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int ci = sub * CPL + c;
-      if (ci < kk) {
-        if (sc[c] < bd) { bd2 = bd; bd = sc[c]; bc = ci; }
-        else if (sc[c] < bd2) bd2 = sc[c];
-      }
-    }
-#pragma unroll
-    for (int o = 1; o < 4; o <<= 1) {
-      const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
-      const int oc = __shfl_xor(bc, o);
-      const bool take = od < bd || (od == bd && oc < bc);
-      const double loser = take ? bd : od;
-      bd2 = fmin(fmin(bd2, od2), loser);
-      if (take) { bd = od; bc = oc; }
-    }
-    if (active && sub == 0) {
-      ub[gi] = sqrt(bd) * (1.0 + 1e-12);
-      lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
-      const int old = assign[gi];
-      if (old != bc) {
-        assign[gi] = bc;
-        const int m = atomicAdd(&s_nmoved, 1);
-        s_moved[m * 3] = slot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
-      }
-    }
-    __syncthreads();
-    const int nmoved = s_nmoved;
-    total_moved += nmoved;
-#pragma unroll 2
-    for (int e = wave; e < nmoved; e += 4) {  // a wave per moved row between the carried sums
-      const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
-      const int64_t mi = i0 + s_need[row0 + s_moved[e * 3]];
-      const long long wi = w ? (long long)w[mi] : 1;
-#pragma unroll
-      for (int j = lane; j <= D; j += 64) {
-        const u64 v = j < D ? (u64)(wi * pts[mi * D + j]) : (u64)wi;
-        atomicAdd(&s_delta[nw * PITCH + j], v);
-        if (old >= 0) atomicAdd(&s_delta[old * PITCH + j], (u64)0 - v);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) s_nmoved = 0;
-    __syncthreads();
-  }
-  KH_STAMP(4);  // scoring
-  if (total_moved == 0) return;
-  if (tid == 0) atomicAdd(&h.chg[dc], (unsigned)total_moved);
-  for (int e = tid; e < kk * PITCH; e += 256) {
-    const u64 v = s_delta[e];
-    if (v != 0) atomicAdd(&h.D[dc][e], v);
-  }
-  KH_STAMP(5);  // flush
-}
-
-// the sums and the counter the plain iterations carried, in the fused iteration's buffers: S[(first - 1) & 1] = (sums, weights), no
-// deltas pending, "something moved" (the first fused launch makes the centroid update the last plain iteration is owed)
-__global__ void k_h_iter_setup(const u64 *__restrict__ sums, const u64 *__restrict__ cnts, const double *__restrict__ cent, int kk_max, HIter h, int first,
-                               const Seg *__restrict__ segs) {
-  const int pp = (first - 1) & 1;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kk_max * 193; e += gridDim.x * blockDim.x) {
-    const int c = e / 193, j = e - c * 193;
-    h.S[pp][e] = j < 192 ? sums[c * 192 + j] : cnts[c];
-    h.D[0][e] = 0; h.D[1][e] = 0; h.D[2][e] = 0;
-    if (j < 192) h.C[pp][c * 192 + j] = cent[c * 192 + j];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { h.chg[0] = 0; h.chg[1] = 0; h.chg[2] = 0; h.chg[(first + 2) % 3] = segs[0].changed ? 1u : 0u; }
-}
-
 // ---- D = 3, one launch for the whole clustering -----------------------------------------------------------------
 // The pixel k-means of QuantizeUsingYakmo (tilingencoder.pas:4434-4532) runs ~180 Lloyd iterations over a few hundred thousand
 // distinct colours per palette: a few microseconds of arithmetic per iteration, so as separate launches (two per iteration, two per
@@ -1338,9 +950,6 @@ __global__ void k_h_iter_setup(const u64 *__restrict__ sums, const u64 *__restri
 #define P3_STAMP(i) do { if (bx == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); st->stamps[i] += t_ - st_last; st_last = t_; } } while (0)
 #else
 #define P3_STAMP(i) do { } while (0)
-#endif
-#ifndef TM_KMH_STAMPS
-#define TM_KMH_STAMPS 0  // diagnostic build: s_memtime spans of k_h_iter's phases (workgroup 1), summed over the launches
 #endif
 #ifndef TM_KM3_NT
 #define TM_KM3_NT 256
@@ -1716,7 +1325,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
                               int max_iter, int32_t *assign, double *cent, std::vector<int> *host_kk, int *host_iters, hipStream_t stream, int *used) {
   *used = 0;
   const int nseg = (int)seg_begin.size();
-  if (k > P3_MAXK || getenv("TM_KM_LEGACY")) return TM_OK;
+  if (k > P3_MAXK) return TM_OK;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1837,7 +1446,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   // leave most of the chip idle while its few workgroups loop
   int64_t total_pts = 0;
   for (int s = 0; s < nseg; s++) total_pts += seg_count[s];
-  static const int blk_target = getenv("TM_KM_BLOCKS") ? atoi(getenv("TM_KM_BLOCKS")) : 768;
+  constexpr int blk_target = 768;
   const int64_t rows_per_blk = std::max<int64_t>(256, (total_pts / blk_target + 255) / 256 * 256);
   int nblk = 0;
   for (int s = 0; s < nseg; s++) {
@@ -1892,7 +1501,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    static const int occ = getenv("TM_KM_OCC") ? atoi(getenv("TM_KM_OCC")) : 2;  // workgroups per CU the slices are sized for
+    constexpr int occ = 2;  // workgroups per CU the slices are sized for
     const int64_t slots = std::max<int64_t>(1, (int64_t)cus * occ / std::max(1, std::min(nseg, cus * occ)));  // workgroups per segment in one round
     const int64_t per_slot = (maxcount + slots - 1) / slots;
     const int64_t rounds = (per_slot + 256 * 5 - 1) / (256 * 5);
@@ -1908,9 +1517,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   TM_HIP(hipMemsetAsync(quiet.p, 0xff, 4, stream));
   // D = 192, one segment, centroids that fit LDS: after H_WARM plain iterations the assignment step only touches the points whose
   // bounds do not prove their assignment (k_h_bounds, then k_assign192 over the list); the arithmetic, hence the result, is unchanged
-  static const int h_warm = getenv("TM_KM_WARM") ? atoi(getenv("TM_KM_WARM")) : 5;
+  constexpr int h_warm = 5;
   const int h_kt = (k + KCH - 1) / KCH * KCH;  // row pitch of the transposed centroids (hcent_t)
-  const bool skipping = d == 192 && nseg == 1 && k <= H_MAXK && !getenv("TM_KM_NOSKIP");
+  const bool skipping = d == 192 && nseg == 1 && k <= H_MAXK;
   DevBuf hub, hlb, hcent_t, hmove, hhalf, hneed, hcnt;
   const size_t l_lds = (size_t)192 * KCH * 8 + (size_t)k * 193 * 8 + (size_t)256 * 3 * 4 + 16;  // k_assign192_list
   if (skipping) {
@@ -1923,40 +1532,16 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     TM_HIP(hipMemsetAsync(hcent_t.p, 0, (size_t)h_kt * 192 * 8, stream));
     hipLaunchKernelGGL(k_cent_transpose, dim3(12), dim3(256), 0, stream, ds, cent, hcent_t.as<double>(), h_kt);
     if ((size_t)k * 193 * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_update), hipFuncAttributeMaxDynamicSharedMemorySize, k * 193 * 8);
-    if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
-  // TM_KM_FUSED=1: the skipping iterations as ONE launch each (k_h_iter) instead of three.  Built and measured in round 3: it saves two
-  // launch turnarounds (4.5 us each) and loses more than that -- 48-58 us per iteration against 41 (phase spans of one workgroup: sums and
-  // centroids 12 %, centroid pairs 19 %, bounds 3 %, rechecks 26 %, scoring its OWN unproven points 37 %: the three kernels spread the
-  // unproven points of a crowded slice over fresh workgroups, one launch leaves them to the slice's own) -- so the three kernels ship
-  const bool fused = skipping && k <= KCH && max_iter > h_warm && getenv("TM_KM_FUSED") != nullptr;
-  DevBuf fbuf;
-  HIter hit;
-  memset(&hit, 0, sizeof(hit));
-  const size_t f_lds = (size_t)192 * KCH * 8 + (size_t)KCH * 193 * 8 + (size_t)2 * H_SLICE * 4 + 64 * 3 * 4;
-  if (fused) {
-    TM_CHECK(f_lds <= 160 * 1024, TM_E_INVAL, "k-means: the single-launch iteration needs %zu bytes of LDS (the CU has 163840)", f_lds);
-    const size_t sb = (size_t)k * 193 * 8, cb = (size_t)k * 192 * 8;
-    TM_TRY(fbuf.alloc(5 * sb + 2 * cb + 64));
-    uint8_t *b = fbuf.as<uint8_t>();
-    hit.S[0] = reinterpret_cast<u64 *>(b); hit.S[1] = reinterpret_cast<u64 *>(b + sb);
-    hit.D[0] = reinterpret_cast<u64 *>(b + 2 * sb); hit.D[1] = reinterpret_cast<u64 *>(b + 3 * sb); hit.D[2] = reinterpret_cast<u64 *>(b + 4 * sb);
-    hit.C[0] = reinterpret_cast<double *>(b + 5 * sb); hit.C[1] = reinterpret_cast<double *>(b + 5 * sb + cb);
-    hit.chg = reinterpret_cast<unsigned *>(b + 5 * sb + 2 * cb);
-    TM_HIP(hipMemsetAsync(fbuf.p, 0, 5 * sb + 2 * cb + 64, stream));
-    if (f_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_iter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f_lds);
-  }
-  bool fused_started = false;
   int it = 0, issued = 0;
   // Convergence is a flag on the device; the launches after it return at once.  The host queues the iterations in batches and reads the
   // flag of a batch while the NEXT batch runs (a copy into page-locked memory and an event behind every batch): the device never waits
   // for the host to look, and at most two short batches of launches are wasted at the end.  (Batches of 16 with the stream drained at
   // every poll left the device idle ~30 us six times per clustering and, on the bench clip, 42 no-op launches -- 0.45 ms -- behind the
   // 87th iteration.)
-  int *const pin = getenv("TM_KM_POLL_DRAIN") ? nullptr : pinned_words();
-  static const int poll_env = getenv("TM_KM_POLL_EVERY") ? std::max(1, atoi(getenv("TM_KM_POLL_EVERY"))) : 0;  // (A/B aid)
-  const int poll_every = poll_env ? poll_env : pin ? 4 : 16;
+  int *const pin = pinned_words();
+  const int poll_every = pin ? 4 : 16;
   hipEvent_t pev[2] = {nullptr, nullptr};
   struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{pev};
   if (pin) {
@@ -1971,30 +1556,12 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         const int gb = (int)((n + H_SLICE - 1) / H_SLICE);
         if (issued < h_warm) {
           const bool last_plain = issued == h_warm - 1;
-          static const bool warm_list = getenv("TM_KM_WARM_LIST4") != nullptr;  // A/B aid: the plain iterations through the list kernel, every point listed (measured 0.17 ms per iteration slower: every point moves at first, and the moved rows are its serial part)
-          if (warm_list)
-            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)((n + 63) / 64)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
-                               cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), (const int32_t *)nullptr, (const unsigned *)nullptr);
-          else
           launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
                            quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
-          if (fused && last_plain) {  // the update this iteration is owed is the first fused launch's: hand over the carried sums
-            hipLaunchKernelGGL(k_h_iter_setup, dim3(16), dim3(256), 0, stream, sums.as<u64>(), cnts.as<u64>(), (const double *)cent, k, hit, h_warm, (const Seg *)ds);
-            fused_started = true;
-            continue;
-          }
-        } else if (fused) {
-          hipLaunchKernelGGL(k_h_iter, dim3(gb), dim3(256), f_lds, stream, pts, n, w, (const Seg *)ds, hit, issued, 0, assign, hub.as<double>(), hlb.as<double>(), quiet.as<int>());
-          continue;
         } else {
           hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), 0, stream, pts, n, ds, (const double *)cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
-          static const bool list1 = getenv("TM_KM_LIST1") != nullptr;  // A/B aid: a thread per point
-          if (!list1)
-            hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)std::min<int64_t>((n + 63) / 64, 768)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
-                               cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
-          else
-          hipLaunchKernelGGL(k_assign192_list<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+          hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)std::min<int64_t>((n + 63) / 64, 768)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
                              cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
         }
         hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
@@ -2040,36 +1607,6 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     if (qflag >= 0) it = qflag;
   }
   TM_HIP(hipGetLastError());
-#if TM_KMH_STAMPS
-  if (fused_started) {
-    unsigned long long stv[6];
-    TM_HIP(hipMemcpy(stv, reinterpret_cast<const unsigned long long *>(hit.chg + 4), sizeof(stv), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[tm_kmh stamps] workgroup 1, ticks summed over the launches: sums+centroids %llu, pairs %llu, bounds %llu, rechecks %llu, scoring %llu, flush %llu\n", stv[0], stv[1],
-            stv[2], stv[3], stv[4], stv[5]);
-  }
-#endif
-  if (fused_started) {  // the final centroids sit in the fused iteration's buffers: those of the converged assignment, or one more update at the cap
-    int q = -1;
-    {
-      HostRead hr_(stream);
-      TM_TRY(hr_.get(&q, quiet.p, 4));
-      TM_TRY(hr_.wait());
-    }
-    int final_it = q;
-    if (q < 0) {
-      hipLaunchKernelGGL(k_h_iter, dim3(1), dim3(256), f_lds, stream, pts, n, w, (const Seg *)ds, hit, max_iter, 1, assign, hub.as<double>(), hlb.as<double>(), quiet.as<int>());
-      TM_HIP(hipGetLastError());
-      int q2 = -1;
-      {
-        HostRead hr_(stream);
-        TM_TRY(hr_.get(&q2, quiet.p, 4));
-        TM_TRY(hr_.wait());
-      }
-      final_it = q2 >= 0 ? q2 : max_iter;  // (the last assignment may itself have moved nothing: then its centroids stand)
-      if (q2 >= 0) it = q2;
-    }
-    if (final_it >= h_warm - 1) TM_HIP(hipMemcpyAsync(cent, hit.C[final_it & 1], (size_t)k * 192 * 8, hipMemcpyDeviceToDevice, stream));
-  }
   if (host_iters) *host_iters = it;
   {
     HostRead hr_(stream);
@@ -2393,17 +1930,14 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
   TM_TRY(cent.alloc((size_t)npal * 192 * 8));
   TM_TRY(cnt.alloc((size_t)npal * 8));
   TM_TRY(lut.alloc((size_t)npal * 4));
-  int kk = 0, iters = 0;
-  if (getenv("TM_KM_FARTHEST_FIRST")) {  // the first rounds' seeding, kept for A/B runs (the oracle's tmo_kmeans_i32)
-    TM_TRY(run_kmeans(feat, use, n, 192, npal, max_iter, assign.p, cent.p, &kk, &iters, stream));
-  } else {
+  int iters = 0;
+  {
     DevBuf dseeds;  // the seeds never leave the device: no read-back, no drain of the stream, no upload between the seeding and the iterations
     TM_TRY(pp_seeds((const int32_t *)feat, (const uint32_t *)use, n, npal, nullptr, stream, &dseeds));
     std::vector<int64_t> b{0}, c{n};
     std::vector<int> kks;
     TM_TRY(kmeans_batched((const int32_t *)feat, (const uint32_t *)use, 192, b, c, npal, max_iter, assign.as<int32_t>(), cent.as<double>(), &kks, &iters, stream, nullptr,
                           dseeds.as<long long>()));
-    kk = kks[0];
   }
   kmeans_run_stats().tile_iters = iters;
   kmeans_run_stats().tile_points = n;
@@ -2433,65 +1967,6 @@ int run_palettize(const void *feat, const void *use, int64_t n, int npal, int ma
 struct FfCand { long long dist, gidx; int32_t row[192]; };  // one farthest-first candidate per process: largest min-distance, then lowest global index
 struct FfState { int kk, done; };
 
-__global__ __launch_bounds__(256) void k_ffd_update(const int32_t *__restrict__ pts, int64_t n, const int32_t *__restrict__ cur_row,
-                                                    long long *__restrict__ mind, BestKey *__restrict__ partial) {
-  __shared__ BestKey s_best[4];
-  __shared__ int32_t s_c[192];
-  for (int j = threadIdx.x; j < 192; j += 256) s_c[j] = cur_row[j];
-  __syncthreads();
-  BestKey mine{0, LLONG_MIN};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int4 *p = reinterpret_cast<const int4 *>(pts + i * 192);
-    long long dd = 0;
-    for (int j = 0; j < 48; j++) {
-      const int4 v = p[j];
-      const long long t0 = (long long)v.x - s_c[4 * j], t1 = (long long)v.y - s_c[4 * j + 1];
-      const long long t2 = (long long)v.z - s_c[4 * j + 2], t3 = (long long)v.w - s_c[4 * j + 3];
-      dd += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
-    }
-    long long m = mind[i];
-    if (dd < m) { m = dd; mind[i] = m; }
-    const BestKey cand{m, -(long long)i};
-    if (better(cand, mine)) mine = cand;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    BestKey other{__shfl_xor(mine.dist, o), __shfl_xor(mine.negidx, o)};
-    if (better(other, mine)) mine = other;
-  }
-  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int wv = 1; wv < 4; wv++)
-      if (better(s_best[wv], mine)) mine = s_best[wv];
-    partial[blockIdx.x] = mine;
-  }
-}
-// this process's candidate: first = 1 -> "I hold global point 0" (the first centre); else the best of the blocks' partials
-__global__ __launch_bounds__(256) void k_ffd_cand(const BestKey *__restrict__ partial, int nblk, const int32_t *__restrict__ pts, int64_t n,
-                                                  long long global_begin, int first, FfCand *__restrict__ out) {
-  __shared__ BestKey s_best[256];
-  const int tid = threadIdx.x;
-  BestKey best{0, LLONG_MIN};
-  if (first) {
-    if (tid == 0) best = (n > 0 && global_begin == 0) ? BestKey{1, 0} : BestKey{-1, LLONG_MIN};
-  } else {
-    for (int b = tid; b < nblk; b += 256) {
-      const BestKey c = partial[b];
-      if (better(c, best)) best = c;
-    }
-  }
-  s_best[tid] = best;
-  __syncthreads();
-  if (!first)
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o && better(s_best[tid + o], s_best[tid])) s_best[tid] = s_best[tid + o];
-      __syncthreads();
-    }
-  best = s_best[0];
-  const bool has = best.negidx != LLONG_MIN && best.dist > 0;
-  if (tid == 0) { out->dist = has ? best.dist : -1; out->gidx = has ? global_begin + (-best.negidx) : 0x7fffffffffffffffll; }
-  if (tid < 192) out->row[tid] = has ? pts[(-best.negidx) * 192 + tid] : 0;
-}
 // every process makes the same choice among the gathered candidates
 __global__ __launch_bounds__(256) void k_ffd_pick(const FfCand *__restrict__ cands, int world, int k, FfState *__restrict__ st, int32_t *__restrict__ cur_row,
                                                   double *__restrict__ cent) {
@@ -2575,13 +2050,8 @@ int run_palettize_dist(const void *feat_local, const void *use_local, int64_t n,
     TM_HIP(hipStreamSynchronize(stream));  // h0 is on the stack
   }
   FfCand *cd = cand.as<FfCand>();
-  const bool ff = getenv("TM_KM_FARTHEST_FIRST") != nullptr;
   for (int c = 0; c < k; c++) {
-    if (ff) {
-      if (c > 0)
-        hipLaunchKernelGGL(k_ffd_update, dim3(nblk), dim3(256), 0, stream, pts, n, cur_row.as<int32_t>(), mind.as<long long>(), partial.as<BestKey>());
-      hipLaunchKernelGGL(k_ffd_cand, dim3(1), dim3(256), 0, stream, partial.as<BestKey>(), nblk, pts, n, (long long)global_begin, c == 0 ? 1 : 0, cand.as<FfCand>());
-    } else {
+    {
       const int first = c == 0 ? 1 : 0;
       if (n > 0)
         hipLaunchKernelGGL(k_pp_mass, dim3(nb), dim3(PP_NT), 0, stream, pts, w, n, cur_row.as<int32_t>(), ppstate.as<PpState>(), first, mind.as<long long>(), bsum.as<PpSum>());
@@ -2776,7 +2246,6 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
     {
       for (int p = 0; p < npal; p++) { sb[p] = lb[p]; sc[p] = p % pal_world == pal_rank ? lb[p + 1] - lb[p] : 0; }  // other processes' palettes: empty segments
       TM_CHECK(lb[npal] == (long long)nu, TM_E_INVAL, "quantize: a tile names palette >= PaletteCount");
-      if (getenv("TM_KM_DEBUG")) { fprintf(stderr, "quantize: %u unique colours, per palette:", nu); for (int p = 0; p < npal; p++) fprintf(stderr, " %lld", (long long)sc[p]); fprintf(stderr, "\n"); }
     }
     TM_TRY(pts.alloc((size_t)std::max<unsigned>(nu, 1) * 12));
     TM_TRY(assign.alloc((size_t)std::max<unsigned>(nu, 1) * 4));
@@ -2785,7 +2254,7 @@ int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n
                        ukeys.as<u64>(), (int64_t)nu, pts.as<int32_t>());
     std::vector<int> kk;
     int iters = 0;
-    const bool dbg = getenv("TM_PP_DEBUG") != nullptr;
+    const bool dbg = knobs().pp_debug;
     const auto t_km = std::chrono::steady_clock::now();
     if (dbg) (void)hipStreamSynchronize(stream);
     const auto t_km0 = std::chrono::steady_clock::now();

@@ -903,6 +903,7 @@ static void launch_scan2(int ht, int hq, const Knn2Args &a, hipStream_t stream) 
 static std::atomic<double> g_list_entries_per_group{640.0};
 static void launch_seed3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_seed_ht) }
 static void launch_consume3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_consume_ht) }
+static void launch_collect3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_collect_ht) }
 
 static int device_cus() {  // compute units of the current device (persistent kernels launch one workgroup per CU)
   static int ncu = 0;
@@ -921,6 +922,7 @@ static int device_cus() {  // compute units of the current device (persistent ke
 static int launch_scan3(tm_knn_index_impl *ix, int64_t nq, int64_t nqt, int64_t ntt, int prune, const KnnBoxes &bx, unsigned long long *stats, hipStream_t stream) {
   const int ns = knn3_sub_tiles(ix->plan.hq), nsp = (ns + 1) & ~1;
   Knn3Args a;
+  memset(&a, 0, sizeof(a));  // (collection-mode fields stay off: no_seeds = 0, split = 0)
   a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
   a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
   a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
@@ -1186,6 +1188,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     double cur = g_list_entries_per_group.load();
     while (per > cur && !g_list_entries_per_group.compare_exchange_weak(cur, per)) {}
   }
+  TM_CHECK(!(shape == 3 && cnt[29] != 0), TM_E_HIP, "knn: the scan met a corrupted tile list (guard word %llx)", cnt[29]);
   if (shape == 3 && prune && cnt[20] > ix->arena_cap) {  // the tile lists did not fit the arena: the cursor says what they need
     TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
     if (getenv("TM_KNN_DEBUG")) fprintf(stderr, "[tm_knn] list arena: %llu entries needed, %llu held -- searching again\n", cnt[20], (unsigned long long)ix->arena_cap);
@@ -1324,6 +1327,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   bx.ghi = ix->grp_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
+  if (getenv("TM_KNN_V1")) {  // the first scan shape's collection kernel, kept for A/B runs
   KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
               nullptr, nullptr, nullptr, stream};
   a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
@@ -1333,6 +1337,57 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     a.split = wgs >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(wgs, 1)));
   }
   launch_mfma(ix->plan.ht, ix->plan.hq, a);
+  } else {
+    // The third scan shape in collection mode (tm_knn3_kernel.h): bounds from the thresholds, tile lists judged against them (no seeds:
+    // every tile goes through the lists), then the consume kernel appending every row within its query's threshold.
+    const int ns = knn3_sub_tiles_topk(ix->plan.hq), nsp = (ns + 1) & ~1;
+    hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 255) / 256, 4096)), dim3(256), 0, stream, ix->qkey.as<uint32_t>(), nqt, bx, ntt,
+                       ix->qmeta.as<int>());
+    TM_TRY(ix->counters.alloc(256 + 2048));
+    Knn3Args a;
+    memset(&a, 0, sizeof(a));
+    a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
+    a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
+    a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = n; a.qmeta = ix->qmeta.as<int>();
+    a.thmask = ix->thmask.as<uint8_t>();
+    TM_CHECK(ntt < (1 << 24), TM_E_UNSUPPORTED, "knn: %lld database tiles exceed the list entries' 24-bit tile index", (long long)ntt);
+    a.ns = ns; a.mode = K3_MODE_LISTS; a.tdouble = ix->plan.tscale == 2;
+    a.n_groups = (nqt + ns - 1) / ns;
+    a.max_segs = (int)(ntt / (K3_LCAP - K3_LIST_NT) + 2);
+    a.no_seeds = 1;
+    a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
+    // few queries left: their few workgroups would each walk most of the database one after the other -- share the tile lists
+    a.split = a.n_groups >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(a.n_groups, 1)));
+    TM_TRY(ix->gsmax.alloc((size_t)nqt * 4));
+    TM_TRY(ix->segs.alloc((size_t)a.n_groups * a.max_segs * 8)); TM_TRY(ix->nsegs.alloc((size_t)a.n_groups * 4));
+    a.gsmax = ix->gsmax.as<unsigned>(); a.segs = ix->segs.as<uint2>(); a.nsegs = ix->nsegs.as<int>();
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16);
+    a.stats = stats; a.seed_stats = nullptr; a.arena_cursor = stats + 18;
+    a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
+    a.grid_blocks = (int)std::min<int64_t>(a.n_groups * a.split, (int64_t)device_cus() * K3_WGS);
+    hipLaunchKernelGGL(k_knn_tau_bounds, dim3((unsigned)std::min<int64_t>((nqt + 7) / 8, 2048)), dim3(256), 0, stream, tau.as<int>(), n, nqt, a.gsmax);
+    for (int attempt = 0;; attempt++) {
+      // collection lists are long (a threshold from 32 tiles of the curve is loose): twice the nearest-neighbour search's experience to begin with
+      const uint64_t want = std::max<uint64_t>(ix->arena_want, std::max<uint64_t>(1u << 16, (uint64_t)((double)a.n_groups * 2.0 * g_list_entries_per_group.load())));
+      TM_CHECK(want < (1ull << 32), TM_E_UNSUPPORTED, "knn: %llu list entries exceed the arena's 32-bit offsets", (unsigned long long)want);
+      TM_TRY(ix->arena_tile.alloc((size_t)want * 4)); TM_TRY(ix->arena_lb.alloc((size_t)want * nsp * 2));
+      ix->arena_cap = want;
+      a.ltile = ix->arena_tile.as<unsigned>(); a.llb = ix->arena_lb.as<uint16_t>(); a.arena_cap = ix->arena_cap;
+      TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256, stream));
+      hipLaunchKernelGGL(k_knn_lists, dim3((unsigned)a.n_groups), dim3(K3_LIST_NT), 0, stream, a);
+      unsigned long long cursor = 0;
+      {  // the lists must fit before anything is collected through them (a second collection pass would double the candidates)
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(&cursor, stats + 18, 8));
+        TM_TRY(hr_.wait());
+      }
+      if (cursor <= ix->arena_cap) break;
+      TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
+      ix->arena_want = cursor + cursor / 4;
+    }
+    launch_collect3(ix->plan.ht, ix->plan.hq, a, stream);
+    TM_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
@@ -1340,12 +1395,15 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   TM_HIP(hipGetLastError());
   unsigned int novf = 0;
   int flag = 0;
+  unsigned long long guard = 0;
   {
     HostRead hr_(stream);
     TM_TRY(hr_.get(&novf, counter.p, 4));
     TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
+    if (!getenv("TM_KNN_V1")) TM_TRY(hr_.get(&guard, ix->counters.as<uint8_t>() + 16 + 27 * 8, 8));
     TM_TRY(hr_.wait());
   }
+  TM_CHECK(guard == 0, TM_E_HIP, "knn: the collection scan met a corrupted tile list (guard word %llx)", guard);
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   if (getenv("TM_KNN_DEBUG"))
     fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,
@@ -1396,5 +1454,6 @@ void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pa
 
 int knn2_sub_tiles(int hq) { return k2_ns(6 + std::min(std::max(hq, 0), 6)); }
 int knn3_sub_tiles(int hq) { return k3_ns(6 + std::min(std::max(hq, 0), 6)); }
+int knn3_sub_tiles_topk(int hq) { return k3_ns_topk(6 + std::min(std::max(hq, 0), 6)); }
 
 }  // namespace tmx

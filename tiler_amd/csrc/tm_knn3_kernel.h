@@ -77,11 +77,18 @@ struct Knn3Args {
   uint2 *segs;                  // [n_groups][max_segs] (first entry, entries) of each list segment
   int *nsegs;                   // [n_groups]
   int max_segs;
-  unsigned *ltile;              // arena [arena_cap] tile of each entry
+  unsigned *ltile;              // arena [arena_cap] tile << 8 | mask of the tile's non-zero high-digit chunks, per entry
   uint16_t *llb;                // arena [arena_cap][nsp] lower bounds per sub-tile slot
   unsigned long long arena_cap; // entries
   unsigned long long *arena_cursor;  // entries handed out (keeps counting past the capacity: the host sizes the next arena from it)
   int *best_key, *best_tile;
+  // collection mode (the k nearest rows, ann_kdtree_short_search_multi, tilingencoder.pas:1563): see k_knn_consume<.., TOPK = true>
+  int *tau;                     // [n_qtiles * 32] every sorted query's threshold (d'' <= tau); the scan leaves its final one
+  uint2 *cand;                  // [nq][cand_cap] (d'', sorted row) of every row within the threshold
+  int *cand_cnt;                // [nq] rows appended (keeps counting past cand_cap)
+  int cand_cap, cand_k;
+  int split;                    // workgroups that share one group's tile list (entry j goes to part j mod split)
+  int no_seeds;                 // lists: no seed kernel ran (collection mode), so no tile is left out of the lists
   unsigned long long *stats;    // consume: [0] blocks evaluated, [1] tiles read, [2] exact (query, row) pairs, [3] list entries consumed
   unsigned long long *seed_stats;  // [64][4] striped by workgroup: blocks, tiles read, pairs of the seed kernel
   int64_t n_groups;
@@ -117,7 +124,9 @@ __device__ __forceinline__ unsigned k3_bound_of(unsigned mx) { return mx == ~0u 
 // lane's 16 bytes (chunk stride 1024).
 // `tm` / `qm` (wave-uniform): bit kc set = high-digit chunk kc of the tile / of the sub-tile holds a non-zero digit.  A product with an
 // all-zero chunk adds nothing and is skipped, its LDS read with it: the columns are packed widest first (make_plan_scaled), so a tile of
-// smooth content has its high digits in the first chunk or two only.
+// smooth content has its high digits in the first chunk or two only.  (Measured against straight-line chains for the common mask shapes,
+// picked by one or two uniform tests: a predicate per product is as fast or faster on both bench clips -- the other waves of the SIMD
+// fill the matrix pipe while a product waits for its LDS read -- skips more, and needs no spilled register.)
 template <int HT, int HQ, bool TD>
 __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q, unsigned tm, unsigned qm) {
   constexpr int HM = HT < HQ ? HT : HQ;
@@ -204,12 +213,70 @@ __device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, in
   return refresh;
 }
 
+// Collection mode's epilogue.  The query's state in LDS: `best` = (tau + 1) << 32 | step (tau: its threshold, d'' <= tau; step = its first
+// threshold / 8), `lad` = 7 x 16-bit counters, rows seen with d'' <= (8 - j) step for j = 1..7.  Every row within the threshold is
+// appended to the query's candidate list; once cand_k rows lie at or below a rung, the k-th nearest is at most that rung + 1 and the
+// threshold drops to it (the threshold only ever falls, every value it takes is a valid bound: the waves of a workgroup, and the parts of
+// a split group, lower it on their own evidence).  Returns true in lanes that lowered a threshold the sub-tile's bound may hang on.
+template <bool TD>
+__device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, const v16i &ntr, int tile, bool countable, int half, unsigned qn, unsigned long long *best,
+                                                 unsigned *lad, bool qvalid, int64_t q, const Knn3Args &a, unsigned sm_now) {
+  int t[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
+  const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
+                     min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
+  const unsigned tau1 = k3_peek(reinterpret_cast<unsigned *>(best) + 1);  // tau + 1
+  bool refresh = false;
+  if (qvalid && (unsigned)tm + qn + 1u <= tau1) {
+    const unsigned step = k3_peek(reinterpret_cast<unsigned *>(best));
+    unsigned c[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const unsigned d1 = (unsigned)t[r] + qn + 1u;  // d'' + 1
+      if (d1 <= tau1) {
+        const int slot = atomicAdd(&a.cand_cnt[q], 1);
+        if (slot < a.cand_cap) a.cand[q * a.cand_cap + slot] = make_uint2(d1 - 1u, (unsigned)((tile << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+#pragma unroll
+        for (int j = 1; j <= 7; j++) c[j - 1] += (countable && d1 <= (unsigned)(8 - j) * step + 1u) ? 1u : 0u;
+      }
+    }
+    // the counters saturate where they stop mattering: a rung that has its cand_k rows takes no more (so no 16-bit field overflows
+    // into its neighbour: at most cand_k + 16 rows x 2 half-waves x 16 waves land in one)
+    const unsigned k = (unsigned)a.cand_k;
+    unsigned cur[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) cur[w] = k3_peek(&lad[w]);
+    unsigned add[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      const unsigned have = (cur[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      if (have < k) add[j >> 1] += c[j] << (16 * (j & 1));
+    }
+    unsigned now[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) now[w] = add[w] ? atomicAdd(&lad[w], add[w]) + add[w] : cur[w];
+    int rung = 0;
+#pragma unroll
+    for (int j = 1; j <= 7; j++)
+      if (((now[(j - 1) >> 1] >> (16 * ((j - 1) & 1))) & 0xFFFFu) >= k) rung = j;
+    // cand_k rows have d'' <= the rung, i.e. SSD <= rung + 1: no row beyond that can be among the k nearest
+    const unsigned tnew1 = (unsigned)(8 - rung) * step + 2u;  // (new tau = rung value + 1) + 1
+    if (rung > 0 && step > 0 && tnew1 < tau1) {
+      const unsigned pre = atomicMin(reinterpret_cast<unsigned *>(best) + 1, tnew1);
+      const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
+      refresh = tnew1 < pre && pre >= thr;
+    }
+  }
+  return refresh;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ 1. seeds
 // One workgroup (8 waves) per query group: wave w holds seed tile w in registers; the group's sub-tiles pass through LDS three at a time
 // (double buffered, LDS-DMA), every wave scoring each against its tile.  Bests meet in LDS (64-bit atomic minimum per query) and leave as
 // gbest / gtie / gsmax.  ~62 KB of LDS: two workgroups per CU, 100 registers per wave.
 constexpr int K3_SEED_SLICE = 3;
-template <int HT, int HQ, bool TD>
+template <int HT, int HQ, bool TD, bool UNUSED>
 __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a) {
   constexpr int KT = 6 + HT, KQ = 6 + HQ;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
@@ -333,8 +400,8 @@ __global__ __launch_bounds__(K3_LIST_NT) void k_knn_lists(const Knn3Args a) {
   if (tid == 0) s_ctl[0] = 0;
   __syncthreads();
   const int home = s_qbox[7];
-  const int r0a = (int)max((int64_t)0, min((int64_t)home - (K3_SEEDS / 2 - 1), n_ttiles - K3_SEEDS));
-  const int r0b = (int)min((int64_t)r0a + K3_SEEDS, n_ttiles);
+  const int r0a = a.no_seeds ? 0 : (int)max((int64_t)0, min((int64_t)home - (K3_SEEDS / 2 - 1), n_ttiles - K3_SEEDS));
+  const int r0b = a.no_seeds ? 0 : (int)min((int64_t)r0a + K3_SEEDS, n_ttiles);
   const int n_grp = (int)((n_ttiles + KNN_GROUP - 1) / KNN_GROUP), home_run = home / KNN_GROUP;
   const int total_run_slots = 2 * max(home_run, n_grp - 1 - home_run) + 1, n_run_batches = (total_run_slots + RB - 1) / RB;
   int nseg = 0;
@@ -439,7 +506,7 @@ __global__ __launch_bounds__(K3_LIST_NT) void k_knn_lists(const Knn3Args a) {
         for (int w = 0; w < (tid >> 6); w++) base += s_wcnt[w];
         const int idx = base + __popcll(pb & ((1ull << lane) - 1ull));
         if (any) {
-          s_ltile[idx] = (unsigned)tile | ((unsigned)a.thmask[tile] << 24);  // the entry carries the tile's high-chunk mask: the consumer has it before the tile
+          s_ltile[idx] = ((unsigned)tile << 8) | (unsigned)a.thmask[tile];  // the entry carries the tile's high-chunk mask: the consumer has it before the tile
 #pragma unroll
           for (int p = 0; p < 8; p++) s_llbw[idx * 8 + p] = lbw[p];
         }
@@ -453,19 +520,36 @@ __global__ __launch_bounds__(K3_LIST_NT) void k_knn_lists(const Knn3Args a) {
   if (tid == 0) a.nsegs[g] = min(nseg, a.max_segs);
 }
 
+// collection mode: the bound every sub-tile's tiles are judged against, from its queries' thresholds (what the seed kernel derives from
+// the bests in the nearest-neighbour search)
+__global__ __launch_bounds__(256) void k_knn_tau_bounds(const int *__restrict__ tau, int64_t nq, int64_t n_qtiles, unsigned *__restrict__ gsmax) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w * 2 < n_qtiles; w += (int64_t)gridDim.x * 4) {
+    const int64_t st = w * 2 + (lane >> 5), q = st * 32 + (lane & 31);
+    unsigned v = (st < n_qtiles && q < nq) ? (unsigned)(tau[q] + 1) : 0u;  // tau + 1 = the SSD bound
+    for (int o = 16; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if ((lane & 31) == 0 && st < n_qtiles) gsmax[st] = k3_bound_of(v);
+  }
+}
 #endif  // TM_KNN3_WITH_LISTS
 
 // ------------------------------------------------------------------------------------------------------------------ 3. consume
-template <int HT, int HQ, bool TD>
+// TOPK: collection mode for the k nearest rows (ann_kdtree_short_search_multi, tilingencoder.pas:1563).  Every query comes with a threshold
+// (an upper bound of its k-th smallest SSD, a.tau); nothing is seeded, the lists are judged against the thresholds' bounds, and instead of
+// keeping a minimum the epilogue appends every row within the threshold to the query's candidate list and walks the threshold down its
+// ladder (k3_epilogue_topk).  One sub-tile fewer per group pays for the ladder's counters in LDS.  a.split > 1: the group's list is
+// shared by that many workgroups (passes over few queries would otherwise leave most of the chip idle).
+constexpr int k3_ns_topk(int kq) { return k3_ns(kq) > 1 ? k3_ns(kq) - 1 : 1; }
+template <int HT, int HQ, bool TD, bool TOPK>
 __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   constexpr int KT = 6 + HT, KQ = 6 + HQ;
   constexpr int T_BYTES = KT * 1024 + 128 + 64, Q_BYTES = KQ * 1024 + 128;
-  constexpr int NS = k3_ns(KQ), NSP = (NS + 1) & ~1, NW = K3_NW, NT = K3_NT, LCAP = K3_LCAP;
+  constexpr int NS = TOPK ? k3_ns_topk(KQ) : k3_ns(KQ), NSP = (NS + 1) & ~1, NW = K3_NW, NT = K3_NT, LCAP = K3_LCAP;
   // one LDS object, carved by hand (16-byte aligned pieces)
   constexpr int OFF_QN = NS * KQ * 1024, OFF_BEST = OFF_QN + NS * 128, OFF_TIE = OFF_BEST + NS * 256, OFF_QBOX = OFF_TIE + NS * 128,
                 OFF_SMAX = OFF_QBOX + NS * 64, OFF_QMASK = OFF_SMAX + 64, OFF_CTL = OFF_QMASK + 64, OFF_LTILE = OFF_CTL + 64, OFF_LLB = OFF_LTILE + LCAP * 4,
-                LDS_TOTAL = OFF_LLB + LCAP * NSP * 2;
-  static_assert(LDS_TOTAL == k3_lds_bytes(NS, KQ) && LDS_TOTAL <= K3_LDS, "LDS carve");
+                OFF_LAD = OFF_LLB + LCAP * NSP * 2, LDS_TOTAL = OFF_LAD + (TOPK ? NS * 32 * 16 : 0);
+  static_assert(OFF_LAD == k3_lds_bytes(NS, KQ) && LDS_TOTAL <= K3_LDS, "LDS carve");
   __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TOTAL];
   int *const s_qn = reinterpret_cast<int *>(lds + OFF_QN);                                  // [NS][32] 2 * (|q-c|^2 >> 1)
   unsigned long long *const s_best = reinterpret_cast<unsigned long long *>(lds + OFF_BEST);  // [NS][32] (d'' + 1) << 32 | sorted row
@@ -476,6 +560,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   int *const s_ctl = reinterpret_cast<int *>(lds + OFF_CTL);                                // [0] list length, [1] cursor, [3] group
   unsigned *const s_ltile = reinterpret_cast<unsigned *>(lds + OFF_LTILE);                  // [LCAP]
   uint16_t *const s_llb = reinterpret_cast<uint16_t *>(lds + OFF_LLB);                      // [LCAP][NSP]
+  [[maybe_unused]] unsigned *const s_lad = reinterpret_cast<unsigned *>(lds + OFF_LAD);     // TOPK: [NS][32][4] the ladder's 7 x 16-bit counters
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
 #if TM_KNN3_STAMPS
@@ -489,6 +574,8 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
   long long nblocks = 0, nloads = 0, npairs = 0, nlisted = 0, nmfma = 0;
   const bool dense = a.mode == K3_MODE_DENSE;
+  const int split = TOPK ? max(1, a.split) : 1;
+  const int64_t n_units = a.n_groups * split;  // what the tickets deal: (group, part of its list)
   for (;;) {
   __syncthreads();  // the previous group's LDS is no longer read
   if (tid == 0) {
@@ -497,19 +584,21 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
       const unsigned x = (xcc + k) & 7u;
       const unsigned t = atomicAdd(&a.tickets[x], 1u);
 #if TM_KNN3_XCD_CONTIG
-      const int64_t per = (a.n_groups + 7) / 8;
+      const int64_t per = (n_units + 7) / 8;
       const int64_t gg = (int64_t)x * per + t;
-      if ((int64_t)t < per && gg < a.n_groups) gsel = gg;
+      if ((int64_t)t < per && gg < n_units) gsel = gg;
 #else
       const int64_t gg = ((int64_t)(t / K3_XCD_RUN) * 8 + x) * K3_XCD_RUN + (t % K3_XCD_RUN);
-      if (gg < a.n_groups) gsel = gg;
+      if (gg < n_units) gsel = gg;
 #endif
     }
     s_ctl[3] = (int)gsel;
   }
   __syncthreads();
-  const int64_t g = __builtin_amdgcn_readfirstlane(s_ctl[3]);
-  if (g < 0) break;
+  const int64_t unit = __builtin_amdgcn_readfirstlane(s_ctl[3]);
+  if (unit < 0) break;
+  const int64_t g = unit / split;
+  const int part = (int)(unit - g * split);
   const int64_t st0 = g * NS;
   const int nvalid = (int)min((int64_t)NS, a.n_qtiles - st0);
   const int64_t n_ttiles = a.n_ttiles;
@@ -530,8 +619,14 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
     const bool real = (i >> 5) < nvalid && !dense;
     s_qn[i] = reinterpret_cast<const int *>(a.qpack + st * (int64_t)Q_BYTES + KQ * 1024)[i & 31] & ~1;
-    s_best[i] = real ? a.gbest[st0 * 32 + i] : ~0ull;
-    s_tie[i] = real ? a.gtie[st0 * 32 + i] : ~0u;
+    if constexpr (TOPK) {  // (tau + 1) << 32 | tau / 8; queries that are padding get tau = -1: nothing is within it
+      const int tau = (real && st0 * 32 + i < a.nq) ? a.tau[st0 * 32 + i] : -1;
+      s_best[i] = ((unsigned long long)(unsigned)(tau + 1) << 32) | (unsigned)(tau > 0 ? tau >> 3 : 0);
+      for (int w = 0; w < 4; w++) s_lad[i * 4 + w] = 0;
+    } else {
+      s_best[i] = real ? a.gbest[st0 * 32 + i] : ~0ull;
+      s_tie[i] = real ? a.gtie[st0 * 32 + i] : ~0u;
+    }
   }
   if (tp < 16) {
     s_smax[tp] = (tp < nvalid && !dense) ? a.gsmax[st0 + tp] : 0xFFFEu;
@@ -549,12 +644,16 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     if (dense) {  // every tile, every sub-tile
       list_n = (int)min((int64_t)LCAP, n_ttiles - (int64_t)seg * LCAP);
       for (int i = tl; i < list_n; i += NT) {
-        s_ltile[i] = (unsigned)(seg * LCAP + i) | ((unsigned)a.thmask[seg * LCAP + i] << 24);
+        s_ltile[i] = ((unsigned)(seg * LCAP + i) << 8) | (unsigned)a.thmask[seg * LCAP + i];
         for (int p = 0; p < NSP; p++) s_llb[i * NSP + p] = p < nvalid ? 0 : 0xFFFF;
       }
     } else {
       const uint2 sg = a.segs[g * a.max_segs + seg];
       list_n = (int)sg.y;
+      if (list_n != 0 && ((unsigned long long)sg.x + sg.y > a.arena_cap || list_n > LCAP)) {  // never by construction (a segment that did not fit the arena has 0 entries): a guard against a corrupted segment table
+        if (tl == 0) atomicMax(a.stats + 27, 0x100000000ull | sg.y);
+        list_n = 0;
+      }
       for (int i = tl; i < list_n; i += NT) s_ltile[i] = a.ltile[sg.x + i];
       const unsigned *src = reinterpret_cast<const unsigned *>(a.llb) + (size_t)sg.x * (NSP / 2);
 #pragma unroll 1
@@ -566,11 +665,12 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     // ---------------------------------------------------------------- consume: every wave on its own
     {
       nlisted += (wave == 0) ? list_n : 0;
-      auto next_entry = [&](int &tile_o, int &lb_o, unsigned &mask_o) -> bool {
+      auto next_entry = [&](int &tile_o, unsigned &tm_o, int &lb_o, unsigned &mask_o) -> bool {
         for (;;) {
           int j = 0;
           if (lane == 0) j = atomicAdd(&s_ctl[1], 1);
           j = __builtin_amdgcn_readfirstlane(j);
+          if (TOPK) j = j * split + part;  // a split group: this workgroup takes every split-th entry
           if (j >= list_n) return false;
 #if TM_KNN3_REFRESH_EVERY
           if ((j & (TM_KNN3_REFRESH_EVERY - 1)) == TM_KNN3_REFRESH_EVERY - 1)
@@ -584,23 +684,29 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           const int lb = lane < NSP ? (int)s_llb[j * NSP + lane] : 0xFFFF;
           const int sm = lane < NS ? (int)k3_peek(&s_smax[lane]) : -1;
           const unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lb <= sm);
-          if (m) { tile_o = __builtin_amdgcn_readfirstlane(t); lb_o = lb; mask_o = m; return true; }  // (tile_o: tile | high-chunk mask << 24)
+          // Entry word = tile << 8 | mask: the tile comes out by a SHIFT.  (An earlier layout, tile | mask << 24 with `tile = word & 0xFFFFFF`,
+          // met a compiler combine that treats the 64-bit multiply by the tile size as a 24-bit multiply, drops the AND as redundant for one,
+          // and then selects a full 32-bit v_mad_u64_u32: the loads went to word * 12 KB -- a memory aperture violation on the GPU box.)
+          if (m) { tile_o = __builtin_amdgcn_readfirstlane((int)((unsigned)t >> 8)); tm_o = (unsigned)__builtin_amdgcn_readfirstlane(t) & 0xFFu; lb_o = lb; mask_o = m; return true; }
         }
       };
-      int tile_w = 0, lbv = 0;
-      unsigned mask = 0;
-      bool have = next_entry(tile_w, lbv, mask);
+      int tile = 0, lbv = 0;
+      unsigned mask = 0, tmw = 0;
+      bool have = next_entry(tile, tmw, lbv, mask);
       while (have) {
-        const int tile = tile_w & 0xFFFFFF;
-        const unsigned tm = (unsigned)tile_w >> 24;
+        const unsigned tm = tmw;
+        if (tile >= n_ttiles) {  // never by construction: a list entry outside the database (a guard: the loads below must not follow it)
+          if (lane == 0) atomicMax(a.stats + 27, 0x200000000ull | (unsigned)tile);
+          break;
+        }
         v4i T[KT];
         v16i ntr;
         k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
         nloads++;
         // the entry after this one is chosen while the loads fly
         int ntile = 0, nlb = 0;
-        unsigned nmask = 0;
-        const bool nhave = next_entry(ntile, nlb, nmask);
+        unsigned nmask = 0, ntm = 0;
+        const bool nhave = next_entry(ntile, ntm, nlb, nmask);
         const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
         while (mask) {
           const int s = __builtin_ctz(mask);
@@ -613,7 +719,15 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16, tm, qm);
           nmfma += 6 + __builtin_popcount(tm & qm) + __builtin_popcount(qm) + __builtin_popcount(tm);
           const int qi = s * 32 + (lane & 31);
-          const bool refresh = k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], sm_now);
+          bool refresh;
+          if constexpr (TOPK) {
+            const int64_t q = (st0 + s) * 32 + (lane & 31);
+            // (the last database tile pads with copies of its last row: they are candidates like any row -- the select stage drops them --
+            // but must not count towards a rung)
+            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, (unsigned)s_qn[qi], &s_best[qi], &s_lad[qi * 4], q < a.nq, q, a, sm_now);
+          } else {
+            refresh = k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], sm_now);
+          }
           if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
             const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1));  // = largest d'' + 1
             if (mx != ~0u && lane == 0) atomicMin(&s_smax[s], k3_bound_of(mx));
@@ -621,7 +735,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           nblocks++;
           npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
         }
-        tile_w = ntile; lbv = nlb; mask = nmask; have = nhave;
+        tile = ntile; tmw = ntm; lbv = nlb; mask = nmask; have = nhave;
       }
     }
     K3_STAMP(2);  // consuming
@@ -643,8 +757,12 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     const unsigned long long k = s_best[i];
     const unsigned hi = (unsigned)(k >> 32);
     const int64_t q = st * 32 + (i & 31);
-    a.best_key[q] = (int)(hi - 1u);
-    a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
+    if constexpr (TOPK) {  // the final threshold: k_topk_select drops the stored candidates above it
+      if (q < a.nq && hi > 0) atomicMin(&a.tau[q], (int)(hi - 1u));
+    } else {
+      a.best_key[q] = (int)(hi - 1u);
+      a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
+    }
   }
   K3_STAMP(4);  // results
   }  // next query group
@@ -666,30 +784,37 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
 // one per HT, defined in tm_knn3_k<HT>.hip
 template <int HT> void knn3_launch_seed_ht(int hq, const Knn3Args &a, hipStream_t stream);
 template <int HT> void knn3_launch_consume_ht(int hq, const Knn3Args &a, hipStream_t stream);
-int knn3_sub_tiles(int hq);  // NS of the queries' digit plan
+template <int HT> void knn3_launch_collect_ht(int hq, const Knn3Args &a, hipStream_t stream);  // k_knn_consume<.., TOPK = true>
+int knn3_sub_tiles(int hq);       // NS of the queries' digit plan
+int knn3_sub_tiles_topk(int hq);  // ... in collection mode
 
-#define TM_KNN3_LAUNCH(KERNEL, HT, HQ)                                                                  \
+// FLAG: the kernels' fourth template argument (k_knn_consume's TOPK; the seed kernel ignores its own)
+#define TM_KNN3_LAUNCH(KERNEL, HT, HQ, FLAG)                                                            \
   do {                                                                                                 \
-    if (a.tdouble) hipLaunchKernelGGL((KERNEL<HT, HQ, true>), grid, block, 0, stream, a);              \
-    else hipLaunchKernelGGL((KERNEL<HT, HQ, false>), grid, block, 0, stream, a);                       \
+    if (a.tdouble) hipLaunchKernelGGL((KERNEL<HT, HQ, true, FLAG>), grid, block, 0, stream, a);        \
+    else hipLaunchKernelGGL((KERNEL<HT, HQ, false, FLAG>), grid, block, 0, stream, a);                 \
   } while (0)
-#define TM_KNN3_CASE(KERNEL, HT, HQ) \
-  case HQ: TM_KNN3_LAUNCH(KERNEL, HT, HQ); break;
-#define TM_KNN3_SWITCH(KERNEL, HT)                                                                                            \
+#define TM_KNN3_CASE(KERNEL, HT, HQ, FLAG) \
+  case HQ: TM_KNN3_LAUNCH(KERNEL, HT, HQ, FLAG); break;
+#define TM_KNN3_SWITCH(KERNEL, HT, FLAG)                                                                                      \
   switch (hq) {                                                                                                               \
-    TM_KNN3_CASE(KERNEL, HT, 0) TM_KNN3_CASE(KERNEL, HT, 1) TM_KNN3_CASE(KERNEL, HT, 2) TM_KNN3_CASE(KERNEL, HT, 3)           \
-    TM_KNN3_CASE(KERNEL, HT, 4) TM_KNN3_CASE(KERNEL, HT, 5)                                                                   \
-    default: TM_KNN3_LAUNCH(KERNEL, HT, 6);                                                                                   \
+    TM_KNN3_CASE(KERNEL, HT, 0, FLAG) TM_KNN3_CASE(KERNEL, HT, 1, FLAG) TM_KNN3_CASE(KERNEL, HT, 2, FLAG)                     \
+    TM_KNN3_CASE(KERNEL, HT, 3, FLAG) TM_KNN3_CASE(KERNEL, HT, 4, FLAG) TM_KNN3_CASE(KERNEL, HT, 5, FLAG)                     \
+    default: TM_KNN3_LAUNCH(KERNEL, HT, 6, FLAG);                                                                             \
   }
 
 #define TM_KNN3_DEFINE_HT(HT)                                                                         \
   template <> void knn3_launch_seed_ht<HT>(int hq, const Knn3Args &a, hipStream_t stream) {          \
     const dim3 grid((unsigned)a.n_groups), block(K3_SEEDS * 64);                                      \
-    TM_KNN3_SWITCH(k_knn_seed, HT)                                                                    \
+    TM_KNN3_SWITCH(k_knn_seed, HT, false)                                                             \
   }                                                                                                   \
   template <> void knn3_launch_consume_ht<HT>(int hq, const Knn3Args &a, hipStream_t stream) {       \
     const dim3 grid((unsigned)a.grid_blocks), block(K3_NT);                                           \
-    TM_KNN3_SWITCH(k_knn_consume, HT)                                                                 \
+    TM_KNN3_SWITCH(k_knn_consume, HT, false)                                                          \
+  }                                                                                                   \
+  template <> void knn3_launch_collect_ht<HT>(int hq, const Knn3Args &a, hipStream_t stream) {       \
+    const dim3 grid((unsigned)a.grid_blocks), block(K3_NT);                                           \
+    TM_KNN3_SWITCH(k_knn_consume, HT, true)                                                           \
   }
 
 }  // namespace tmx

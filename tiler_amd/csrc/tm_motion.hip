@@ -495,7 +495,7 @@ int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, i
                          hipStream_t stream) {
   TM_CHECK(tm_w > 0 && tm_h > 0 && radius >= 1 && radius <= 128, TM_E_INVAL, "motion search: bad arguments");
   const int bw = (tm_w + MS_TB - 1) / MS_TB, bh = (tm_h + MS_TB - 1) / MS_TB;
-  if (getenv("TM_MOTION_VALU")) {  // the VALU kernel alone (A/B runs)
+  if (knobs().motion_valu) {  // the VALU kernel alone (A/B runs)
     hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
                        (uint32_t *)best_err, (int8_t *)px, (int8_t *)py, (const int *)nullptr);
     TM_HIP(hipGetLastError());

@@ -52,8 +52,6 @@ HostRead::~HostRead() {
 }
 int HostRead::get(void *dst, const void *src, size_t bytes) {
   if (bytes == 0) return TM_OK;
-  static const bool off_env = getenv("TM_NO_PINNED_READBACK") != nullptr;  // A/B aid
-  if (off_env) t_pin.failed = true;
   if (!t_pin.p && !t_pin.failed) {
     void *q = nullptr;
     if (hipHostMalloc(&q, PinnedArea::CAP, hipHostMallocPortable) == hipSuccess) t_pin.p = (uint8_t *)q;
@@ -145,7 +143,22 @@ void pool_free(void *p, size_t bytes) {
   t_pool.held += bytes;
 }
 
+namespace { thread_local Knobs t_knobs; }
+const Knobs &knobs() { return t_knobs; }
+void knobs_reload() {
+  auto on = [](const char *name) { const char *v = getenv(name); return v != nullptr && !(v[0] == '0' && v[1] == 0); };  // set, and not "0"
+  Knobs k;
+  k.knn_debug = on("TM_KNN_DEBUG"); k.knn_noprune = on("TM_KNN_NOPRUNE"); k.topk_brute = on("TM_TOPK_BRUTE"); k.no_query_groups = on("TM_NO_QUERY_GROUPS");
+  k.dither_own_keys = on("TM_DITHER_OWN_KEYS"); k.dither_no_dedup = on("TM_DITHER_NO_DEDUP"); k.dither_literal = on("TM_DITHER_LITERAL");
+  k.dedup_plain = on("TM_DEDUP_PLAIN"); k.dedup_degrade_hash = on("TM_DEDUP_DEGRADE_HASH"); k.dedup_full_order = on("TM_DEDUP_FULL_ORDER");
+  k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST");
+  if (const char *v = getenv("TM_EPU_TABLE_GIB")) k.epu_table_gib = atof(v);
+  if (const char *v = getenv("TM_COMM_TIMEOUT_S")) k.comm_timeout_s = std::max(1.0, atof(v));
+  t_knobs = k;
+}
+
 int require_device() {
+  knobs_reload();  // every compute entry point of the C ABI comes through here first
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {

@@ -2,7 +2,7 @@
 # development aid: KNN parity tests on the current build, then the headline bench (no extras) with the second and the third scan shape
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "knn or KNN or match or motion_search_q" > gpurun_out/knn_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_encoder.py -x -q -m gpu -k "knn or KNN or match or motion_search_q or topk or epu or extended" > gpurun_out/knn_tests.log 2>&1
 rc=$?
 tail -5 gpurun_out/knn_tests.log
 [ $rc -ne 0 ] && { grep -n "Error\|error\|assert" gpurun_out/knn_tests.log | tail -20; exit $rc; }
