@@ -314,13 +314,13 @@ def main():
     def timed(nsteps):
         barrier()
         t0 = time.perf_counter()
-        knn = dict(ms=0.0, pairs=0, launches=0, seed_ms=0.0, lists_ms=0.0, consume_ms=0.0, seed_pairs=0, consume_pairs=0)
+        knn = dict(ms=0.0, pairs=0, launches=0, seed_ms=0.0, lists_ms=0.0, consume_ms=0.0, seed_pairs=0, consume_pairs=0, consume_mfma=0)
         stage_ms, stage_max, step_max, tl = np.zeros(8), np.zeros(8), 0.0, t0
         for _ in range(nsteps):
             step()
             ks = enc.KnnStats()
             knn["ms"] += ks["kernel_ms"]; knn["pairs"] += ks["pairs"]; knn["launches"] += ks["launches"]
-            for k in ("seed_ms", "lists_ms", "consume_ms", "seed_pairs", "consume_pairs"):
+            for k in ("seed_ms", "lists_ms", "consume_ms", "seed_pairs", "consume_pairs", "consume_mfma"):
                 knn[k] += ks[k]
             sm = enc.StageMs()
             stage_ms += sm
@@ -346,6 +346,8 @@ def main():
     per_launch_ms = knn["consume_ms"] / nl
     alg_ops_per_launch = 384.0 * knn["consume_pairs"] / nl  # 2*192 integer ops per (query, tile) pair
     achieved = alg_ops_per_launch / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+    # what the matrix pipe really executed: the consume kernel's 32x32x32 int8 instructions (65 536 ops each), zero chunks skipped
+    mfma_tops = knn["consume_mfma"] / nl * 65536.0 / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
     scan_ms = knn["ms"] / nl
     achieved_scan = 384.0 * knn["pairs"] / nl / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     ms_per_step = dt / args.steps * 1e3
@@ -395,9 +397,9 @@ def main():
                               "ms": scan_ms, "pairs": knn["pairs"] / nl, "achieved": achieved_scan, "frac": achieved_scan / I8_DENSE_PEAK_TOPS,
                               "note": "the whole search = three kernels back to back (seeds, tile lists, consume); `frac` here prices all evaluated pairs "
                                       "against the three kernels' time, the roofline line above the dominant kernel alone"},
-                     "mfma_pipe_frac": achieved * (2 * ks["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
+                     "mfma_pipe_frac": mfma_tops / I8_DENSE_PEAK_TOPS, "mfma_instructions_per_launch": knn["consume_mfma"] / nl,
                      "note": "int8 ops; algorithmic = 384 ops per evaluated (query, distinct database row) pair (exact count: padding rows are not pairs); "
-                             "the kernel executes 2*k_bytes ops per pair on the MFMA pipe"},
+                             "the kernel's chain has k_bytes / 32 matrix instructions per 32 x 32 block and skips those whose high-digit chunk is all zero: mfma_pipe_frac prices the instructions it issued"},
     }
     if traffic is not None:  # what the committed PMC passes of this kernel build say beside the traffic: matrix pipe busy time, L2 hit rate
         out["roofline"].update({"pmc_" + k: v for k, v in _traffic_from_profiles.extra.items()})
@@ -469,7 +471,7 @@ def main():
                                  "note": "bare v_mfma_i32_32x32x32_i8 loop (two waves per SIMD, operands in registers) and a = b + s*c over 3 x 1 GiB; "
                                          "roofline.frac stays against the 5000 TOP/s vendor figure"}
         out["roofline"]["frac_of_measured_peak"] = achieved / tops.value if tops.value > 0 else None
-        out["roofline"]["mfma_pipe_frac_of_measured_peak"] = achieved * (2 * ks["k_bytes"] / 384.0) / tops.value if tops.value > 0 else None
+        out["roofline"]["mfma_pipe_frac_of_measured_peak"] = mfma_tops / tops.value if tops.value > 0 else None
     if world == 1:
         # per-stage rooflines: the streaming kernels timed on their own (torch events on the stream the stage seam
         # launches on) on the clip's own data; Dither and the k-means stage from the step's wall time
@@ -558,10 +560,11 @@ def main():
             enc.Run(s_)
         del os.environ["TM_KNN_NOPRUNE"]
         kd = enc.KnnStats()
+        dense_mfma = kd["consume_mfma"] * 65536.0 / (kd["consume_ms"] * 1e-3) / 1e12 if kd["consume_ms"] > 0 else 0.0
         dense = 384.0 * kd["pairs"] / max(kd["launches"], 1) / (kd["kernel_ms"] / max(kd["launches"], 1) * 1e-3) / 1e12  # (dense: the consume kernel is the whole search)
         out["roofline_dense"] = {"bound": "mfma", "achieved": dense, "peak": I8_DENSE_PEAK_TOPS, "unit": "TFLOP/s", "frac": dense / I8_DENSE_PEAK_TOPS,
-                                 "mfma_pipe_frac": dense * (2 * kd["k_bytes"] / 384.0) / I8_DENSE_PEAK_TOPS,
-                                 "mfma_pipe_frac_of_measured_peak": (dense * (2 * kd["k_bytes"] / 384.0) / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
+                                 "mfma_pipe_frac": dense_mfma / I8_DENSE_PEAK_TOPS,
+                                 "mfma_pipe_frac_of_measured_peak": (dense_mfma / out["measured_peaks"]["mfma_i8_tops"]) if "measured_peaks" in out else None,
                                  "launch_ms": kd["kernel_ms"] / max(kd["launches"], 1), "pairs_per_launch": kd["pairs"] / max(kd["launches"], 1),
                                  "pairs_expected": float(kd.get("queries", q_total)) * float(kd["db_rows"]),
                                  "note": "same kernel, pruning disabled (TM_KNN_NOPRUNE=1): every (query, distinct row) pair evaluated; parity-tested in tests/test_gpu_parity.py::test_knn_dense_mode*"}

@@ -16,6 +16,32 @@
  *      owns several processes/GPUs (bench.py, tiler_amd.distributed) can put RCCL collectives between them.
  *   3. Fine seam    ann_kdtree_* / yakmo_* / bico_*  == the DLL imports of extern.pas:178-223, same
  *      per-call semantics, plus *_batch twins (per-call GPU use is latency bound; kept for compatibility).
+ *
+ * Several GPUs: ONE PROCESS PER GPU, and only that.  The surveyed boundary sketched a tm_set_device_mask for one process driving 1/2/4/8
+ * devices; it is not built and will not be: an encoder is bound to one device (tm_set_device) and one host thread, N encoders become one
+ * job through tm_comm_init (RCCL inside the library) or tm_set_collective (the host's own communicator), and the reference's single
+ * control thread (tiler.lpr:64-70) starts N copies of itself with a rank each.  One process per device is what
+ * RCCL and the driver's launcher (torch.distributed.run) assume, it keeps a fault or an out-of-memory on one device from taking the
+ * other seven encoders with it, and the steps' host tails (OptimizePalettes, the key-frame logic, LZMA) run N times in parallel
+ * instead of queueing on one thread.
+ *
+ * Environment switches.  All are optional; they are sampled at the API boundary (tm_create, tm_run, every tm_stage_* and fine-seam entry)
+ * and never read inside a step.  Set and not "0" = on.
+ *   TM_KNN_DEBUG            one line per search on stderr: the three kernels' times, pairs evaluated, list sizes, matrix instructions
+ *   TM_KNN_NOPRUNE          the nearest-neighbour scan evaluates every (query, row) pair (bench.py's dense diagnostic launch)
+ *   TM_TOPK_BRUTE           the k-nearest search by the VALU brute force (tests compare the pruned scan with it)
+ *   TM_EPU_TABLE_GIB=<x>    above this size the (tile, palette) feature table is not built, the pairs asked for are (default 6)
+ *   TM_NO_QUERY_GROUPS      Reconstruct searches once per tile-map item instead of once per distinct frame tile (tests)
+ *   TM_DITHER_OWN_KEYS      Dither collects its (palette, colour) pairs itself instead of taking PreparePalettes' keys (tests)
+ *   TM_DITHER_NO_DEDUP      Dither plans every pixel on its own (tests); TM_DITHER_LITERAL: every tile through the literal-sort kernel
+ *   TM_DEDUP_PLAIN          exact dedup by the comparator sort alone; TM_DEDUP_DEGRADE_HASH: a 2-bit hash, so that every group
+ *                           collides (tests); TM_DEDUP_FULL_ORDER: the whole order, not only the rows that can survive the budget (tests)
+ *   TM_MOTION_VALU          the motion search's VALU kernel only (tests drive both kernels)
+ *   TM_PP_DEBUG             PreparePalettes prints its sub-steps' wall times (adds synchronisations)
+ *   TM_COMM_FORCE_DIST      a one-process communicator still walks the sharded code paths (tests on a one-GPU box)
+ *   TM_COMM_TIMEOUT_S=<s>   how long tm_comm_init (and a collective of the library's own communicator) waits for the other processes (120)
+ *   TM_POOL_GIB=<x>         cap of the device-memory pool a thread keeps (96); TM_HOST_THREADS=<n>: OptimizePalettes' helper threads
+ *                           (both read once per process)
  */
 #ifndef TILEMOTION_H
 #define TILEMOTION_H
@@ -201,8 +227,10 @@ TM_API int tm_sync_tilemap(tm_encoder *);
 /* pairs = (query, distinct database row) pairs the kernel evaluated; db_rows = distinct rows searched (<= global tiles) */
 TM_API int tm_get_knn_stats(tm_encoder *, double *kernel_ms, int64_t *pairs, int *launches, int *k_bytes, int64_t *db_rows);
 /* the same launches kernel by kernel (the scan is three kernels): device ms of k_knn_seed / k_knn_lists / k_knn_consume,
- * and the (query, row) pairs the seed and the consume kernel evaluated; kernel_ms above is the sum of the three, pairs the sum of the two */
-TM_API int tm_get_knn_kernel_split(tm_encoder *, double ms[3], int64_t pairs[2]);
+ * the (query, row) pairs the seed and the consume kernel evaluated, and the 32x32x32 int8 matrix instructions the consume kernel issued for them
+ * (a chain has 6 + HT + HQ + min(HT, HQ); products with an all-zero high-digit chunk are skipped); kernel_ms above is the sum of the three
+ * times, pairs the sum of the two counts */
+TM_API int tm_get_knn_kernel_split(tm_encoder *, double ms[3], int64_t pairs[3]);
 /* queries of the last Reconstruct's searches: the DISTINCT frame tiles when Reduce's exact groups can be used (one process, motion
  * prediction off), every tile-map item otherwise */
 TM_API int64_t tm_get_knn_queries(tm_encoder *);

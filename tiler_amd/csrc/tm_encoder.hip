@@ -265,7 +265,7 @@ struct tm_encoder {
   int64_t knn_pairs = 0;
   int knn_launches = 0, knn_kbytes = 0;
   double knn_split_ms[3] = {0, 0, 0};  // seeds / lists / consume kernels of those launches
-  int64_t knn_split_pairs[2] = {0, 0};
+  int64_t knn_split_pairs[3] = {0, 0, 0};
   KmeansRunStats km_stats;  // of the last PreparePalettes (single process: the sharded path runs its own loops)
   int64_t knn_db_rows = 0;  // distinct database rows actually searched
   int64_t knn_queries = 0;  // queries of the last Reconstruct's searches (distinct frame tiles when Reduce's groups are used)
@@ -1032,7 +1032,7 @@ static int step_reconstruct(tm_encoder *e) {
   }
   e->knn_ms = 0; e->knn_pairs = 0; e->knn_launches = 0; e->knn_db_rows = 0; e->knn_queries = 0;
   for (double &v : e->knn_split_ms) v = 0;
-  e->knn_split_pairs[0] = e->knn_split_pairs[1] = 0;
+  e->knn_split_pairs[0] = e->knn_split_pairs[1] = e->knn_split_pairs[2] = 0;
   const bool epu = e->s.FrameTilingExtendedPaletteUsage;
   if (epu) {
     // FrameTilingExtendedPaletteUsage (1559-1610): the 64 nearest rows of the whole database (duplicates included, as
@@ -1152,10 +1152,10 @@ static int step_reconstruct(tm_encoder *e) {
       knn_index_stats(ix, &ms, &kb, &pairs);
       e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
       {
-        double sm[3]; int64_t sp[2];
+        double sm[3]; int64_t sp[3];
         knn_index_kernel_split(ix, sm, sp);
         for (int i_ = 0; i_ < 3; i_++) e->knn_split_ms[i_] += sm[i_];
-        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1];
+        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1]; e->knn_split_pairs[2] += sp[2];
       }
       hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, gt.as<int32_t>(), e->tm_tile.as<int32_t>());
       hipLaunchKernelGGL(k_lookup, dim3(gridn(e->q)), dim3(256), 0, e->stream, e->q_group.as<int32_t>(), e->q, ge.as<int32_t>(), e->tm_err.as<int32_t>());
@@ -1177,10 +1177,10 @@ static int step_reconstruct(tm_encoder *e) {
       knn_index_stats(ix, &ms, &kb, &pairs);
       e->knn_ms += ms; e->knn_pairs += pairs; e->knn_launches++; e->knn_kbytes = kb;
       {
-        double sm[3]; int64_t sp[2];
+        double sm[3]; int64_t sp[3];
         knn_index_kernel_split(ix, sm, sp);
         for (int i_ = 0; i_ < 3; i_++) e->knn_split_ms[i_] += sm[i_];
-        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1];
+        e->knn_split_pairs[0] += sp[0]; e->knn_split_pairs[1] += sp[1]; e->knn_split_pairs[2] += sp[2];
       }
     }
   }
@@ -2041,10 +2041,10 @@ int tm_get_kmeans_iters(tm_encoder *e, int *tile_iters, int64_t *tile_points, in
   return TM_OK;
 }
 
-int tm_get_knn_kernel_split(tm_encoder *e, double ms[3], int64_t pairs[2]) {
+int tm_get_knn_kernel_split(tm_encoder *e, double ms[3], int64_t pairs[3]) {
   TM_CHECK(e && ms && pairs, TM_E_INVAL, "null argument");
   for (int i = 0; i < 3; i++) ms[i] = e->knn_split_ms[i];
-  pairs[0] = e->knn_split_pairs[0]; pairs[1] = e->knn_split_pairs[1];
+  pairs[0] = e->knn_split_pairs[0]; pairs[1] = e->knn_split_pairs[1]; pairs[2] = e->knn_split_pairs[2];
   return TM_OK;
 }
 

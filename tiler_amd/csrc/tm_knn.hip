@@ -30,7 +30,6 @@
 #include "tm_common.h"
 #include "tm_internal.h"
 #include "tm_knn_kernel.h"
-#include "tm_knn2_kernel.h"
 #define TM_KNN3_WITH_LISTS
 #include "tm_knn3_kernel.h"
 
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
                                                   const int16_t *__restrict__ centre, const int16_t *__restrict__ perm,
                                                   const uint32_t *__restrict__ rowperm, int with_box, CurveSpec cs,
                                                   int *__restrict__ box_lo, int *__restrict__ box_hi, uint8_t *__restrict__ out,
-                                                  int *__restrict__ err_flag, int *__restrict__ qmeta /* query side of the second scan shape: [ntiles][16] */,
+                                                  int *__restrict__ err_flag, int *__restrict__ qmeta /* query side: [ntiles][16] box, home tile, high-chunk mask */,
                                                   uint8_t *__restrict__ hmask /* database side: [ntiles] which high-digit chunks of the tile hold a non-zero digit */) {
   __shared__ int16_t s_c[192], s_p[192];
   __shared__ __attribute__((aligned(16))) int s_v[32][196];  // (pitch 196: a row's 16-value groups are 16-byte aligned, and sixteen rows' groups cover the 64 banks once)
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
     __syncthreads();
     // centred, permuted values of the 32 rows
     if (qmeta && threadIdx.x >= 192 && threadIdx.x < 224) {
-      // the sub-tile's bounding box over the box columns, as the first scan shape computes it in its prologue: the rows are in LDS here (a
+      // the sub-tile's bounding box over the box columns, as the first scan shape computed it in its prologue: the rows are in LDS here (a
       // kernel of its own gathered six scattered columns of every row again, 0.33 ms for 3.2 M rows), and these lanes have nothing else to do
       const int r = threadIdx.x - 192;
       int lo[KNN_NC], hi[KNN_NC];
@@ -569,20 +568,16 @@ static bool plan_covers(const KnnPlan &plan, const ColStats &st, int hch, int sc
   return true;
 }
 
-// The database digits doubled whenever the doubled values still fit two digits and cost no more products than the plain plan
-// (TM_KNN_TSCALE=1 keeps the plain plan for A/B runs): the scan's block epilogue is 16 vector instructions shorter with them.
+// The database digits doubled whenever the doubled values still fit two digits and cost no more products than the plain plan: the
+// scan's block epilogue is 16 vector instructions shorter with them.
 static int make_plan(const ColStats &ts, const ColStats &qs, KnnPlan *plan) {
-  const char *e = getenv("TM_KNN_TSCALE");
-  if (!(e && atoi(e) == 1)) {
-    KnnPlan p2, p1;
-    make_plan_scaled(ts, qs, &p2, 2);
-    make_plan_scaled(ts, qs, &p1, 1);
-    auto cost = [](const KnnPlan &p) { return p.ht + p.hq + std::min(p.ht, p.hq); };
-    if (plan_covers(p2, ts, p2.ht, 2) && plan_covers(p2, qs, p2.hq) && (cost(p2) <= cost(p1) || (e && atoi(e) == 2))) { *plan = p2; return TM_OK; }
-    *plan = p1;
-    return TM_OK;
-  }
-  return make_plan_scaled(ts, qs, plan, 1);
+  KnnPlan p2, p1;
+  make_plan_scaled(ts, qs, &p2, 2);
+  make_plan_scaled(ts, qs, &p1, 1);
+  auto cost = [](const KnnPlan &p) { return p.ht + p.hq + std::min(p.ht, p.hq); };
+  if (plan_covers(p2, ts, p2.ht, 2) && plan_covers(p2, qs, p2.hq) && cost(p2) <= cost(p1)) { *plan = p2; return TM_OK; }
+  *plan = p1;
+  return TM_OK;
 }
 
 struct tm_knn_index_impl {
@@ -598,7 +593,7 @@ struct tm_knn_index_impl {
   CurveSpec curve;
   DevBuf tie_list, counters;                        // counters: [0] tie count (u32), [2..3] visited (u64)
   DevBuf tccol, qccol;                              // the rows' three curve columns (k_row_radial -> k_curve_keys)
-  DevBuf qmeta;                                     // per query sub-tile: box + home tile (second scan shape)
+  DevBuf qmeta;                                     // per query sub-tile: box, home tile, high-chunk mask
   // third scan shape: what the seed kernel leaves for the other two (bests, tie values, bounds) and the groups' tile lists
   DevBuf gbest, gtie, gsmax, segs, nsegs, arena_tile, arena_lb;
   DevBuf thmask;                                    // per database tile: which of its high-digit chunks are not all zero
@@ -609,7 +604,7 @@ struct tm_knn_index_impl {
   int64_t last_visited = 0, last_ties = 0;
   double last_ms = 0;
   int last_kbytes = 0;
-  int64_t last_pairs = 0, last_seed_pairs = 0;
+  int64_t last_pairs = 0, last_seed_pairs = 0, last_mfma = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~tm_knn_index_impl() {
     if (ev0) (void)hipEventDestroy(ev0);
@@ -856,18 +851,6 @@ __global__ void k_topk_fill(int32_t *__restrict__ out_idx, uint32_t *__restrict_
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { out_idx[i] = -1; out_err[i] = 0xffffffffu; }
 }
 
-static void launch_mfma(int ht, int hq, const KnnLaunch &a) {
-  switch (ht) {
-    case 0: knn_launch_ht<0>(hq, a); break;
-    case 1: knn_launch_ht<1>(hq, a); break;
-    case 2: knn_launch_ht<2>(hq, a); break;
-    case 3: knn_launch_ht<3>(hq, a); break;
-    case 4: knn_launch_ht<4>(hq, a); break;
-    case 5: knn_launch_ht<5>(hq, a); break;
-    default: knn_launch_ht<6>(hq, a); break;
-  }
-}
-
 // per query sub-tile: the database tile its first query falls into on the curve (the sub-tile's box is written by k_knn_pack)
 __global__ __launch_bounds__(256) void k_knn_qmeta(const uint32_t *__restrict__ qkey, int64_t n_qtiles, KnnBoxes bx, int64_t n_ttiles, int *__restrict__ qmeta) {
   for (int64_t st = (int64_t)blockIdx.x * 256 + threadIdx.x; st < n_qtiles; st += (int64_t)gridDim.x * 256) {
@@ -875,18 +858,6 @@ __global__ __launch_bounds__(256) void k_knn_qmeta(const uint32_t *__restrict__ 
     int64_t lo = 0, hi = n_ttiles;
     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (bx.tkey[mid] <= k0) lo = mid + 1; else hi = mid; }
     qmeta[st * 16 + 7] = (int)max((int64_t)0, lo - 1);
-  }
-}
-
-static void launch_scan2(int ht, int hq, const Knn2Args &a, hipStream_t stream) {
-  switch (ht) {
-    case 0: knn2_launch_ht<0>(hq, a, stream); break;
-    case 1: knn2_launch_ht<1>(hq, a, stream); break;
-    case 2: knn2_launch_ht<2>(hq, a, stream); break;
-    case 3: knn2_launch_ht<3>(hq, a, stream); break;
-    case 4: knn2_launch_ht<4>(hq, a, stream); break;
-    case 5: knn2_launch_ht<5>(hq, a, stream); break;
-    default: knn2_launch_ht<6>(hq, a, stream); break;
   }
 }
 
@@ -1015,7 +986,7 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
     TM_TRY(make_plan(ix->tstats, qs, &ix->plan));
     TM_CHECK(plan_covers(ix->plan, ix->tstats, ix->plan.ht, ix->plan.tscale) && plan_covers(ix->plan, qs, ix->plan.hq), TM_E_UNSUPPORTED,
              "knn: feature range exceeds the exact two-digit int8 split");
-    if (getenv("TM_KNN_DEBUG"))
+    if (knobs().knn_debug)
       fprintf(stderr, "[tm_knn] nq=%lld nt=%lld big columns: database %d (digits x%d), queries %d -> HT=%d HQ=%d K=%d bytes\n", (long long)nq,
               (long long)ix->nt, ix->plan.nbig_t, ix->plan.tscale, ix->plan.nbig_q, ix->plan.ht, ix->plan.hq,
               192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq)));
@@ -1053,32 +1024,19 @@ static int prepare_search(tm_knn_index_impl *ix, const void *queries, int64_t nq
       CurveSpec &cs = ix->curve;
       // Measured on the bench clip (column ranges 20262 / 13399 / 13118, R in 2566..5284): every dimension over its own range with
       // 8, 7, 7, 8 bits and log2 R -- R cells of 0.3 % -- evaluates 15.3 G pairs (scan 18.4 ms); 8, 8, 8, 8: 14.7 G but 20.0 ms;
-      // isotropic cells (TM_KNN_CURVE=iso: 9, 8, 8, 6 bits, linear R): 18.6 G, 21.4 ms; columns only (10, 10, 10): 28.9 G, 30.2 ms.
+      // isotropic cells (9, 8, 8, 6 bits, linear R): 18.6 G, 21.4 ms; columns only (10, 10, 10): 28.9 G, 30.2 ms.
       // The k-nearest scans use the same curve (measured after their kernel stopped spilling: first collection pass of the
       // extended-palette run 112 ms on this curve, 146 ms on 10, 10, 10 bits of the columns alone).
-      const char *mode = getenv("TM_KNN_CURVE");
-      if (!(mode && !strcmp(mode, "iso"))) {
+      {
         const int nb[4] = {8, 7, 7, 8};
         cs.rlog = 1;
         for (int d = 0; d < 3; d++) { cs.bits[d] = nb[d]; cs.off[d] = (float)cs.lo[d]; cs.scale[d] = (float)((1 << nb[d]) - 1) / (float)cs.range[d]; }
         cs.bits[3] = nb[3]; cs.off[3] = log2f(rlo + 1.0f);
         cs.scale[3] = ((float)(1 << nb[3]) - 0.001f) / std::max(1e-6f, log2f(rhi + 1.0f) - log2f(rlo + 1.0f));
-      } else {
-        // isotropic cells: one cell width w for the three columns and the radial coordinate, the smallest power of two at which the
-        // four bit counts fit the 32-bit key
-        cs.rlog = 0;
-        const float ext[4] = {(float)cs.range[0], (float)cs.range[1], (float)cs.range[2], rhi - rlo};
-        float w = 1.0f / 64;
-        for (;; w *= 2) {
-          int total = 0;
-          for (int d = 0; d < 4; d++) { cs.bits[d] = std::max(1, std::min(16, (int)std::ceil(std::log2(ext[d] / w + 1.0f)))); total += cs.bits[d]; }
-          if (total <= 32) break;
-        }
-        for (int d = 0; d < 4; d++) { cs.off[d] = d < 3 ? (float)cs.lo[d] : rlo; cs.scale[d] = 1.0f / w; }
       }
-      if (getenv("TM_KNN_DEBUG"))
+      if (knobs().knn_debug)
         fprintf(stderr, "[tm_knn] curve: column ranges %d %d %d, radial %.1f..%.1f -> bits %d %d %d %d (%s)\n", cs.range[0], cs.range[1], cs.range[2], rlo, rhi,
-                cs.bits[0], cs.bits[1], cs.bits[2], cs.bits[3], cs.rlog ? "own ranges, log radial" : "isotropic cells");
+                cs.bits[0], cs.bits[1], cs.bits[2], cs.bits[3], "own ranges, log radial");
       fresh_radial = true;
     }
     TM_TRY(sort_by_curve(ix, ix->tccol, ix->nt, ix->tradial, ix->tperm, ix->skey2, stream));
@@ -1119,10 +1077,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_TRY(ix->best_tile.alloc((size_t)nqt * 32 * 4));
   TM_TRY(ix->tie_list.alloc((size_t)nq * 4));
   TM_TRY(ix->counters.alloc(256 + 2048));  // [4..15]: phase stamps of a diagnostic build; bytes 128..159: the group tickets; bytes 256..: the seed kernel's striped counters
-  const int prune = getenv("TM_KNN_NOPRUNE") ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
-  // the scan's shape: 3 = seeds / lists / consume (tm_knn3_kernel.h); 2 = round 2-3's single kernel, 1 = round 1's, both kept for A/B runs
-  const int shape = getenv("TM_KNN_V1") ? 1 : getenv("TM_KNN_V2") ? 2 : 3;
-  const bool v1 = shape == 1;
+  const int prune = knobs().knn_noprune ? 0 : 1;  // diagnostic: full scan with the same kernel (bench.py roofline_dense)
   int *bt = ix->best_tile.as<int>();
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
@@ -1132,36 +1087,15 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
   unsigned long long *stats = reinterpret_cast<unsigned long long *>(ix->counters.as<uint8_t>() + 16);
-  if (!v1) {
-    hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 255) / 256, 4096)), dim3(256), 0, stream, ix->qkey.as<uint32_t>(), nqt, bx, ntt,
-                       ix->qmeta.as<int>());
-    TM_HIP(hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_knn_qmeta, dim3((unsigned)std::min<int64_t>((nqt + 255) / 256, 4096)), dim3(256), 0, stream, ix->qkey.as<uint32_t>(), nqt, bx, ntt,
+                     ix->qmeta.as<int>());
+  TM_HIP(hipGetLastError());
   int flag = 0;
   unsigned long long cnt[32 + 256] = {0};
   for (int attempt = 0;; attempt++) {
   TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256 + 2048, stream));
   TM_HIP(hipEventRecord(ix->ev0, stream));
-  if (shape == 3) {
-    TM_TRY(launch_scan3(ix, nq, nqt, ntt, prune, bx, stats, stream));
-  } else if (shape == 2) {
-    const int ns = knn2_sub_tiles(ix->plan.hq);
-    Knn2Args a;
-    a.tpack = ix->tpack.as<uint8_t>(); a.n_ttiles = ntt; a.nt_rows = ix->nt;
-    a.box_lo = bx.lo; a.box_hi = bx.hi; a.grp_lo = bx.glo; a.grp_hi = bx.ghi;
-    a.qpack = ix->qpack.as<uint8_t>(); a.n_qtiles = nqt; a.nq = nq; a.qmeta = ix->qmeta.as<int>();
-    a.prune = prune; a.tdouble = ix->plan.tscale == 2; a.best_key = ix->best_key.as<int>(); a.best_tile = bt; a.stats = stats;
-    a.n_groups = (nqt + ns - 1) / ns;
-    a.grid_blocks = (int)std::min<int64_t>(a.n_groups, (int64_t)device_cus() * K2_WGS);
-    a.tickets = reinterpret_cast<unsigned *>(ix->counters.as<uint8_t>() + 128);
-    launch_scan2(ix->plan.ht, ix->plan.hq, a, stream);
-  } else
-  {
-    KnnLaunch l{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, (const int16_t *)queries, ix->qperm.as<uint32_t>(),
-                ix->qkey.as<uint32_t>(), nq, prune, ix->best_key.as<int>(), bt, stats, stream};
-    l.tshift = ix->plan.tscale == 2 ? 0 : 1;
-    launch_mfma(ix->plan.ht, ix->plan.hq, l);
-  }
+  TM_TRY(launch_scan3(ix, nq, nqt, ntt, prune, bx, stats, stream));
   TM_HIP(hipGetLastError());
   TM_HIP(hipEventRecord(ix->ev1, stream));
   {
@@ -1182,16 +1116,16 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   }
   cnt[12] = cnt[13] = cnt[14] = 0;  // the seed kernel's blocks, tiles read, pairs: summed over its 64 striped slots
   for (int i = 0; i < 64; i++) { cnt[12] += cnt[32 + i * 4]; cnt[13] += cnt[32 + i * 4 + 1]; cnt[14] += cnt[32 + i * 4 + 2]; }
-  if (shape == 3 && prune) {  // remember what the lists needed (never below the starting guess: a small search says little about the next)
+  if (prune) {  // remember what the lists needed (never below the starting guess: a small search says little about the next)
     const int ns_ = knn3_sub_tiles(ix->plan.hq);
     const double per = 1.3 * (double)cnt[20] / (double)std::max<int64_t>(1, (nqt + ns_ - 1) / ns_);
     double cur = g_list_entries_per_group.load();
     while (per > cur && !g_list_entries_per_group.compare_exchange_weak(cur, per)) {}
   }
-  TM_CHECK(!(shape == 3 && cnt[29] != 0), TM_E_HIP, "knn: the scan met a corrupted tile list (guard word %llx)", cnt[29]);
-  if (shape == 3 && prune && cnt[20] > ix->arena_cap) {  // the tile lists did not fit the arena: the cursor says what they need
+  TM_CHECK(cnt[29] == 0, TM_E_HIP, "knn: the scan met a corrupted tile list (guard word %llx)", cnt[29]);
+  if (prune && cnt[20] > ix->arena_cap) {  // the tile lists did not fit the arena: the cursor says what they need
     TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
-    if (getenv("TM_KNN_DEBUG")) fprintf(stderr, "[tm_knn] list arena: %llu entries needed, %llu held -- searching again\n", cnt[20], (unsigned long long)ix->arena_cap);
+    if (knobs().knn_debug) fprintf(stderr, "[tm_knn] list arena: %llu entries needed, %llu held -- searching again\n", cnt[20], (unsigned long long)ix->arena_cap);
     ix->arena_want = cnt[20] + cnt[20] / 4;
     continue;
   }
@@ -1201,62 +1135,38 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   float ms = 0;
   TM_HIP(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
   ix->last_ms = ms;
-  if (shape == 3) {  // the three kernels on their own (ev0 | seeds | ev_seed | lists | ev_lists | consume | ev1)
+  {  // the three kernels on their own (ev0 | seeds | ev_seed | lists | ev_lists | consume | ev1)
     float a_ = 0, b_ = 0, c_ = 0;
     TM_HIP(hipEventElapsedTime(&a_, ix->ev0, ix->ev_seed));
     TM_HIP(hipEventElapsedTime(&b_, ix->ev_seed, ix->ev_lists));
     TM_HIP(hipEventElapsedTime(&c_, ix->ev_lists, ix->ev1));
     ix->last_seed_ms = a_; ix->last_lists_ms = b_; ix->last_consume_ms = c_;
-  } else {
-    ix->last_seed_ms = ix->last_lists_ms = 0; ix->last_consume_ms = ms;
   }
   ix->last_kbytes = 192 + 32 * (ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
   ix->last_visited = (int64_t)cnt[2];
   ix->last_ties = (int64_t)(cnt[0] & 0xffffffffull);
-  // pairs actually evaluated: exact (real query, real row) pairs from the second scan shape; the first counts whole 32 x 32 blocks
-  ix->last_pairs = v1 ? ix->last_visited * 1024 : (int64_t)(cnt[4] + cnt[14]);  // (cnt[12..14]: the third shape's seed kernel)
+  // pairs actually evaluated: exact (real query, real row) pairs; cnt[12..14]: the seed kernel's blocks, tiles, pairs
+  ix->last_pairs = (int64_t)(cnt[4] + cnt[14]);
   ix->last_seed_pairs = (int64_t)cnt[14];
-  ix->last_blocks = (int64_t)(cnt[2] + cnt[12]); ix->last_loads = (int64_t)(cnt[3] + cnt[13]); ix->last_listed = v1 ? 0 : (int64_t)cnt[5];
-  if (getenv("TM_KNN_DEBUG")) {
-    const int nsg = shape == 3 ? knn3_sub_tiles(ix->plan.hq) : knn2_sub_tiles(ix->plan.hq);
-    const int64_t groups = v1 ? (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW) : (nqt + nsg - 1) / nsg;
-    if (shape == 3) fprintf(stderr, "[tm_knn] v3: seeds %.3f ms, lists %.3f ms (%.1f entries per group, arena %.0f %% full), consume %.3f ms, %.2f of %d matrix instructions per block\n", ix->last_seed_ms, ix->last_lists_ms,
-                            (double)cnt[20] / (double)groups, 100.0 * (double)cnt[20] / (double)std::max<uint64_t>(1, ix->arena_cap), ix->last_consume_ms,
-                            (double)cnt[21] / (double)std::max<unsigned long long>(1, cnt[2]), 6 + ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
-    fprintf(stderr, "[tm_knn] %s kernel %.3f ms, evaluated %.3f%% of %lld x %lld pairs (%lld blocks; workgroups read %.3f%% of tiles, %.1f per group; %.1f list entries per group), %lld tie settlements\n",
-            v1 ? "v1" : shape == 2 ? "v2" : "v3", ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)ix->last_blocks,
+  ix->last_mfma = (int64_t)cnt[21];
+  ix->last_blocks = (int64_t)(cnt[2] + cnt[12]); ix->last_loads = (int64_t)(cnt[3] + cnt[13]); ix->last_listed = (int64_t)cnt[5];
+  if (knobs().knn_debug) {
+    const int nsg = knn3_sub_tiles(ix->plan.hq);
+    const int64_t groups = (nqt + nsg - 1) / nsg;
+    fprintf(stderr, "[tm_knn] seeds %.3f ms, lists %.3f ms (%.1f entries per group, arena %.0f %% full), consume %.3f ms, %.2f of %d matrix instructions per block\n", ix->last_seed_ms, ix->last_lists_ms,
+            (double)cnt[20] / (double)groups, 100.0 * (double)cnt[20] / (double)std::max<uint64_t>(1, ix->arena_cap), ix->last_consume_ms,
+            (double)cnt[21] / (double)std::max<unsigned long long>(1, cnt[2]), 6 + ix->plan.ht + ix->plan.hq + std::min(ix->plan.ht, ix->plan.hq));
+    fprintf(stderr, "[tm_knn] scan %.3f ms, evaluated %.3f%% of %lld x %lld pairs (%lld blocks; workgroups read %.3f%% of tiles, %.1f per group; %.1f list entries per group), %lld tie settlements\n",
+            ms, 100.0 * (double)ix->last_pairs / ((double)nq * (double)ix->nt), (long long)nq, (long long)ix->nt, (long long)ix->last_blocks,
             100.0 * (double)ix->last_loads / ((double)groups * (double)ntt), (double)ix->last_loads / (double)groups, (double)ix->last_listed / (double)groups, (long long)ix->last_ties);
   }
 #if TM_KNN3_STAMPS
-  if (shape == 3) {
+  {
     static const char *names3[6] = {"prologue", "segment load", "consume", "end-of-segment wait", "results", "total"};
     for (int i = 0; i < 6; i++) fprintf(stderr, "[tm_knn3 stamps] %-24s %6.2f %% of the consume kernel's wave time\n", names3[i], 100.0 * (double)cnt[6 + i] / (double)cnt[11]);
     static const char *names_s[7] = {"set-up", "wait: first slice + tile", "wait: later slices", "blocks", "end barrier", "results", "total"};
     for (int i = 0; i < 7; i++) fprintf(stderr, "[tm_knn3 stamps] seeds: %-24s %6.2f %% of wave time (%.0f clock ticks per wave)\n", names_s[i], 100.0 * (double)cnt[22 + i] / (double)cnt[28],
                                         (double)cnt[22 + i] / (8.0 * (double)((nqt + knn3_sub_tiles(ix->plan.hq) - 1) / knn3_sub_tiles(ix->plan.hq))));
-  }
-#endif
-#if TM_KNN2_STAMPS
-  if (shape == 2) {
-    static const char *names2[10] = {"prologue", "list building", "consume seeds", "consume lists", "end-of-list wait (seeds)", "end-of-list wait (lists)",
-                                     "  of consume: pop next", "  of consume: pop + tile landed", "results", "total"};
-    for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn2 stamps] %-32s %6.2f %% of wave time\n", names2[i], 100.0 * (double)cnt[6 + i] / (double)cnt[15]);
-    {  // inside the consume loop (cnt[20..27] = stats[18..25])
-      const double blocks = (double)std::max<unsigned long long>(1, cnt[2]), steps = (double)std::max<unsigned long long>(1, cnt[25] + cnt[26]);
-      fprintf(stderr, "[tm_knn2 stamps] per block: wave time %.0f cycles; per step (%llu single, %llu pairs): top %.0f, chain %.0f, epilogue %.0f cycles; "
-                      "update branch in %.1f %% of blocks, refresh in %.2f %%; tile load issue %.0f cycles per tile\n",
-              (double)cnt[15] / blocks, cnt[25], cnt[26], (double)cnt[20] / steps, (double)cnt[21] / steps, (double)cnt[22] / steps,
-              100.0 * (double)cnt[23] / blocks, 100.0 * (double)cnt[24] / blocks, (double)cnt[27] / (double)std::max<unsigned long long>(1, cnt[3]));
-    }
-  }
-#endif
-#if TM_KNN_STAMPS
-  {
-    static const char *names[10] = {"prologue", "wait data", "barrier", "issue", "box re-test", "MFMA + epilogue", "best refresh", "total", "next tile", "(list builds)"};
-    for (int i = 0; i < 10; i++) fprintf(stderr, "[tm_knn stamps] %-18s %8.1f cycles per staged tile per wave (%5.1f %%)\n", names[i],
-                                        (double)cnt[4 + i] / ((double)cnt[3] * KNN_NW), 100.0 * (double)cnt[4 + i] / (double)cnt[11]);
-    fprintf(stderr, "[tm_knn stamps] per staged tile and wave: %.3f sub-tiles listed, %.3f evaluated, wave idle on %.1f %% of staged tiles\n",
-            (double)cnt[14] / ((double)cnt[3] * KNN_NW), (double)cnt[2] / ((double)cnt[3] * KNN_NW), 100.0 * (double)cnt[15] / ((double)cnt[3] * KNN_NW));
   }
 #endif
   return TM_OK;
@@ -1316,7 +1226,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     hipLaunchKernelGGL(k_sorted_row_norms, dim3(gridn_k(ix->nt)), dim3(256), 0, stream, ix->db, ix->tperm.as<uint32_t>(), ix->nt, tnorm.as<uint32_t>());
     hipLaunchKernelGGL(k_topk_tau, dim3((unsigned)(n_pad / 64)), dim3(64), (size_t)k * 64 * 4, stream, (const uint32_t *)feats, ix->qperm.as<uint32_t>(),
                        ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), tnorm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
-                       getenv("TM_TOPK_WINDOW") ? atoi(getenv("TM_TOPK_WINDOW")) : TOPK_WINDOW_DEFAULT, tau.as<int>());
+                       TOPK_WINDOW_DEFAULT, tau.as<int>());
   }
   hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, rowmap, tau.as<int>(),
                      map_sorted.as<uint32_t>());
@@ -1327,17 +1237,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   bx.ghi = ix->grp_hi.as<int>();
   bx.tkey = ix->tkey.as<uint32_t>();
   for (int d = 0; d < KNN_NC; d++) { bx.col[d] = ix->curve.col[d]; bx.cen[d] = ix->plan.centre[ix->curve.col[d]]; }
-  if (getenv("TM_KNN_V1")) {  // the first scan shape's collection kernel, kept for A/B runs
-  KnnLaunch a{ix->tpack.as<uint8_t>(), ntt, bx, ix->qpack.as<uint8_t>(), nqt, feats, ix->qperm.as<uint32_t>(), ix->qkey.as<uint32_t>(), n, 1,
-              nullptr, nullptr, nullptr, stream};
-  a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
-  a.tshift = ix->plan.tscale == 2 ? 0 : 1;
-  {  // few queries left: their few workgroups would each stage most of the database one after the other -- share the tile list
-    const int64_t wgs = (nqt + KNN_NQ * KNN_NW - 1) / (KNN_NQ * KNN_NW);
-    a.split = wgs >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(wgs, 1)));
-  }
-  launch_mfma(ix->plan.ht, ix->plan.hq, a);
-  } else {
+  {
     // The third scan shape in collection mode (tm_knn3_kernel.h): bounds from the thresholds, tile lists judged against them (no seeds:
     // every tile goes through the lists), then the consume kernel appending every row within its query's threshold.
     const int ns = knn3_sub_tiles_topk(ix->plan.hq), nsp = (ns + 1) & ~1;
@@ -1391,7 +1291,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
-                     getenv("TM_TOPK_NOFILTER") ? 1 : 0);
+                     0);
   TM_HIP(hipGetLastError());
   unsigned int novf = 0;
   int flag = 0;
@@ -1400,12 +1300,12 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     HostRead hr_(stream);
     TM_TRY(hr_.get(&novf, counter.p, 4));
     TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
-    if (!getenv("TM_KNN_V1")) TM_TRY(hr_.get(&guard, ix->counters.as<uint8_t>() + 16 + 27 * 8, 8));
+    TM_TRY(hr_.get(&guard, ix->counters.as<uint8_t>() + 16 + 27 * 8, 8));
     TM_TRY(hr_.wait());
   }
   TM_CHECK(guard == 0, TM_E_HIP, "knn: the collection scan met a corrupted tile list (guard word %llx)", guard);
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
-  if (getenv("TM_KNN_DEBUG"))
+  if (knobs().knn_debug)
     fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   if (novf == 0) return TM_OK;
@@ -1441,9 +1341,9 @@ int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq
   return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
 }
 
-void knn_index_kernel_split(tm_knn_index_impl *ix, double ms[3], int64_t pairs[2]) {
+void knn_index_kernel_split(tm_knn_index_impl *ix, double ms[3], int64_t pairs[3]) {
   ms[0] = ix->last_seed_ms; ms[1] = ix->last_lists_ms; ms[2] = ix->last_consume_ms;
-  pairs[0] = ix->last_seed_pairs; pairs[1] = ix->last_pairs - ix->last_seed_pairs;
+  pairs[0] = ix->last_seed_pairs; pairs[1] = ix->last_pairs - ix->last_seed_pairs; pairs[2] = ix->last_mfma;
 }
 
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs) {
@@ -1452,7 +1352,6 @@ void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pa
   if (pairs) *pairs = ix->last_pairs;
 }
 
-int knn2_sub_tiles(int hq) { return k2_ns(6 + std::min(std::max(hq, 0), 6)); }
 int knn3_sub_tiles(int hq) { return k3_ns(6 + std::min(std::max(hq, 0), 6)); }
 int knn3_sub_tiles_topk(int hq) { return k3_ns_topk(6 + std::min(std::max(hq, 0), 6)); }
 

@@ -370,8 +370,8 @@ class TilingEncoder:
                                        ctypes.byref(rows)))
         self._L.tm_get_knn_queries.restype = c_int64
         self._L.tm_get_knn_queries.argtypes = [c_void_p]
-        sm, sp = (c_double * 3)(), (c_int64 * 2)()
+        sm, sp = (c_double * 3)(), (c_int64 * 3)()
         check(self._L.tm_get_knn_kernel_split(c_void_p(self._h), sm, sp))
         return dict(kernel_ms=ms.value, pairs=pairs.value, launches=launches.value, k_bytes=kb.value, db_rows=rows.value,
                     queries=int(self._L.tm_get_knn_queries(c_void_p(self._h))),
-                    seed_ms=sm[0], lists_ms=sm[1], consume_ms=sm[2], seed_pairs=sp[0], consume_pairs=sp[1])
+                    seed_ms=sm[0], lists_ms=sm[1], consume_ms=sm[2], seed_pairs=sp[0], consume_pairs=sp[1], consume_mfma=sp[2])

@@ -8,9 +8,9 @@ tail -5 gpurun_out/knn_tests.log
 [ $rc -ne 0 ] && { grep -n "Error\|error\|assert" gpurun_out/knn_tests.log | tail -20; exit $rc; }
 ARGS="--steps ${AB_STEPS:-5} --warmup 1 --no-cpu-baseline --no-motion-extra --no-defaults-extra --no-dense-extra --no-h2d-extra --no-kmodes-extra ${AB_ARGS:-}"
 for rep in 1 2; do
-for v in v2 v3 "$@"; do
-  unset TM_KNN_V2 TM_LIB_VARIANT
-  if [ $v = v2 ]; then export TM_KNN_V2=1; elif [ $v != v3 ]; then export TM_LIB_VARIANT=$v; fi
+for v in v3 "$@"; do
+  unset TM_LIB_VARIANT
+  if [ $v != v3 ]; then export TM_LIB_VARIANT=$v; fi
   TM_KNN_DEBUG=1 timeout -k 10 400 python bench.py $ARGS > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
   python - $v <<'PY'
 import json, sys
@@ -20,6 +20,6 @@ print('%s fps=%.0f ms=%.2f knn_ms=%.3f frac=%.4f' % (v, j['value'], j['ms_per_st
 w = j.get('with_frozen_columns')
 if w: print('   frozen: fps=%.0f ms=%.2f' % (w['value'], w['ms_per_step']), w['knn_kernels_ms'], w['stage_ms'])
 PY
-  grep "tm_knn\] v\|stamps" gpurun_out/ab_$v.err | tail -${AB_TAIL:-4}
+  grep "tm_knn\] seeds\|tm_knn\] scan\|stamps" gpurun_out/ab_$v.err | tail -${AB_TAIL:-4}
 done
 done
