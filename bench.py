@@ -544,11 +544,11 @@ def main():
             d5 = time.perf_counter() - t1
             per_iter = (d5 - d1) / max(1, (pit5 - pit1) // nk)
             bk = 80.0 * nk
-            sr["kmodes"] = {"bound": "hbm", "kernel": "k_kmodes_argmin + k_kmodes_walk + k_kmodes_apply per bin of 960 points", "achieved": bk / per_iter / 1e9, "peak": HBM_PEAK_GBS,
+            sr["kmodes"] = {"bound": "hbm", "kernel": "k_kmodes_owner + k_kmodes_walker per bin of 960 points (one graph per iteration)", "achieved": bk / per_iter / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": bk / per_iter / 1e9 / HBM_PEAK_GBS, "ms_per_iteration": per_iter * 1e3, "rows": nk, "clusters": kk_,
                             "init_and_first_iteration_ms": d1 * 1e3, "algorithmic_bytes_per_iteration": bk,
                             "note": "tm_stage_kmodes_dev (TKModes.ComputeKModes, kmodes.pas:923-1094) on device pointers, 80 B per point and iteration; "
-                                    "every bin of 960 points is three dependent launches (score, moves in order, histogram update), which is what the time is"}
+                                    "every bin of 960 points is two dependent launches (owners: previous moves into the histograms + scores; walker: the moves in order), which is what the time is: bound \"hbm\" prices the bytes, the chain of 2 x 1 686 launches is the limit"}
             del rows_k
         sr["knn"] = {k: out["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_ms", "scan")}
         out["stage_rooflines"] = sr

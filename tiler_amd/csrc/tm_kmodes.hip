@@ -174,14 +174,194 @@ __global__ __launch_bounds__(64) void k_kmodes_init_modes(const uint8_t *__restr
   }
 }
 
-// ---- one bin of KModesIter (851-921), three launches.
-// (1) the bin's points against the modes as they stand NOW (the reference scores a bin at its start): k_kmodes_argmin over [b0, b1).
-// (2) k_kmodes_walk, one workgroup: the bin's cost, then its points in order -- a point whose score names another cluster moves (memberships
-//     and member counts at once; the histograms follow in (3)); a move that empties a cluster is followed by the repair of 879-897: a
-//     member of the LAST largest cluster, the RandInt-th in index order, moves into the empty one (found by all threads together: each
-//     counts its stretch of the memberships).  The moves go on a list in the order they happen.
-constexpr int KM_BIN = 960, KM_WT = 1024;
-__global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, int64_t b1, int k, KmState st) {
+// ---- KModesIter (851-921), two launches per bin.
+// The reference walks bins of 960 points: a bin is scored against the modes as they stand at its start, then its points move one after
+// the other, every move updating two clusters' histograms and modes (MovePointCat, 774-803).  Rounds 2-3 ran that as three dependent
+// launches per bin (score, walk, apply: 56 ms per iteration at config 5's 1.6 M rows, all of it launch turnaround; 760 ms for the first
+// iteration, in whose bins nearly every point moves).  Now (25.7 ms per iteration over iterations 2-5, 115 ms for init + the first):
+//   * k_kmodes_owner, G workgroups: owner w holds the clusters c = w (mod G) -- nobody else touches their histograms and modes.  It
+//     applies the PREVIOUS bin's moves that enter or leave its clusters (in order: Huang's online update), then scores THIS bin's points
+//     against its own modes only and leaves, per point, its own best (distance, cluster) as one key;
+//   * k_kmodes_walker, one workgroup: the minimum over the owners' keys of every point of the bin (the LAST minimum wins, kmodes.pas:272) --
+//     the reference's score of the bin at its start, since every owner applied every earlier move before it scored --, then the bin's
+//     points in order (a point whose score names another cluster moves; a move that empties a cluster is followed by the repair of
+//     879-897), the bin's move list for the next owner launch.
+// (Built and measured first as ONE resident launch per iteration, owners and walker meeting through flags in memory: the same work, 70 ms --
+// on eight XCDs with an L2 each every hand-over between workgroups is an agent-scope release / acquire and several microseconds, and a
+// bin has four of them in a row; two kernel boundaries cost less.  The iteration's 2 x bins + 1 launches are a graph, replayed.)
+// MovePointCat's histogram side for one (cluster, attribute) pair: the wave holds the pair's row of counters (four per lane) and its mode and
+// applies, in order, the moves flagged in `m` (lane = move: `cur_l` its point's value of the attribute, `in` = it enters the cluster) -- the
+// counter of the value up and the mode following it when it is overtaken; the counter down and, when the mode itself lost a member, the
+// first largest counter as the new mode (kmodes.pas:774-803).
+__device__ __forceinline__ void km_apply_moves(int (&t)[4], int &mode, unsigned long long m, int cur_l, bool in, int nmod, int lane) {
+  while (m) {
+    const int bit = __builtin_ctzll(m);
+    m &= m - 1;
+    const int cur = __builtin_amdgcn_readlane(cur_l, bit);
+    const bool enters = __builtin_amdgcn_readlane((int)in, bit) != 0;
+    const int own = cur & 63, sl = cur >> 6;
+    const int d = enters ? 1 : -1;
+    if (lane == own) { t[0] += sl == 0 ? d : 0; t[1] += sl == 1 ? d : 0; t[2] += sl == 2 ? d : 0; t[3] += sl == 3 ? d : 0; }
+    if (enters) {
+      const int msl = mode >> 6;
+      const int vm = __builtin_amdgcn_readlane(msl == 0 ? t[0] : msl == 1 ? t[1] : msl == 2 ? t[2] : t[3], mode & 63);
+      const int vc = __builtin_amdgcn_readlane(sl == 0 ? t[0] : sl == 1 ? t[1] : sl == 2 ? t[2] : t[3], own);
+      if (vm < vc) mode = cur;
+    } else if (mode == cur) {
+      mode = km_first_largest(t, nmod, lane);
+    }
+  }
+}
+
+#ifndef TM_KM_OWNERS
+#define TM_KM_OWNERS 64
+#endif
+constexpr int KM_BIN = 960, KM_WT = 1024, KM_MAX_OWNERS = TM_KM_OWNERS, KM_STAGE = 768;
+
+// bin < 0: only the moves of the last bin are applied (the iteration's closing launch); first = 1: there are no moves to apply yet
+__global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, int G, int64_t bin, int first, KmState st,
+                                                        unsigned *__restrict__ partial /* [G][KM_BIN] keys: distance << 12 | 4095 - cluster */) {
+  extern __shared__ int s_dyn[];  // the owned clusters' modes as words [owned][20], their touched flags, the previous bin's relevant moves, those moves' rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+  const int nown = (k - w + G - 1) / G;  // clusters w, w + G, w + 2 G, ...
+  const int max_own = (k + G - 1) / G;
+  uint32_t *const s_mode = reinterpret_cast<uint32_t *>(s_dyn);                 // [nown][20]
+  int *const s_touch = s_dyn + max_own * KM_WORDS;                              // [nown]: a move of the previous bin enters or leaves the cluster
+  int3 *const s_rel = reinterpret_cast<int3 *>(s_touch + max_own);              // those moves, in order
+  uint4 *const s_rows = reinterpret_cast<uint4 *>(s_dyn + ((max_own * (KM_WORDS + 1) + 3 * (2 * KM_BIN + 8) + 3) & ~3));  // [KM_STAGE][5]: their points
+  __shared__ unsigned s_nrel;
+  __shared__ int s_hist[KM_WT / 64][256];
+  for (int e = tid; e < KM_WT / 64 * 256; e += KM_WT) (&s_hist[0][0])[e] = 0;
+  for (int e = tid; e < nown * KM_WORDS; e += KM_WT) s_mode[e] = reinterpret_cast<const uint32_t *>(st.cent)[(size_t)(w + (e / KM_WORDS) * G) * KM_WORDS + e % KM_WORDS];
+  for (int e = tid; e < nown; e += KM_WT) s_touch[e] = 0;
+  if (tid == 0) s_nrel = 0;
+  __syncthreads();
+  const unsigned nmv = first ? 0u : *st.nmoves;
+  if (nmv > 0) {
+    // ---- MovePointCat's histogram side (774-803) for the owned clusters, a wave per (cluster, attribute) pair
+    if (wave == 0) {  // ordered compaction of the relevant moves
+      unsigned nrel = 0;
+      for (unsigned e0 = 0; e0 < nmv; e0 += 64) {
+        const unsigned e = e0 + lane;
+        int3 mv = make_int3(0, -1, -1);
+        if (e < nmv) mv = st.mlist[e];
+        const bool rin = mv.y >= 0 && mv.y % G == w, rout = mv.z >= 0 && mv.z % G == w;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(rin || rout);
+        if (rin || rout) s_rel[nrel + __popcll(m & ((1ull << lane) - 1ull))] = mv;
+        if (rin) s_touch[mv.y / G] = 1;
+        if (rout) s_touch[mv.z / G] = 1;
+        nrel += __popcll(m);
+      }
+      if (lane == 0) s_nrel = nrel;
+    }
+    __syncthreads();
+    const unsigned nrel = s_nrel;
+    // The moved points' rows come into LDS first, KM_STAGE moves at a time (in a bin of the first iteration nearly every point moves: a
+    // (pair, 64 moves) step that fetched its values from memory itself waited a round trip each, 240 microseconds per bin)
+    for (unsigned r0 = 0; r0 < nrel; r0 += KM_STAGE) {
+      const unsigned nr = min((unsigned)KM_STAGE, nrel - r0);
+      if (r0) __syncthreads();
+      for (unsigned e = tid; e < nr * 5; e += KM_WT) s_rows[e] = reinterpret_cast<const uint4 *>(rows)[(int64_t)s_rel[r0 + e / 5].x * 5 + e % 5];
+      __syncthreads();
+      // a wave's pairs in batches of KM_PB: the batch's histogram rows are all asked for before any is used
+      constexpr int KM_PB = 5;
+      for (int pr0 = wave; pr0 < nown * KM_ATTRS; pr0 += KM_PB * (KM_WT / 64)) {
+        int t[KM_PB][4];
+        bool act[KM_PB];
+#pragma unroll
+        for (int i = 0; i < KM_PB; i++) {
+          const int pr = pr0 + i * (KM_WT / 64);
+          act[i] = pr < nown * KM_ATTRS && s_touch[pr / KM_ATTRS] != 0;
+          if (act[i]) {
+            const int64_t gp = (int64_t)(w + (pr / KM_ATTRS) * G) * KM_ATTRS + pr % KM_ATTRS;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) t[i][sl] = lane + 64 * sl < nmod ? st.freq[gp * nmod + lane + 64 * sl] : 0;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < KM_PB; i++) {
+          if (!act[i]) continue;
+          const int pr = pr0 + i * (KM_WT / 64);
+          const int oc = pr / KM_ATTRS, a = pr - oc * KM_ATTRS, c = w + oc * G;
+          const int64_t gp = (int64_t)c * KM_ATTRS + a;
+          int mode = (int)reinterpret_cast<const uint8_t *>(s_mode + oc * KM_WORDS)[a];
+          // The counters first, all the pair's moves at once (LDS atomics on the wave's own row of 256).  Huang's mode is at every moment A
+          // largest counter -- an arrival takes the mode over only by strictly passing it, a departure of the mode's value re-reads the
+          // first largest -- so when the counters after the last move have ONE largest, that is the mode whatever the order was.  Only a
+          // tie at the end needs the moves replayed in order (a hot cluster takes nearly all 960 moves of a first-iteration bin: replayed
+          // one by one for each of its 80 attributes that was 240 microseconds per bin).
+          int *const h = &s_hist[wave][0];
+          bool any = false;
+          for (unsigned e0 = 0; e0 < nr; e0 += 64) {
+            const unsigned e = e0 + lane;
+            int3 mv = make_int3(0, -1, -1);
+            if (e < nr) mv = s_rel[r0 + e];
+            const bool in = mv.y == c, out = mv.z == c;
+            if (in || out) atomicAdd(&h[reinterpret_cast<const uint8_t *>(s_rows)[e * KM_ATTRS + a]], in ? 1 : -1);
+            any = any || __builtin_amdgcn_ballot_w64(in || out) != 0;
+          }
+          if (!any) continue;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          int nt[4];
+#pragma unroll
+          for (int sl = 0; sl < 4; sl++) { nt[sl] = t[i][sl] + h[lane + 64 * sl]; h[lane + 64 * sl] = 0; }
+          int mx = -1, at = 0;
+#pragma unroll
+          for (int sl = 0; sl < 4; sl++) if (lane + 64 * sl < nmod && nt[sl] > mx) { mx = nt[sl]; at = lane + 64 * sl; }
+          int wmx = mx;
+          for (int o = 32; o > 0; o >>= 1) wmx = max(wmx, __shfl_xor(wmx, o));
+          int ties = 0;
+#pragma unroll
+          for (int sl = 0; sl < 4; sl++) ties += (lane + 64 * sl < nmod && nt[sl] == wmx) ? 1 : 0;
+          const unsigned long long holders = __builtin_amdgcn_ballot_w64(ties > 0);
+          const bool one = __popcll(holders) == 1 && __builtin_amdgcn_readlane(ties, __builtin_ctzll(holders)) == 1;
+          if (one) {
+            mode = __builtin_amdgcn_readlane(at, __builtin_ctzll(holders));
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) t[i][sl] = nt[sl];
+          } else {
+            for (unsigned e0 = 0; e0 < nr; e0 += 64) {
+              const unsigned e = e0 + lane;
+              int3 mv = make_int3(0, -1, -1);
+              if (e < nr) mv = s_rel[r0 + e];
+              const bool in = mv.y == c, out = mv.z == c;
+              const unsigned long long m = __builtin_amdgcn_ballot_w64(in || out);
+              if (!m) continue;
+              const int cur_l = (in || out) ? (int)reinterpret_cast<const uint8_t *>(s_rows)[e * KM_ATTRS + a] : 0;
+              km_apply_moves(t[i], mode, m, cur_l, in, nmod, lane);
+            }
+          }
+#pragma unroll
+          for (int sl = 0; sl < 4; sl++) if (lane + 64 * sl < nmod) st.freq[gp * nmod + lane + 64 * sl] = t[i][sl];
+          if (lane == 0) reinterpret_cast<uint8_t *>(s_mode + oc * KM_WORDS)[a] = (uint8_t)mode;
+        }
+      }
+    }
+    if (nrel > 0) {
+      __syncthreads();
+      // the owned modes go back where the next launches (and the host) read them
+      for (int e = tid; e < nown * KM_WORDS; e += KM_WT) reinterpret_cast<uint32_t *>(st.cent)[(size_t)(w + (e / KM_WORDS) * G) * KM_WORDS + e % KM_WORDS] = s_mode[e];
+    }
+  }
+  if (bin < 0) return;
+  // ---- the bin's points against the owned modes as they stand now
+  const int64_t b0 = bin * KM_BIN, b1 = min(b0 + (int64_t)KM_BIN, n);
+  const int nb = (int)(b1 - b0);
+  if (tid < nb) {
+    uint32_t p[KM_WORDS];
+#pragma unroll
+    for (int q = 0; q < KM_WORDS; q += 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(rows) + (b0 + tid) * KM_WORDS + q);
+      p[q] = v.x; p[q + 1] = v.y; p[q + 2] = v.z; p[q + 3] = v.w;
+    }
+    // the owner's own arg-min: a distance has 18 bits (80 * (255 + 2048)), a cluster 12; among equal distances the LAST cluster wins
+    unsigned key = 0xffffffffu;
+    for (int oc = 0; oc < nown; oc++) key = min(key, (km_dissim(s_mode + oc * KM_WORDS, p) << 12) | (unsigned)(4095 - (w + oc * G)));
+    partial[(size_t)w * KM_BIN + tid] = key;
+  }
+}
+
+__global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G, int64_t bin, KmState st, const unsigned *__restrict__ partial) {
   extern __shared__ int s_members[];  // [k]
   __shared__ int s_mb[KM_BIN], s_cl[KM_BIN];
   __shared__ unsigned long long s_cost[KM_WT / 64];
@@ -189,10 +369,29 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, in
   __shared__ int s_state, s_from, s_to;   // 0 done, 1 a repair is wanted: cluster s_to is empty, donor s_from
   __shared__ unsigned s_pick;
   __shared__ long long s_found;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = (int)(b1 - b0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b0 = bin * KM_BIN, b1 = min(b0 + (int64_t)KM_BIN, n);
+  const int nb = (int)(b1 - b0);
   for (int c = tid; c < k; c += KM_WT) s_members[c] = st.members[c];
+  // the bin's scores: the minimum over the owners' keys (smallest distance, then the LAST cluster: kmodes.pas:272, 414).  One workgroup
+  // fetches all of them and a CU has only so many misses in flight: with a word per (point, cluster) -- 245 KB at 64 clusters -- this
+  // fetch alone was 12 of the walker's 16 microseconds, so the owners are few (KM_MAX_OWNERS) and reduce their clusters themselves
   unsigned long long cost = 0;
-  for (int j = tid; j < nb; j += KM_WT) { s_mb[j] = st.memb[b0 + j]; s_cl[j] = st.clust[b0 + j]; cost += st.dis[b0 + j]; }
+  if (tid < nb) {
+    unsigned key = 0xffffffffu;
+    for (int g0 = 0; g0 < G; g0 += 16) {
+      unsigned d[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) d[u] = g0 + u < G ? partial[(size_t)(g0 + u) * KM_BIN + tid] : 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < 16; u++) key = min(key, d[u]);
+    }
+    const unsigned best = key >> 12;
+    const int res = 4095 - (int)(key & 4095u);
+    s_cl[tid] = res;
+    s_mb[tid] = st.memb[b0 + tid];
+    cost = best;
+  }
   for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
   if (lane == 0) s_cost[wave] = cost;
   __syncthreads();
@@ -207,7 +406,33 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, in
       int state = 0;
       while (chunk * 64 < nb) {
         const int j0 = chunk * 64;
-        if (fresh) { todo = j0 + 64 <= nb ? ~0ull : ((1ull << (nb - j0)) - 1ull); fresh = false; }
+        if (fresh) {
+          todo = j0 + 64 <= nb ? ~0ull : ((1ull << (nb - j0)) - 1ull);
+          fresh = false;
+          // The chunk's moves at once when none of them can empty a cluster: every leaver takes its member away first -- if no count
+          // reaches zero with the departures alone, none does in the points' order with the arrivals in between either, there is no repair and
+          // the outcome (memberships, counts, the list in the points' order) is the walk's.  Otherwise the departures are put back
+          // and the chunk is walked a point at a time.
+          const bool mv1 = j0 + lane < nb && s_mb[j0 + lane] != s_cl[j0 + lane];
+          const unsigned long long all = __builtin_amdgcn_ballot_w64(mv1);
+          if (!all) { chunk++; fresh = true; continue; }
+          const int old1 = mv1 ? s_mb[j0 + lane] : 0, to1 = mv1 ? s_cl[j0 + lane] : 0;
+          const int pre = mv1 ? atomicSub(&s_members[old1], 1) : 2;
+          if (!__builtin_amdgcn_ballot_w64(mv1 && pre <= 1)) {
+            if (mv1) {
+              atomicAdd(&s_members[to1], 1);
+              st.memb[b0 + j0 + lane] = to1;
+              s_mb[j0 + lane] = to1;
+              st.mlist[nmv + __popcll(all & ((1ull << lane) - 1ull))] = make_int3((int)(b0 + j0 + lane), to1, old1);
+            }
+            nmv += __popcll(all);
+            moves += __popcll(all);
+            chunk++;
+            fresh = true;
+            continue;
+          }
+          if (mv1) atomicAdd(&s_members[old1], 1);
+        }
         const bool mine = j0 + lane < nb && ((todo >> lane) & 1ull) && s_mb[j0 + lane] != s_cl[j0 + lane];
         const unsigned long long mv = __builtin_amdgcn_ballot_w64(mine);
         if (!mv) { chunk++; fresh = true; continue; }
@@ -250,7 +475,7 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, in
     // ---- all threads: the s_pick-th point (in index order) whose membership is s_from
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int from = s_from;
-    const int64_t lo = std::min<int64_t>((int64_t)tid * per, n), hi = std::min<int64_t>(lo + per, n);
+    const int64_t lo = min((int64_t)tid * per, n), hi = min(lo + per, n);
     int cnt = 0;
     for (int64_t i = lo; i < hi; i++) cnt += __hip_atomic_load(&st.memb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == from ? 1 : 0;
     int inc = cnt;  // inclusive prefix inside the wave
@@ -295,59 +520,6 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walk(int64_t n, int64_t b0, in
     *st.moves += moves;
     *st.nmoves = nmv;
     *st.seed = seed;
-  }
-}
-
-// (3) MovePointCat's histogram side (774-803), one wave per (cluster, attribute): the wave holds the pair's row of counters (four per
-//     lane) and its mode, walks the bin's move list in order and applies the moves that enter or leave its cluster -- the counter of the
-//     point's value up and the mode following it when it is overtaken; the counter down and, when the mode itself lost a member, the first
-//     largest counter as the new mode.  Pairs are independent of each other, which is all the parallelism the online update has.
-__global__ __launch_bounds__(256) void k_kmodes_apply(const uint8_t *__restrict__ rows, int k, int nmod, KmState st) {
-  const unsigned nmv = *st.nmoves;
-  if (nmv == 0) return;
-  const int lane = threadIdx.x & 63;
-  const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pr >= k * KM_ATTRS) return;
-  const int c = pr / KM_ATTRS, a = pr - c * KM_ATTRS;
-  int t[4];
-  bool loaded = false;
-  int mode = 0;
-  for (unsigned e0 = 0; e0 < nmv; e0 += 64) {
-    const unsigned e = e0 + lane;
-    int3 mv = make_int3(0, -1, -1);
-    if (e < nmv) mv = st.mlist[e];
-    const bool in = mv.y == c, out = mv.z == c;
-    unsigned long long m = __builtin_amdgcn_ballot_w64(in || out);
-    if (!m) continue;
-    const int cur_l = (in || out) ? (int)rows[(int64_t)mv.x * KM_ATTRS + a] : 0;  // the matching moves' values, fetched together
-    if (!loaded) {
-#pragma unroll
-      for (int sl = 0; sl < 4; sl++) t[sl] = lane + 64 * sl < nmod ? st.freq[(int64_t)pr * nmod + lane + 64 * sl] : 0;
-      mode = st.cent[pr];
-      loaded = true;
-    }
-    while (m) {
-      const int bit = __builtin_ctzll(m);
-      m &= m - 1;
-      const int cur = __builtin_amdgcn_readlane(cur_l, bit);
-      const bool enters = __builtin_amdgcn_readlane((int)in, bit) != 0;
-      const int own = cur & 63, sl = cur >> 6;
-      const int d = enters ? 1 : -1;
-      if (lane == own) { t[0] += sl == 0 ? d : 0; t[1] += sl == 1 ? d : 0; t[2] += sl == 2 ? d : 0; t[3] += sl == 3 ? d : 0; }
-      if (enters) {
-        const int msl = mode >> 6;
-        const int vm = __builtin_amdgcn_readlane(msl == 0 ? t[0] : msl == 1 ? t[1] : msl == 2 ? t[2] : t[3], mode & 63);
-        const int vc = __builtin_amdgcn_readlane(sl == 0 ? t[0] : sl == 1 ? t[1] : sl == 2 ? t[2] : t[3], own);
-        if (vm < vc) mode = cur;
-      } else if (mode == cur) {
-        mode = km_first_largest(t, nmod, lane);
-      }
-    }
-  }
-  if (loaded) {
-#pragma unroll
-    for (int sl = 0; sl < 4; sl++) if (lane + 64 * sl < nmod) st.freq[(int64_t)pr * nmod + lane + 64 * sl] = t[sl];
-    if (lane == 0) st.cent[pr] = (uint8_t)mode;
   }
 }
 
@@ -397,6 +569,50 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     TM_HIP(hipStreamSynchronize(stream));  // init[] is on the stack
   }
   hipLaunchKernelGGL(k_kmodes_validate, dim3((unsigned)std::min<int64_t>((n * KM_ATTRS + 255) / 256, 4096)), dim3(256), 0, stream, rows, n * KM_ATTRS, nmod, st.bad);
+  // KModesIter's two kernels: G owners (clusters dealt round-robin) and the walker
+  const int G = std::min(k, KM_MAX_OWNERS);
+  const int max_own = (k + G - 1) / G;
+  const size_t owner_lds = (size_t)((max_own * (KM_WORDS + 1) + 3 * (2 * KM_BIN + 8) + 3) & ~3) * 4 + (size_t)KM_STAGE * KM_ATTRS;
+  TM_CHECK(owner_lds <= 120 * 1024 && (size_t)k * 4 <= 48 * 1024, TM_E_INVAL, "kmodes: %d clusters need %zu bytes of LDS per workgroup", k, owner_lds);
+  if (owner_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_kmodes_owner), hipFuncAttributeMaxDynamicSharedMemorySize, (int)owner_lds);
+  DevBuf dpart;
+  TM_TRY(dpart.alloc((size_t)KM_BIN * G * 4));
+  // One iteration is 2 * bins + 1 dependent launches with the same arguments every time: a graph, built once per call and replayed
+  // (the host's share of a launch is then paid once, not 3 400 times per iteration)
+  struct IterGraph {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~IterGraph() { if (exec) (void)hipGraphExecDestroy(exec); if (g) (void)hipGraphDestroy(g); }
+  } iter_graph;
+  {
+    TM_HIP(hipGraphCreate(&iter_graph.g, 0));
+    const int64_t nbins = (n + KM_BIN - 1) / KM_BIN;
+    unsigned *part_p = dpart.as<unsigned>();
+    int k_ = k, nmod_ = nmod, G_ = G;
+    int64_t n_ = n;
+    const uint8_t *rows_ = rows;
+    hipGraphNode_t prev = nullptr;
+    auto add = [&](const void *fn, unsigned grid, size_t shm, void **params) -> int {
+      hipKernelNodeParams np;
+      memset(&np, 0, sizeof np);
+      np.func = const_cast<void *>(fn);
+      np.gridDim = dim3(grid); np.blockDim = dim3(KM_WT); np.sharedMemBytes = (unsigned)shm; np.kernelParams = params;
+      hipGraphNode_t node;
+      TM_HIP(hipGraphAddKernelNode(&node, iter_graph.g, prev ? &prev : nullptr, prev ? 1 : 0, &np));
+      prev = node;
+      return TM_OK;
+    };
+    for (int64_t bin = 0; bin <= nbins; bin++) {
+      int64_t b = bin < nbins ? bin : -1;  // the closing launch applies the last bin's moves
+      int first = bin == 0 ? 1 : 0;
+      void *po[] = {&rows_, &n_, &k_, &nmod_, &G_, &b, &first, &st, &part_p};
+      TM_TRY(add(reinterpret_cast<const void *>(&k_kmodes_owner), (unsigned)G, owner_lds, po));
+      if (bin == nbins) break;
+      void *pw[] = {&n_, &k_, &G_, &b, &st, &part_p};
+      TM_TRY(add(reinterpret_cast<const void *>(&k_kmodes_walker), 1u, (size_t)k * 4, pw));
+    }
+    TM_HIP(hipGraphInstantiate(&iter_graph.exec, iter_graph.g, nullptr, nullptr, 0));
+  }
   const size_t lds = (size_t)k * KM_ATTRS;
   TM_CHECK(lds <= 160 * 1024 - 1024, TM_E_INVAL, "kmodes: the modes of %d clusters do not fit LDS", k);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_kmodes_argmin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -458,13 +674,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
       point_iters += n;
       // ---- KModesIter (851-921): bins of 960 points, each scored against the modes as they stand when its turn comes
       TM_HIP(hipMemsetAsync(dscal.as<uint8_t>() + 8, 0, 12, stream));  // cost, moves
-      for (int64_t b0 = 0; b0 < n; b0 += KM_BIN) {
-        const int64_t b1 = std::min<int64_t>(b0 + KM_BIN, n);
-        TM_TRY(score(b0, b1));
-        hipLaunchKernelGGL(k_kmodes_walk, dim3(1), dim3(KM_WT), (size_t)k * 4, stream, n, b0, b1, k, st);
-        hipLaunchKernelGGL(k_kmodes_apply, dim3((unsigned)((k * KM_ATTRS + 3) / 4)), dim3(256), 0, stream, rows, k, nmod, st);
-      }
-      TM_HIP(hipGetLastError());
+      TM_HIP(hipGraphLaunch(iter_graph.exec, stream));
       Scal h;
       TM_TRY(read_scal(&h));
       const uint64_t cost = h.cost;

@@ -12,7 +12,7 @@ pids=(); objs=()
 for src in "$HERE"/*.hip; do
   obj="$OBJ/$(basename "${src%.hip}").o"; objs+=("$obj")
   case "$(basename "$src")" in
-    tm_knn*.hip|tm_kmeans.hip|tm_features.hip) $HIPCC $FLAGS -c "$src" -o "$obj" & pids+=($!) ;;
+    tm_knn*.hip|tm_kmeans.hip|tm_features.hip|tm_kmodes.hip) $HIPCC $FLAGS -c "$src" -o "$obj" & pids+=($!) ;;
     *) cp "$HERE/.obj/$(basename "${src%.hip}").o" "$obj" ;;   # unaffected by the knn shape macros
   esac
 done
