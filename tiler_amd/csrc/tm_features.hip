@@ -118,29 +118,35 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
   const int zz = snake[lane];
   const int64_t niter = (n + 3) / 4;
   int buf = 0;
+  // a tile's pixel of this lane: the colour the reference's ConvertToCpnPixels would read
+  auto fetch = [&](int64_t t) -> uint32_t {
+    const int f = mirror_flags ? mirror_flags[t] : 0;
+    const int y = lane >> 3, x = lane & 7;
+    const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // ConvertToCpnPixels 3080-3085 / 3093-3098
+    if (SRC == 1) return (uint32_t)palettes[(int64_t)pal_idx[t] * pal_size + pal_px[t * 64 + src]];
+    if (SRC == 3) {
+      const int64_t tile = t / use_lab;
+      return (uint32_t)palettes[(t - tile * use_lab) * pal_size + pal_px[tile * 64 + src]];
+    }
+    if (SRC == 4) {  // row t = the (tile, palette) pair pairs[t] = tile << 32 | palette (all ones: a pad, black)
+      const unsigned long long pr = reinterpret_cast<const unsigned long long *>(tiles)[t];
+      return pr == ~0ull ? 0u : (uint32_t)palettes[(int64_t)(uint32_t)pr * pal_size + pal_px[(int64_t)(pr >> 32) * 64 + src]];
+    }
+    if (SRC == 2) {
+      const int ww = pal_size - 7;
+      const int64_t wy = t / ww, wx = t - wy * ww;
+      return tiles[(wy + y) * pal_size + wx + x];  // CopyRGBPixels(ABackBuffer, x, AIndex), 879-887
+    }
+    return tiles[(pal_idx ? (int64_t)pal_idx[t] : t) * 64 + src];  // (SRC 0 with a row list: row t of the output is tile pal_idx[t])
+  };
+  // A wave works on its own tile and its own LDS rows: nothing here is shared between waves, so no barrier -- and the NEXT tile's
+  // pixel (two or three dependent loads deep) is asked for before this tile's 192 dot products start, not after them
+  uint32_t col = 0;
+  if (blockIdx.x < niter && blockIdx.x * 4ll + wave < n) col = fetch(blockIdx.x * 4ll + wave);
   for (int64_t it = blockIdx.x; it < niter; it += gridDim.x, buf ^= 1) {
     const int64_t t = it * 4 + wave;
     const bool valid = t < n;
     if (valid) {
-      const int f = mirror_flags ? mirror_flags[t] : 0;
-      const int y = lane >> 3, x = lane & 7;
-      const int src = (((f & 2) ? 7 - y : y) << 3) | ((f & 1) ? 7 - x : x);  // ConvertToCpnPixels 3080-3085 / 3093-3098
-      uint32_t col;
-      if (SRC == 1) {
-        col = (uint32_t)palettes[(int64_t)pal_idx[t] * pal_size + pal_px[t * 64 + src]];
-      } else if (SRC == 3) {
-        const int64_t tile = t / use_lab;
-        col = (uint32_t)palettes[(t - tile * use_lab) * pal_size + pal_px[tile * 64 + src]];
-      } else if (SRC == 4) {  // row t = the (tile, palette) pair pairs[t] = tile << 32 | palette (all ones: a pad, black)
-        const unsigned long long pr = reinterpret_cast<const unsigned long long *>(tiles)[t];
-        col = pr == ~0ull ? 0u : (uint32_t)palettes[(int64_t)(uint32_t)pr * pal_size + pal_px[(int64_t)(pr >> 32) * 64 + src]];
-      } else if (SRC == 2) {
-        const int ww = pal_size - 7;
-        const int64_t wy = t / ww, wx = t - wy * ww;
-        col = tiles[(wy + y) * pal_size + wx + x];  // CopyRGBPixels(ABackBuffer, x, AIndex), 879-887
-      } else {
-        col = tiles[(pal_idx ? (int64_t)pal_idx[t] : t) * 64 + src];  // (SRC 0 with a row list: row t of the output is tile pal_idx[t])
-      }
       float yy, uu, vv;
       if (use_lab && SRC != 3 && SRC != 4)
         rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
@@ -150,7 +156,11 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
       s_cpn[buf][wave][64 + lane] = uu;
       s_cpn[buf][wave][128 + lane] = vv;
     }
-    __syncthreads();
+    {
+      const int64_t tn = (it + gridDim.x) * 4 + wave;
+      if (it + gridDim.x < niter && tn < n) col = fetch(tn);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the wave's LDS operations are in order: its reads below see its writes above)
     if (valid) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {

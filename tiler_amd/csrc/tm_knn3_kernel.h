@@ -174,6 +174,25 @@ __device__ __forceinline__ void k3_load_tile(const uint8_t *tb, int lane, int ha
   }
 }
 
+// ... leaving out the high-digit chunks the tile's mask says are all zero (the chain skips their products: bit kc clear = T[6 + kc] never
+// read).  On the literal bench clip the consume kernel pulled 43.7 GB per launch through the L2s' far side -- 3.4 TB/s, the matrix pipe
+// waiting on it -- and two in five of those bytes were zeros.
+template <int KT>
+__device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane, int half, unsigned tm, v4i (&T)[KT], v16i &ntr) {
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
+#pragma unroll
+  for (int kc = 6; kc < KT; kc++) {
+    T[kc] = v4i{0, 0, 0, 0};
+    if ((tm >> (kc - 6)) & 1u) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
+  }
+#pragma unroll
+  for (int q4 = 0; q4 < 4; q4++) {
+    const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
+    ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
+  }
+}
+
 // A block's epilogue: the row minimum of each query (lane & 31; the two half-waves hold 16 rows each) against its running best in LDS.
 // d'' = 2 X + |t-c|^2 + 2 (|q-c|^2 >> 1) = SSD - parity.  Returns true in lanes whose improvement may have lowered the sub-tile's largest
 // best (the caller refreshes the bound when any lane says so); `sm_now` = the sub-tile's published bound, or 0 to ask for a refresh on
@@ -701,7 +720,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
         }
         v4i T[KT];
         v16i ntr;
-        k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
+        k3_load_tile_masked<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, tm, T, ntr);
         nloads++;
         // the entry after this one is chosen while the loads fly
         int ntile = 0, nlb = 0;

@@ -1,4 +1,4 @@
-"""Collapses the rocprofv3 counter_collection CSVs of tools/pmc_knn.sh into one row per (kernel, dispatch): counter sums."""
+"""Collapses the rocprofv3 counter_collection CSVs of tools/pmc_knn3.sh into one row per (kernel, dispatch): counter sums."""
 import csv
 import glob
 import os

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the headline bench (no extras): gpurun_out/prof_<tag>/
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - > /dev/null
