@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const int32_t *__restrict__ 
 // first iteration in which nothing changed anywhere (so the host can poll rarely).
 __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int nseg, int k, int d, int carry, u64 *__restrict__ sums,
                                                      u64 *__restrict__ cnts, double *__restrict__ cent, int it,
-                                                     int *__restrict__ quiet_iter) {
+                                                     int *__restrict__ quiet_iter, int *host_quiet = nullptr /* page-locked host word that gets the flag too */) {
   if (*quiet_iter >= 0) return;
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
@@ -565,7 +565,10 @@ __global__ __launch_bounds__(1024) void k_update_all(Seg *__restrict__ segs, int
   if (!carry)
     for (int64_t sc = threadIdx.x; sc < (int64_t)nseg * k; sc += 1024) cnts[sc] = 0;
   __syncthreads();
-  if (threadIdx.x == 0 && s_any == 0 && *quiet_iter < 0) *quiet_iter = it;
+  if (threadIdx.x == 0 && s_any == 0 && *quiet_iter < 0) {
+    *quiet_iter = it;
+    if (host_quiet) __hip_atomic_store(host_quiet, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 template <int PPT>
@@ -876,7 +879,8 @@ __global__ void k_cent_transpose(const Seg *__restrict__ segs, const double *__r
 // nearest other centroid (rounded down)
 __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k, u64 *__restrict__ sums, u64 *__restrict__ cnts, double *__restrict__ cent,
                                                    double *__restrict__ cent_t /* [192][kt], zero beyond kk */, int kt, double *__restrict__ cmove,
-                                                   double *__restrict__ shalf, unsigned *__restrict__ need_cnt, int it, int *__restrict__ quiet_iter) {
+                                                   double *__restrict__ shalf, unsigned *__restrict__ need_cnt, int it, int *__restrict__ quiet_iter,
+                                                   int *host_quiet = nullptr /* page-locked host word that gets the flag too */) {
   if (*quiet_iter >= 0) return;
   extern __shared__ double s_new[];  // [kk][193] (odd pitch: the pair loop reads two rows at once)
   __shared__ unsigned long long s_min[H_MAXK];
@@ -928,7 +932,10 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
     for (int o = 32; o > 0; o >>= 1) mx2 = fmax(mx2, __shfl_xor(mx2, o));
     if (lane == 0) {
       cmove[k] = mx; cmove[k + 1] = mx2; cmove[k + 2] = (double)amx;
-      if (!changed && *quiet_iter < 0) *quiet_iter = it;
+      if (!changed && *quiet_iter < 0) {
+        *quiet_iter = it;
+        if (host_quiet) __hip_atomic_store(host_quiet, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       segs[0].changed = 0;
     }
   }
@@ -1540,7 +1547,12 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
   // for the host to look, and at most two short batches of launches are wasted at the end.  (Batches of 16 with the stream drained at
   // every poll left the device idle ~30 us six times per clustering and, on the bench clip, 42 no-op launches -- 0.45 ms -- behind the
   // 87th iteration.)
-  int *const pin = pinned_words();
+  // (the flag reaches the host in a page-locked word the update kernel itself writes: a 4-byte copy behind every batch was a launch of its own
+  // -- 75 of them per clustering on the literal bench clip)
+  int *pin = pinned_words();
+  int *pin_dev = nullptr;
+  if (pin && hipHostGetDevicePointer(reinterpret_cast<void **>(&pin_dev), pin, 0) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; pin_dev = nullptr; }
+  if (pin) __atomic_store_n(&pin[0], -1, __ATOMIC_RELEASE);
   const int poll_every = pin ? 4 : 16;
   hipEvent_t pev[2] = {nullptr, nullptr};
   struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 2; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{pev};
@@ -1565,7 +1577,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
                              cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
         }
         hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
-                           hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>());
+                           hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>(), pin_dev);
         continue;
       }
       if (d == 3) {
@@ -1578,7 +1590,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       } else {
         launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192, quiet.as<int>());
       }
-      hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, (d == 192 || fuse3) ? 1 : 0, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>());
+      hipLaunchKernelGGL(k_update_all, dim3(1), dim3(1024), 0, stream, ds, nseg, k, d, (d == 192 || fuse3) ? 1 : 0, sums.as<u64>(), cnts.as<u64>(), cent, issued, quiet.as<int>(), pin_dev);
     }
     if (!pin) {
       int q = -1;
@@ -1591,19 +1603,18 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       it = issued;
       continue;
     }
-    TM_HIP(hipMemcpyAsync(&pin[nbatch & 1], quiet.p, 4, hipMemcpyDeviceToHost, stream));
     TM_HIP(hipEventRecord(pev[nbatch & 1], stream));
     nbatch++;
     it = issued;
     if (nbatch >= 2) {  // the batch before the one just queued
       TM_HIP(hipEventSynchronize(pev[nbatch & 1]));
-      qflag = pin[nbatch & 1];
+      qflag = __atomic_load_n(&pin[0], __ATOMIC_ACQUIRE);  // (written once: -1 until an update finds the clustering quiet)
       if (qflag >= 0) { it = qflag; break; }
     }
   }
   if (pin && qflag < 0 && nbatch >= 1) {  // the last batch queued
     TM_HIP(hipEventSynchronize(pev[(nbatch - 1) & 1]));
-    qflag = pin[(nbatch - 1) & 1];
+    qflag = __atomic_load_n(&pin[0], __ATOMIC_ACQUIRE);
     if (qflag >= 0) it = qflag;
   }
   TM_HIP(hipGetLastError());
