@@ -37,6 +37,8 @@
  *   TM_DEDUP_PLAIN          exact dedup by the comparator sort alone; TM_DEDUP_DEGRADE_HASH: a 2-bit hash, so that every group
  *                           collides (tests); TM_DEDUP_FULL_ORDER: the whole order, not only the rows that can survive the budget (tests)
  *   TM_MOTION_VALU          the motion search's VALU kernel only (tests drive both kernels)
+ *   TM_FEATURES_PLAIN       the int16 DCT features sum every coefficient in the reference's order (no separable first look; the tests
+ *                           compare the two forms)
  *   TM_PP_DEBUG             PreparePalettes prints its sub-steps' wall times (adds synchronisations)
  *   TM_COMM_FORCE_DIST      a one-process communicator still walks the sharded code paths (tests on a one-GPU box)
  *   TM_COMM_TIMEOUT_S=<s>   how long tm_comm_init (and a collective of the library's own communicator) waits for the other processes (120)

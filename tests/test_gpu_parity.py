@@ -79,6 +79,36 @@ def test_features_rgb_extremes(oracle):
     assert stages.features_rgb(_dev(t[:0]), None, 1, False).shape == (0, 192)
 
 
+@pytest.mark.parametrize("mode,use_lab", [(1, False), (0, False), (3, False), (4, True), (4, False), (3, True)])
+def test_features_first_look_agrees_with_reference_order(mode, use_lab, monkeypatch):
+    """The int16 features take a separable first look at every coefficient and sum it in the reference's order only when the rounding
+    is in doubt (tm_features.hip): over 300 000 tiles of every kind -- noise, flat, two-colour, ramps, near-black -- both forms give the
+    same 57.6 M integers (TM_FEATURES_PLAIN=1 sums every coefficient the reference's way; that form is the one checked against the
+    oracle above, at the oracle's sizes)."""
+    from tiler_amd import stages
+    g = torch.Generator(device="cuda").manual_seed(1234 + mode)
+    n = 300000
+    t = torch.randint(0, 1 << 24, (n, 64), generator=g, device="cuda", dtype=torch.int32)
+    k = n // 6
+    t[k:2 * k] = t[k:2 * k, :1]                                         # flat
+    two = torch.randint(0, 1 << 24, (k, 2), generator=g, device="cuda", dtype=torch.int32)
+    pick = torch.randint(0, 2, (k, 64), generator=g, device="cuda")
+    t[2 * k:3 * k] = torch.gather(two, 1, pick)                         # two colours
+    ramp = (torch.arange(64, device="cuda", dtype=torch.int32) % 8)[None, :] * torch.randint(0, 32, (k, 1), generator=g, device="cuda", dtype=torch.int32)
+    base = torch.randint(0, 32, (k, 1), generator=g, device="cuda", dtype=torch.int32)
+    v = (ramp + base).clamp_(0, 255)
+    t[3 * k:4 * k] = v | (v << 8) | (v << 16)                           # grey ramps
+    t[4 * k:5 * k] &= 0x070707                                          # near black
+    flags = torch.randint(0, 4, (n,), generator=g, device="cuda", dtype=torch.uint8)
+    monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
+    fast = stages.features_rgb(t, flags, mode, use_lab)
+    monkeypatch.setenv("TM_FEATURES_PLAIN", "1")
+    plain = stages.features_rgb(t, flags, mode, use_lab)
+    monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
+    diff = (fast != plain)
+    assert not bool(diff.any()), "%d of %d coefficients differ, first at %s" % (int(diff.sum()), diff.numel(), torch.nonzero(diff)[0].tolist())
+
+
 def test_features_pal_and_cluster(tiles_flags, oracle):
     from tiler_amd import stages
     tiles, _ = tiles_flags

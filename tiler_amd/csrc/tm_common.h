@@ -48,7 +48,7 @@ int require_device();
 struct Knobs {
   bool knn_debug = false, knn_noprune = false, topk_brute = false, no_query_groups = false, dither_own_keys = false, dither_no_dedup = false,
        dither_literal = false, dedup_plain = false, dedup_degrade_hash = false, dedup_full_order = false, motion_valu = false, pp_debug = false,
-       comm_force_dist = false;
+       comm_force_dist = false, features_plain = false;
   double epu_table_gib = 6.0, comm_timeout_s = 120.0;
 };
 const Knobs &knobs();
@@ -120,6 +120,7 @@ int *pinned_words();
 struct DeviceTables {
   float *dct_lut_f32[2] = {nullptr, nullptr};   // FDCTLut[special][4096]
   double *dct_lut_f64[2] = {nullptr, nullptr};  // FDCTLutDouble
+  double *dct_cos_f64[2] = {nullptr, nullptr};  // the LUT's two cosine factors, cos((x + 0.5) u pi / div) as [u][x] (the int16 feature kernel's fast path)
   double *weights = nullptr;                    // cDCTWeights [3][8][8]
   float *srgb_lut = nullptr;                    // inverse sRGB of c/255, as Single
   uint8_t *snake = nullptr;                     // cDCTSnake

@@ -102,16 +102,20 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
                                                       int weighted, int use_lab, const float *__restrict__ lut,
                                                       const double *__restrict__ weights, const uint8_t *__restrict__ snake,
                                                       const float *__restrict__ srgb_lut, int16_t *__restrict__ out,
-                                                      int *__restrict__ colmm /* null, or [384]: running min / max of the 192 output columns (atomics) */) {
-  __shared__ __attribute__((aligned(16))) float s_cpn[2][4][192];
+                                                      int *__restrict__ colmm /* null, or [384]: running min / max of the 192 output columns (atomics) */,
+                                                      const double *__restrict__ cosd /* [8][8] the LUT's cosine factor, cos((x + 0.5) u pi / div) */, int plain) {
+  __shared__ __attribute__((aligned(16))) double s_cpn[2][4][192];  // the tile's planes, widened once where they are made
+  __shared__ __attribute__((aligned(16))) float s_lut[4096];    // FDCTLut as the reference holds it (Singles): the in-order sums read it
+  __shared__ __attribute__((aligned(16))) double s_row[4][64];  // a wave's row transforms, [u][y]
   int mmn[3] = {INT_MAX, INT_MAX, INT_MAX}, mmx[3] = {INT_MIN, INT_MIN, INT_MIN};  // of this lane's three output columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float l[64];
+  for (int e = threadIdx.x; e < 1024; e += 256) reinterpret_cast<float4 *>(s_lut)[e] = reinterpret_cast<const float4 *>(lut)[e];
+  // lane = v * 8 + u is coefficient (u, v); in the row pass the same lane stands for (u, row y = lane >> 3)
+  double au[8], av[8];
 #pragma unroll
-  for (int k = 0; k < 64; k += 4) {
-    const float4 v = *reinterpret_cast<const float4 *>(lut + lane * 64 + k);
-    l[k] = v.x; l[k + 1] = v.y; l[k + 2] = v.z; l[k + 3] = v.w;
-  }
+  for (int x = 0; x < 8; x++) { au[x] = cosd[(lane & 7) * 8 + x]; av[x] = cosd[(lane >> 3) * 8 + x]; }
+  // cDCTUVRatio (utils.pas:100-109): 0.5, Single(sqrt(0.5)), 1
+  const double ruv = (lane == 0) ? 0.5 : (((lane & 7) == 0 || (lane >> 3) == 0) ? 0.707106769084930419921875 : 1.0);
   double w[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) w[c] = weights[c * 64 + lane];
@@ -143,18 +147,27 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
   // pixel (two or three dependent loads deep) is asked for before this tile's 192 dot products start, not after them
   uint32_t col = 0;
   if (blockIdx.x < niter && blockIdx.x * 4ll + wave < n) col = fetch(blockIdx.x * 4ll + wave);
+  __syncthreads();  // s_lut is whole
+  float lnorm;  // the Euclidean norm of this lane's LUT row, rounded up (4 for the plain DCT's rows)
+  {
+    double q2 = 0.0;
+    for (int k = 0; k < 64; k++) { const double v = (double)s_lut[lane * 64 + ((k + lane) & 63)]; q2 = fma(v, v, q2); }  // (rotated: no bank conflict)
+    lnorm = (float)(sqrt(q2) * (1.0 + 1e-6));
+  }
   for (int64_t it = blockIdx.x; it < niter; it += gridDim.x, buf ^= 1) {
-    const int64_t t = it * 4 + wave;
-    const bool valid = t < n;
+    const int64_t t_out = it * 4 + wave;
+    const bool valid = t_out < n;
+    float mine[3] = {0.0f, 0.0f, 0.0f};  // this lane's pixel, per plane
     if (valid) {
       float yy, uu, vv;
       if (use_lab && SRC != 3 && SRC != 4)
         rgb_to_lab_det(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, srgb_lut, yy, uu, vv);
       else
         rgb_to_yuv(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, yy, uu, vv);
-      s_cpn[buf][wave][lane] = yy;
-      s_cpn[buf][wave][64 + lane] = uu;
-      s_cpn[buf][wave][128 + lane] = vv;
+      s_cpn[buf][wave][lane] = (double)yy;
+      s_cpn[buf][wave][64 + lane] = (double)uu;
+      s_cpn[buf][wave][128 + lane] = (double)vv;
+      mine[0] = yy; mine[1] = uu; mine[2] = vv;
     }
     {
       const int64_t tn = (it + gridDim.x) * 4 + wave;
@@ -164,30 +177,71 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
     if (valid) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        const float *cp = &s_cpn[buf][wave][c * 64];
-        double acc0 = 0.0, acc1 = 0.0;
+        const double *cp = &s_cpn[buf][wave][c * 64];
+        // The reference's sum (exact_sum below) costs 130 vector instructions per coefficient and plane: 64 Single products, Single sums
+        // of pairs, 32 conversions, 34 double additions, in DCTInner_asm's order.  What is stored is only Round(z w).  So z is first
+        // computed the cheap way -- the LUT is cos x cos x ratio: a row transform shared by the eight coefficients of a column of the
+        // LUT, then a column transform, 16 fused multiply-adds in double -- together with a bound on how far the reference's z can lie
+        // from it:  |z_ref - z_fast| <= sum|p_k| (2^-23 + 2^-24)(1 + 2^-20),  p_k = pixel x LUT entry (every product and every pair
+        // sum of the reference rounds to Single once: 2 x 2^-24 relative; the LUT's Singles are within 2^-24 of the doubles they were
+        // rounded from, which are this path's cos x cos x ratio to 2^-52; the double-precision steps of both paths stay below 2^-47),
+        // and sum|p_k| <= |pixels| |LUT row| (Euclidean norms).  When z_fast w is farther than that (times |w|) from every half-integer, both
+        // round to the same integer.  Otherwise -- a few coefficients per thousand -- the coefficient is summed the reference's way, by
+        // the whole wave (lane k = product k; the order's pairings are lane exchanges: xor 4 in Single, xor 8 and xor 2 in double, then the
+        // four 16-element steps in sequence).
+        auto exact_sum = [&](int coef) -> double {  // z of coefficient `coef` in DCTInner_asm's order (utils.pas:892-921), uniform over the wave
+          const float e = __fmul_rn(mine[c], s_lut[coef * 64 + lane]);
+          const float s4 = __fadd_rn(e, __shfl_xor(e, 4));                 // (p0+p4, p1+p5, p2+p6, p3+p7 | p8+p12, ...): Single
+          double d = (double)s4;
+          d = __dadd_rn(d, __shfl_xor(d, 8));                              // (double)s + (double)t
+          d = __dadd_rn(d, __shfl_xor(d, 2));                              // ... + the second pair: a0 in lane 16 j, a1 in lane 16 j + 1
+          double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 64; k += 16) {  // DCTInner_asm, one 16-element step (utils.pas:892-921)
-          // packed fp32 (v_pk_mul_f32 / v_pk_add_f32): two IEEE operations per instruction, each rounded on its own like the
-          // reference's mulps / addps lanes (-ffp-contract=off: nothing fuses)
-          f32x2 p[8];
-#pragma unroll
-          for (int q = 0; q < 16; q += 4) {
-            const float4 cv = *reinterpret_cast<const float4 *>(cp + k + q);
-            p[q >> 1] = f32x2{cv.x, cv.y} * f32x2{l[k + q], l[k + q + 1]};
-            p[(q >> 1) + 1] = f32x2{cv.z, cv.w} * f32x2{l[k + q + 2], l[k + q + 3]};
-          }
-          const f32x2 s01 = p[0] + p[2], s23 = p[1] + p[3];  // (p0+p4, p1+p5), (p2+p6, p3+p7)
-          const f32x2 t01 = p[4] + p[6], t23 = p[5] + p[7];  // (p8+p12, p9+p13), (p10+p14, p11+p15)
-          const double a0 = __dadd_rn(__dadd_rn((double)s01.x, (double)t01.x), __dadd_rn((double)s23.x, (double)t23.x));
-          const double a1 = __dadd_rn(__dadd_rn((double)s01.y, (double)t01.y), __dadd_rn((double)s23.y, (double)t23.y));
-          acc0 = __dadd_rn(acc0, a0);
-          acc1 = __dadd_rn(acc1, a1);
+          for (int j = 0; j < 4; j++) { acc0 = __dadd_rn(acc0, __shfl(d, 16 * j)); acc1 = __dadd_rn(acc1, __shfl(d, 16 * j + 1)); }
+          return __dadd_rn(acc0, acc1);
+        };
+        double t;
+        bool doubtful;
+        if (plain) {
+          t = 0.0;
+          doubtful = true;
+        } else {
+          // sum of the pixels' squares over the wave (row operations and four lane reads, no LDS; 64 non-negative Singles: within 2^-17 of exact)
+          float sq = mine[c] * mine[c];
+          sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xf, 0xf, true));
+          sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xf, 0xf, true));
+          sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xf, 0xf, true));
+          sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x140, 0xf, 0xf, true));
+          const float sq_all = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 16))) +
+                               (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 48)));
+          const double sa = (double)(lnorm * (__builtin_amdgcn_sqrtf(sq_all) * 1.00001f));  // >= sum |pixel x LUT entry| (Cauchy-Schwarz; lnorm = the LUT row's norm, rounded up; the hardware's root is good to 1 ulp)
+          const double2 *fp = reinterpret_cast<const double2 *>(cp + (lane >> 3) * 8);
+          const double2 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
+          double r = au[0] * f0.x;
+          r = fma(au[1], f0.y, r); r = fma(au[2], f1.x, r); r = fma(au[3], f1.y, r);
+          r = fma(au[4], f2.x, r); r = fma(au[5], f2.y, r); r = fma(au[6], f3.x, r); r = fma(au[7], f3.y, r);
+          s_row[wave][(lane & 7) * 8 + (lane >> 3)] = r;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          const double2 *rp = reinterpret_cast<const double2 *>(&s_row[wave][(lane & 7) * 8]);
+          const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next plane's row transforms land after these reads)
+          double z = av[0] * r0.x;
+          z = fma(av[1], r0.y, z); z = fma(av[2], r1.x, z); z = fma(av[3], r1.y, z);
+          z = fma(av[4], r2.x, z); z = fma(av[5], r2.y, z); z = fma(av[6], r3.x, z); z = fma(av[7], r3.y, z);
+          z *= ruv;
+          t = weighted ? z * w[c] : z;
+          const double slack = sa * 1.81e-7 * (weighted ? fabs(w[c]) : 1.0) + 1e-9 * (fabs(t) + 1.0);  // 1.81e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
+          const double fl = floor(t);
+          doubtful = !(fabs(t - fl - 0.5) > slack) || !(slack < 0.25);
         }
-        double z = __dadd_rn(acc0, acc1);
-        if (weighted) z = __dmul_rn(z, w[c]);
-        const int16_t o = (int16_t)__double2ll_rn(z);  // Round(): half to even (3126)
-        out[t * 192 + c * 64 + zz] = o;
+        for (unsigned long long m = __builtin_amdgcn_ballot_w64(doubtful); m; m &= m - 1) {
+          const int coef = __builtin_ctzll(m);
+          const double z = exact_sum(coef);
+          if (lane == coef) t = weighted ? __dmul_rn(z, w[c]) : z;
+        }
+        // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
+        const int16_t o = fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+        out[t_out * 192 + c * 64 + zz] = o;
         mmn[c] = min(mmn[c], (int)o);
         mmx[c] = max(mmx[c], (int)o);
       }
@@ -404,7 +458,7 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(mode)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -418,7 +472,7 @@ int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int
   const int grid = grid_for(n, 4);
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      (const int32_t *)rows, nullptr, 0, (const uint8_t *)nullptr, n, mode_weighted(mode) ? 1 : 0, use_lab,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)colmm);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)colmm, tab->dct_cos_f64[mode_special(mode)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -432,7 +486,7 @@ int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, cons
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<1>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px,
                      (const int32_t *)pal_idx, (const int32_t *)palettes, pal_size, nullptr, n, mode_weighted(mode) ? 1 : 0, 0,
-                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
+                     tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(mode)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -442,7 +496,7 @@ int launch_features_pairs(const void *pal_px, const void *pairs, int64_t n, cons
   TM_TRY(get_tables(&tab));
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<4>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)pairs, (const uint8_t *)pal_px, nullptr,
-                     (const int32_t *)palettes, pal_size, nullptr, n, 1, 0, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
+                     (const int32_t *)palettes, pal_size, nullptr, n, 1, 0, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[0], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -455,7 +509,7 @@ int launch_features_table(const void *pal_px, int64_t ntiles, const void *palett
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_i16<3>, dim3(grid_for(n, 4)), dim3(256), 0, stream, nullptr, (const uint8_t *)pal_px, nullptr,
                      (const int32_t *)palettes, pal_size, nullptr, n, 1, npal, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights,
-                     tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr);
+                     tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
@@ -467,7 +521,7 @@ int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stre
   const int64_t n = (int64_t)(w - 7) * (h - 7);
   hipLaunchKernelGGL(k_features_i16<2>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)fb, nullptr, nullptr, nullptr, w,
                      nullptr, n, 1, 0, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights, tab->snake, tab->srgb_lut,
-                     (int16_t *)out, (int *)nullptr);
+                     (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }

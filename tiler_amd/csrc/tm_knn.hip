@@ -1184,7 +1184,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   }
 #if TM_KNN3_STAMPS
   {
-    static const char *names3[6] = {"prologue", "segment load", "consume", "end-of-segment wait", "results", "total"};
+    static const char *names3[6] = {"prologue + results", "segment load", "consume", "end-of-segment wait", "waiting for the tile", "total"};
     for (int i = 0; i < 6; i++) fprintf(stderr, "[tm_knn3 stamps] %-24s %6.2f %% of the consume kernel's wave time\n", names3[i], 100.0 * (double)cnt[6 + i] / (double)cnt[11]);
     static const char *names_s[7] = {"set-up", "wait: first slice + tile", "wait: later slices", "blocks", "end barrier", "results", "total"};
     for (int i = 0; i < 7; i++) fprintf(stderr, "[tm_knn3 stamps] seeds: %-24s %6.2f %% of wave time (%.0f clock ticks per wave)\n", names_s[i], 100.0 * (double)cnt[22 + i] / (double)cnt[28],

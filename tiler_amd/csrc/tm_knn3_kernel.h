@@ -726,6 +726,11 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
         int ntile = 0, nlb = 0;
         unsigned nmask = 0, ntm = 0;
         const bool nhave = next_entry(ntile, ntm, nlb, nmask);
+#if TM_KNN3_STAMPS
+        K3_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        K3_STAMP(4);  // waiting for the tile's loads (what is left of their latency behind the choice of the next entry)
+#endif
         const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
         while (mask) {
           const int s = __builtin_ctz(mask);
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
       a.best_tile[q] = (int)(((unsigned)k & 0x3fffffffu) | (s_tie[i] == hi ? (1u << 30) : 0u));
     }
   }
-  K3_STAMP(4);  // results
+  K3_STAMP(0);  // results (counted with the prologue)
   }  // next query group
 #if TM_KNN3_STAMPS
   if (a.stats && lane == 0) {

@@ -151,7 +151,7 @@ void knobs_reload() {
   k.knn_debug = on("TM_KNN_DEBUG"); k.knn_noprune = on("TM_KNN_NOPRUNE"); k.topk_brute = on("TM_TOPK_BRUTE"); k.no_query_groups = on("TM_NO_QUERY_GROUPS");
   k.dither_own_keys = on("TM_DITHER_OWN_KEYS"); k.dither_no_dedup = on("TM_DITHER_NO_DEDUP"); k.dither_literal = on("TM_DITHER_LITERAL");
   k.dedup_plain = on("TM_DEDUP_PLAIN"); k.dedup_degrade_hash = on("TM_DEDUP_DEGRADE_HASH"); k.dedup_full_order = on("TM_DEDUP_FULL_ORDER");
-  k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST");
+  k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST"); k.features_plain = on("TM_FEATURES_PLAIN");
   if (const char *v = getenv("TM_EPU_TABLE_GIB")) k.epu_table_gib = atof(v);
   if (const char *v = getenv("TM_COMM_TIMEOUT_S")) k.comm_timeout_s = std::max(1.0, atof(v));
   t_knobs = k;
@@ -246,6 +246,10 @@ int get_tables(const DeviceTables **out) {
             }
       TM_TRY(upload(&t.dct_lut_f64[special], l64.data(), 4096));
       TM_TRY(upload(&t.dct_lut_f32[special], l32.data(), 4096));
+      double cs[64];
+      for (int u = 0; u < 8; u++)
+        for (int x = 0; x < 8; x++) cs[u * 8 + x] = std::cos((x + 0.5) * u * M_PI / div);
+      TM_TRY(upload(&t.dct_cos_f64[special], cs, 64));
     }
     TM_TRY(upload(&t.weights, &kDCTWeights[0][0][0], 192));
     float srgb[256];  // utils.pas:378-384: r := ir/255.0 (Single); gamma expansion; stored back into a Single

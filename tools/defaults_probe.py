@@ -19,7 +19,7 @@ enc = TilingEncoder()
 enc.LoadDefaultSettings()
 enc.PaletteCount = 16
 enc.MotionPredictRadius = radius
-enc.FrameTilingExtendedPaletteUsage = True
+enc.FrameTilingExtendedPaletteUsage = (int(sys.argv[3]) != 0) if len(sys.argv) > 3 else True
 enc.SetVideo(W, H, 24.0, F)
 enc.SetFramesDevice(frames)
 for r in range(reps):
