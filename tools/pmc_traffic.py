@@ -12,23 +12,27 @@ import sys
 out, tag = sys.argv[1], sys.argv[2]
 has_dense = "--dense" in sys.argv[3:]
 rows = {}
+consume_name = "k_knn_consume"
 for line in open(os.path.join(out, "summary.txt")).read().splitlines()[1:]:
     f = line.split(",")
     pas, disp = f[0], int([x for x in f if x.isdigit()][0])  # (the kernel's template arguments hold commas too: the first all-digit field is the dispatch)
     kern = next((k for k in ("k_knn_seed", "k_knn_lists", "k_knn_consume") if k in line), None)
     if kern is None:
         continue
+    if kern == "k_knn_consume":
+        consume_name = line.split("tmx::")[1].split(",%d," % disp)[0]
     c = {x.split("=")[0]: float(x.split("=")[1]) for x in f if "=" in x}
     rows.setdefault((pas, kern), []).append((disp, c))
 for v in rows.values():
     v.sort()
 
 
-def launches(pas, kern):
+def launches(pas, kern):  # (pruned launches, dense launch): the run's FIRST search sizes its list arena from a guess and is repeated -- left out
     v = rows.get((pas, kern), [])
+    dense = []
     if kern == "k_knn_consume" and has_dense:
-        return v[:-1], v[-1:]
-    return v, []
+        v, dense = v[:-1], v[-1:]
+    return v[-2:], dense
 
 
 def mean(xs):
@@ -65,7 +69,7 @@ lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
 lib.tm_version.restype = ctypes.c_char_p
 print(json.dumps({
     "kernel_build": lib.tm_version().decode(),
-    "kernel": "k_knn_consume<6,6,true,false>",
+    "kernel": consume_name,
     "workload": "1280x720 x 300, 16 palettes (bench.py default)",
     "traffic_bytes": cons["traffic_bytes"],
     "fetch_size_kib_per_launch": cons["fetch_size_kib_per_launch"],
