@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
     for (int d = 0; d < KNN_NC; d++) qv[d] = qrow[bx.col[d]];
     if (threadIdx.x == 0) { s_min = 0xffffffffu; s_nt = 0; s_ng = 0; }
     __syncthreads();
-    unsigned int mine = 0xffffffffu;
+    // (the scan's winner reaches the minimum: only rows of a LOWER original index can replace it, the others are not even read)
+    unsigned int mine = (unsigned int)out_idx[q];
     auto rows = [&](int64_t t, int r0, int r1) {
       for (int r = r0; r < r1; r++) {
         const int64_t sr = t * 32 + r;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) void k_knn_ties(const int16_t *__restrict__ qu
     __syncthreads();
     const int total = min(s_nt, 2048) * 32;
     for (int e = threadIdx.x; e < total; e += 256) rows(s_tlist[e >> 5], e & 31, (e & 31) + 1);
-    if (mine != 0xffffffffu) atomicMin(&s_min, mine);
+    if (mine != (unsigned int)out_idx[q]) atomicMin(&s_min, mine);
     __syncthreads();
     if (threadIdx.x == 0 && s_min != 0xffffffffu) out_idx[q] = (int)s_min;
     __syncthreads();
