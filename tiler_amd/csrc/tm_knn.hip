@@ -702,7 +702,10 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
 //  3. k_topk_select: exact SSD (d'' + the query norm's parity bit), original row index, rank by (SSD, index), first k out.
 //     A query whose list overflowed lowers its tau to the k-th smallest of what it did store (still a valid bound) and is
 //     scanned again with the other overflowed queries.
-constexpr int TOPK_WINDOW_DEFAULT = 32;  // tiles (of 32 rows) sampled for the first threshold (8: 1.45 s, 32: 0.99 s, 128: 1.00 s on the bench clip)
+#ifndef TM_TOPK_WINDOW
+#define TM_TOPK_WINDOW 32
+#endif
+constexpr int TOPK_WINDOW_DEFAULT = TM_TOPK_WINDOW;  // tiles (of 32 rows) sampled for the first threshold (8: 1.45 s, 32: 0.99 s, 128: 1.00 s on the bench clip)
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int topk_dot2(uint32_t a, uint32_t b, int c) {
@@ -735,8 +738,29 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
   int64_t start = max((int64_t)0, lo - 1 - window / 2);
   start = min(start, max((int64_t)0, ntt - window));
   const int64_t r0 = start * 32, r1 = min(nt, (start + window) * 32);
+  // The k smallest so far sit in LDS [slot][lane]; what decides whether a row enters is their largest.  The slots are taken in groups
+  // of eight with each group's largest (and where it sits) in registers: replacing the largest re-reads ITS group only -- with 64 lanes
+  // some lane replaces at almost every row, and a re-scan of all k slots per row was three quarters of this kernel.
   int cnt = 0, mslot = 0;
   uint32_t mx = 0;
+  uint32_t gm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int gs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int ngr = (k + 7) >> 3;
+  auto regroup = [&](int g) {  // group g's largest and its slot, then the overall ones
+    uint32_t m = 0;
+    int at = g * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int sl = g * 8 + i;
+      const uint32_t v = sl < k ? s_d[sl * 64 + lane] : 0u;
+      if (sl < k && (v > m || i == 0)) { m = v; at = sl; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (j == g) { gm[j] = m; gs[j] = at; }
+    mx = gm[0]; mslot = gs[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) if (j < ngr && gm[j] > mx) { mx = gm[j]; mslot = gs[j]; }
+  };
   for (int64_t r = r0; r < r1; r++) {
     const uint32_t *row = db + (int64_t)tperm[r] * 96;
     int acc = 0;
@@ -745,15 +769,12 @@ __global__ __launch_bounds__(64) void k_topk_tau(const uint32_t *__restrict__ qu
     const uint32_t d = qn + tnorm[r] - 2u * (uint32_t)acc;
     if (cnt < k) {
       s_d[cnt * 64 + lane] = d;
-      if (d > mx || cnt == 0) { mx = d; mslot = cnt; }
       cnt++;
+      if (cnt == k)
+        for (int g = 0; g < ngr; g++) regroup(g);
     } else if (d < mx) {
       s_d[mslot * 64 + lane] = d;
-      mx = 0;
-      for (int s = 0; s < k; s++) {
-        const uint32_t v = s_d[s * 64 + lane];
-        if (v > mx) { mx = v; mslot = s; }
-      }
+      regroup(mslot >> 3);
     }
   }
   tau[p] = (cnt >= k && mx < 0x7fffffffu) ? (int)mx : 0x7ffffffe;  // fewer than k rows in the window: everything is a candidate
