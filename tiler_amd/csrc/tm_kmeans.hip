@@ -723,7 +723,7 @@ __device__ __forceinline__ int quad_bcast(int v) {  // lane Q of every group of 
   return __builtin_amdgcn_update_dpp(0, v, Q | (Q << 2) | (Q << 4) | (Q << 6), 0xf, 0xf, true);
 }
 
-__global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
+__device__ __forceinline__ void assign192_list4_body(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
                                                          const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
                                                          int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
                                                          double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
@@ -867,6 +867,125 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
     if (j == D) atomicAdd(&cnts[c], v);
     else atomicAdd(&sums[(int64_t)c * D + j], v);
   }
+}
+
+// The same for at most KCH centroids, a lane per (point, centroid) pair: 16 points per pass of a workgroup, their rows staged through
+// LDS (the 16 lanes of a point read one address), one chain of 192 terms per lane instead of four of them.  Late in a clustering the list
+// holds a few thousand points: with 64 points per workgroup that was 16-80 busy workgroups each working through four-chain passes; here
+// it is four times as many workgroups with passes a third as long.  Every accumulator still sums its 192 terms in order; the 16 lanes'
+// (best, second best) merge by (distance, centroid index), which is what the in-order scan with its strict `<` computes.
+constexpr int L16_P = 16;
+__device__ __forceinline__ void assign192_list16_body(const int32_t *__restrict__ pts, int64_t n_total, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
+                                                          const double *__restrict__ cent_t /* [192][kt] */, int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums,
+                                                          u64 *__restrict__ cnts, const int *__restrict__ quiet, double *__restrict__ ub, double *__restrict__ lb,
+                                                          const int32_t *__restrict__ need, const unsigned *__restrict__ need_cnt) {
+  if (*quiet >= 0) return;
+  constexpr int D = 192;
+  const unsigned cnt = *need_cnt;
+  if (blockIdx.x * (unsigned)L16_P >= cnt) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  double *const s_c = reinterpret_cast<double *>(s_raw);                 // [D][KCH] (zero beyond kk: cent_t is)
+  u64 *const s_delta = reinterpret_cast<u64 *>(s_raw + D * KCH * 8);    // [kk][D + 1]
+  __shared__ __attribute__((aligned(16))) int s_rows[L16_P * D];
+  __shared__ int s_moved[L16_P * 3], s_gi[L16_P], s_nmoved;
+  const int kk = segs[0].kk, tid = threadIdx.x, pslot = tid >> 4, cl = tid & 15, wave = tid >> 6, lane = tid & 63;
+  auto stage = [&](unsigned row0, int4 (&x)[3]) {  // the pass's rows: 16 x 768 bytes, three 16-byte pieces per thread
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int piece = u * 256 + tid, pr = piece / 48, off = piece - pr * 48;
+      const int64_t gi = need[min(row0 + (unsigned)pr, cnt - 1)];
+      x[u] = reinterpret_cast<const int4 *>(pts + gi * D)[off];
+    }
+  };
+  int4 x[3];
+  stage(blockIdx.x * (unsigned)L16_P, x);
+  for (int e = tid; e < kk * (D + 1); e += 256) s_delta[e] = 0;
+  if (tid == 0) s_nmoved = 0;
+  for (int e = tid; e < D * KCH; e += 256) s_c[e] = cent_t[(int64_t)(e / KCH) * kt + (e % KCH)];
+  int total_moved = 0;
+#pragma unroll 1
+  for (unsigned row0 = blockIdx.x * (unsigned)L16_P; row0 < cnt; row0 += gridDim.x * (unsigned)L16_P) {
+    __syncthreads();  // the rows of the pass before are no longer read (first pass: s_c, s_delta are whole)
+#pragma unroll
+    for (int u = 0; u < 3; u++) reinterpret_cast<int4 *>(s_rows)[u * 256 + tid] = x[u];
+    if (tid < L16_P) s_gi[tid] = need[min(row0 + (unsigned)tid, cnt - 1)];
+    __syncthreads();
+    {
+      const unsigned nrow0 = row0 + gridDim.x * (unsigned)L16_P;
+      if (nrow0 < cnt) stage(nrow0, x);  // the next pass's rows, while this one is scored
+    }
+    const bool active = row0 + pslot < cnt;
+    const int64_t gi = s_gi[pslot];
+    double sacc = 0.0;
+    {
+      const int *rp = s_rows + pslot * D;
+      const double *cp = s_c + cl;
+#pragma unroll 16
+      for (int j = 0; j < D; j++) {
+        const double t0 = __dsub_rn((double)rp[j], cp[j * KCH]);
+        sacc = __fma_rn(t0, t0, sacc);
+      }
+    }
+    double bd = cl < kk ? sacc : 1.0e300, bd2 = 1.0e300;
+    int bc = cl < kk ? cl : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
+      const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
+      const int oc = __shfl_xor(bc, o);
+      const bool take = od < bd || (od == bd && oc < bc);
+      const double loser = take ? bd : od;
+      bd2 = fmin(fmin(bd2, od2), loser);
+      if (take) { bd = od; bc = oc; }
+    }
+    if (active && cl == 0) {
+      ub[gi] = sqrt(bd) * (1.0 + 1e-12);
+      lb[gi] = sqrt(bd2) * (1.0 - 1e-12);
+      const int old = assign[gi];
+      if (old != bc) {
+        assign[gi] = bc;
+        const int m = atomicAdd(&s_nmoved, 1);
+        s_moved[m * 3] = pslot; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
+      }
+    }
+    __syncthreads();
+    const int nmoved = s_nmoved;
+    total_moved += nmoved;
+    for (int e = wave; e < nmoved; e += 4) {  // a wave per moved row between the carried sums (its row is still in LDS)
+      const int old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2], ps = s_moved[e * 3];
+      const int64_t mi = s_gi[ps];
+      const long long wi = w ? (long long)w[mi] : 1;
+#pragma unroll
+      for (int j = lane; j <= D; j += 64) {
+        const u64 v = j < D ? (u64)(wi * s_rows[ps * D + j]) : (u64)wi;
+        atomicAdd(&s_delta[nw * (D + 1) + j], v);
+        if (old >= 0) atomicAdd(&s_delta[old * (D + 1) + j], (u64)0 - v);
+      }
+    }
+    __syncthreads();  // the moved list has been read
+    if (tid == 0) s_nmoved = 0;
+  }
+  if (total_moved == 0) return;
+  if (tid == 0) atomicAdd(&segs[0].changed, total_moved);
+  for (int e = tid; e < kk * (D + 1); e += 256) {
+    const u64 v = s_delta[e];
+    if (v == 0) continue;
+    const int c = e / (D + 1), j = e - c * (D + 1);
+    if (j == D) atomicAdd(&cnts[c], v);
+    else atomicAdd(&sums[(int64_t)c * D + j], v);
+  }
+}
+
+// The list kernel: the four-lanes-per-point passes for long lists (the early iterations: tens of thousands of unproven points, where 64
+// points per pass keep the chip's double-precision pipes full), the lane-per-pair passes for short ones (measured on the two bench
+// clips: 31.9 against 21.7 microseconds per launch over the frozen clip's 87 iterations, 17.3 against 19.7 over the literal clip's 295).
+constexpr unsigned LIST16_BELOW = 8192;
+__global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
+                                                         const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
+                                                         int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
+                                                         double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
+                                                         const unsigned *__restrict__ need_cnt) {
+  if (need && k <= KCH && *need_cnt < LIST16_BELOW) assign192_list16_body(pts, n_total, w, segs, cent_t, kt, assign, sums, cnts, quiet, ub, lb, need, need_cnt);
+  else assign192_list4_body(pts, pts_chunked, n_total, w, segs, k, cent_t, kt, assign, sums, cnts, quiet, ub, lb, need, need_cnt);
 }
 
 // the seeds' centroids into the transposed copy the list kernels read (k_h_update keeps it current afterwards)
@@ -1573,7 +1692,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         } else {
           hipLaunchKernelGGL(k_h_bounds, dim3(gb), dim3(256), 0, stream, pts, n, ds, (const double *)cent, assign, hub.as<double>(), hlb.as<double>(), hmove.as<double>(),
                              hhalf.as<double>(), k, hneed.as<int32_t>(), hcnt.as<unsigned>(), quiet.as<int>());
-          hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)std::min<int64_t>((n + 63) / 64, 768)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
+          hipLaunchKernelGGL(k_assign192_list4, dim3((unsigned)std::min<int64_t>((n + 63) / 64, k <= KCH ? 1024 : 768)), dim3(256), l_lds, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, hcent_t.as<double>(), h_kt, assign, sums.as<u64>(),
                              cnts.as<u64>(), quiet.as<int>(), hub.as<double>(), hlb.as<double>(), hneed.as<int32_t>(), hcnt.as<unsigned>());
         }
         hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
