@@ -978,7 +978,10 @@ __device__ __forceinline__ void assign192_list16_body(const int32_t *__restrict_
 // The list kernel: the four-lanes-per-point passes for long lists (the early iterations: tens of thousands of unproven points, where 64
 // points per pass keep the chip's double-precision pipes full), the lane-per-pair passes for short ones (measured on the two bench
 // clips: 31.9 against 21.7 microseconds per launch over the frozen clip's 87 iterations, 17.3 against 19.7 over the literal clip's 295).
-constexpr unsigned LIST16_BELOW = 8192;
+#ifndef TM_LIST16_BELOW
+#define TM_LIST16_BELOW 8192
+#endif
+constexpr unsigned LIST16_BELOW = TM_LIST16_BELOW;
 __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
                                                          const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
                                                          int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
@@ -1000,24 +1003,35 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
                                                    double *__restrict__ cent_t /* [192][kt], zero beyond kk */, int kt, double *__restrict__ cmove,
                                                    double *__restrict__ shalf, unsigned *__restrict__ need_cnt, int it, int *__restrict__ quiet_iter,
                                                    int *host_quiet = nullptr /* page-locked host word that gets the flag too */) {
-  if (*quiet_iter >= 0) return;
   extern __shared__ double s_new[];  // [kk][193] (odd pitch: the pair loop reads two rows at once)
   __shared__ unsigned long long s_min[H_MAXK];
   __shared__ double s_move[H_MAXK];
-  const int kk = segs[0].kk, tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (the first centroid of every wave is asked for together with the two words that say how many there are and whether anything moved:
+  // one round trip to memory instead of two at the head of a launch that is all latency)
+  u64 cn0 = 0, sm0[3] = {0, 0, 0};
+  double old0[3] = {0.0, 0.0, 0.0};
+  if (wave < k) {
+    cn0 = cnts[wave];
+#pragma unroll
+    for (int u = 0; u < 3; u++) { old0[u] = cent[wave * 192 + lane + 64 * u]; sm0[u] = sums[wave * 192 + lane + 64 * u]; }
+  }
+  const int kk = segs[0].kk;
   const bool changed = segs[0].changed != 0;
-  const int wave = tid >> 6, lane = tid & 63;
+  if (*quiet_iter >= 0) return;
   auto wave_sum = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
   if (tid < H_MAXK) s_min[tid] = 0x7ff0000000000000ull;  // +inf
   if (tid == 0) *need_cnt = 0;
   // a wave per centroid, 3 dimensions per lane: new position, displacement (the sums only feed the bounds, margins of 1e-9: their order is free)
   for (int c = wave; c < kk; c += 16) {
-    const u64 cn = cnts[c];
+    const u64 cn = c == wave ? cn0 : cnts[c];
     double sd = 0.0;
-    for (int j = lane; j < 192; j += 64) {
-      const double old = cent[c * 192 + j];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      const int j = lane + 64 * u;
+      const double old = c == wave ? old0[u] : cent[c * 192 + j];
       double nw = old;
-      if (changed && cn > 0) { nw = __ddiv_rn((double)(long long)sums[c * 192 + j], (double)(long long)cn); cent[c * 192 + j] = nw; }
+      if (changed && cn > 0) { nw = __ddiv_rn((double)(long long)(c == wave ? sm0[u] : sums[c * 192 + j]), (double)(long long)cn); cent[c * 192 + j] = nw; }
       s_new[c * 193 + j] = nw;
       cent_t[(int64_t)j * kt + c] = nw;
       const double t = nw - old;
