@@ -609,16 +609,26 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
                                                   const double *__restrict__ cmove /* [k] displacement of each centroid, then the largest, the second largest, whose */,
                                                   const double *__restrict__ shalf /* [k] half the distance to the nearest other centroid */, int k,
                                                   int32_t *__restrict__ need, unsigned *__restrict__ need_cnt, const int *__restrict__ quiet) {
-  if (*quiet >= 0) return;
   __shared__ int s_list[H_SLICE], s_need[H_SLICE];
   __shared__ int s_nlist, s_nneed;
   __shared__ unsigned s_base;
   const int tid = threadIdx.x;
-  if (tid == 0) { s_nlist = 0; s_nneed = 0; }
-  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
+  // (the slice's assignments and bounds are asked for together with the flag and the displacements: one round trip, not two)
+  constexpr int RB = H_SLICE / 256;
+  int b_a[RB];
+  double b_u[RB], b_l[RB];
+#pragma unroll
+  for (int r = 0; r < RB; r++) {
+    const int64_t i = i0 + r * 256 + tid;
+    const int64_t ii = i < n ? i : i0;  // (the slice's first point exists)
+    b_a[r] = assign[ii]; b_u[r] = ub[ii]; b_l[r] = lb[ii];
+  }
   const double dmax = cmove[k], dmax2 = cmove[k + 1];
   const int amax = (int)cmove[k + 2];
-  const int64_t i0 = (int64_t)blockIdx.x * H_SLICE;
+  if (*quiet >= 0) return;
+  if (tid == 0) { s_nlist = 0; s_nneed = 0; }
+  __syncthreads();
   // pass 1, every point of the slice: move the bounds with the centroids; the points whose loosened bounds no longer prove them -> LDS list.
   // The four points of a thread go through it side by side -- their loads first, then the table look-ups that depend on them, then the
   // arithmetic, one list append per wave: with a loop that could leave early and an LDS atomic per listed point the compiler kept the
@@ -630,10 +640,8 @@ __global__ __launch_bounds__(256) void k_h_bounds(const int32_t *__restrict__ pt
     bool valid[R], listed[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const int64_t i = i0 + r * 256 + tid;
-      valid[r] = i < n;
-      const int64_t ii = valid[r] ? i : i0;  // (the slice's first point exists)
-      a[r] = assign[ii]; u[r] = ub[ii]; l[r] = lb[ii];
+      valid[r] = i0 + r * 256 + tid < n;
+      a[r] = b_a[r]; u[r] = b_u[r]; l[r] = b_l[r];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) { mv[r] = cmove[a[r]]; sh[r] = shalf[a[r]]; }
@@ -725,12 +733,10 @@ __device__ __forceinline__ int quad_bcast(int v) {  // lane Q of every group of 
 
 __device__ __forceinline__ void assign192_list4_body(const int32_t *__restrict__ pts, const int32_t *__restrict__ pts_chunked, int64_t n_total,
                                                          const uint32_t *__restrict__ w, Seg *__restrict__ segs, int k, const double *__restrict__ cent_t /* [192][kt] */,
-                                                         int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
+                                                         int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts,
                                                          double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
-                                                         const unsigned *__restrict__ need_cnt) {
-  if (*quiet >= 0) return;
+                                                         const unsigned cnt /* the list's length; no list: every point */) {
   constexpr int D = 192, NP = 64, CPL = KCH / 4;  // points per pass of a workgroup, centroids per lane and pass
-  const unsigned cnt = need ? *need_cnt : (unsigned)n_total;  // no list: every point (the plain iterations)
   if (blockIdx.x * (unsigned)NP >= cnt) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ int s_nmoved;
@@ -877,11 +883,9 @@ __device__ __forceinline__ void assign192_list4_body(const int32_t *__restrict__
 constexpr int L16_P = 16;
 __device__ __forceinline__ void assign192_list16_body(const int32_t *__restrict__ pts, int64_t n_total, const uint32_t *__restrict__ w, Seg *__restrict__ segs,
                                                           const double *__restrict__ cent_t /* [192][kt] */, int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums,
-                                                          u64 *__restrict__ cnts, const int *__restrict__ quiet, double *__restrict__ ub, double *__restrict__ lb,
-                                                          const int32_t *__restrict__ need, const unsigned *__restrict__ need_cnt) {
-  if (*quiet >= 0) return;
+                                                          u64 *__restrict__ cnts, double *__restrict__ ub, double *__restrict__ lb,
+                                                          const int32_t *__restrict__ need, const unsigned cnt) {
   constexpr int D = 192;
-  const unsigned cnt = *need_cnt;
   if (blockIdx.x * (unsigned)L16_P >= cnt) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   double *const s_c = reinterpret_cast<double *>(s_raw);                 // [D][KCH] (zero beyond kk: cent_t is)
@@ -987,8 +991,11 @@ __global__ __launch_bounds__(256) void k_assign192_list4(const int32_t *__restri
                                                          int kt, int32_t *__restrict__ assign, u64 *__restrict__ sums, u64 *__restrict__ cnts, const int *__restrict__ quiet,
                                                          double *__restrict__ ub, double *__restrict__ lb, const int32_t *__restrict__ need,
                                                          const unsigned *__restrict__ need_cnt) {
-  if (need && k <= KCH && *need_cnt < LIST16_BELOW) assign192_list16_body(pts, n_total, w, segs, cent_t, kt, assign, sums, cnts, quiet, ub, lb, need, need_cnt);
-  else assign192_list4_body(pts, pts_chunked, n_total, w, segs, k, cent_t, kt, assign, sums, cnts, quiet, ub, lb, need, need_cnt);
+  const int q0 = *quiet;                                   // (the two control words in one round trip)
+  const unsigned cnt0 = need ? *need_cnt : (unsigned)n_total;
+  if (q0 >= 0) return;
+  if (need && k <= KCH && cnt0 < LIST16_BELOW) assign192_list16_body(pts, n_total, w, segs, cent_t, kt, assign, sums, cnts, ub, lb, need, cnt0);
+  else assign192_list4_body(pts, pts_chunked, n_total, w, segs, k, cent_t, kt, assign, sums, cnts, ub, lb, need, cnt0);
 }
 
 // the seeds' centroids into the transposed copy the list kernels read (k_h_update keeps it current afterwards)
