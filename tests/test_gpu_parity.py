@@ -107,6 +107,12 @@ def test_features_first_look_agrees_with_reference_order(mode, use_lab, monkeypa
     monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
     diff = (fast != plain)
     assert not bool(diff.any()), "%d of %d coefficients differ, first at %s" % (int(diff.sum()), diff.numel(), torch.nonzero(diff)[0].tolist())
+    if mode == 4 and use_lab:  # the clustering's int32 features (k_features_cluster_i32) take the same first look
+        cfast = stages.features_cluster(t, mode)
+        monkeypatch.setenv("TM_FEATURES_PLAIN", "1")
+        cplain = stages.features_cluster(t, mode)
+        monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
+        assert torch.equal(cfast, cplain)
 
 
 def test_features_pal_and_cluster(tiles_flags, oracle):

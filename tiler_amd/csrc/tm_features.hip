@@ -268,17 +268,19 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
 __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__restrict__ tiles, int64_t n, int weighted,
                                                               const double *__restrict__ lut, const double *__restrict__ weights,
                                                               const uint8_t *__restrict__ snake, const float *__restrict__ srgb_lut,
-                                                              int32_t *__restrict__ out) {
-  // the planes as DOUBLES: every lane multiplies the same 192 plane values by its own LUT row, so they are widened once, by the lane that
-  // made them, instead of 192 times in every lane (v_cvt_f64_f32 runs at half rate: 204 of them were a third of the kernel)
+                                                              int32_t *__restrict__ out, const double *__restrict__ cosd /* [8][8] the LUT's cosine factor */, int plain) {
+  // the planes as DOUBLES, widened once by the lane that made them
   __shared__ __attribute__((aligned(16))) double s_cpn[2][4][192];
+  __shared__ __attribute__((aligned(16))) double s_row[4][64];  // a wave's row transforms, [u][y]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double l[64];
+  // The reference sums a coefficient's 64 double products one after the other (DCTInner<PDouble>, utils.pas:782-872) and stores Round(z w).
+  // As in k_features_i16: z first by the LUT's two cosine factors (a row transform shared through LDS, then a column transform: 16 fused
+  // multiply-adds), which differs from the sequential sum by less than 128 x 2^-53 x sum|pixel x LUT| < 4e-10 here (|pixel| <= 128, 64
+  // of them, |w| < 2.7); a coefficient whose z w lies within 1e-6 of a half-integer -- two in a million -- is summed the reference's way.
+  double au[8], av[8];
 #pragma unroll
-  for (int k = 0; k < 64; k += 2) {
-    const double2 v = *reinterpret_cast<const double2 *>(lut + lane * 64 + k);
-    l[k] = v.x; l[k + 1] = v.y;
-  }
+  for (int x = 0; x < 8; x++) { au[x] = cosd[(lane & 7) * 8 + x]; av[x] = cosd[(lane >> 3) * 8 + x]; }
+  const double ruv = (lane == 0) ? 0.5 : (((lane & 7) == 0 || (lane >> 3) == 0) ? 0.707106769084930419921875 : 1.0);
   double w[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) w[c] = weights[c * 64 + lane];
@@ -296,20 +298,46 @@ __global__ __launch_bounds__(256) void k_features_cluster_i32(const uint32_t *__
       s_cpn[buf][wave][64 + lane] = (double)uu;
       s_cpn[buf][wave][128 + lane] = (double)vv;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave reads only what it wrote: its LDS operations are in order)
     if (valid) {
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const double *cp = &s_cpn[buf][wave][c * 64];
-        double r = 0.0;
-#pragma unroll
-        for (int k = 0; k < 64; k += 2) {
-          const double2 cv = *reinterpret_cast<const double2 *>(cp + k);
-          r = __dadd_rn(r, __dmul_rn(cv.x, l[k]));
-          r = __dadd_rn(r, __dmul_rn(cv.y, l[k + 1]));
+        auto in_order = [&]() -> double {  // the reference's sum
+          double r = 0.0;
+          for (int k = 0; k < 64; k += 2) {
+            const double2 cv = *reinterpret_cast<const double2 *>(cp + k);
+            const double2 lv = *reinterpret_cast<const double2 *>(lut + lane * 64 + k);
+            r = __dadd_rn(r, __dmul_rn(cv.x, lv.x));
+            r = __dadd_rn(r, __dmul_rn(cv.y, lv.y));
+          }
+          return weighted ? __dmul_rn(r, w[c]) : r;
+        };
+        double tv = 0.0;
+        bool doubtful = true;
+        if (!plain) {
+          const double2 *fp = reinterpret_cast<const double2 *>(cp + (lane >> 3) * 8);
+          const double2 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
+          double r = au[0] * f0.x;
+          r = fma(au[1], f0.y, r); r = fma(au[2], f1.x, r); r = fma(au[3], f1.y, r);
+          r = fma(au[4], f2.x, r); r = fma(au[5], f2.y, r); r = fma(au[6], f3.x, r); r = fma(au[7], f3.y, r);
+          s_row[wave][(lane & 7) * 8 + (lane >> 3)] = r;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          const double2 *rp = reinterpret_cast<const double2 *>(&s_row[wave][(lane & 7) * 8]);
+          const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          double z = av[0] * r0.x;
+          z = fma(av[1], r0.y, z); z = fma(av[2], r1.x, z); z = fma(av[3], r1.y, z);
+          z = fma(av[4], r2.x, z); z = fma(av[5], r2.y, z); z = fma(av[6], r3.x, z); z = fma(av[7], r3.y, z);
+          z *= ruv;
+          tv = weighted ? z * w[c] : z;
+          doubtful = !(fabs(tv - floor(tv) - 0.5) > 1e-6) || !(fabs(tv) < 1.0e9);
         }
-        if (weighted) r = __dmul_rn(r, w[c]);
-        out[t * 192 + c * 64 + zz] = (int32_t)__double2ll_rn(r);
+        if (__builtin_amdgcn_ballot_w64(doubtful)) {  // (uniform)
+          const double ex = in_order();
+          if (doubtful) tv = ex;
+        }
+        out[t * 192 + c * 64 + zz] = (int32_t)__double2ll_rn(tv);
       }
     }
   }
@@ -533,7 +561,7 @@ int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, h
   if (n <= 0) return TM_OK;
   hipLaunchKernelGGL(k_features_cluster_i32, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, n,
                      mode_weighted(mode) ? 1 : 0, tab->dct_lut_f64[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut,
-                     (int32_t *)out);
+                     (int32_t *)out, tab->dct_cos_f64[mode_special(mode)], knobs().features_plain ? 1 : 0);
   TM_HIP(hipGetLastError());
   return TM_OK;
 }
