@@ -231,12 +231,24 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restric
   uint4 *const s_rows = reinterpret_cast<uint4 *>(s_dyn + ((max_own * (KM_WORDS + 1) + 3 * (2 * KM_BIN + 8) + 3) & ~3));  // [KM_STAGE][5]: their points
   __shared__ unsigned s_nrel;
   __shared__ int s_hist[KM_WT / 64][256];
+  // (what the launch needs from memory and can name at once -- the count of pending moves, the bin's own points -- is asked for here,
+  // with the modes: a round trip each that the launch, which is all latency, does not wait for later)
+  const unsigned nmv = first ? 0u : *st.nmoves;
+  const int64_t b0 = max((int64_t)0, bin) * KM_BIN, b1 = min(b0 + (int64_t)KM_BIN, n);
+  const int nb = bin < 0 ? 0 : (int)(b1 - b0);
+  uint32_t p[KM_WORDS];
+  if (tid < nb) {
+#pragma unroll
+    for (int q = 0; q < KM_WORDS; q += 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(rows) + (b0 + tid) * KM_WORDS + q);
+      p[q] = v.x; p[q + 1] = v.y; p[q + 2] = v.z; p[q + 3] = v.w;
+    }
+  }
   for (int e = tid; e < KM_WT / 64 * 256; e += KM_WT) (&s_hist[0][0])[e] = 0;
   for (int e = tid; e < nown * KM_WORDS; e += KM_WT) s_mode[e] = reinterpret_cast<const uint32_t *>(st.cent)[(size_t)(w + (e / KM_WORDS) * G) * KM_WORDS + e % KM_WORDS];
   for (int e = tid; e < nown; e += KM_WT) s_touch[e] = 0;
   if (tid == 0) s_nrel = 0;
   __syncthreads();
-  const unsigned nmv = first ? 0u : *st.nmoves;
   if (nmv > 0) {
     // ---- MovePointCat's histogram side (774-803) for the owned clusters, a wave per (cluster, attribute) pair
     if (wave == 0) {  // ordered compaction of the relevant moves
@@ -345,15 +357,7 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restric
   }
   if (bin < 0) return;
   // ---- the bin's points against the owned modes as they stand now
-  const int64_t b0 = bin * KM_BIN, b1 = min(b0 + (int64_t)KM_BIN, n);
-  const int nb = (int)(b1 - b0);
   if (tid < nb) {
-    uint32_t p[KM_WORDS];
-#pragma unroll
-    for (int q = 0; q < KM_WORDS; q += 4) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(rows) + (b0 + tid) * KM_WORDS + q);
-      p[q] = v.x; p[q + 1] = v.y; p[q + 2] = v.z; p[q + 3] = v.w;
-    }
     // the owner's own arg-min: a distance has 18 bits (80 * (255 + 2048)), a cluster 12; among equal distances the LAST cluster wins
     unsigned key = 0xffffffffu;
     for (int oc = 0; oc < nown; oc++) key = min(key, (km_dissim(s_mode + oc * KM_WORDS, p) << 12) | (unsigned)(4095 - (w + oc * G)));
@@ -376,27 +380,35 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G
   // the bin's scores: the minimum over the owners' keys (smallest distance, then the LAST cluster: kmodes.pas:272, 414).  One workgroup
   // fetches all of them and a CU has only so many misses in flight: with a word per (point, cluster) -- 245 KB at 64 clusters -- this
   // fetch alone was 12 of the walker's 16 microseconds, so the owners are few (KM_MAX_OWNERS) and reduce their clusters themselves
+  // (all of the point's keys, its membership and the generator's seed in flight together: the launch is a chain of round trips to memory,
+  // and four batches of sixteen keys were four of them)
   unsigned long long cost = 0;
+  const uint32_t seed0 = *st.seed;
   if (tid < nb) {
+    static_assert(KM_MAX_OWNERS <= 64, "the walker holds one key per owner");
+    const int mb = st.memb[b0 + tid];
     unsigned key = 0xffffffffu;
-    for (int g0 = 0; g0 < G; g0 += 16) {
-      unsigned d[16];
+#ifndef TM_KM_WALKER_BATCH
+#define TM_KM_WALKER_BATCH 64
+#endif
+    for (int g0 = 0; g0 < G; g0 += TM_KM_WALKER_BATCH) {
+      unsigned d[TM_KM_WALKER_BATCH];
 #pragma unroll
-      for (int u = 0; u < 16; u++) d[u] = g0 + u < G ? partial[(size_t)(g0 + u) * KM_BIN + tid] : 0xffffffffu;
+      for (int u = 0; u < TM_KM_WALKER_BATCH; u++) d[u] = g0 + u < G ? partial[(size_t)(g0 + u) * KM_BIN + tid] : 0xffffffffu;
 #pragma unroll
-      for (int u = 0; u < 16; u++) key = min(key, d[u]);
+      for (int u = 0; u < TM_KM_WALKER_BATCH; u++) key = min(key, d[u]);
     }
     const unsigned best = key >> 12;
     const int res = 4095 - (int)(key & 4095u);
     s_cl[tid] = res;
-    s_mb[tid] = st.memb[b0 + tid];
+    s_mb[tid] = mb;
     cost = best;
   }
   for (int o = 32; o > 0; o >>= 1) cost += __shfl_xor(cost, o);
   if (lane == 0) s_cost[wave] = cost;
   __syncthreads();
   unsigned nmv = 0, moves = 0;
-  uint32_t seed = *st.seed;
+  uint32_t seed = seed0;
   int chunk = 0;                 // wave 0's place in the bin: 64 points at a time
   unsigned long long todo = 0;   // the chunk's points still to look at
   bool fresh = true;
