@@ -1257,7 +1257,14 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   const auto t_start = std::chrono::steady_clock::now();
   TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
-  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(512, ((int64_t)24 << 30) / (n * 8)));
+  // candidates a query may store: 512 in the first pass; the passes over the overflowed queries have far fewer queries and take what 24 GB
+  // hold, up to 1024 -- the threshold an overflowed query leaves is the k-th smallest of what it STORED, and on data whose distances
+  // bunch (the literal bench clip: four in five queries overflow the first pass) 512 stored rows moved it by a third per pass; 4096 made the
+  // select kernel's sort the cost instead (a pass of 826 000 queries: 522 ms against 25)
+#ifndef TM_TOPK_CAP_LATER
+#define TM_TOPK_CAP_LATER 1024
+#endif
+  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? 512 : TM_TOPK_CAP_LATER, ((int64_t)24 << 30) / (n * 8)));
   DevBuf tau, map_sorted, cand, cand_cnt, ovf, counter;
   TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
   TM_TRY(cand.alloc((size_t)n * cap * 8)); TM_TRY(cand_cnt.alloc((size_t)n * 4));
@@ -1332,6 +1339,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     launch_collect3(ix->plan.ht, ix->plan.hq, a, stream);
     TM_HIP(hipGetLastError());
   }
+  if ((size_t)topk_pow2(cap) * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topk_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)topk_pow2(cap) * 8));
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
