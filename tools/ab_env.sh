@@ -1,5 +1,5 @@
 #!/bin/bash
-# development aid: the headline bench with and without one environment switch, alternating, in one GPU call:  tools/ab_env.sh TM_KM_WARM_PLAIN=1
+# development aid: the headline bench with and without one environment switch, alternating, in one GPU call:  tools/ab_env.sh TM_NO_QUERY_GROUPS=1
 set -o pipefail
 mkdir -p gpurun_out
 for rep in 1 2; do

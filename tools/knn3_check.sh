@@ -1,5 +1,5 @@
 #!/bin/bash
-# development aid: KNN parity tests on the current build, then the headline bench (no extras) with the second and the third scan shape
+# development aid: KNN parity tests on the current build, then the headline bench (no extras) with the third scan shape
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_encoder.py -x -q -m gpu -k "knn or KNN or match or motion_search_q or topk or epu or extended" > gpurun_out/knn_tests.log 2>&1
