@@ -810,20 +810,30 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
   const int th = nofilter ? INT_MAX : tau[p];
   const uint32_t parity = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31] & 1u;
   int n = 0;
-  for (int base = 0; base < stored; base += 64) {
-    const int i = base + lane;
-    unsigned long long key = ~0ull;
-    bool valid = false;
-    if (i < stored) {
-      const uint2 c = cand[p * cap + i];
-      const int64_t srow = c.y;
+  // (the stored candidates are asked for eight chunks of 64 at a time: a chunk per round trip to memory was most of this kernel -- the sort
+  // below is 1.5 ms of the bench clip's 23)
+  for (int base0 = 0; base0 < stored; base0 += 512) {
+    uint2 cbuf[8];
+    uint32_t orow[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = base0 + u * 64 + lane; cbuf[u] = i < stored ? cand[p * cap + i] : make_uint2(0x7fffffffu, 0xffffffffu); }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {  // (the original indices of the rows that pass: gathered together as well)
+      const int i = base0 + u * 64 + lane;
       // signed, like the scan's own test: d'' = SSD - parity is -1 for an exact match of a query with an odd norm
-      valid = (int)c.x <= th && srow < nt;  // padded rows of the last tile replicate row nt-1: not rows
-      if (valid) key = ((unsigned long long)(c.x + parity) << 32) | tperm[srow];
+      ok[u] = i < stored && (int)cbuf[u].x <= th && (int64_t)cbuf[u].y < nt;  // padded rows of the last tile replicate row nt-1: not rows
+      orow[u] = ok[u] ? tperm[cbuf[u].y] : 0u;
     }
-    const unsigned long long m = __ballot(valid);
-    if (valid) s_key[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
-    n += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (base0 + u * 64 >= stored) break;  // (uniform)
+      const bool valid = ok[u];
+      const unsigned long long key = ((unsigned long long)(cbuf[u].x + parity) << 32) | orow[u];
+      const unsigned long long m = __ballot(valid);
+      if (valid) s_key[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
+      n += __popcll(m);
+    }
   }
   int n2 = 64;
   while (n2 < n) n2 <<= 1;
