@@ -153,12 +153,36 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr
     for (int kc = 0; kc < HT; kc++)
       if ((tm >> kc) & 1u)
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
+  }
+  // the first two operands of the last phase are asked for before the second shift's sixteen instructions, which hide part of their latency
+  // (asked for at the very top of the chain instead: four spilled registers, 12.35 against 12.30 ms)
+  v4i qa = *reinterpret_cast<const v4i *>(q), qb = *reinterpret_cast<const v4i *>(q + 1024);
+  __builtin_amdgcn_sched_barrier(0);
+  if (HT + HQ > 0) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
   }
-#pragma unroll
-  for (int kc = 0; kc < 6; kc++)
-    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);              // T_L . Q_L
+  // T_L . Q_L, always six products: the LDS read of product i + 1 is issued BEFORE the matrix instruction of product i (two operand
+  // buffers in turn; the scheduling barriers keep the order -- left alone the compiler reads each operand into the same four registers
+  // right after the instruction before it and waits out the whole LDS latency in front of every one of the six)
+  {
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[0], qa, acc, 0, 0, 0);
+    qa = *reinterpret_cast<const v4i *>(q + 2 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[1], qb, acc, 0, 0, 0);
+    qb = *reinterpret_cast<const v4i *>(q + 3 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[2], qa, acc, 0, 0, 0);
+    qa = *reinterpret_cast<const v4i *>(q + 4 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[3], qb, acc, 0, 0, 0);
+    qb = *reinterpret_cast<const v4i *>(q + 5 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[4], qa, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[5], qb, acc, 0, 0, 0);
+  }
   return acc;
 }
 
