@@ -512,6 +512,23 @@ def test_kmeans(oracle, n, d, k):
     assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64)), "centroids must match bit for bit"
 
 
+def test_kmeans_192_list_kernel_switches_shape_inside_a_clustering(oracle):
+    """60 000 points in loose clusters, 16 centroids: the first skipping iterations list more than 8 192 unproven points (the list kernel's
+    four-lanes-per-point passes), the later ones fewer (its lane-per-pair passes of 16 points): both shapes and the switch between them
+    inside one clustering, against the oracle's plain Lloyd"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(99)
+    n, d, k = 60000, 192, 16
+    centres = rng.integers(-1500, 1500, size=(40, d))
+    pts = (centres[rng.integers(0, 40, size=n)] + rng.integers(-700, 701, size=(n, d))).astype(np.int32)
+    w = rng.integers(1, 9, size=n).astype(np.uint32)
+    kk, assign, cent, iters = oracle.kmeans(pts, w, k)
+    g_kk, g_assign, g_cent, g_iters = stages.kmeans(_dev(pts), _dev(w), k)
+    assert g_kk == kk and g_iters == iters
+    assert np.array_equal(g_assign.cpu().numpy(), assign)
+    assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64))
+
+
 @pytest.mark.parametrize("k", [16, 40])
 @pytest.mark.parametrize("case", ["lattice-ties", "tight-clusters", "one-cluster-far"])
 def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k):
