@@ -39,6 +39,8 @@
  *   TM_MOTION_VALU          the motion search's VALU kernel only (tests drive both kernels)
  *   TM_FEATURES_PLAIN       the int16 DCT features sum every coefficient in the reference's order (no separable first look; the tests
  *                           compare the two forms)
+ *   TM_KM_LAUNCHES          the tile -> palette k-means runs its skipping iterations as three launches each instead of one resident launch
+ *                           for all of them (tests compare the two)
  *   TM_PP_DEBUG             PreparePalettes prints its sub-steps' wall times (adds synchronisations)
  *   TM_COMM_FORCE_DIST      a one-process communicator still walks the sharded code paths (tests on a one-GPU box)
  *   TM_COMM_TIMEOUT_S=<s>   how long tm_comm_init (and a collective of the library's own communicator) waits for the other processes (120)

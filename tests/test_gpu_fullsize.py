@@ -187,7 +187,26 @@ def test_full_size_properties(oracle, name, tmp_path):
     enc.close()
 
 
-@pytest.mark.parametrize("n,d,k", [(994105, 192, 16), (1618022, 192, 64), (20_000_000, 3, 16)])
+@pytest.mark.parametrize("n,k,sep", [(320705, 16, 0), (524288, 16, 120), (262145, 7, 300)])
+def test_kmeans_resident_launch_equals_the_launches_per_iteration(n, k, sep, monkeypatch):
+    """the tile -> palette clustering at the bench clip's size (320 705 points: 256 resident workgroups, two rounds of points each, one barrier
+    per iteration) on loosely clustered points that keep moving for many iterations: k_h_resident against the three launches per iteration
+    (TM_KM_LAUNCHES=1) -- assignments, centroids bit for bit, iteration count"""
+    from tiler_amd import stages
+    g = torch.Generator(device="cuda").manual_seed(n + k)
+    centres = torch.randint(-sep, sep + 1, (k * 3, 192), generator=g, device="cuda", dtype=torch.int32)  # (sep 0: structureless noise, the slowest to settle)
+    pts = centres[torch.randint(0, k * 3, (n,), generator=g, device="cuda")] + torch.randint(-1000, 1001, (n, 192), generator=g, device="cuda", dtype=torch.int32)
+    w = torch.randint(1, 9, (n,), generator=g, device="cuda", dtype=torch.int32)
+    monkeypatch.delenv("TM_KM_LAUNCHES", raising=False)
+    kk, assign, cent, iters = stages.kmeans(pts, w, k, 300)
+    monkeypatch.setenv("TM_KM_LAUNCHES", "1")
+    kk2, assign2, cent2, iters2 = stages.kmeans(pts, w, k, 300)
+    assert (kk, iters) == (kk2, iters2) and iters > 20
+    assert torch.equal(assign, assign2)
+    assert torch.equal(cent.view(torch.int64), cent2.view(torch.int64))
+
+
+@pytest.mark.parametrize("n,d,k", [(320705, 192, 16), (994105, 192, 16), (1618022, 192, 64), (20_000_000, 3, 16)])
 def test_kmeans_fixed_point_at_full_size(n, d, k):
     """Lloyd's fixed point at the sizes of configs[3]/[4]: every point sits with its nearest centroid (lowest index on
     ties, IEEE double in dimension order) and every centroid is the exact weighted mean of its points"""

@@ -493,9 +493,21 @@ def test_lab_of_every_colour(oracle):
     assert bad.size == 0, (bad.size, [hex(int(c)) for c in bad[:5]], got[bad[:5]], want[bad[:5]])
 
 
-@pytest.mark.parametrize("n,d,k", [(500, 3, 16), (40, 3, 64), (300, 192, 8), (1, 3, 4), (2000, 192, 40)])
-def test_kmeans(oracle, n, d, k):
+@pytest.fixture(params=["resident", "launches"])
+def km_path(request, monkeypatch):
+    """the tile k-means' skipping iterations: one resident launch for all of them (k_h_resident, <= 16 centroids), or three launches each"""
+    if request.param == "launches":
+        monkeypatch.setenv("TM_KM_LAUNCHES", "1")
+    else:
+        monkeypatch.delenv("TM_KM_LAUNCHES", raising=False)
+    return request.param
+
+
+@pytest.mark.parametrize("n,d,k", [(500, 3, 16), (40, 3, 64), (300, 192, 8), (1, 3, 4), (2000, 192, 40), (5000, 192, 16), (1500, 192, 3)])
+def test_kmeans(oracle, n, d, k, km_path):
     from tiler_amd import stages
+    if km_path == "launches" and not (d == 192 and k <= 16):
+        pytest.skip("one path only")
     rng = np.random.default_rng(n + d + k)
     if d == 3:
         pts = rng.integers(0, 256, size=(n, 3)).astype(np.int32)
@@ -512,8 +524,8 @@ def test_kmeans(oracle, n, d, k):
     assert np.array_equal(g_cent.cpu().numpy()[:kk].view(np.uint64), cent[:kk].view(np.uint64)), "centroids must match bit for bit"
 
 
-def test_kmeans_192_list_kernel_switches_shape_inside_a_clustering(oracle):
-    """60 000 points in loose clusters, 16 centroids: the first skipping iterations list more than 8 192 unproven points (the list kernel's
+def test_kmeans_192_list_kernel_switches_shape_inside_a_clustering(oracle, km_path):
+    """(resident: 59 workgroups with a barrier between them, lists of several passes early on)  60 000 points in loose clusters, 16 centroids: the first skipping iterations list more than 8 192 unproven points (the list kernel's
     four-lanes-per-point passes), the later ones fewer (its lane-per-pair passes of 16 points): both shapes and the switch between them
     inside one clustering, against the oracle's plain Lloyd"""
     from tiler_amd import stages
@@ -531,12 +543,14 @@ def test_kmeans_192_list_kernel_switches_shape_inside_a_clustering(oracle):
 
 @pytest.mark.parametrize("k", [16, 40])
 @pytest.mark.parametrize("case", ["lattice-ties", "tight-clusters", "one-cluster-far"])
-def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k):
-    """the iterations that skip points whose bounds prove their assignment (k_h_bounds, k_assign192_list4) against the oracle's plain Lloyd
+def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k, km_path):
+    """(k = 16: through the resident launch and through the three launches per iteration; k = 40: the launches only)  the iterations that skip points whose bounds prove their assignment (k_h_bounds, k_assign192_list4) against the oracle's plain Lloyd
     on data that stresses them: lattice points with many EXACTLY equal distances (ties go to the lowest centroid), clusters tighter than
     the margins of any sloppy bound, and one far cluster (large centroid displacements in the first iterations); 40 centroids take three
     passes of 16 through the list kernel, whose four lanes per point each score four centroids of a pass"""
     from tiler_amd import stages
+    if km_path == "launches" and k > 16:
+        pytest.skip("one path only")
     rng = np.random.default_rng(len(case))
     n, d = 6000, 192
     if case == "lattice-ties":

@@ -1081,6 +1081,372 @@ __global__ __launch_bounds__(1024) void k_h_update(Seg *__restrict__ segs, int k
   }
 }
 
+// ---- D = 192, at most KCH centroids: ALL skipping iterations in ONE resident launch (round 5) -----------------------------------------
+// The three launches of a skipping iteration (k_h_bounds, k_assign192_list4, k_h_update) are each a chain of dependent round trips to
+// memory -- 11 + 14.5 + 8.3 microseconds for a few thousand unproven points out of 320 705, 295 times on the literal bench clip.  Here one
+// workgroup of 1024 threads per CU stays resident for the whole clustering:
+//   * a workgroup OWNS up to 2 x 1024 points (interleaved over the grid, so that unproven points spread evenly); their assignment and
+//     their two bounds live in LDS (bounds as Singles rounded the safe way: a bound only has to be a bound), so the pass over all points
+//     that moves the bounds with the centroids touches no memory at all;
+//   * every workgroup keeps its own copy of the centroids and of the carried integer sums, and applies every iteration's update itself
+//     (16 x 192 quotients, displacements, pairwise half-distances: identical arithmetic in every workgroup, so no exchange);
+//   * what crosses workgroups per iteration is ONE thing: the integer deltas of the sums caused by the points that moved (u64 atomic adds
+//     into one of three rotating buffers, exact and order-free) plus their count, behind ONE barrier of the grid.  Every cross-workgroup
+//     datum is an agent-scope atomic on both sides (adds, relaxed 8-byte loads, relaxed stores to clear), every storing wave drains its
+//     vmcnt before its workgroup arrives, every load of the data comes after a workgroup barrier behind the poll: the hand-off form of
+//     MI355X_MICROARCH.md "Valid forms" that needs no L2 write-back and no L1 invalidate -- the two fences were 23 of the 103 microseconds
+//     of round 2's resident attempt, its thread-per-point passes most of the rest;
+//   * unproven points: the distance to the own centroid first (16 lanes per point, k_h_bounds' arithmetic), then the full scoring with a
+//     lane per (point, centroid) pair, 64 points per pass, rows in LDS -- k_assign192_list4's lane-per-pair arithmetic: every accumulator
+//     sums its 192 terms in order, ties to the lowest centroid.
+// The skip rule is sound (every bound rounded the safe way, the margins of k_h_bounds), so the assignments, hence the sums, centroids and
+// iteration count, are bit for bit those of the plain iterations, of the three-launch path (TM_KM_LAUNCHES=1) and of the oracle.
+#ifndef TM_KMR_STAMPS
+#define TM_KMR_STAMPS 0
+#endif
+constexpr int HR_NT = 1024, HR_P = 64, HR_PITCH = KCH + 1, HR_MAXR = 2, HR_E = KCH * 193;
+constexpr int HR_NSTAMP = 12;
+struct HrState {                    // zeroed before the launch
+  u64 delta[3][HR_E];              // the sums' deltas of one iteration ([c][193], the count last); three in rotation
+  unsigned changed[3];             // points that moved in that iteration
+  unsigned timeout;                // a barrier gave up (a workgroup was not resident)
+  alignas(128) unsigned bar;       // arrivals
+  unsigned pad0[31];
+  alignas(128) unsigned rel;       // the epoch the last arrival publishes; the waiting workgroups poll THIS line
+  unsigned pad1[31];
+  u64 stamps[HR_NSTAMP + 4];       // diagnostic build: s_memtime spans of workgroup 0's phases; listed / rechecked-and-failed points of all workgroups
+};
+#if TM_KMR_STAMPS
+#define HR_STAMP(i) do { if (g == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); st->stamps[i] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define HR_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ float hr_up(double x) { return (float)(x * (1.0 + 1.2e-7)); }                       // a Single >= x (x >= 0, far below FLT_MAX)
+__device__ __forceinline__ float hr_down(double x) { x = fmin(x, 1.0e37); return (float)(x - fabs(x) * 1.2e-7); }  // a Single <= x
+
+// every thread of the workgroup calls it; false: the spin gave up, the caller leaves.  No fence: see the header comment.
+__device__ __forceinline__ bool hr_barrier(HrState *st, unsigned &epoch, unsigned nblk, int *s_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics and stores have been performed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    epoch++;
+    int ok = 1;
+    if (nblk > 1) {
+      if (__hip_atomic_fetch_add(&st->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * nblk)
+        __hip_atomic_store(&st->rel, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned spins = 1; __hip_atomic_load(&st->rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 0 && (spins > (1u << 22) || __hip_atomic_load(&st->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(&st->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, Seg *__restrict__ segs, int k,
+                                                      double *__restrict__ cent /* [k][192], in and out */, const u64 *__restrict__ sums, const u64 *__restrict__ cnts,
+                                                      const double *__restrict__ cmove, const double *__restrict__ shalf, int32_t *__restrict__ assign,
+                                                      const double *__restrict__ ub, const double *__restrict__ lb, HrState *__restrict__ st, int it0, int max_iter,
+                                                      int *__restrict__ quiet_iter, int rounds /* 1024-point rounds a workgroup owns, <= HR_MAXR */) {
+  constexpr int D = 192;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  double *const s_c = reinterpret_cast<double *>(s_raw);                                      // [D][HR_PITCH]: centroid c, dimension j at j * HR_PITCH + c
+  u64 *const s_sum = reinterpret_cast<u64 *>(s_raw + D * HR_PITCH * 8);                      // [KCH][193] carried sums, the count last
+  u64 *const s_delta = s_sum + HR_E;                                                          // [KCH][193] this workgroup's deltas of the iteration
+  int *const s_rows = reinterpret_cast<int *>(s_delta + HR_E);                                // [HR_P][D] rows of the points being scored
+  float *const s_ub = reinterpret_cast<float *>(s_rows + HR_P * D);                           // [rounds * 1024]
+  float *const s_lb = s_ub + rounds * HR_NT;
+  uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_lb + rounds * HR_NT);              // slots whose loosened bounds prove nothing
+  uint16_t *const s_need = s_list + rounds * HR_NT;                                           // slots to score
+  uint8_t *const s_a = reinterpret_cast<uint8_t *>(s_need + rounds * HR_NT);                  // assignment (0xff: no point in the slot)
+  __shared__ double s_move[KCH + 2], s_half[KCH];
+  __shared__ unsigned long long s_min[KCH];
+  __shared__ int s_amax, s_nlist, s_nneed, s_nmoved, s_ok;
+  __shared__ int s_moved[HR_P * 3];
+  __shared__ unsigned s_wt[HR_P];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = tid >> 4, l16 = tid & 15;
+  const int g = blockIdx.x;
+  const unsigned G = gridDim.x;
+  if (*quiet_iter >= 0) return;  // converged in the plain iterations (every workgroup reads the same word)
+  const int kk = segs[0].kk;
+  auto gidx = [&](int slot) { return ((int64_t)(slot >> 10) * G + g) * HR_NT + (slot & (HR_NT - 1)); };
+#if TM_KMR_STAMPS
+  u64 st_last = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- state in: the centroids, the carried sums, the bounds the last plain iteration left, what the last update says about the centroids
+  for (int e = tid; e < D * HR_PITCH; e += HR_NT) { const int j = e / HR_PITCH, c = e - j * HR_PITCH; s_c[e] = c < kk ? cent[c * D + j] : 0.0; }
+  for (int e = tid; e < HR_E; e += HR_NT) {
+    const int c = e / 193, j = e - c * 193;
+    s_sum[e] = c < kk ? (j < D ? sums[c * D + j] : cnts[c]) : 0;
+    s_delta[e] = 0;
+  }
+  for (int r = 0; r < rounds; r++) {
+    const int slot = r * HR_NT + tid;
+    const int64_t i = gidx(slot);
+    const bool valid = i < n;
+    s_a[slot] = valid ? (uint8_t)assign[i] : (uint8_t)0xff;
+    s_ub[slot] = valid ? hr_up(ub[i]) : 0.0f;
+    s_lb[slot] = valid ? hr_down(lb[i]) : 0.0f;
+  }
+  if (tid < KCH) { s_move[tid] = tid < kk ? cmove[tid] : 0.0; s_half[tid] = tid < kk ? shalf[tid] : 0.0; }
+  if (tid == 0) { s_move[KCH] = cmove[k]; s_move[KCH + 1] = cmove[k + 1]; s_amax = (int)cmove[k + 2]; s_nlist = 0; s_nneed = 0; s_nmoved = 0; }
+  unsigned epoch = 0;
+  int it = it0, quiet_at = -1;
+  __syncthreads();
+  HR_STAMP(0);
+  for (; it < max_iter; it++) {
+    const int b = it % 3;
+    // ---- pass over all owned points: the bounds move with the centroids; what they no longer prove goes on the list
+    {
+      const double dmax = s_move[KCH], dmax2 = s_move[KCH + 1];
+      const int amax = s_amax;
+      int cnt = 0;
+      unsigned long long bal[HR_MAXR];
+      bool listed[HR_MAXR];
+#pragma unroll
+      for (int r = 0; r < HR_MAXR; r++) {
+        listed[r] = false;
+        if (r < rounds) {
+          const int slot = r * HR_NT + tid;
+          const int a = s_a[slot];
+          const bool valid = a != 0xff;
+          const int ac = valid ? a : 0;
+          const double un = (double)s_ub[slot] + s_move[ac];
+          const double ln = (double)s_lb[slot] - (a == amax ? dmax2 : dmax);  // lb bounds the OTHER centroids: the own one's displacement does not loosen it
+          const float unf = hr_up(un), lnf = hr_down(ln);
+          if (valid) { s_ub[slot] = unf; s_lb[slot] = lnf; }
+          listed[r] = valid && !((double)unf * (1.0 + H_ETA) < fmax(s_half[ac], (double)lnf) * (1.0 - H_ETA));
+        }
+        bal[r] = __builtin_amdgcn_ballot_w64(listed[r]);
+        cnt += __popcll(bal[r]);
+      }
+      if (cnt) {  // (uniform in the wave)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_nlist, cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int r = 0; r < HR_MAXR; r++) {
+          if (listed[r]) s_list[base + __popcll(bal[r] & ((1ull << lane) - 1ull))] = (uint16_t)(r * HR_NT + tid);
+          base += __popcll(bal[r]);
+        }
+      }
+    }
+    __syncthreads();
+    HR_STAMP(1);
+    // ---- the listed points: the distance to the own centroid tightens ub (16 lanes per point, 12 dimensions each: k_h_bounds' arithmetic -- the
+    // partial sums add in another order than the scoring's chain; both stay within 2.2e-14 of the exact sum, far inside the factor 1 + 1e-12).
+    // Still unproven -> the need list; the first HR_P of them leave their rows in LDS for the scoring.
+    const int nlist = s_nlist;
+    {
+      auto rfetch = [&](int t0, int4 (&x)[3], int &slot) {
+        const int t = t0 + grp;
+        slot = s_list[t < nlist ? t : 0];
+        const int4 *p = reinterpret_cast<const int4 *>(pts + gidx(slot) * D + l16 * 12);
+        x[0] = p[0]; x[1] = p[1]; x[2] = p[2];
+      };
+      int4 x[3] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+      int slot = 0;
+      if (nlist > 0) rfetch(0, x, slot);
+#pragma unroll 1
+      for (int t0 = 0; t0 < nlist; t0 += HR_P) {
+        const bool act = t0 + grp < nlist;
+        const int4 v0 = x[0], v1 = x[1], v2 = x[2];
+        const int cslot = slot;
+        if (t0 + HR_P < nlist) rfetch(t0 + HR_P, x, slot);  // the next pass's rows, while this one's are summed
+        const int a = s_a[cslot];
+        const int pv[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+        double sd = 0.0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const double d0 = __dsub_rn((double)pv[j], s_c[(l16 * 12 + j) * HR_PITCH + a]); sd = __fma_rn(d0, d0, sd); }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+        int np = -1;
+        if (act && l16 == 0) {
+          const float uf = hr_up(sqrt(sd) * (1.0 + 1e-12));
+          s_ub[cslot] = uf;
+          if (!((double)uf * (1.0 + H_ETA) < fmax(s_half[a], (double)s_lb[cslot]) * (1.0 - H_ETA))) { np = atomicAdd(&s_nneed, 1); s_need[np] = (uint16_t)cslot; }
+        }
+        np = __shfl(np, lane & 48);
+        if (np >= 0 && np < HR_P) {
+          int4 *dst = reinterpret_cast<int4 *>(s_rows + np * D + l16 * 12);
+          dst[0] = v0; dst[1] = v1; dst[2] = v2;
+        }
+      }
+    }
+    __syncthreads();
+    HR_STAMP(2);
+    // ---- full scoring of the need list, HR_P points per pass, a lane per (point, centroid) pair
+    const int nneed = s_nneed;
+    int total_moved = 0;
+#if TM_KMR_STAMPS
+    if (tid == 0 && (nlist | nneed)) { atomicAdd(&st->stamps[HR_NSTAMP], (u64)nlist); atomicAdd(&st->stamps[HR_NSTAMP + 1], (u64)nneed); }
+#endif
+#pragma unroll 1
+    for (int base = 0; base < nneed; base += HR_P) {
+      if (base > 0) {  // (the first pass's rows came from the recheck)
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int piece = u * HR_NT + tid, pr = piece / 48, off = piece - pr * 48;
+          const int sl = s_need[min(base + pr, nneed - 1)];
+          reinterpret_cast<int4 *>(s_rows)[piece] = reinterpret_cast<const int4 *>(pts + gidx(sl) * D)[off];
+        }
+        __syncthreads();
+      }
+      const bool active = base + grp < nneed;
+      const int slot = s_need[active ? base + grp : base];
+      const int64_t gi = gidx(slot);
+      unsigned wv = 1u;
+      if (active && l16 == 0 && w) wv = w[gi];  // only a moved point needs it, but it comes from memory: asked for now it arrives under the chain
+      double bd = 1.0e300, bd2 = 1.0e300;
+      int bc = 0x7fffffff;
+      if (base + (wave << 2) < nneed) {  // (uniform in the wave: the waves without a point skip the chain)
+        double sacc = 0.0;
+        const int4 *rp = reinterpret_cast<const int4 *>(s_rows + grp * D);
+        const double *cp = s_c + l16;
+#pragma unroll 4
+        for (int j4 = 0; j4 < D / 4; j4++) {
+          const int4 v = rp[j4];
+          const double t0 = __dsub_rn((double)v.x, cp[(j4 * 4 + 0) * HR_PITCH]); sacc = __fma_rn(t0, t0, sacc);
+          const double t1 = __dsub_rn((double)v.y, cp[(j4 * 4 + 1) * HR_PITCH]); sacc = __fma_rn(t1, t1, sacc);
+          const double t2 = __dsub_rn((double)v.z, cp[(j4 * 4 + 2) * HR_PITCH]); sacc = __fma_rn(t2, t2, sacc);
+          const double t3 = __dsub_rn((double)v.w, cp[(j4 * 4 + 3) * HR_PITCH]); sacc = __fma_rn(t3, t3, sacc);
+        }
+        if (l16 < kk) { bd = sacc; bc = l16; }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
+          const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
+          const int oc = __shfl_xor(bc, o);
+          const bool take = od < bd || (od == bd && oc < bc);
+          const double loser = take ? bd : od;
+          bd2 = fmin(fmin(bd2, od2), loser);
+          if (take) { bd = od; bc = oc; }
+        }
+        if (active && l16 == 0) {
+          s_ub[slot] = hr_up(sqrt(bd) * (1.0 + 1e-12));
+          s_lb[slot] = hr_down(sqrt(bd2) * (1.0 - 1e-12));
+          const int old = s_a[slot];
+          if (old != bc) {
+            s_a[slot] = (uint8_t)bc;
+            const int m = atomicAdd(&s_nmoved, 1);
+            s_moved[m * 3] = grp; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
+            s_wt[grp] = wv;
+          }
+        }
+      }
+      __syncthreads();
+      const int nmoved = s_nmoved;
+      total_moved += nmoved;
+      for (int e = wave; e < nmoved; e += HR_NT / 64) {  // a wave per moved row between the carried sums (its row is in LDS)
+        const int ps = s_moved[e * 3], old = s_moved[e * 3 + 1], nw = s_moved[e * 3 + 2];
+        const long long wi = (long long)s_wt[ps];
+#pragma unroll
+        for (int j = lane; j <= D; j += 64) {
+          const u64 v = j < D ? (u64)(wi * s_rows[ps * D + j]) : (u64)wi;
+          atomicAdd(&s_delta[nw * 193 + j], v);
+          atomicAdd(&s_delta[old * 193 + j], (u64)0 - v);
+        }
+      }
+      __syncthreads();  // the moved list and the rows have been read
+      if (tid == 0) s_nmoved = 0;
+    }
+    HR_STAMP(3);
+    // ---- this workgroup's deltas -> the iteration's buffer
+    if (total_moved) {
+      for (int e = tid; e < HR_E; e += HR_NT) {
+        const u64 v = s_delta[e];
+        if (v == 0) continue;
+        s_delta[e] = 0;
+        __hip_atomic_fetch_add(&st->delta[b][e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) __hip_atomic_fetch_add(&st->changed[b], (unsigned)total_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    HR_STAMP(4);
+    if (!hr_barrier(st, epoch, G, &s_ok)) return;
+    HR_STAMP(5);
+    if (tid == 0) { s_nlist = 0; s_nneed = 0; }  // (every thread has read them: the barrier; the next pass over the points comes behind further ones)
+    // ---- every workgroup: the iteration's deltas into its own sums; new centroids; what the bounds need
+    const unsigned tot = __hip_atomic_load(&st->changed[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      u64 dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int e = u * HR_NT + tid; dv[u] = e < HR_E ? __hip_atomic_load(&st->delta[b][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+      // the buffer of the iteration after next: read for the last time before the barrier just passed, added to again only behind the next one
+      const int b2 = (it + 2) % 3;
+      const int per = (HR_E + (int)G - 1) / (int)G;
+      if (tid < per && g * per + tid < HR_E) __hip_atomic_store(&st->delta[b2][g * per + tid], (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g == 0 && tid == 0) __hip_atomic_store(&st->changed[b2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int e = u * HR_NT + tid; if (e < HR_E && dv[u]) s_sum[e] += dv[u]; }
+    }
+    if (tot == 0) { quiet_at = it; break; }
+    if (tid < KCH) s_min[tid] = 0x7ff0000000000000ull;  // +inf
+    __syncthreads();
+    HR_STAMP(6);
+    // a wave per centroid, 3 dimensions per lane: new position = exact integer sum / weight (one IEEE division; an empty cluster keeps its
+    // centroid), displacement (rounded up; the sums here only feed the bounds, margins of 1e-9: their order is free)
+    if (wave < kk) {
+      const int c = wave;
+      const u64 cn = s_sum[c * 193 + D];
+      double sd = 0.0;
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int j = lane + 64 * u;
+        const double old = s_c[j * HR_PITCH + c];
+        double nw = old;
+        if (cn > 0) { nw = __ddiv_rn((double)(long long)s_sum[c * 193 + j], (double)(long long)cn); s_c[j * HR_PITCH + c] = nw; }
+        const double t = nw - old;
+        sd += t * t;
+      }
+      for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      if (lane == 0) s_move[c] = sqrt(sd) * (1.0 + 1e-9);
+    }
+    __syncthreads();
+    for (int pr = grp; pr < kk * kk; pr += HR_NT / 16) {  // pairwise distances, 16 lanes per pair: the smallest per centroid (non-negative doubles order like their bit patterns)
+      const int ca = pr / kk, cb = pr - ca * kk;
+      if (ca >= cb) continue;  // (uniform in a group of 16 lanes, and the exchanges below stay inside one)
+      double sd = 0.0;
+#pragma unroll
+      for (int u = 0; u < 12; u++) { const int j = l16 + 16 * u; const double t = s_c[j * HR_PITCH + ca] - s_c[j * HR_PITCH + cb]; sd += t * t; }
+      for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      if (l16 == 0) {
+        atomicMin(&s_min[ca], (unsigned long long)__double_as_longlong(sd));
+        atomicMin(&s_min[cb], (unsigned long long)__double_as_longlong(sd));
+      }
+    }
+    __syncthreads();
+    if (tid < kk) s_half[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
+    if (wave == 1) {  // the largest displacement, the largest among the others, and whose the largest is (the first of several)
+      const double v = lane < kk ? s_move[lane] : 0.0;
+      double mx = v;
+      for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+      const int amx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v == mx && (lane < kk || mx == 0.0)));
+      double mx2 = lane == amx ? 0.0 : v;
+      for (int o = 32; o > 0; o >>= 1) mx2 = fmax(mx2, __shfl_xor(mx2, o));
+      if (lane == 0) { s_move[KCH] = mx; s_move[KCH + 1] = mx2; s_amax = amx; }
+    }
+    __syncthreads();
+    HR_STAMP(7);
+  }
+  // ---- state out
+  __syncthreads();
+  for (int r = 0; r < rounds; r++) {
+    const int slot = r * HR_NT + tid;
+    const int64_t i = gidx(slot);
+    if (i < n) assign[i] = (int32_t)s_a[slot];
+  }
+  if (g == 0) {
+    for (int e = tid; e < kk * D; e += HR_NT) { const int c = e / D, j = e - c * D; cent[e] = s_c[j * HR_PITCH + c]; }
+    if (tid == 0) { segs[0].changed = 0; if (quiet_at >= 0) *quiet_iter = quiet_at; }
+  }
+}
+
 // ---- D = 3, one launch for the whole clustering -----------------------------------------------------------------
 // The pixel k-means of QuantizeUsingYakmo (tilingencoder.pas:4434-4532) runs ~180 Lloyd iterations over a few hundred thousand
 // distinct colours per palette: a few microseconds of arithmetic per iteration, so as separate launches (two per iteration, two per
@@ -1573,7 +1939,7 @@ __global__ void k_seed_centres(Seg *__restrict__ segs, int nseg, int k, const in
 static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const std::vector<int64_t> &seg_begin,
                           const std::vector<int64_t> &seg_count, int k, int max_iter, int32_t *assign, double *cent,
                           std::vector<int> *host_kk, int *host_iters, hipStream_t stream, const int64_t *init_idx = nullptr,
-                          const long long *dev_init_idx = nullptr /* the same on the device (D2 seeding leaves them there) */) {
+                          const long long *dev_init_idx = nullptr /* the same on the device (D2 seeding leaves them there) */, bool allow_resident = true) {
   TM_CHECK(d == 3 || d == 192, TM_E_INVAL, "kmeans: only d = 3 (pixels) or 192 (tile features) are built");
   TM_CHECK(k >= 1 && k <= 65536, TM_E_INVAL, "kmeans: k out of range");
   const int nseg = (int)seg_begin.size();
@@ -1682,6 +2048,66 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     if (l_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assign192_list4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_lds);
   }
   int it = 0, issued = 0;
+  // D = 192, at most KCH centroids, points that fit the chip's LDS two rounds deep: the plain iterations, then ALL skipping iterations as one
+  // resident launch (k_h_resident), a workgroup per CU.  Should a workgroup not become resident (another process holding CUs with a resident
+  // launch of its own) the barrier gives up and the clustering is repeated from its seeds through the launches-per-iteration path below.
+  bool resident_done = false;
+  if (skipping && allow_resident && !knobs().km_launches && k <= KCH && max_iter > h_warm) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t per_round = (int64_t)HR_NT;
+    const int grid = (int)std::min<int64_t>(cus, (n + per_round - 1) / per_round);
+    const int rounds = (int)((n + (int64_t)grid * per_round - 1) / ((int64_t)grid * per_round));
+    const size_t r_lds = (size_t)192 * HR_PITCH * 8 + (size_t)HR_E * 16 + (size_t)HR_P * 192 * 4 + (size_t)rounds * HR_NT * (4 + 4 + 2 + 2 + 1) + 16;
+    if (rounds <= HR_MAXR && r_lds <= 160 * 1024 - 4096) {
+      DevBuf hstate;
+      TM_TRY(hstate.alloc(sizeof(HrState)));
+      TM_HIP(hipMemsetAsync(hstate.p, 0, sizeof(HrState), stream));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r_lds);
+      for (; issued < h_warm; issued++) {
+        const bool last_plain = issued == h_warm - 1;
+        launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
+                         quiet.as<int>(), last_plain ? hub.as<double>() : nullptr, last_plain ? hlb.as<double>() : nullptr);
+        hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
+                           hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>(), (int *)nullptr);
+      }
+      hipLaunchKernelGGL(k_h_resident, dim3(grid), dim3(HR_NT), r_lds, stream, pts, w, n, ds, k, cent, sums.as<u64>(), cnts.as<u64>(), hmove.as<double>(), hhalf.as<double>(), assign,
+                         hub.as<double>(), hlb.as<double>(), hstate.as<HrState>(), h_warm, max_iter, quiet.as<int>(), rounds);
+      TM_HIP(hipGetLastError());
+      int q = -1;
+      HrState *hs_dev = hstate.as<HrState>();
+      unsigned timed_out = 0;
+#if TM_KMR_STAMPS
+      std::vector<u64> stamps(HR_NSTAMP + 4);
+#endif
+      {
+        HostRead hr_(stream);
+        TM_TRY(hr_.get(&q, quiet.p, 4));
+        TM_TRY(hr_.get(&timed_out, &hs_dev->timeout, 4));
+#if TM_KMR_STAMPS
+        TM_TRY(hr_.get(stamps.data(), hs_dev->stamps, stamps.size() * 8));
+#endif
+        TM_TRY(hr_.wait());
+      }
+      if (timed_out) {
+        fprintf(stderr, "[tm_kmeans] the resident tile k-means gave up at its barrier; repeating the clustering with one launch per step\n");
+        return kmeans_batched(pts, w, d, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, init_idx, dev_init_idx, false);
+      }
+      it = q >= 0 ? q : max_iter;
+#if TM_KMR_STAMPS
+      {
+        const double ni = std::max(1, it - h_warm + (q >= 0 ? 1 : 0));
+        static const char *names[8] = {"state in", "bounds pass", "own-centroid recheck", "scoring", "flush", "barrier", "deltas in", "update"};
+        fprintf(stderr, "[tm_kmr stamps] %d workgroups x %d rounds, %d resident iterations; workgroup 0, s_memtime ticks per iteration:", grid, rounds, (int)ni);
+        for (int i2 = 1; i2 < 8; i2++) fprintf(stderr, " %s %.0f,", names[i2], (double)stamps[i2] / ni);
+        fprintf(stderr, " state in %.0f (once); per iteration %.1f points listed, %.1f scored (all workgroups)\n", (double)stamps[0], (double)stamps[HR_NSTAMP] / ni,
+                (double)stamps[HR_NSTAMP + 1] / ni);
+      }
+#endif
+      resident_done = true;
+    }
+  }
   // Convergence is a flag on the device; the launches after it return at once.  The host queues the iterations in batches and reads the
   // flag of a batch while the NEXT batch runs (a copy into page-locked memory and an event behind every batch): the device never waits
   // for the host to look, and at most two short batches of launches are wasted at the end.  (Batches of 16 with the stream drained at
@@ -1701,7 +2127,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     TM_HIP(hipEventCreateWithFlags(&pev[1], hipEventDisableTiming));
   }
   int nbatch = 0, qflag = -1;
-  while (issued < max_iter) {
+  while (issued < max_iter && !resident_done) {
     const int batch = std::min(poll_every, max_iter - issued);
     for (int b = 0; b < batch; b++, issued++) {
       if (skipping) {
@@ -1752,7 +2178,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       if (qflag >= 0) { it = qflag; break; }
     }
   }
-  if (pin && qflag < 0 && nbatch >= 1) {  // the last batch queued
+  if (pin && qflag < 0 && nbatch >= 1 && !resident_done) {  // the last batch queued
     TM_HIP(hipEventSynchronize(pev[(nbatch - 1) & 1]));
     qflag = __atomic_load_n(&pin[0], __ATOMIC_ACQUIRE);
     if (qflag >= 0) it = qflag;
