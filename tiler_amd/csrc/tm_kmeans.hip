@@ -1110,17 +1110,36 @@ struct HrState {                    // zeroed before the launch
   u64 delta[3][HR_E];              // the sums' deltas of one iteration ([c][193], the count last); three in rotation
   unsigned changed[3];             // points that moved in that iteration
   unsigned timeout;                // a barrier gave up (a workgroup was not resident)
-  alignas(128) unsigned bar;       // arrivals
-  unsigned pad0[31];
-  alignas(128) unsigned rel;       // the epoch the last arrival publishes; the waiting workgroups poll THIS line
-  unsigned pad1[31];
+  // the barrier: arrivals are counted in eight shards (workgroup g on shard g % 8: atomics on one word take their turns, ~12 ns each); the
+  // last arrival of a shard adds one to each of the eight replicas of `top` (one instruction, eight lanes); a waiting workgroup polls its
+  // shard's replica until all shards are in (loads on one word queue up like atomics do: 32 pollers a line).  A round trip to the memory
+  // side is about a microsecond here, so the count of dependent ones is the barrier's price: arrival, replica add, poll.
+  // Every word on a 128-byte line of its own.
+  struct alignas(128) Line { unsigned v; unsigned pad[31]; };
+  Line bar[8], top[8];
   u64 stamps[HR_NSTAMP + 4];       // diagnostic build: s_memtime spans of workgroup 0's phases; listed / rechecked-and-failed points of all workgroups
+#if TM_KMR_STAMPS
+  unsigned log[300][10];           // per iteration: workgroup 0's spans of phases 1-7, its listed and scored points, the points scored by all
+#endif
 };
 #if TM_KMR_STAMPS
-#define HR_STAMP(i) do { if (g == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); st->stamps[i] += t_ - st_last; st_last = t_; } } while (0)
+#define HR_STAMP(i) do { if (g == 0 && tid == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); s_stamp[i] += t_ - st_last; st_last = t_; } } while (0)
 #else
 #define HR_STAMP(i) do { } while (0)
 #endif
+
+// exchanges inside a row of 16 lanes without the LDS crossbar a __shfl_xor goes through (a data-parallel-primitive move is one vector
+// instruction): lane ^ 1, lane ^ 2 (quad permutations), then the mirror image inside 8 and inside 16 lanes -- after the four steps every lane
+// of a row has combined all sixteen
+template <int CTRL>
+__device__ __forceinline__ int hr_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double hr_dpp(double v) { return __hiloint2double(hr_dpp<CTRL>(__double2hiint(v)), hr_dpp<CTRL>(__double2loint(v))); }
+constexpr int HR_X1 = 0xB1, HR_X2 = 0x4E, HR_M8 = 0x141, HR_M16 = 0x140;  // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ double hr_sum16(double v) {
+  v += hr_dpp<HR_X1>(v); v += hr_dpp<HR_X2>(v); v += hr_dpp<HR_M8>(v); v += hr_dpp<HR_M16>(v);
+  return v;
+}
 
 __device__ __forceinline__ float hr_up(double x) { return (float)(x * (1.0 + 1.2e-7)); }                       // a Single >= x (x >= 0, far below FLT_MAX)
 __device__ __forceinline__ float hr_down(double x) { x = fmin(x, 1.0e37); return (float)(x - fabs(x) * 1.2e-7); }  // a Single <= x
@@ -1129,13 +1148,18 @@ __device__ __forceinline__ float hr_down(double x) { x = fmin(x, 1.0e37); return
 __device__ __forceinline__ bool hr_barrier(HrState *st, unsigned &epoch, unsigned nblk, int *s_ok) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics and stores have been performed
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
     epoch++;
     int ok = 1;
     if (nblk > 1) {
-      if (__hip_atomic_fetch_add(&st->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * nblk)
-        __hip_atomic_store(&st->rel, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (unsigned spins = 1; __hip_atomic_load(&st->rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
+      const unsigned sh = blockIdx.x & 7u, nsh = nblk < 8u ? nblk : 8u;
+      const unsigned mine = (nblk - sh + 7u) >> 3;  // workgroups on this shard
+      bool last = false;
+      if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&st->bar[sh].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * mine;
+      last = __builtin_amdgcn_readfirstlane((int)last) != 0;
+      if (last && threadIdx.x < 8) __hip_atomic_fetch_add(&st->top[threadIdx.x].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one instruction, eight lines
+      if (threadIdx.x == 0)
+      for (unsigned spins = 1; __hip_atomic_load(&st->top[sh].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nsh; spins++) {
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 255u) == 0 && (spins > (1u << 22) || __hip_atomic_load(&st->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           __hip_atomic_store(&st->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1144,18 +1168,20 @@ __device__ __forceinline__ bool hr_barrier(HrState *st, unsigned &epoch, unsigne
         }
       }
     }
-    *s_ok = ok;
+    if (threadIdx.x == 0) *s_ok = ok;
   }
   __syncthreads();
   return *s_ok != 0;
 }
 
+template <int ROUNDS /* 1024-point rounds a workgroup owns: a constant, so that the LDS arrays' places are */>
 __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict__ pts, const uint32_t *__restrict__ w, int64_t n, Seg *__restrict__ segs, int k,
                                                       double *__restrict__ cent /* [k][192], in and out */, const u64 *__restrict__ sums, const u64 *__restrict__ cnts,
                                                       const double *__restrict__ cmove, const double *__restrict__ shalf, int32_t *__restrict__ assign,
                                                       const double *__restrict__ ub, const double *__restrict__ lb, HrState *__restrict__ st, int it0, int max_iter,
-                                                      int *__restrict__ quiet_iter, int rounds /* 1024-point rounds a workgroup owns, <= HR_MAXR */) {
-  constexpr int D = 192;
+                                                      int *__restrict__ quiet_iter) {
+  constexpr int D = 192, rounds = ROUNDS;
+  static_assert(ROUNDS >= 1 && ROUNDS <= HR_MAXR, "rounds");
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   double *const s_c = reinterpret_cast<double *>(s_raw);                                      // [D][HR_PITCH]: centroid c, dimension j at j * HR_PITCH + c
   u64 *const s_sum = reinterpret_cast<u64 *>(s_raw + D * HR_PITCH * 8);                      // [KCH][193] carried sums, the count last
@@ -1165,19 +1191,26 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
   float *const s_lb = s_ub + rounds * HR_NT;
   uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_lb + rounds * HR_NT);              // slots whose loosened bounds prove nothing
   uint16_t *const s_need = s_list + rounds * HR_NT;                                           // slots to score
-  uint8_t *const s_a = reinterpret_cast<uint8_t *>(s_need + rounds * HR_NT);                  // assignment (0xff: no point in the slot)
+  unsigned *const s_w = reinterpret_cast<unsigned *>(s_need + rounds * HR_NT);                // the points' weights (a moved point's comes from here, not from memory behind the chain)
+  uint8_t *const s_a = reinterpret_cast<uint8_t *>(s_w + rounds * HR_NT);                     // assignment (0xff: no point in the slot)
   __shared__ double s_move[KCH + 2], s_half[KCH];
   __shared__ unsigned long long s_min[KCH];
   __shared__ int s_amax, s_nlist, s_nneed, s_nmoved, s_ok;
   __shared__ int s_moved[HR_P * 3];
   __shared__ unsigned s_wt[HR_P];
+  __shared__ uint16_t s_pair[KCH * (KCH - 1) / 2];  // the centroid pairs a < b, a | b << 8
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = tid >> 4, l16 = tid & 15;
   const int g = blockIdx.x;
   const unsigned G = gridDim.x;
   if (*quiet_iter >= 0) return;  // converged in the plain iterations (every workgroup reads the same word)
   const int kk = segs[0].kk;
-  auto gidx = [&](int slot) { return ((int64_t)(slot >> 10) * G + g) * HR_NT + (slot & (HR_NT - 1)); };
+  auto gidx = [&](int slot) { return (int64_t)slot * G + g; };  // point i belongs to workgroup i % G: every workgroup the same share of every stretch of the tiles
 #if TM_KMR_STAMPS
+  __shared__ u64 s_stamp[HR_NSTAMP];  // (accumulated in LDS, written out at the end: a global read-modify-write per stamp costs more than most phases)
+  __shared__ u64 s_prev[8];
+  if (tid < HR_NSTAMP) s_stamp[tid] = 0;
+  if (tid < 8) s_prev[tid] = 0;
+  __syncthreads();
   u64 st_last = __builtin_amdgcn_s_memtime();
 #endif
   // ---- state in: the centroids, the carried sums, the bounds the last plain iteration left, what the last update says about the centroids
@@ -1194,8 +1227,13 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
     s_a[slot] = valid ? (uint8_t)assign[i] : (uint8_t)0xff;
     s_ub[slot] = valid ? hr_up(ub[i]) : 0.0f;
     s_lb[slot] = valid ? hr_down(lb[i]) : 0.0f;
+    s_w[slot] = valid && w ? w[i] : 1u;
   }
   if (tid < KCH) { s_move[tid] = tid < kk ? cmove[tid] : 0.0; s_half[tid] = tid < kk ? shalf[tid] : 0.0; }
+  if (tid < kk * kk) {
+    const int a = tid / kk, b2 = tid - a * kk;
+    if (a < b2) s_pair[a * kk - a * (a + 1) / 2 + (b2 - a - 1)] = (uint16_t)(a | (b2 << 8));
+  }
   if (tid == 0) { s_move[KCH] = cmove[k]; s_move[KCH + 1] = cmove[k + 1]; s_amax = (int)cmove[k + 2]; s_nlist = 0; s_nneed = 0; s_nmoved = 0; }
   unsigned epoch = 0;
   int it = it0, quiet_at = -1;
@@ -1265,8 +1303,7 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
         double sd = 0.0;
 #pragma unroll
         for (int j = 0; j < 12; j++) { const double d0 = __dsub_rn((double)pv[j], s_c[(l16 * 12 + j) * HR_PITCH + a]); sd = __fma_rn(d0, d0, sd); }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+        sd = hr_sum16(sd);
         int np = -1;
         if (act && l16 == 0) {
           const float uf = hr_up(sqrt(sd) * (1.0 + 1e-12));
@@ -1301,33 +1338,52 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
       }
       const bool active = base + grp < nneed;
       const int slot = s_need[active ? base + grp : base];
-      const int64_t gi = gidx(slot);
-      unsigned wv = 1u;
-      if (active && l16 == 0 && w) wv = w[gi];  // only a moved point needs it, but it comes from memory: asked for now it arrives under the chain
       double bd = 1.0e300, bd2 = 1.0e300;
       int bc = 0x7fffffff;
       if (base + (wave << 2) < nneed) {  // (uniform in the wave: the waves without a point skip the chain)
+        // 192 terms in order, four dimensions per step: the NEXT step's LDS reads (a 16-byte read of the row, four centroid values) are
+        // issued before this step's arithmetic -- the scheduling barriers keep them there: left alone the compiler reads each operand right
+        // before its use and waits out an LDS round trip every second term (24 000 cycles per pass with a lone wave per SIMD; the stamps)
         double sacc = 0.0;
         const int4 *rp = reinterpret_cast<const int4 *>(s_rows + grp * D);
         const double *cp = s_c + l16;
-#pragma unroll 4
-        for (int j4 = 0; j4 < D / 4; j4++) {
-          const int4 v = rp[j4];
-          const double t0 = __dsub_rn((double)v.x, cp[(j4 * 4 + 0) * HR_PITCH]); sacc = __fma_rn(t0, t0, sacc);
-          const double t1 = __dsub_rn((double)v.y, cp[(j4 * 4 + 1) * HR_PITCH]); sacc = __fma_rn(t1, t1, sacc);
-          const double t2 = __dsub_rn((double)v.z, cp[(j4 * 4 + 2) * HR_PITCH]); sacc = __fma_rn(t2, t2, sacc);
-          const double t3 = __dsub_rn((double)v.w, cp[(j4 * 4 + 3) * HR_PITCH]); sacc = __fma_rn(t3, t3, sacc);
+        auto ld = [&](int jb, int4 &r, double (&c)[4]) {
+          r = rp[jb];
+#pragma unroll
+          for (int u = 0; u < 4; u++) c[u] = cp[(jb * 4 + u) * HR_PITCH];
+        };
+        auto acc = [&](const int4 &r, const double (&c)[4]) {
+          const int v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const double t = __dsub_rn((double)v[u], c[u]); sacc = __fma_rn(t, t, sacc); }
+        };
+        int4 ra, rb;
+        double ca[4], cb[4];
+        ld(0, ra, ca);
+#pragma unroll
+        for (int jb = 0; jb < D / 4; jb += 2) {
+          ld(jb + 1, rb, cb);
+          __builtin_amdgcn_sched_barrier(0);
+          acc(ra, ca);
+          __builtin_amdgcn_sched_barrier(0);
+          if (jb + 2 < D / 4) ld(jb + 2, ra, ca);
+          __builtin_amdgcn_sched_barrier(0);
+          acc(rb, cb);
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (l16 < kk) { bd = sacc; bc = l16; }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {  // the 16 lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest
-          const double od = __shfl_xor(bd, o), od2 = __shfl_xor(bd2, o);
-          const int oc = __shfl_xor(bc, o);
+        // the 16 lanes of a point: the best by (distance, index); the second best distance = the smallest of the rest (whatever the pairing)
+        auto merge = [&](auto ctrl) {
+          constexpr int C = decltype(ctrl)::value;
+          const double od = hr_dpp<C>(bd), od2 = hr_dpp<C>(bd2);
+          const int oc = hr_dpp<C>(bc);
           const bool take = od < bd || (od == bd && oc < bc);
           const double loser = take ? bd : od;
           bd2 = fmin(fmin(bd2, od2), loser);
           if (take) { bd = od; bc = oc; }
-        }
+        };
+        merge(std::integral_constant<int, HR_X1>{}); merge(std::integral_constant<int, HR_X2>{});
+        merge(std::integral_constant<int, HR_M8>{}); merge(std::integral_constant<int, HR_M16>{});
         if (active && l16 == 0) {
           s_ub[slot] = hr_up(sqrt(bd) * (1.0 + 1e-12));
           s_lb[slot] = hr_down(sqrt(bd2) * (1.0 - 1e-12));
@@ -1336,7 +1392,7 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
             s_a[slot] = (uint8_t)bc;
             const int m = atomicAdd(&s_nmoved, 1);
             s_moved[m * 3] = grp; s_moved[m * 3 + 1] = old; s_moved[m * 3 + 2] = bc;
-            s_wt[grp] = wv;
+            s_wt[grp] = s_w[slot];
           }
         }
       }
@@ -1404,38 +1460,50 @@ __global__ __launch_bounds__(HR_NT) void k_h_resident(const int32_t *__restrict_
         const double t = nw - old;
         sd += t * t;
       }
-      for (int o = 32; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      sd = hr_sum16(sd);
+      sd += __shfl_xor(sd, 16);
+      sd += __shfl_xor(sd, 32);
       if (lane == 0) s_move[c] = sqrt(sd) * (1.0 + 1e-9);
     }
     __syncthreads();
-    for (int pr = grp; pr < kk * kk; pr += HR_NT / 16) {  // pairwise distances, 16 lanes per pair: the smallest per centroid (non-negative doubles order like their bit patterns)
-      const int ca = pr / kk, cb = pr - ca * kk;
-      if (ca >= cb) continue;  // (uniform in a group of 16 lanes, and the exchanges below stay inside one)
+    for (int pr = grp; pr < kk * (kk - 1) / 2; pr += HR_NT / 16) {  // pairwise distances, 16 lanes per pair: the smallest per centroid (non-negative doubles order like their bit patterns)
+      const int ca = s_pair[pr] & 0xff, cb = s_pair[pr] >> 8;
       double sd = 0.0;
 #pragma unroll
       for (int u = 0; u < 12; u++) { const int j = l16 + 16 * u; const double t = s_c[j * HR_PITCH + ca] - s_c[j * HR_PITCH + cb]; sd += t * t; }
-      for (int o = 8; o > 0; o >>= 1) sd += __shfl_xor(sd, o);
+      sd = hr_sum16(sd);
       if (l16 == 0) {
         atomicMin(&s_min[ca], (unsigned long long)__double_as_longlong(sd));
         atomicMin(&s_min[cb], (unsigned long long)__double_as_longlong(sd));
       }
     }
-    __syncthreads();
-    if (tid < kk) s_half[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
-    if (wave == 1) {  // the largest displacement, the largest among the others, and whose the largest is (the first of several)
-      const double v = lane < kk ? s_move[lane] : 0.0;
-      double mx = v;
-      for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-      const int amx = __builtin_ctzll(__builtin_amdgcn_ballot_w64(v == mx && (lane < kk || mx == 0.0)));
-      double mx2 = lane == amx ? 0.0 : v;
-      for (int o = 32; o > 0; o >>= 1) mx2 = fmax(mx2, __shfl_xor(mx2, o));
-      if (lane == 0) { s_move[KCH] = mx; s_move[KCH + 1] = mx2; s_amax = amx; }
+    if (tid == HR_NT - 1) {  // the largest displacement, the largest among the others, and whose the largest is (the first of several): sixteen values, one lane
+      double mv[KCH];
+#pragma unroll
+      for (int c = 0; c < KCH; c++) mv[c] = s_move[c];
+      double mx = 0.0, mx2 = 0.0;
+      int amx = 0;
+#pragma unroll
+      for (int c = 0; c < KCH; c++) {
+        const double v = c < kk ? mv[c] : 0.0;
+        if (v > mx) { mx2 = mx; mx = v; amx = c; } else mx2 = fmax(mx2, v);
+      }
+      s_move[KCH] = mx; s_move[KCH + 1] = mx2; s_amax = amx;
     }
     __syncthreads();
+    if (tid < kk) s_half[tid] = kk > 1 ? 0.5 * sqrt(__longlong_as_double((long long)s_min[tid])) * (1.0 - 1e-9) : 1.0e300;
+    __syncthreads();
     HR_STAMP(7);
+#if TM_KMR_STAMPS
+    if (g == 0 && tid < 7 && it < 300) { st->log[it][tid] = (unsigned)(s_stamp[tid + 1] - s_prev[tid]); s_prev[tid] = s_stamp[tid + 1]; }
+    if (g == 0 && tid == 0 && it < 300) { st->log[it][7] = (unsigned)nlist; st->log[it][8] = (unsigned)nneed; st->log[it][9] = tot; }
+#endif
   }
   // ---- state out
   __syncthreads();
+#if TM_KMR_STAMPS
+  if (g == 0 && tid < HR_NSTAMP) st->stamps[tid] = s_stamp[tid];
+#endif
   for (int r = 0; r < rounds; r++) {
     const int slot = r * HR_NT + tid;
     const int64_t i = gidx(slot);
@@ -2056,15 +2124,16 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t per_round = (int64_t)HR_NT;
-    const int grid = (int)std::min<int64_t>(cus, (n + per_round - 1) / per_round);
-    const int rounds = (int)((n + (int64_t)grid * per_round - 1) / ((int64_t)grid * per_round));
-    const size_t r_lds = (size_t)192 * HR_PITCH * 8 + (size_t)HR_E * 16 + (size_t)HR_P * 192 * 4 + (size_t)rounds * HR_NT * (4 + 4 + 2 + 2 + 1) + 16;
-    if (rounds <= HR_MAXR && r_lds <= 160 * 1024 - 4096) {
+    const int grid = (int)std::min<int64_t>(cus, (n + HR_NT - 1) / HR_NT);
+    const int rounds = (int)(((n + grid - 1) / grid + HR_NT - 1) / HR_NT);  // a workgroup owns the points i with i % grid == its index: slots of 1024
+    const size_t r_lds = (size_t)192 * HR_PITCH * 8 + (size_t)HR_E * 16 + (size_t)HR_P * 192 * 4 + (size_t)rounds * HR_NT * (4 + 4 + 2 + 2 + 4 + 1) + 16;
+    if (rounds <= HR_MAXR && r_lds <= 160 * 1024 - 2048) {
       DevBuf hstate;
       TM_TRY(hstate.alloc(sizeof(HrState)));
       TM_HIP(hipMemsetAsync(hstate.p, 0, sizeof(HrState), stream));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_h_resident), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r_lds);
+      auto kres = rounds == 1 ? &k_h_resident<1> : &k_h_resident<2>;
+      static_assert(HR_MAXR == 2, "one instantiation per number of rounds");
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r_lds);
       for (; issued < h_warm; issued++) {
         const bool last_plain = issued == h_warm - 1;
         launch_assign192(ppt192, dim3(nblk192, nseg), lds192, stream, pts, ptsc.as<int32_t>(), n, w, ds, k, cent, assign, sums.as<u64>(), cnts.as<u64>(), rows192, lds_delta192,
@@ -2072,14 +2141,15 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         hipLaunchKernelGGL(k_h_update, dim3(1), dim3(1024), (size_t)k * 193 * 8, stream, ds, k, sums.as<u64>(), cnts.as<u64>(), cent, hcent_t.as<double>(), h_kt, hmove.as<double>(),
                            hhalf.as<double>(), hcnt.as<unsigned>(), issued, quiet.as<int>(), (int *)nullptr);
       }
-      hipLaunchKernelGGL(k_h_resident, dim3(grid), dim3(HR_NT), r_lds, stream, pts, w, n, ds, k, cent, sums.as<u64>(), cnts.as<u64>(), hmove.as<double>(), hhalf.as<double>(), assign,
-                         hub.as<double>(), hlb.as<double>(), hstate.as<HrState>(), h_warm, max_iter, quiet.as<int>(), rounds);
+      hipLaunchKernelGGL(kres, dim3(grid), dim3(HR_NT), r_lds, stream, pts, w, n, ds, k, cent, sums.as<u64>(), cnts.as<u64>(), hmove.as<double>(), hhalf.as<double>(), assign,
+                         hub.as<double>(), hlb.as<double>(), hstate.as<HrState>(), h_warm, max_iter, quiet.as<int>());
       TM_HIP(hipGetLastError());
       int q = -1;
       HrState *hs_dev = hstate.as<HrState>();
       unsigned timed_out = 0;
 #if TM_KMR_STAMPS
       std::vector<u64> stamps(HR_NSTAMP + 4);
+      std::vector<unsigned> hlog(300 * 10);
 #endif
       {
         HostRead hr_(stream);
@@ -2087,6 +2157,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         TM_TRY(hr_.get(&timed_out, &hs_dev->timeout, 4));
 #if TM_KMR_STAMPS
         TM_TRY(hr_.get(stamps.data(), hs_dev->stamps, stamps.size() * 8));
+        TM_TRY(hr_.get(hlog.data(), hs_dev->log, hlog.size() * 4));
 #endif
         TM_TRY(hr_.wait());
       }
@@ -2103,6 +2174,9 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         for (int i2 = 1; i2 < 8; i2++) fprintf(stderr, " %s %.0f,", names[i2], (double)stamps[i2] / ni);
         fprintf(stderr, " state in %.0f (once); per iteration %.1f points listed, %.1f scored (all workgroups)\n", (double)stamps[0], (double)stamps[HR_NSTAMP] / ni,
                 (double)stamps[HR_NSTAMP + 1] / ni);
+        for (int i2 = h_warm; i2 < std::min(it, 300); i2 += (i2 < 16 ? 1 : i2 < 64 ? 8 : 32))
+          fprintf(stderr, "[tm_kmr log] iteration %3d: bounds %5u recheck %5u scoring %6u flush %5u barrier %6u deltas %5u update %5u | wg0 listed %4u scored %4u | moved (all) %u\n", i2, hlog[i2 * 10],
+                  hlog[i2 * 10 + 1], hlog[i2 * 10 + 2], hlog[i2 * 10 + 3], hlog[i2 * 10 + 4], hlog[i2 * 10 + 5], hlog[i2 * 10 + 6], hlog[i2 * 10 + 7], hlog[i2 * 10 + 8], hlog[i2 * 10 + 9]);
       }
 #endif
       resident_done = true;
