@@ -1560,39 +1560,45 @@ struct Seg3State {      // zeroed before the launch
   u64 sums[P3_MAXK][3];
   u64 cnts[P3_MAXK];
   u64 pick[P3_MAXK];
-  unsigned bar, changed[3], timeout, pad[3];
-  alignas(128) unsigned rel;  // the barrier's release word, in a line of its own: the waiting workgroups poll IT, so their loads do not queue up with the arrivals' atomics on `bar`
-  unsigned pad2[31];
+  unsigned changed[3], timeout, pad[4];
+  // the barrier of the segment's workgroups, as k_h_resident's (HrState): arrivals counted in up to eight shards, a shard's last arrival adds to
+  // eight replicas of `top`, the waiting workgroups poll their shard's replica; every word on a 128-byte line of its own
+  struct alignas(128) Line { unsigned v; unsigned pad[31]; };
+  Line bar[8], top[8];
 #if TM_KM3_STAMPS
   u64 stamps[8];  // diagnostic build: s_memtime spans of workgroup 0's phases, summed over the iterations
 #endif
 };
 
-__device__ __forceinline__ bool p3_barrier(unsigned *bar, unsigned *rel, unsigned &epoch, unsigned nblk, unsigned *timeout) {
-  // every thread of the workgroup calls it; false: the spin gave up (a workgroup of the segment is not resident), the caller leaves
+__device__ __forceinline__ bool p3_barrier(Seg3State *st, unsigned &epoch, unsigned nblk, unsigned bx) {
+  // every thread of the workgroup calls it; false: the spin gave up (a workgroup of the segment is not resident), the caller leaves.
+  // No fence: everything that crosses workgroups here is an agent-scope atomic on both sides (adds and maxima, relaxed loads), every wave
+  // drains its vmcnt before its workgroup arrives, every load of the data comes behind a workgroup barrier behind the poll -- the hand-off form
+  // of MI355X_MICROARCH.md "Valid forms" that needs no L2 write-back and no L1 invalidate (1.7 us each, twice per iteration, before).
   __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x < 64) {
     epoch++;
-    const unsigned target = epoch * nblk;
-    // the last to arrive publishes the epoch; everybody else polls that word (arrivals are counted on `bar`, which nobody reads in a loop)
-    // (acquire-release on the arrival, release on the publication: the other workgroups' writes are ordered before the waiters' acquire
-    // through the last arriver, as the memory model wants it -- not only because every cross-workgroup datum here is an agent-scope atomic)
-    if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == target)
-      __hip_atomic_store(rel, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
-    for (unsigned spins = 1; __hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch; spins++) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((spins & 255u) == 0 && (spins > (1u << 24) || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  // (a second round trip: rarely)
-        __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
+    if (nblk > 1) {
+      const unsigned sh = bx & 7u, nsh = nblk < 8u ? nblk : 8u;
+      const unsigned mine = (nblk - sh + 7u) >> 3;  // workgroups on this shard
+      bool last = false;
+      if (threadIdx.x == 0) last = __hip_atomic_fetch_add(&st->bar[sh].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * mine;
+      last = __builtin_amdgcn_readfirstlane((int)last) != 0;
+      if (last && threadIdx.x < 8) __hip_atomic_fetch_add(&st->top[threadIdx.x].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // one instruction, eight lines
+      if (threadIdx.x == 0)
+      for (unsigned spins = 1; __hip_atomic_load(&st->top[sh].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nsh; spins++) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255u) == 0 && (spins > (1u << 24) || __hip_atomic_load(&st->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  // (a second round trip: rarely)
+          __hip_atomic_store(&st->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_ok = ok;
+    if (threadIdx.x == 0) s_ok = ok;
   }
   __syncthreads();
   return s_ok != 0;
@@ -1666,7 +1672,7 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
       for (int wv = 1; wv < P3_NT / 64; wv++) best = s_red[wv] > best ? s_red[wv] : best;
       if (best >> 32) atomicMax(&st->pick[c], best);
     }
-    if (!p3_barrier(&st->bar, &st->rel, epoch, nbx, &st->timeout)) return;
+    if (!p3_barrier(st, epoch, nbx, (unsigned)bx)) return;
     const u64 win = __hip_atomic_load(&st->pick[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((win >> 32) == 0) break;  // no distinct point left
     const int32_t *pc = pts + (sg.begin + (int64_t)(0xffffffffu - (uint32_t)win)) * 3;
@@ -1838,7 +1844,7 @@ __global__ __launch_bounds__(P3_NT, P3_WGS) void k_kmeans3_persistent(const int3
     }
     if (tid == 0 && s_chg) atomicAdd(&st->changed[it % 3], (unsigned)s_chg);
     P3_STAMP(4);  // flush
-    if (!p3_barrier(&st->bar, &st->rel, epoch, nbx, &st->timeout)) return;
+    if (!p3_barrier(st, epoch, nbx, (unsigned)bx)) return;
     P3_STAMP(5);  // barrier of the segment's workgroups
     // (the three loads leave together: one round trip instead of three)
     const int uc = min(tid / 3, P3_MAXK - 1), uj = tid - (tid / 3) * 3;
