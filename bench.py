@@ -206,6 +206,70 @@ def cpu_baseline(width, height, nframes, palette_count, t_global, t_distinct, se
     }
 
 
+def parity_gate(enc, frames, nframes, tm_w, tm_h, oracle_so):
+    """BASELINE.md section 3's gate, on the clip and the encoder state the timed steps ran on, called between Reconstruct and Reindex of one
+    more (untimed) step: (1) 4 096 queries of four frames against an exact fp64 scan of the whole database (integer-valued doubles: the matmul
+    is exact) -- tile index (lowest among equals) and error; (2) with the CPU baseline's oracle at hand, 192 global tiles' dither indices against
+    the oracle's Thomas-Knoll.  Returns a dict; "passed" is False on the first mismatch."""
+    import torch
+    from tiler_amd import stages
+    res = {"passed": True, "knn_sample": None, "dither_sample": None}
+    per = tm_w * tm_h
+    hdr, pal_px, rgb = enc.Tiles()
+    pals = enc.Palettes()
+    pal_idx = hdr["PalIdx_Initial"].astype(np.int32)
+    T = pal_px.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(20251005)
+    db = stages.features_pal(torch.from_numpy(pal_px).cuda(), torch.from_numpy(pal_idx).cuda(), torch.from_numpy(pals).cuda(), 1)
+    dbd = db.to(torch.float64)
+    dn = (dbd * dbd).sum(1)
+    checked = wrong = 0
+    kinds = {"tile_index": 0, "psnr": 0, "palette_of_tile": 0}
+    first_bad = None
+    for f in torch.randint(0, nframes, (4,), generator=gen, device="cuda").tolist():
+        ft, _, _ = stages.load(frames[f:f + 1], tm_w, tm_h)
+        qf = stages.features_rgb(ft, None, 1, False)
+        pick = torch.randperm(per, generator=gen, device="cuda")[:1024]
+        tmap = enc.TileMap(f)
+        got_idx = torch.from_numpy(tmap["TileIdx"].astype(np.int64)).cuda()[pick]
+        got_psnr = tmap["PSNR"][pick.cpu().numpy()]
+        for s0 in range(0, pick.shape[0], 256):
+            q = qf[pick[s0:s0 + 256]].to(torch.float64)
+            d = (q * q).sum(1)[:, None] + dn[None, :] - 2.0 * (q @ dbd.T)
+            m = d.min(1).values
+            first = (d == m[:, None]).to(torch.uint8).argmax(1)  # lowest index among the minima
+            bad_i = first != got_idx[s0:s0 + 256]
+            kinds["tile_index"] += int(bad_i.sum().item())
+            if first_bad is None and bool(bad_i.any()):
+                j = int(torch.nonzero(bad_i)[0].item())
+                gi = int(got_idx[s0 + j].item())
+                first_bad = {"frame": f, "position": int(pick[s0 + j].item()), "got_tile": gi, "want_tile": int(first[j].item()), "want_err": float(m[j].item()),
+                             "err_of_got_tile": float(d[j, gi].item()) if 0 <= gi < T else None}
+            # EuclideanToPSNR, utils.pas:1074-1078: the mean error as a Single, the logarithm in double, the result a Single
+            r32 = (m.cpu().numpy() * (1.0 / 192)).astype(np.float32)
+            want = (10.0 * np.log10(255.0 * 255.0 / np.maximum(np.float32(0.5), r32).astype(np.float64))).astype(np.float32)
+            kinds["psnr"] += int((~np.isclose(got_psnr[s0:s0 + 256], want, rtol=1e-6)).sum())
+            checked += q.shape[0]
+        kinds["palette_of_tile"] += int((tmap["PalIdx"] != pal_idx[tmap["TileIdx"]]).sum())
+    wrong = sum(kinds.values())
+    res["knn_sample"] = {"queries": checked, "database_rows": int(T), "mismatches": wrong, "by_kind": kinds, "first_wrong_tile": first_bad,
+                         "against": "exact fp64 scan (torch matmul on integer-valued doubles), lowest index among equals"}
+    res["passed"] &= wrong == 0
+    del db, dbd, dn
+    if oracle_so is not None:
+        from tests.oracle_binding import Oracle
+        o = Oracle(oracle_so)
+        sample = torch.randint(0, T, (192,), generator=gen, device="cuda").cpu().numpy()
+        gflags = ((hdr["Flags"] >> 3) & 3).astype(np.uint8)
+        want = o.dither(rgb[sample], gflags[sample], pal_idx[sample], pals, True)
+        bad = int((pal_px[sample] != want).any(axis=1).sum())
+        res["dither_sample"] = {"tiles": 192, "mismatches": bad, "against": "the oracle's Thomas-Knoll (DeviseBestMixingPlanThomasKnoll, tilingencoder.pas:2565-2612) on the same tiles and palettes"}
+        res["passed"] &= bad == 0
+    else:
+        res["dither_sample"] = "skipped: the oracle is only loaded where the CPU baseline runs (rank 0 of a one-GPU run without --no-cpu-baseline)"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,6 +467,30 @@ def main():
     }
     if traffic is not None:  # what the committed PMC passes of this kernel build say beside the traffic: matrix pipe busy time, L2 hit rate
         out["roofline"].update({"pmc_" + k: v for k, v in _traffic_from_profiles.extra.items()})
+    # ---- parity gate, outside the timed region: one more step on the very clip and encoder `value` was timed on, checked
+    # between its Reconstruct and its Reindex.  Every rank runs the step (its collectives need them all); rank 0 checks.  A mismatch is fatal.
+    gate_box = {}
+
+    def _gate():
+        if rank == 0 and args.motion_radius == 0:
+            oracle_so = None
+            if world == 1 and not args.no_cpu_baseline:
+                import subprocess
+                oracle_so = os.path.join(ROOT, "oracle", "libtm_oracle.so")
+                if not os.path.exists(oracle_so):
+                    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libtm_oracle.so"])
+            gate_box.update(parity_gate(enc, frames, F, c["tm_w"], c["tm_h"], oracle_so))
+    distributed.run_all(enc, F, rank, world, before_reindex=_gate)
+    if rank == 0:
+        if args.motion_radius != 0:
+            out["parity_gate"] = "not run: the gate checks the KNN-only pipeline of the headline (MotionPredictRadius=0)"
+        else:
+            out["parity_gate"] = "passed" if gate_box.get("passed") else "FAILED"
+            out["parity_gate_detail"] = {k: v for k, v in gate_box.items() if k != "passed"}
+            if not gate_box.get("passed"):
+                print(json.dumps(out), flush=True)
+                print("[bench] PARITY GATE FAILED: %r" % (gate_box,), file=sys.stderr)
+                raise SystemExit(3)
     if world == 1 and not args.no_h2d_extra:
         # SURVEY.md 8(d)'s metric as it is defined, "H2D/D2H included": the same K steps with the clip in page-locked host memory -- every
         # step is handed the clip anew (tm_set_frames_host lends it until that step's Load has returned) and its Load moves 4*W*H*F bytes

@@ -29,6 +29,7 @@
  * and never read inside a step.  Set and not "0" = on.
  *   TM_KNN_DEBUG            one line per search on stderr: the three kernels' times, pairs evaluated, list sizes, matrix instructions
  *   TM_KNN_NOPRUNE          the nearest-neighbour scan evaluates every (query, row) pair (bench.py's dense diagnostic launch)
+ *   TM_KNN_ARENA_ENTRIES=<n> first size of the scan's tile-list arena (tests: a tiny one, so that a search is repeated with the counted size)
  *   TM_TOPK_BRUTE           the k-nearest search by the VALU brute force (tests compare the pruned scan with it)
  *   TM_EPU_TABLE_GIB=<x>    above this size the (tile, palette) feature table is not built, the pairs asked for are (default 6)
  *   TM_NO_QUERY_GROUPS      Reconstruct searches once per tile-map item instead of once per distinct frame tile (tests)
@@ -308,6 +309,10 @@ TM_API void tm_knn_index_destroy(tm_knn_index *);
 TM_API int tm_knn_index_search(tm_knn_index *, const void *queries_i16, int64_t nq, void *out_idx, void *out_err, void *stream);
 /* measured device time (ms, HIP events on `stream`) of the distance kernel in the last search, and its MFMA K */
 TM_API int tm_knn_index_last_stats(tm_knn_index *, double *kernel_ms, int *k_bytes, int64_t *pairs);
+/* diagnostics (tests): the digit plan of the calling thread's last scan -- 32-column chunks that carry a high digit on the database / query
+ * side, 0..6 each, and whether it was the k-nearest collection: together they name the instantiation of the scan's kernels that ran -- and
+ * how often a scan of this process has been repeated with a larger tile-list arena (TM_KNN_ARENA_ENTRIES sets the first size) */
+TM_API int tm_knn_last_plan(int *ht, int *hq, int *topk, int64_t *arena_retries);
 
 /* A12: Dither (:1873) = PreparePlan (:2268) + DitherTile (:2688) for every tile.  tiles/flags as above,
  * pal_idx i32 [n], palettes i32 [npal][pal_size] -> pal_px u8 [n][64] (canonical orientation). */

@@ -18,10 +18,12 @@ SIZES = {
 }
 
 
-def device_video(w, h, nf, seed=1234, noise=8, rho=0.25, cut=100):
+def device_video(w, h, nf, seed=1234, noise=8, rho=0.25, cut=100, freeze=True):
+    """freeze=True: every third tile column keeps its frame-0 gradient (exact inter-frame duplicates, the clip of rounds 1-3);
+    freeze=False: SURVEY.md 8(d)'s generator as written -- the clip bench.py quotes `value` on (no duplicate frame tiles)"""
     g = torch.Generator(device="cuda").manual_seed(seed)
     y, x = torch.meshgrid(torch.arange(h, device="cuda"), torch.arange(w, device="cuda"), indexing="ij")
-    frozen = ((x >> 3) % 3 == 0)
+    frozen = ((x >> 3) % 3 == 0) if freeze else torch.zeros_like(x, dtype=torch.bool)
     out = torch.empty((nf, h, w), dtype=torch.int32, device="cuda")
     th, tw = (h + 7) // 8, (w + 7) // 8
     for f in range(nf):
@@ -59,16 +61,18 @@ def exact_nn(qf, db, block=256):
     return idx, err
 
 
-@pytest.mark.parametrize("name", ["720p300", "1080p1000", "4k600"])
+@pytest.mark.parametrize("name", ["720p300", "720p300-literal", "1080p1000", "4k600"])
 def test_full_size_properties(oracle, name, tmp_path):
     from tiler_amd import stages
     from tiler_amd.encoder import TilingEncoder, TEncoderStep as S
+    literal = name.endswith("-literal")  # the generator as SURVEY.md 8(d) writes it: what bench.py's `value` is timed on
+    name = name.split("-")[0]
     w, h, nf, npal = SIZES[name]
     free, _ = torch.cuda.mem_get_info()
     need = nf * h * w * 4 * 4.5
     if free < need:
         pytest.skip(f"needs ~{need / 2**30:.0f} GiB of HBM")
-    frames = device_video(w, h, nf)
+    frames = device_video(w, h, nf, freeze=not literal)
     tm_w, tm_h = w // 8, h // 8
     per, q = tm_w * tm_h, nf * tm_w * tm_h
     enc = TilingEncoder()

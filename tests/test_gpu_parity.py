@@ -115,6 +115,78 @@ def test_features_first_look_agrees_with_reference_order(mode, use_lab, monkeypa
         assert torch.equal(cfast, cplain)
 
 
+def _tile_kinds(n, seed):
+    """noise, flat, two-colour, grey ramps, near-black and plain noise again: the kinds test_features_first_look_agrees_with_reference_order builds"""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 1 << 24, size=(n, 64), dtype=np.uint32)
+    k = n // 6
+    t[k:2 * k] = t[k:2 * k, :1]
+    two = rng.integers(0, 1 << 24, size=(k, 2), dtype=np.uint32)
+    t[2 * k:3 * k] = np.take_along_axis(two, rng.integers(0, 2, size=(k, 64)), axis=1)
+    v = np.clip((np.arange(64) % 8)[None, :] * rng.integers(0, 32, size=(k, 1)) + rng.integers(0, 32, size=(k, 1)), 0, 255).astype(np.uint32)
+    t[3 * k:4 * k] = v | (v << 8) | (v << 16)
+    t[4 * k:5 * k] &= 0x070707
+    return t, rng.integers(0, 4, size=n).astype(np.uint8)
+
+
+def test_features_default_path_against_the_oracle_at_scale(oracle):
+    """the shipped (separable first look) int16 features of 120 000 tiles of every kind against the ORACLE's reference-order sums, for the
+    two forms the pipeline runs: pvsWeightedDCT on YUV with mirrors (the search's features, A5 / A13 / A14) and the clustering's int32
+    features (pvsWeightedSpeDCT on Lab, A6).  The in-doubt branch fires for a few coefficients per thousand: ~70 000 of them here."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tiler_amd import stages
+    n = 120000
+    t, flags = _tile_kinds(n, 2025)
+    parts = [slice(i * n // 8, (i + 1) * n // 8) for i in range(8)]
+    with ThreadPoolExecutor(8) as ex:  # (ctypes drops the GIL)
+        exp = np.concatenate(list(ex.map(lambda sl: oracle.features_rgb(t[sl], flags[sl], 1, False), parts)))
+        expc = np.concatenate(list(ex.map(lambda sl: oracle.features_cluster(t[sl], 4), parts)))
+    got = stages.features_rgb(_dev(t), _dev(flags), 1, False).cpu().numpy()
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, "%d coefficients differ, first at tile %d coefficient %d" % (bad.shape[0], bad[0][0], bad[0][1])
+    gotc = stages.features_cluster(_dev(t), 4).cpu().numpy()
+    assert np.array_equal(gotc, expc)
+
+
+def test_features_first_look_in_every_source_instantiation(monkeypatch):
+    """the first look's margin in the kernel's other sources: palette-indexed tiles (k_features_i16<1>: small palettes, extreme
+    colours), all 8 x 8 windows of a frame buffer (<2>), the (tile, palette) table (<3>) and pairs (<4>) through the k-nearest re-rank's
+    two paths -- default against TM_FEATURES_PLAIN=1 (every coefficient in the reference's order)"""
+    from tiler_amd import stages
+    g = torch.Generator(device="cuda").manual_seed(808)
+    n, npal = 200000, 6
+    palettes = torch.randint(0, 1 << 24, (npal, 16), generator=g, device="cuda", dtype=torch.int32)
+    palettes[0, :] = torch.tensor([0, 0xFFFFFF] * 8, device="cuda", dtype=torch.int32)          # extremes
+    palettes[1, :] = torch.arange(16, device="cuda", dtype=torch.int32) * 0x010101               # near black
+    palettes[2, 2:] = palettes[2, :1]                                                              # three live colours
+    pal_idx = torch.randint(0, npal, (n,), generator=g, device="cuda", dtype=torch.int32)
+    pal_px = torch.randint(0, 16, (n, 64), generator=g, device="cuda", dtype=torch.uint8)
+    pal_px[: n // 4] = pal_px[: n // 4] & 1                                                        # two-colour tiles
+    fb = torch.randint(0, 1 << 24, (136, 264), generator=g, device="cuda", dtype=torch.int32)
+    fb[:, :64] = fb[:1, :64]
+    fb[40:80] &= 0x0F0F0F
+    q = stages.features_pal(pal_px[:3000], pal_idx[:3000], palettes, 1)
+    knn_idx, _ = stages.knn_topk(q, stages.features_pal(pal_px[:20000], pal_idx[:20000], palettes, 1), 64)
+
+    def run():
+        a = stages.features_pal(pal_px, pal_idx, palettes, 1)
+        b = stages.window_dcts(fb)
+        c = stages.epu_rerank(q, knn_idx, pal_px[:20000], pal_idx[:20000], palettes)
+        return a, b, c
+    monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
+    monkeypatch.delenv("TM_EPU_TABLE_GIB", raising=False)
+    fa, fb_, fc = run()
+    monkeypatch.setenv("TM_EPU_TABLE_GIB", "0")   # the pairs asked for, not the table
+    _, _, fd = run()
+    monkeypatch.setenv("TM_FEATURES_PLAIN", "1")
+    _, _, pd = run()
+    monkeypatch.delenv("TM_EPU_TABLE_GIB")
+    pa, pb, pc = run()
+    assert torch.equal(fa, pa) and torch.equal(fb_, pb)
+    for x, y in zip(fc + fd, pc + pd):
+        assert torch.equal(x, y)
+
+
 def test_features_pal_and_cluster(tiles_flags, oracle):
     from tiler_amd import stages
     tiles, _ = tiles_flags
@@ -266,19 +338,114 @@ def test_knn_dense_mode_large(monkeypatch):
     assert pairs == nq * nt
 
 
-@pytest.mark.parametrize("dense", [False, True])
-def test_knn_first_scan_shape_still_exact(dense, monkeypatch):
-    """TM_KNN_V1=1 selects the first scan shape (tm_knn_kernel.h: the k-nearest collection scans still run on it)"""
+def _plan_data(rng, nq, nt, ct, cq):
+    """rows whose first ct (database) / cq (query) columns need a second int8 digit and whose other columns fit one: the digit plan becomes
+    HT = ceil(ct / 32), HQ = ceil(cq / 32) (tm_knn.hip: make_plan_scaled)"""
+    db = rng.integers(-25, 26, size=(nt, 192)).astype(np.int32)
+    q = rng.integers(-25, 26, size=(nq, 192)).astype(np.int32)
+    if ct:
+        db[:, :ct] = rng.integers(-400, 401, size=(nt, ct))
+    if cq:
+        q[:, :cq] = rng.integers(-400, 401, size=(nq, cq))
+    db[nt // 2:] = db[: nt - nt // 2]  # every row twice, far apart in index: ties everywhere, the lower index must win
+    return db.astype(np.int16), q.astype(np.int16)
+
+
+_SEEN_PLANS = set()
+
+
+@pytest.mark.parametrize("hq", range(7))
+@pytest.mark.parametrize("ht", range(7))
+def test_knn_every_digit_plan(ht, hq):
+    """every instantiation <HT, HQ> of the scan's kernels (7 x 7 digit plans: k_knn_seed, k_knn_consume and, below, its collection mode) is
+    driven once and named by what the library says ran (tm_knn_last_plan): nearest neighbour against the fp64 brute force, pruned and dense.
+    (Round 4's fault sat in one instantiation, <6, 6, collection>, that no test named.)"""
     from tiler_amd import stages
-    monkeypatch.setenv("TM_KNN_V1", "1")
-    if dense:
-        monkeypatch.setenv("TM_KNN_NOPRUNE", "1")
-    rng = np.random.default_rng(99)
-    db, q = _hostile("features", rng, 3000, 9000)
+    rng = np.random.default_rng(1000 + ht * 7 + hq)
+    nq, nt = 700, 4200
+    db, q = _plan_data(rng, nq, nt, 32 * ht - (5 if ht else 0), 32 * hq - (5 if hq else 0))
     eidx, eerr = _torch_nn(q, db)
     idx, err = stages.knn(_dev(q), _dev(db))
-    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr)
-    assert np.array_equal(idx.cpu().numpy(), eidx)
+    got = stages.knn_last_plan()
+    assert got[:3] == (ht, hq, 0), "the data was built for <%d, %d>, the library planned %r" % (ht, hq, got)
+    _SEEN_PLANS.add((ht, hq, 0))
+    assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr) and np.array_equal(idx.cpu().numpy(), eidx)
+
+
+@pytest.mark.parametrize("ht,hq", [(6, 6), (0, 0), (6, 0), (0, 6), (3, 5), (5, 3), (1, 1), (2, 6), (6, 2), (4, 4), (1, 6), (6, 1), (2, 3), (3, 2), (5, 5), (4, 1), (1, 4)])
+def test_knn_topk_digit_plans(ht, hq, monkeypatch):
+    """the collection mode of the consume kernel (k = 64) on named digit plans, <6, 6> first, against the VALU brute force's exact top 64"""
+    from tiler_amd import stages
+    monkeypatch.delenv("TM_TOPK_BRUTE", raising=False)
+    rng = np.random.default_rng(5000 + ht * 7 + hq)
+    nq, nt, k = 300, 6000, 64
+    db, q = _plan_data(rng, nq, nt, 32 * ht - (7 if ht else 0), 32 * hq - (7 if hq else 0))
+    idx, err = stages.knn_topk(_dev(q), _dev(db), k)
+    got = stages.knn_last_plan()
+    assert got[:3] == (ht, hq, 1), "the data was built for <%d, %d, collection>, the library planned %r" % (ht, hq, got)
+    _SEEN_PLANS.add((ht, hq, 1))
+    monkeypatch.setenv("TM_TOPK_BRUTE", "1")
+    bidx, berr = stages.knn_topk(_dev(q), _dev(db), k)
+    assert torch.equal(err, berr) and torch.equal(idx, bidx)
+
+
+def test_knn_plans_covered():
+    """(runs after the two tests above in file order) every nearest-neighbour instantiation and the listed collection ones were named"""
+    if not _SEEN_PLANS:
+        pytest.skip("the plan tests did not run in this session")
+    assert {(a, b, 0) for a in range(7) for b in range(7)} <= _SEEN_PLANS
+    assert (6, 6, 1) in _SEEN_PLANS
+
+
+@pytest.mark.parametrize("mode", ["nearest", "topk"])
+def test_knn_list_arena_overflow_is_repeated_with_the_counted_size(mode, monkeypatch):
+    """TM_KNN_ARENA_ENTRIES=64: the tile lists of the first attempt cannot fit, the scan reads the counted size back and runs again
+    (knn_index_search / the collection pass): the result is the brute force's, and the retry counter moved.  (The arena's floor and the
+    process-wide experience otherwise make this path depend on test order: ADVICE r04.)"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(77)
+    centres = _rand_features(rng, 30, 500).astype(np.int32)
+    nt, nq = 30000, 6000
+    db = (centres[rng.integers(0, 30, size=nt)] + rng.integers(-80, 81, size=(nt, 192))).astype(np.int16)
+    q = (centres[rng.integers(0, 30, size=nq)] + rng.integers(-80, 81, size=(nq, 192))).astype(np.int16)
+    monkeypatch.setenv("TM_KNN_ARENA_ENTRIES", "64")
+    before = stages.knn_last_plan()[3]
+    if mode == "nearest":
+        eidx, eerr = _torch_nn(q, db)
+        idx, err = stages.knn(_dev(q), _dev(db))
+        assert np.array_equal(err.cpu().numpy().view(np.uint32), eerr) and np.array_equal(idx.cpu().numpy(), eidx)
+    else:
+        k = 64
+        idx, err = stages.knn_topk(_dev(q[:1500]), _dev(db), k)
+        monkeypatch.delenv("TM_KNN_ARENA_ENTRIES")
+        monkeypatch.setenv("TM_TOPK_BRUTE", "1")
+        bidx, berr = stages.knn_topk(_dev(q[:1500]), _dev(db), k)
+        assert torch.equal(err, berr) and torch.equal(idx, bidx)
+    assert stages.knn_last_plan()[3] > before, "the search was not repeated: the arena did not overflow"
+
+
+def test_knn_high_chunk_masks_with_many_tiles():
+    """list entries are tile << 8 | mask of the tile's non-zero high-digit chunks: more than 65 536 database tiles (2.2 M rows) whose high chunks
+    are non-zero on most tiles, pruned scan against the exact fp64 scan on a sample; the guard word the consume loop leaves (a tile index or a
+    segment out of range) is checked by the library on every search and would fail it (round 4's aperture fault: tile | mask << 24)"""
+    from tiler_amd import stages
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    nt, nq = 2_200_000, 20_000
+    centres = torch.randint(-1500, 1501, (64, 192), generator=g, device="cuda", dtype=torch.int32)
+    centres[:, 40:] //= 15  # (the wide columns are a prefix of 40: every possible SSD stays below 2^31)
+    db = (centres[torch.randint(0, 64, (nt,), generator=g, device="cuda")] + torch.randint(-300, 301, (nt, 192), generator=g, device="cuda", dtype=torch.int32)).to(torch.int16)
+    q = (centres[torch.randint(0, 64, (nq,), generator=g, device="cuda")] + torch.randint(-300, 301, (nq, 192), generator=g, device="cuda", dtype=torch.int32)).to(torch.int16)
+    idx, err = stages.knn(q, db)
+    ht, hq, _, _ = stages.knn_last_plan()
+    assert ht >= 1 and hq >= 1 and nt // 32 > 65536
+    dbd = db.to(torch.float64)
+    dn = (dbd * dbd).sum(1)
+    for s0 in range(0, 2048, 256):
+        qq = q[s0:s0 + 256].to(torch.float64)
+        d = (qq * qq).sum(1)[:, None] + dn[None, :] - 2.0 * (qq @ dbd.T)
+        m = d.min(1).values
+        first = (d == m[:, None]).to(torch.uint8).argmax(1)
+        assert torch.equal(first.to(torch.int32), idx[s0:s0 + 256]) and torch.equal(m.to(torch.int64), err[s0:s0 + 256].to(torch.int64) & 0xFFFFFFFF)
 
 
 def test_knn_many_groups_clustered():

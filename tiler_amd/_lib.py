@@ -43,6 +43,7 @@ SIGNATURES = {
     "tm_knn_index_destroy": (None, [c_void_p]),
     "tm_knn_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "tm_knn_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "tm_knn_last_plan": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
     "tm_stage_dedup": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     "tm_stage_kmeans": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                 ctypes.POINTER(c_int), c_void_p]),

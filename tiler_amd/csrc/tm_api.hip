@@ -109,6 +109,13 @@ int tm_knn_index_last_stats(tm_knn_index *ix, double *kernel_ms, int *k_bytes, i
   return TM_OK;
 }
 
+int tm_knn_last_plan(int *ht, int *hq, int *topk, int64_t *arena_retries) {
+  long long r = 0;
+  knn_last_plan(ht, hq, topk, &r);
+  if (arena_retries) *arena_retries = (int64_t)r;
+  return TM_OK;
+}
+
 int tm_stage_knn(const void *queries_i16, int64_t nq, const void *db_i16, int64_t nt, void *out_idx, void *out_err, void *stream) {
   knobs_reload();
   tm_knn_index_impl *ix = nullptr;

@@ -50,6 +50,7 @@ struct Knobs {
        dither_literal = false, dedup_plain = false, dedup_degrade_hash = false, dedup_full_order = false, motion_valu = false, pp_debug = false,
        comm_force_dist = false, features_plain = false, km_launches = false;
   double epu_table_gib = 6.0, comm_timeout_s = 120.0;
+  long long knn_arena_entries = 0;
 };
 const Knobs &knobs();
 void knobs_reload();

@@ -38,6 +38,7 @@ void knn_index_destroy(tm_knn_index_impl *ix);
 // query_colmm (optional): the queries' column ranges as launch_features_rgb_rows leaves them (device, [384]) -- saves the search its own pass
 int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, void *out_idx, void *out_err, hipStream_t stream, const void *query_colmm = nullptr);
 void knn_index_stats(tm_knn_index_impl *ix, double *ms, int *kbytes, int64_t *pairs);
+void knn_last_plan(int *ht, int *hq, int *topk, long long *arena_retries);
 // the last search's three kernels on their own: ms of seeds / lists / consume; pairs evaluated by seeds / consume, matrix instructions the consume kernel issued
 void knn_index_kernel_split(tm_knn_index_impl *ix, double ms[3], int64_t pairs[3]);
 // grp_off / grp_members (optional): the index was built over DISTINCT rows; results are expanded to the original rows (member lists

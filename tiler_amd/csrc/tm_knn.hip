@@ -926,6 +926,22 @@ __global__ __launch_bounds__(256) void k_knn_qmeta(const uint32_t *__restrict__ 
     default: FN<6>(hq, a, stream); break;                            \
   }
 static std::atomic<double> g_list_entries_per_group{640.0};
+// diagnostics for the tests (tm_knn_last_plan): the digit plan and mode of the calling thread's last scan (which instantiation of the
+// kernels ran), and how many times a scan of this process was repeated because its tile lists outgrew the arena
+struct KnnLastPlan { int ht = -1, hq = -1, topk = 0; };
+static thread_local KnnLastPlan t_last_plan;
+static std::atomic<long long> g_arena_retries{0};
+void knn_last_plan(int *ht, int *hq, int *topk, long long *arena_retries) {
+  if (ht) *ht = t_last_plan.ht;
+  if (hq) *hq = t_last_plan.hq;
+  if (topk) *topk = t_last_plan.topk;
+  if (arena_retries) *arena_retries = g_arena_retries.load();
+}
+// the arena's first size: TM_KNN_ARENA_ENTRIES (tests: a tiny arena, so that the repeat-with-the-counted-size path runs) or the experience
+static uint64_t arena_first_size(int64_t n_groups, double factor) {
+  if (knobs().knn_arena_entries > 0) return (uint64_t)knobs().knn_arena_entries;
+  return std::max<uint64_t>(1u << 16, (uint64_t)((double)n_groups * factor * g_list_entries_per_group.load()));
+}
 static void launch_seed3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_seed_ht) }
 static void launch_consume3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_consume_ht) }
 static void launch_collect3(int ht, int hq, const Knn3Args &a, hipStream_t stream) { TM_KNN3_BY_HT(knn3_launch_collect_ht) }
@@ -961,7 +977,7 @@ static int launch_scan3(tm_knn_index_impl *ix, int64_t nq, int64_t nqt, int64_t 
     TM_TRY(ix->segs.alloc((size_t)a.n_groups * a.max_segs * 8)); TM_TRY(ix->nsegs.alloc((size_t)a.n_groups * 4));
     // entries per group: what the process's searches have needed so far (+ 30 %), 640 to begin with -- an index lives for one Reconstruct,
     // the experience is kept beside it
-    const uint64_t want = std::max<uint64_t>(ix->arena_want, std::max<uint64_t>(1u << 16, (uint64_t)((double)a.n_groups * g_list_entries_per_group.load())));
+    const uint64_t want = std::max<uint64_t>(ix->arena_want, arena_first_size(a.n_groups, 1.0));
     TM_CHECK(want < (1ull << 32), TM_E_UNSUPPORTED, "knn: %llu list entries exceed the arena's 32-bit offsets", (unsigned long long)want);
     TM_TRY(ix->arena_tile.alloc((size_t)want * 4)); TM_TRY(ix->arena_lb.alloc((size_t)want * nsp * 2));  // (no-ops while they are large enough)
     ix->arena_cap = want;
@@ -983,6 +999,7 @@ static int launch_scan3(tm_knn_index_impl *ix, int64_t nq, int64_t nqt, int64_t 
     TM_HIP(hipEventRecord(ix->ev_seed, stream));
     TM_HIP(hipEventRecord(ix->ev_lists, stream));
   }
+  t_last_plan.ht = ix->plan.ht; t_last_plan.hq = ix->plan.hq; t_last_plan.topk = 0;
   launch_consume3(ix->plan.ht, ix->plan.hq, a, stream);
   TM_HIP(hipGetLastError());
   return TM_OK;
@@ -1181,6 +1198,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
     if (knobs().knn_debug) fprintf(stderr, "[tm_knn] list arena: %llu entries needed, %llu held -- searching again\n", cnt[20], (unsigned long long)ix->arena_cap);
     ix->arena_want = cnt[20] + cnt[20] / 4;
+    g_arena_retries.fetch_add(1);
     continue;
   }
   break;
@@ -1329,7 +1347,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     hipLaunchKernelGGL(k_knn_tau_bounds, dim3((unsigned)std::min<int64_t>((nqt + 7) / 8, 2048)), dim3(256), 0, stream, tau.as<int>(), n, nqt, a.gsmax);
     for (int attempt = 0;; attempt++) {
       // collection lists are long (a threshold from 32 tiles of the curve is loose): twice the nearest-neighbour search's experience to begin with
-      const uint64_t want = std::max<uint64_t>(ix->arena_want, std::max<uint64_t>(1u << 16, (uint64_t)((double)a.n_groups * 2.0 * g_list_entries_per_group.load())));
+      const uint64_t want = std::max<uint64_t>(ix->arena_want, arena_first_size(a.n_groups, 2.0));
       TM_CHECK(want < (1ull << 32), TM_E_UNSUPPORTED, "knn: %llu list entries exceed the arena's 32-bit offsets", (unsigned long long)want);
       TM_TRY(ix->arena_tile.alloc((size_t)want * 4)); TM_TRY(ix->arena_lb.alloc((size_t)want * nsp * 2));
       ix->arena_cap = want;
@@ -1345,7 +1363,9 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
       if (cursor <= ix->arena_cap) break;
       TM_CHECK(attempt < 2, TM_E_HIP, "knn: the list arena overflowed again after growing to %llu entries", (unsigned long long)ix->arena_cap);
       ix->arena_want = cursor + cursor / 4;
+      g_arena_retries.fetch_add(1);
     }
+    t_last_plan.ht = ix->plan.ht; t_last_plan.hq = ix->plan.hq; t_last_plan.topk = 1;
     launch_collect3(ix->plan.ht, ix->plan.hq, a, stream);
     TM_HIP(hipGetLastError());
   }

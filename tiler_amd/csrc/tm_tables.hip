@@ -154,6 +154,7 @@ void knobs_reload() {
   k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST"); k.features_plain = on("TM_FEATURES_PLAIN"); k.km_launches = on("TM_KM_LAUNCHES");
   if (const char *v = getenv("TM_EPU_TABLE_GIB")) k.epu_table_gib = atof(v);
   if (const char *v = getenv("TM_COMM_TIMEOUT_S")) k.comm_timeout_s = std::max(1.0, atof(v));
+  if (const char *v = getenv("TM_KNN_ARENA_ENTRIES")) k.knn_arena_entries = std::max(0ll, atoll(v));
   t_knobs = k;
 }
 

@@ -176,9 +176,10 @@ class Collective:
         return self._cb
 
 
-def run_all(enc, nframes, rank=0, world=1, group=None):
+def run_all(enc, nframes, rank=0, world=1, group=None, before_reindex=None):
     """Run(esAll) over `world` processes.  `enc` needs Run/SetCollective/SetQueryShard/KeyFrames and the MotionPredictRadius
-    setting (TilingEncoder or a stand-in)."""
+    setting (TilingEncoder or a stand-in).  before_reindex (optional): called on every rank between Reconstruct and Reindex, when the
+    tile maps still index the dithered global tiles (bench.py's parity gate)."""
     from .encoder import TEncoderStep as S
     coll = getattr(enc, "_collective", None)
     native = getattr(enc, "_native_comm", None)  # TilingEncoder.CommInit: the library's own RCCL communicator carries the merges
@@ -211,4 +212,6 @@ def run_all(enc, nframes, rank=0, world=1, group=None):
         first, count = keyframe_shard(enc.KeyFrames(), nframes, rank, world)
         enc.SetQueryShard(first, count)
     run(S.esReconstruct)
+    if before_reindex is not None:
+        before_reindex()
     run(S.esReindex)

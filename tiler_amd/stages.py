@@ -110,6 +110,13 @@ def knn(queries, db):
     return idx, err
 
 
+def knn_last_plan():
+    """(ht, hq, topk, arena_retries): the digit plan and mode of this thread's last scan, and the process's count of repeated scans (tests)"""
+    ht, hq, tk, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    check(lib().tm_knn_last_plan(ctypes.byref(ht), ctypes.byref(hq), ctypes.byref(tk), ctypes.byref(r)))
+    return ht.value, hq.value, tk.value, r.value
+
+
 class KnnIndex:
     """ann_kdtree_short_create analogue: the database is packed once and searched by many query batches."""
 
