@@ -186,6 +186,72 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr
   return acc;
 }
 
+// Two blocks at once: the tile against TWO sub-tiles, two independent accumulators fed in turn (the tile's A operands serve both).  A wave's
+// lone chain leaves the matrix pipe idle between its dependent products and while each operand comes out of LDS -- with four waves per SIMD
+// (the register file allows no more) the pipe sat busy 43 % of the time for three rounds; two chains interleaved in one instruction stream
+// halve what a wave exposes of both latencies.  The arithmetic of each chain is k3_chain's, product for product.
+#ifndef TM_KNN3_DUAL
+#define TM_KNN3_DUAL 0  // measured (round 5): 13.9 against 12.5 ms at 16 waves (twelve spilled registers), 13.7 against ~14.1 at 12 waves: the chain's own latency is not what the pipe waits for
+#endif
+template <int HT, int HQ, bool TD>
+__device__ __forceinline__ void k3_chain2(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q0, const uint8_t *q1, unsigned tm, unsigned qm0, unsigned qm1,
+                                          v16i &acc0, v16i &acc1) {
+  constexpr int HM = HT < HQ ? HT : HQ;
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
+  if (TD && HT + HQ == 0) { acc0 = ntr; acc1 = ntr; }
+  if (HM > 0) {
+    const unsigned h0 = tm & qm0, h1 = tm & qm1;
+    if (h0 | h1) {
+#pragma unroll
+      for (int kc = 0; kc < HM; kc++) {
+        if ((h0 >> kc) & 1u) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q0 + (6 + kc) * 1024), acc0, 0, 0, 0);  // T_H . Q_H
+        if ((h1 >> kc) & 1u) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q1 + (6 + kc) * 1024), acc1, 0, 0, 0);
+      }
+      if (h0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc0[r] = (int)((unsigned)acc0[r] << 8);
+      }
+      if (h1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc1[r] = (int)((unsigned)acc1[r] << 8);
+      }
+    }
+  }
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int kc = 0; kc < HQ; kc++) {
+      if ((qm0 >> kc) & 1u) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q0 + (6 + kc) * 1024), acc0, 0, 0, 0);      // T_L . Q_H
+      if ((qm1 >> kc) & 1u) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q1 + (6 + kc) * 1024), acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int kc = 0; kc < HT; kc++)
+      if ((tm >> kc) & 1u) {
+        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q0 + kc * 1024), acc0, 0, 0, 0);                            // T_H . Q_L
+        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q1 + kc * 1024), acc1, 0, 0, 0);
+      }
+  }
+  v4i qa = *reinterpret_cast<const v4i *>(q0), qb = *reinterpret_cast<const v4i *>(q1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (HT + HQ > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc0[r] = (int)(((unsigned)acc0[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc1[r] = (int)(((unsigned)acc1[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+  }
+  // T_L . Q_L, six products a chain, the chains in turn: an operand buffer is asked for again right behind the matrix instruction that read it,
+  // two matrix instructions before its next use
+#pragma unroll
+  for (int kc = 0; kc < 6; kc++) {
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], qa, acc0, 0, 0, 0);
+    if (kc < 5) qa = *reinterpret_cast<const v4i *>(q0 + (kc + 1) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], qb, acc1, 0, 0, 0);
+    if (kc < 5) qb = *reinterpret_cast<const v4i *>(q1 + (kc + 1) * 1024);
+  }
+}
+
 // a tile's MFMA A operands and the rows' norms, straight into registers (global_load_dwordx4, 1 KB contiguous per instruction)
 template <int KT>
 __device__ __forceinline__ void k3_load_tile(const uint8_t *tb, int lane, int half, v4i (&T)[KT], v16i &ntr) {
@@ -223,14 +289,13 @@ __device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane,
 // every improvement.
 template <bool TD>
 __device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, int tile, int half, unsigned qn, unsigned long long *best, unsigned *tie,
-                                            unsigned sm_now) {
+                                            unsigned sm_now, unsigned cur_hi /* the query's best as read BEFORE the chain: stale only on the safe side (a best only falls) */) {
   int t[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
   const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
                      min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
   const unsigned key_hi = (unsigned)tm + qn + 1u;  // d'' + 1 >= 0
-  const unsigned cur_hi = k3_peek(reinterpret_cast<unsigned *>(best) + 1);
   bool refresh = false;
   if (key_hi <= cur_hi) {
     // which row (the first one reaching the minimum), and is it alone: a compare, a select and an add-with-carry per register
@@ -374,9 +439,10 @@ __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a)
     if (active) {
       for (int j = 0; j < SL && sl * SL + j < nvalid; j++) {
         const int s = sl * SL + j;
-        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16, tm, (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[s]));
         const int qi = s * 32 + (lane & 31);
-        k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], 0u);
+        const unsigned cur_hi = k3_peek(reinterpret_cast<unsigned *>(&s_best[qi]) + 1), qn = (unsigned)s_qn[qi];  // (asked for before the chain: they arrive under it)
+        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16, tm, (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[s]));
+        k3_epilogue<TD>(acc, ntr, tile, half, qn, &s_best[qi], &s_tie[qi], 0u, cur_hi);
         nblocks++;
         npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
       }
@@ -677,6 +743,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   }
   const int nseg = dense ? (int)((n_ttiles + LCAP - 1) / LCAP) : a.nsegs[g];
   __syncthreads();  // (waits for the LDS-DMA pieces too)
+  const unsigned qmask_v = s_qmask[lane & 15];  // lane s: sub-tile s's mask of non-zero high-digit chunks
   K3_STAMP(0);  // prologue
 
   for (int seg = 0; seg < nseg; seg++) {
@@ -708,7 +775,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     // ---------------------------------------------------------------- consume: every wave on its own
     {
       nlisted += (wave == 0) ? list_n : 0;
-      auto next_entry = [&](int &tile_o, unsigned &tm_o, int &lb_o, unsigned &mask_o) -> bool {
+      auto next_entry = [&](int &tile_o, unsigned &tm_o, int &lb_o, unsigned &mask_o, int &sm_o) -> bool {
         for (;;) {
           int j = 0;
           if (lane == 0) j = atomicAdd(&s_ctl[1], 1);
@@ -730,12 +797,12 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           // Entry word = tile << 8 | mask: the tile comes out by a SHIFT.  (An earlier layout, tile | mask << 24 with `tile = word & 0xFFFFFF`,
           // met a compiler combine that treats the 64-bit multiply by the tile size as a 24-bit multiply, drops the AND as redundant for one,
           // and then selects a full 32-bit v_mad_u64_u32: the loads went to word * 12 KB -- a memory aperture violation on the GPU box.)
-          if (m) { tile_o = __builtin_amdgcn_readfirstlane((int)((unsigned)t >> 8)); tm_o = (unsigned)__builtin_amdgcn_readfirstlane(t) & 0xFFu; lb_o = lb; mask_o = m; return true; }
+          if (m) { tile_o = __builtin_amdgcn_readfirstlane((int)((unsigned)t >> 8)); tm_o = (unsigned)__builtin_amdgcn_readfirstlane(t) & 0xFFu; lb_o = lb; mask_o = m; sm_o = sm; return true; }
         }
       };
-      int tile = 0, lbv = 0;
+      int tile = 0, lbv = 0, smv = 0;
       unsigned mask = 0, tmw = 0;
-      bool have = next_entry(tile, tmw, lbv, mask);
+      bool have = next_entry(tile, tmw, lbv, mask, smv);
       while (have) {
         const unsigned tm = tmw;
         if (tile >= n_ttiles) {  // never by construction: a list entry outside the database (a guard: the loads below must not follow it)
@@ -747,34 +814,26 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
         k3_load_tile_masked<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, tm, T, ntr);
         nloads++;
         // the entry after this one is chosen while the loads fly
-        int ntile = 0, nlb = 0;
+        int ntile = 0, nlb = 0, nsm = 0;
         unsigned nmask = 0, ntm = 0;
-        const bool nhave = next_entry(ntile, ntm, nlb, nmask);
+        const bool nhave = next_entry(ntile, ntm, nlb, nmask, nsm);
 #if TM_KNN3_STAMPS
         K3_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         K3_STAMP(4);  // waiting for the tile's loads (what is left of their latency behind the choice of the next entry)
 #endif
         const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
-        while (mask) {
-          const int s = __builtin_ctz(mask);
-          mask &= mask - 1;
-          // the sub-tile's best may have tightened since the entry was popped
-          const int lbs = __builtin_amdgcn_readlane(lbv, s);
-          const unsigned sm_now = (unsigned)__builtin_amdgcn_readfirstlane((int)k3_peek(&s_smax[s]));
-          if (lbs > (int)sm_now) continue;
-          const unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane((int)s_qmask[s]);
-          const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s * (KQ * 1024) + lane * 16, tm, qm);
-          nmfma += 6 + __builtin_popcount(tm & qm) + __builtin_popcount(qm) + __builtin_popcount(tm);
+        // a block's epilogue and the refresh of its sub-tile's bound
+        auto finish = [&](const v16i &acc, int s, unsigned sm_now, unsigned cur_hi, unsigned qn) {
           const int qi = s * 32 + (lane & 31);
           bool refresh;
           if constexpr (TOPK) {
             const int64_t q = (st0 + s) * 32 + (lane & 31);
             // (the last database tile pads with copies of its last row: they are candidates like any row -- the select stage drops them --
             // but must not count towards a rung)
-            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, (unsigned)s_qn[qi], &s_best[qi], &s_lad[qi * 4], q < a.nq, q, a, sm_now);
+            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, qn, &s_best[qi], &s_lad[qi * 4], q < a.nq, q, a, sm_now);
           } else {
-            refresh = k3_epilogue<TD>(acc, ntr, tile, half, (unsigned)s_qn[qi], &s_best[qi], &s_tie[qi], sm_now);
+            refresh = k3_epilogue<TD>(acc, ntr, tile, half, qn, &s_best[qi], &s_tie[qi], sm_now, cur_hi);
           }
           if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
             const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1));  // = largest d'' + 1
@@ -782,8 +841,55 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           }
           nblocks++;
           npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
+        };
+        // the next sub-tile that still wants the tile (its best may have tightened since the entry was popped); -1: none left
+        auto pick = [&](unsigned &sm_o) -> int {
+          while (mask) {
+            const int s = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int lbs = __builtin_amdgcn_readlane(lbv, s);
+#ifndef TM_KNN3_REPEEK
+#define TM_KNN3_REPEEK 1
+#endif
+            const unsigned sm_now = TM_KNN3_REPEEK ? (unsigned)__builtin_amdgcn_readfirstlane((int)k3_peek(&s_smax[s])) : (unsigned)__builtin_amdgcn_readlane(smv, s);
+            if (lbs > (int)sm_now) continue;
+            sm_o = sm_now;
+            return s;
+          }
+          return -1;
+        };
+        for (;;) {
+          unsigned sm0 = 0, sm1 = 0;
+          const int s0 = pick(sm0);
+          if (s0 < 0) break;
+          // the sub-tile's mask comes out of a register (lane s of qmask_v), the query's best and norm are asked for before the chain: every
+          // LDS round trip a block can do without, or start early, is one the wave does not sit out between its matrix instructions
+          const unsigned qm0 = (unsigned)__builtin_amdgcn_readlane((int)qmask_v, s0);
+          const int qi0 = s0 * 32 + (lane & 31);
+#ifndef TM_KNN3_PRE_QN
+#define TM_KNN3_PRE_QN 1
+#endif
+          const unsigned cur0 = TOPK ? 0u : k3_peek(reinterpret_cast<unsigned *>(&s_best[qi0]) + 1);
+          unsigned qn0 = 0;
+          if (TM_KNN3_PRE_QN) qn0 = (unsigned)s_qn[qi0];
+          const int s1 = (TM_KNN3_DUAL && !TOPK) ? pick(sm1) : -1;
+          if (s1 >= 0) {  // two blocks at once
+            const unsigned qm1 = (unsigned)__builtin_amdgcn_readlane((int)qmask_v, s1);
+            const int qi1 = s1 * 32 + (lane & 31);
+            const unsigned cur1 = k3_peek(reinterpret_cast<unsigned *>(&s_best[qi1]) + 1), qn1 = (unsigned)s_qn[qi1];
+            v16i acc0, acc1;
+            k3_chain2<HT, HQ, TD>(T, ntr, lds + s0 * (KQ * 1024) + lane * 16, lds + s1 * (KQ * 1024) + lane * 16, tm, qm0, qm1, acc0, acc1);
+            nmfma += 12 + __builtin_popcount(tm & qm0) + __builtin_popcount(qm0) + __builtin_popcount(tm & qm1) + __builtin_popcount(qm1) + 2 * __builtin_popcount(tm);
+            finish(acc0, s0, sm0, cur0, qn0);
+            finish(acc1, s1, sm1, cur1, qn1);
+          } else {
+            const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s0 * (KQ * 1024) + lane * 16, tm, qm0);
+            nmfma += 6 + __builtin_popcount(tm & qm0) + __builtin_popcount(qm0) + __builtin_popcount(tm);
+            if (!TM_KNN3_PRE_QN) qn0 = (unsigned)s_qn[qi0];
+            finish(acc, s0, sm0, cur0, qn0);
+          }
         }
-        tile = ntile; tmw = ntm; lbv = nlb; mask = nmask; have = nhave;
+        tile = ntile; tmw = ntm; lbv = nlb; mask = nmask; have = nhave; smv = nsm;
       }
     }
     K3_STAMP(2);  // consuming
