@@ -795,7 +795,8 @@ __global__ void k_sorted_row_norms(const int16_t *__restrict__ rows, const uint3
 // interleave by index with the members of other candidates at exactly the same SSD (rare).
 __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *__restrict__ qperm, const uint8_t *__restrict__ qpack, int q_bytes,
                                                     const uint32_t *__restrict__ tperm, int64_t nt, const uint2 *__restrict__ cand,
-                                                    const int *__restrict__ cand_cnt, int cap, int k, int *__restrict__ tau,
+                                                    const int *__restrict__ cand_cnt, int cap, int k, int *__restrict__ tau, const int *__restrict__ tau_in /* the thresholds the scan started from */,
+                                                    int *__restrict__ step /* in: the pass's rung spacing; out, overflowed queries: the next pass's */,
                                                     const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
                                                     uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count,
                                                     const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members, int nofilter) {
@@ -808,6 +809,23 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
   // The scan left its final threshold in tau (it walks down the ladder while rows come in): stored candidates above it cannot be among
   // the k nearest, and dropping them before the sort shrinks it (a full list of 512 typically keeps about a hundred).
   const int th = nofilter ? INT_MAX : tau[p];
+  if (total > cap) {
+    // The list filled up: the query is scanned again.  Its threshold is the one the scan's ladder ended on; the next pass's ladder hangs eight
+    // rungs over the bracket this pass left -- from that threshold down to the rung below it, which did not fill.  (Where the rungs hang is a
+    // matter of speed only: every threshold a filled rung gives is a valid bound.  The k-th smallest of the rows that WERE stored, a bound
+    // too, is no longer worked out: the first `cap` rows met say little where thousands lie within the threshold, and sorting them for it
+    // was most of this kernel's time on such data.)
+    if (lane == 0) {
+      const int tn = min(th, 0x7ffffffe), t_in = tau_in[p], st = max(1, min(step[p], t_in >> 3));  // (the spacing as the scan clamped it)
+      tau[p] = tn;
+      // ... unless the threshold ended on the ladder's LOWEST rung: then nothing says how far below it the k-th nearest lies, and a ladder
+      // an eighth as wide would only crawl down by its own width per pass: eighths of the threshold again
+      const bool lowest = (long long)tn <= (long long)t_in - 7ll * st;
+      step[p] = lowest ? max(1, tn >> 3) : max(1, st >> 3);
+      ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
+    }
+    return;
+  }
   const uint32_t parity = reinterpret_cast<const uint32_t *>(qpack + (p >> 5) * (int64_t)q_bytes + q_bytes - 128)[p & 31] & 1u;
   int n = 0;
   // (the stored candidates are asked for eight chunks of 64 at a time: a chunk per round trip to memory was most of this kernel -- the sort
@@ -835,6 +853,63 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
       n += __popcll(m);
     }
   }
+  if (n > 1024) {
+    // the same from LDS, for the long lists the last passes give their few queries (up to 8 192 rows at, or tied with, the k-th distance)
+    __syncthreads();
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (int i = lane; i < n; i += 64) { const uint32_t v = (uint32_t)(s_key[i] >> 32); lo = min(lo, v); hi = max(hi, v); }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+      for (int i0 = 0; i0 < n; i0 += 64) c += __popcll(__ballot(i0 + lane < n && (uint32_t)(s_key[min(i0 + lane, n - 1)] >> 32) <= mid));
+      if (c >= k) hi = mid; else lo = mid + 1;
+    }
+    int m2 = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {  // in place: a chunk's survivors land at or before the chunk
+      const unsigned long long key = s_key[min(i0 + lane, n - 1)];
+      const bool keep = i0 + lane < n && (uint32_t)(key >> 32) <= lo;
+      const unsigned long long m = __ballot(keep);
+      if (keep) s_key[m2 + __popcll(m & ((1ull << lane) - 1ull))] = key;
+      m2 += __popcll(m);
+    }
+    n = m2;
+  } else if (n > 2 * k) {
+    // Only the k smallest matter: the smallest SSD V with k candidates at or below it, by bisection over the values (sixteen keys a lane in
+    // registers, a ballot a chunk and step), then only the candidates up to V go through the sort -- a full bitonic sort of several hundred
+    // keys in LDS was this kernel's time (~1.2 microseconds of a CU's LDS bandwidth per query).
+    __syncthreads();
+    uint32_t ssd[16], idx[16];
+    uint32_t lo = 0xffffffffu, hi = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = u * 64 + lane;
+      const unsigned long long key = i < n ? s_key[i] : ~0ull;
+      ssd[u] = (uint32_t)(key >> 32); idx[u] = (uint32_t)key;
+      if (i < n) { lo = min(lo, ssd[u]); hi = max(hi, ssd[u]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, o)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, o)); }
+    const int nch = (n + 63) >> 6;
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (u < nch) c += __popcll(__ballot(u * 64 + lane < n && ssd[u] <= mid));
+      if (c >= k) hi = mid; else lo = mid + 1;
+    }
+    __syncthreads();  // every key is in registers
+    int m2 = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      if (u >= nch) break;  // (uniform)
+      const bool keep = u * 64 + lane < n && ssd[u] <= lo;
+      const unsigned long long m = __ballot(keep);
+      if (keep) s_key[m2 + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)ssd[u] << 32) | idx[u];
+      m2 += __popcll(m);
+    }
+    n = m2;
+  }
   int n2 = 64;
   while (n2 < n) n2 <<= 1;
   for (int i = n + lane; i < n2; i += 64) s_key[i] = ~0ull;
@@ -850,13 +925,6 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
       }
       __syncthreads();
     }
-  if (total > cap) {  // overflow: the k-th smallest stored SSD is a tighter valid threshold; scan this query again
-    if (lane == 0) {
-      tau[p] = (int)min((unsigned long long)min(th, 0x7ffffffe), s_key[k - 1] >> 32);  // SSD bound (d'' <= SSD), never above the scan's own
-      ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
-    }
-    return;
-  }
   const int64_t q = out_map ? out_map[p] : qperm[p];
   // The k nearest ROWS come from the first k candidates: a member of a later candidate has at least k members before it.
   const int m = min(n, k);
@@ -1246,22 +1314,26 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
 
 
 __global__ void k_topk_sorted_aux(const uint32_t *__restrict__ qperm, int64_t n, int64_t n_pad, const int *__restrict__ tau_by_row,
-                                  const uint32_t *__restrict__ rowmap, int *__restrict__ tau_sorted, uint32_t *__restrict__ map_sorted) {
+                                  const int *__restrict__ step_by_row, const uint32_t *__restrict__ rowmap, int *__restrict__ tau_sorted,
+                                  int *__restrict__ tau_in_sorted, int *__restrict__ step_sorted, uint32_t *__restrict__ map_sorted) {
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pad; p += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t row = qperm[min(p, n - 1)];
     if (tau_by_row) tau_sorted[p] = tau_by_row[row];
+    const int tau = tau_sorted[p];
+    tau_in_sorted[p] = tau;  // (the scan overwrites tau_sorted with the thresholds it ends on)
+    step_sorted[p] = step_by_row ? step_by_row[row] : (tau > 0 ? tau >> 3 : 0);  // a first pass: rungs at eighths of the threshold
     if (p < n) map_sorted[p] = rowmap ? rowmap[row] : row;
   }
 }
 __global__ void k_topk_gather_sub(const int16_t *__restrict__ feats, const uint32_t *__restrict__ qperm, const uint32_t *__restrict__ list, int64_t n,
-                                  const int *__restrict__ tau_sorted, const uint32_t *__restrict__ map_sorted, int16_t *__restrict__ sub,
-                                  int *__restrict__ sub_tau, uint32_t *__restrict__ sub_map) {
+                                  const int *__restrict__ tau_sorted, const int *__restrict__ step_sorted, const uint32_t *__restrict__ map_sorted,
+                                  int16_t *__restrict__ sub, int *__restrict__ sub_tau, int *__restrict__ sub_step, uint32_t *__restrict__ sub_map) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n * 24; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t j = e / 24;
     const int v = (int)(e - j * 24);
     const uint32_t p = list[j];
     reinterpret_cast<uint4 *>(sub)[e] = reinterpret_cast<const uint4 *>(feats + (int64_t)qperm[p] * 192)[v];
-    if (v == 0) { sub_tau[j] = tau_sorted[p]; sub_map[j] = map_sorted[p]; }
+    if (v == 0) { sub_tau[j] = tau_sorted[p]; sub_step[j] = step_sorted[p]; sub_map[j] = map_sorted[p]; }
   }
 }
 __global__ void k_topk_scatter(const int32_t *__restrict__ idx, const uint32_t *__restrict__ err, const uint32_t *__restrict__ map, int64_t n, int k,
@@ -1280,8 +1352,8 @@ static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_
 // rowmap[i] (or i) of out_idx / out_err; overflowed queries recurse with their tightened thresholds
 struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; const void *full_db = nullptr; int64_t full_nt = 0; };
 
-static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const uint32_t *rowmap, int k, int32_t *out_idx,
-                     uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
+static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const int *step_by_row, const uint32_t *rowmap, int k,
+                     int32_t *out_idx, uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
   const auto t_start = std::chrono::steady_clock::now();
   TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
@@ -1292,9 +1364,11 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
 #ifndef TM_TOPK_CAP_LATER
 #define TM_TOPK_CAP_LATER 1024
 #endif
-  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? 512 : TM_TOPK_CAP_LATER, ((int64_t)24 << 30) / (n * 8)));
-  DevBuf tau, map_sorted, cand, cand_cnt, ovf, counter;
-  TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
+  // (from the fourth pass on -- a few thousand queries at most -- up to 8 192: what is left by then are queries with hundreds of rows AT their
+  // k-th distance, which no threshold separates; the select stage picks the k smallest of a long list by bisection)
+  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? 512 : depth < 3 ? TM_TOPK_CAP_LATER : 8192, ((int64_t)24 << 30) / (n * 8)));
+  DevBuf tau, tau_in, step, map_sorted, cand, cand_cnt, ovf, counter;
+  TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(tau_in.alloc((size_t)n_pad * 4)); TM_TRY(step.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
   TM_TRY(cand.alloc((size_t)n * cap * 8)); TM_TRY(cand_cnt.alloc((size_t)n * 4));
   TM_TRY(ovf.alloc((size_t)n * 4)); TM_TRY(counter.alloc(16));
   TM_HIP(hipMemsetAsync(cand_cnt.p, 0, (size_t)n * 4, stream));
@@ -1307,8 +1381,8 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
                        ix->qkey.as<uint32_t>(), n, (const uint32_t *)ix->db, ix->tperm.as<uint32_t>(), tnorm.as<uint32_t>(), ix->tkey.as<uint32_t>(), ix->nt, ntt, k,
                        TOPK_WINDOW_DEFAULT, tau.as<int>());
   }
-  hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, rowmap, tau.as<int>(),
-                     map_sorted.as<uint32_t>());
+  hipLaunchKernelGGL(k_topk_sorted_aux, dim3(gridn_k(n_pad)), dim3(256), 0, stream, ix->qperm.as<uint32_t>(), n, n_pad, tau_by_row, step_by_row, rowmap, tau.as<int>(),
+                     tau_in.as<int>(), step.as<int>(), map_sorted.as<uint32_t>());
   KnnBoxes bx;
   bx.lo = ix->box_lo.as<int>();
   bx.hi = ix->box_hi.as<int>();
@@ -1334,7 +1408,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     a.n_groups = (nqt + ns - 1) / ns;
     a.max_segs = (int)(ntt / (K3_LCAP - K3_LIST_NT) + 2);
     a.no_seeds = 1;
-    a.tau = tau.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
+    a.tau = tau.as<int>(); a.step = step.as<int>(); a.cand = cand.as<uint2>(); a.cand_cnt = cand_cnt.as<int>(); a.cand_cap = cap; a.cand_k = k;
     // few queries left: their few workgroups would each walk most of the database one after the other -- share the tile lists
     a.split = a.n_groups >= 512 ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(64, 1024 / std::max<int64_t>(a.n_groups, 1)));
     TM_TRY(ix->gsmax.alloc((size_t)nqt * 4));
@@ -1371,7 +1445,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   }
   if ((size_t)topk_pow2(cap) * 8 > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_topk_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)topk_pow2(cap) * 8));
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
-                     knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(),
+                     knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(), tau_in.as<int>(), step.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
                      0);
   TM_HIP(hipGetLastError());
@@ -1391,13 +1465,15 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   if (novf == 0) return TM_OK;
-  DevBuf sub, sub_tau, sub_map;
-  TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
+  DevBuf sub, sub_tau, sub_step, sub_map;
+  TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_step.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
   hipLaunchKernelGGL(k_topk_gather_sub, dim3(gridn_k((int64_t)novf * 24)), dim3(256), 0, stream, feats, ix->qperm.as<uint32_t>(), ovf.as<uint32_t>(),
-                     (int64_t)novf, tau.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_map.as<uint32_t>());
+                     (int64_t)novf, tau.as<int>(), step.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_step.as<int>(), sub_map.as<uint32_t>());
   TM_HIP(hipGetLastError());
   cand.release();  // the recursion allocates its own
-  if (depth >= 16 || (depth >= 2 && (int64_t)novf * 10 > n * 9)) {  // thresholds stopped helping (many rows at exactly the k-th distance): exact brute force for the stragglers
+  // Every pass cuts the bracket its ladder spans to an eighth (or, from the lowest rung, the threshold itself): a dozen passes take any threshold
+  // down to single units.  What still overflows then has more rows at exactly the k-th distance than a list holds: exact brute force for those.
+  if (depth >= 12 || (depth >= 6 && (int64_t)novf * 10 > n * 9)) {
     DevBuf bi, be;
     TM_TRY(bi.alloc((size_t)novf * k * 4)); TM_TRY(be.alloc((size_t)novf * k * 4));
     TM_TRY(launch_knn_topk(sub.p, novf, ex.full_db ? ex.full_db : (const void *)ix->db, ex.full_db ? ex.full_nt : ix->nt, k, bi.p, be.p, stream));
@@ -1407,7 +1483,7 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
     TM_HIP(hipStreamSynchronize(stream));
     return TM_OK;
   }
-  return topk_pass(ix, sub.as<int16_t>(), novf, sub_tau.as<int>(), sub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream, ex);
+  return topk_pass(ix, sub.as<int16_t>(), novf, sub_tau.as<int>(), sub_step.as<int>(), sub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream, ex);
 }
 
 int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq, int k, void *out_idx, void *out_err, hipStream_t stream,
@@ -1420,7 +1496,7 @@ int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq
   if (ix->nt == 0) return TM_OK;
   TopkExpand ex;
   ex.grp_off = (const uint32_t *)grp_off; ex.grp_members = (const uint32_t *)grp_members; ex.full_db = full_db; ex.full_nt = full_nt;
-  return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
+  return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
 }
 
 void knn_index_kernel_split(tm_knn_index_impl *ix, double ms[3], int64_t pairs[3]) {

@@ -84,6 +84,7 @@ struct Knn3Args {
   int *best_key, *best_tile;
   // collection mode (the k nearest rows, ann_kdtree_short_search_multi, tilingencoder.pas:1563): see k_knn_consume<.., TOPK = true>
   int *tau;                     // [n_qtiles * 32] every sorted query's threshold (d'' <= tau); the scan leaves its final one
+  const int *step;              // [n_qtiles * 32] the spacing of its ladder's rungs below the threshold (null: tau / 8)
   uint2 *cand;                  // [nq][cand_cap] (d'', sorted row) of every row within the threshold
   int *cand_cnt;                // [nq] rows appended (keeps counting past cand_cap)
   int cand_cap, cand_k;
@@ -321,14 +322,19 @@ __device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, in
   return refresh;
 }
 
-// Collection mode's epilogue.  The query's state in LDS: `best` = (tau + 1) << 32 | step (tau: its threshold, d'' <= tau; step = its first
-// threshold / 8), `lad` = 7 x 16-bit counters, rows seen with d'' <= (8 - j) step for j = 1..7.  Every row within the threshold is
-// appended to the query's candidate list; once cand_k rows lie at or below a rung, the k-th nearest is at most that rung + 1 and the
-// threshold drops to it (the threshold only ever falls, every value it takes is a valid bound: the waves of a workgroup, and the parts of
-// a split group, lower it on their own evidence).  Returns true in lanes that lowered a threshold the sub-tile's bound may hang on.
+// Collection mode's epilogue.  The query's state in LDS: `best` = (tau + 1) << 32 | step (tau: its threshold, d'' <= tau), `base` = the
+// threshold it came with + 1, `lad` = 7 x 16-bit counters: rows seen with d'' + 1 <= base - j step for j = 1..7 -- the ladder's rungs hang
+// below the pass's first threshold at the spacing the host chose (tau / 8 in a first pass; an eighth of the bracket the pass before left --
+// its last threshold down to the rung below it that did NOT fill -- afterwards: on data whose distances bunch, a rung spacing of tau / 8
+// moved the threshold by a third per pass).  Every row within the threshold is appended to the query's candidate list UNTIL THE LIST IS
+// FULL (bit 31 of lad[3]: from then on the query is only counted -- it will be scanned again anyway, and its appends, a global atomic and
+// eight bytes each, were most of the collection scans' time on such data); once cand_k rows lie at or below a rung, the k-th nearest is at
+// most that rung + 1 and the threshold drops to it (the threshold only ever falls, every value it takes is a valid bound: the waves of a
+// workgroup, and the parts of a split group, lower it on their own evidence).  Returns true in lanes that lowered a threshold the
+// sub-tile's bound may hang on.
 template <bool TD>
 __device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, const v16i &ntr, int tile, bool countable, int half, unsigned qn, unsigned long long *best,
-                                                 unsigned *lad, bool qvalid, int64_t q, const Knn3Args &a, unsigned sm_now) {
+                                                 unsigned *lad, const unsigned *base_p, bool qvalid, int64_t q, const Knn3Args &a, unsigned sm_now) {
   int t[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
@@ -337,18 +343,23 @@ __device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, const v16i &nt
   const unsigned tau1 = k3_peek(reinterpret_cast<unsigned *>(best) + 1);  // tau + 1
   bool refresh = false;
   if (qvalid && (unsigned)tm + qn + 1u <= tau1) {
-    const unsigned step = k3_peek(reinterpret_cast<unsigned *>(best));
+    const unsigned step = k3_peek(reinterpret_cast<unsigned *>(best)), base = *base_p;
+    bool full = (k3_peek(&lad[3]) >> 31) != 0, filled = false;
     unsigned c[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const unsigned d1 = (unsigned)t[r] + qn + 1u;  // d'' + 1
       if (d1 <= tau1) {
-        const int slot = atomicAdd(&a.cand_cnt[q], 1);
-        if (slot < a.cand_cap) a.cand[q * a.cand_cap + slot] = make_uint2(d1 - 1u, (unsigned)((tile << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+        if (!full) {
+          const int slot = atomicAdd(&a.cand_cnt[q], 1);  // (ends above the capacity for a query whose list filled: how the select stage knows)
+          if (slot < a.cand_cap) a.cand[q * a.cand_cap + slot] = make_uint2(d1 - 1u, (unsigned)((tile << 5) | ((r & 3) + 8 * (r >> 2) + 4 * half)));
+          else { full = true; filled = true; }
+        }
 #pragma unroll
-        for (int j = 1; j <= 7; j++) c[j - 1] += (countable && d1 <= (unsigned)(8 - j) * step + 1u) ? 1u : 0u;
+        for (int j = 1; j <= 7; j++) c[j - 1] += (countable && d1 + (unsigned)j * step <= base) ? 1u : 0u;
       }
     }
+    if (filled) atomicOr(&lad[3], 0x80000000u);
     // the counters saturate where they stop mattering: a rung that has its cand_k rows takes no more (so no 16-bit field overflows
     // into its neighbour: at most cand_k + 16 rows x 2 half-waves x 16 waves land in one)
     const unsigned k = (unsigned)a.cand_k;
@@ -364,12 +375,13 @@ __device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, const v16i &nt
     unsigned now[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) now[w] = add[w] ? atomicAdd(&lad[w], add[w]) + add[w] : cur[w];
+    now[3] &= 0x7FFFFFFFu;
     int rung = 0;
 #pragma unroll
     for (int j = 1; j <= 7; j++)
       if (((now[(j - 1) >> 1] >> (16 * ((j - 1) & 1))) & 0xFFFFu) >= k) rung = j;
-    // cand_k rows have d'' <= the rung, i.e. SSD <= rung + 1: no row beyond that can be among the k nearest
-    const unsigned tnew1 = (unsigned)(8 - rung) * step + 2u;  // (new tau = rung value + 1) + 1
+    // cand_k rows have d'' + 1 <= base - rung step, i.e. SSD <= that: no row beyond it can be among the k nearest
+    const unsigned tnew1 = base - (unsigned)rung * step + 1u;  // (new tau = the rung's bound) + 1
     if (rung > 0 && step > 0 && tnew1 < tau1) {
       const unsigned pre = atomicMin(reinterpret_cast<unsigned *>(best) + 1, tnew1);
       const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
@@ -728,9 +740,13 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
     const int64_t st = min(st0 + (i >> 5), a.n_qtiles - 1);
     const bool real = (i >> 5) < nvalid && !dense;
     s_qn[i] = reinterpret_cast<const int *>(a.qpack + st * (int64_t)Q_BYTES + KQ * 1024)[i & 31] & ~1;
-    if constexpr (TOPK) {  // (tau + 1) << 32 | tau / 8; queries that are padding get tau = -1: nothing is within it
-      const int tau = (real && st0 * 32 + i < a.nq) ? a.tau[st0 * 32 + i] : -1;
-      s_best[i] = ((unsigned long long)(unsigned)(tau + 1) << 32) | (unsigned)(tau > 0 ? tau >> 3 : 0);
+    if constexpr (TOPK) {  // (tau + 1) << 32 | rung spacing; queries that are padding get tau = -1: nothing is within it
+      const bool qreal = real && st0 * 32 + i < a.nq;
+      const int tau = qreal ? a.tau[st0 * 32 + i] : -1;
+      int stp = tau > 0 ? tau >> 3 : 0;  // (seven rungs fit below the threshold whatever the host asks for)
+      if (a.step && qreal && stp > 0) stp = min(stp, max(1, a.step[st0 * 32 + i]));
+      s_best[i] = ((unsigned long long)(unsigned)(tau + 1) << 32) | (unsigned)stp;
+      s_tie[i] = (unsigned)(tau + 1);  // the ladder's base (the nearest-neighbour scan's tie words are not used in this mode)
       for (int w = 0; w < 4; w++) s_lad[i * 4 + w] = 0;
     } else {
       s_best[i] = real ? a.gbest[st0 * 32 + i] : ~0ull;
@@ -831,7 +847,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
             const int64_t q = (st0 + s) * 32 + (lane & 31);
             // (the last database tile pads with copies of its last row: they are candidates like any row -- the select stage drops them --
             // but must not count towards a rung)
-            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, qn, &s_best[qi], &s_lad[qi * 4], q < a.nq, q, a, sm_now);
+            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, qn, &s_best[qi], &s_lad[qi * 4], &s_tie[qi], q < a.nq, q, a, sm_now);
           } else {
             refresh = k3_epilogue<TD>(acc, ntr, tile, half, qn, &s_best[qi], &s_tie[qi], sm_now, cur_hi);
           }

@@ -14,7 +14,7 @@ from tiler_amd.encoder import TilingEncoder  # noqa: E402
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 radius = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 F, W, H = 300, 1280, 720
-frames = torch.from_numpy(synth.video(F, W, H).view(np.int32)).cuda()
+frames = torch.from_numpy(synth.video(F, W, H, freeze=os.environ.get("TM_PROBE_LITERAL") != "1").view(np.int32)).cuda()  # TM_PROBE_LITERAL=1: the generator as written
 enc = TilingEncoder()
 enc.LoadDefaultSettings()
 enc.PaletteCount = 16
