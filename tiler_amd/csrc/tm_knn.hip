@@ -1364,9 +1364,18 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
 #ifndef TM_TOPK_CAP_LATER
 #define TM_TOPK_CAP_LATER 1024
 #endif
+#ifndef TM_TOPK_CAP_FIRST
+#define TM_TOPK_CAP_FIRST 512
+#endif
+#ifndef TM_TOPK_BUDGET_GIB
+#define TM_TOPK_BUDGET_GIB 24  // candidate lists of a pass (also capped at a third of the free device memory)
+#endif
   // (from the fourth pass on -- a few thousand queries at most -- up to 8 192: what is left by then are queries with hundreds of rows AT their
   // k-th distance, which no threshold separates; the select stage picks the k smallest of a long list by bisection)
-  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? 512 : depth < 3 ? TM_TOPK_CAP_LATER : 8192, ((int64_t)24 << 30) / (n * 8)));
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)32 << 30; }
+  const int64_t budget = std::max<int64_t>((int64_t)4 << 30, std::min<int64_t>((int64_t)TM_TOPK_BUDGET_GIB << 30, (int64_t)(free_b / 3)));
+  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? TM_TOPK_CAP_FIRST : depth < 3 ? TM_TOPK_CAP_LATER : 8192, budget / (n * 8)));
   DevBuf tau, tau_in, step, map_sorted, cand, cand_cnt, ovf, counter;
   TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(tau_in.alloc((size_t)n_pad * 4)); TM_TRY(step.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
   TM_TRY(cand.alloc((size_t)n * cap * 8)); TM_TRY(cand_cnt.alloc((size_t)n * 4));
