@@ -42,6 +42,8 @@
  *                           compare the two forms)
  *   TM_KM_LAUNCHES          the tile -> palette k-means runs its skipping iterations as three launches each instead of one resident launch
  *                           for all of them (tests compare the two)
+ *   TM_PP_SHARDED           several processes: the tile -> palette clustering stays data-parallel (an all-reduce per Lloyd iteration) even where
+ *                           every process could run it whole in one resident launch (tests, A/B)
  *   TM_PP_DEBUG             PreparePalettes prints its sub-steps' wall times (adds synchronisations)
  *   TM_COMM_FORCE_DIST      a one-process communicator still walks the sharded code paths (tests on a one-GPU box)
  *   TM_COMM_TIMEOUT_S=<s>   how long tm_comm_init (and a collective of the library's own communicator) waits for the other processes (120)

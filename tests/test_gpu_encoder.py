@@ -364,8 +364,9 @@ class _FakeDist:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("radius,epu,world", [(0, False, 2), (0, True, 2), (8, False, 2), (8, True, 2), (8, True, 3), (8, False, 6), (0, False, 5)])
-def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
+@pytest.mark.parametrize("radius,epu,world,pp_sharded", [(0, False, 2, False), (0, True, 2, True), (8, False, 2, True), (8, True, 2, False), (8, True, 3, True),
+                                                         (8, False, 6, False), (0, False, 5, True), (0, False, 4, False)])
+def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world, pp_sharded):
     """tiler_amd.distributed.run_all with REAL encoders: the ranks (threads, one GPU) shard Load / Reduce / PreparePalettes (data-parallel
     Lloyd, palette-parallel quantisation) / Dither / Reconstruct -- with motion prediction on: PredictMotion and whole key-frame groups --
     through the library's collective callback, and must end with exactly the single-process result.  With 6 ranks on 4 key frames some
@@ -373,6 +374,12 @@ def test_sharded_ranks_merge_to_the_single_run(monkeypatch, radius, epu, world):
     import threading
     from tiler_amd import synth, distributed
     from tiler_amd.encoder import TilingEncoder
+    # pp_sharded: the tile -> palette clustering data-parallel (run_palettize_dist: an all-reduce per Lloyd iteration) instead of run whole by
+    # every rank (one resident launch each; the ranks are threads here: the launches take their turns)
+    if pp_sharded:
+        monkeypatch.setenv("TM_PP_SHARDED", "1")
+    else:
+        monkeypatch.delenv("TM_PP_SHARDED", raising=False)
     frames = synth.video(12, 64, 48, cut=3)
     kw = dict(PaletteCount=3, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=radius, FrameTilingExtendedPaletteUsage=epu, GlobalTilingTileCount=150)
     ref = _run_encoder(frames, **kw)

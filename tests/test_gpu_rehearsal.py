@@ -39,8 +39,34 @@ def test_two_ranks_on_one_device_equal_the_single_process():
     for key in ("final_tiles_after_reindex", "global_tiles_T", "query_tiles", "distinct_database_rows"):
         assert two["config"][key] == one["config"][key], key
     c = two["collectives_per_step"]
-    assert c["path"].startswith("host callback") and c["all_reduce_sum_i64"] >= 1 and c["all_gather"] >= 1
+    assert c["path"].startswith("host callback") and c["all_gather"] >= 1
+    # PreparePalettes: the tile -> palette clustering is run whole by every rank (one resident launch each, no collective) -- the only int64
+    # all-reduces a step has belong to the data-parallel Lloyd iterations, which are gone; the whole step stays far below the ~330 collectives
+    # (one per Lloyd iteration) it took before
+    calls = sum(c[k] for k in ("all_reduce_sum_i32", "all_reduce_max_i32", "all_reduce_sum_i64", "all_gather"))
+    assert c["all_reduce_sum_i64"] == 0 and calls <= 40, c
     by = c["bytes_by_stage"]
     # Reduce moves keys and candidates, not every distinct tile: 16 B per distinct frame tile + 264 B per candidate, against 264 B per distinct tile before
     distinct = one["config"]["knn_queries"]  # (the single process searches once per distinct frame tile)
     assert by["esReduce"] < 0.5 * 264 * distinct, (by, distinct)
+
+
+def test_two_ranks_on_the_literal_clip_and_the_data_parallel_clustering():
+    """the same on SURVEY.md 8(d)'s generator as written (the clip `value` is quoted on: no duplicate frame tiles, a tile -> palette clustering
+    that runs to its iteration cap), with the clustering replicated (the default: <= 120 collectives per step asked for, ~15 taken) and with
+    TM_PP_SHARDED=1 (the data-parallel Lloyd: an int64 all-reduce per iteration) -- both equal the single process"""
+    small = ["--width", "640", "--height", "360", "--frames", "120", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-motion-extra",
+             "--no-defaults-extra", "--no-dense-extra", "--no-h2d-extra", "--no-frozen-extra", "--no-kmodes-extra"]
+    one = _bench(["--gpus", "1"] + small)
+    assert one["parity_gate"] == "passed"
+    for env in ({"TM_BENCH_REHEARSE": "1"}, {"TM_BENCH_REHEARSE": "1", "TM_PP_SHARDED": "1"}):
+        two = _bench(["--gpus", "2"] + small, env=env)
+        assert two["n_gpus"] == 2 and two["parity_gate"] == "passed"
+        for key in ("final_tiles_after_reindex", "global_tiles_T", "query_tiles", "distinct_database_rows"):
+            assert two["config"][key] == one["config"][key], key
+        c = two["collectives_per_step"]
+        calls = sum(c[k] for k in ("all_reduce_sum_i32", "all_reduce_max_i32", "all_reduce_sum_i64", "all_gather"))
+        if "TM_PP_SHARDED" in env:
+            assert c["all_reduce_sum_i64"] >= 5, c
+        else:
+            assert c["all_reduce_sum_i64"] == 0 and calls <= 120, c

@@ -931,6 +931,17 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     // of the exact integer sums (run_palettize_dist), then the palette indices of all shares are all-gathered.  Palette colours:
     // the palettes are independent tasks (one thread per palette in the reference, 1864): process r quantises the palettes
     // p = r (mod world), an all-reduce(SUM) assembles the set.
+    if (!knobs().pp_sharded && palettize_resident(e->t, e->s.PaletteCount)) {
+      // Up to 16 palettes and half a million tiles the single-GPU clustering is ONE resident launch of a few milliseconds (k_h_resident), and every
+      // process holds all the global tiles: each runs it whole.  Sharded, a Lloyd iteration is an all-reduce of 25 KB -- 300 latency-bound
+      // collectives on the bench clip, more than the whole clustering takes here -- plus two all-gathers per seeding pick; replicated there is none.
+      // Integer sums and a fixed seed: every process ends with the same palettes.  (TM_PP_SHARDED=1 keeps the data-parallel form for A/B and tests.)
+      TM_TRY(feat.alloc((size_t)e->t * 192 * 4));
+      TM_TRY(launch_features_cluster(e->gtiles.p, e->t, e->s.DitheringMode, feat.p, e->stream));
+      lap("cluster features (all tiles, every process)");
+      TM_TRY(run_palettize(feat.p, e->guse.p, e->t, e->s.PaletteCount, 300, e->gpal_idx.p, e->stream));
+      lap("tile -> palette (192-D, replicated)");
+    } else {
     int64_t t0, t1;
     share_of(e->t, e->co.rank, e->co.world, &t0, &t1);
     const int64_t nl = t1 - t0;
@@ -944,6 +955,7 @@ static int step_prepare_palettes(tm_encoder *e) {  // PreparePalettes, tilingenc
     TM_TRY(gather_var(e, lidx.p, nl, 4, all, &counts));
     TM_HIP(hipMemcpyAsync(e->gpal_idx.p, all.p, (size_t)e->t * 4, hipMemcpyDeviceToDevice, e->stream));
     lap("tile -> palette (192-D, data-parallel)");
+    }
     progress(e, TM_STEP_PREPARE_PALETTES, 1, 3);
     TM_TRY(run_quantize_palettes_part(e->gtiles.p, e->gpal_idx.p, e->t, e->s.PaletteCount, e->s.PaletteSize, 300, e->palettes_dev.p, e->co.rank, e->co.world, e->stream));
     TM_TRY(e->co.allreduce_sum_i32(e->palettes_dev.p, (int64_t)e->s.PaletteCount * e->s.PaletteSize));

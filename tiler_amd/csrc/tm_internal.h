@@ -102,6 +102,7 @@ int run_quantize_palettes(const void *tiles, const void *pal_idx, int64_t n, int
 int run_quantize_palettes_part(const void *tiles, const void *pal_idx, int64_t n, int npal, int pal_size, int max_iter, void *out_palettes,
                                int pal_rank, int pal_world, hipStream_t stream, DevBuf *keep_keys = nullptr, int64_t *keep_n = nullptr);
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream);
+bool palettize_resident(int64_t n, int npal);  // the clustering above would take the resident launch (then several processes each run it whole)
 // tm_dedup.hip, Reduce over several processes (see there): a 16-byte key per distinct tile (rows[idx[r]], use[r]) and, on the gathered keys of
 // all processes, the tiles that can be among the first `target` of the merged order (in_s: uint32 flags)
 int reduce_make_keys(const void *rows, const void *idx, const void *use, int64_t n, int row_bytes, void *keys_out /* n x 16 bytes */, hipStream_t stream);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdlib>
 #include <climits>
 #include <vector>
@@ -30,6 +31,12 @@
 namespace tmx {
 
 typedef unsigned long long u64;
+
+// One resident launch at a time per process: the resident kernels (k_h_resident, k_kmeans3_persistent) need all their workgroups on the chip
+// together, and two of them started from two host threads could each be dealt part of the CUs and wait for the rest for ever (until their
+// barriers give up).  Held from the launch to the read-back that ends it.  (Two PROCESSES on one device are not covered: there the barrier's
+// time limit and the launches-per-iteration path are the answer -- a development set-up, one process per device is the deployment.)
+static std::mutex g_resident_launch;
 
 struct Seg {      // per segment state, device resident
   int64_t begin;  // first point
@@ -1161,7 +1168,7 @@ __device__ __forceinline__ bool hr_barrier(HrState *st, unsigned &epoch, unsigne
       if (threadIdx.x == 0)
       for (unsigned spins = 1; __hip_atomic_load(&st->top[sh].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nsh; spins++) {
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255u) == 0 && (spins > (1u << 22) || __hip_atomic_load(&st->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if ((spins & 255u) == 0 && (spins > (1u << 21) || __hip_atomic_load(&st->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {  // (~2 s: an iteration is microseconds)
           __hip_atomic_store(&st->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;
@@ -1949,6 +1956,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   TM_HIP(hipMemsetAsync(dstate.p, 0, sizeof(Seg3State) * hs.size(), stream));
   TM_HIP(hipMemsetAsync(dcent.p, 0, sizeof(double) * hs.size() * k * 3, stream));
   TM_CHECK(nblk >= 1 && k >= 1 && k <= P3_MAXK, TM_E_INVAL, "k-means: resident launch of %d workgroups for %d centres (at most %d)", nblk, k, P3_MAXK);
+  std::unique_lock<std::mutex> resident_lock(g_resident_launch);
   hipLaunchKernelGGL(k_kmeans3_persistent, dim3(nblk), dim3(P3_NT), 0, stream, pts, w, dsegs.as<Seg3>(), dstate.as<Seg3State>(), k, max_iter, assign,
                      dcent.as<double>());
   TM_HIP(hipGetLastError());
@@ -1961,6 +1969,7 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
     TM_TRY(hr_.get(hcent.data(), dcent.p, hcent.size() * 8));
     TM_TRY(hr_.wait());
   }
+  resident_lock.unlock();
   int iters = 0;
   for (size_t i = 0; i < hs.size(); i++)
     if (hstate[i].timeout != 0) {  // a workgroup of a segment never became resident (the barrier gave up): the launches-per-iteration path instead
@@ -2137,6 +2146,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
       DevBuf hstate;
       TM_TRY(hstate.alloc(sizeof(HrState)));
       TM_HIP(hipMemsetAsync(hstate.p, 0, sizeof(HrState), stream));
+      std::unique_lock<std::mutex> resident_lock(g_resident_launch);
       auto kres = rounds == 1 ? &k_h_resident<1> : &k_h_resident<2>;
       static_assert(HR_MAXR == 2, "one instantiation per number of rounds");
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kres), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r_lds);
@@ -2167,6 +2177,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
 #endif
         TM_TRY(hr_.wait());
       }
+      resident_lock.unlock();
       if (timed_out) {
         fprintf(stderr, "[tm_kmeans] the resident tile k-means gave up at its barrier; repeating the clustering with one launch per step\n");
         return kmeans_batched(pts, w, d, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, init_idx, dev_init_idx, false);
@@ -2576,6 +2587,15 @@ static int pp_seeds(const int32_t *pts, const uint32_t *w, int64_t n, int k, std
 KmeansRunStats &kmeans_run_stats() {
   static thread_local KmeansRunStats st;
   return st;
+}
+
+// would run_palettize put the clustering through the resident launch?  (one process per GPU: then every process clusters ALL global tiles
+// itself -- 6 ms, no collective -- instead of a share of them with an all-reduce per Lloyd iteration)
+bool palettize_resident(int64_t n, int npal) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return !knobs().km_launches && npal <= KCH && n > 0 && n <= (int64_t)HR_MAXR * HR_NT * cus;
 }
 
 int run_palettize(const void *feat, const void *use, int64_t n, int npal, int max_iter, void *out_pal_idx, hipStream_t stream) {
