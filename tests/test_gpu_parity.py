@@ -185,6 +185,16 @@ def test_features_first_look_in_every_source_instantiation(monkeypatch):
     assert torch.equal(fa, pa) and torch.equal(fb_, pb)
     for x, y in zip(fc + fd, pc + pd):
         assert torch.equal(x, y)
+    # the windows by strips (k_window_dcts: conversions and row transforms shared between windows) against the window-at-a-time kernel
+    monkeypatch.delenv("TM_FEATURES_PLAIN")
+    monkeypatch.setenv("TM_WINDOW_DCTS_BY_TILE", "1")
+    assert torch.equal(stages.window_dcts(fb), fb_)
+    for hh, ww_ in ((8, 8), (9, 41), (17, 8), (23, 77)):  # ragged strips, a single window
+        small = fb[:hh, :ww_].contiguous()
+        by_tile = stages.window_dcts(small)
+        monkeypatch.delenv("TM_WINDOW_DCTS_BY_TILE")
+        assert torch.equal(stages.window_dcts(small), by_tile)
+        monkeypatch.setenv("TM_WINDOW_DCTS_BY_TILE", "1")
 
 
 def test_features_pal_and_cluster(tiles_flags, oracle):

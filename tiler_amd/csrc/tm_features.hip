@@ -95,6 +95,19 @@ __global__ __launch_bounds__(256) void k_load_tiles(const uint32_t *__restrict__
 // (row t = tile t div P under palette t mod P, P passed in use_lab: the vectors 1590-1591 recompute per query).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The first look's verdict on one coefficient, in Single arithmetic (double-precision instructions issue at a quarter of the Singles' rate
+// here, and the verdict was a third of a coefficient's): t = z w from the separable transform (double), sa >= sum |pixel x LUT entry|, wabs = |w|.
+// The reference's z_ref w lies within slack = sa (2^-23 + 2^-24)(1 + 2^-17)(1 + 2^-20) |w| + 1e-9 (|t| + 1) of t (k_features_i16 has the
+// derivation), and tf = Single(t) within |t| 2^-24 of t: when tf is farther than the two together from every half-integer, Round(z_ref w) =
+// rint(tf).  Returns false (in doubt: the caller sums the coefficient in the reference's order) otherwise, and for values no int16 path needs.
+__device__ __forceinline__ bool first_look_rounds(double t, float sa, float wabs, int &o) {
+  const float tf = (float)t, at = fabsf(tf);
+  const float slack = sa * (1.82e-7f * wabs) + 1.1e-9f * (at + 1.0f) + at * 6.1e-8f;
+  const float fr = tf - floorf(tf);  // exact
+  o = (int)rintf(tf);
+  return fabsf(fr - 0.5f) > slack && slack < 0.25f && at < 1.0e6f;
+}
+
 template <int SRC>
 __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict__ tiles, const uint8_t *__restrict__ pal_px,
                                                       const int32_t *__restrict__ pal_idx, const int32_t *__restrict__ palettes,
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
         };
         double t;
         bool doubtful;
+        int o_fast = 0;
         if (plain) {
           t = 0.0;
           doubtful = true;
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
           sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x140, 0xf, 0xf, true));
           const float sq_all = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 16))) +
                                (__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq), 48)));
-          const double sa = (double)(lnorm * (__builtin_amdgcn_sqrtf(sq_all) * 1.00001f));  // >= sum |pixel x LUT entry| (Cauchy-Schwarz; lnorm = the LUT row's norm, rounded up; the hardware's root is good to 1 ulp)
+          const float sa = lnorm * (__builtin_amdgcn_sqrtf(sq_all) * 1.00001f);  // >= sum |pixel x LUT entry| (Cauchy-Schwarz; lnorm = the LUT row's norm, rounded up; the hardware's root is good to 1 ulp)
           const double2 *fp = reinterpret_cast<const double2 *>(cp + (lane >> 3) * 8);
           const double2 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
           double r = au[0] * f0.x;
@@ -230,9 +244,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
           z = fma(av[4], r2.x, z); z = fma(av[5], r2.y, z); z = fma(av[6], r3.x, z); z = fma(av[7], r3.y, z);
           z *= ruv;
           t = weighted ? z * w[c] : z;
-          const double slack = sa * 1.81e-7 * (weighted ? fabs(w[c]) : 1.0) + 1e-9 * (fabs(t) + 1.0);  // 1.81e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
-          const double fl = floor(t);
-          doubtful = !(fabs(t - fl - 0.5) > slack) || !(slack < 0.25);
+          doubtful = !first_look_rounds(t, sa, weighted ? fabsf((float)w[c]) * 1.000001f : 1.0f, o_fast);  // 1.82e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
         }
         for (unsigned long long m = __builtin_amdgcn_ballot_w64(doubtful); m; m &= m - 1) {
           const int coef = __builtin_ctzll(m);
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
           if (lane == coef) t = weighted ? __dmul_rn(z, w[c]) : z;
         }
         // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
-        const int16_t o = fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+        const int16_t o = !doubtful ? (int16_t)o_fast : fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
         out[t_out * 192 + c * 64 + zz] = o;
         mmn[c] = min(mmn[c], (int)o);
         mmx[c] = max(mmx[c], (int)o);
@@ -542,11 +554,139 @@ int launch_features_table(const void *pal_px, int64_t ntiles, const void *palett
   return TM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Every 8 x 8 window of a frame buffer (PredictMotion.DoDCTs / Reconstruct.DoDCTs, tilingencoder.pas:1157-1182, 1437-1462), weighted DCT on
+// YUV: what k_features_i16<2> computes a window at a time -- 64 colour conversions, eight row transforms and a column transform per window
+// and plane -- shares nearly all of it between windows: a pixel is converted once per strip (not 64 times), a row's transform at a
+// horizontal position serves the eight windows that contain it (not one), and only the column transform and the rounding are a window's
+// own.  The reference's order of summation shares nothing (DCTInner_asm, fixed order in Single and double), but only Round(z w) is stored:
+// z the cheap way first, the reference's order when the rounding is in doubt, exactly as in k_features_i16 (same bound, same fallback).
+// A workgroup takes strips of WD_RY x WD_CX windows: (1) the strip's pixels -> three planes of Singles in LDS; per plane: (2) the row
+// transform of every (row, horizontal position) by an 8-point fast DCT in double (35 operations for eight outputs: any order of summation
+// serves, the bound on |z_ref - z_fast| has nine decimal orders of room for it) and the row's sum of squares, (3) the windows' sums of
+// squares, (4) a wave per window, lane = coefficient (u, v): eight multiply-adds down the column, weight, slack, Round.
+constexpr int WD_RY = 8, WD_CX = 32, WD_PW = WD_CX + 8;  // window rows and columns of a strip; pitch of a plane row (WD_CX + 7 pixels)
+__global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict__ fb, int w, int h, const float *__restrict__ lut, const double *__restrict__ weights,
+                                                     const uint8_t *__restrict__ snake, const double *__restrict__ cosd, int16_t *__restrict__ out, int plain) {
+  __shared__ float s_pl[3][WD_RY + 7][WD_PW];                                     // the strip's planes (Singles, as ConvertToCpnPixels leaves them)
+  __shared__ __attribute__((aligned(16))) double s_r[WD_RY + 7][WD_CX][8];         // one plane's row transforms [row][horizontal position][u]
+  __shared__ float s_rs[WD_RY + 7][WD_CX];                                          // ... and the rows' sums of squares
+  __shared__ float s_ws[WD_RY][WD_CX];                                              // the windows' sums of squares
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ww = w - 7, wh = h - 7;
+  const int nsx = (ww + WD_CX - 1) / WD_CX, nsy = (wh + WD_RY - 1) / WD_RY;
+  double av[8];
+#pragma unroll
+  for (int x = 0; x < 8; x++) av[x] = cosd[(lane >> 3) * 8 + x];
+  const double ruv = (lane == 0) ? 0.5 : (((lane & 7) == 0 || (lane >> 3) == 0) ? 0.707106769084930419921875 : 1.0);  // cDCTUVRatio (utils.pas:100-109)
+  double wgt[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) wgt[c] = weights[c * 64 + lane];
+  const int zz = snake[lane];
+  float lnorm;  // the Euclidean norm of this lane's LUT row, rounded up
+  {
+    double q2 = 0.0;
+    for (int k = 0; k < 64; k++) { const double v = (double)lut[lane * 64 + k]; q2 = fma(v, v, q2); }
+    lnorm = (float)(sqrt(q2) * (1.0 + 1e-6));
+  }
+  // cos(k pi / 16)
+  constexpr double C1 = 0.98078528040323044913, C2 = 0.92387953251128675613, C3 = 0.83146961230254523708, C4 = 0.70710678118654752440,
+                   C5 = 0.55557023301960222474, C6 = 0.38268343236508977173, C7 = 0.19509032201612826785;
+  for (int strip = blockIdx.x; strip < nsx * nsy; strip += gridDim.x) {
+    const int sy = strip / nsx, sx = strip - sy * nsx;
+    const int y0 = sy * WD_RY, x0 = sx * WD_CX;
+    __syncthreads();  // the strip before is done with the planes
+    for (int e = tid; e < (WD_RY + 7) * (WD_CX + 7); e += 256) {  // pixels beyond the frame repeat its edge: they only feed windows that are not stored
+      const int py = e / (WD_CX + 7), px = e - py * (WD_CX + 7);
+      const uint32_t col = fb[(int64_t)min(y0 + py, h - 1) * w + min(x0 + px, w - 1)];  // CopyRGBPixels(ABackBuffer, x, AIndex), 879-887
+      float yy, uu, vv;
+      rgb_to_yuv(col & 0xff, (col >> 8) & 0xff, (col >> 16) & 0xff, yy, uu, vv);
+      s_pl[0][py][px] = yy; s_pl[1][py][px] = uu; s_pl[2][py][px] = vv;
+    }
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+      __syncthreads();  // the planes are whole / the plane before is done with s_r
+      if (!plain)
+      for (int e = tid; e < (WD_RY + 7) * WD_CX; e += 256) {
+        const int ry = e / WD_CX, rx = e - ry * WD_CX;
+        const float *pp = &s_pl[c][ry][rx];
+        const float f0 = pp[0], f1 = pp[1], f2 = pp[2], f3 = pp[3], f4 = pp[4], f5 = pp[5], f6 = pp[6], f7 = pp[7];
+        s_rs[ry][rx] = ((f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3)) + ((f4 * f4 + f5 * f5) + (f6 * f6 + f7 * f7));
+        const double p0 = f0, p1 = f1, p2 = f2, p3 = f3, p4 = f4, p5 = f5, p6 = f6, p7 = f7;
+        const double s0 = p0 + p7, s1 = p1 + p6, s2 = p2 + p5, s3 = p3 + p4, d0 = p0 - p7, d1 = p1 - p6, d2 = p2 - p5, d3 = p3 - p4;
+        const double e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+        double *r = s_r[ry][rx];
+        r[0] = e0 + e1;
+        r[4] = C4 * (e0 - e1);
+        r[2] = fma(C2, e2, C6 * e3);
+        r[6] = fma(C6, e2, -(C2 * e3));
+        r[1] = fma(C1, d0, fma(C3, d1, fma(C5, d2, C7 * d3)));
+        r[3] = fma(C3, d0, fma(-C7, d1, fma(-C1, d2, -(C5 * d3))));
+        r[5] = fma(C5, d0, fma(-C1, d1, fma(C7, d2, C3 * d3)));
+        r[7] = fma(C7, d0, fma(-C5, d1, fma(C3, d2, -(C1 * d3))));
+      }
+      __syncthreads();
+      if (!plain) {
+        const int wy = tid / WD_CX, wx = tid - wy * WD_CX;  // 256 threads = WD_RY x WD_CX windows
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sq += s_rs[wy + k][wx];
+        s_ws[wy][wx] = sq;
+      }
+      __syncthreads();
+      for (int wi = wave; wi < WD_RY * WD_CX; wi += 4) {
+        const int wy = wi / WD_CX, wx = wi - wy * WD_CX;
+        if (y0 + wy >= wh || x0 + wx >= ww) continue;  // (uniform in the wave)
+        const int64_t t_out = (int64_t)(y0 + wy) * ww + x0 + wx;
+        const float mine = s_pl[c][wy + (lane >> 3)][wx + (lane & 7)];  // this lane's pixel of the window (the in-order sum's product k = lane)
+        auto exact_sum = [&](int coef) -> double {  // z of coefficient `coef` in DCTInner_asm's order (utils.pas:892-921), uniform over the wave
+          const float e = __fmul_rn(mine, lut[coef * 64 + lane]);
+          const float s4 = __fadd_rn(e, __shfl_xor(e, 4));
+          double d = (double)s4;
+          d = __dadd_rn(d, __shfl_xor(d, 8));
+          d = __dadd_rn(d, __shfl_xor(d, 2));
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) { acc0 = __dadd_rn(acc0, __shfl(d, 16 * j)); acc1 = __dadd_rn(acc1, __shfl(d, 16 * j + 1)); }
+          return __dadd_rn(acc0, acc1);
+        };
+        double t = 0.0;
+        bool doubtful = true;
+        int o_fast = 0;
+        if (!plain) {
+          const double *rp = &s_r[wy][wx][lane & 7];
+          double z = av[0] * rp[0];
+#pragma unroll
+          for (int k = 1; k < 8; k++) z = fma(av[k], rp[k * WD_CX * 8], z);
+          z *= ruv;
+          t = z * wgt[c];
+          const float sa = lnorm * (__builtin_amdgcn_sqrtf(s_ws[wy][wx]) * 1.00001f);  // >= sum |pixel x LUT entry| (Cauchy-Schwarz)
+          doubtful = !first_look_rounds(t, sa, fabsf((float)wgt[c]) * 1.000001f, o_fast);
+        }
+        for (unsigned long long m = __builtin_amdgcn_ballot_w64(doubtful); m; m &= m - 1) {
+          const int coef = __builtin_ctzll(m);
+          const double z = exact_sum(coef);
+          if (lane == coef) t = __dmul_rn(z, wgt[c]);
+        }
+        // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
+        out[t_out * 192 + c * 64 + zz] = !doubtful ? (int16_t)o_fast : fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+      }
+    }
+  }
+}
+
 int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream) {
   const DeviceTables *tab;
   TM_TRY(get_tables(&tab));
   TM_CHECK(w >= 8 && h >= 8, TM_E_INVAL, "frame buffer %dx%d smaller than a tile", w, h);
   const int64_t n = (int64_t)(w - 7) * (h - 7);
+  if (!knobs().window_dcts_by_tile) {
+    const int strips = ((w - 7 + WD_CX - 1) / WD_CX) * ((h - 7 + WD_RY - 1) / WD_RY);
+    hipLaunchKernelGGL(k_window_dcts, dim3(std::min(strips, 256 * 4)), dim3(256), 0, stream, (const uint32_t *)fb, w, h, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)],
+                       tab->weights, tab->snake, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], (int16_t *)out, knobs().features_plain ? 1 : 0);
+    TM_HIP(hipGetLastError());
+    return TM_OK;
+  }
   hipLaunchKernelGGL(k_features_i16<2>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)fb, nullptr, nullptr, nullptr, w,
                      nullptr, n, 1, 0, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights, tab->snake, tab->srgb_lut,
                      (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], knobs().features_plain ? 1 : 0);
