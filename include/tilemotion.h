@@ -193,8 +193,9 @@ enum { TM_ARRAY_TILEMAP_TILE = 0, TM_ARRAY_TILEMAP_ERR = 1, TM_ARRAY_TILEMAP_PAL
                                   dither shards hold 0: merge with SUM, as bytes or as count/4 32-bit words (count is a multiple of 64) */ };
 TM_API int tm_set_query_shard(tm_encoder *, int first_frame, int frame_count /* <0: to the end */);
 /* One process per GPU with the merges INSIDE the steps: the host hands the encoder its rank, the number of processes and a
- * callback that performs a collective over them (RCCL through the host's own communicator: the library links no communication
- * layer).  The callback runs on the caller's thread with the encoder's stream idle; it returns 0 once the result is in place.
+ * callback that performs a collective over them (the host's own communicator -- RCCL through torch.distributed in bench.py, gloo in the
+ * CPU tests; the library ALSO links RCCL and can carry the collectives itself, tm_comm_init below, which bench.py takes with
+ * TM_BENCH_NATIVE=1).  The callback runs on the caller's thread with the encoder's stream idle; it returns 0 once the result is in place.
  *   kind: TM_COLL_ALLREDUCE_SUM_I32 / _MAX_I32 / _SUM_I64: `count` elements in `dev_buf`, in place;
  *         TM_COLL_ALLGATHER_BYTES: `count` bytes from `dev_buf` of every process into `dev_recv` (world x count bytes, rank order).
  * With it set, Run(step) shards by itself: Load by frame (motion prediction off), Reduce as a local exact dedup + an all-gather of

@@ -1937,17 +1937,33 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
     hs.push_back(g);
     which.push_back(s);
   }
-  {  // all workgroups must be resident together: what the runtime says fits a CU (registers, LDS, the launch bound of three), not a guess
+  // All workgroups of a launch must be resident together: what the runtime says fits a CU (registers, LDS, the launch bound of three), not a
+  // guess.  More colours than the chip holds at once (3.1 M: the motion-prediction configurations of the bench clip) go as several launches,
+  // each a run of whole segments (palettes are independent), one after the other on the stream.
+  std::vector<std::pair<size_t, size_t>> batches;  // [first, last) of hs
+  {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kmeans3_persistent, P3_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     per_cu = std::min(per_cu, P3_WGS);
-    if (nblk > per_cu * cus) return TM_OK;
+    const int capacity = per_cu * cus;
+    size_t b0 = 0;
+    int acc = 0;
+    for (size_t i = 0; i < hs.size(); i++) {
+      if (hs[i].blk_count > capacity) return TM_OK;  // one palette alone does not fit: the launches-per-iteration path
+      if (acc + hs[i].blk_count > capacity) { batches.push_back({b0, i}); b0 = i; acc = 0; }
+      acc += hs[i].blk_count;
+    }
+    if (b0 < hs.size()) batches.push_back({b0, hs.size()});
   }
   if (host_kk) host_kk->assign(nseg, 0);
   if (host_iters) *host_iters = 0;
   *used = 1;
   if (hs.empty()) return TM_OK;
-  hs[0].nseg = (int)hs.size();
+  for (const auto &b : batches) {  // a launch sees its own segments only: workgroup indices from 0, the count in its first element
+    const int base = hs[b.first].blk_first;
+    for (size_t i = b.first; i < b.second; i++) hs[i].blk_first -= base;
+    hs[b.first].nseg = (int)(b.second - b.first);
+  }
   DevBuf dsegs, dstate, dcent;
   TM_TRY(dsegs.alloc(sizeof(Seg3) * hs.size()));
   TM_TRY(dstate.alloc(sizeof(Seg3State) * hs.size()));
@@ -1957,8 +1973,12 @@ static int kmeans3_persistent(const int32_t *pts, const uint32_t *w, const std::
   TM_HIP(hipMemsetAsync(dcent.p, 0, sizeof(double) * hs.size() * k * 3, stream));
   TM_CHECK(nblk >= 1 && k >= 1 && k <= P3_MAXK, TM_E_INVAL, "k-means: resident launch of %d workgroups for %d centres (at most %d)", nblk, k, P3_MAXK);
   std::unique_lock<std::mutex> resident_lock(g_resident_launch);
-  hipLaunchKernelGGL(k_kmeans3_persistent, dim3(nblk), dim3(P3_NT), 0, stream, pts, w, dsegs.as<Seg3>(), dstate.as<Seg3State>(), k, max_iter, assign,
-                     dcent.as<double>());
+  for (const auto &b : batches) {
+    int grid = 0;
+    for (size_t i = b.first; i < b.second; i++) grid += hs[i].blk_count;
+    hipLaunchKernelGGL(k_kmeans3_persistent, dim3(grid), dim3(P3_NT), 0, stream, pts, w, dsegs.as<Seg3>() + b.first, dstate.as<Seg3State>() + b.first, k, max_iter, assign,
+                       dcent.as<double>() + b.first * (size_t)k * 3);
+  }
   TM_HIP(hipGetLastError());
   std::vector<Seg3State> hstate(hs.size());
   std::vector<double> hcent(hs.size() * (size_t)k * 3);
