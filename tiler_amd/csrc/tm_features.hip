@@ -575,20 +575,21 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ww = w - 7, wh = h - 7;
   const int nsx = (ww + WD_CX - 1) / WD_CX, nsy = (wh + WD_RY - 1) / WD_RY;
-  double av[8];
-#pragma unroll
-  for (int x = 0; x < 8; x++) av[x] = cosd[(lane >> 3) * 8 + x];
-  const double ruv = (lane == 0) ? 0.5 : (((lane & 7) == 0 || (lane >> 3) == 0) ? 0.707106769084930419921875 : 1.0);  // cDCTUVRatio (utils.pas:100-109)
-  double wgt[3];
-#pragma unroll
-  for (int c = 0; c < 3; c++) wgt[c] = weights[c * 64 + lane];
-  const int zz = snake[lane];
-  float lnorm;  // the Euclidean norm of this lane's LUT row, rounded up
-  {
+  // per coefficient cf = v * 8 + u: cDCTUVRatio (utils.pas:100-109) x weight, |weight|, the LUT row's Euclidean norm (rounded up), the zig-zag place
+  // (read from LDS per coefficient: eight doubles, sixteen Singles and eight indices per lane in registers instead cost a wave per SIMD: 0.35 against 0.32 ms)
+  __shared__ double s_cw[3][64];
+  __shared__ float s_wa[3][64], s_ln[64];
+  __shared__ int s_zz[64];
+  __shared__ __attribute__((aligned(16))) int16_t s_out[4][8 * 64];  // a wave's run of eight windows, one plane
+  if (tid < 64) {
+    const double ruv = (tid == 0) ? 0.5 : (((tid & 7) == 0 || (tid >> 3) == 0) ? 0.707106769084930419921875 : 1.0);
+    for (int c = 0; c < 3; c++) { const double wv = weights[c * 64 + tid]; s_cw[c][tid] = ruv * wv; s_wa[c][tid] = fabsf((float)wv) * 1.000001f; }
     double q2 = 0.0;
-    for (int k = 0; k < 64; k++) { const double v = (double)lut[lane * 64 + k]; q2 = fma(v, v, q2); }
-    lnorm = (float)(sqrt(q2) * (1.0 + 1e-6));
+    for (int k = 0; k < 64; k++) { const double v = (double)lut[tid * 64 + k]; q2 = fma(v, v, q2); }
+    s_ln[tid] = (float)(sqrt(q2) * (1.0 + 1e-6));
+    s_zz[tid] = snake[tid];
   }
+  (void)cosd;
   // cos(k pi / 16)
   constexpr double C1 = 0.98078528040323044913, C2 = 0.92387953251128675613, C3 = 0.83146961230254523708, C4 = 0.70710678118654752440,
                    C5 = 0.55557023301960222474, C6 = 0.38268343236508977173, C7 = 0.19509032201612826785;
@@ -634,42 +635,68 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
         s_ws[wy][wx] = sq;
       }
       __syncthreads();
-      for (int wi = wave; wi < WD_RY * WD_CX; wi += 4) {
-        const int wy = wi / WD_CX, wx = wi - wy * WD_CX;
-        if (y0 + wy >= wh || x0 + wx >= ww) continue;  // (uniform in the wave)
-        const int64_t t_out = (int64_t)(y0 + wy) * ww + x0 + wx;
-        const float mine = s_pl[c][wy + (lane >> 3)][wx + (lane & 7)];  // this lane's pixel of the window (the in-order sum's product k = lane)
-        auto exact_sum = [&](int coef) -> double {  // z of coefficient `coef` in DCTInner_asm's order (utils.pas:892-921), uniform over the wave
-          const float e = __fmul_rn(mine, lut[coef * 64 + lane]);
-          const float s4 = __fadd_rn(e, __shfl_xor(e, 4));
-          double d = (double)s4;
-          d = __dadd_rn(d, __shfl_xor(d, 8));
-          d = __dadd_rn(d, __shfl_xor(d, 2));
-          double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) { acc0 = __dadd_rn(acc0, __shfl(d, 16 * j)); acc1 = __dadd_rn(acc1, __shfl(d, 16 * j + 1)); }
-          return __dadd_rn(acc0, acc1);
-        };
-        double t = 0.0;
-        bool doubtful = true;
-        int o_fast = 0;
+      // (4) a wave per run of EIGHT consecutive windows of a strip row, lane = (window j, u): the lane's eight row transforms R[wy .. wy + 7][wx][u] go
+      // through the same 8-point fast DCT down the column -- 35 double-precision operations for its eight coefficients v = 0..7 where a lane per
+      // coefficient spent eight multiply-adds on ONE -- then weight, verdict, and the run's 8 x 64 coefficients of this plane leave through LDS as
+      // eight 128-byte lines (a lane per 16 bytes; a lane per coefficient stored two bytes at a time).
+      for (int gi = wave; gi < WD_RY * (WD_CX / 8); gi += 4) {
+        const int wy = gi / (WD_CX / 8), wx0 = (gi - wy * (WD_CX / 8)) * 8;
+        if (y0 + wy >= wh || x0 + wx0 >= ww) continue;  // (uniform in the wave)
+        const int j = lane >> 3, u = lane & 7, wx = wx0 + j;
+        unsigned dmask = 0;  // bit v: coefficient (u, v) of window j is in doubt
+        int16_t *so = s_out[wave];
         if (!plain) {
-          const double *rp = &s_r[wy][wx][lane & 7];
-          double z = av[0] * rp[0];
+          const double *rp = &s_r[wy][wx][u];
+          const double p0 = rp[0], p1 = rp[WD_CX * 8], p2 = rp[2 * WD_CX * 8], p3 = rp[3 * WD_CX * 8], p4 = rp[4 * WD_CX * 8], p5 = rp[5 * WD_CX * 8], p6 = rp[6 * WD_CX * 8],
+                       p7 = rp[7 * WD_CX * 8];
+          const double s0 = p0 + p7, s1 = p1 + p6, s2 = p2 + p5, s3 = p3 + p4, d0 = p0 - p7, d1 = p1 - p6, d2 = p2 - p5, d3 = p3 - p4;
+          const double e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+          double z[8];
+          z[0] = e0 + e1;
+          z[4] = C4 * (e0 - e1);
+          z[2] = fma(C2, e2, C6 * e3);
+          z[6] = fma(C6, e2, -(C2 * e3));
+          z[1] = fma(C1, d0, fma(C3, d1, fma(C5, d2, C7 * d3)));
+          z[3] = fma(C3, d0, fma(-C7, d1, fma(-C1, d2, -(C5 * d3))));
+          z[5] = fma(C5, d0, fma(-C1, d1, fma(C7, d2, C3 * d3)));
+          z[7] = fma(C7, d0, fma(-C5, d1, fma(C3, d2, -(C1 * d3))));
+          const float root = __builtin_amdgcn_sqrtf(s_ws[wy][wx]) * 1.00001f;
 #pragma unroll
-          for (int k = 1; k < 8; k++) z = fma(av[k], rp[k * WD_CX * 8], z);
-          z *= ruv;
-          t = z * wgt[c];
-          const float sa = lnorm * (__builtin_amdgcn_sqrtf(s_ws[wy][wx]) * 1.00001f);  // >= sum |pixel x LUT entry| (Cauchy-Schwarz)
-          doubtful = !first_look_rounds(t, sa, fabsf((float)wgt[c]) * 1.000001f, o_fast);
+          for (int v = 0; v < 8; v++) {
+            const int cf = v * 8 + u;
+            const double t = z[v] * s_cw[c][cf];  // cDCTUVRatio and the weight in one factor
+            int o;
+            const bool ok = first_look_rounds(t, s_ln[cf] * root, s_wa[c][cf], o);  // sa >= sum |pixel x LUT entry| (Cauchy-Schwarz)
+            so[j * 64 + s_zz[cf]] = (int16_t)o;
+            dmask |= ok ? 0u : (1u << v);
+          }
+        } else dmask = 0xffu;
+        // the coefficients in doubt, one after the other by the whole wave: lane k = product k of DCTInner_asm's sum (utils.pas:892-921)
+        for (unsigned long long m = __builtin_amdgcn_ballot_w64(dmask != 0); m; m &= m - 1) {
+          const int src = __builtin_ctzll(m);
+          const int sj = src >> 3, su = src & 7;
+          const float mine = s_pl[c][wy + (lane >> 3)][wx0 + sj + (lane & 7)];  // this lane's pixel of window sj
+          for (unsigned vm = (unsigned)__builtin_amdgcn_readlane((int)dmask, src); vm; vm &= vm - 1) {
+            const int coef = __builtin_ctz(vm) * 8 + su;
+            const float e = __fmul_rn(mine, lut[coef * 64 + lane]);
+            const float s4 = __fadd_rn(e, __shfl_xor(e, 4));
+            double d = (double)s4;
+            d = __dadd_rn(d, __shfl_xor(d, 8));
+            d = __dadd_rn(d, __shfl_xor(d, 2));
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { acc0 = __dadd_rn(acc0, __shfl(d, 16 * q)); acc1 = __dadd_rn(acc1, __shfl(d, 16 * q + 1)); }
+            const double t = __dmul_rn(__dadd_rn(acc0, acc1), weights[c * 64 + coef]);
+            // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
+            if (lane == src) so[sj * 64 + s_zz[coef]] = fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+          }
         }
-        for (unsigned long long m = __builtin_amdgcn_ballot_w64(doubtful); m; m &= m - 1) {
-          const int coef = __builtin_ctzll(m);
-          const double z = exact_sum(coef);
-          if (lane == coef) t = __dmul_rn(z, wgt[c]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS operations are in order: its reads below see its writes above)
+        if (x0 + wx < ww) {  // lane = (window j, 16-byte piece u) of the plane's 128 bytes
+          const int64_t t_out = (int64_t)(y0 + wy) * ww + x0 + wx;
+          *reinterpret_cast<uint4 *>(out + t_out * 192 + c * 64 + u * 8) = *reinterpret_cast<const uint4 *>(so + j * 64 + u * 8);
         }
-        // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
-        out[t_out * 192 + c * 64 + zz] = !doubtful ? (int16_t)o_fast : fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next run's coefficients land after these reads)
       }
     }
   }
