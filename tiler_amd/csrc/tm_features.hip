@@ -100,12 +100,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The reference's z_ref w lies within slack = sa (2^-23 + 2^-24)(1 + 2^-17)(1 + 2^-20) |w| + 1e-9 (|t| + 1) of t (k_features_i16 has the
 // derivation), and tf = Single(t) within |t| 2^-24 of t: when tf is farther than the two together from every half-integer, Round(z_ref w) =
 // rint(tf).  Returns false (in doubt: the caller sums the coefficient in the reference's order) otherwise, and for values no int16 path needs.
-__device__ __forceinline__ bool first_look_rounds(double t, float sa, float wabs, int &o) {
-  const float tf = (float)t, at = fabsf(tf);
-  const float slack = sa * (1.82e-7f * wabs) + 1.1e-9f * (at + 1.0f) + at * 6.1e-8f;
-  const float fr = tf - floorf(tf);  // exact
+// (sw = sa x 1.82e-7 |w|: the caller folds what is constant per coefficient.  slack < 0.25 also bounds |t| by 4 x 10^6: rintf is exact there.)
+__device__ __forceinline__ bool first_look_rounds(double t, float sw, int &o) {
+  const float tf = (float)t;
+  const float slack = fmaf(fabsf(tf), 6.21e-8f, sw + 1.1e-9f);
+  const float fr = __builtin_amdgcn_fractf(tf);  // tf - floor(tf), exact
   o = (int)rintf(tf);
-  return fabsf(fr - 0.5f) > slack && slack < 0.25f && at < 1.0e6f;
+  return fabsf(fr - 0.5f) > slack && slack < 0.25f;
 }
 
 template <int SRC>
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void k_features_i16(const uint32_t *__restrict
           z = fma(av[4], r2.x, z); z = fma(av[5], r2.y, z); z = fma(av[6], r3.x, z); z = fma(av[7], r3.y, z);
           z *= ruv;
           t = weighted ? z * w[c] : z;
-          doubtful = !first_look_rounds(t, sa, weighted ? fabsf((float)w[c]) * 1.000001f : 1.0f, o_fast);  // 1.82e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
+          doubtful = !first_look_rounds(t, sa * (1.82e-7f * (weighted ? fabsf((float)w[c]) * 1.000001f : 1.0f)), o_fast);  // 1.82e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
         }
         for (unsigned long long m = __builtin_amdgcn_ballot_w64(doubtful); m; m &= m - 1) {
           const int coef = __builtin_ctzll(m);
@@ -575,18 +576,18 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ww = w - 7, wh = h - 7;
   const int nsx = (ww + WD_CX - 1) / WD_CX, nsy = (wh + WD_RY - 1) / WD_RY;
-  // per coefficient cf = v * 8 + u: cDCTUVRatio (utils.pas:100-109) x weight, |weight|, the LUT row's Euclidean norm (rounded up), the zig-zag place
+  // per coefficient cf = v * 8 + u: cDCTUVRatio (utils.pas:100-109) x weight, the slack's factor, the zig-zag place
   // (read from LDS per coefficient: eight doubles, sixteen Singles and eight indices per lane in registers instead cost a wave per SIMD: 0.35 against 0.32 ms)
   __shared__ double s_cw[3][64];
-  __shared__ float s_wa[3][64], s_ln[64];
+  __shared__ float s_kw[3][64];  // 1.82e-7 x |weight| x the LUT row's norm: what of the slack is the coefficient's own
   __shared__ int s_zz[64];
   __shared__ __attribute__((aligned(16))) int16_t s_out[4][8 * 64];  // a wave's run of eight windows, one plane
   if (tid < 64) {
     const double ruv = (tid == 0) ? 0.5 : (((tid & 7) == 0 || (tid >> 3) == 0) ? 0.707106769084930419921875 : 1.0);
-    for (int c = 0; c < 3; c++) { const double wv = weights[c * 64 + tid]; s_cw[c][tid] = ruv * wv; s_wa[c][tid] = fabsf((float)wv) * 1.000001f; }
     double q2 = 0.0;
     for (int k = 0; k < 64; k++) { const double v = (double)lut[tid * 64 + k]; q2 = fma(v, v, q2); }
-    s_ln[tid] = (float)(sqrt(q2) * (1.0 + 1e-6));
+    const float ln = (float)(sqrt(q2) * (1.0 + 1e-6));
+    for (int c = 0; c < 3; c++) { const double wv = weights[c * 64 + tid]; s_cw[c][tid] = ruv * wv; s_kw[c][tid] = 1.82e-7f * (fabsf((float)wv) * 1.000001f) * ln * 1.000001f; }
     s_zz[tid] = snake[tid];
   }
   (void)cosd;
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
             const int cf = v * 8 + u;
             const double t = z[v] * s_cw[c][cf];  // cDCTUVRatio and the weight in one factor
             int o;
-            const bool ok = first_look_rounds(t, s_ln[cf] * root, s_wa[c][cf], o);  // sa >= sum |pixel x LUT entry| (Cauchy-Schwarz)
+            const bool ok = first_look_rounds(t, s_kw[c][cf] * root, o);  // root x the LUT row's norm >= sum |pixel x LUT entry| (Cauchy-Schwarz)
             so[j * 64 + s_zz[cf]] = (int16_t)o;
             dmask |= ok ? 0u : (1u << v);
           }
