@@ -640,6 +640,12 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
       // through the same 8-point fast DCT down the column -- 35 double-precision operations for its eight coefficients v = 0..7 where a lane per
       // coefficient spent eight multiply-adds on ONE -- then weight, verdict, and the run's 8 x 64 coefficients of this plane leave through LDS as
       // eight 128-byte lines (a lane per 16 bytes; a lane per coefficient stored two bytes at a time).
+      // (the lane's eight factors of this plane, and its zig-zag places, once per plane instead of once per coefficient)
+      double cwr[8];
+      float kwr[8];
+      int zzr[8];
+#pragma unroll
+      for (int v = 0; v < 8; v++) { cwr[v] = s_cw[c][v * 8 + (lane & 7)]; kwr[v] = s_kw[c][v * 8 + (lane & 7)]; zzr[v] = (lane >> 3) * 64 + s_zz[v * 8 + (lane & 7)]; }  // (zzr: the place in the wave's run)
       for (int gi = wave; gi < WD_RY * (WD_CX / 8); gi += 4) {
         const int wy = gi / (WD_CX / 8), wx0 = (gi - wy * (WD_CX / 8)) * 8;
         if (y0 + wy >= wh || x0 + wx0 >= ww) continue;  // (uniform in the wave)
@@ -664,11 +670,10 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
           const float root = __builtin_amdgcn_sqrtf(s_ws[wy][wx]) * 1.00001f;
 #pragma unroll
           for (int v = 0; v < 8; v++) {
-            const int cf = v * 8 + u;
-            const double t = z[v] * s_cw[c][cf];  // cDCTUVRatio and the weight in one factor
+            const double t = z[v] * cwr[v];  // cDCTUVRatio and the weight in one factor
             int o;
-            const bool ok = first_look_rounds(t, s_kw[c][cf] * root, o);  // root x the LUT row's norm >= sum |pixel x LUT entry| (Cauchy-Schwarz)
-            so[j * 64 + s_zz[cf]] = (int16_t)o;
+            const bool ok = first_look_rounds(t, kwr[v] * root, o);  // root x the LUT row's norm >= sum |pixel x LUT entry| (Cauchy-Schwarz)
+            so[zzr[v]] = (int16_t)o;
             dmask |= ok ? 0u : (1u << v);
           }
         } else dmask = 0xffu;
