@@ -135,6 +135,16 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0;
   if (TD && HT + HQ == 0) acc = ntr;  // a single phase: the rows' term is the chain's starting value
+#ifndef TM_KNN3_OPAQUE_ZERO
+#define TM_KNN3_OPAQUE_ZERO 0
+#endif
+#if TM_KNN3_OPAQUE_ZERO
+  // (measured in round 5 and left off: the compiler, seeing through the zero, gives the first T_H . Q_H product the constant 0 as its C operand
+  // where that product runs and builds the zero with 23 register moves on every other path; made opaque here it is 16 moves on every path --
+  // and the kernel takes 12.7 instead of 12.2 ms.  A never-zeroed accumulator -- every product in two forms behind a scalar branch on "has a
+  // product run yet" -- compiled to 200 register-pair copies between the forms.)
+  asm volatile("" : "+v"(acc));
+#endif
   if (HM > 0) {
     if (tm & qm) {
 #pragma unroll
