@@ -85,15 +85,13 @@ def _spawn_ranks(n):
     """`--gpus N` without a launcher: N fresh rank processes through torch.distributed.run, started from this process BEFORE it has
     made any GPU call (never an exec: a process that has initialised the GPU must not be replaced).  Rank 0's JSON line is relayed on
     stdout, everything else goes to stderr; the exit code is the launcher's (non-zero if any rank failed)."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver of this pool only does dmabuf IPC
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the launcher picks the rendezvous port itself (c10d store on 127.0.0.1, port 0 = any free one): a port found here by bind-and-close
+    # could be taken by another process before the launcher binds it (ADVICE r04)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0",
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in proc.stdout:
