@@ -42,6 +42,8 @@
  *                           compare the two forms)
  *   TM_KM_LAUNCHES          the tile -> palette k-means runs its skipping iterations as three launches each instead of one resident launch
  *                           for all of them (tests compare the two)
+ *   TM_KM_RESIDENT_FAIL     the resident launch of the tile k-means is treated as if its barrier had given up: the clustering is repeated from its
+ *                           seeds through the launches (tests: the fallback's result must be the same)
  *   TM_WINDOW_DCTS_BY_TILE  the sliding-window features of motion prediction a window at a time (k_features_i16<2>) instead of by strips that share
  *                           the colour conversion and the row transforms between windows (tests compare the two)
  *   TM_PP_SHARDED           several processes: the tile -> palette clustering stays data-parallel (an all-reduce per Lloyd iteration) even where

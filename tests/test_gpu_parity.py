@@ -670,20 +670,23 @@ def test_lab_of_every_colour(oracle):
     assert bad.size == 0, (bad.size, [hex(int(c)) for c in bad[:5]], got[bad[:5]], want[bad[:5]])
 
 
-@pytest.fixture(params=["resident", "launches"])
+@pytest.fixture(params=["resident", "launches", "resident-gave-up"])
 def km_path(request, monkeypatch):
-    """the tile k-means' skipping iterations: one resident launch for all of them (k_h_resident, <= 16 centroids), or three launches each"""
+    """the tile k-means' skipping iterations: one resident launch for all of them (k_h_resident, <= 16 centroids), three launches each, or the
+    resident launch treated as if its barrier had given up (the clustering is then repeated from its seeds through the launches)"""
+    monkeypatch.delenv("TM_KM_LAUNCHES", raising=False)
+    monkeypatch.delenv("TM_KM_RESIDENT_FAIL", raising=False)
     if request.param == "launches":
         monkeypatch.setenv("TM_KM_LAUNCHES", "1")
-    else:
-        monkeypatch.delenv("TM_KM_LAUNCHES", raising=False)
+    elif request.param == "resident-gave-up":
+        monkeypatch.setenv("TM_KM_RESIDENT_FAIL", "1")
     return request.param
 
 
 @pytest.mark.parametrize("n,d,k", [(500, 3, 16), (40, 3, 64), (300, 192, 8), (1, 3, 4), (2000, 192, 40), (5000, 192, 16), (1500, 192, 3)])
 def test_kmeans(oracle, n, d, k, km_path):
     from tiler_amd import stages
-    if km_path == "launches" and not (d == 192 and k <= 16):
+    if km_path != "resident" and not (d == 192 and k <= 16):
         pytest.skip("one path only")
     rng = np.random.default_rng(n + d + k)
     if d == 3:
@@ -726,7 +729,7 @@ def test_kmeans_192_skipping_iterations_are_exact(oracle, case, k, km_path):
     the margins of any sloppy bound, and one far cluster (large centroid displacements in the first iterations); 40 centroids take three
     passes of 16 through the list kernel, whose four lanes per point each score four centroids of a pass"""
     from tiler_amd import stages
-    if km_path == "launches" and k > 16:
+    if km_path != "resident" and k > 16:
         pytest.skip("one path only")
     rng = np.random.default_rng(len(case))
     n, d = 6000, 192

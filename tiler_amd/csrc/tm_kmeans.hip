@@ -2198,6 +2198,7 @@ static int kmeans_batched(const int32_t *pts, const uint32_t *w, int d, const st
         TM_TRY(hr_.wait());
       }
       resident_lock.unlock();
+      if (knobs().km_resident_fail) timed_out = 1;  // (tests: the path a barrier that gave up takes)
       if (timed_out) {
         fprintf(stderr, "[tm_kmeans] the resident tile k-means gave up at its barrier; repeating the clustering with one launch per step\n");
         return kmeans_batched(pts, w, d, seg_begin, seg_count, k, max_iter, assign, cent, host_kk, host_iters, stream, init_idx, dev_init_idx, false);
