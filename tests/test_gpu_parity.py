@@ -197,6 +197,28 @@ def test_features_first_look_in_every_source_instantiation(monkeypatch):
         monkeypatch.setenv("TM_WINDOW_DCTS_BY_TILE", "1")
 
 
+@pytest.mark.parametrize("mode,use_lab", [(1, False), (0, False), (1, True)])
+def test_features_eight_tiles_a_wave_against_a_tile_at_a_time(monkeypatch, mode, use_lab):
+    """k_features_tiles8 (a lane per tile row / column, fast 8-point DCTs, the default for RGB tiles in the plain DCT modes) against
+    k_features_i16<0> (TM_FEATURES_BY_TILE=1) and against every coefficient in the reference's order (TM_FEATURES_PLAIN=1), over every
+    kind of tile, with and without mirror flags, at counts that leave the last wave ragged"""
+    from tiler_amd import stages
+    t, flags = _tile_kinds(60011, 77 + mode)
+    td, fd = _dev(t), _dev(flags)
+    for n in (60011, 4099, 9, 8, 7, 1):
+        for fl in (None, fd[:n].contiguous()):
+            monkeypatch.delenv("TM_FEATURES_BY_TILE", raising=False)
+            monkeypatch.delenv("TM_FEATURES_PLAIN", raising=False)
+            got = stages.features_rgb(td[:n].contiguous(), fl, mode, use_lab)
+            monkeypatch.setenv("TM_FEATURES_BY_TILE", "1")
+            by_tile = stages.features_rgb(td[:n].contiguous(), fl, mode, use_lab)
+            assert torch.equal(got, by_tile), (n, fl is not None)
+            if n <= 4099:
+                monkeypatch.delenv("TM_FEATURES_BY_TILE")
+                monkeypatch.setenv("TM_FEATURES_PLAIN", "1")
+                assert torch.equal(stages.features_rgb(td[:n].contiguous(), fl, mode, use_lab), got), (n, fl is not None)
+
+
 def test_features_pal_and_cluster(tiles_flags, oracle):
     from tiler_amd import stages
     tiles, _ = tiles_flags

@@ -490,6 +490,177 @@ int launch_load(const void *frames, int nframes, int img_w, int img_h, int tm_w,
   return TM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A4 + A5 for RGB tiles, plain (non-"special") DCT modes: k_features_i16<0>'s work with a lane per (tile, row) / (tile, u) instead of a lane
+// per coefficient -- a wave takes EIGHT tiles.  A lane converts its row's eight pixels, takes them through the 8-point fast DCT (35 double-precision
+// operations for the row's eight outputs), the outputs change hands through LDS (transposed), and the lane of (tile, u) takes the eight
+// row transforms R[u][y] through the same DCT down the column: 70 operations a lane for 8 x 8 coefficients where a lane per coefficient spends
+// sixteen multiply-adds on one.  Weight, the first look's verdict, the in-doubt coefficients in the reference's order by the whole wave,
+// exactly as in k_features_i16 and k_window_dcts; a plane's coefficients leave through LDS as 128-byte lines.  (The first look's z may be
+// summed in any order: its bound has nine decimal orders of room.)
+constexpr int F8_TP = 72;  // pitch (doubles) of a tile's transposed row transforms: eight tiles' lanes then cover the banks evenly
+__global__ __launch_bounds__(256) void k_features_tiles8(const uint32_t *__restrict__ tiles, const int32_t *__restrict__ rows, const uint8_t *__restrict__ mirror_flags, int64_t n,
+                                                         int weighted, int use_lab, const float *__restrict__ lut, const double *__restrict__ weights,
+                                                         const uint8_t *__restrict__ snake, const float *__restrict__ srgb_lut, int16_t *__restrict__ out,
+                                                         int *__restrict__ colmm /* null, or [384]: running min / max of the 192 output columns (atomics) */, int plain) {
+  __shared__ double s_cw[3][64];
+  __shared__ float s_kw[3][64];
+  __shared__ int s_zz[64];
+  __shared__ __attribute__((aligned(16))) float s_px[4][3][8][64];   // the planes as Singles, for the in-order sums; at the very end: the columns' ranges
+  __shared__ __attribute__((aligned(16))) double s_t[4][8 * F8_TP];   // a wave's eight tiles, one plane: row transforms [tile][u][y]
+  __shared__ __attribute__((aligned(16))) int16_t s_out[4][8 * 64];   // ... and its coefficients in output order
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, y = lane & 7, u = y;
+  if (tid < 64) {
+    const double ruv = (tid == 0) ? 0.5 : (((tid & 7) == 0 || (tid >> 3) == 0) ? 0.707106769084930419921875 : 1.0);  // cDCTUVRatio (utils.pas:100-109)
+    double q2 = 0.0;
+    for (int k = 0; k < 64; k++) { const double v = (double)lut[tid * 64 + k]; q2 = fma(v, v, q2); }
+    const float ln = (float)(sqrt(q2) * (1.0 + 1e-6));  // the LUT row's Euclidean norm, rounded up
+    for (int c = 0; c < 3; c++) {
+      const double wv = weighted ? weights[c * 64 + tid] : 1.0;
+      s_cw[c][tid] = ruv * wv;
+      s_kw[c][tid] = 1.82e-7f * (fabsf((float)wv) * 1.000001f) * ln * 1.000001f;  // 1.82e-7 > (2^-23 + 2^-24) (1 + 2^-17)(1 + 2^-20)
+    }
+    s_zz[tid] = snake[tid];
+  }
+  __syncthreads();
+  constexpr double C1 = 0.98078528040323044913, C2 = 0.92387953251128675613, C3 = 0.83146961230254523708, C4 = 0.70710678118654752440,
+                   C5 = 0.55557023301960222474, C6 = 0.38268343236508977173, C7 = 0.19509032201612826785;  // cos(k pi / 16)
+  auto dct8 = [&](const double (&p)[8], double (&r)[8]) {
+    const double s0 = p[0] + p[7], s1 = p[1] + p[6], s2 = p[2] + p[5], s3 = p[3] + p[4], d0 = p[0] - p[7], d1 = p[1] - p[6], d2 = p[2] - p[5], d3 = p[3] - p[4];
+    const double e0 = s0 + s3, e1 = s1 + s2, e2 = s0 - s3, e3 = s1 - s2;
+    r[0] = e0 + e1;
+    r[4] = C4 * (e0 - e1);
+    r[2] = fma(C2, e2, C6 * e3);
+    r[6] = fma(C6, e2, -(C2 * e3));
+    r[1] = fma(C1, d0, fma(C3, d1, fma(C5, d2, C7 * d3)));
+    r[3] = fma(C3, d0, fma(-C7, d1, fma(-C1, d2, -(C5 * d3))));
+    r[5] = fma(C5, d0, fma(-C1, d1, fma(C7, d2, C3 * d3)));
+    r[7] = fma(C7, d0, fma(-C5, d1, fma(C3, d2, -(C1 * d3))));
+  };
+  int zzr[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) zzr[v] = j * 64 + s_zz[v * 8 + u];  // the place of coefficient (u, v) in the wave's run
+  int mmn[3] = {INT_MAX, INT_MAX, INT_MAX}, mmx[3] = {INT_MIN, INT_MIN, INT_MIN};  // of output column `lane` of each plane
+  int16_t *const so = s_out[wave];
+  double *const st = s_t[wave];
+  const int64_t ngroups = (n + 7) >> 3;
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+    const int64_t t_out = g * 8 + j;
+    const bool valid = t_out < n;
+    float pl[3][8];
+    {  // this lane's row of its tile, as ConvertToCpnPixels reads it (mirrors 3080-3085 / 3093-3098)
+      const int64_t tile = valid ? (rows ? (int64_t)rows[t_out] : t_out) : (rows ? (int64_t)rows[n - 1] : n - 1);
+      const int f = (valid && mirror_flags) ? mirror_flags[t_out] : 0;
+      const uint4 *src = reinterpret_cast<const uint4 *>(tiles + tile * 64 + ((f & 2) ? 7 - y : y) * 8);
+      const uint4 a = src[0], b = src[1];
+      uint32_t px[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      if (f & 1) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) { const uint32_t tmp = px[x]; px[x] = px[7 - x]; px[7 - x] = tmp; }
+      }
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        if (use_lab) rgb_to_lab_det(px[x] & 0xff, (px[x] >> 8) & 0xff, (px[x] >> 16) & 0xff, srgb_lut, pl[0][x], pl[1][x], pl[2][x]);
+        else rgb_to_yuv(px[x] & 0xff, (px[x] >> 8) & 0xff, (px[x] >> 16) & 0xff, pl[0][x], pl[1][x], pl[2][x]);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float4 *dst = reinterpret_cast<float4 *>(&s_px[wave][c][j][y * 8]);
+        dst[0] = make_float4(pl[c][0], pl[c][1], pl[c][2], pl[c][3]);
+        dst[1] = make_float4(pl[c][4], pl[c][5], pl[c][6], pl[c][7]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {  // (unrolled: the planes' registers and ranges are then addressed statically -- no scratch)
+      unsigned dmask = 0;  // bit v: coefficient (u, v) of tile j is in doubt
+      if (!plain) {
+        float sq = 0.0f;
+        double p[8], r[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) { sq = fmaf(pl[c][x], pl[c][x], sq); p[x] = (double)pl[c][x]; }
+        // the tile's sum of squares over its eight lanes (row moves: lane ^ 1, lane ^ 2, the mirror image inside eight)
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0xB1, 0xf, 0xf, true));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x4E, 0xf, 0xf, true));
+        sq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq), 0x141, 0xf, 0xf, true));
+        const float root = __builtin_amdgcn_sqrtf(sq) * 1.00001f;  // x the LUT row's norm >= sum |pixel x LUT entry| (Cauchy-Schwarz)
+        dct8(p, r);
+#pragma unroll
+        for (int uu = 0; uu < 8; uu++) st[j * F8_TP + uu * 8 + y] = r[uu];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS operations are in order)
+        {
+          const double2 *rp = reinterpret_cast<const double2 *>(st + j * F8_TP + u * 8);
+          const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+          p[0] = r0.x; p[1] = r0.y; p[2] = r1.x; p[3] = r1.y; p[4] = r2.x; p[5] = r2.y; p[6] = r3.x; p[7] = r3.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next plane's row transforms land after these reads)
+        double z[8];
+        dct8(p, z);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+          const double t = z[v] * s_cw[c][v * 8 + u];  // cDCTUVRatio and the weight in one factor
+          int o;
+          const bool ok = first_look_rounds(t, s_kw[c][v * 8 + u] * root, o);
+          so[zzr[v]] = (int16_t)o;
+          dmask |= ok ? 0u : (1u << v);
+        }
+        if (!valid) dmask = 0;
+      } else dmask = valid ? 0xffu : 0u;
+      // the coefficients in doubt, one after the other by the whole wave: lane k = product k of DCTInner_asm's sum (utils.pas:892-921)
+      for (unsigned long long m = __builtin_amdgcn_ballot_w64(dmask != 0); m; m &= m - 1) {
+        const int src = __builtin_ctzll(m);
+        const int sj = src >> 3, su = src & 7;
+        const float mine = s_px[wave][c][sj][lane];
+        for (unsigned vm = (unsigned)__builtin_amdgcn_readlane((int)dmask, src); vm; vm &= vm - 1) {
+          const int coef = __builtin_ctz(vm) * 8 + su;
+          const float e = __fmul_rn(mine, lut[coef * 64 + lane]);
+          const float s4 = __fadd_rn(e, __shfl_xor(e, 4));
+          double d = (double)s4;
+          d = __dadd_rn(d, __shfl_xor(d, 8));
+          d = __dadd_rn(d, __shfl_xor(d, 2));
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) { acc0 = __dadd_rn(acc0, __shfl(d, 16 * q)); acc1 = __dadd_rn(acc1, __shfl(d, 16 * q + 1)); }
+          const double zex = __dadd_rn(acc0, acc1);
+          const double t = weighted ? __dmul_rn(zex, weights[c * 64 + coef]) : zex;
+          // Round(): half to even (3126), then the store into a SmallInt (the low 16 bits)
+          if (lane == src) so[sj * 64 + s_zz[coef]] = fabs(t) < 2.0e9 ? (int16_t)__double2int_rn(t) : (int16_t)__double2ll_rn(t);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (colmm) {  // output column `lane` of this plane over the run's tiles
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++)
+          if (g * 8 + jj < n) { const int v = so[jj * 64 + lane]; mmn[c] = min(mmn[c], v); mmx[c] = max(mmx[c], v); }
+      }
+      if (valid) *reinterpret_cast<uint4 *>(out + t_out * 192 + c * 64 + u * 8) = *reinterpret_cast<const uint4 *>(so + j * 64 + u * 8);  // lane = (tile, 16-byte piece)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next plane's coefficients land after these reads)
+    }
+  }
+  if (colmm) {  // the search's digit plan wants the columns' ranges: one atomic pair per column and workgroup
+    int *s_mm = reinterpret_cast<int *>(&s_px[0][0][0][0]);  // [4][384]
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) { s_mm[wave * 384 + c * 64 + lane] = mmn[c]; s_mm[wave * 384 + 192 + c * 64 + lane] = mmx[c]; }
+    __syncthreads();
+    for (int i = tid; i < 192; i += 256) {
+      const int a = min(min(s_mm[i], s_mm[384 + i]), min(s_mm[768 + i], s_mm[1152 + i]));
+      const int b = max(max(s_mm[192 + i], s_mm[384 + 192 + i]), max(s_mm[768 + 192 + i], s_mm[1152 + 192 + i]));
+      if (a != INT_MAX) { atomicMin(&colmm[i], a); atomicMax(&colmm[192 + i], b); }
+    }
+  }
+}
+
+// k_features_tiles8 where it applies (RGB tiles, the plain DCT's cosines); TM_FEATURES_BY_TILE=1: always the tile-at-a-time kernel (tests, A/B)
+static bool features_tiles8(int mode, int64_t n, const void *tiles, const void *rows, const void *mirror_flags, int use_lab, void *out, void *colmm, const DeviceTables *tab,
+                            hipStream_t stream) {
+  if (mode_special(mode) || knobs().features_by_tile) return false;
+  const int64_t groups = (n + 7) / 8;
+  hipLaunchKernelGGL(k_features_tiles8, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((groups + 3) / 4, 256 * 6))), dim3(256), 0, stream, (const uint32_t *)tiles,
+                     (const int32_t *)rows, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab, tab->dct_lut_f32[0], tab->weights, tab->snake, tab->srgb_lut,
+                     (int16_t *)out, (int *)colmm, knobs().features_plain ? 1 : 0);
+  return true;
+}
+
 int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, int mode, int use_lab, void *out,
                         hipStream_t stream) {
   const DeviceTables *tab;
@@ -497,6 +668,7 @@ int launch_features_rgb(const void *tiles, int64_t n, const void *mirror_flags, 
   TM_CHECK(mode != TM_PVS_WAVELETS, TM_E_UNSUPPORTED, "wavelet features on int16 vectors are unimplemented in the reference too (tilingencoder.pas:3111)");
   TM_CHECK(mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   if (n <= 0) return TM_OK;
+  if (features_tiles8(mode, n, tiles, nullptr, mirror_flags, use_lab, out, nullptr, tab, stream)) { TM_HIP(hipGetLastError()); return TM_OK; }
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      nullptr, nullptr, 0, (const uint8_t *)mirror_flags, n, mode_weighted(mode) ? 1 : 0, use_lab,
                      tab->dct_lut_f32[mode_special(mode)], tab->weights, tab->snake, tab->srgb_lut, (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(mode)], knobs().features_plain ? 1 : 0);
@@ -510,6 +682,7 @@ int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int
   TM_TRY(get_tables(&tab));
   TM_CHECK(mode != TM_PVS_WAVELETS && mode >= 0 && mode <= 4, TM_E_INVAL, "bad TPsyVisMode %d", mode);
   if (n <= 0) return TM_OK;
+  if (features_tiles8(mode, n, tiles, rows, nullptr, use_lab, out, colmm, tab, stream)) { TM_HIP(hipGetLastError()); return TM_OK; }
   const int grid = grid_for(n, 4);
   hipLaunchKernelGGL(k_features_i16<0>, dim3(grid), dim3(256), 0, stream, (const uint32_t *)tiles, nullptr,
                      (const int32_t *)rows, nullptr, 0, (const uint8_t *)nullptr, n, mode_weighted(mode) ? 1 : 0, use_lab,
