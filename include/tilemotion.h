@@ -44,6 +44,9 @@
  *                           for all of them (tests compare the two)
  *   TM_FEATURES_BY_TILE     the int16 features of RGB tiles by the tile-at-a-time kernel (k_features_i16<0>) instead of eight tiles a wave
  *                           (k_features_tiles8; tests compare the two)
+ *   TM_MOTION_PACK_SEPARATE the encoder's motion search as three launches per frame (int16 window features, their packing, the search) instead of
+ *                           window features made in the search's layout at once (A/B runs, tests)
+ *   TM_MOTION_FORCE_FLAG    treat every frame as beyond the matrix search's exact range: the fallback (int16 windows + VALU search) runs (tests)
  *   TM_KM_RESIDENT_FAIL     the resident launch of the tile k-means is treated as if its barrier had given up: the clustering is repeated from its
  *                           seeds through the launches (tests: the fallback's result must be the same)
  *   TM_WINDOW_DCTS_BY_TILE  the sliding-window features of motion prediction a window at a time (k_features_i16<2>) instead of by strips that share

@@ -485,6 +485,28 @@ def test_sharded_reduce_moves_only_what_can_survive(monkeypatch, mode):
         assert nbytes[0] < 0.5 * distinct * 264 * 1  # far below one copy of every distinct tile (gathering them all moves world x that)
 
 
+def test_motion_search_forms_agree(monkeypatch):
+    """the encoder's motion search -- window features made in the matrix search's layout at once (k_window_dcts<true>) -- against the two-pass form
+    (int16 window features, k_mo_pack_win; TM_MOTION_PACK_SEPARATE=1) and against the fallback of a frame beyond the matrix form's exact range
+    (int16 windows + the VALU search, TM_MOTION_FORCE_FLAG=1), on frames whose window rows end inside a block of 32 and whose last strip is ragged"""
+    from tiler_amd import synth
+    frames = synth.video(5, 232, 144, cut=3, noise=40)
+    got = {}
+    for env in (None, "TM_MOTION_PACK_SEPARATE", "TM_MOTION_FORCE_FLAG"):
+        for k in ("TM_MOTION_PACK_SEPARATE", "TM_MOTION_FORCE_FLAG"):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        enc = _run_encoder(frames, PaletteCount=2, ShotTransMinSecondsPerKF=0.1, MotionPredictRadius=32, FrameTilingExtendedPaletteUsage=False, GlobalTilingTileCount=900)
+        maps = [enc.TileMap(f) for f in range(5)]
+        got[env] = [np.concatenate([np.asarray(m[k]).astype(np.int64).ravel() for m in maps]) for k in ("TileIdx", "PalIdx", "Flags", "PredictedX", "PredictedY")] + \
+                   [np.concatenate([np.asarray(m["PSNR"]).view(np.uint32).astype(np.int64).ravel() for m in maps])]
+    assert sum(int(((m >> 2) & 1).sum()) for m in [got[None][2]]) > 0  # some items are motion predicted
+    for env in ("TM_MOTION_PACK_SEPARATE", "TM_MOTION_FORCE_FLAG"):
+        for a, b in zip(got[None], got[env]):
+            assert np.array_equal(a, b), env
+
+
 @pytest.mark.parametrize("radius", [0, 8])
 def test_y4m_and_png_export_show_what_the_player_shows(oracle, tmp_path, radius):
     """GenerateY4M / GeneratePNGs (tilingencoder.pas:2126-2199, 2075-2124): the rendered output frames must be the pictures the reference's

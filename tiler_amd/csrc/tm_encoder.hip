@@ -664,11 +664,10 @@ static int step_predict_motion(tm_encoder *e) {
     const int src = f >= 1 ? f - 1 : (e->nframes > 1 ? 1 : -1);
     if (src >= 0) TM_TRY(launch_tiles_to_screen(e->ftiles.as<uint8_t>() + (int64_t)src * per * 256, e->fflags.as<uint8_t>() + (int64_t)src * per, e->tm_w, e->tm_h, screen.p, e->stream));
     else TM_HIP(hipMemsetAsync(screen.p, 0, (size_t)sw * sh * 4, e->stream));  // a single frame is searched in a black buffer
-    TM_TRY(launch_window_dcts(screen.p, sw, sh, win.p, e->stream));
     const int64_t off = (int64_t)f * per;
     TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, per, e->fflags.as<uint8_t>() + off, TM_PVS_WEIGHTED_DCT, 0, cur.p, e->stream));
-    TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, e->pm_err.as<uint32_t>() + off,
-                                e->tm_px.as<int8_t>() + off, e->tm_py.as<int8_t>() + off, e->stream));
+    TM_TRY(launch_motion_search_fb(cur.p, e->tm_w, e->tm_h, screen.p, win.p, e->s.MotionPredictRadius, e->pm_err.as<uint32_t>() + off,
+                                   e->tm_px.as<int8_t>() + off, e->tm_py.as<int8_t>() + off, e->stream));
     if ((f & 15) == 15) progress(e, TM_STEP_PREDICT_MOTION, f, e->nframes);
   }
   if (e->dist()) {  // owner holds the value, everyone else 0
@@ -1229,10 +1228,9 @@ static int step_reconstruct(tm_encoder *e) {
       const int64_t off = (int64_t)f * per;
       const bool search = !is_kf[(size_t)f];  // (Index <> PKeyFrame.StartFrame) and (ARadius >= 0), 1496
       if (search) {
-        TM_TRY(launch_window_dcts(fb[cb].p, sw, sh, win.p, e->stream));
         TM_TRY(launch_features_rgb(e->ftiles.as<uint8_t>() + off * 256, per, e->fflags.as<uint8_t>() + off, TM_PVS_WEIGHTED_DCT, 0, cur.p, e->stream));
-        TM_TRY(launch_motion_search(cur.p, e->tm_w, e->tm_h, win.p, e->s.MotionPredictRadius, mp.p, e->tm_px.as<int8_t>() + off,
-                                    e->tm_py.as<int8_t>() + off, e->stream));
+        TM_TRY(launch_motion_search_fb(cur.p, e->tm_w, e->tm_h, fb[cb].p, win.p, e->s.MotionPredictRadius, mp.p, e->tm_px.as<int8_t>() + off,
+                                       e->tm_py.as<int8_t>() + off, e->stream));
       }
       TM_TRY(launch_recon_decide(e->tm_w, (int)per, epu ? 1 : 0, search ? mp.p : nullptr, e->fflags.as<uint8_t>() + off, e->gpal_idx.p, e->gpal_px.p,
                                  e->palettes_dev.p, e->s.PaletteSize, fb[cb].p, fb[cb ^ 1].p, e->tm_tile.as<int32_t>() + off,

@@ -740,8 +740,36 @@ int launch_features_table(const void *pal_px, int64_t ntiles, const void *palett
 // serves, the bound on |z_ref - z_fast| has nine decimal orders of room for it) and the row's sum of squares, (3) the windows' sums of
 // squares, (4) a wave per window, lane = coefficient (u, v): eight multiply-adds down the column, weight, slack, Round.
 constexpr int WD_RY = 8, WD_CX = 32, WD_PW = WD_CX + 8;  // window rows and columns of a strip; pitch of a plane row (WD_CX + 7 pixels)
+// PACK: the coefficients leave in the motion search's matrix layout (tm_internal.h: launch_window_dcts_packed) instead of as int16 rows.  A strip's
+// 32 columns are one block of that layout; lane (window j, piece u) holds block b = 8 c + u of the reference's 24 blocks of eight coefficients
+// (CompareEuclideanDCTPtr_asm, utils.pas:559-725: two halves of twelve) and knows where its digits go: plain blocks (0-4, 7-11 of a half) to matrix
+// block 10 half + (0..9), block 6 joined by block 5 (its lane neighbour) to matrix block 20 + half as b5 + b6, block 5's lane fills the padding
+// (matrix blocks 22 / 23) with zeros; block 7 of the first half is stored raw as well; the squares of what went into the matrix are summed per window
+// over the three planes.  Low digit = the int16's low byte, signed; high digit = its high byte + the low byte's top bit.
+typedef short wd_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short wd_u16x2 __attribute__((ext_vector_type(2)));
+template <bool PACK>
 __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict__ fb, int w, int h, const float *__restrict__ lut, const double *__restrict__ weights,
-                                                     const uint8_t *__restrict__ snake, const double *__restrict__ cosd, int16_t *__restrict__ out, int plain) {
+                                                     const uint8_t *__restrict__ snake, const double *__restrict__ cosd, int16_t *__restrict__ out, int plain,
+                                                     const int *__restrict__ only_if, uint8_t *__restrict__ packed, const int16_t *__restrict__ cur, int ntiles,
+                                                     int *__restrict__ flag) {
+  if (only_if && !*only_if) return;  // (the fallback's launch: the matrix search took this frame)
+  __shared__ uint32_t s_nrm[PACK ? WD_RY : 1][WD_CX];  // PACK: the windows' sums of squares of what the matrix holds, over the planes
+  bool bad = false;
+  if constexpr (PACK) {  // the tile side's range check (its digits are made inside the search kernel)
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)ntiles * 24; i += (int64_t)gridDim.x * 256) {
+      const int blk = (int)(i % 24) % 12;
+      if (blk == 5) continue;  // never enters on the tile side
+      const int lim = blk == 6 ? MM_LIMIT6 : MM_LIMIT;
+      const uint4 v = reinterpret_cast<const uint4 *>(cur)[i];
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int lo = (int16_t)(wv[k] & 0xffff), hi = (int16_t)(wv[k] >> 16);
+        bad |= lo > lim || lo < -lim || hi > lim || hi < -lim;
+      }
+    }
+  }
   __shared__ float s_pl[3][WD_RY + 7][WD_PW];                                     // the strip's planes (Singles, as ConvertToCpnPixels leaves them)
   __shared__ __attribute__((aligned(16))) double s_r[WD_RY + 7][WD_CX][8];         // one plane's row transforms [row][horizontal position][u]
   __shared__ float s_rs[WD_RY + 7][WD_CX];                                          // ... and the rows' sums of squares
@@ -819,6 +847,12 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
       int zzr[8];
 #pragma unroll
       for (int v = 0; v < 8; v++) { cwr[v] = s_cw[c][v * 8 + (lane & 7)]; kwr[v] = s_kw[c][v * 8 + (lane & 7)]; zzr[v] = (lane >> 3) * 64 + s_zz[v * 8 + (lane & 7)]; }  // (zzr: the place in the wave's run)
+      // PACK: this lane's block of eight coefficients in this plane, where it goes, its range (see the kernel's head)
+      const int pk_b = c * 8 + (lane & 7), pk_hf = pk_b >= 12 ? 1 : 0, pk_bi = pk_b - pk_hf * 12;
+      const int pk_mb = pk_bi < 5 ? pk_hf * 10 + pk_bi : pk_bi == 5 ? 22 + pk_hf : pk_bi == 6 ? 20 + pk_hf : pk_hf * 10 + pk_bi - 2;
+      const uint32_t pk_lim = ((pk_bi == 5 || pk_bi == 6) ? MM_LIMIT6 : MM_LIMIT) * 0x00010001u;
+      const uint32_t keep_own = pk_bi == 5 ? 0u : 0xffffffffu, keep_left = pk_bi == 6 ? 0xffffffffu : 0u;
+      const unsigned piece0 = (unsigned)(((pk_mb >> 2) * 64 + ((pk_mb >> 1) & 1) * 32 + (lane >> 3)) * 16 + (pk_mb & 1) * 8);
       for (int gi = wave; gi < WD_RY * (WD_CX / 8); gi += 4) {
         const int wy = gi / (WD_CX / 8), wx0 = (gi - wy * (WD_CX / 8)) * 8;
         if (y0 + wy >= wh || x0 + wx0 >= ww) continue;  // (uniform in the wave)
@@ -871,28 +905,76 @@ __global__ __launch_bounds__(256) void k_window_dcts(const uint32_t *__restrict_
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS operations are in order: its reads below see its writes above)
-        if (x0 + wx < ww) {  // lane = (window j, 16-byte piece u) of the plane's 128 bytes
-          const int64_t t_out = (int64_t)(y0 + wy) * ww + x0 + wx;
-          *reinterpret_cast<uint4 *>(out + t_out * 192 + c * 64 + u * 8) = *reinterpret_cast<const uint4 *>(so + j * 64 + u * 8);
+        if constexpr (!PACK) {
+          if (x0 + wx < ww) {  // lane = (window j, 16-byte piece u) of the plane's 128 bytes
+            const int64_t t_out = (int64_t)(y0 + wy) * ww + x0 + wx;
+            *reinterpret_cast<uint4 *>(out + t_out * 192 + c * 64 + u * 8) = *reinterpret_cast<const uint4 *>(so + j * 64 + u * 8);
+          }
+        } else {
+          const bool live = x0 + wx < ww;  // (a window position past the row's end is all zeros, as k_mo_pack_win leaves it)
+          const uint4 raw = live ? *reinterpret_cast<const uint4 *>(so + j * 64 + u * 8) : make_uint4(0, 0, 0, 0);
+          uint32_t x[4] = {raw.x, raw.y, raw.z, raw.w};
+          // range: |v| <= lim  <=>  (uint16)(v + lim) <= 2 lim
+          wd_u16x2 rg = __builtin_bit_cast(wd_u16x2, x[0]) + __builtin_bit_cast(wd_u16x2, pk_lim);
+#pragma unroll
+          for (int k = 1; k < 4; k++) rg = __builtin_elementwise_max(rg, __builtin_bit_cast(wd_u16x2, x[k]) + __builtin_bit_cast(wd_u16x2, pk_lim));
+          bad |= __builtin_bit_cast(uint32_t, __builtin_elementwise_max(rg, __builtin_bit_cast(wd_u16x2, 2u * pk_lim))) != 2u * pk_lim;
+          uint32_t sq = 0, hd[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[k], 0x111, 0xf, 0xf, true);  // the lane before: block 5 beside block 6
+            const uint32_t v = __builtin_bit_cast(uint32_t, __builtin_bit_cast(wd_u16x2, x[k] & keep_own) + __builtin_bit_cast(wd_u16x2, left & keep_left));
+            sq = (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(wd_s16x2, v), __builtin_bit_cast(wd_s16x2, v), (int)sq, false);
+            x[k] = v;
+            hd[k] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(wd_u16x2, v) + __builtin_bit_cast(wd_u16x2, 0x00800080u));  // high digit = high byte of v + 128
+          }
+          uint8_t *obase = packed + ((int64_t)(y0 + wy) * nsx + sx) * MM_BLK_BYTES;  // (uniform in the wave)
+          const unsigned piece = piece0 + (unsigned)wx0 * 16u;
+          *reinterpret_cast<uint2 *>(obase + piece) = make_uint2(__builtin_amdgcn_perm(x[1], x[0], 0x06040200u), __builtin_amdgcn_perm(x[3], x[2], 0x06040200u));
+          *reinterpret_cast<uint2 *>(obase + MM_CH * 1024 + piece) = make_uint2(__builtin_amdgcn_perm(hd[1], hd[0], 0x07050301u), __builtin_amdgcn_perm(hd[3], hd[2], 0x07050301u));
+          if (pk_b == 7) *reinterpret_cast<uint4 *>(obase + MM_QUIRK + wx * 16) = raw;  // block 7 of the first half, raw: its pair sums are re-squared on the VALU
+          sq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sq, 0xB1, 0xf, 0xf, true);   // over the window's eight lanes
+          sq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sq, 0x4E, 0xf, 0xf, true);
+          sq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sq, 0x141, 0xf, 0xf, true);
+          if (u == 0) {  // (the same wave has this run in every plane)
+            const uint32_t tot = (c == 0 ? 0u : s_nrm[wy][wx]) + sq;
+            if (c < 2) s_nrm[wy][wx] = tot;
+            else reinterpret_cast<uint32_t *>(obase + MM_NORM)[wx] = tot;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next run's coefficients land after these reads)
       }
     }
   }
+  if constexpr (PACK) { if (bad) atomicOr(flag, 1); }
 }
 
-int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream) {
+int launch_window_dcts_packed(const void *fb, int w, int h, const void *cur, int ntiles, void *packed, int *flag, hipStream_t stream) {
+  const DeviceTables *tab;
+  TM_TRY(get_tables(&tab));
+  TM_CHECK(w >= 8 && h >= 8, TM_E_INVAL, "frame buffer %dx%d smaller than a tile", w, h);
+  const int strips = ((w - 7 + WD_CX - 1) / WD_CX) * ((h - 7 + WD_RY - 1) / WD_RY);
+  hipLaunchKernelGGL(k_window_dcts<true>, dim3(std::min(strips, 256 * 4)), dim3(256), 0, stream, (const uint32_t *)fb, w, h, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)],
+                     tab->weights, tab->snake, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], (int16_t *)nullptr, knobs().features_plain ? 1 : 0, (const int *)nullptr,
+                     (uint8_t *)packed, (const int16_t *)cur, ntiles, flag);
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream, const int *only_if) {
   const DeviceTables *tab;
   TM_TRY(get_tables(&tab));
   TM_CHECK(w >= 8 && h >= 8, TM_E_INVAL, "frame buffer %dx%d smaller than a tile", w, h);
   const int64_t n = (int64_t)(w - 7) * (h - 7);
   if (!knobs().window_dcts_by_tile) {
     const int strips = ((w - 7 + WD_CX - 1) / WD_CX) * ((h - 7 + WD_RY - 1) / WD_RY);
-    hipLaunchKernelGGL(k_window_dcts, dim3(std::min(strips, 256 * 4)), dim3(256), 0, stream, (const uint32_t *)fb, w, h, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)],
-                       tab->weights, tab->snake, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], (int16_t *)out, knobs().features_plain ? 1 : 0);
+    hipLaunchKernelGGL(k_window_dcts<false>, dim3(std::min(strips, 256 * 4)), dim3(256), 0, stream, (const uint32_t *)fb, w, h, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)],
+                       tab->weights, tab->snake, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], (int16_t *)out, knobs().features_plain ? 1 : 0, only_if, (uint8_t *)nullptr,
+                       (const int16_t *)nullptr, 0, (int *)nullptr);
     TM_HIP(hipGetLastError());
     return TM_OK;
   }
+  TM_CHECK(only_if == nullptr, TM_E_INVAL, "the window-at-a-time kernel has no conditional form");  // (launch_motion_search_fb takes the two-pass form under TM_WINDOW_DCTS_BY_TILE)
   hipLaunchKernelGGL(k_features_i16<2>, dim3(grid_for(n, 4)), dim3(256), 0, stream, (const uint32_t *)fb, nullptr, nullptr, nullptr, w,
                      nullptr, n, 1, 0, tab->dct_lut_f32[mode_special(TM_PVS_WEIGHTED_DCT)], tab->weights, tab->snake, tab->srgb_lut,
                      (int16_t *)out, (int *)nullptr, tab->dct_cos_f64[mode_special(TM_PVS_WEIGHTED_DCT)], knobs().features_plain ? 1 : 0);

@@ -19,7 +19,17 @@ int launch_features_rgb_rows(const void *tiles, const void *rows, int64_t n, int
 int launch_features_pal(const void *pal_px, const void *pal_idx, int64_t n, const void *palettes, int pal_size, int mode, void *out,
                         hipStream_t stream);
 int launch_features_cluster(const void *tiles, int64_t n, int mode, void *out, hipStream_t stream);
-int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream);
+int launch_window_dcts(const void *fb, int w, int h, void *out, hipStream_t stream, const int *only_if = nullptr);
+// The windows' features straight into the matrix layout of the motion search (tm_motion.hip: what k_mo_pack_win makes of the int16 rows) -- the
+// int16 rows are then never written.  Per block of 32 consecutive window positions of a row: [12 chunks][64 lanes][16 B] digits (low digits of the
+// 160 plain coefficients + the 16 of b5 + b6, then the high digits), 32 norms, block 7 of the first half raw.  `flag` (device int, preset 0) is
+// raised when a coefficient of the windows or of the `ntiles` tiles `cur` (their int16 features) lies beyond the range in which the matrix form is exact.
+constexpr int MM_CH = 6;                                             // 32-wide chunks of the 160 plain coefficients + 16 of block 6 + 16 of padding
+constexpr int MM_DIG = 2 * MM_CH * 1024, MM_NORM = MM_DIG, MM_QUIRK = MM_DIG + 128;
+constexpr int MM_BLK_BYTES = MM_QUIRK + 32 * 16;                     // 12928
+constexpr int MM_LIMIT6 = 10922;                                     // |coefficient| bound of blocks 5 and 6 under which a6 - b5 - b6 cannot saturate
+constexpr int MM_LIMIT = 16383;                                      // |coefficient| bound under which no plain difference saturates
+int launch_window_dcts_packed(const void *fb, int w, int h, const void *cur, int ntiles, void *packed, int *flag, hipStream_t stream);
 // int16 features of the (tile, palette) pairs pairs[i] = tile << 32 | palette (the rows the extended-palette re-rank asks for)
 int launch_features_pairs(const void *pal_px, const void *pairs, int64_t n, const void *palettes, int pal_size, void *out, hipStream_t stream);
 int launch_features_table(const void *pal_px, int64_t ntiles, const void *palettes, int npal, int pal_size, void *out, hipStream_t stream);
@@ -65,6 +75,11 @@ int compact_kept(const void *keep, int64_t n, void *out_idx, void *pos, int64_t 
 // tm_motion.hip: motion prediction (tilingencoder.pas:1154-1282, 1496-1654) and Reduce's tile-count search (4014-4046)
 int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, int radius, void *best_err, void *px, void *py,
                          hipStream_t stream);
+// the encoder's form: window features of the frame buffer `fb` (tm_w * 8 x tm_h * 8) and the search in one go -- the windows are made in the
+// search's matrix layout at once (launch_window_dcts_packed); `win` ((tm_w*8-7) * (tm_h*8-7) * 384 B) is written only by the fallback (a frame
+// whose coefficients leave the matrix form's exact range, or TM_MOTION_VALU=1) and by TM_MOTION_PACK_SEPARATE=1 (the two-pass form, for A/B runs)
+int launch_motion_search_fb(const void *cur, int tm_w, int tm_h, const void *fb, void *win, int radius, void *best_err, void *px, void *py,
+                            hipStream_t stream);
 int launch_tiles_to_screen(const void *tiles, const void *flags, int tm_w, int tm_h, void *screen, hipStream_t stream);
 int launch_recon_decide(int tm_w, int per, int pal_from_map, const void *mp_err, const void *fflags, const void *gpal_idx, const void *gpal_px,
                         const void *palettes, int pal_size, const void *back, void *front, void *tm_tile, void *tm_pal, void *tm_err,

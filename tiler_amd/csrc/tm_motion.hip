@@ -167,12 +167,8 @@ __global__ __launch_bounds__(256) void k_motion_search(const int16_t *__restrict
 // A frame whose data could saturate raises a flag on the device: this kernel then leaves at once and k_motion_search runs instead.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-constexpr int MM_CH = 6;                                             // 32-wide chunks of the 160 plain coefficients + 16 of block 6 + 16 of padding
-constexpr int MM_DIG = 2 * MM_CH * 1024, MM_NORM = MM_DIG, MM_QUIRK = MM_DIG + 128;
-constexpr int MM_BLK_BYTES = MM_QUIRK + 32 * 16;                     // 12928
-constexpr int MM_LIMIT6 = 10922;                                     // |coefficient| bound of blocks 5 and 6 under which a6 - b5 - b6 cannot saturate
+// (MM_CH, MM_DIG, MM_NORM, MM_QUIRK, MM_BLK_BYTES, MM_LIMIT, MM_LIMIT6: tm_internal.h -- k_window_dcts<true> writes the same layout)
 constexpr int MM_TR = 4, MM_TC = 8;                                  // tiles of a workgroup: 4 rows x 8 columns
-constexpr int MM_LIMIT = 16383;                                      // |coefficient| bound under which no plain difference saturates
 
 __device__ __forceinline__ int mm_plain_col(int pb) {  // first coefficient of plain block pb (0..19): blocks 0-4, 7-11 of each half
   const int hf = pb / 10, bi = pb - hf * 10;
@@ -513,6 +509,33 @@ int launch_motion_search(const void *cur, int tm_w, int tm_h, const void *win, i
   const int gw = (tm_w + MM_TC - 1) / MM_TC, gh = (tm_h + MM_TR - 1) / MM_TR;
   hipLaunchKernelGGL(k_mo_search_mfma, dim3(8 * ((gw * gh + 7) / 8)), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, gw * gh, packed.as<uint8_t>(), nbx, radius - 1, flag.as<int>(),
                      (uint32_t *)best_err, (int8_t *)px, (int8_t *)py);
+  hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
+                     (uint32_t *)best_err, (int8_t *)px, (int8_t *)py, flag.as<int>());
+  TM_HIP(hipGetLastError());
+  return TM_OK;
+}
+
+int launch_motion_search_fb(const void *cur, int tm_w, int tm_h, const void *fb, void *win, int radius, void *best_err, void *px, void *py,
+                            hipStream_t stream) {
+  TM_CHECK(tm_w > 0 && tm_h > 0 && radius >= 1 && radius <= 128, TM_E_INVAL, "motion search: bad arguments");
+  const int sw = tm_w * 8, sh = tm_h * 8;
+  if (knobs().motion_valu || knobs().motion_pack_separate || knobs().window_dcts_by_tile) {
+    TM_TRY(launch_window_dcts(fb, sw, sh, win, stream));
+    return launch_motion_search(cur, tm_w, tm_h, win, radius, best_err, px, py, stream);
+  }
+  const int bw = (tm_w + MS_TB - 1) / MS_TB, bh = (tm_h + MS_TB - 1) / MS_TB;
+  const int ww = sw - 7, wh = sh - 7, nbx = (ww + 31) / 32;
+  DevBuf packed, flag;  // (released at return: the pool hands memory back out in stream order, and everything here is on `stream`)
+  TM_TRY(packed.alloc((size_t)wh * nbx * MM_BLK_BYTES));
+  TM_TRY(flag.alloc(sizeof(int)));
+  if (knobs().motion_force_flag) { const int one = 1; TM_HIP(hipMemcpyAsync(flag.p, &one, sizeof(int), hipMemcpyHostToDevice, stream)); TM_HIP(hipStreamSynchronize(stream)); }
+  else TM_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), stream));
+  TM_TRY(launch_window_dcts_packed(fb, sw, sh, cur, tm_w * tm_h, packed.p, flag.as<int>(), stream));
+  const int gw = (tm_w + MM_TC - 1) / MM_TC, gh = (tm_h + MM_TR - 1) / MM_TR;
+  hipLaunchKernelGGL(k_mo_search_mfma, dim3(8 * ((gw * gh + 7) / 8)), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, gw * gh, packed.as<uint8_t>(), nbx, radius - 1, flag.as<int>(),
+                     (uint32_t *)best_err, (int8_t *)px, (int8_t *)py);
+  // a frame beyond the matrix form's range (decided on the device): the int16 rows after all, and the VALU search -- both leave at once otherwise
+  TM_TRY(launch_window_dcts(fb, sw, sh, win, stream, flag.as<int>()));
   hipLaunchKernelGGL(k_motion_search, dim3(bw * bh), dim3(256), 0, stream, (const int16_t *)cur, tm_w, tm_h, (const int16_t *)win, radius - 1,
                      (uint32_t *)best_err, (int8_t *)px, (int8_t *)py, flag.as<int>());
   TM_HIP(hipGetLastError());
