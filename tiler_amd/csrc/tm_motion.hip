@@ -24,8 +24,10 @@ __device__ __forceinline__ uint32_t sat_sub2(uint32_t a, uint32_t b) {  // psubs
   const s16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b));
   return __builtin_bit_cast(uint32_t, r);
 }
-__device__ __forceinline__ uint32_t sq2(uint32_t d) {  // pmaddwd of a dword with itself, mod 2^32: v_dot2c_i32_i16
-  return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, d), 0, false);
+__device__ __forceinline__ uint32_t sq2(uint32_t d) {  // pmaddwd of a dword with itself, mod 2^32 (the three-operand form: no accumulator to zero first)
+  uint32_t r;
+  asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(d));
+  return r;
 }
 __device__ __forceinline__ uint32_t sq2acc(uint32_t d, uint32_t acc) {  // acc + pmaddwd(d, d): v_dot2c accumulates in place
   return (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, d), (int)acc, false);
@@ -266,14 +268,14 @@ __global__ __launch_bounds__(256) void k_mo_pack_win(const int16_t *__restrict__
   if (bad) atomicOr(flag, 1);
 }
 
-__global__ __launch_bounds__(256) void k_mo_search_mfma(const int16_t *__restrict__ cur, int tm_w, int tm_h, int ngroups, const uint8_t *__restrict__ packed, int nbx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mo_search_mfma(const int16_t *__restrict__ cur, int tm_w, int tm_h, int ngroups, const uint8_t *__restrict__ packed, int nbx,
                                                         int r, const int *__restrict__ flag, uint32_t *__restrict__ best_err,
                                                         int8_t *__restrict__ out_px, int8_t *__restrict__ out_py) {
   if (*flag) return;  // a coefficient beyond +-16383 somewhere in this frame: k_motion_search takes it
   __shared__ __attribute__((aligned(16))) uint32_t s_q[4][32][4];  // per wave: block 7 (first half) of the item's 32 windows
   __shared__ uint32_t s_err[8][32];
   __shared__ int s_pos[8][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, t = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, t = lane & 31;  // (wave: in a scalar register, and with it the item loop's arithmetic)
   const int gw = (tm_w + MM_TC - 1) / MM_TC;
   // workgroups are dealt to the XCDs round robin: workgroup b works on group (b % 8) * ceil(n / 8) + b / 8, so that the groups running
   // on one XCD are neighbours in the picture and find each other's window blocks in that XCD's L2 (placement is a matter of speed only)
@@ -325,7 +327,10 @@ __global__ __launch_bounds__(256) void k_mo_search_mfma(const int16_t *__restric
   const int ux0 = max(0, gx * MM_TC * 8 - r - 1), ux1 = min(sw - 8, lx + r);
   const int bx0 = ux0 >> 5, nbu = (ux1 >> 5) - bx0 + 1, nitems = (uy1 - uy0 + 1) * nbu;
   uint32_t best = 0xffffffffu;
-  int bpos = 0x7fffffff;
+  int bposa = 0x7ffffff0;  // the best candidate's raster position, less 4 * half
+  const unsigned wx0h = wx0 - 4u * (unsigned)half;  // (window of row q: wxa + 4 * half)
+  const int dxh = dx + 4 - 4 * half;
+  const uint32_t *sq_lane = &s_q[wave][4 * half][0];
   for (int it = wave; it < nitems; it += 4) {
     const int row = it / nbu, wy = uy0 + row, bx = bx0 + (it - row * nbu);
     const uint8_t *base = packed + ((int64_t)wy * nbx + bx) * MM_BLK_BYTES;
@@ -357,26 +362,30 @@ __global__ __launch_bounds__(256) void k_mo_search_mfma(const int16_t *__restric
 #pragma unroll
     for (int c = 0; c < MM_CH; c++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[c], Bf[c], acc, 0, 0, 0);  // b_L . a_L
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // block 7 of the item's windows is in LDS (written by this wave's own lanes)
+    // The sixteen accumulator rows: row q is window m0 = (q & 3) + 8 (q >> 2) of the block for the lanes of the first half, m0 + 4 for the second.
+    // Everything about the window that does not depend on the lane is scalar (wave, item, q are); a lane sees its candidates in raster order
+    // (items go up the rows and along them, m0 goes up with q), so a tie never replaces what it holds: err < best alone decides.
     const bool rowin = (unsigned)wy - wy0 <= wyr;
+    const int posrow = wy * ww + bx * 32;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-      const int m = (q & 3) + 8 * (q >> 2) + 4 * half, wx = bx * 32 + m;
-      const bool in = rowin && (unsigned)wx - wx0 <= wxr;
-      if (!__builtin_amdgcn_ballot_w64(in)) continue;  // no tile of the group can use this window
-      const uint4 b7h1 = *reinterpret_cast<const uint4 *>(&s_q[wave][m][0]);
+      const int m0 = (q & 3) + 8 * (q >> 2), wxa = bx * 32 + m0;
+      if (wxa + 4 < ux0 || wxa > ux1) continue;  // neither window of the row is in reach of a tile of the group
+      const bool in = rowin && (unsigned)wxa - wx0h <= wxr;
+      const uint4 b7h1 = *reinterpret_cast<const uint4 *>(&sq_lane[m0 * 4]);
       uint32_t e = na + nbr[q] - 2u * (uint32_t)acc[q];  // the 20 plain blocks and both block 6 terms
       const uint32_t p0 = sq2(sat_sub2(a7h1.x, b7h1.x)), p1 = sq2(sat_sub2(a7h1.y, b7h1.y)), p2 = sq2(sat_sub2(a7h1.z, b7h1.z)),
                      p3 = sq2(sat_sub2(a7h1.w, b7h1.w));
       e = sq2acc(p3, sq2acc(p2, sq2acc(p1, sq2acc(p0, e))));  // the pair sums re-squared as int16 pairs (their plain sum is in the matrix part)
       uint32_t err;  // + manhattan penalty (1236)
-      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(wx), "v"(dx), "v"(e));
-      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "v"(wy), "v"(dy), "v"(err));
-      const int pos = wy * ww + wx;
-      const bool take = in && (err < best || (err == best && pos < bpos));
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "s"(wxa + 4), "v"(dxh), "v"(e));  // |wx - dx|, both sides + 4 - 4 * half (unsigned operands)
+      asm("v_sad_u32 %0, %1, %2, %3" : "=v"(err) : "s"(wy), "v"(dy), "v"(err));
+      const bool take = in && err < best;
       best = take ? err : best;
-      bpos = take ? pos : bpos;
+      bposa = take ? posrow + m0 : bposa;
     }
   }
+  const int bpos = bposa + 4 * half;
   s_err[wave * 2 + half][t] = best;
   s_pos[wave * 2 + half][t] = bpos;
   __syncthreads();
