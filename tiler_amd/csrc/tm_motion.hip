@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int it = wave; it < nitems; it += 4) {
     const int row = it / nbu, wy = uy0 + row, bx = bx0 + (it - row * nbu);
     const uint8_t *base = packed + ((int64_t)wy * nbx + bx) * MM_BLK_BYTES;
+    const uint4 quirk = *reinterpret_cast<const uint4 *>(base + MM_QUIRK + (lane & 31) * 16);  // (first: its way through LDS then does not wait for the operands)
     v4i Af[2 * MM_CH];
 #pragma unroll
     for (int kc = 0; kc < 2 * MM_CH; kc++) Af[kc] = *reinterpret_cast<const v4i *>(base + (kc * 64 + lane) * 16);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       nbr[q4 * 4] = (uint32_t)x[0]; nbr[q4 * 4 + 1] = (uint32_t)x[1]; nbr[q4 * 4 + 2] = (uint32_t)x[2]; nbr[q4 * 4 + 3] = (uint32_t)x[3];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the previous item's block 7 are over
-    if (lane < 32) reinterpret_cast<uint4 *>(&s_q[wave][0][0])[lane] = *reinterpret_cast<const uint4 *>(base + MM_QUIRK + lane * 16);
+    if (lane < 32) reinterpret_cast<uint4 *>(&s_q[wave][0][0])[lane] = quirk;
     v16i acc;
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] = 0;
