@@ -47,6 +47,8 @@
  *   TM_MOTION_PACK_SEPARATE the encoder's motion search as three launches per frame (int16 window features, their packing, the search) instead of
  *                           window features made in the search's layout at once (A/B runs, tests)
  *   TM_MOTION_FORCE_FLAG    treat every frame as beyond the matrix search's exact range: the fallback (int16 windows + VALU search) runs (tests)
+ *   TM_TOPK_ESTIMATE        0: the k-nearest search never takes its first thresholds from a sample of the database (the curve window's bound instead);
+ *                           1: whenever the database has rows enough for a sample (default: many queries against >= 16 384 rows)
  *   TM_KM_RESIDENT_FAIL     the resident launch of the tile k-means is treated as if its barrier had given up: the clustering is repeated from its
  *                           seeds through the launches (tests: the fallback's result must be the same)
  *   TM_WINDOW_DCTS_BY_TILE  the sliding-window features of motion prediction a window at a time (k_features_i16<2>) instead of by strips that share

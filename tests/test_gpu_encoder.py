@@ -180,12 +180,16 @@ def test_save_gtm_matches_host_writer_on_oracle_tables(oracle, tmp_path, radius)
     enc.close()
 
 
-def test_extended_palette_usage_scan_matches_brute_force():
+@pytest.mark.parametrize("sampled", [False, True])
+def test_extended_palette_usage_scan_matches_brute_force(monkeypatch, sampled):
     """a clip large enough for duplicate-heavy databases, candidate overflows and re-scans: the pruned MFMA k-nearest scan with
-    duplicate expansion gives the same encoder output as the VALU brute force over all rows (TM_TOPK_BRUTE=1)"""
+    duplicate expansion gives the same encoder output as the VALU brute force over all rows (TM_TOPK_BRUTE=1); sampled: the scan's first
+    thresholds from a sample of the database (TM_TOPK_ESTIMATE=1: what a full-size clip gets by itself), with member lists on the full database"""
     import os
     from tiler_amd import synth
     frames = synth.video(12, 320, 176, cut=6)
+    if sampled:
+        monkeypatch.setenv("TM_TOPK_ESTIMATE", "1")
     outs = []
     for brute in (False, True):
         if brute:

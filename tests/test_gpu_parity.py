@@ -955,8 +955,19 @@ def test_motion_search_matrix_path(oracle, monkeypatch, tm_w, tm_h, radius, amp)
 
 
 # ---- (f)#3 FrameTilingExtendedPaletteUsage -------------------------------------------------------------------------
-@pytest.mark.parametrize("nt,k", [(700, 64), (40, 64), (300, 5)])
-def test_knn_topk(oracle, nt, k):
+@pytest.fixture(params=["by-size", "sampled", "bound"])
+def topk_thresholds(request, monkeypatch):
+    """where the k-nearest search's first thresholds come from: the shipped rule (a sample of the database for many queries against a database
+    of some size, tm_knn.hip: knn_index_search_topk), the sample whenever the database has rows enough for one (TM_TOPK_ESTIMATE=1: queries that
+    find fewer than k rows within their estimate are searched again), never (=0: the curve window's bound)"""
+    monkeypatch.delenv("TM_TOPK_ESTIMATE", raising=False)
+    if request.param != "by-size":
+        monkeypatch.setenv("TM_TOPK_ESTIMATE", "1" if request.param == "sampled" else "0")
+    return request.param
+
+
+@pytest.mark.parametrize("nt,k", [(700, 64), (40, 64), (300, 5), (3000, 64)])
+def test_knn_topk(oracle, nt, k, topk_thresholds):
     from tiler_amd import stages
     rng = np.random.default_rng(nt + k)
     db = _rand_features(rng, nt, 300)
@@ -970,7 +981,7 @@ def test_knn_topk(oracle, nt, k):
     assert np.array_equal(_host_u32(err), eerr)
 
 
-def test_knn_topk_on_norm_shells(oracle):
+def test_knn_topk_on_norm_shells(oracle, topk_thresholds):
     """k nearest rows where the radial box dimension is most selective (rows on thin norm shells, queries between them)"""
     from tiler_amd import stages
     rng = np.random.default_rng(64)
@@ -1034,7 +1045,7 @@ def test_epu_rerank_without_the_table(tiles_flags, oracle, monkeypatch):
     assert np.array_equal(_host_u32(e), ee)
 
 
-def test_knn_topk_matches_brute_force_at_scale():
+def test_knn_topk_matches_brute_force_at_scale(topk_thresholds):
     """the pruned MFMA collection scan against the exact VALU brute force (TM_TOPK_BRUTE=1) on clustered data with many
     duplicates and near-duplicates: overflow re-scans and the (distance, index) order at the 64th place get exercised"""
     import os

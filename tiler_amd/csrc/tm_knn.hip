@@ -702,6 +702,15 @@ static int run_pack(tm_knn_index_impl *ix, const void *feat, int64_t n, int nega
 //  3. k_topk_select: exact SSD (d'' + the query norm's parity bit), original row index, rank by (SSD, index), first k out.
 //     A query whose list overflowed lowers its tau to the k-th smallest of what it did store (still a valid bound) and is
 //     scanned again with the other overflowed queries.
+#ifndef TM_TOPK_EST_STRIDE
+#define TM_TOPK_EST_STRIDE 16  // the sample a large search's first thresholds come from: every 16th row ...
+#endif
+#ifndef TM_TOPK_EST_K
+#define TM_TOPK_EST_K 12       // ... and the distance of its 12th nearest: about 192 rows of the whole database lie within it, give or take 55
+#endif
+#ifndef TM_TOPK_STEP_SHIFT
+#define TM_TOPK_STEP_SHIFT 3  // a first pass's rungs (and a restart's) hang at tau >> this below the threshold
+#endif
 #ifndef TM_TOPK_WINDOW
 #define TM_TOPK_WINDOW 32
 #endif
@@ -799,7 +808,9 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
                                                     int *__restrict__ step /* in: the pass's rung spacing; out, overflowed queries: the next pass's */,
                                                     const uint32_t *__restrict__ out_map /* null: qperm */, int32_t *__restrict__ out_idx,
                                                     uint32_t *__restrict__ out_err, uint32_t *__restrict__ ovf_list, unsigned int *__restrict__ ovf_count,
-                                                    const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members, int nofilter) {
+                                                    const uint32_t *__restrict__ grp_off, const uint32_t *__restrict__ grp_members, int nofilter,
+                                                    uint32_t *__restrict__ unf_list /* non-null: the thresholds were ESTIMATES (topk_estimate) -- a query with fewer than k rows within its
+                                                    threshold goes on this list (count: ovf_count[1]) and is searched again from a bound that holds */) {
   extern __shared__ unsigned long long s_key[];  // [cap rounded up to a power of two]
   __shared__ uint32_t s_mult[64];
   const int64_t p = blockIdx.x;
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
       // ... unless the threshold ended on the ladder's LOWEST rung: then nothing says how far below it the k-th nearest lies, and a ladder
       // an eighth as wide would only crawl down by its own width per pass: eighths of the threshold again
       const bool lowest = (long long)tn <= (long long)t_in - 7ll * st;
-      step[p] = lowest ? max(1, tn >> 3) : max(1, st >> 3);
+      step[p] = lowest ? max(1, tn >> TM_TOPK_STEP_SHIFT) : max(1, st >> 3);
       ovf_list[atomicAdd(ovf_count, 1u)] = (uint32_t)p;
     }
     return;
@@ -852,6 +863,10 @@ __global__ __launch_bounds__(64) void k_topk_select(int64_t nq, const uint32_t *
       if (valid) s_key[n + __popcll(m & ((1ull << lane) - 1ull))] = key;
       n += __popcll(m);
     }
+  }
+  if (unf_list && n < k) {  // (uniform in the wave.  n counts DISTINCT rows: with member lists k rows may need fewer, the second search only costs time)
+    if (lane == 0) unf_list[atomicAdd(ovf_count + 1, 1u)] = (uint32_t)p;
+    return;
   }
   if (n > 1024) {
     // the same from LDS, for the long lists the last passes give their few queries (up to 8 192 rows at, or tied with, the k-th distance)
@@ -1321,7 +1336,7 @@ __global__ void k_topk_sorted_aux(const uint32_t *__restrict__ qperm, int64_t n,
     if (tau_by_row) tau_sorted[p] = tau_by_row[row];
     const int tau = tau_sorted[p];
     tau_in_sorted[p] = tau;  // (the scan overwrites tau_sorted with the thresholds it ends on)
-    step_sorted[p] = step_by_row ? step_by_row[row] : (tau > 0 ? tau >> 3 : 0);  // a first pass: rungs at eighths of the threshold
+    step_sorted[p] = step_by_row ? step_by_row[row] : (tau > 0 ? max(1, tau >> TM_TOPK_STEP_SHIFT) : 0);  // a first pass: rungs at this fraction of the threshold
     if (p < n) map_sorted[p] = rowmap ? rowmap[row] : row;
   }
 }
@@ -1345,6 +1360,22 @@ __global__ void k_topk_scatter(const int32_t *__restrict__ idx, const uint32_t *
   }
 }
 
+// every `stride`-th row of the database: the sample a large search takes its first thresholds from (knn_index_search_topk)
+__global__ void k_topk_sample_rows(const int16_t *__restrict__ db, int64_t nt, int stride, int64_t ns, int16_t *__restrict__ out) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < ns * 24; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / 24;
+    const int v = (int)(e - j * 24);
+    reinterpret_cast<uint4 *>(out)[e] = reinterpret_cast<const uint4 *>(db + min(j * stride, nt - 1) * 192)[v];
+  }
+}
+// the sample search's ke-th distance as the full search's first threshold (0xFFFFFFFF: the sample had fewer than ke rows for this query)
+__global__ void k_topk_tau_from_sample(const uint32_t *__restrict__ err, int64_t nq, int ke, int *__restrict__ tau) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t e = err[i * ke + ke - 1];
+    tau[i] = e < 0x7ffffffeu ? (int)e : 0x7ffffffe;
+  }
+}
+
 static int topk_pow2(int v) { int r = 64; while (r < v) r <<= 1; return r; }
 static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
 
@@ -1353,7 +1384,7 @@ static int gridn_k(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_
 struct TopkExpand { const uint32_t *grp_off = nullptr, *grp_members = nullptr; const void *full_db = nullptr; int64_t full_nt = 0; };
 
 static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, const int *tau_by_row, const int *step_by_row, const uint32_t *rowmap, int k,
-                     int32_t *out_idx, uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex) {
+                     int32_t *out_idx, uint32_t *out_err, int depth, hipStream_t stream, const TopkExpand &ex, bool estimated = false) {
   const auto t_start = std::chrono::steady_clock::now();
   TM_TRY(prepare_search(ix, feats, n, stream));
   const int64_t nqt = (n + 31) / 32, ntt = (ix->nt + 31) / 32, n_pad = ((nqt + 1) / 2) * 64;
@@ -1376,7 +1407,8 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)32 << 30; }
   const int64_t budget = std::max<int64_t>((int64_t)4 << 30, std::min<int64_t>((int64_t)TM_TOPK_BUDGET_GIB << 30, (int64_t)(free_b / 3)));
   const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? TM_TOPK_CAP_FIRST : depth < 3 ? TM_TOPK_CAP_LATER : 8192, budget / (n * 8)));
-  DevBuf tau, tau_in, step, map_sorted, cand, cand_cnt, ovf, counter;
+  DevBuf tau, tau_in, step, map_sorted, cand, cand_cnt, ovf, counter, unf;
+  if (estimated) TM_TRY(unf.alloc((size_t)n * 4));
   TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(tau_in.alloc((size_t)n_pad * 4)); TM_TRY(step.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));
   TM_TRY(cand.alloc((size_t)n * cap * 8)); TM_TRY(cand_cnt.alloc((size_t)n * 4));
   TM_TRY(ovf.alloc((size_t)n * 4)); TM_TRY(counter.alloc(16));
@@ -1456,14 +1488,15 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   hipLaunchKernelGGL(k_topk_select, dim3((unsigned)n), dim3(64), (size_t)topk_pow2(cap) * 8, stream, n, ix->qperm.as<uint32_t>(), ix->qpack.as<uint8_t>(),
                      knn_tile_bytes(ix->plan.hq, 0), ix->tperm.as<uint32_t>(), ix->nt, cand.as<uint2>(), cand_cnt.as<int>(), cap, k, tau.as<int>(), tau_in.as<int>(), step.as<int>(),
                      map_sorted.as<uint32_t>(), out_idx, out_err, ovf.as<uint32_t>(), counter.as<unsigned int>(), ex.grp_off, ex.grp_members,
-                     0);
+                     0, estimated ? unf.as<uint32_t>() : (uint32_t *)nullptr);
   TM_HIP(hipGetLastError());
-  unsigned int novf = 0;
+  unsigned int novf = 0, nunf = 0;
   int flag = 0;
   unsigned long long guard = 0;
   {
     HostRead hr_(stream);
     TM_TRY(hr_.get(&novf, counter.p, 4));
+    TM_TRY(hr_.get(&nunf, counter.as<uint8_t>() + 4, 4));
     TM_TRY(hr_.get(&flag, ix->err_flag.p, sizeof(int)));
     TM_TRY(hr_.get(&guard, ix->counters.as<uint8_t>() + 16 + 27 * 8, 8));
     TM_TRY(hr_.wait());
@@ -1471,15 +1504,28 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   TM_CHECK(guard == 0, TM_E_HIP, "knn: the collection scan met a corrupted tile list (guard word %llx)", guard);
   TM_CHECK(flag == 0, TM_E_UNSUPPORTED, "knn: feature range exceeds the exact two-digit int8 split (|v-c| >= 32640)");
   if (knobs().knn_debug)
-    fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries, cap %d, %u overflowed, %.1f ms\n", k, depth, (long long)n, cap, novf,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
-  if (novf == 0) return TM_OK;
+    fprintf(stderr, "[tm_knn] top-%d pass %d: %lld queries of %lld rows, cap %d, %u overflowed, %u fell short of their estimate, %.1f ms\n", k, depth, (long long)n,
+            (long long)ix->nt, cap, novf, nunf, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  if (novf == 0 && nunf == 0) return TM_OK;
+  // (both subsets are gathered before either is searched: a search re-sorts the index's query side)
+  DevBuf usub, usub_tau, usub_step, usub_map;
+  if (nunf > 0) {
+    TM_TRY(usub.alloc((size_t)nunf * 384)); TM_TRY(usub_tau.alloc((size_t)nunf * 4)); TM_TRY(usub_step.alloc((size_t)nunf * 4)); TM_TRY(usub_map.alloc((size_t)nunf * 4));
+    hipLaunchKernelGGL(k_topk_gather_sub, dim3(gridn_k((int64_t)nunf * 24)), dim3(256), 0, stream, feats, ix->qperm.as<uint32_t>(), unf.as<uint32_t>(),
+                       (int64_t)nunf, tau.as<int>(), step.as<int>(), map_sorted.as<uint32_t>(), usub.as<int16_t>(), usub_tau.as<int>(), usub_step.as<int>(), usub_map.as<uint32_t>());
+    TM_HIP(hipGetLastError());
+  }
   DevBuf sub, sub_tau, sub_step, sub_map;
-  TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_step.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
-  hipLaunchKernelGGL(k_topk_gather_sub, dim3(gridn_k((int64_t)novf * 24)), dim3(256), 0, stream, feats, ix->qperm.as<uint32_t>(), ovf.as<uint32_t>(),
-                     (int64_t)novf, tau.as<int>(), step.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_step.as<int>(), sub_map.as<uint32_t>());
-  TM_HIP(hipGetLastError());
-  cand.release();  // the recursion allocates its own
+  if (novf > 0) {
+    TM_TRY(sub.alloc((size_t)novf * 384)); TM_TRY(sub_tau.alloc((size_t)novf * 4)); TM_TRY(sub_step.alloc((size_t)novf * 4)); TM_TRY(sub_map.alloc((size_t)novf * 4));
+    hipLaunchKernelGGL(k_topk_gather_sub, dim3(gridn_k((int64_t)novf * 24)), dim3(256), 0, stream, feats, ix->qperm.as<uint32_t>(), ovf.as<uint32_t>(),
+                       (int64_t)novf, tau.as<int>(), step.as<int>(), map_sorted.as<uint32_t>(), sub.as<int16_t>(), sub_tau.as<int>(), sub_step.as<int>(), sub_map.as<uint32_t>());
+    TM_HIP(hipGetLastError());
+  }
+  cand.release();  // the recursions allocate their own
+  if (nunf > 0)  // from the curve window's bound (any k rows give one), as a search without estimates starts
+    TM_TRY(topk_pass(ix, usub.as<int16_t>(), nunf, nullptr, nullptr, usub_map.as<uint32_t>(), k, out_idx, out_err, depth + 1, stream, ex));
+  if (novf == 0) return TM_OK;
   // Every pass cuts the bracket its ladder spans to an eighth (or, from the lowest rung, the threshold itself): a dozen passes take any threshold
   // down to single units.  What still overflows then has more rows at exactly the k-th distance than a list holds: exact brute force for those.
   if (depth >= 12 || (depth >= 6 && (int64_t)novf * 10 > n * 9)) {
@@ -1505,6 +1551,33 @@ int knn_index_search_topk(tm_knn_index_impl *ix, const void *queries, int64_t nq
   if (ix->nt == 0) return TM_OK;
   TopkExpand ex;
   ex.grp_off = (const uint32_t *)grp_off; ex.grp_members = (const uint32_t *)grp_members; ex.full_db = full_db; ex.full_nt = full_nt;
+  // Many queries against a database of some size: the first thresholds come from a SAMPLE of the database.  The curve window's bound (the k-th
+  // smallest of 1 024 rows near the query on the curve) holds but is loose -- on the literal bench clip the 512-th nearest row is 5 % farther
+  // than the 64-th, a bound that is off by a factor two lets thousands of rows in, four queries in five overflowed their lists and took three
+  // more passes to bracket their k-th distance.  The ke-th nearest row among every S-th row of the database is an ESTIMATE of the (ke S)-th
+  // nearest row's distance whatever the distances' law is (the rows within it number ke S give or take S sqrt(ke)): no bound, so a query that
+  // finds fewer than k rows within it is searched again the old way (k_topk_select's list of those), but nearly all find between k and the
+  // list's capacity at once.  The sample's own search is this same function on a sixteenth of the rows (where the curve window is a third of
+  // the database and its bound is good).
+  const int est = knobs().topk_estimate;  // -1: by size, 0: never, 1: whenever the sample has ke rows
+  constexpr int S = TM_TOPK_EST_STRIDE, KE = TM_TOPK_EST_K;
+  const int64_t ns = (ix->nt + S - 1) / S;
+  if (est != 0 && k >= 32 && ns >= 4 * KE && (est == 1 || (ix->nt >= 16384 && nq >= 4 * ix->nt))) {
+    DevBuf srows, eidx, eerr, tau_est;
+    TM_TRY(srows.alloc((size_t)ns * 384)); TM_TRY(eidx.alloc((size_t)nq * KE * 4)); TM_TRY(eerr.alloc((size_t)nq * KE * 4)); TM_TRY(tau_est.alloc((size_t)nq * 4));
+    hipLaunchKernelGGL(k_topk_sample_rows, dim3(gridn_k(ns * 24)), dim3(256), 0, stream, ix->db, ix->nt, S, ns, srows.as<int16_t>());
+    TM_HIP(hipGetLastError());
+    tm_knn_index_impl *six = nullptr;
+    TM_TRY(knn_index_create(srows.p, ns, stream, &six));
+    const int rc = knn_index_search_topk(six, queries, nq, KE, eidx.p, eerr.p, stream, nullptr, nullptr, nullptr, 0);
+    if (rc == TM_OK) TM_HIP(hipStreamSynchronize(stream));  // (the sample index owns scratch the stream may still read)
+    knn_index_destroy(six);
+    if (rc != TM_OK) return rc;
+    hipLaunchKernelGGL(k_topk_tau_from_sample, dim3(gridn_k(nq)), dim3(256), 0, stream, eerr.as<uint32_t>(), nq, KE, tau_est.as<int>());
+    TM_HIP(hipGetLastError());
+    eidx.release(); srows.release();
+    return topk_pass(ix, (const int16_t *)queries, nq, tau_est.as<int>(), nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex, true);
+  }
   return topk_pass(ix, (const int16_t *)queries, nq, nullptr, nullptr, nullptr, k, (int32_t *)out_idx, (uint32_t *)out_err, 0, stream, ex);
 }
 
