@@ -1406,7 +1406,10 @@ static int topk_pass(tm_knn_index_impl *ix, const int16_t *feats, int64_t n, con
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)32 << 30; }
   const int64_t budget = std::max<int64_t>((int64_t)4 << 30, std::min<int64_t>((int64_t)TM_TOPK_BUDGET_GIB << 30, (int64_t)(free_b / 3)));
-  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? TM_TOPK_CAP_FIRST : depth < 3 ? TM_TOPK_CAP_LATER : 8192, budget / (n * 8)));
+#ifndef TM_TOPK_CAP_FIRST_SMALLK
+#define TM_TOPK_CAP_FIRST_SMALLK 512  // ... of a search for fewer than 32 rows (the sample search of knn_index_search_topk)
+#endif
+  const int cap = (int)std::max<int64_t>(2 * k, std::min<int64_t>(depth == 0 ? (k < 32 ? TM_TOPK_CAP_FIRST_SMALLK : TM_TOPK_CAP_FIRST) : depth < 3 ? TM_TOPK_CAP_LATER : 8192, budget / (n * 8)));
   DevBuf tau, tau_in, step, map_sorted, cand, cand_cnt, ovf, counter, unf;
   if (estimated) TM_TRY(unf.alloc((size_t)n * 4));
   TM_TRY(tau.alloc((size_t)n_pad * 4)); TM_TRY(tau_in.alloc((size_t)n_pad * 4)); TM_TRY(step.alloc((size_t)n_pad * 4)); TM_TRY(map_sorted.alloc((size_t)n * 4));

@@ -12,6 +12,6 @@ j = json.loads(open('gpurun_out/epu_%s.json' % sys.argv[1]).read().strip().split
 r = j["with_extended_palette_usage"]
 print(sys.argv[1], sys.argv[2] or "literal", "EPU only: %.0f fps, reconstruct %.1f ms" % (r["value"], r["stage_ms"]["reconstruct"]), "| with motion: reconstruct %.1f" % j["with_motion_and_extended_palette_usage"]["stage_ms"]["reconstruct"])
 PY
-    grep "top-64 pass" gpurun_out/epu_$v.err | head -5 | sed 's/^/    /'
+    grep "top-[0-9]* pass" gpurun_out/epu_$v.err | tail -7 | sed 's/^/    /'
   done
 done
