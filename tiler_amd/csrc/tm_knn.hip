@@ -202,7 +202,10 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
 #pragma unroll 8
       for (int p = part; p < 192; p += 8) { const int v = s_v[r][p]; sq += (uint32_t)(v * v); }
       sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4);
-      if (part == 0) { s_norm[r] = sq; reinterpret_cast<uint32_t *>(obase + kch * 1024)[r] = sq; }
+      // what the pack keeps per row is what the scan's chain starts from (k3_chain's `cin`): the query side's |q-c|^2 (the kernel drops its
+      // parity), the database side's |t-c|^2 where its digits are those of 2 (t - c), and |t-c|^2 >> 1 where not -- the parities then go
+      // into the tile's box (word 14)
+      if (part == 0) { s_norm[r] = sq; reinterpret_cast<uint32_t *>(obase + kch * 1024)[r] = (with_box && scale == 1) ? sq >> 1 : sq; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // (rows >= n replicate row n - 1: they add no digit the real rows do not have)
@@ -227,8 +230,11 @@ __global__ __launch_bounds__(256) void k_knn_pack(const int16_t *__restrict__ fe
         const long long rest = std::max(0ll, (long long)s - boxsq);
         int lo = max(0, (int)floor(sqrt((double)rest)) - 1), hi = (int)ceil(sqrt((double)rest)) + 1;
         for (int o = 16; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        const unsigned par = (unsigned)__builtin_amdgcn_ballot_w64((s & 1u) != 0);  // (lanes 0..31: one per row)
         if (threadIdx.x == 0) {
           int *tb = reinterpret_cast<int *>(obase + kch * 1024 + 128);
+          tb[14] = (int)par;
+          tb[15] = 0;
           tb[KNN_NC] = lo;
           tb[KNN_ND + KNN_NC] = hi;
           box_lo[(int64_t)KNN_NC * ntiles + tile] = lo;

@@ -120,58 +120,58 @@ __device__ __forceinline__ unsigned k3_isqrt(unsigned x) {
 // the bound a sub-tile's tiles are judged against, from its largest best mx = d'' + 1 (an SSD bound): an upper bound of its square root
 __device__ __forceinline__ unsigned k3_bound_of(unsigned mx) { return mx == ~0u ? 0xFFFEu : min(0xFFFEu, (unsigned)__builtin_amdgcn_sqrtf((float)mx) + 3u); }
 
-// One block's chain: X over the digit products on one accumulator shifted between the phases; with TD (database digits of 2 (t - c)) the
-// rows' own term |t-c|^2 rides in on the second shift and the chain ends in 2 X + |t-c|^2.  `q` = the sub-tile's B operands in LDS at this
-// lane's 16 bytes (chunk stride 1024).
+// One block's chain: X over the digit products on one accumulator shifted between the phases; the rows' own term `cin` rides in on the
+// second shift.  With TD (database digits of 2 (t - c)) cin = |t-c|^2 and the chain ends in 2 X + |t-c|^2 = d'' - qn; without, cin =
+// |t-c|^2 >> 1 and it ends in Y = X + (|t-c|^2 >> 1): d'' - qn = 2 Y + (|t-c|^2 & 1), which the epilogue makes only for the blocks that
+// can matter (the doubling of sixteen registers was a fifth of a block's vector instructions).  `q` = the sub-tile's B operands in LDS at
+// this lane's 16 bytes (chunk stride 1024).
 // `tm` / `qm` (wave-uniform): bit kc set = high-digit chunk kc of the tile / of the sub-tile holds a non-zero digit.  A product with an
 // all-zero chunk adds nothing and is skipped, its LDS read with it: the columns are packed widest first (make_plan_scaled), so a tile of
 // smooth content has its high digits in the first chunk or two only.  (Measured against straight-line chains for the common mask shapes,
 // picked by one or two uniform tests: a predicate per product is as fast or faster on both bench clips -- the other waves of the SIMD
 // fill the matrix pipe while a product waits for its LDS read -- skips more, and needs no spilled register.)
 template <int HT, int HQ, bool TD>
-__device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q, unsigned tm, unsigned qm) {
+__device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &cin, const uint8_t *q, unsigned tm, unsigned qm) {
   constexpr int HM = HT < HQ ? HT : HQ;
-  v16i acc;
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v16i acc = cin;  // a single phase: the rows' term is the chain's starting value
+  if constexpr (HT + HQ > 0) {
+    // No register is zeroed for a block: whatever the masks say, the chain's FIRST product is one that always runs, with the constant 0 as
+    // its C operand.  That is T_H0 . Q_H0 where any T_H . Q_H product runs, and the first product of the middle phase otherwise (T_H0 . Q_L0;
+    // T_L0 . Q_H0 for a database without high digits) -- a chunk its mask calls empty is all zeros (k3_load_tile_masked fills a skipped
+    // chunk with them), so the product then adds nothing: a matrix instruction instead of sixteen moves.
+    const v4i *const fa = HT > 0 ? &T[6] : &T[0];
+    const uint8_t *const fq = HT > 0 ? q : q + 6 * 1024;
+    bool hh = false;
+    if constexpr (HM > 0) hh = (tm & qm) != 0;
+    if (hh) {
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6], *reinterpret_cast<const v4i *>(q + 6 * 1024), zero, 0, 0, 0);                  // T_H . Q_H
 #pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0;
-  if (TD && HT + HQ == 0) acc = ntr;  // a single phase: the rows' term is the chain's starting value
-#ifndef TM_KNN3_OPAQUE_ZERO
-#define TM_KNN3_OPAQUE_ZERO 0
-#endif
-#if TM_KNN3_OPAQUE_ZERO
-  // (measured in round 5 and left off: the compiler, seeing through the zero, gives the first T_H . Q_H product the constant 0 as its C operand
-  // where that product runs and builds the zero with 23 register moves on every other path; made opaque here it is 16 moves on every path --
-  // and the kernel takes 12.7 instead of 12.2 ms.  A never-zeroed accumulator -- every product in two forms behind a scalar branch on "has a
-  // product run yet" -- compiled to 200 register-pair copies between the forms.)
-  asm volatile("" : "+v"(acc));
-#endif
-  if (HM > 0) {
-    if (tm & qm) {
-#pragma unroll
-      for (int kc = 0; kc < HM; kc++)
+      for (int kc = 1; kc < HM; kc++)
         if (((tm & qm) >> kc) & 1u)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);  // T_H . Q_H
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*fa, *reinterpret_cast<const v4i *>(fq), acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*fa, *reinterpret_cast<const v4i *>(fq), zero, 0, 0, 0);
     }
-  }
-  if (HT + HQ > 0) {
 #pragma unroll
-    for (int kc = 0; kc < HQ; kc++)
+    for (int kc = (HT > 0 ? 0 : 1); kc < HQ; kc++)
       if ((qm >> kc) & 1u)
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);      // T_L . Q_H
 #pragma unroll
-    for (int kc = 0; kc < HT; kc++)
+    for (int kc = 1; kc < HT; kc++)
       if ((tm >> kc) & 1u)
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + kc * 1024), acc, 0, 0, 0);        // T_H . Q_L
   }
-  // the first two operands of the last phase are asked for before the second shift's sixteen instructions, which hide part of their latency
+  // the first two operands of the last phase are asked for before the shift's sixteen instructions, which hide part of their latency
   // (asked for at the very top of the chain instead: four spilled registers, 12.35 against 12.30 ms)
   v4i qa = *reinterpret_cast<const v4i *>(q), qb = *reinterpret_cast<const v4i *>(q + 1024);
   __builtin_amdgcn_sched_barrier(0);
-  if (HT + HQ > 0) {
+  if constexpr (HT + HQ > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+    for (int r = 0; r < 16; r++) acc[r] = (int)(((unsigned)acc[r] << 8) + (unsigned)cin[r]);
   }
   // T_L . Q_L, always six products: the LDS read of product i + 1 is issued BEFORE the matrix instruction of product i (two operand
   // buffers in turn; the scheduling barriers keep the order -- left alone the compiler reads each operand into the same four registers
@@ -205,12 +205,12 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &ntr
 #define TM_KNN3_DUAL 0  // measured (round 5): 13.9 against 12.5 ms at 16 waves (twelve spilled registers), 13.7 against ~14.1 at 12 waves: the chain's own latency is not what the pipe waits for
 #endif
 template <int HT, int HQ, bool TD>
-__device__ __forceinline__ void k3_chain2(const v4i (&T)[6 + HT], const v16i &ntr, const uint8_t *q0, const uint8_t *q1, unsigned tm, unsigned qm0, unsigned qm1,
+__device__ __forceinline__ void k3_chain2(const v4i (&T)[6 + HT], const v16i &cin, const uint8_t *q0, const uint8_t *q1, unsigned tm, unsigned qm0, unsigned qm1,
                                           v16i &acc0, v16i &acc1) {
   constexpr int HM = HT < HQ ? HT : HQ;
 #pragma unroll
   for (int r = 0; r < 16; r++) { acc0[r] = 0; acc1[r] = 0; }
-  if (TD && HT + HQ == 0) { acc0 = ntr; acc1 = ntr; }
+  if (HT + HQ == 0) { acc0 = cin; acc1 = cin; }
   if (HM > 0) {
     const unsigned h0 = tm & qm0, h1 = tm & qm1;
     if (h0 | h1) {
@@ -246,9 +246,9 @@ __device__ __forceinline__ void k3_chain2(const v4i (&T)[6 + HT], const v16i &nt
   __builtin_amdgcn_sched_barrier(0);
   if (HT + HQ > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc0[r] = (int)(((unsigned)acc0[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+    for (int r = 0; r < 16; r++) acc0[r] = (int)(((unsigned)acc0[r] << 8) + (unsigned)cin[r]);
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc1[r] = (int)(((unsigned)acc1[r] << 8) + (TD ? (unsigned)ntr[r] : 0u));
+    for (int r = 0; r < 16; r++) acc1[r] = (int)(((unsigned)acc1[r] << 8) + (unsigned)cin[r]);
   }
   // T_L . Q_L, six products a chain, the chains in turn: an operand buffer is asked for again right behind the matrix instruction that read it,
   // two matrix instructions before its next use
@@ -263,23 +263,32 @@ __device__ __forceinline__ void k3_chain2(const v4i (&T)[6 + HT], const v16i &nt
   }
 }
 
-// a tile's MFMA A operands and the rows' norms, straight into registers (global_load_dwordx4, 1 KB contiguous per instruction)
+// a tile's MFMA A operands and the rows' terms, straight into registers (global_load_dwordx4, 1 KB contiguous per instruction).  The
+// pack (k_knn_pack, database side) holds per row the chain's starting value -- |t-c|^2 where the digits are those of 2 (t - c), |t-c|^2 >> 1
+// where not -- and in the 15th word of the tile's box the 32 parities |t-c|^2 & 1 (bit = row); `pwh` = that word shifted so that bit
+// k3_prow(r) is accumulator register r's row in this half-wave.
+__device__ __forceinline__ constexpr int k3_prow(int r) { return (r & 3) + 8 * (r >> 2); }
 template <int KT>
-__device__ __forceinline__ void k3_load_tile(const uint8_t *tb, int lane, int half, v4i (&T)[KT], v16i &ntr) {
+__device__ __forceinline__ void k3_load_rows(const uint8_t *tb, int half, v16i &cin, unsigned &pwh) {
+#pragma unroll
+  for (int q4 = 0; q4 < 4; q4++) {  // accumulator register r holds row (r&3) + 8*(r>>2) + 4*half
+    const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
+    cin[q4 * 4] = x[0]; cin[q4 * 4 + 1] = x[1]; cin[q4 * 4 + 2] = x[2]; cin[q4 * 4 + 3] = x[3];
+  }
+  pwh = *reinterpret_cast<const unsigned *>(tb + KT * 1024 + 128 + 14 * 4) >> (4 * half);
+}
+template <int KT>
+__device__ __forceinline__ void k3_load_tile(const uint8_t *tb, int lane, int half, v4i (&T)[KT], v16i &cin, unsigned &pwh) {
 #pragma unroll
   for (int kc = 0; kc < KT; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
-#pragma unroll
-  for (int q4 = 0; q4 < 4; q4++) {  // |t-c|^2 of accumulator row r: (r&3) + 8*(r>>2) + 4*half
-    const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
-    ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
-  }
+  k3_load_rows<KT>(tb, half, cin, pwh);
 }
 
 // ... leaving out the high-digit chunks the tile's mask says are all zero (the chain skips their products: bit kc clear = T[6 + kc] never
 // read).  On the literal bench clip the consume kernel pulled 43.7 GB per launch through the L2s' far side -- 3.4 TB/s, the matrix pipe
 // waiting on it -- and two in five of those bytes were zeros.
 template <int KT>
-__device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane, int half, unsigned tm, v4i (&T)[KT], v16i &ntr) {
+__device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane, int half, unsigned tm, v4i (&T)[KT], v16i &cin, unsigned &pwh) {
 #pragma unroll
   for (int kc = 0; kc < 6; kc++) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
 #pragma unroll
@@ -287,11 +296,38 @@ __device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane,
     T[kc] = v4i{0, 0, 0, 0};
     if ((tm >> (kc - 6)) & 1u) T[kc] = *reinterpret_cast<const v4i *>(tb + (kc * 64 + lane) * 16);
   }
+  k3_load_rows<KT>(tb, half, cin, pwh);
+}
+
+// the minimum of the chain's sixteen values of a lane
+__device__ __forceinline__ int k3_min16(const int (&t)[16]) {
+  return min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
+             min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
+}
+// what a block's sixteen values say about a lane's query before anything is made of them: a LOWER bound of the smallest d'' - qn.  With
+// TD the chain's values are d'' - qn themselves; without, d'' - qn = 2 Y + parity and 2 min(Y) is at most one below the smallest.
+template <bool TD>
+__device__ __forceinline__ int k3_first_look(const v16i &acc) {
+  int y[16];
 #pragma unroll
-  for (int q4 = 0; q4 < 4; q4++) {
-    const v4i x = *reinterpret_cast<const v4i *>(tb + KT * 1024 + (q4 * 8 + half * 4) * 4);
-    ntr[q4 * 4] = x[0]; ntr[q4 * 4 + 1] = x[1]; ntr[q4 * 4 + 2] = x[2]; ntr[q4 * 4 + 3] = x[3];
-  }
+  for (int r = 0; r < 16; r++) y[r] = acc[r];
+  const int ym = k3_min16(y);
+  return TD ? ym : (int)((unsigned)ym << 1);
+}
+// Can the block matter to a query whose bound is `bound` (its best d'' + 1, or its threshold + 1)?  With TD the test the epilogue makes
+// itself; without, the first look is a lower bound that can lie one below the truth -- at -1 where a query meets its own row and both norms
+// are odd (d'' + 1 = 0) -- so the compare is a signed one against the bound cut to 2^31 - 1: a value that wraps goes the safe way (in).
+template <bool TD>
+__device__ __forceinline__ bool k3_may_matter(const v16i &acc, unsigned qn, unsigned bound) {
+  const unsigned look = (unsigned)k3_first_look<TD>(acc) + qn + 1u;
+  return TD ? look <= bound : (int)look <= (int)min(bound, 0x7FFFFFFFu);
+}
+// ... and the values themselves (d'' - qn of accumulator register r)
+template <bool TD>
+__device__ __forceinline__ void k3_values(const v16i &acc, unsigned pwh, int (&t)[16]) {
+  if (!TD) asm volatile("" : "+v"(pwh));  // (the sixteen parity bits are taken out HERE, on the rare path: seen through, the compiler takes them out once per tile and keeps sixteen registers for them)
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) | ((pwh >> k3_prow(r)) & 1u));
 }
 
 // A block's epilogue: the row minimum of each query (lane & 31; the two half-waves hold 16 rows each) against its running best in LDS.
@@ -299,35 +335,35 @@ __device__ __forceinline__ void k3_load_tile_masked(const uint8_t *tb, int lane,
 // best (the caller refreshes the bound when any lane says so); `sm_now` = the sub-tile's published bound, or 0 to ask for a refresh on
 // every improvement.
 template <bool TD>
-__device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, int tile, int half, unsigned qn, unsigned long long *best, unsigned *tie,
+__device__ __forceinline__ bool k3_epilogue(const v16i &acc, unsigned pwh, int tile, int half, unsigned qn, unsigned long long *best, unsigned *tie,
                                             unsigned sm_now, unsigned cur_hi /* the query's best as read BEFORE the chain: stale only on the safe side (a best only falls) */) {
-  int t[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
-  const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
-                     min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
-  const unsigned key_hi = (unsigned)tm + qn + 1u;  // d'' + 1 >= 0
   bool refresh = false;
-  if (key_hi <= cur_hi) {
-    // which row (the first one reaching the minimum), and is it alone: a compare, a select and an add-with-carry per register
-    int ridx = 0;
-    unsigned cnt = 0;
+  if (k3_may_matter<TD>(acc, qn, cur_hi)) {  // (rare: the seeds and the lists' order leave few blocks that improve a best)
+    int t[16];
+    k3_values<TD>(acc, pwh, t);
+    const int tm = k3_min16(t);
+    const unsigned key_hi = (unsigned)tm + qn + 1u;  // d'' + 1 >= 0
+    if (key_hi <= cur_hi) {
+      // which row (the first one reaching the minimum), and is it alone: a compare, a select and an add-with-carry per register
+      int ridx = 0;
+      unsigned cnt = 0;
 #pragma unroll
-    for (int r = 15; r >= 0; r--) {
-      const bool e = t[r] == tm;
-      ridx = e ? r : ridx;
-      cnt += e ? 1u : 0u;
+      for (int r = 15; r >= 0; r--) {
+        const bool e = t[r] == tm;
+        ridx = e ? r : ridx;
+        cnt += e ? 1u : 0u;
+      }
+      const int row = (ridx & 3) + ((ridx & 12) << 1) + 4 * half;
+      const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
+      const unsigned long long pre = atomicMin(best, key);
+      const unsigned pre_hi = (unsigned)(pre >> 32);
+      if (pre_hi == key_hi || cnt > 1) atomicMin(tie, key_hi);  // the value was reached a second time
+      // The sub-tile's largest best can only have moved if this query held it: its old best is then no smaller than what the published
+      // bound was made from ((bound - 3)^2; a bound of 0xFFFE stands for "some query has no best yet").  A refresh skipped by a race only
+      // leaves the bound loose (and is made good at the end of the segment).
+      const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
+      refresh = key_hi < pre_hi && pre_hi >= thr;
     }
-    const int row = (ridx & 3) + ((ridx & 12) << 1) + 4 * half;
-    const unsigned long long key = ((unsigned long long)key_hi << 32) | (unsigned)((tile << 5) | row);
-    const unsigned long long pre = atomicMin(best, key);
-    const unsigned pre_hi = (unsigned)(pre >> 32);
-    if (pre_hi == key_hi || cnt > 1) atomicMin(tie, key_hi);  // the value was reached a second time
-    // The sub-tile's largest best can only have moved if this query held it: its old best is then no smaller than what the published
-    // bound was made from ((bound - 3)^2; a bound of 0xFFFE stands for "some query has no best yet").  A refresh skipped by a race only
-    // leaves the bound loose (and is made good at the end of the segment).
-    const unsigned thr = sm_now > 3u ? (sm_now - 3u) * (sm_now - 3u) : 0u;
-    refresh = key_hi < pre_hi && pre_hi >= thr;
   }
   return refresh;
 }
@@ -343,16 +379,15 @@ __device__ __forceinline__ bool k3_epilogue(const v16i &acc, const v16i &ntr, in
 // workgroup, and the parts of a split group, lower it on their own evidence).  Returns true in lanes that lowered a threshold the
 // sub-tile's bound may hang on.
 template <bool TD>
-__device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, const v16i &ntr, int tile, bool countable, int half, unsigned qn, unsigned long long *best,
+__device__ __forceinline__ bool k3_epilogue_topk(const v16i &acc, unsigned pwh, int tile, bool countable, int half, unsigned qn, unsigned long long *best,
                                                  unsigned *lad, const unsigned *base_p, bool qvalid, int64_t q, const Knn3Args &a, unsigned sm_now) {
-  int t[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) t[r] = TD ? acc[r] : (int)(((unsigned)acc[r] << 1) + (unsigned)ntr[r]);
-  const int tm = min(min(min(min(t[0], t[1]), min(t[2], t[3])), min(min(t[4], t[5]), min(t[6], t[7]))),
-                     min(min(min(t[8], t[9]), min(t[10], t[11])), min(min(t[12], t[13]), min(t[14], t[15]))));
   const unsigned tau1 = k3_peek(reinterpret_cast<unsigned *>(best) + 1);  // tau + 1
   bool refresh = false;
-  if (qvalid && (unsigned)tm + qn + 1u <= tau1) {
+  // (the first look is a lower bound: a lane it lets in with no row within the threshold appends and counts nothing -- every row is tested
+  // by its own value below -- and at most lowers its threshold on the rungs' counts as they stand, which is valid at any time)
+  if (qvalid && k3_may_matter<TD>(acc, qn, tau1)) {
+    int t[16];
+    k3_values<TD>(acc, pwh, t);
     const unsigned step = k3_peek(reinterpret_cast<unsigned *>(best)), base = *base_p;
     bool full = (k3_peek(&lad[3]) >> 31) != 0, filled = false;
     unsigned c[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -448,8 +483,9 @@ __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a)
   const int tile = r0a + (active ? wave : 0);
   const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)a.thmask[tile]);
   v4i T[KT];
-  v16i ntr;
-  k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, ntr);
+  v16i cin;
+  unsigned pwh;
+  k3_load_tile<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, T, cin, pwh);
   const int n_slices = (nvalid + SL - 1) / SL;
   long long nblocks = 0, npairs = 0;
   const int vt = (int)min((int64_t)32, a.nt_rows - (int64_t)tile * 32);
@@ -463,8 +499,8 @@ __global__ __launch_bounds__(K3_SEEDS * 64, 4) void k_knn_seed(const Knn3Args a)
         const int s = sl * SL + j;
         const int qi = s * 32 + (lane & 31);
         const unsigned cur_hi = k3_peek(reinterpret_cast<unsigned *>(&s_best[qi]) + 1), qn = (unsigned)s_qn[qi];  // (asked for before the chain: they arrive under it)
-        const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, &s_q[sl & 1][j * KQ * 1024] + lane * 16, tm, (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[s]));
-        k3_epilogue<TD>(acc, ntr, tile, half, qn, &s_best[qi], &s_tie[qi], 0u, cur_hi);
+        const v16i acc = k3_chain<HT, HQ, TD>(T, cin, &s_q[sl & 1][j * KQ * 1024] + lane * 16, tm, (unsigned)__builtin_amdgcn_readfirstlane((int)s_qm[s]));
+        k3_epilogue<TD>(acc, pwh, tile, half, qn, &s_best[qi], &s_tie[qi], 0u, cur_hi);
         nblocks++;
         npairs += (long long)vt * (int)min((int64_t)32, a.nq - (st0 + s) * 32);
       }
@@ -836,8 +872,9 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
           break;
         }
         v4i T[KT];
-        v16i ntr;
-        k3_load_tile_masked<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, tm, T, ntr);
+        v16i cin;
+        unsigned pwh;
+        k3_load_tile_masked<KT>(a.tpack + (int64_t)tile * T_BYTES, lane, half, tm, T, cin, pwh);
         nloads++;
         // the entry after this one is chosen while the loads fly
         int ntile = 0, nlb = 0, nsm = 0;
@@ -857,9 +894,9 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
             const int64_t q = (st0 + s) * 32 + (lane & 31);
             // (the last database tile pads with copies of its last row: they are candidates like any row -- the select stage drops them --
             // but must not count towards a rung)
-            refresh = k3_epilogue_topk<TD>(acc, ntr, tile, tile != (int)n_ttiles - 1, half, qn, &s_best[qi], &s_lad[qi * 4], &s_tie[qi], q < a.nq, q, a, sm_now);
+            refresh = k3_epilogue_topk<TD>(acc, pwh, tile, tile != (int)n_ttiles - 1, half, qn, &s_best[qi], &s_lad[qi * 4], &s_tie[qi], q < a.nq, q, a, sm_now);
           } else {
-            refresh = k3_epilogue<TD>(acc, ntr, tile, half, qn, &s_best[qi], &s_tie[qi], sm_now, cur_hi);
+            refresh = k3_epilogue<TD>(acc, pwh, tile, half, qn, &s_best[qi], &s_tie[qi], sm_now, cur_hi);
           }
           if (__builtin_amdgcn_ballot_w64(refresh)) {  // refresh the sub-tile's largest best (bests only go down: a late writer is only loose)
             const unsigned mx = k3_wave_umax(k3_peek(reinterpret_cast<unsigned *>(s_best) + qi * 2 + 1));  // = largest d'' + 1
@@ -904,12 +941,17 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
             const int qi1 = s1 * 32 + (lane & 31);
             const unsigned cur1 = k3_peek(reinterpret_cast<unsigned *>(&s_best[qi1]) + 1), qn1 = (unsigned)s_qn[qi1];
             v16i acc0, acc1;
-            k3_chain2<HT, HQ, TD>(T, ntr, lds + s0 * (KQ * 1024) + lane * 16, lds + s1 * (KQ * 1024) + lane * 16, tm, qm0, qm1, acc0, acc1);
+            k3_chain2<HT, HQ, TD>(T, cin, lds + s0 * (KQ * 1024) + lane * 16, lds + s1 * (KQ * 1024) + lane * 16, tm, qm0, qm1, acc0, acc1);
             nmfma += 12 + __builtin_popcount(tm & qm0) + __builtin_popcount(qm0) + __builtin_popcount(tm & qm1) + __builtin_popcount(qm1) + 2 * __builtin_popcount(tm);
             finish(acc0, s0, sm0, cur0, qn0);
             finish(acc1, s1, sm1, cur1, qn1);
           } else {
-            const v16i acc = k3_chain<HT, HQ, TD>(T, ntr, lds + s0 * (KQ * 1024) + lane * 16, tm, qm0);
+#ifndef TM_KNN3_SETPRIO
+#define TM_KNN3_SETPRIO 0  // a wave inside its chain ahead of the waves between chains when the SIMD picks whom to issue
+#endif
+            if (TM_KNN3_SETPRIO) __builtin_amdgcn_s_setprio(TM_KNN3_SETPRIO);
+            const v16i acc = k3_chain<HT, HQ, TD>(T, cin, lds + s0 * (KQ * 1024) + lane * 16, tm, qm0);
+            if (TM_KNN3_SETPRIO) __builtin_amdgcn_s_setprio(0);
             nmfma += 6 + __builtin_popcount(tm & qm0) + __builtin_popcount(qm0) + __builtin_popcount(tm);
             if (!TM_KNN3_PRE_QN) qn0 = (unsigned)s_qn[qi0];
             finish(acc, s0, sm0, cur0, qn0);
