@@ -1252,6 +1252,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   TM_HIP(hipGetLastError());
   int flag = 0;
   unsigned long long cnt[32 + 256] = {0};
+  [[maybe_unused]] unsigned long long stamps_in_consume[3] = {0, 0, 0};
   for (int attempt = 0;; attempt++) {
   TM_HIP(hipMemsetAsync(ix->counters.p, 0, 256 + 2048, stream));
   TM_HIP(hipEventRecord(ix->ev0, stream));
@@ -1274,6 +1275,7 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
     TM_TRY(hr_.get(cnt, ix->counters.p, 256 + 2048));
     TM_TRY(hr_.wait());
   }
+  for (int i = 0; i < 3; i++) stamps_in_consume[i] = cnt[12 + i];  // (a diagnostic build's: stats[10..12])
   cnt[12] = cnt[13] = cnt[14] = 0;  // the seed kernel's blocks, tiles read, pairs: summed over its 64 striped slots
   for (int i = 0; i < 64; i++) { cnt[12] += cnt[32 + i * 4]; cnt[13] += cnt[32 + i * 4 + 1]; cnt[14] += cnt[32 + i * 4 + 2]; }
   if (prune) {  // remember what the lists needed (never below the starting guess: a small search says little about the next)
@@ -1325,6 +1327,8 @@ int knn_index_search(tm_knn_index_impl *ix, const void *queries, int64_t nq, voi
   {
     static const char *names3[6] = {"prologue + results", "segment load", "consume", "end-of-segment wait", "waiting for the tile", "total"};
     for (int i = 0; i < 6; i++) fprintf(stderr, "[tm_knn3 stamps] %-24s %6.2f %% of the consume kernel's wave time\n", names3[i], 100.0 * (double)cnt[6 + i] / (double)cnt[11]);
+    static const char *names3b[3] = {"  of consume: pick", "  of consume: chain", "  of consume: epilogue"};
+    for (int i = 0; i < 3; i++) fprintf(stderr, "[tm_knn3 stamps] %-24s %6.2f %% (%.0f ticks per block)\n", names3b[i], 100.0 * (double)stamps_in_consume[i] / (double)cnt[11], (double)stamps_in_consume[i] / (double)std::max<unsigned long long>(1, cnt[2]));
     static const char *names_s[7] = {"set-up", "wait: first slice + tile", "wait: later slices", "blocks", "end barrier", "results", "total"};
     for (int i = 0; i < 7; i++) fprintf(stderr, "[tm_knn3 stamps] seeds: %-24s %6.2f %% of wave time (%.0f clock ticks per wave)\n", names_s[i], 100.0 * (double)cnt[22 + i] / (double)cnt[28],
                                         (double)cnt[22 + i] / (8.0 * (double)((nqt + knn3_sub_tiles(ix->plan.hq) - 1) / knn3_sub_tiles(ix->plan.hq))));

@@ -140,21 +140,23 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &cin
     // its C operand.  That is T_H0 . Q_H0 where any T_H . Q_H product runs, and the first product of the middle phase otherwise (T_H0 . Q_L0;
     // T_L0 . Q_H0 for a database without high digits) -- a chunk its mask calls empty is all zeros (k3_load_tile_masked fills a skipped
     // chunk with them), so the product then adds nothing: a matrix instruction instead of sixteen moves.
-    const v4i *const fa = HT > 0 ? &T[6] : &T[0];
-    const uint8_t *const fq = HT > 0 ? q : q + 6 * 1024;
+    constexpr int FA = HT > 0 ? 6 : 0;  // the middle phase's first product: chunk FA of the tile, chunk FQ of the sub-tile
+    constexpr int FQ = HT > 0 ? 0 : 6;
     bool hh = false;
     if constexpr (HM > 0) hh = (tm & qm) != 0;
     if (hh) {
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6], *reinterpret_cast<const v4i *>(q + 6 * 1024), zero, 0, 0, 0);                  // T_H . Q_H
+      if constexpr (HM > 0) {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6], *reinterpret_cast<const v4i *>(q + 6 * 1024), zero, 0, 0, 0);                // T_H . Q_H
 #pragma unroll
-      for (int kc = 1; kc < HM; kc++)
-        if (((tm & qm) >> kc) & 1u)
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);
+        for (int kc = 1; kc < HM; kc++)
+          if (((tm & qm) >> kc) & 1u)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[6 + kc], *reinterpret_cast<const v4i *>(q + (6 + kc) * 1024), acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*fa, *reinterpret_cast<const v4i *>(fq), acc, 0, 0, 0);
+        for (int r = 0; r < 16; r++) acc[r] = (int)((unsigned)acc[r] << 8);
+      }
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[FA], *reinterpret_cast<const v4i *>(q + FQ * 1024), acc, 0, 0, 0);
     } else {
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*fa, *reinterpret_cast<const v4i *>(fq), zero, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[FA], *reinterpret_cast<const v4i *>(q + FQ * 1024), zero, 0, 0, 0);
     }
 #pragma unroll
     for (int kc = (HT > 0 ? 0 : 1); kc < HQ; kc++)
@@ -195,6 +197,17 @@ __device__ __forceinline__ v16i k3_chain(const v4i (&T)[6 + HT], const v16i &cin
     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(T[5], qb, acc, 0, 0, 0);
   }
   return acc;
+}
+
+// matrix instructions k3_chain issues for a block with these masks
+template <int HT, int HQ>
+__device__ __forceinline__ int k3_chain_products(unsigned tm, unsigned qm) {
+  constexpr int HM = HT < HQ ? HT : HQ;
+  if (HT + HQ == 0) return 6;
+  int n = 7;  // the last phase's six and the middle phase's first
+  if (HM > 0 && (tm & qm)) n += 1 + __builtin_popcount((tm & qm) >> 1);
+  n += HT > 0 ? __builtin_popcount(qm) + __builtin_popcount(tm >> 1) : __builtin_popcount(qm >> 1);
+  return n;
 }
 
 // Two blocks at once: the tile against TWO sub-tiles, two independent accumulators fed in turn (the tile's A operands serve both).  A wave's
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
 #if TM_KNN3_STAMPS
-  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
   const unsigned long long st_begin = st_last;
 #endif
   // Persistent workgroups (one per CU): a workgroup draws query groups until none is left.  Groups are dealt in runs of K3_XCD_RUN
@@ -924,6 +937,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
         for (;;) {
           unsigned sm0 = 0, sm1 = 0;
           const int s0 = pick(sm0);
+          K3_STAMP(5);  // choosing the block's sub-tile (the bound's fresh look)
           if (s0 < 0) break;
           // the sub-tile's mask comes out of a register (lane s of qmask_v), the query's best and norm are asked for before the chain: every
           // LDS round trip a block can do without, or start early, is one the wave does not sit out between its matrix instructions
@@ -946,15 +960,16 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
             finish(acc0, s0, sm0, cur0, qn0);
             finish(acc1, s1, sm1, cur1, qn1);
           } else {
-#ifndef TM_KNN3_SETPRIO
-#define TM_KNN3_SETPRIO 0  // a wave inside its chain ahead of the waves between chains when the SIMD picks whom to issue
-#endif
-            if (TM_KNN3_SETPRIO) __builtin_amdgcn_s_setprio(TM_KNN3_SETPRIO);
+            // (s_setprio 2 around the chain -- a wave inside its chain ahead of the waves between chains -- measured: no change)
+            // (measured in round 5 and dropped: every product's operand read one product ahead -- the reads issued whatever the predicates say, with
+            // no lane enabled where the product will not run, so that the waits can name the read they need: 13.5 against 11.8 ms; the thirteen
+            // reads that read nothing still pass through the CU's one LDS queue)
             const v16i acc = k3_chain<HT, HQ, TD>(T, cin, lds + s0 * (KQ * 1024) + lane * 16, tm, qm0);
-            if (TM_KNN3_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            nmfma += 6 + __builtin_popcount(tm & qm0) + __builtin_popcount(qm0) + __builtin_popcount(tm);
+            nmfma += k3_chain_products<HT, HQ>(tm, qm0);
+            K3_STAMP(6);  // the chain, up to the issue of its last matrix instruction
             if (!TM_KNN3_PRE_QN) qn0 = (unsigned)s_qn[qi0];
             finish(acc, s0, sm0, cur0, qn0);
+            K3_STAMP(7);  // the epilogue (behind the wait for the chain's result)
           }
         }
         tile = ntile; tmw = ntm; lbv = nlb; mask = nmask; have = nhave; smv = nsm;
@@ -992,6 +1007,7 @@ __global__ __launch_bounds__(K3_NT) void k_knn_consume(const Knn3Args a) {
   if (a.stats && lane == 0) {
     for (int i = 0; i < 5; i++) atomicAdd(a.stats + 4 + i, st_acc[i]);
     atomicAdd(a.stats + 9, __builtin_amdgcn_s_memtime() - st_begin);
+    for (int i = 5; i < 8; i++) atomicAdd(a.stats + 5 + i, st_acc[i]);  // [10..12]: inside "consume" (the host reads them before it reuses the slots)
   }
 #endif
   if (a.stats && lane == 0) {
