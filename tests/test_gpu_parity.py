@@ -649,14 +649,19 @@ def test_dither_distinct_pairs_with_many_palettes(monkeypatch):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("path", ["hash", "hash-collisions", "plain"])
+@pytest.mark.parametrize("path", ["hash", "hash-collisions", "hash-sort", "hash-sort-collisions", "plain"])
 @pytest.mark.parametrize("kind", ["rgb", "pal"])
 def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):
-    """three ways through the kernel: rows grouped by their 64-bit hash; the hash cut to 2 bits, so that different rows collide and the
-    call has to notice and take the plain path; the plain path (merge sort of all rows) asked for outright"""
+    """the ways through the kernel: rows grouped by their 64-bit hash in a hash table (the default) or by a radix sort of the hashes
+    (TM_DEDUP_SORT); either with the hash cut to 2 bits, so that different rows collide and the call has to notice and take the plain path;
+    the plain path (merge sort of all rows) asked for outright"""
     from tiler_amd import stages
-    if path == "hash-collisions":
+    for name in ("TM_DEDUP_DEGRADE_HASH", "TM_DEDUP_PLAIN", "TM_DEDUP_SORT"):
+        monkeypatch.delenv(name, raising=False)
+    if path.endswith("collisions"):
         monkeypatch.setenv("TM_DEDUP_DEGRADE_HASH", "1")
+    if path.startswith("hash-sort"):
+        monkeypatch.setenv("TM_DEDUP_SORT", "1")
     if path == "plain":
         monkeypatch.setenv("TM_DEDUP_PLAIN", "1")
     tiles, _ = tiles_flags

@@ -53,26 +53,114 @@ struct RowLess {
 };
 
 // 64-bit content hash: 16 lanes per row, one uint4 each per 256 bytes; position enters every term, the terms add up
+// (`lead`: the row's first dword as lane `sub` 0 read it)
+__device__ __forceinline__ unsigned long long row_hash16(const uint32_t *__restrict__ rows, int64_t row, int64_t n, int dwords, int sub, uint32_t &lead) {
+  unsigned long long h = 0;
+  if (row < n)
+    for (int v = sub; v < dwords / 4; v += 16) {
+      const uint4 x = *reinterpret_cast<const uint4 *>(rows + row * dwords + v * 4);
+      if (v == 0) lead = x.x;
+      unsigned long long a = ((unsigned long long)x.y << 32 | x.x) + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * v + 1);
+      unsigned long long b = ((unsigned long long)x.w << 32 | x.z) + 0xC2B2AE3D27D4EB4Full * (unsigned long long)(2 * v + 2);
+      a ^= a >> 32; a *= 0xD6E8FEB86659FD93ull; a ^= a >> 32;
+      b ^= b >> 29; b *= 0xBF58476D1CE4E5B9ull; b ^= b >> 32;
+      h += a * 0x94D049BB133111EBull + b;
+    }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  return h;
+}
 __global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade, int shift,
                                                   unsigned long long *__restrict__ hash) {
   const int sub = threadIdx.x & 15;
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {  // a block covers 16 rows per pass
     const int64_t row = r0 + (threadIdx.x >> 4);
-    unsigned long long h = 0;
-    if (row < n)
-      for (int v = sub; v < dwords / 4; v += 16) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(rows + row * dwords + v * 4);
-        unsigned long long a = ((unsigned long long)x.y << 32 | x.x) + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * v + 1);
-        unsigned long long b = ((unsigned long long)x.w << 32 | x.z) + 0xC2B2AE3D27D4EB4Full * (unsigned long long)(2 * v + 2);
-        a ^= a >> 32; a *= 0xD6E8FEB86659FD93ull; a ^= a >> 32;
-        b ^= b >> 29; b *= 0xBF58476D1CE4E5B9ull; b ^= b >> 32;
-        h += a * 0x94D049BB133111EBull + b;
-      }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    uint32_t lead = 0;
+    const unsigned long long h = row_hash16(rows, row, n, dwords, sub, lead);
     if (row < n && sub == 0) hash[row] = degrade ? (h & 3) : (h >> shift);  // degrade: test hook that forces collisions; shift: only the top bits are kept (run_dedup_ex)
   }
+}
+
+// ---- grouping by a hash TABLE (the default front end since round 5; the hash SORT above stays behind TM_DEDUP_SORT) ------------------------
+// The sort made equal rows neighbours -- seven radix passes over (hash, index) of the clip's 4.32 M frame tiles, head marks, two scans and the
+// run bookkeeping: 0.96 of Reduce's 2.2 ms -- where all that is asked is each row's group: its lowest-index member and the group's use count.
+// An open-addressing table of 64-bit hashes (linear probing, at most two thirds full) gives that with one compare-and-swap per probe:
+//   k_dd_insert   hashes a row (16 lanes) and claims or finds its hash's slot; the claimant leaves its index as the slot's OWNER, a row that
+//                 finds the hash present lowers the slot's MINDUP (atomic minimum).  Both words of a slot lie side by side.
+//   k_dd_resolve  representative = min(owner, mindup); a row that is not its own representative is compared with it IN FULL (a hash shared by
+//                 different rows puts them into one slot, where at least one of them differs from the slot's lowest row: the flag sends the call
+//                 down the plain path exactly as the sort's full compare did) and adds its use to the representative's count.
+//   k_dd_compact  the representatives in index order (an exclusive scan of the head marks), their own use added, and what the partial order
+//                 below wants of them -- use count and leading dword -- as arrays in that order (its three passes gathered both per row).
+// Integer atomics only: the groups, their representatives and counts do not depend on who came first.
+struct DdSlot { uint32_t owner, mindup; };
+__global__ __launch_bounds__(256) void k_dd_insert(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade, int bytewise,
+                                                   unsigned long long *__restrict__ tkey, DdSlot *__restrict__ tslot, uint32_t mask,
+                                                   uint32_t *__restrict__ slot_of, uint32_t *__restrict__ lead_of) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {
+    const int64_t row = r0 + (threadIdx.x >> 4);
+    uint32_t lead = 0;
+    unsigned long long h = row_hash16(rows, row, n, dwords, sub, lead);
+    if (row < n && sub == 0) {
+      if (degrade) h &= 3;
+      const unsigned long long key = h ? h : 1ull;  // (0 = an empty slot)
+      uint32_t s = (uint32_t)(h ^ (h >> 32)) & mask;
+      for (;;) {
+        const unsigned long long old = atomicCAS(&tkey[s], 0ull, key);
+        if (old == 0ull) { tslot[s].owner = (uint32_t)row; break; }  // (read by the next kernel)
+        if (old == key) { atomicMin(&tslot[s].mindup, (uint32_t)row); break; }
+        s = (s + 1) & mask;
+      }
+      slot_of[row] = s;
+      lead_of[row] = bytewise ? __builtin_bswap32(lead) : lead;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_dd_resolve(const uint32_t *__restrict__ rows, int64_t n, int dwords, const DdSlot *__restrict__ tslot,
+                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ use_in, uint32_t *__restrict__ rep,
+                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ use_rep, int *__restrict__ collision) {
+  const int sub = threadIdx.x & 15, vecs = dwords / 4;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {
+    const int64_t row = r0 + (threadIdx.x >> 4);
+    bool diff = false;
+    if (row < n) {
+      const DdSlot sl = tslot[slot_of[row]];
+      const uint32_t r = min(sl.owner, sl.mindup);
+      if (r != (uint32_t)row) {
+        const uint4 *pa = reinterpret_cast<const uint4 *>(rows + (int64_t)r * dwords);
+        const uint4 *pb = reinterpret_cast<const uint4 *>(rows + row * dwords);
+        for (int v = sub; v < vecs; v += 16) {
+          const uint4 x = pa[v], y = pb[v];
+          diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+        }
+      }
+      if (sub == 0) {
+        rep[row] = r;
+        head[row] = r == (uint32_t)row ? 1u : 0u;
+        if (r != (uint32_t)row) {
+          const uint32_t u = use_in ? use_in[row] : 1u;
+          if (u) atomicAdd(&use_rep[r], u);
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(diff) && (threadIdx.x & 63) == 0) *collision = 1;
+  }
+}
+__global__ void k_dd_compact(int64_t n, const uint32_t *__restrict__ head, const uint32_t *__restrict__ head_excl, const uint32_t *__restrict__ use_in,
+                             const uint32_t *__restrict__ lead_of, uint32_t *__restrict__ use_rep, uint32_t *__restrict__ uniq, uint32_t *__restrict__ cuse,
+                             uint32_t *__restrict__ clead) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (head[i]) {
+      const uint32_t j = head_excl[i], u = use_rep[i] + (use_in ? use_in[i] : 1u);
+      use_rep[i] = u;
+      uniq[j] = (uint32_t)i;
+      cuse[j] = u;
+      clead[j] = lead_of[i];
+    }
 }
 
 // runs of equal hash: head flags as k_mark_heads writes them; a non-head row that differs from its predecessor is a collision.  16 lanes per row: a uint4 each, so a 256-byte row is one coalesced read per side (a thread
@@ -145,11 +233,13 @@ __global__ void k_po_fold(const uint32_t *__restrict__ hist8, int bins, uint32_t
     hist[e] = s;
   }
 }
-__global__ __launch_bounds__(256) void k_po_use_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t *__restrict__ hist8) {
+// (cuse / clead: the distinct rows' use counts and leading dwords in uniq's order where the table front end made them; null: gathered per row)
+__global__ __launch_bounds__(256) void k_po_use_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, const uint32_t *__restrict__ cuse,
+                                                     uint32_t *__restrict__ hist8) {
   __shared__ uint32_t s_h[1024];
   for (int e = threadIdx.x; e < 1024; e += 256) s_h[e] = 0;
   __syncthreads();
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&s_h[min(use_rep[uniq[i]], 1023u)], 1u);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) atomicAdd(&s_h[min(cuse ? cuse[i] : use_rep[uniq[i]], 1023u)], 1u);
   __syncthreads();
   uint32_t *hist = hist8 + po_xcc() * 1024;
   for (int e = threadIdx.x; e < 1024; e += 256) if (s_h[e]) atomicAdd(&hist[e], s_h[e]);
@@ -160,13 +250,17 @@ __device__ __forceinline__ uint32_t po_lead(const RowLess &less, uint32_t row) {
 }
 // among the rows used exactly `use_star` times: a histogram of the leading dword's top 12 bits
 __global__ __launch_bounds__(256) void k_po_lead_hist(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t use_star, RowLess less,
-                                                      uint32_t *__restrict__ hist8) {
+                                                      const uint32_t *__restrict__ cuse, const uint32_t *__restrict__ clead, uint32_t *__restrict__ hist8) {
   __shared__ uint32_t s_h[4096];
   for (int e = threadIdx.x; e < 4096; e += 256) s_h[e] = 0;
   __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t r = uniq[i];
-    if (use_rep[r] == use_star) atomicAdd(&s_h[po_lead(less, r) >> 20], 1u);
+    if (cuse) {
+      if (cuse[i] == use_star) atomicAdd(&s_h[clead[i] >> 20], 1u);
+    } else {
+      const uint32_t r = uniq[i];
+      if (use_rep[r] == use_star) atomicAdd(&s_h[po_lead(less, r) >> 20], 1u);
+    }
   }
   __syncthreads();
   uint32_t *hist = hist8 + po_xcc() * 4096;
@@ -174,18 +268,19 @@ __global__ __launch_bounds__(256) void k_po_lead_hist(const uint32_t *__restrict
 }
 // candidate = used more often than use_star, or exactly that often with a leading dword in the first buckets
 __global__ void k_po_flags(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ use_rep, uint32_t use_star, uint32_t last_bucket, RowLess less,
-                           uint32_t *__restrict__ flag) {
+                           const uint32_t *__restrict__ cuse, const uint32_t *__restrict__ clead, uint32_t *__restrict__ flag) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t r = uniq[i], u = use_rep[r];
-    flag[i] = (u > use_star || (u == use_star && (po_lead(less, r) >> 20) <= last_bucket)) ? 1u : 0u;
+    const uint32_t u = cuse ? cuse[i] : use_rep[uniq[i]];
+    flag[i] = (u > use_star || (u == use_star && ((cuse ? clead[i] : po_lead(less, uniq[i])) >> 20) <= last_bucket)) ? 1u : 0u;
   }
 }
 // candidates to the front (as sort keys: ~use and the leading dword ride along), the others behind them in the order they come
 __global__ void k_po_split(const uint32_t *__restrict__ uniq, int64_t nu, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, int64_t ncand,
-                           const uint32_t *__restrict__ use_rep, RowLess less, PrefixKey *__restrict__ cand, uint32_t *__restrict__ order_out) {
+                           const uint32_t *__restrict__ use_rep, RowLess less, const uint32_t *__restrict__ cuse, const uint32_t *__restrict__ clead,
+                           PrefixKey *__restrict__ cand, uint32_t *__restrict__ order_out) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t r = uniq[i];
-    if (flag[i]) cand[pos[i]] = PrefixKey{((unsigned long long)(~use_rep[r]) << 32) | po_lead(less, r), r, 0u};
+    if (flag[i]) cand[pos[i]] = PrefixKey{((unsigned long long)(~(cuse ? cuse[i] : use_rep[r])) << 32) | (cuse ? clead[i] : po_lead(less, r)), r, 0u};
     else order_out[ncand + (i - pos[i])] = r;
   }
 }
@@ -298,7 +393,41 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
                        headpos.as<uint32_t>());
     return TM_OK;
   };
-  if (!knobs().dedup_plain) {
+  // the table front end (see k_dd_insert): rep, use_rep, uniq (in index order) and the distinct count without a sort
+  DevBuf cuse, clead;
+  bool table_ok = false;
+  uint32_t last_excl = 0, last_head = 0;
+  if (!knobs().dedup_plain && !knobs().dedup_sort) {
+    int64_t slots = 1024;
+    while (slots * 2 < n * 3) slots *= 2;
+    DevBuf tkey, tslot, slot_of, lead_of;
+    TM_TRY(tkey.alloc((size_t)slots * 8)); TM_TRY(tslot.alloc((size_t)slots * sizeof(DdSlot))); TM_TRY(slot_of.alloc(n * 4)); TM_TRY(lead_of.alloc(n * 4));
+    TM_TRY(cuse.alloc(n * 4)); TM_TRY(clead.alloc(n * 4));
+    TM_HIP(hipMemsetAsync(tkey.p, 0, (size_t)slots * 8, stream));
+    TM_HIP(hipMemsetAsync(tslot.p, 0xff, (size_t)slots * sizeof(DdSlot), stream));
+    TM_HIP(hipMemsetAsync(use_rep.p, 0, n * 4, stream));
+    const unsigned g16 = (unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32);
+    hipLaunchKernelGGL(k_dd_insert, dim3(g16), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4, knobs().dedup_degrade_hash ? 1 : 0, less.bytewise,
+                       tkey.as<unsigned long long>(), tslot.as<DdSlot>(), (uint32_t)(slots - 1), slot_of.as<uint32_t>(), lead_of.as<uint32_t>());
+    hipLaunchKernelGGL(k_dd_resolve, dim3(g16), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4, tslot.as<DdSlot>(), slot_of.as<uint32_t>(),
+                       (const uint32_t *)use_in, rep.as<uint32_t>(), head.as<uint32_t>(), use_rep.as<uint32_t>(), hflag.as<int>());
+    size_t tb3 = 0;
+    TM_HIP(rocprim::exclusive_scan(nullptr, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    TM_TRY(tmp.alloc(tb3));
+    TM_HIP(rocprim::exclusive_scan(tmp.p, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    hipLaunchKernelGGL(k_dd_compact, dim3(gridn(n)), dim3(256), 0, stream, n, head.as<uint32_t>(), head_excl.as<uint32_t>(), (const uint32_t *)use_in,
+                       lead_of.as<uint32_t>(), use_rep.as<uint32_t>(), uniq.as<uint32_t>(), cuse.as<uint32_t>(), clead.as<uint32_t>());
+    int collision = 0;
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&last_excl, head_excl.as<uint32_t>() + (n - 1), 4));
+      TM_TRY(hr_.get(&last_head, head.as<uint32_t>() + (n - 1), 4));
+      TM_TRY(hr_.get(&collision, hflag.p, 4));
+      TM_TRY(hr_.wait());
+    }
+    if (!collision) grouped = table_ok = true;  // (two different rows under one hash, about once in 2^20 calls of the clip's size: the plain path below, exact and slow)
+  }
+  if (!knobs().dedup_plain && knobs().dedup_sort) {
     DevBuf hkey, hkey2;
     TM_TRY(hkey.alloc(n * 8)); TM_TRY(hkey2.alloc(n * 8));
     // The sort only has to bring equal rows together, so the hash keeps only as many of its top bits (whole 8-bit passes of the sort) as hold
@@ -325,8 +454,7 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     grouped = true;  // until the flag says otherwise: it is read with the distinct count below, one round trip for both
   }
   if (!grouped) TM_TRY(plain_heads());
-  uint32_t last_excl = 0, last_head = 0;
-  for (;;) {
+  while (!table_ok) {
     size_t tb2 = 0;
     TM_HIP(rocprim::inclusive_scan(nullptr, tb2, headpos.as<uint32_t>(), hps.as<uint32_t>(), (size_t)n, rocprim::maximum<uint32_t>(), stream));
     size_t tb3 = 0;
@@ -364,7 +492,8 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     TM_TRY(h1.alloc(1024 * 4)); TM_TRY(h2.alloc(4096 * 4)); TM_TRY(h8.alloc(8 * 4096 * 4));
     const int po_grid = std::min(gridn(nu), 1024);  // (every workgroup flushes its bins: fewer workgroups, fewer atomics on the popular ones)
     TM_HIP(hipMemsetAsync(h8.p, 0, 8 * 1024 * 4, stream));
-    hipLaunchKernelGGL(k_po_use_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), h8.as<uint32_t>());
+    const uint32_t *cu = table_ok ? cuse.as<uint32_t>() : nullptr, *cl = table_ok ? clead.as<uint32_t>() : nullptr;
+    hipLaunchKernelGGL(k_po_use_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), cu, h8.as<uint32_t>());
     hipLaunchKernelGGL(k_po_fold, dim3(4), dim3(256), 0, stream, h8.as<uint32_t>(), 1024, h1.as<uint32_t>());
     std::vector<uint32_t> hh1(1024), hh2(4096);
     {
@@ -380,7 +509,7 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     }
     if (ustar >= 1 && ustar < 1023) {  // (a cut inside the clamped bin -- 1023 uses and more -- takes the full sort below)
       TM_HIP(hipMemsetAsync(h8.p, 0, 8 * 4096 * 4, stream));
-      hipLaunchKernelGGL(k_po_lead_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, less, h8.as<uint32_t>());
+      hipLaunchKernelGGL(k_po_lead_hist, dim3(po_grid), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, less, cu, cl, h8.as<uint32_t>());
       hipLaunchKernelGGL(k_po_fold, dim3(16), dim3(256), 0, stream, h8.as<uint32_t>(), 4096, h2.as<uint32_t>());
       {
         HostRead hr_(stream);
@@ -394,14 +523,14 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
         if (ncand >= exact_first) { bstar = b; break; }
       }
       TM_TRY(flag.alloc((size_t)nu * 4)); TM_TRY(fpos.alloc((size_t)nu * 4));
-      hipLaunchKernelGGL(k_po_flags, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, (uint32_t)bstar, less, flag.as<uint32_t>());
+      hipLaunchKernelGGL(k_po_flags, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, use_rep.as<uint32_t>(), (uint32_t)ustar, (uint32_t)bstar, less, cu, cl, flag.as<uint32_t>());
       size_t tbs = 0;
       TM_HIP(rocprim::exclusive_scan(nullptr, tbs, flag.as<uint32_t>(), fpos.as<uint32_t>(), 0u, (size_t)nu, rocprim::plus<uint32_t>(), stream));
       TM_TRY(tmp.alloc(tbs));
       TM_HIP(rocprim::exclusive_scan(tmp.p, tbs, flag.as<uint32_t>(), fpos.as<uint32_t>(), 0u, (size_t)nu, rocprim::plus<uint32_t>(), stream));
       DevBuf pk, pk2;
       TM_TRY(pk.alloc((size_t)ncand * sizeof(PrefixKey))); TM_TRY(pk2.alloc((size_t)ncand * sizeof(PrefixKey)));
-      hipLaunchKernelGGL(k_po_split, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, flag.as<uint32_t>(), fpos.as<uint32_t>(), ncand, use_rep.as<uint32_t>(), less,
+      hipLaunchKernelGGL(k_po_split, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, flag.as<uint32_t>(), fpos.as<uint32_t>(), ncand, use_rep.as<uint32_t>(), less, cu, cl,
                          pk.as<PrefixKey>(), ord2.as<uint32_t>());
       const PrefixLess pless{less};
       size_t tbu = 0;
