@@ -88,23 +88,34 @@ __global__ __launch_bounds__(256) void k_row_hash(const uint32_t *__restrict__ r
 // An open-addressing table of 64-bit hashes (linear probing, at most two thirds full) gives that with one compare-and-swap per probe:
 //   k_dd_insert   hashes a row (16 lanes) and claims or finds its hash's slot; the claimant leaves its index as the slot's OWNER, a row that
 //                 finds the hash present lowers the slot's MINDUP (atomic minimum).  Both words of a slot lie side by side.
-//   k_dd_resolve  representative = min(owner, mindup); a row that is not its own representative is compared with it IN FULL (a hash shared by
-//                 different rows puts them into one slot, where at least one of them differs from the slot's lowest row: the flag sends the call
-//                 down the plain path exactly as the sort's full compare did) and adds its use to the representative's count.
+//   k_dd_resolve  representative = min(owner, mindup); a row that is not its own representative adds its use to the representative's count
+//   k_dd_verify   ... and is compared with it IN FULL (a hash shared by different rows puts them into one slot, where at least one of them
+//                 differs from the slot's lowest row: the flag sends the call down the plain path exactly as the sort's full compare did).
 //   k_dd_compact  the representatives in index order (an exclusive scan of the head marks), their own use added, and what the partial order
 //                 below wants of them -- use count and leading dword -- as arrays in that order (its three passes gathered both per row).
 // Integer atomics only: the groups, their representatives and counts do not depend on who came first.
 struct DdSlot { uint32_t owner, mindup; };
+// (a workgroup hashes 256 rows sixteen at a time -- 16 lanes per row: coalesced 256-byte reads -- and then every thread takes ONE row to the
+// table: with the row's first lane doing its probing the kernel had four atomics in flight per wave and took 607 us, 380 of them waiting)
 __global__ __launch_bounds__(256) void k_dd_insert(const uint32_t *__restrict__ rows, int64_t n, int dwords, int degrade, int bytewise,
                                                    unsigned long long *__restrict__ tkey, DdSlot *__restrict__ tslot, uint32_t mask,
                                                    uint32_t *__restrict__ slot_of, uint32_t *__restrict__ lead_of) {
+  __shared__ unsigned long long s_h[256];
+  __shared__ uint32_t s_lead[256];
   const int sub = threadIdx.x & 15;
-  const int64_t stride = (int64_t)gridDim.x * 16;
-  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {
-    const int64_t row = r0 + (threadIdx.x >> 4);
-    uint32_t lead = 0;
-    unsigned long long h = row_hash16(rows, row, n, dwords, sub, lead);
-    if (row < n && sub == 0) {
+  for (int64_t c0 = blockIdx.x * (int64_t)256; c0 < n; c0 += (int64_t)gridDim.x * 256) {
+    __syncthreads();  // (the previous chunk's hashes have been taken)
+#pragma unroll 4
+    for (int p = 0; p < 16; p++) {
+      const int lr = p * 16 + (threadIdx.x >> 4);
+      uint32_t lead = 0;
+      const unsigned long long h = row_hash16(rows, c0 + lr, n, dwords, sub, lead);
+      if (sub == 0) { s_h[lr] = h; s_lead[lr] = lead; }
+    }
+    __syncthreads();
+    const int64_t row = c0 + threadIdx.x;
+    if (row < n) {
+      unsigned long long h = s_h[threadIdx.x];
       if (degrade) h &= 3;
       const unsigned long long key = h ? h : 1ull;  // (0 = an empty slot)
       uint32_t s = (uint32_t)(h ^ (h >> 32)) & mask;
@@ -115,40 +126,58 @@ __global__ __launch_bounds__(256) void k_dd_insert(const uint32_t *__restrict__ 
         s = (s + 1) & mask;
       }
       slot_of[row] = s;
+      const uint32_t lead = s_lead[threadIdx.x];
       lead_of[row] = bytewise ? __builtin_bswap32(lead) : lead;
     }
   }
 }
-__global__ __launch_bounds__(256) void k_dd_resolve(const uint32_t *__restrict__ rows, int64_t n, int dwords, const DdSlot *__restrict__ tslot,
-                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ use_in, uint32_t *__restrict__ rep,
-                                                    uint32_t *__restrict__ head, uint32_t *__restrict__ use_rep, int *__restrict__ collision) {
-  const int sub = threadIdx.x & 15, vecs = dwords / 4;
-  const int64_t stride = (int64_t)gridDim.x * 16;
-  for (int64_t r0 = blockIdx.x * (int64_t)16; r0 < n; r0 += stride) {
-    const int64_t row = r0 + (threadIdx.x >> 4);
-    bool diff = false;
-    if (row < n) {
-      const DdSlot sl = tslot[slot_of[row]];
-      const uint32_t r = min(sl.owner, sl.mindup);
-      if (r != (uint32_t)row) {
-        const uint4 *pa = reinterpret_cast<const uint4 *>(rows + (int64_t)r * dwords);
-        const uint4 *pb = reinterpret_cast<const uint4 *>(rows + row * dwords);
+// a thread per row: its representative, head mark, and a duplicate's use added to the representative's count
+__global__ __launch_bounds__(256) void k_dd_resolve(int64_t n, const DdSlot *__restrict__ tslot, const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ use_in,
+                                                    uint32_t *__restrict__ rep, uint32_t *__restrict__ head, uint32_t *__restrict__ use_rep) {
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    const DdSlot sl = tslot[slot_of[row]];
+    const uint32_t r = min(sl.owner, sl.mindup);
+    rep[row] = r;
+    head[row] = r == (uint32_t)row ? 1u : 0u;
+    if (r != (uint32_t)row) {
+      const uint32_t u = use_in ? use_in[row] : 1u;
+      if (u) atomicAdd(&use_rep[r], u);
+    }
+  }
+}
+// every row that is not its own representative against it in full: a wave looks at 64 rows at once (one coalesced read of their
+// representatives) and compares the duplicates among them four at a time, 16 lanes per row (a walk over all rows 16 lanes each was a chain of
+// dependent loads: 77 us for a clip without a single duplicate)
+__global__ __launch_bounds__(256) void k_dd_verify(const uint32_t *__restrict__ rows, int64_t n, int dwords, const uint32_t *__restrict__ rep, int *__restrict__ collision) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4, vecs = dwords / 4;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  bool diff = false;
+  for (int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; base < n; base += nw * 64) {
+    const int64_t row = base + lane;
+    const uint32_t r = row < n ? rep[row] : (uint32_t)row;
+    unsigned long long m = __builtin_amdgcn_ballot_w64(r != (uint32_t)row);
+    while (m) {
+      int mine = -1;  // this 16-lane group's duplicate of the round: the grp-th of the next four
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          if (t == grp) mine = b;
+        }
+      }
+      const uint32_t rr = (uint32_t)__shfl((int)r, mine >= 0 ? mine : 0);  // (every lane takes part: the source lane may belong to a group that sits this round out)
+      if (mine >= 0) {
+        const uint4 *pa = reinterpret_cast<const uint4 *>(rows + (int64_t)rr * dwords);
+        const uint4 *pb = reinterpret_cast<const uint4 *>(rows + (base + mine) * dwords);
         for (int v = sub; v < vecs; v += 16) {
           const uint4 x = pa[v], y = pb[v];
           diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
         }
       }
-      if (sub == 0) {
-        rep[row] = r;
-        head[row] = r == (uint32_t)row ? 1u : 0u;
-        if (r != (uint32_t)row) {
-          const uint32_t u = use_in ? use_in[row] : 1u;
-          if (u) atomicAdd(&use_rep[r], u);
-        }
-      }
     }
-    if (__builtin_amdgcn_ballot_w64(diff) && (threadIdx.x & 63) == 0) *collision = 1;
   }
+  if (__builtin_amdgcn_ballot_w64(diff) && lane == 0) *collision = 1;
 }
 __global__ void k_dd_compact(int64_t n, const uint32_t *__restrict__ head, const uint32_t *__restrict__ head_excl, const uint32_t *__restrict__ use_in,
                              const uint32_t *__restrict__ lead_of, uint32_t *__restrict__ use_rep, uint32_t *__restrict__ uniq, uint32_t *__restrict__ cuse,
@@ -406,11 +435,12 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
     TM_HIP(hipMemsetAsync(tkey.p, 0, (size_t)slots * 8, stream));
     TM_HIP(hipMemsetAsync(tslot.p, 0xff, (size_t)slots * sizeof(DdSlot), stream));
     TM_HIP(hipMemsetAsync(use_rep.p, 0, n * 4, stream));
-    const unsigned g16 = (unsigned)std::min<int64_t>((n + 15) / 16, 256 * 32);
-    hipLaunchKernelGGL(k_dd_insert, dim3(g16), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4, knobs().dedup_degrade_hash ? 1 : 0, less.bytewise,
-                       tkey.as<unsigned long long>(), tslot.as<DdSlot>(), (uint32_t)(slots - 1), slot_of.as<uint32_t>(), lead_of.as<uint32_t>());
-    hipLaunchKernelGGL(k_dd_resolve, dim3(g16), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4, tslot.as<DdSlot>(), slot_of.as<uint32_t>(),
-                       (const uint32_t *)use_in, rep.as<uint32_t>(), head.as<uint32_t>(), use_rep.as<uint32_t>(), hflag.as<int>());
+    hipLaunchKernelGGL(k_dd_insert, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 8)), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4,
+                       knobs().dedup_degrade_hash ? 1 : 0, less.bytewise, tkey.as<unsigned long long>(), tslot.as<DdSlot>(), (uint32_t)(slots - 1), slot_of.as<uint32_t>(),
+                       lead_of.as<uint32_t>());
+    hipLaunchKernelGGL(k_dd_resolve, dim3(gridn(n)), dim3(256), 0, stream, n, tslot.as<DdSlot>(), slot_of.as<uint32_t>(), (const uint32_t *)use_in, rep.as<uint32_t>(),
+                       head.as<uint32_t>(), use_rep.as<uint32_t>());
+    hipLaunchKernelGGL(k_dd_verify, dim3(gridn(n)), dim3(256), 0, stream, (const uint32_t *)rows, n, row_bytes / 4, rep.as<uint32_t>(), hflag.as<int>());
     size_t tb3 = 0;
     TM_HIP(rocprim::exclusive_scan(nullptr, tb3, head.as<uint32_t>(), head_excl.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     TM_TRY(tmp.alloc(tb3));
