@@ -1088,12 +1088,19 @@ def _kmodes_rows(case, rng):
     raise ValueError(case)
 
 
+@pytest.mark.parametrize("path", ["fast-leg", "binwise"])
 @pytest.mark.parametrize("num_init", [0, -7, 3])
 @pytest.mark.parametrize("case", ["clusters", "uniform", "identical", "few-points"])
-def test_kmodes(oracle, case, num_init):
+def test_kmodes(oracle, case, num_init, path, monkeypatch):
     """A17: TKModes.ComputeKModes (kmodes.pas:923-1094) -- labels, modes, cost and the best run's iteration count equal the oracle's
-    restatement on structured, structureless and degenerate inputs, from point 0, from point 7 and over three spread starting points"""
+    restatement on structured, structureless and degenerate inputs, from point 0, from point 7 and over three spread starting points;
+    with the later iterations' fast leg (all remaining points scored at once, the bins walked by one launch until a mode changes: it
+    runs to the end on "clusters", stops at once on "uniform" and hands over to the bin-by-bin launches, meets the empty-cluster repairs on
+    "identical") and with every iteration bin by bin (TM_KMODES_BINWISE)"""
     from tiler_amd import stages
+    monkeypatch.delenv("TM_KMODES_BINWISE", raising=False)
+    if path == "binwise":
+        monkeypatch.setenv("TM_KMODES_BINWISE", "1")
     rng = np.random.default_rng(len(case) * 10 + 3)
     rows, k, nmod = _kmodes_rows(case, rng)
     if num_init < 0 and rows.shape[0] <= -num_init:

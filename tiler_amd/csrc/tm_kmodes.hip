@@ -15,6 +15,7 @@
 // What bounds it is that bin-serial rule, not bytes: three dependent launches per 960 points.  The host keeps the stopping rule with its
 // three graces (1040-1049) and reads sixteen bytes per iteration.
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <vector>
@@ -219,10 +220,13 @@ __device__ __forceinline__ void km_apply_moves(int (&t)[4], int &mode, unsigned 
 constexpr int KM_BIN = 960, KM_WT = 1024, KM_MAX_OWNERS = TM_KM_OWNERS, KM_STAGE = 768;
 
 // bin < 0: only the moves of the last bin are applied (the iteration's closing launch); first = 1: there are no moves to apply yet
-__global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, int G, int64_t bin, int first, KmState st,
-                                                        unsigned *__restrict__ partial /* [G][KM_BIN] keys: distance << 12 | 4095 - cluster */) {
-  extern __shared__ int s_dyn[];  // the owned clusters' modes as words [owned][20], their touched flags, the previous bin's relevant moves, those moves' rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+// (the body of k_kmodes_owner; `w` = the owner's number, `s_dyn` = its dynamic LDS.  Returns, in every thread, whether a word of an owned mode
+// changed -- what k_kmodes_fast stops on.)
+__device__ __forceinline__ bool km_owner_body(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, int G, int w, int64_t bin, int first, KmState st,
+                                              unsigned *__restrict__ partial /* [G][KM_BIN] keys: distance << 12 | 4095 - cluster */, int *s_dyn) {
+  // s_dyn: the owned clusters' modes as words [owned][20], their touched flags, the previous bin's relevant moves, those moves' rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bool changed = false;
   const int nown = (k - w + G - 1) / G;  // clusters w, w + G, w + 2 G, ...
   const int max_own = (k + G - 1) / G;
   uint32_t *const s_mode = reinterpret_cast<uint32_t *>(s_dyn);                 // [nown][20]
@@ -352,10 +356,20 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restric
     if (nrel > 0) {
       __syncthreads();
       // the owned modes go back where the next launches (and the host) read them
-      for (int e = tid; e < nown * KM_WORDS; e += KM_WT) reinterpret_cast<uint32_t *>(st.cent)[(size_t)(w + (e / KM_WORDS) * G) * KM_WORDS + e % KM_WORDS] = s_mode[e];
+      for (int e = tid; e < nown * KM_WORDS; e += KM_WT) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(st.cent) + (size_t)(w + (e / KM_WORDS) * G) * KM_WORDS + e % KM_WORDS;
+        if (*dst != s_mode[e]) {
+          changed = true;
+#ifdef TM_KM_COUNT_MODE_CHANGES
+          atomicAdd(st.seed + 1, 1u);  // (diagnostic build: words of modes that changed, in the scalars' padding)
+#endif
+        }
+        *dst = s_mode[e];
+      }
+      changed = __syncthreads_or(changed ? 1 : 0) != 0;
     }
   }
-  if (bin < 0) return;
+  if (bin < 0) return changed;
   // ---- the bin's points against the owned modes as they stand now
   if (tid < nb) {
     // the owner's own arg-min: a distance has 18 bits (80 * (255 + 2048)), a cluster 12; among equal distances the LAST cluster wins
@@ -363,10 +377,24 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restric
     for (int oc = 0; oc < nown; oc++) key = min(key, (km_dissim(s_mode + oc * KM_WORDS, p) << 12) | (unsigned)(4095 - (w + oc * G)));
     partial[(size_t)w * KM_BIN + tid] = key;
   }
+  return changed;
+}
+// (`start`: the bin this iteration's bin-by-bin work begins at -- 0, or where the fast leg handed over: the graph's launches for the bins before
+// it return at once, and the first one behind it has no moves to apply)
+__global__ __launch_bounds__(KM_WT) void k_kmodes_owner(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, int G, int64_t bin, int first, KmState st,
+                                                        unsigned *__restrict__ partial, const long long *__restrict__ start) {
+  extern __shared__ int s_dyn[];
+  const long long s0 = *start;
+  if (bin >= 0 && bin < s0) return;
+  (void)km_owner_body(rows, n, k, nmod, G, (int)blockIdx.x, bin, (first || bin == s0) ? 1 : 0, st, partial, s_dyn);
 }
 
-__global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G, int64_t bin, KmState st, const unsigned *__restrict__ partial) {
-  extern __shared__ int s_members[];  // [k]
+// what a launch that walks many bins keeps on chip between them (k_kmodes_fast): the member counts stay in s_members, these in LDS
+struct KmFastAcc { unsigned long long cost; unsigned moves; uint32_t seed; };
+// (the body of k_kmodes_walker; `s_members` = k words of LDS.  acc != nullptr (k_kmodes_fast): the bin's scores are st.clust / st.dis as a
+// scoring launch over many bins left them, the member counts are in s_members already and cost, move count and seed are acc's: a bin then
+// costs one round trip to memory, for its points.  Returns the number of moves the bin made, in every thread.)
+__device__ __forceinline__ unsigned km_walker_body(int64_t n, int k, int G, int64_t bin, KmState st, const unsigned *__restrict__ partial, int *s_members, KmFastAcc *acc) {
   __shared__ int s_mb[KM_BIN], s_cl[KM_BIN];
   __shared__ unsigned long long s_cost[KM_WT / 64];
   __shared__ int s_cnt[KM_WT], s_wtot[KM_WT / 64];
@@ -376,15 +404,19 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b0 = bin * KM_BIN, b1 = min(b0 + (int64_t)KM_BIN, n);
   const int nb = (int)(b1 - b0);
-  for (int c = tid; c < k; c += KM_WT) s_members[c] = st.members[c];
+  if (!acc) for (int c = tid; c < k; c += KM_WT) s_members[c] = st.members[c];
   // the bin's scores: the minimum over the owners' keys (smallest distance, then the LAST cluster: kmodes.pas:272, 414).  One workgroup
   // fetches all of them and a CU has only so many misses in flight: with a word per (point, cluster) -- 245 KB at 64 clusters -- this
   // fetch alone was 12 of the walker's 16 microseconds, so the owners are few (KM_MAX_OWNERS) and reduce their clusters themselves
   // (all of the point's keys, its membership and the generator's seed in flight together: the launch is a chain of round trips to memory,
   // and four batches of sixteen keys were four of them)
   unsigned long long cost = 0;
-  const uint32_t seed0 = *st.seed;
-  if (tid < nb) {
+  const uint32_t seed0 = acc ? acc->seed : *st.seed;
+  if (tid < nb && acc) {
+    s_cl[tid] = st.clust[b0 + tid];
+    s_mb[tid] = st.memb[b0 + tid];
+    cost = st.dis[b0 + tid];
+  } else if (tid < nb) {
     static_assert(KM_MAX_OWNERS <= 64, "the walker holds one key per owner");
     const int mb = st.memb[b0 + tid];
     unsigned key = 0xffffffffu;
@@ -480,7 +512,7 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G
         }
       }
       if (lane == 0) s_state = state;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the memberships written so far are what the search below reads
+      if (state) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // a repair: the memberships written so far are what the search below reads (a write-back of the L2 -- microseconds: only then)
     }
     __syncthreads();
     if (s_state == 0) break;
@@ -524,14 +556,206 @@ __global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G
     __syncthreads();
   }
   __syncthreads();
-  for (int c = tid; c < k; c += KM_WT) st.members[c] = s_members[c];
+  if (!acc) for (int c = tid; c < k; c += KM_WT) st.members[c] = s_members[c];
   if (tid == 0) {
     unsigned long long c = 0;
     for (int w2 = 0; w2 < KM_WT / 64; w2++) c += s_cost[w2];
-    *st.cost += c;
-    *st.moves += moves;
-    *st.nmoves = nmv;
-    *st.seed = seed;
+    if (acc) {
+      acc->cost += c; acc->moves += moves; acc->seed = seed;
+    } else {
+      *st.cost += c;
+      *st.moves += moves;
+      *st.nmoves = nmv;
+      *st.seed = seed;
+    }
+  }
+  __shared__ unsigned s_nmv_out;
+  if (tid == 0) s_nmv_out = nmv;
+  __syncthreads();
+  return s_nmv_out;
+}
+__global__ __launch_bounds__(KM_WT) void k_kmodes_walker(int64_t n, int k, int G, int64_t bin, KmState st, const unsigned *__restrict__ partial,
+                                                         const long long *__restrict__ start) {
+  extern __shared__ int s_members_dyn[];  // [k]
+  if (bin < *start) return;
+  (void)km_walker_body(n, k, G, bin, st, partial, s_members_dyn, nullptr);
+}
+
+// ---- the fast leg of an iteration (round 5): as long as no MODE changes, the scores of all remaining points are known in advance.
+// A bin's scores depend on the modes alone, and late in a clustering the modes hardly ever move (at config 5's shape: 23 116 moves and at most
+// 128 changed mode words in the second iteration, 1 825 moves and none in the third, none at all in the fourth) -- yet every bin paid two
+// dependent launches, 13 microseconds, for a scoring whose outcome was known.  Here ONE scoring launch (k_kmodes_argmin over all remaining
+// points, every CU) leaves clust / dis, and ONE workgroup then walks bin after bin in a single launch: the walker's body on those scores, then the
+// owners' body as the one owner of every cluster (MovePointCat's histograms and modes for the bin's moves, at once rather than at the next
+// bin's start: nothing reads them in between).  The first bin whose moves change a word of a mode ends the launch -- the scores of the bins
+// behind it are no longer the reference's -- and leaves its number; the host scores again from there, or, after KM_FAST_STOPS such stops in
+// an iteration, finishes it bin by bin with the two launches.  The bins walked this way are exactly the reference's: same scores (same modes),
+// same walk, same updates in the same order.
+constexpr int KM_FAST_STOPS = 4;
+// MovePointCat (774-803) for `nmv` moves (point, to, from) of one bin, one after the other as `list` has them: a thread per (side, attribute)
+// of a move -- its point leaves `from` and enters `to`, two different clusters, 80 independent (cluster, attribute) pairs each.  An arrival
+// takes the pair's mode over only by strictly passing it; a departure of the mode's own value re-reads the first largest counter.  A bin's few
+// moves nearly always touch different clusters: then they are independent of each other too, and up to KM_FAST_PAR of them go at once (a
+// thread per (move, side, attribute): one chain of round trips to memory for the bin instead of one per move).  Sets *changed when a mode
+// changes.  (The owners' batched form of this, made for bins in which hundreds of points move, is a dozen barriers and round trips whatever
+// the count: 70 us a bin where a late bin has one or two moves.)
+constexpr unsigned KM_FAST_PAR = KM_WT / (2 * KM_ATTRS);
+__device__ __forceinline__ void km_light_apply(const uint8_t *__restrict__ rows, int nmod, KmState st, const int3 *list, unsigned nmv, int *changed) {
+  const int tid = threadIdx.x;
+  bool par = nmv <= KM_FAST_PAR;
+  if (par && nmv > 1) {
+    int3 mvs[KM_FAST_PAR];
+#pragma unroll
+    for (unsigned m = 0; m < KM_FAST_PAR; m++) mvs[m] = m < nmv ? list[m] : make_int3(0, -1 - 2 * (int)m, -2 - 2 * (int)m);
+#pragma unroll
+    for (unsigned x = 0; x < KM_FAST_PAR; x++)
+#pragma unroll
+      for (unsigned y = x + 1; y < KM_FAST_PAR; y++)
+        if (mvs[x].y == mvs[y].y || mvs[x].y == mvs[y].z || mvs[x].z == mvs[y].y || mvs[x].z == mvs[y].z) par = false;
+  }
+  const unsigned steps = par ? 1u : nmv;
+  for (unsigned step = 0; step < steps; step++) {
+    const unsigned m = par ? (unsigned)tid / (2 * KM_ATTRS) : step;
+    const int lt = par ? tid % (2 * KM_ATTRS) : tid;
+    if (m < nmv && (par || tid < 2 * KM_ATTRS)) {
+      const int3 mv = list[m];
+      const bool enters = lt >= KM_ATTRS;
+      const int a = enters ? lt - KM_ATTRS : lt, c = enters ? mv.y : mv.z;
+      if (c >= 0) {
+        const int v = rows[(int64_t)mv.x * KM_ATTRS + a];
+        int *const t = st.freq + ((int64_t)c * KM_ATTRS + a) * nmod;
+        uint8_t *const mp = st.cent + (int64_t)c * KM_ATTRS + a;
+        const int mode = *mp;
+        int nm = mode;
+        if (enters) {
+          const int tv = t[v] + 1;
+          t[v] = tv;
+          if ((mode == v ? tv : t[mode]) < tv) nm = v;
+        } else {
+          t[v] -= 1;
+          if (mode == v) {  // GetMaxValueIndex (155-167): the first largest
+            int bv = INT_MIN;
+            for (int i = 0; i < nmod; i++) { const int x = t[i]; if (x > bv) { bv = x; nm = i; } }
+          }
+        }
+        if (nm != mode) { *mp = (uint8_t)nm; *changed = 1; }
+      }
+    }
+    __syncthreads();  // (the next move of the list may meet the same pair)
+  }
+}
+
+// The walk looks KM_SB bins ahead: one pass over their points (scores, memberships, distances: one round trip for 15 360 points) gives every
+// bin's cost and the points that want to move, in order.  A bin without movers is done with its cost.  A bin whose movers cannot empty a
+// cluster (every cluster keeps a member whatever the order: the departures alone leave it one) needs no walk either: memberships and counts
+// change by what the movers say, MovePointCat goes over them in their order.  Only a bin in which a cluster might run empty -- the repair
+// of 879-897 draws from the generator and moves a point from anywhere -- takes the walker's body; the look-ahead starts again behind it.
+constexpr int KM_SB = 16, KM_SB_MOVERS = 128;
+__global__ __launch_bounds__(KM_WT) void k_kmodes_fast(const uint8_t *__restrict__ rows, int64_t n, int k, int nmod, int64_t bin_begin, int64_t nbins, KmState st,
+                                                       long long *__restrict__ stop /* the first bin not walked */) {
+  extern __shared__ int s_members[];  // [k]
+  __shared__ KmFastAcc s_acc;
+  __shared__ int s_changed, s_unsafe;
+  __shared__ unsigned long long s_sbcost[KM_SB];
+  __shared__ unsigned s_nmover;
+  __shared__ int3 s_mover[KM_SB_MOVERS], s_sorted[KM_SB_MOVERS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = tid; c < k; c += KM_WT) s_members[c] = st.members[c];
+  if (tid == 0) { s_acc.cost = 0; s_acc.moves = 0; s_acc.seed = *st.seed; s_changed = 0; }
+  __syncthreads();
+  int64_t bin = bin_begin;  // the first bin not walked yet
+  while (bin < nbins && !s_changed) {
+    const int nsb = (int)min((int64_t)KM_SB, nbins - bin);
+    const int64_t p0 = bin * KM_BIN, p1 = min(n, (bin + nsb) * KM_BIN);
+    if (tid < KM_SB) s_sbcost[tid] = 0;
+    if (tid == 0) { s_nmover = 0; s_unsafe = 0; }
+    __syncthreads();
+    for (int64_t base = p0; base < p1; base += KM_WT) {
+      const int64_t p = base + tid;
+      const bool in = p < p1;
+      const int cl = in ? st.clust[p] : 0, mb = in ? st.memb[p] : 0;
+      const unsigned long long d = in ? st.dis[p] : 0;
+      const int b = in ? (int)((p - p0) / KM_BIN) : -1;
+      // a wave's 64 consecutive points lie in one bin or two
+      const int bA = __builtin_amdgcn_readfirstlane(b);
+      int bB = -1;
+      {
+        const unsigned long long other = __builtin_amdgcn_ballot_w64(b >= 0 && b != bA);
+        if (other) bB = __builtin_amdgcn_readlane(b, __builtin_ctzll(other));
+      }
+      unsigned long long sa = b == bA ? d : 0, sb = (bB >= 0 && b == bB) ? d : 0;
+      for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+      if (lane == 0) {
+        if (bA >= 0 && sa) atomicAdd(&s_sbcost[bA], sa);
+        if (bB >= 0 && sb) atomicAdd(&s_sbcost[bB], sb);
+      }
+      if (in && cl != mb) {
+        const unsigned slot = atomicAdd(&s_nmover, 1u);
+        if (slot < KM_SB_MOVERS) s_mover[slot] = make_int3((int)p, cl, mb);
+      }
+    }
+    __syncthreads();
+    const unsigned nm = s_nmover;
+    if (nm <= KM_SB_MOVERS) {  // into the points' order
+      if ((unsigned)tid < nm) {
+        const int3 me = s_mover[tid];
+        unsigned rank = 0;
+        for (unsigned j = 0; j < nm; j++) rank += s_mover[j].x < me.x ? 1u : 0u;
+        s_sorted[rank] = me;
+      }
+      __syncthreads();
+    }
+    unsigned at = 0;  // the movers of the bins before `bin` are done
+    bool rescan = false;
+    for (int b = 0; b < nsb && !rescan; b++, bin++) {
+      unsigned mb_ = 0;
+      bool heavy = nm > KM_SB_MOVERS;
+      if (!heavy) {
+        const int64_t pend = (bin + 1) * KM_BIN;
+        while (at + mb_ < nm && s_sorted[at + mb_].x < pend) mb_++;
+        if (mb_ == 0) {
+          if (tid == 0) s_acc.cost += s_sbcost[b];
+          continue;
+        }
+        // can a cluster run empty?  not if every cluster the bin's movers leave keeps a member with all of them gone
+        if ((unsigned)tid < mb_) {
+          const int f = s_sorted[at + tid].z;
+          int leavers = 0;
+          for (unsigned j = 0; j < mb_; j++) leavers += s_sorted[at + j].z == f ? 1 : 0;
+          if (s_members[f] - leavers < 1) s_unsafe = 1;
+        }
+        __syncthreads();
+        heavy = s_unsafe != 0;
+      }
+      if (heavy) {  // the walk proper, then its moves; what the look-ahead saw of later bins may be stale (a repair moves a point from anywhere)
+        const unsigned nmv = km_walker_body(n, k, 1, bin, st, nullptr, s_members, &s_acc);
+        if (nmv) km_light_apply(rows, nmod, st, st.mlist, nmv, &s_changed);
+        __syncthreads();
+        rescan = nm <= KM_SB_MOVERS;  // (more movers than the look-ahead holds: every bin of it takes the walk, nothing of it is used)
+      } else {
+        if ((unsigned)tid < mb_) {
+          const int3 mv = s_sorted[at + tid];
+          st.memb[mv.x] = mv.y;
+          atomicSub(&s_members[mv.z], 1);
+          atomicAdd(&s_members[mv.y], 1);
+        }
+        if (tid == 0) { s_acc.cost += s_sbcost[b]; s_acc.moves += mb_; }
+        __syncthreads();
+        km_light_apply(rows, nmod, st, s_sorted + at, mb_, &s_changed);
+        at += mb_;
+      }
+      if (s_changed) { bin++; break; }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int c = tid; c < k; c += KM_WT) st.members[c] = s_members[c];
+  if (tid == 0) {
+    *st.cost += s_acc.cost;
+    *st.moves += s_acc.moves;
+    *st.seed = s_acc.seed;
+    *st.nmoves = 0;  // (every move is applied)
+    *stop = bin;
   }
 }
 
@@ -591,6 +815,9 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
   TM_TRY(dpart.alloc((size_t)KM_BIN * G * 4));
   // One iteration is 2 * bins + 1 dependent launches with the same arguments every time: a graph, built once per call and replayed
   // (the host's share of a launch is then paid once, not 3 400 times per iteration)
+  DevBuf dstop;  // [0] where the fast leg stopped, [1] the bin the iteration's graph starts at (its launches for earlier bins return at once)
+  TM_TRY(dstop.alloc(16));
+  TM_HIP(hipMemsetAsync(dstop.p, 0, 16, stream));
   struct IterGraph {
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -600,6 +827,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     TM_HIP(hipGraphCreate(&iter_graph.g, 0));
     const int64_t nbins = (n + KM_BIN - 1) / KM_BIN;
     unsigned *part_p = dpart.as<unsigned>();
+    const long long *start_p = dstop.as<long long>() + 1;
     int k_ = k, nmod_ = nmod, G_ = G;
     int64_t n_ = n;
     const uint8_t *rows_ = rows;
@@ -617,14 +845,18 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     for (int64_t bin = 0; bin <= nbins; bin++) {
       int64_t b = bin < nbins ? bin : -1;  // the closing launch applies the last bin's moves
       int first = bin == 0 ? 1 : 0;
-      void *po[] = {&rows_, &n_, &k_, &nmod_, &G_, &b, &first, &st, &part_p};
+      void *po[] = {&rows_, &n_, &k_, &nmod_, &G_, &b, &first, &st, &part_p, &start_p};
       TM_TRY(add(reinterpret_cast<const void *>(&k_kmodes_owner), (unsigned)G, owner_lds, po));
       if (bin == nbins) break;
-      void *pw[] = {&n_, &k_, &G_, &b, &st, &part_p};
+      void *pw[] = {&n_, &k_, &G_, &b, &st, &part_p, &start_p};
       TM_TRY(add(reinterpret_cast<const void *>(&k_kmodes_walker), 1u, (size_t)k * 4, pw));
     }
     TM_HIP(hipGraphInstantiate(&iter_graph.exec, iter_graph.g, nullptr, nullptr, 0));
   }
+  // the fast leg's workgroup owns every cluster: its LDS holds all k modes and the member counts beside the walker's and the owners' fixed arrays
+  const int64_t nbins = (n + KM_BIN - 1) / KM_BIN;
+  const size_t fast_lds = (size_t)k * 4;
+  const bool fast_ok = !knobs().kmodes_binwise;
   const size_t lds = (size_t)k * KM_ATTRS;
   TM_CHECK(lds <= 160 * 1024 - 1024, TM_E_INVAL, "kmodes: the modes of %d clusters do not fit LDS", k);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_kmodes_argmin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -686,11 +918,40 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
       point_iters += n;
       // ---- KModesIter (851-921): bins of 960 points, each scored against the modes as they stand when its turn comes
       TM_HIP(hipMemsetAsync(dscal.as<uint8_t>() + 8, 0, 12, stream));  // cost, moves
-      TM_HIP(hipGraphLaunch(iter_graph.exec, stream));
+      const auto t_it0 = std::chrono::steady_clock::now();
+      if (fast_ok && itr >= 2) {
+        // the fast leg (k_kmodes_fast): all remaining points scored at once, bins walked by one launch until a mode changes
+        int64_t b = 0;
+        int stops = 0;
+        while (b < nbins && stops < KM_FAST_STOPS) {
+          TM_TRY(score(b * KM_BIN, n));
+          hipLaunchKernelGGL(k_kmodes_fast, dim3(1), dim3(KM_WT), fast_lds, stream, rows, n, k, nmod, b, nbins, st, dstop.as<long long>());
+          TM_HIP(hipGetLastError());
+          long long stop = 0;
+          TM_HIP(hipMemcpyAsync(&stop, dstop.p, 8, hipMemcpyDeviceToHost, stream));
+          TM_HIP(hipStreamSynchronize(stream));
+          TM_CHECK(stop > b && stop <= nbins, TM_E_HIP, "kmodes: the fast leg stopped at bin %lld of [%lld, %lld]", stop, (long long)b, (long long)nbins);
+          if (stop < nbins) stops++;
+          b = stop;
+        }
+        if (knobs().pp_debug) fprintf(stderr, "[tm_kmodes] iteration %d: the fast leg walked %lld of %lld bins (%d stops)\n", itr, (long long)b, (long long)nbins, stops);
+        if (b < nbins) {  // the modes keep moving: the rest of the iteration bin by bin, by the graph from bin b on (the fast leg left no move unapplied)
+          const long long bb = b, zero = 0;
+          TM_HIP(hipMemcpyAsync(dstop.as<long long>() + 1, &bb, 8, hipMemcpyHostToDevice, stream));
+          TM_HIP(hipGraphLaunch(iter_graph.exec, stream));
+          TM_HIP(hipMemcpyAsync(dstop.as<long long>() + 1, &zero, 8, hipMemcpyHostToDevice, stream));
+          TM_HIP(hipStreamSynchronize(stream));  // (bb and zero are this frame's)
+        }
+      } else {
+        TM_HIP(hipGraphLaunch(iter_graph.exec, stream));
+      }
       Scal h;
       TM_TRY(read_scal(&h));
       const uint64_t cost = h.cost;
       const int moves = (int)h.moves;
+      if (knobs().pp_debug)
+        fprintf(stderr, "[tm_kmodes] run %d iteration %d: cost %llu, %d moves, %.2f ms (mode words changed so far, counted by a diagnostic build: %u)\n", run, itr,
+                (unsigned long long)cost, moves, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_it0).count(), h.pad);
       converged = cost >= prevcost;
       if (converged) {  // SameValue(cost, prevcost, prevcost div 1000), 1041
         const double a = (double)cost, b = (double)prevcost;
