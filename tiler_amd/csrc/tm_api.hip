@@ -17,7 +17,7 @@ int tm_device_count(void) {
 }
 
 // the trailing token names the build of the KNN scan kernel: PMC passes under profiles/ are keyed by it (bench.py reads `traffic` from them)
-const char *tm_version(void) { return "tilemotion-mi355x 0.3 (gfx950) knn-scan3-r05a"; }
+const char *tm_version(void) { return "tilemotion-mi355x 0.3 (gfx950) knn-scan3-r05b"; }
 
 int tm_stage_load(const void *frames, int nframes, int img_w, int img_h, int tm_w, int tm_h, void *tiles, void *flags,
                   void *lab_means, void *stream) {

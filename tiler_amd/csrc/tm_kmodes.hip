@@ -622,21 +622,23 @@ __device__ __forceinline__ void km_light_apply(const uint8_t *__restrict__ rows,
       const bool enters = lt >= KM_ATTRS;
       const int a = enters ? lt - KM_ATTRS : lt, c = enters ? mv.y : mv.z;
       if (c >= 0) {
-        const int v = rows[(int64_t)mv.x * KM_ATTRS + a];
+        // two round trips to memory: the point's value and the pair's mode; then the counters (an arrival's two, all of a departure's row --
+        // four in five values of a leaving point are their pair's mode, whose departure asks for the first largest)
         int *const t = st.freq + ((int64_t)c * KM_ATTRS + a) * nmod;
         uint8_t *const mp = st.cent + (int64_t)c * KM_ATTRS + a;
+        const int v = rows[(int64_t)mv.x * KM_ATTRS + a];
         const int mode = *mp;
         int nm = mode;
         if (enters) {
-          const int tv = t[v] + 1;
+          const int tv0 = t[v], tm0 = t[mode];
+          const int tv = tv0 + 1;
           t[v] = tv;
-          if ((mode == v ? tv : t[mode]) < tv) nm = v;
+          if ((mode == v ? tv : tm0) < tv) nm = v;
         } else {
-          t[v] -= 1;
-          if (mode == v) {  // GetMaxValueIndex (155-167): the first largest
-            int bv = INT_MIN;
-            for (int i = 0; i < nmod; i++) { const int x = t[i]; if (x > bv) { bv = x; nm = i; } }
-          }
+          int bv = INT_MIN, bi = mode;  // GetMaxValueIndex (155-167) over the row as it is AFTER the departure: the first largest
+          for (int i = 0; i < nmod; i++) { const int x = t[i] - (i == v ? 1 : 0); if (x > bv) { bv = x; bi = i; } }
+          t[v] -= 1;  // (the row's line is in the cache)
+          if (mode == v) nm = bi;
         }
         if (nm != mode) { *mp = (uint8_t)nm; *changed = 1; }
       }
@@ -911,6 +913,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
     TM_HIP(hipGetLastError());
     TM_HIP(hipStreamSynchronize(stream));  // `which` is host memory the copy above reads
     int itr = 0, worse = 0, bestitr = 0;
+    long long prev_moves = LLONG_MAX;
     bool converged = false;
     uint64_t prevcost = ~0ull, bestcost = ~0ull;
     while (itr < max_iter && !converged) {
@@ -919,7 +922,9 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
       // ---- KModesIter (851-921): bins of 960 points, each scored against the modes as they stand when its turn comes
       TM_HIP(hipMemsetAsync(dscal.as<uint8_t>() + 8, 0, 12, stream));  // cost, moves
       const auto t_it0 = std::chrono::steady_clock::now();
-      if (fast_ok && itr >= 2) {
+      // (not where the iteration before moved more than 16 points a bin: with that many movers nearly every bin changes a mode or has more
+      // moves than the one workgroup's move-by-move MovePointCat is good for)
+      if (fast_ok && itr >= 2 && prev_moves <= 16 * nbins) {
         // the fast leg (k_kmodes_fast): all remaining points scored at once, bins walked by one launch until a mode changes
         int64_t b = 0;
         int stops = 0;
@@ -967,6 +972,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
         TM_HIP(hipMemcpyAsync(dbestc.p, dcent.p, (size_t)k * KM_ATTRS, hipMemcpyDeviceToDevice, stream));
       }
       prevcost = cost;
+      prev_moves = moves;
     }
     if (bestcost < all_best) {  // 1078-1085: the first run with the strictly smallest cost
       all_best = bestcost;
