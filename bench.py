@@ -588,7 +588,7 @@ def main():
         del feats
         ms, _ = ev_time(lambda: stages.dedup(tiles), reps=3)
         b = q_total * 260
-        sr["dedup"] = {"bound": "hbm", "kernel": "run_dedup (hash, radix sorts, compare, merge sort of distinct rows)", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        sr["dedup"] = {"bound": "hbm", "kernel": "run_dedup (hash table, full compare against the representative, radix sort of the distinct rows' prefixes + ties by whole rows)", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": b, "note": "one 256 B key read + one 4 B index written per tile; blocking call (host reads the distinct count)"}
         del tiles, flags
         # 64 error-feedback steps x PaletteSize colours per planned pixel, 9 int32 / fp32 operations per compare; the stage plans every DISTINCT

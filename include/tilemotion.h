@@ -36,7 +36,9 @@
  *   TM_DITHER_OWN_KEYS      Dither collects its (palette, colour) pairs itself instead of taking PreparePalettes' keys (tests)
  *   TM_DITHER_NO_DEDUP      Dither plans every pixel on its own (tests); TM_DITHER_LITERAL: every tile through the literal-sort kernel
  *   TM_DEDUP_PLAIN          exact dedup by the comparator sort alone; TM_DEDUP_SORT: equal rows grouped by the radix sort of their hashes
- *                           (the front end of rounds 1-4) instead of the hash table; TM_DEDUP_DEGRADE_HASH: a 2-bit hash, so that every group
+ *                           (the front end of rounds 1-4) instead of the hash table; TM_DEDUP_RADIX_MIN=n: the distinct rows go into content
+ *                           order by a radix sort of their 8-byte prefixes (whole rows compared only within short runs of equal prefixes;
+ *                           the comparator merge sort where a run is long) from n rows on (default 2^20; tests: 1); TM_DEDUP_DEGRADE_HASH: a 2-bit hash, so that every group
  *                           collides (tests); TM_DEDUP_FULL_ORDER: the whole order, not only the rows that can survive the budget (tests)
  *   TM_MOTION_VALU          the motion search's VALU kernel only (tests drive both kernels)
  *   TM_FEATURES_PLAIN       the int16 DCT features sum every coefficient in the reference's order (no separable first look; the tests

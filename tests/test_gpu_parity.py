@@ -684,6 +684,54 @@ def test_dedup_reindex(tiles_flags, oracle, kind, path, monkeypatch):
     assert np.array_equal(g_remap.cpu().numpy().astype(np.int64), remap)
 
 
+@pytest.mark.parametrize("longest", [8, 9])
+@pytest.mark.parametrize("kind", ["rgb", "pal"])
+def test_dedup_runs_of_equal_prefixes(oracle, kind, longest, monkeypatch):
+    """the content sort's two legs: from TM_DEDUP_RADIX_MIN distinct rows on they go by a radix sort of their 8-byte prefixes, rows that share
+    a prefix are put in order by whole-row compares inside their run (runs of 2..8 rows here, differing first in every possible later dword,
+    top bits included), and a run of 9 sends the call to the comparator merge sort; every case against the oracle, and the merge sort
+    outright (the default at this size) against the same"""
+    from tiler_amd import stages
+    rng = np.random.default_rng(77 + longest)
+    if kind == "rgb":
+        rows = rng.integers(0, 1 << 24, size=(3000, 64), dtype=np.int64).astype(np.uint32)
+        at = 100
+        for run in range(2, longest + 1):
+            for rep in range(6):
+                base = rows[at].copy()
+                for j in range(run):
+                    rows[at + j] = base
+                    d = int(rng.integers(2, 64))  # the first dword that differs (the prefix is dwords 0 and 1)
+                    rows[at + j, d:] = rng.integers(0, 1 << 24, size=64 - d)
+                    if j & 1:
+                        rows[at + j, d] |= 0x80000000  # unsigned compare
+                at += run
+        rows = rows.view(np.int32)
+        use = None
+    else:
+        rows = rng.integers(0, 16, size=(3000, 64), dtype=np.uint8)
+        at = 100
+        for run in range(2, longest + 1):
+            for rep in range(6):
+                base = rows[at].copy()
+                for j in range(run):
+                    rows[at + j] = base
+                    d = int(rng.integers(8, 64))  # (the prefix is the first 8 bytes)
+                    rows[at + j, d:] = rng.integers(0, 256, size=64 - d)
+                at += run
+        use = rng.integers(1, 4, size=3000).astype(np.uint32)
+    nu, rep_, order, use_out, remap = oracle.dedup(rows, use)
+    for radix in (True, False):
+        monkeypatch.delenv("TM_DEDUP_RADIX_MIN", raising=False)
+        if radix:
+            monkeypatch.setenv("TM_DEDUP_RADIX_MIN", "1")
+        g_nu, g_remap, g_order, g_use = stages.dedup(_dev(rows), _dev(use) if use is not None else None)
+        assert g_nu == nu
+        assert np.array_equal(g_order.cpu().numpy().astype(np.int64), order)
+        assert np.array_equal(g_use.cpu().numpy().view(np.uint32), use_out)
+        assert np.array_equal(g_remap.cpu().numpy().astype(np.int64), remap)
+
+
 def test_lab_of_every_colour(oracle):
     """RGBToLAB (utils.pas:374-410) on the device over the WHOLE domain: all 2^24 colours through tm_stage_rgb_to_lab against the oracle's
     deterministic form (which tests/test_oracle_pins.py proves equal to the reference's libm power() on the same domain).  The kernels

@@ -51,7 +51,7 @@ struct Knobs {
        comm_force_dist = false, features_plain = false, km_launches = false, kmodes_binwise = false, pp_sharded = false, window_dcts_by_tile = false, km_resident_fail = false, features_by_tile = false, motion_pack_separate = false, motion_force_flag = false;
   int topk_estimate = -1;  // TM_TOPK_ESTIMATE: the k-nearest search's first thresholds from a sample of the database: -1 by size, 0 never, 1 whenever possible
   double epu_table_gib = 6.0, comm_timeout_s = 120.0;
-  long long knn_arena_entries = 0;
+  long long knn_arena_entries = 0, dedup_radix_min = 1ll << 20;
 };
 const Knobs &knobs();
 void knobs_reload();

@@ -244,6 +244,45 @@ __global__ void k_prefix_rows(const PrefixKey *__restrict__ keys, int64_t nu, ui
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) uniq[i] = keys[i].row;
 }
 
+// ---- the content sort of MANY distinct rows: by the 8-byte prefix with a radix sort, whole rows only where prefixes tie -----------------
+// The comparator merge sort of (prefix, row) keys takes 2 ms for the clip's 4.32 M distinct frame tiles (a dedup without a tile budget: the
+// whole order is asked for).  Most keys differ in their prefix: a radix sort of (prefix, row) pairs orders those for good, and what is left
+// are short runs of equal prefixes, each put into content order by the thread at its head (insertion sort with the full comparator; a stable
+// sort leaves equal prefixes in the order they came in, any order would do).  A run longer than PK_MAX_RUN rows -- flat content: thousands of
+// rows may share their first pixels -- sets a flag and the call takes the comparator merge sort as before: the same result by construction
+// (one total order).  Only from TM_DEDUP_RADIX_MIN keys on (default 2^20): below that the merge sort's fixed cost is small and a wasted
+// radix sort is not (Reindex's 321 k palette-index rows tie in long runs on the bench clip: measured, 0.14 ms lost).
+__global__ void k_pk_split(const PrefixKey *__restrict__ pk, int64_t m, unsigned long long *__restrict__ key, uint32_t *__restrict__ row) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) { key[i] = pk[i].prefix; row[i] = pk[i].row; }
+}
+constexpr int PK_MAX_RUN = 8;
+__global__ void k_pk_ties(const unsigned long long *__restrict__ key, uint32_t *__restrict__ row, int64_t m, RowLess less, int *__restrict__ too_long) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = key[i];
+    if ((i > 0 && key[i - 1] == k) || i + 1 >= m || key[i + 1] != k) continue;  // not the head of a run of two or more
+    int len = 2;
+    while (len <= PK_MAX_RUN && i + len < m && key[i + len] == k) len++;
+    if (len > PK_MAX_RUN) { *too_long = 1; continue; }
+    uint32_t r[PK_MAX_RUN];
+#pragma unroll
+    for (int j = 0; j < PK_MAX_RUN; j++) r[j] = j < len ? row[i + j] : 0u;
+#pragma unroll
+    for (int a = 1; a < PK_MAX_RUN; a++) {  // insertion sort (a register array: compile-time indices, the moves by selects)
+      if (a < len) {
+        const uint32_t x = r[a];
+        int pos = a;
+#pragma unroll
+        for (int b = a - 1; b >= 0; b--)
+          if (pos == b + 1 && less.cmp(x, r[b]) < 0) { r[b + 1] = r[b]; pos = b; }
+#pragma unroll
+        for (int b = 0; b < PK_MAX_RUN; b++) if (b == pos) r[b] = x;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PK_MAX_RUN; j++) if (j < len) row[i + j] = r[j];
+  }
+}
+
 // ---- only the first `exact_first` positions of the final order matter (Reduce keeps that many tiles): which distinct rows can be there --
 // use counts of the distinct rows, clamped to 1023: a histogram per workgroup in LDS (most rows are used once: one global counter would take
 // every row's atomic in turn), flushed with one atomic per occupied bin
@@ -389,6 +428,39 @@ __global__ void k_remap(const uint32_t *__restrict__ rep, const int32_t *__restr
 }
 
 static inline int gridn(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 16)); }
+
+// m keys (prefix, row) into content order; the rows of that order to out_rows
+static int sort_prefix_keys(DevBuf &pk, int64_t m, const RowLess &less, uint32_t *out_rows, DevBuf &tmp, hipStream_t stream) {
+  if (m <= 0) return TM_OK;
+  if (m >= knobs().dedup_radix_min) {
+    DevBuf k1, k2, r1, r2, flag;
+    TM_TRY(k1.alloc((size_t)m * 8)); TM_TRY(k2.alloc((size_t)m * 8)); TM_TRY(r1.alloc((size_t)m * 4)); TM_TRY(r2.alloc((size_t)m * 4)); TM_TRY(flag.alloc(4));
+    TM_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_pk_split, dim3(gridn(m)), dim3(256), 0, stream, pk.as<PrefixKey>(), m, k1.as<unsigned long long>(), r1.as<uint32_t>());
+    size_t tb = 0;
+    TM_HIP(rocprim::radix_sort_pairs(nullptr, tb, k1.as<unsigned long long>(), k2.as<unsigned long long>(), r1.as<uint32_t>(), r2.as<uint32_t>(), (size_t)m, 0, 64, stream));
+    TM_TRY(tmp.alloc(tb));
+    TM_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k1.as<unsigned long long>(), k2.as<unsigned long long>(), r1.as<uint32_t>(), r2.as<uint32_t>(), (size_t)m, 0, 64, stream));
+    hipLaunchKernelGGL(k_pk_ties, dim3(gridn(m)), dim3(256), 0, stream, k2.as<unsigned long long>(), r2.as<uint32_t>(), m, less, flag.as<int>());
+    TM_HIP(hipMemcpyAsync(out_rows, r2.p, (size_t)m * 4, hipMemcpyDeviceToDevice, stream));
+    int too_long = 0;
+    {
+      HostRead hr_(stream);
+      TM_TRY(hr_.get(&too_long, flag.p, 4));
+      TM_TRY(hr_.wait());
+    }
+    if (!too_long) return TM_OK;
+  }
+  DevBuf pk2;
+  TM_TRY(pk2.alloc((size_t)m * sizeof(PrefixKey)));
+  const PrefixLess pless{less};
+  size_t tbu = 0;
+  TM_HIP(rocprim::merge_sort(nullptr, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)m, pless, stream));
+  TM_TRY(tmp.alloc(tbu));
+  TM_HIP(rocprim::merge_sort(tmp.p, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)m, pless, stream));
+  hipLaunchKernelGGL(k_prefix_rows, dim3(gridn(m)), dim3(256), 0, stream, pk2.as<PrefixKey>(), m, out_rows);
+  return TM_OK;
+}
 
 // by_index = 0: the reference's ReindexTiles order (use desc, content asc), zero-use rows dropped.
 // by_index = 1: representatives in ascending original index (used to search only distinct database rows; any
@@ -558,16 +630,11 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
       TM_HIP(rocprim::exclusive_scan(nullptr, tbs, flag.as<uint32_t>(), fpos.as<uint32_t>(), 0u, (size_t)nu, rocprim::plus<uint32_t>(), stream));
       TM_TRY(tmp.alloc(tbs));
       TM_HIP(rocprim::exclusive_scan(tmp.p, tbs, flag.as<uint32_t>(), fpos.as<uint32_t>(), 0u, (size_t)nu, rocprim::plus<uint32_t>(), stream));
-      DevBuf pk, pk2;
-      TM_TRY(pk.alloc((size_t)ncand * sizeof(PrefixKey))); TM_TRY(pk2.alloc((size_t)ncand * sizeof(PrefixKey)));
+      DevBuf pk;
+      TM_TRY(pk.alloc((size_t)ncand * sizeof(PrefixKey)));
       hipLaunchKernelGGL(k_po_split, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, flag.as<uint32_t>(), fpos.as<uint32_t>(), ncand, use_rep.as<uint32_t>(), less, cu, cl,
                          pk.as<PrefixKey>(), ord2.as<uint32_t>());
-      const PrefixLess pless{less};
-      size_t tbu = 0;
-      TM_HIP(rocprim::merge_sort(nullptr, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)ncand, pless, stream));
-      TM_TRY(tmp.alloc(tbu));
-      TM_HIP(rocprim::merge_sort(tmp.p, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)ncand, pless, stream));
-      hipLaunchKernelGGL(k_prefix_rows, dim3(gridn(ncand)), dim3(256), 0, stream, pk2.as<PrefixKey>(), ncand, ord2.as<uint32_t>());
+      TM_TRY(sort_prefix_keys(pk, ncand, less, ord2.as<uint32_t>(), tmp, stream));
       TM_HIP(hipGetLastError());
       ranked = true;
       live = (unsigned long long)nu;
@@ -575,15 +642,10 @@ int run_dedup_ex(const void *rows, int64_t n, int row_bytes, const void *use_in,
   }
   if (!ranked && grouped && !by_index) {  // the distinct rows, now in hash order -> content order (what the stable ranking sort below relies on; the
                                // by-index form ranks by row number alone: any order of the distinct rows will do)
-    DevBuf pk, pk2;
-    TM_TRY(pk.alloc((size_t)nu * sizeof(PrefixKey))); TM_TRY(pk2.alloc((size_t)nu * sizeof(PrefixKey)));
+    DevBuf pk;
+    TM_TRY(pk.alloc((size_t)nu * sizeof(PrefixKey)));
     hipLaunchKernelGGL(k_prefix_keys, dim3(gridn(nu)), dim3(256), 0, stream, uniq.as<uint32_t>(), nu, less, pk.as<PrefixKey>());
-    const PrefixLess pless{less};
-    size_t tbu = 0;
-    TM_HIP(rocprim::merge_sort(nullptr, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)nu, pless, stream));
-    TM_TRY(tmp.alloc(tbu));
-    TM_HIP(rocprim::merge_sort(tmp.p, tbu, pk.as<PrefixKey>(), pk2.as<PrefixKey>(), (size_t)nu, pless, stream));
-    hipLaunchKernelGGL(k_prefix_rows, dim3(gridn(nu)), dim3(256), 0, stream, pk2.as<PrefixKey>(), nu, uniq.as<uint32_t>());
+    TM_TRY(sort_prefix_keys(pk, nu, less, uniq.as<uint32_t>(), tmp, stream));
     // pk / pk2 go back to the pool here; later users are ordered behind these kernels on the same stream (as with `tmp`)
   }
   if (!ranked) {

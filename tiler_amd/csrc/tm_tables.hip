@@ -155,6 +155,7 @@ void knobs_reload() {
   if (const char *v = getenv("TM_TOPK_ESTIMATE")) k.topk_estimate = (v[0] == '0' && v[1] == 0) ? 0 : 1;
   if (const char *v = getenv("TM_EPU_TABLE_GIB")) k.epu_table_gib = atof(v);
   if (const char *v = getenv("TM_COMM_TIMEOUT_S")) k.comm_timeout_s = std::max(1.0, atof(v));
+  if (const char *v = getenv("TM_DEDUP_RADIX_MIN")) k.dedup_radix_min = std::max(0ll, atoll(v));
   if (const char *v = getenv("TM_KNN_ARENA_ENTRIES")) k.knn_arena_entries = std::max(0ll, atoll(v));
   t_knobs = k;
 }

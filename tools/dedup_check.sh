@@ -19,6 +19,8 @@ j = json.loads(open('gpurun_out/dd_%s.json' % v).read().strip().splitlines()[-1]
 print('%s fps=%.0f ms=%.2f gate=%s' % (v, j['value'], j['ms_per_step'], j.get('parity_gate')), j['stage_ms'])
 w = j.get('with_frozen_columns')
 if w: print('   frozen: fps=%.0f ms=%.2f' % (w['value'], w['ms_per_step']), w['stage_ms'])
+d = j.get('stage_rooflines', {}).get('dedup')
+if d: print('   dedup operator: %.3f ms, frac %.3f' % (d['ms'], d['frac']))
 PY
 done
 done
