@@ -351,7 +351,7 @@ template <bool TD>
 __device__ __forceinline__ bool k3_epilogue(const v16i &acc, unsigned pwh, int tile, int half, unsigned qn, unsigned long long *best, unsigned *tie,
                                             unsigned sm_now, unsigned cur_hi /* the query's best as read BEFORE the chain: stale only on the safe side (a best only falls) */) {
   bool refresh = false;
-  if (k3_may_matter<TD>(acc, qn, cur_hi)) {  // (rare: the seeds and the lists' order leave few blocks that improve a best)
+  if (k3_may_matter<TD>(acc, qn, cur_hi)) {  // (by the counters nearly half of the listed blocks improve or tie some query's best)
     int t[16];
     k3_values<TD>(acc, pwh, t);
     const int tm = k3_min16(t);
