@@ -46,7 +46,9 @@
  *   TM_KM_LAUNCHES          the tile -> palette k-means runs its skipping iterations as three launches each instead of one resident launch
  *                           for all of them (tests compare the two)
  *   TM_KMODES_BINWISE       every k-modes iteration bin by bin (two launches per 960 points) -- without the leg that scores all remaining points
- *                           at once and walks the bins in one launch for as long as no mode changes (tests compare the two)
+ *                           at once and walks the bins in one launch for as long as no mode changes (tests compare the two);
+ *                           TM_KMODES_FAST_ALWAYS: that leg is tried in every iteration after the first, also behind an iteration that moved many
+ *                           points (tests: its stops and the hand-over to the bin-by-bin launches in the middle of an iteration)
  *   TM_FEATURES_BY_TILE     the int16 features of RGB tiles by the tile-at-a-time kernel (k_features_i16<0>) instead of eight tiles a wave
  *                           (k_features_tiles8; tests compare the two)
  *   TM_MOTION_PACK_SEPARATE the encoder's motion search as three launches per frame (int16 window features, their packing, the search) instead of

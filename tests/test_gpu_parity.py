@@ -732,6 +732,49 @@ def test_dedup_runs_of_equal_prefixes(oracle, kind, longest, monkeypatch):
         assert np.array_equal(g_remap.cpu().numpy().astype(np.int64), remap)
 
 
+@pytest.mark.parametrize("kind", ["rgb", "pal-use"])
+def test_dedup_table_equals_the_hash_sort_at_scale(kind, monkeypatch):
+    """the hash table against the front end it replaced (TM_DEDUP_SORT) on 2.4 M rows of which a third are duplicates, in runs from two to
+    hundreds of copies scattered over the whole index range: distinct count, order, merged use counts and remap equal; the RGB case has more
+    than 2^20 distinct rows, so its content sort is the radix sort of prefixes with whole-row ties (a planted family of rows that share
+    their first two dwords included), the other carries use counts, zeros among them"""
+    from tiler_amd import stages
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    n, nd = 2_400_000, 1_600_000
+    if kind == "rgb":
+        base = torch.randint(0, 1 << 24, (nd, 64), generator=g, device="cuda", dtype=torch.int32)
+        base[1000:1006, :2] = base[1000, :2]   # six distinct rows under one 8-byte prefix
+        use = None
+    else:
+        base = torch.randint(0, 16, (nd, 64), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+        use = torch.randint(0, 5, (n,), generator=g, device="cuda", dtype=torch.int32)
+    src = torch.randint(0, nd, (n,), generator=g, device="cuda")
+    src[: nd] = torch.arange(nd, device="cuda")            # every distinct row at least once
+    src[nd: nd + 300] = 7                                  # one long run
+    src = src[torch.randperm(n, generator=g, device="cuda")]
+    rows = base[src].contiguous()
+    monkeypatch.delenv("TM_DEDUP_SORT", raising=False)
+    a = stages.dedup(rows, use)
+    monkeypatch.setenv("TM_DEDUP_SORT", "1")
+    b = stages.dedup(rows, use)
+    torch.cuda.synchronize()
+    assert a[0] == b[0] and a[0] <= nd
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+    if kind == "rgb":
+        assert a[0] == nd
+        order = a[2].long()
+        first = rows[order[:-1]].long() & 0xFFFFFFFF
+        second = rows[order[1:]].long() & 0xFFFFFFFF
+        neq = first != second
+        col = neq.int().argmax(1)
+        idx = torch.arange(order.numel() - 1, device="cuda")
+        u = a[3].long()
+        assert bool((u[:-1] >= u[1:]).all())                                       # use count descending ...
+        same = u[:-1] == u[1:]
+        assert bool((first[idx, col] < second[idx, col])[same].all())              # ... content strictly ascending among equal counts (CompareDWord: unsigned)
+
+
 def test_lab_of_every_colour(oracle):
     """RGBToLAB (utils.pas:374-410) on the device over the WHOLE domain: all 2^24 colours through tm_stage_rgb_to_lab against the oracle's
     deterministic form (which tests/test_oracle_pins.py proves equal to the reference's libm power() on the same domain).  The kernels
@@ -1136,19 +1179,23 @@ def _kmodes_rows(case, rng):
     raise ValueError(case)
 
 
-@pytest.mark.parametrize("path", ["fast-leg", "binwise"])
+@pytest.mark.parametrize("path", ["fast-leg", "fast-leg-always", "binwise"])
 @pytest.mark.parametrize("num_init", [0, -7, 3])
 @pytest.mark.parametrize("case", ["clusters", "uniform", "identical", "few-points"])
 def test_kmodes(oracle, case, num_init, path, monkeypatch):
     """A17: TKModes.ComputeKModes (kmodes.pas:923-1094) -- labels, modes, cost and the best run's iteration count equal the oracle's
     restatement on structured, structureless and degenerate inputs, from point 0, from point 7 and over three spread starting points;
     with the later iterations' fast leg (all remaining points scored at once, the bins walked by one launch until a mode changes: it
-    runs to the end on "clusters", stops at once on "uniform" and hands over to the bin-by-bin launches, meets the empty-cluster repairs on
-    "identical") and with every iteration bin by bin (TM_KMODES_BINWISE)"""
+    runs to the end on "clusters", stops at once on "uniform" and hands over to the bin-by-bin launches in the middle of the iteration when
+    TM_KMODES_FAST_ALWAYS has it tried there, meets the empty-cluster repairs on "identical") and with every iteration bin by bin
+    (TM_KMODES_BINWISE)"""
     from tiler_amd import stages
     monkeypatch.delenv("TM_KMODES_BINWISE", raising=False)
+    monkeypatch.delenv("TM_KMODES_FAST_ALWAYS", raising=False)
     if path == "binwise":
         monkeypatch.setenv("TM_KMODES_BINWISE", "1")
+    if path == "fast-leg-always":  # (by default the leg is not tried behind an iteration that moved more than 16 points a bin)
+        monkeypatch.setenv("TM_KMODES_FAST_ALWAYS", "1")
     rng = np.random.default_rng(len(case) * 10 + 3)
     rows, k, nmod = _kmodes_rows(case, rng)
     if num_init < 0 and rows.shape[0] <= -num_init:
@@ -1174,10 +1221,17 @@ def test_kmodes_on_device_pointers_at_the_4k_clip_shape(oracle):
     rows[noise] = rng.integers(0, 48, size=int(noise.sum()))
     rows = rows.astype(np.uint8)
     exp_labels, exp_cent, exp_cost, exp_iters = oracle.kmodes(rows, k, 0, 48, 3)
-    labels, cent, cost, iters, point_iters = stages.kmodes_dev(torch.from_numpy(rows).cuda(), k, 0, 48, 3)
-    assert cost == exp_cost and iters == exp_iters and point_iters == 3 * n
-    assert np.array_equal(cent.cpu().numpy(), exp_cent)
-    assert np.array_equal(labels.cpu().numpy(), exp_labels)
+    import os
+    drows = torch.from_numpy(rows).cuda()
+    for always in ("0", "1"):  # the later iterations' fast leg as shipped, and tried in the second iteration too (stops, then the hand-over)
+        os.environ["TM_KMODES_FAST_ALWAYS"] = always
+        try:
+            labels, cent, cost, iters, point_iters = stages.kmodes_dev(drows, k, 0, 48, 3)
+        finally:
+            del os.environ["TM_KMODES_FAST_ALWAYS"]
+        assert cost == exp_cost and iters == exp_iters and point_iters == 3 * n
+        assert np.array_equal(cent.cpu().numpy(), exp_cent)
+        assert np.array_equal(labels.cpu().numpy(), exp_labels)
 
 
 def _dl3_image(case, rng):

@@ -48,7 +48,7 @@ int require_device();
 struct Knobs {
   bool knn_debug = false, knn_noprune = false, topk_brute = false, no_query_groups = false, dither_own_keys = false, dither_no_dedup = false,
        dither_literal = false, dedup_plain = false, dedup_sort = false, dedup_degrade_hash = false, dedup_full_order = false, motion_valu = false, pp_debug = false,
-       comm_force_dist = false, features_plain = false, km_launches = false, kmodes_binwise = false, pp_sharded = false, window_dcts_by_tile = false, km_resident_fail = false, features_by_tile = false, motion_pack_separate = false, motion_force_flag = false;
+       comm_force_dist = false, features_plain = false, km_launches = false, kmodes_binwise = false, kmodes_fast_always = false, pp_sharded = false, window_dcts_by_tile = false, km_resident_fail = false, features_by_tile = false, motion_pack_separate = false, motion_force_flag = false;
   int topk_estimate = -1;  // TM_TOPK_ESTIMATE: the k-nearest search's first thresholds from a sample of the database: -1 by size, 0 never, 1 whenever possible
   double epu_table_gib = 6.0, comm_timeout_s = 120.0;
   long long knn_arena_entries = 0, dedup_radix_min = 1ll << 20;

@@ -924,7 +924,7 @@ int run_kmodes_dev(const uint8_t *rows, int64_t n, int k, int num_init, int nmod
       const auto t_it0 = std::chrono::steady_clock::now();
       // (not where the iteration before moved more than 16 points a bin: with that many movers nearly every bin changes a mode or has more
       // moves than the one workgroup's move-by-move MovePointCat is good for)
-      if (fast_ok && itr >= 2 && prev_moves <= 16 * nbins) {
+      if (fast_ok && itr >= 2 && (prev_moves <= 16 * nbins || knobs().kmodes_fast_always)) {
         // the fast leg (k_kmodes_fast): all remaining points scored at once, bins walked by one launch until a mode changes
         int64_t b = 0;
         int stops = 0;

@@ -151,7 +151,7 @@ void knobs_reload() {
   k.knn_debug = on("TM_KNN_DEBUG"); k.knn_noprune = on("TM_KNN_NOPRUNE"); k.topk_brute = on("TM_TOPK_BRUTE"); k.no_query_groups = on("TM_NO_QUERY_GROUPS");
   k.dither_own_keys = on("TM_DITHER_OWN_KEYS"); k.dither_no_dedup = on("TM_DITHER_NO_DEDUP"); k.dither_literal = on("TM_DITHER_LITERAL");
   k.dedup_plain = on("TM_DEDUP_PLAIN"); k.dedup_sort = on("TM_DEDUP_SORT"); k.dedup_degrade_hash = on("TM_DEDUP_DEGRADE_HASH"); k.dedup_full_order = on("TM_DEDUP_FULL_ORDER");
-  k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST"); k.features_plain = on("TM_FEATURES_PLAIN"); k.km_launches = on("TM_KM_LAUNCHES"); k.kmodes_binwise = on("TM_KMODES_BINWISE"); k.pp_sharded = on("TM_PP_SHARDED"); k.window_dcts_by_tile = on("TM_WINDOW_DCTS_BY_TILE"); k.km_resident_fail = on("TM_KM_RESIDENT_FAIL"); k.features_by_tile = on("TM_FEATURES_BY_TILE"); k.motion_pack_separate = on("TM_MOTION_PACK_SEPARATE"); k.motion_force_flag = on("TM_MOTION_FORCE_FLAG");
+  k.motion_valu = on("TM_MOTION_VALU"); k.pp_debug = on("TM_PP_DEBUG"); k.comm_force_dist = on("TM_COMM_FORCE_DIST"); k.features_plain = on("TM_FEATURES_PLAIN"); k.km_launches = on("TM_KM_LAUNCHES"); k.kmodes_binwise = on("TM_KMODES_BINWISE"); k.kmodes_fast_always = on("TM_KMODES_FAST_ALWAYS"); k.pp_sharded = on("TM_PP_SHARDED"); k.window_dcts_by_tile = on("TM_WINDOW_DCTS_BY_TILE"); k.km_resident_fail = on("TM_KM_RESIDENT_FAIL"); k.features_by_tile = on("TM_FEATURES_BY_TILE"); k.motion_pack_separate = on("TM_MOTION_PACK_SEPARATE"); k.motion_force_flag = on("TM_MOTION_FORCE_FLAG");
   if (const char *v = getenv("TM_TOPK_ESTIMATE")) k.topk_estimate = (v[0] == '0' && v[1] == 0) ? 0 : 1;
   if (const char *v = getenv("TM_EPU_TABLE_GIB")) k.epu_table_gib = atof(v);
   if (const char *v = getenv("TM_COMM_TIMEOUT_S")) k.comm_timeout_s = std::max(1.0, atof(v));
